@@ -1,0 +1,45 @@
+#!/bin/bash
+# TEST INFRASTRUCTURE ONLY — builds the *real* reference CPU half (Tier-0 maths)
+# from the sources where they lie under /root/reference into oracle/_ref/.
+# Nothing is copied into the repo: generated headers + objects + libplref.so all
+# land in oracle/_ref/ (git-ignored, travels to the GPU box with gpurun).
+#
+# Recipe follows SURVEY.md §8(c): hand-written config.h / config_internal.h /
+# version.h, the reference's own flags (meson.build:406-410), no meson.
+set -euo pipefail
+HERE="$(cd "$(dirname "$0")" && pwd)"
+REF="${PL_REFERENCE:-/root/reference}"
+OUT="$HERE/_ref"
+if [ ! -d "$REF/src" ]; then
+    echo "build_ref: $REF not present (GPU box?) — keeping prebuilt $OUT if any" >&2
+    exit 0
+fi
+mkdir -p "$OUT/gen/libplacebo" "$OUT/obj"
+# config.h from the reference template (substitution output only)
+sed -e 's/@majorver@/7/' -e 's/@apiver@/365/' \
+    -e 's/@extra_defs@/#undef PL_HAVE_VULKAN\n#undef PL_HAVE_OPENGL\n#undef PL_HAVE_D3D11\n#undef PL_HAVE_LCMS\n#undef PL_HAVE_SHADERC\n#undef PL_HAVE_GLSLANG\n#undef PL_HAVE_XXHASH\n#undef PL_HAVE_DOVI\n#undef PL_HAVE_LIBDOVI/' \
+    "$REF/src/include/libplacebo/config.h.in" > "$OUT/gen/libplacebo/config.h"
+cat > "$OUT/gen/config_internal.h" <<'EOT'
+#pragma once
+#define BUILD_API_VER 365
+#define BUILD_FIX_VER 0
+#define PL_DEBUG_ABORT 0
+#define PL_HAVE_EXECINFO 1
+EOT
+echo '#define BUILD_VERSION "v7.365.0"' > "$OUT/gen/version.h"
+
+CFLAGS="-std=c11 -O2 -fPIC -D_GNU_SOURCE -DPL_STATIC -DPL_HAVE_PTHREAD -DPTHREAD_HAS_SETCLOCK \
+ -fno-math-errno -fno-signed-zeros -fno-trapping-math -w \
+ -I$OUT/gen -I$REF/src/include -I$REF/src"
+SRCS="filters tone_mapping gamut_mapping colorspace dither common log pl_alloc pl_string cache format"
+OBJS=""
+for s in $SRCS; do
+    gcc $CFLAGS -c "$REF/src/$s.c" -o "$OUT/obj/$s.o"
+    OBJS="$OBJS $OUT/obj/$s.o"
+done
+g++ -std=c++20 -O2 -fPIC -w -DPL_STATIC -I$OUT/gen -I$REF/src/include -I$REF/src \
+    -c "$REF/src/convert.cc" -o "$OUT/obj/convert.o"
+# ref_shim.c is OUR glue (exposes a few internals as plain C-ABI for ctypes)
+gcc $CFLAGS -c "$HERE/ref_shim.c" -o "$OUT/obj/ref_shim.o"
+g++ -shared -Wl,--no-undefined -o "$OUT/libplref.so" $OBJS "$OUT/obj/convert.o" "$OUT/obj/ref_shim.o" -lm -lpthread
+echo "built $OUT/libplref.so"
