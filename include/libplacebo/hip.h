@@ -1,0 +1,66 @@
+/*
+ * libplacebo-hip: the HIP / CDNA4 backend constructor.
+ *
+ * Sits next to the reference's vulkan.h / opengl.h / d3d11.h and follows the
+ * same pattern (opengl.h:33-42,114-122): a backend object that owns a pl_gpu.
+ * All work is queued on one HIP stream; textures are pitched linear arrays in
+ * HBM (no texture units are used — see DESIGN.md).
+ */
+#ifndef LIBPLACEBO_HIP_H_
+#define LIBPLACEBO_HIP_H_
+
+#include <libplacebo/gpu.h>
+
+PL_API_BEGIN
+
+typedef const struct pl_hip_t {
+    pl_gpu gpu;
+    int device;         // HIP device ordinal
+    void *stream;       // hipStream_t all work is queued on
+    const char *arch;   // e.g. "gfx950:sramecc+:xnack-"
+    int compute_units;
+} *pl_hip;
+
+struct pl_hip_params {
+    int device;         // HIP device ordinal to use
+    // Optional externally owned hipStream_t (e.g. torch's current stream).
+    // If NULL, a private non-blocking stream is created.
+    void *stream;
+    // Report limits.max_shmem_size = this many bytes (0 = 65536). Generic code
+    // uses it to decide e.g. whether error diffusion fits in LDS
+    // (renderer.c:2290); CDNA4 allows up to 163840.
+    size_t max_shmem_size;
+};
+
+#define pl_hip_params(...) (&(struct pl_hip_params) { __VA_ARGS__ })
+PL_API extern const struct pl_hip_params pl_hip_default_params;
+
+// Number of HIP devices visible to this process (0 if no GPU / no runtime).
+PL_API int pl_hip_device_count(void);
+
+// Creates the backend; NULL (and a log message) on failure. Never falls back
+// to a CPU path: without a usable HIP device there is no pl_gpu.
+PL_API pl_hip pl_hip_create(pl_log log, const struct pl_hip_params *params);
+PL_API void pl_hip_destroy(pl_hip *hip);
+PL_API pl_hip pl_hip_get(pl_gpu gpu);
+
+// Wrap an existing device allocation (e.g. a torch tensor) as a pl_tex,
+// like pl_opengl_wrap / pl_vulkan_wrap. The memory is borrowed, not owned.
+struct pl_hip_wrap_params {
+    void *ptr;          // device pointer to texel (0,0)
+    int width, height;
+    size_t row_pitch;   // bytes (0 = tightly packed)
+    pl_fmt format;
+};
+
+#define pl_hip_wrap_params(...) (&(struct pl_hip_wrap_params) { __VA_ARGS__ })
+PL_API pl_tex pl_hip_wrap(pl_gpu gpu, const struct pl_hip_wrap_params *params);
+
+// Device pointer / pitch of a texture created by this backend.
+PL_API void *pl_hip_tex_ptr(pl_tex tex, size_t *out_row_pitch);
+// Device pointer of a buffer created by this backend.
+PL_API void *pl_hip_buf_ptr(pl_buf buf);
+
+PL_API_END
+
+#endif // LIBPLACEBO_HIP_H_

@@ -1,0 +1,83 @@
+/*
+ * libplacebo-hip: sampling stages (K1-K6).
+ * API-compatible with the reference's
+ * src/include/libplacebo/shaders/sampling.h:34-61 (pl_sample_src), :64-103
+ * (deband), :110-175 (samplers), :180-230 (filter params).
+ */
+#ifndef LIBPLACEBO_SHADERS_SAMPLING_H_
+#define LIBPLACEBO_SHADERS_SAMPLING_H_
+
+#include <libplacebo/colorspace.h>
+#include <libplacebo/filters.h>
+#include <libplacebo/shaders.h>
+
+PL_API_BEGIN
+
+struct pl_sample_src {
+    pl_tex tex;             // texture to sample (required on this backend)
+    pl_rect2df rect;        // sub-rect to sample from (0 = whole texture)
+    enum pl_tex_address_mode address_mode;
+
+    // Accepted for source compatibility with the reference's "external
+    // sampler" mode; not supported here (tex must be set).
+    int tex_w, tex_h;
+    enum pl_fmt_type format;
+    enum pl_sampler_type sampler;
+    enum pl_tex_sample_mode mode;
+    float sampled_w, sampled_h;
+
+    int components;         // number of components to sample (0 = 4)
+    uint8_t component_mask; // overrides `components` if set
+    int new_w, new_h;       // output size (0 = round(|rect|))
+    float scale;            // multiplied into the result (0 = 1)
+};
+
+#define pl_sample_src(...) (&(struct pl_sample_src) { __VA_ARGS__ })
+
+struct pl_deband_params {
+    int iterations;
+    float threshold;
+    float radius;
+    float grain;
+    float grain_neutral[3];
+};
+
+#define PL_DEBAND_DEFAULTS  \
+    .iterations = 1,        \
+    .threshold  = 3.0,      \
+    .radius     = 16.0,     \
+    .grain      = 4.0,
+
+#define pl_deband_params(...) (&(struct pl_deband_params) {PL_DEBAND_DEFAULTS __VA_ARGS__ })
+PL_API extern const struct pl_deband_params pl_deband_default_params;
+
+PL_API void pl_shader_deband(pl_shader sh, const struct pl_sample_src *src,
+                             const struct pl_deband_params *params);
+
+PL_API bool pl_shader_sample_direct(pl_shader sh, const struct pl_sample_src *src);
+PL_API bool pl_shader_sample_nearest(pl_shader sh, const struct pl_sample_src *src);
+PL_API bool pl_shader_sample_bilinear(pl_shader sh, const struct pl_sample_src *src);
+PL_API bool pl_shader_sample_bicubic(pl_shader sh, const struct pl_sample_src *src);
+PL_API bool pl_shader_sample_hermite(pl_shader sh, const struct pl_sample_src *src);
+PL_API bool pl_shader_sample_gaussian(pl_shader sh, const struct pl_sample_src *src);
+PL_API bool pl_shader_sample_oversample(pl_shader sh, const struct pl_sample_src *src,
+                                        float threshold);
+
+struct pl_sample_filter_params {
+    struct pl_filter_config filter;
+    float antiring;
+    bool no_compute;    // evaluate taps in the reference's gather/fragment order
+    bool no_widening;
+    pl_shader_obj *lut; // required: persistent LUT / filter state
+};
+
+#define pl_sample_filter_params(...) (&(struct pl_sample_filter_params) { __VA_ARGS__ })
+
+PL_API bool pl_shader_sample_polar(pl_shader sh, const struct pl_sample_src *src,
+                                   const struct pl_sample_filter_params *params);
+PL_API bool pl_shader_sample_ortho2(pl_shader sh, const struct pl_sample_src *src,
+                                    const struct pl_sample_filter_params *params);
+
+PL_API_END
+
+#endif // LIBPLACEBO_SHADERS_SAMPLING_H_

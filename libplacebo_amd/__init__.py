@@ -1,0 +1,249 @@
+"""libplacebo_amd — Python harness over the C-ABI of libplacebo_hip.so.
+
+The product is the C/HIP library (include/libplacebo/*.h); this package only
+binds it with ctypes so tests and bench.py can drive it, and mirrors the
+reference's object model (pl_gpu / pl_tex / pl_shader / pl_dispatch) 1:1.
+There is no Python or CPU implementation of any stage in here: without the
+built library (and, for anything that launches work, a HIP device) calls fail.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _capi as capi
+from ._capi import BuildError  # noqa: F401
+
+_lib = None
+
+
+def lib():
+    """The loaded libplacebo_hip.so (raises BuildError if it was not built)."""
+    global _lib
+    if _lib is None:
+        _lib = capi.declare(capi.load())
+    return _lib
+
+
+# numpy dtype <-> pl_fmt name
+_FMT_DTYPES = {
+    "r8": (np.uint8, 1), "rg8": (np.uint8, 2), "rgba8": (np.uint8, 4),
+    "r16": (np.uint16, 1), "rg16": (np.uint16, 2), "rgba16": (np.uint16, 4),
+    "r16hf": (np.float16, 1), "rg16hf": (np.float16, 2), "rgba16hf": (np.float16, 4),
+    "r32f": (np.float32, 1), "rg32f": (np.float32, 2), "rgba32f": (np.float32, 4),
+}
+
+ADDRESS_CLAMP, ADDRESS_REPEAT, ADDRESS_MIRROR = 0, 1, 2
+DITHER_BLUE_NOISE, DITHER_ORDERED_LUT, DITHER_ORDERED_FIXED, DITHER_WHITE_NOISE = 0, 1, 2, 3
+FILTER_UPSCALING, FILTER_DOWNSCALING, FILTER_FRAME_MIXING = 1, 2, 4
+
+
+def filter_config(name, usage=FILTER_UPSCALING):
+    """Look up one of the built-in scaler configs (pl_find_filter_config)."""
+    p = lib().pl_find_filter_config(name.encode(), usage)
+    if not p:
+        raise KeyError(name)
+    return p.contents
+
+
+def hip_device_count():
+    return lib().pl_hip_device_count()
+
+
+class Texture:
+    def __init__(self, gpu, ptr, owned=True):
+        self.gpu, self.ptr, self.owned = gpu, ptr, owned
+
+    @property
+    def w(self):
+        return self.ptr.contents.params.w
+
+    @property
+    def h(self):
+        return self.ptr.contents.params.h
+
+    @property
+    def fmt_name(self):
+        return self.ptr.contents.params.format.contents.name.decode()
+
+    def device_ptr(self):
+        pitch = C.c_size_t()
+        p = lib().pl_hip_tex_ptr(self.ptr, C.byref(pitch))
+        return p, pitch.value
+
+    def upload(self, arr):
+        dt, nc = _FMT_DTYPES[self.fmt_name]
+        arr = np.ascontiguousarray(arr, dtype=dt).reshape(self.h, self.w, nc)
+        xp = capi.TexTransferParams(tex=self.ptr, ptr=arr.ctypes.data)
+        if not lib().pl_tex_upload(self.gpu.gpu, C.byref(xp)):
+            raise RuntimeError("pl_tex_upload failed")
+
+    def download(self):
+        dt, nc = _FMT_DTYPES[self.fmt_name]
+        out = np.empty((self.h, self.w, nc), dtype=dt)
+        xp = capi.TexTransferParams(tex=self.ptr, ptr=out.ctypes.data)
+        if not lib().pl_tex_download(self.gpu.gpu, C.byref(xp)):
+            raise RuntimeError("pl_tex_download failed")
+        return out
+
+    def destroy(self):
+        if self.ptr:
+            p = self.ptr
+            lib().pl_tex_destroy(self.gpu.gpu, C.byref(p))
+            self.ptr = None
+
+
+class ShaderObj:
+    """A pl_shader_obj slot (persistent LUT / filter state)."""
+
+    def __init__(self):
+        self.slot = C.c_void_p(None)
+
+    def destroy(self):
+        lib().pl_shader_obj_destroy(C.byref(self.slot))
+
+
+class Shader:
+    """A pl_shader obtained from pl_dispatch_begin."""
+
+    def __init__(self, gpu):
+        self.gpu = gpu
+        self.sh = C.c_void_p(lib().pl_dispatch_begin(gpu.dp))
+        self._keep = []
+
+    def _src(self, tex, rect=None, new_w=0, new_h=0, components=0, scale=0.0,
+             address_mode=ADDRESS_CLAMP, component_mask=0):
+        s = capi.SampleSrc(tex=tex.ptr, address_mode=address_mode, components=components,
+                           component_mask=component_mask, new_w=new_w, new_h=new_h, scale=scale)
+        if rect is not None:
+            s.rect = capi.Rect2df(*rect)
+        return s
+
+    def sample(self, kind, tex, **kw):
+        s = self._src(tex, **{k: v for k, v in kw.items() if k != "threshold"})
+        if kind == "oversample":
+            ok = lib().pl_shader_sample_oversample(self.sh, C.byref(s), kw.get("threshold", 0.0))
+        else:
+            ok = getattr(lib(), f"pl_shader_sample_{kind}")(self.sh, C.byref(s))
+        return ok
+
+    def sample_polar(self, tex, cfg, lut_obj, antiring=0.0, no_compute=False, no_widening=False,
+                     **kw):
+        s = self._src(tex, **kw)
+        fp = capi.SampleFilterParams(filter=cfg, antiring=antiring, no_compute=no_compute,
+                                     no_widening=no_widening,
+                                     lut=C.pointer(lut_obj.slot))
+        self._keep.append(fp)
+        return lib().pl_shader_sample_polar(self.sh, C.byref(s), C.byref(fp))
+
+    def sample_ortho(self, tex, cfg, lut_obj, antiring=0.0, no_widening=False, **kw):
+        s = self._src(tex, **kw)
+        fp = capi.SampleFilterParams(filter=cfg, antiring=antiring, no_widening=no_widening,
+                                     lut=C.pointer(lut_obj.slot))
+        self._keep.append(fp)
+        return lib().pl_shader_sample_ortho2(self.sh, C.byref(s), C.byref(fp))
+
+    def dither(self, depth, state_obj, method=DITHER_BLUE_NOISE, lut_size=6, temporal=False,
+               transfer=3):
+        dp = capi.DitherParams(method=method, lut_size=lut_size, temporal=temporal,
+                               transfer=transfer)
+        lib().pl_shader_dither(self.sh, depth, C.byref(state_obj.slot) if state_obj else None,
+                               C.byref(dp))
+
+    def listing(self):
+        res = lib().pl_shader_finalize(self.sh)
+        return res.contents.glsl.decode() if res else None
+
+    def failed(self):
+        return lib().pl_shader_is_failed(self.sh)
+
+    def finish(self, target, rect=None, timer=None):
+        dp = capi.DispatchParams(shader=C.pointer(self.sh), target=target.ptr, timer=timer)
+        if rect is not None:
+            dp.rect = capi.Rect2d(*rect)
+        return lib().pl_dispatch_finish(self.gpu.dp, C.byref(dp))
+
+    def abort(self):
+        lib().pl_dispatch_abort(self.gpu.dp, C.byref(self.sh))
+
+
+class HipGpu:
+    """pl_hip backend + a pl_dispatch, as a context manager."""
+
+    def __init__(self, device=0, stream=None, log_level=3, max_shmem_size=0):
+        L = lib()
+        self._msgs = []
+
+        def _cb(_priv, level, msg):
+            self._msgs.append((level, msg.decode(errors="replace")))
+
+        self._cb = capi.LOG_CB(_cb)
+        lp = capi.LogParams(log_cb=self._cb, log_priv=None, log_level=log_level)
+        self.log = C.c_void_p(L.pl_log_create(365, C.byref(lp)))
+        hp = capi.HipParams(device=device, stream=stream, max_shmem_size=max_shmem_size)
+        self.hip = L.pl_hip_create(self.log, C.byref(hp))
+        if not self.hip:
+            raise RuntimeError("pl_hip_create failed: " + "; ".join(m for _, m in self._msgs))
+        self.gpu = self.hip.contents.gpu
+        self.dp = C.c_void_p(L.pl_dispatch_create(self.log, self.gpu))
+
+    messages = property(lambda self: list(self._msgs))
+
+    def fmt(self, name):
+        f = lib().pl_find_named_fmt(self.gpu, name.encode())
+        if not f:
+            raise KeyError(name)
+        return f
+
+    def tex_create(self, w, h, fmt, data=None):
+        dt, nc = _FMT_DTYPES[fmt]
+        tp = capi.TexParams(w=w, h=h, format=self.fmt(fmt), sampleable=True, renderable=True,
+                            storable=True, blit_src=True, blit_dst=True, host_writable=True,
+                            host_readable=True)
+        arr = None
+        if data is not None:
+            arr = np.ascontiguousarray(data, dtype=dt).reshape(h, w, nc)
+            tp.initial_data = arr.ctypes.data
+        t = lib().pl_tex_create(self.gpu, C.byref(tp))
+        if not t:
+            raise RuntimeError("pl_tex_create failed: " + "; ".join(m for _, m in self._msgs[-3:]))
+        return Texture(self, t)
+
+    def tex_wrap(self, device_ptr, w, h, fmt, row_pitch=0):
+        wp = capi.HipWrapParams(ptr=device_ptr, width=w, height=h, row_pitch=row_pitch,
+                                format=self.fmt(fmt))
+        t = lib().pl_hip_wrap(self.gpu, C.byref(wp))
+        if not t:
+            raise RuntimeError("pl_hip_wrap failed")
+        return Texture(self, t, owned=False)
+
+    def begin(self):
+        return Shader(self)
+
+    def reset_frame(self):
+        lib().pl_dispatch_reset_frame(self.dp)
+
+    def finish(self):
+        lib().pl_gpu_finish(self.gpu)
+
+    def timer(self):
+        return C.c_void_p(lib().pl_timer_create(self.gpu))
+
+    def timer_query(self, t):
+        return lib().pl_timer_query(self.gpu, t)
+
+    def close(self):
+        L = lib()
+        if self.dp:
+            L.pl_dispatch_destroy(C.byref(self.dp))
+        if self.hip:
+            h = self.hip
+            L.pl_hip_destroy(C.byref(h))
+            self.hip = None
+        if self.log:
+            L.pl_log_destroy(C.byref(self.log))
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()

@@ -1,0 +1,251 @@
+"""ctypes declarations for the C-ABI of libplacebo_hip.so.
+
+One Python class per public struct of include/libplacebo/*.h (same field
+order), and argtypes/restype for every entry point the harness uses. This is
+plumbing only: all arithmetic happens in the C/HIP library.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libplacebo_hip.so")
+
+
+class BuildError(RuntimeError):
+    pass
+
+
+def load():
+    if not os.path.exists(LIB_PATH):
+        raise BuildError(
+            f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(or `make -C libplacebo_amd/csrc`). There is no Python/CPU fallback.")
+    return C.CDLL(LIB_PATH, mode=C.RTLD_GLOBAL)
+
+
+# ---- common.h ---------------------------------------------------------------
+class Rect2d(C.Structure):
+    _fields_ = [("x0", C.c_int), ("y0", C.c_int), ("x1", C.c_int), ("y1", C.c_int)]
+
+
+class Rect2df(C.Structure):
+    _fields_ = [("x0", C.c_float), ("y0", C.c_float), ("x1", C.c_float), ("y1", C.c_float)]
+
+
+class Rect3d(C.Structure):
+    _fields_ = [(n, C.c_int) for n in ("x0", "y0", "z0", "x1", "y1", "z1")]
+
+
+class Matrix3x3(C.Structure):
+    _fields_ = [("m", (C.c_float * 3) * 3)]
+
+
+class Transform3x3(C.Structure):
+    _fields_ = [("mat", Matrix3x3), ("c", C.c_float * 3)]
+
+
+# ---- log.h --------------------------------------------------------------------
+LOG_CB = C.CFUNCTYPE(None, C.c_void_p, C.c_int, C.c_char_p)
+
+
+class LogParams(C.Structure):
+    _fields_ = [("log_cb", LOG_CB), ("log_priv", C.c_void_p), ("log_level", C.c_int)]
+
+
+# ---- filters.h ------------------------------------------------------------------
+class FilterFunction(C.Structure):
+    _fields_ = [("name", C.c_char_p), ("radius", C.c_float), ("resizable", C.c_bool),
+                ("tunable", C.c_bool * 2), ("params", C.c_float * 2),
+                ("weight", C.c_void_p), ("opaque", C.c_bool)]
+
+
+class FilterConfig(C.Structure):
+    _fields_ = [("name", C.c_char_p), ("description", C.c_char_p),
+                ("allowed", C.c_int), ("recommended", C.c_int),
+                ("kernel", C.POINTER(FilterFunction)), ("window", C.POINTER(FilterFunction)),
+                ("radius", C.c_float), ("params", C.c_float * 2), ("wparams", C.c_float * 2),
+                ("clamp", C.c_float), ("blur", C.c_float), ("taper", C.c_float),
+                ("polar", C.c_bool), ("antiring", C.c_float)]
+
+
+class FilterParams(C.Structure):
+    _fields_ = [("config", FilterConfig), ("lut_entries", C.c_int), ("cutoff", C.c_float),
+                ("max_row_size", C.c_int), ("row_stride_align", C.c_int)]
+
+
+class Filter(C.Structure):
+    _fields_ = [("params", FilterParams), ("radius", C.c_float), ("radius_zero", C.c_float),
+                ("weights", C.POINTER(C.c_float)), ("row_size", C.c_int),
+                ("insufficient", C.c_bool), ("row_stride", C.c_int)]
+
+
+# ---- gpu.h / hip.h ----------------------------------------------------------------
+class Fmt(C.Structure):
+    _fields_ = [("name", C.c_char_p), ("signature", C.c_uint64), ("type", C.c_int),
+                ("caps", C.c_int), ("num_components", C.c_int),
+                ("component_depth", C.c_int * 4), ("internal_size", C.c_size_t),
+                ("opaque", C.c_bool), ("emulated", C.c_bool), ("texel_size", C.c_size_t),
+                ("texel_align", C.c_size_t), ("host_bits", C.c_int * 4),
+                ("sample_order", C.c_int * 4), ("gatherable", C.c_bool),
+                ("glsl_type", C.c_char_p), ("glsl_format", C.c_char_p)]
+
+
+class GlslVersion(C.Structure):
+    _fields_ = [("version", C.c_int), ("gles", C.c_bool), ("vulkan", C.c_bool),
+                ("compute", C.c_bool), ("max_shmem_size", C.c_size_t),
+                ("max_group_threads", C.c_uint32), ("max_group_size", C.c_uint32 * 3),
+                ("subgroup_size", C.c_uint32), ("min_gather_offset", C.c_int16),
+                ("max_gather_offset", C.c_int16)]
+
+
+class GpuLimits(C.Structure):
+    _fields_ = [("thread_safe", C.c_bool), ("callbacks", C.c_bool),
+                ("max_buf_size", C.c_size_t), ("max_ubo_size", C.c_size_t),
+                ("max_ssbo_size", C.c_size_t), ("max_vbo_size", C.c_size_t),
+                ("max_mapped_size", C.c_size_t), ("max_buffer_texels", C.c_uint64),
+                ("max_tex_1d_dim", C.c_uint32), ("max_tex_2d_dim", C.c_uint32),
+                ("max_tex_3d_dim", C.c_uint32), ("blittable_1d_3d", C.c_bool),
+                ("buf_transfer", C.c_bool), ("align_tex_xfer_pitch", C.c_size_t),
+                ("align_tex_xfer_offset", C.c_size_t), ("max_variable_comps", C.c_size_t),
+                ("max_constants", C.c_size_t), ("array_size_constants", C.c_bool),
+                ("max_pushc_size", C.c_size_t), ("max_dispatch", C.c_uint32 * 3),
+                ("fragment_queues", C.c_uint32), ("compute_queues", C.c_uint32)]
+
+
+class PciAddress(C.Structure):
+    _fields_ = [("domain", C.c_uint32), ("bus", C.c_uint32), ("device", C.c_uint32),
+                ("function", C.c_uint32)]
+
+
+class Gpu(C.Structure):
+    _fields_ = [("log", C.c_void_p), ("glsl", GlslVersion), ("limits", GpuLimits),
+                ("uuid", C.c_uint8 * 16), ("formats", C.POINTER(C.POINTER(Fmt))),
+                ("num_formats", C.c_int), ("pci", PciAddress)]
+
+
+class Hip(C.Structure):
+    _fields_ = [("gpu", C.POINTER(Gpu)), ("device", C.c_int), ("stream", C.c_void_p),
+                ("arch", C.c_char_p), ("compute_units", C.c_int)]
+
+
+class HipParams(C.Structure):
+    _fields_ = [("device", C.c_int), ("stream", C.c_void_p), ("max_shmem_size", C.c_size_t)]
+
+
+class HipWrapParams(C.Structure):
+    _fields_ = [("ptr", C.c_void_p), ("width", C.c_int), ("height", C.c_int),
+                ("row_pitch", C.c_size_t), ("format", C.POINTER(Fmt))]
+
+
+class TexParams(C.Structure):
+    _fields_ = [("w", C.c_int), ("h", C.c_int), ("d", C.c_int), ("format", C.POINTER(Fmt)),
+                ("sampleable", C.c_bool), ("renderable", C.c_bool), ("storable", C.c_bool),
+                ("blit_src", C.c_bool), ("blit_dst", C.c_bool), ("host_writable", C.c_bool),
+                ("host_readable", C.c_bool), ("initial_data", C.c_void_p),
+                ("user_data", C.c_void_p), ("debug_tag", C.c_char_p)]
+
+
+class Tex(C.Structure):
+    _fields_ = [("params", TexParams), ("sampler_type", C.c_int)]
+
+
+class TexTransferParams(C.Structure):
+    _fields_ = [("tex", C.POINTER(Tex)), ("rc", Rect3d), ("row_pitch", C.c_size_t),
+                ("depth_pitch", C.c_size_t), ("timer", C.c_void_p), ("callback", C.c_void_p),
+                ("priv", C.c_void_p), ("buf", C.c_void_p), ("buf_offset", C.c_size_t),
+                ("ptr", C.c_void_p)]
+
+
+# ---- shaders ----------------------------------------------------------------------
+class ShaderRes(C.Structure):
+    _fields_ = [("glsl", C.c_char_p), ("name", C.c_char_p), ("description", C.c_char_p),
+                ("input", C.c_int), ("output", C.c_int), ("compute_group_size", C.c_int * 2),
+                ("compute_shmem", C.c_size_t), ("num_ops", C.c_int)]
+
+
+class SampleSrc(C.Structure):
+    _fields_ = [("tex", C.POINTER(Tex)), ("rect", Rect2df), ("address_mode", C.c_int),
+                ("tex_w", C.c_int), ("tex_h", C.c_int), ("format", C.c_int),
+                ("sampler", C.c_int), ("mode", C.c_int), ("sampled_w", C.c_float),
+                ("sampled_h", C.c_float), ("components", C.c_int),
+                ("component_mask", C.c_uint8), ("new_w", C.c_int), ("new_h", C.c_int),
+                ("scale", C.c_float)]
+
+
+class DebandParams(C.Structure):
+    _fields_ = [("iterations", C.c_int), ("threshold", C.c_float), ("radius", C.c_float),
+                ("grain", C.c_float), ("grain_neutral", C.c_float * 3)]
+
+
+class SampleFilterParams(C.Structure):
+    _fields_ = [("filter", FilterConfig), ("antiring", C.c_float), ("no_compute", C.c_bool),
+                ("no_widening", C.c_bool), ("lut", C.POINTER(C.c_void_p))]
+
+
+class DitherParams(C.Structure):
+    _fields_ = [("method", C.c_int), ("lut_size", C.c_int), ("temporal", C.c_bool),
+                ("transfer", C.c_int)]
+
+
+class DispatchParams(C.Structure):
+    _fields_ = [("shader", C.POINTER(C.c_void_p)), ("target", C.POINTER(Tex)),
+                ("rect", Rect2d), ("blend_params", C.c_void_p), ("timer", C.c_void_p)]
+
+
+def declare(lib):
+    """Attach argtypes/restypes."""
+    P = C.POINTER
+    vp = C.c_void_p
+
+    def fn(name, res, *args):
+        f = getattr(lib, name)
+        f.restype = res
+        f.argtypes = list(args)
+        return f
+
+    fn("pl_log_create", vp, C.c_int, P(LogParams))
+    fn("pl_log_destroy", None, P(vp))
+
+    fn("pl_filter_generate", P(Filter), vp, P(FilterParams))
+    fn("pl_filter_free", None, P(P(Filter)))
+    fn("pl_filter_sample", C.c_double, P(FilterConfig), C.c_double)
+    fn("pl_find_filter_config", P(FilterConfig), C.c_char_p, C.c_int)
+    fn("pl_filter_radius_bound", C.c_float, P(FilterConfig))
+    fn("pl_generate_bayer_matrix", None, vp, C.c_int)
+    fn("pl_generate_blue_noise", None, vp, C.c_int)
+
+    fn("pl_hip_device_count", C.c_int)
+    fn("pl_hip_create", P(Hip), vp, P(HipParams))
+    fn("pl_hip_destroy", None, P(P(Hip)))
+    fn("pl_hip_wrap", P(Tex), P(Gpu), P(HipWrapParams))
+    fn("pl_hip_tex_ptr", vp, P(Tex), P(C.c_size_t))
+    fn("pl_find_named_fmt", P(Fmt), P(Gpu), C.c_char_p)
+    fn("pl_find_fmt", P(Fmt), P(Gpu), C.c_int, C.c_int, C.c_int, C.c_int, C.c_int)
+    fn("pl_tex_create", P(Tex), P(Gpu), P(TexParams))
+    fn("pl_tex_destroy", None, P(Gpu), P(P(Tex)))
+    fn("pl_tex_upload", C.c_bool, P(Gpu), P(TexTransferParams))
+    fn("pl_tex_download", C.c_bool, P(Gpu), P(TexTransferParams))
+    fn("pl_tex_clear", None, P(Gpu), P(Tex), P(C.c_float))
+    fn("pl_gpu_finish", None, P(Gpu))
+    fn("pl_timer_create", vp, P(Gpu))
+    fn("pl_timer_destroy", None, P(Gpu), P(vp))
+    fn("pl_timer_query", C.c_uint64, P(Gpu), vp)
+
+    fn("pl_dispatch_create", vp, vp, P(Gpu))
+    fn("pl_dispatch_destroy", None, P(vp))
+    fn("pl_dispatch_reset_frame", None, vp)
+    fn("pl_dispatch_begin", vp, vp)
+    fn("pl_dispatch_finish", C.c_bool, vp, P(DispatchParams))
+    fn("pl_dispatch_abort", None, vp, P(vp))
+    fn("pl_shader_finalize", P(ShaderRes), vp)
+    fn("pl_shader_is_failed", C.c_bool, vp)
+    fn("pl_shader_obj_destroy", None, P(vp))
+
+    for n in ("direct", "nearest", "bilinear", "bicubic", "hermite", "gaussian"):
+        fn(f"pl_shader_sample_{n}", C.c_bool, vp, P(SampleSrc))
+    fn("pl_shader_sample_oversample", C.c_bool, vp, P(SampleSrc), C.c_float)
+    fn("pl_shader_sample_polar", C.c_bool, vp, P(SampleSrc), P(SampleFilterParams))
+    fn("pl_shader_sample_ortho2", C.c_bool, vp, P(SampleSrc), P(SampleFilterParams))
+    fn("pl_shader_deband", None, vp, P(SampleSrc), P(DebandParams))
+    fn("pl_shader_dither", None, vp, C.c_int, P(vp), P(DitherParams))
+    return lib

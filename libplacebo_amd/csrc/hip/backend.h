@@ -1,0 +1,67 @@
+/*
+ * libplacebo-hip — thin C interface to the HIP runtime used by the C host
+ * layer (gpu.c). Everything the `pl_gpu` front-end needs from the device:
+ * memory, 2-D copies, stream ordering, event timers.
+ */
+#ifndef PLH_BACKEND_H_
+#define PLH_BACKEND_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#include "plh_device.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+struct plh_dev_info {
+    char name[256];
+    char arch[64];
+    int compute_units;
+    int wavefront_size;
+    size_t lds_per_block;
+    size_t total_mem;
+    int clock_khz;
+    uint8_t uuid[16];
+    int pci_domain, pci_bus, pci_device;
+};
+
+int plh_dev_count(void);
+const char *plh_strerror(int err);
+int plh_dev_open(int device, struct plh_dev_info *info);
+int plh_stream_create(int device, plh_stream *out);
+void plh_stream_destroy(plh_stream s);
+int plh_stream_sync(plh_stream s);
+
+void *plh_malloc(int device, size_t size);
+void plh_free(void *ptr);
+void *plh_host_alloc(size_t size); // pinned
+void plh_host_free(void *ptr);
+
+int plh_copy2d_h2d(plh_stream s, void *dst, size_t dpitch, const void *src, size_t spitch,
+                   size_t row_bytes, size_t rows);
+int plh_copy2d_d2h(plh_stream s, void *dst, size_t dpitch, const void *src, size_t spitch,
+                   size_t row_bytes, size_t rows);
+int plh_copy2d_d2d(plh_stream s, void *dst, size_t dpitch, const void *src, size_t spitch,
+                   size_t row_bytes, size_t rows);
+int plh_memset(plh_stream s, void *dst, int value, size_t size);
+
+typedef void *plh_event;
+int plh_event_create(plh_event *out);
+void plh_event_destroy(plh_event e);
+int plh_event_record(plh_event e, plh_stream s);
+// 1 = ready, 0 = not yet, <0 error
+int plh_event_query(plh_event e);
+int plh_event_sync(plh_event e);
+// elapsed nanoseconds between two completed events
+int plh_event_elapsed_ns(plh_event a, plh_event b, uint64_t *ns);
+
+// fills the whole texture with a constant colour (pl_tex_clear_ex)
+int plh_launch_clear(plh_stream s, const struct plh_view *dst, const float color[4]);
+
+#ifdef __cplusplus
+}
+#endif
+
+#endif // PLH_BACKEND_H_

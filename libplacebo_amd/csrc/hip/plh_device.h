@@ -1,0 +1,172 @@
+/*
+ * libplacebo-hip — internal ABI between the C host layer (shader recording,
+ * dispatch, renderer) and the HIP kernels. Plain C structs, passed to the
+ * kernels *by value* as kernel arguments (SGPR-resident, wave-uniform).
+ *
+ * One `plh_pass` describes one GPU pass = what the reference builds as a
+ * pl_shader and hands to pl_dispatch_finish (src/dispatch.c:1199):
+ *     sampler (how `color` is produced from the source texture)
+ *  -> a chain of per-pixel colour ops (what pl_shader_* calls append)
+ *  -> store to the target rect (translate_compute_shader, dispatch.c:1079-1144)
+ */
+#ifndef PLH_DEVICE_H_
+#define PLH_DEVICE_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- texture formats (packed, linear, pitched 2D arrays in HBM) ---------- */
+enum plh_fmt {
+    PLH_FMT_NONE = 0,
+    PLH_FMT_R8, PLH_FMT_RG8, PLH_FMT_RGBA8,         // unorm8
+    PLH_FMT_R16, PLH_FMT_RG16, PLH_FMT_RGBA16,      // unorm16
+    PLH_FMT_R16F, PLH_FMT_RG16F, PLH_FMT_RGBA16F,   // IEEE half
+    PLH_FMT_R32F, PLH_FMT_RG32F, PLH_FMT_RGBA32F,   // float
+    PLH_FMT_COUNT
+};
+
+struct plh_view {
+    void *ptr;          // device pointer to texel (0,0)
+    int32_t w, h;
+    int32_t pitch;      // bytes per row
+    int32_t fmt;        // enum plh_fmt
+};
+
+/* ---- samplers ------------------------------------------------------------ */
+enum plh_sampler {
+    PLH_SAMPLE_NONE = 0,    // colour starts as (0,0,0,1) (no source)
+    PLH_SAMPLE_NEAREST,     // sampling.c:290 (and :277 on non-LINEAR formats)
+    PLH_SAMPLE_BILINEAR,    // sampling.c:304 / :277 (hardware bilinear, done in ALU)
+    PLH_SAMPLE_BICUBIC,     // sampling.c:318
+    PLH_SAMPLE_HERMITE,     // sampling.c:366
+    PLH_SAMPLE_GAUSSIAN,    // sampling.c:392
+    PLH_SAMPLE_OVERSAMPLE,  // sampling.c:436
+    PLH_SAMPLE_POLAR,       // sampling.c:587 (EWA, LDS-tiled)
+    PLH_SAMPLE_ORTHO,       // sampling.c:950 (one separable pass)
+    PLH_SAMPLE_DEBAND,      // sampling.c:183
+};
+
+enum plh_address_mode {     // gpu.h pl_tex_address_mode
+    PLH_ADDRESS_CLAMP = 0,
+    PLH_ADDRESS_REPEAT,
+    PLH_ADDRESS_MIRROR,
+};
+
+/* polar tap: signed offsets relative to the base texel + flags
+ * (polar_sample(), sampling.c:503-558) packed as x | y<<8 | flags<<16 */
+#define PLH_TAP_SKIPPABLE 1u    // needs the run-time `d < radius` test
+#define PLH_TAP_AR        2u    // may contribute to anti-ringing
+#define PLH_TAP_PACK(x, y, fl) \
+    ((uint32_t) ((uint8_t) (int8_t) (x)) | ((uint32_t) ((uint8_t) (int8_t) (y)) << 8) | \
+     ((uint32_t) (fl) << 16))
+
+struct plh_sampler_args {
+    int32_t type;           // enum plh_sampler
+    struct plh_view src;
+    // vertex attribute `tex_coord` at the 4 quad corners (sh_bind, shaders.c:541-561),
+    // in normalised texture coordinates
+    float pos[4][2];
+    float pt[2];            // 1/tex_size
+    int32_t address_mode;
+    float scale;            // multiplied into the sampled colour
+    uint32_t comp_mask;     // components actually sampled
+    int32_t linear;         // texture bound with LINEAR filtering (for deband etc.)
+
+    // POLAR: 256-entry radial LUT, as {L[i], L[i+1]} pairs; tap list
+    const float *lut;       // device, 2*256 floats (pairs)
+    const uint32_t *taps;   // device, packed taps in evaluation order
+    int32_t num_taps;
+    int32_t bound;          // ceil(radius)
+    float radius, rcp_radius, radius_zero;
+    float antiring;
+    int32_t tile_w, tile_h; // LDS tile (texels)
+    int32_t tile_rows;      // output rows per lane (output tile = 32 x 8*rows)
+    int32_t tile_fp32;      // tile kept as float4 instead of half4
+
+    // ORTHO: weights[256][row_stride] rows; N taps along `dir`
+    const float *weights;   // device
+    int32_t row_size, row_stride;
+    int32_t dir;            // 0 = horizontal, 1 = vertical
+    int32_t use_linear;     // "linear trick" packing (sampling.c:919-936)
+    int32_t use_ar;
+
+    // OVERSAMPLE
+    float ratio[2], threshold;
+
+    // DEBAND
+    int32_t iterations;
+    float db_threshold, db_radius, db_grain;
+    float db_neutral[3];
+    uint32_t prng_seed;     // frame index (sh_prng, shaders.c:965-998)
+};
+
+/* ---- per-pixel colour ops -------------------------------------------------- */
+enum plh_op_kind {
+    PLH_OP_NONE = 0,
+    PLH_OP_SCALE,           // color *= f[0..3]
+    PLH_OP_AFFINE,          // color.rgb = M(f[0..8], row-major) * color.rgb + f[9..11]
+    PLH_OP_LINEARIZE,       // i0 = transfer; f[] = parameters   (colorspace.c:589)
+    PLH_OP_DELINEARIZE,     // i0 = transfer; f[] = parameters   (colorspace.c:722)
+    PLH_OP_SIGMOIDIZE,      // f[0]=center f[1]=slope f[2]=offset f[3]=scale (colorspace.c:851)
+    PLH_OP_UNSIGMOIDIZE,    // (colorspace.c:874)
+    PLH_OP_PREMULTIPLY,     // color.rgb *= color.a  (pl_shader_set_alpha, colorspace.c:26)
+    PLH_OP_UNPREMULTIPLY,   // color.rgb /= max(color.a, 1e-6)
+    PLH_OP_ALPHA_ONE,       // color.a = 1
+    PLH_OP_QUANT_F16,       // round through IEEE half (an rgba16hf FBO store+load)
+    PLH_OP_QUANT_UNORM,     // round through unorm of i0 bits (unorm FBO)
+    PLH_OP_DITHER,          // ptr = size×size float matrix; i0 = size; i1 = method;
+                            // f[0] = 2^depth-1; f[1] = gamma; i2 = depth; f[4..7] = temporal mat2
+    PLH_OP_SWIZZLE,         // i0..i3 packed: output component c takes input comp map[c] (or -1 → 0/1)
+    PLH_OP_TONE_MAP,        // colour mapping (colorspace.c:1612), see k_colormap
+    PLH_OP_CLAMP01,         // color = clamp(color, 0, 1)
+    PLH_OP_BT2020C_DEC, PLH_OP_BT2020C_ENC, // constant-luminance special cases
+    PLH_OP_ICTCP_DEC, PLH_OP_ICTCP_ENC,
+    PLH_OP_XYZ_DEC, PLH_OP_XYZ_ENC,
+};
+
+#define PLH_OP_NF 16
+struct plh_op {
+    int32_t kind;
+    int32_t i0, i1, i2;
+    float f[PLH_OP_NF];
+    const void *ptr;
+    const void *ptr2;
+};
+
+#define PLH_MAX_OPS 20
+
+struct plh_pass {
+    struct plh_sampler_args s;
+
+    int32_t num_pre_ops;    // ops [0, num_pre_ops) run per *source texel* at tile
+                            // load (fused "PASS A"), the rest per output pixel
+    int32_t num_ops;
+    struct plh_op ops[PLH_MAX_OPS];
+
+    // target
+    struct plh_view dst;
+    int32_t base_x, base_y; // dispatch.c:1102-1124
+    int32_t dir_x, dir_y;   // +1 / -1
+    int32_t width, height;  // |rect|
+    float out_scale[2];     // 1/width, 1/height (dispatch.c:1032-1036)
+    int32_t transpose;
+    int32_t frag_x0, frag_y0; // offset added to gl_FragCoord (0 for compute passes)
+
+    // peak detection side output (k_peak)
+    void *peak_buf;
+};
+
+/* ---- launch entry points (implemented in *.hip) --------------------------- */
+typedef void *plh_stream;
+
+// returns 0 on success, a negative hipError otherwise
+int plh_launch_pass(plh_stream stream, const struct plh_pass *pass);
+
+#ifdef __cplusplus
+}
+#endif
+
+#endif // PLH_DEVICE_H_

@@ -1,0 +1,256 @@
+/*
+ * libplacebo-hip — pl_dispatch: lowers a finished pl_shader to kernel launches.
+ *
+ * Counterpart of the reference's src/dispatch.c. The reference finalises GLSL,
+ * hashes it, compiles/caches a pl_pass and binds uniforms (finalize_pass
+ * :732-970); here the shader already *is* the launch description, so
+ * pl_dispatch_finish only has to add the target half:
+ *   - rect defaulting / validation                         dispatch.c:1199-1232
+ *   - compute-emulated rasterisation: out_scale, base, dir dispatch.c:1028-1142
+ *   - blending is not supported (never used on the pl_render_image path with
+ *     blend_params == NULL)
+ */
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <libplacebo/dispatch.h>
+
+#include "shaders_priv.h"
+
+#define MAX_SHADERS 32
+
+struct pass_timing {
+    uint64_t signature;
+    pl_timer timer;
+    struct pl_dispatch_info info;
+    int ring;
+    char desc[128];
+};
+
+struct pl_dispatch_t {
+    pl_log log;
+    pl_gpu gpu;
+    uint8_t current_ident;
+    uint8_t current_index;
+
+    pl_shader pool[MAX_SHADERS];
+    int num_pool;
+
+    void (*info_cb)(void *priv, const struct pl_dispatch_info *);
+    void *info_priv;
+    struct pass_timing timings[64];
+    int num_timings;
+};
+
+pl_dispatch pl_dispatch_create(pl_log log, pl_gpu gpu)
+{
+    struct pl_dispatch_t *dp = calloc(1, sizeof(*dp));
+    if (!dp)
+        return NULL;
+    dp->log = log;
+    dp->gpu = gpu;
+    return dp;
+}
+
+void pl_dispatch_destroy(pl_dispatch *ptr)
+{
+    pl_dispatch dp = ptr ? *ptr : NULL;
+    if (!dp)
+        return;
+    for (int i = 0; i < dp->num_pool; i++)
+        pl_shader_free(&dp->pool[i]);
+    for (int i = 0; i < dp->num_timings; i++)
+        pl_timer_destroy(dp->gpu, &dp->timings[i].timer);
+    free(dp);
+    *ptr = NULL;
+}
+
+void pl_dispatch_reset_frame(pl_dispatch dp)
+{
+    dp->current_ident = 0;
+    dp->current_index++; // uint8 wrap-around, like dispatch.c:1618
+}
+
+pl_shader pl_dispatch_begin(pl_dispatch dp)
+{
+    struct pl_shader_params params = {
+        .id = dp->current_ident++,
+        .gpu = dp->gpu,
+        .index = dp->current_index,
+    };
+    if (dp->num_pool) {
+        pl_shader sh = dp->pool[--dp->num_pool];
+        pl_shader_reset(sh, &params);
+        return sh;
+    }
+    return pl_shader_alloc(dp->log, &params);
+}
+
+void pl_dispatch_abort(pl_dispatch dp, pl_shader *psh)
+{
+    pl_shader sh = psh ? *psh : NULL;
+    if (!sh)
+        return;
+    // release held objects right away, keep the allocation for reuse
+    pl_shader_reset(sh, NULL);
+    if (dp->num_pool < MAX_SHADERS) {
+        dp->pool[dp->num_pool++] = sh;
+    } else {
+        pl_shader_free(&sh);
+    }
+    *psh = NULL;
+}
+
+void pl_dispatch_callback(pl_dispatch dp, void *priv,
+                          void (*cb)(void *priv, const struct pl_dispatch_info *))
+{
+    dp->info_cb = cb;
+    dp->info_priv = priv;
+}
+
+static uint64_t hash_str(const char *s)
+{
+    uint64_t h = 1469598103934665603ull; // FNV-1a
+    for (; *s; s++)
+        h = (h ^ (uint8_t) *s) * 1099511628211ull;
+    return h;
+}
+
+static struct pass_timing *get_timing(pl_dispatch dp, pl_shader sh)
+{
+    if (!dp->info_cb)
+        return NULL;
+    const struct pl_shader_res *res = pl_shader_finalize(sh);
+    const uint64_t sig = hash_str(res->glsl) ^ hash_str(res->description);
+    for (int i = 0; i < dp->num_timings; i++) {
+        if (dp->timings[i].signature == sig)
+            return &dp->timings[i];
+    }
+    if (dp->num_timings == (int) PL_ARRAY_SIZE(dp->timings))
+        return NULL;
+    struct pass_timing *t = &dp->timings[dp->num_timings++];
+    memset(t, 0, sizeof(*t));
+    t->signature = sig;
+    t->timer = pl_timer_create(dp->gpu);
+    snprintf(t->desc, sizeof(t->desc), "%s", res->description);
+    t->info.description = t->desc;
+    t->info.signature = sig;
+    return t;
+}
+
+static void drain_timing(pl_dispatch dp, struct pass_timing *t)
+{
+    if (!t || !t->timer)
+        return;
+    for (uint64_t ns; (ns = pl_timer_query(dp->gpu, t->timer));) {
+        struct pl_dispatch_info *info = &t->info;
+        info->samples[t->ring] = ns;
+        t->ring = (t->ring + 1) % (int) PL_ARRAY_SIZE(info->samples);
+        info->num_samples = PL_MIN(info->num_samples + 1, (int) PL_ARRAY_SIZE(info->samples));
+        info->last = ns;
+        info->peak = PL_MAX(info->peak, ns);
+        uint64_t sum = 0;
+        for (int i = 0; i < info->num_samples; i++)
+            sum += info->samples[i];
+        info->average = sum / info->num_samples;
+        dp->info_cb(dp->info_priv, info);
+    }
+}
+
+bool pl_dispatch_finish(pl_dispatch dp, const struct pl_dispatch_params *params)
+{
+    pl_shader sh = *params->shader;
+    bool ok = false;
+
+    if (sh->failed) {
+        pl_msg(dp->log, PL_LOG_ERR, "Trying to dispatch a failed shader.");
+        goto done;
+    }
+    if (sh->input != PL_SHADER_SIG_NONE || sh->output != PL_SHADER_SIG_COLOR) {
+        pl_msg(dp->log, PL_LOG_ERR, "Trying to dispatch shader with incompatible signature!");
+        goto done;
+    }
+    if (sh->kind != PLH_SHADER_PASS) {
+        pl_msg(dp->log, PL_LOG_ERR, "This shader must be run with pl_dispatch_compute");
+        goto done;
+    }
+    if (params->blend_params) {
+        pl_msg(dp->log, PL_LOG_ERR, "Blending is not supported by the HIP backend");
+        goto done;
+    }
+
+    pl_tex target = params->target;
+    if (!target || pl_tex_params_dimension(target->params) != 2) {
+        pl_msg(dp->log, PL_LOG_ERR, "Trying to dispatch a shader using an invalid target");
+        goto done;
+    }
+    if (!target->params.storable) {
+        pl_msg(dp->log, PL_LOG_ERR, "Trying to dispatch using a non-storable target "
+               "(every pass is a compute pass on this backend).");
+        goto done;
+    }
+
+    pl_rect2d rc = params->rect;
+    if (!pl_rect_w(rc)) {
+        rc.x0 = 0;
+        rc.x1 = target->params.w;
+    }
+    if (!pl_rect_h(rc)) {
+        rc.y0 = 0;
+        rc.y1 = target->params.h;
+    }
+
+    int w, h, tw = abs(pl_rect_w(rc)), th = abs(pl_rect_h(rc));
+    if (pl_shader_output_size(sh, &w, &h) && (w != tw || h != th)) {
+        pl_msg(dp->log, PL_LOG_ERR, "Trying to dispatch a shader with explicit output size "
+               "requirements %dx%d%s using a target rect of size %dx%d.",
+               w, h, sh->transpose ? " (transposed)" : "", tw, th);
+        goto done;
+    }
+
+    struct plh_pass *pass = &sh->pass;
+    plh_tex_view(target, &pass->dst);
+    int width = tw, height = th;
+    if (sh->transpose) {
+        width = th;
+        height = tw;
+    }
+    pass->width = width;
+    pass->height = height;
+    pass->out_scale[0] = 1.0 / width;
+    pass->out_scale[1] = 1.0 / height;
+    pass->base_x = rc.x0 - (rc.x0 > rc.x1);
+    pass->base_y = rc.y0 - (rc.y0 > rc.y1);
+    pass->dir_x = rc.x0 > rc.x1 ? -1 : 1;
+    pass->dir_y = rc.y0 > rc.y1 ? -1 : 1;
+    pass->transpose = sh->transpose;
+    pass->frag_x0 = pass->frag_y0 = 0; // compute passes: rect-relative gl_FragCoord
+
+    struct pass_timing *timing = get_timing(dp, sh);
+    pl_timer timer = params->timer ? params->timer : timing ? timing->timer : NULL;
+    if (timer)
+        plh_timer_begin(dp->gpu, timer);
+    const int err = plh_launch_pass(plh_gpu_stream(dp->gpu), pass);
+    if (timer)
+        plh_timer_end(dp->gpu, timer);
+    if (err) {
+        pl_msg(dp->log, PL_LOG_ERR, "Failed launching pass '%s': %s",
+               sh->description, plh_strerror(err));
+        goto done;
+    }
+    if (!params->timer)
+        drain_timing(dp, timing);
+    ok = true;
+
+done:
+    pl_dispatch_abort(dp, params->shader);
+    return ok;
+}
+
+bool pl_dispatch_compute(pl_dispatch dp, const struct pl_dispatch_compute_params *params)
+{
+    pl_msg(dp->log, PL_LOG_ERR, "pl_dispatch_compute: no standalone compute shaders yet");
+    pl_dispatch_abort(dp, params->shader);
+    return false;
+}

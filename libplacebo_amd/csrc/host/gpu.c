@@ -1,0 +1,654 @@
+/*
+ * libplacebo-hip — the `pl_gpu` object of the HIP backend.
+ *
+ * Role of src/gpu.c (validation front-end, pl_find_fmt :94-128) plus a backend
+ * file such as src/dummy.c / src/opengl/gpu.c (object creation, format table,
+ * limits) in the reference. Textures are pitched linear device arrays; all
+ * work is ordered on one HIP stream, so uploads/passes/downloads issued in API
+ * order execute in that order without further fences.
+ */
+#include <stdlib.h>
+#include <string.h>
+
+#include <libplacebo/hip.h>
+
+#include "gpu_priv.h"
+
+const struct pl_hip_params pl_hip_default_params = {0};
+
+/* ------------------------------------------------------------------------ */
+/* format table                                                              */
+
+#define CAPS_ALL (PL_FMT_CAP_SAMPLEABLE | PL_FMT_CAP_STORABLE | PL_FMT_CAP_LINEAR |    \
+                  PL_FMT_CAP_RENDERABLE | PL_FMT_CAP_BLENDABLE | PL_FMT_CAP_BLITTABLE | \
+                  PL_FMT_CAP_HOST_READABLE | PL_FMT_CAP_READWRITE)
+
+#define FMT(nm, ty, n, bits, plhfmt, vtx, gtype, gfmt) {                                   \
+    .pub = {                                                                            \
+        .name = nm, .type = ty, .num_components = n,                                    \
+        .caps = CAPS_ALL | ((vtx) ? PL_FMT_CAP_VERTEX : 0),                             \
+        .component_depth = { bits, (n) > 1 ? bits : 0, (n) > 2 ? bits : 0, (n) > 3 ? bits : 0 }, \
+        .host_bits       = { bits, (n) > 1 ? bits : 0, (n) > 2 ? bits : 0, (n) > 3 ? bits : 0 }, \
+        .sample_order = {0, 1, 2, 3},                                                   \
+        .internal_size = (n) * (bits) / 8, .texel_size = (n) * (bits) / 8,              \
+        .texel_align = (bits) / 8, .gatherable = true,                                  \
+        .glsl_type = gtype, .glsl_format = gfmt,                                        \
+    }, .plh = plhfmt }
+
+static const struct fmt_priv fmt_table[] = {
+    FMT("r8",       PL_FMT_UNORM, 1,  8, PLH_FMT_R8,      false, "float", "r8"),
+    FMT("rg8",      PL_FMT_UNORM, 2,  8, PLH_FMT_RG8,     false, "vec2",  "rg8"),
+    FMT("rgba8",    PL_FMT_UNORM, 4,  8, PLH_FMT_RGBA8,   false, "vec4",  "rgba8"),
+    FMT("r16",      PL_FMT_UNORM, 1, 16, PLH_FMT_R16,     false, "float", "r16"),
+    FMT("rg16",     PL_FMT_UNORM, 2, 16, PLH_FMT_RG16,    false, "vec2",  "rg16"),
+    FMT("rgba16",   PL_FMT_UNORM, 4, 16, PLH_FMT_RGBA16,  false, "vec4",  "rgba16"),
+    FMT("r16hf",    PL_FMT_FLOAT, 1, 16, PLH_FMT_R16F,    false, "float", "r16f"),
+    FMT("rg16hf",   PL_FMT_FLOAT, 2, 16, PLH_FMT_RG16F,   false, "vec2",  "rg16f"),
+    FMT("rgba16hf", PL_FMT_FLOAT, 4, 16, PLH_FMT_RGBA16F, false, "vec4",  "rgba16f"),
+    FMT("r32f",     PL_FMT_FLOAT, 1, 32, PLH_FMT_R32F,    true,  "float", "r32f"),
+    FMT("rg32f",    PL_FMT_FLOAT, 2, 32, PLH_FMT_RG32F,   true,  "vec2",  "rg32f"),
+    FMT("rgba32f",  PL_FMT_FLOAT, 4, 32, PLH_FMT_RGBA32F, true,  "vec4",  "rgba32f"),
+};
+
+#define NUM_FMTS ((int) PL_ARRAY_SIZE(fmt_table))
+
+// Same ordering rule as the reference's pl_gpu_finalize (gpu/utils.c:26-81);
+// all our formats share caps, so this reduces to "lower depth first, then name"
+static int cmp_fmt(const void *pa, const void *pb)
+{
+    pl_fmt a = *(pl_fmt *) pa, b = *(pl_fmt *) pb;
+    for (int i = 0; i < 4; i++) {
+        if (a->component_depth[i] != b->component_depth[i])
+            return a->component_depth[i] < b->component_depth[i] ? -1 : 1;
+        if (a->host_bits[i] != b->host_bits[i])
+            return a->host_bits[i] < b->host_bits[i] ? -1 : 1;
+    }
+    return strcmp(a->name, b->name);
+}
+
+bool pl_fmt_is_ordered(pl_fmt fmt)
+{
+    for (int i = 0; i < fmt->num_components; i++) {
+        if (fmt->sample_order[i] != i)
+            return false;
+    }
+    return true;
+}
+
+bool pl_fmt_is_float(pl_fmt fmt)
+{
+    return fmt->type == PL_FMT_UNORM || fmt->type == PL_FMT_SNORM ||
+           fmt->type == PL_FMT_FLOAT;
+}
+
+pl_fmt pl_find_fmt(pl_gpu gpu, enum pl_fmt_type type, int num_components,
+                   int min_depth, int host_bits, enum pl_fmt_caps caps)
+{
+    for (int n = 0; n < gpu->num_formats; n++) {
+        pl_fmt fmt = gpu->formats[n];
+        if (fmt->type != type || fmt->num_components != num_components)
+            continue;
+        if ((fmt->caps & caps) != caps)
+            continue;
+        if (host_bits && (fmt->opaque || !pl_fmt_is_ordered(fmt) ||
+                          fmt->texel_size * 8 != (size_t) host_bits * num_components))
+            continue;
+
+        bool ok = true;
+        for (int i = 0; i < fmt->num_components; i++) {
+            ok &= fmt->component_depth[i] >= min_depth;
+            ok &= !host_bits || fmt->host_bits[i] == host_bits;
+        }
+        if (ok)
+            return fmt;
+    }
+    return NULL;
+}
+
+pl_fmt pl_find_vertex_fmt(pl_gpu gpu, enum pl_fmt_type type, int comps)
+{
+    for (int n = 0; n < gpu->num_formats; n++) {
+        pl_fmt fmt = gpu->formats[n];
+        if (fmt->type == type && fmt->num_components == comps &&
+            (fmt->caps & PL_FMT_CAP_VERTEX) && fmt->host_bits[0] == 32)
+            return fmt;
+    }
+    return NULL;
+}
+
+pl_fmt pl_find_named_fmt(pl_gpu gpu, const char *name)
+{
+    for (int n = 0; name && n < gpu->num_formats; n++) {
+        if (!strcmp(gpu->formats[n]->name, name))
+            return gpu->formats[n];
+    }
+    return NULL;
+}
+
+/* ------------------------------------------------------------------------ */
+/* backend object                                                            */
+
+int pl_hip_device_count(void)
+{
+    return plh_dev_count();
+}
+
+pl_hip pl_hip_create(pl_log log, const struct pl_hip_params *params)
+{
+    params = PL_DEF(params, &pl_hip_default_params);
+    if (plh_dev_count() <= params->device) {
+        pl_msg(log, PL_LOG_FATAL, "pl_hip_create: no HIP device %d (found %d). "
+               "There is no CPU fallback for this backend.",
+               params->device, plh_dev_count());
+        return NULL;
+    }
+
+    struct gpu_priv *p = calloc(1, sizeof(*p));
+    if (!p)
+        return NULL;
+
+    int err = plh_dev_open(params->device, &p->info);
+    if (err) {
+        pl_msg(log, PL_LOG_FATAL, "pl_hip_create: opening device %d failed: %s",
+               params->device, plh_strerror(err));
+        free(p);
+        return NULL;
+    }
+
+    p->device = params->device;
+    if (params->stream) {
+        p->stream = params->stream;
+    } else {
+        err = plh_stream_create(p->device, &p->stream);
+        if (err) {
+            pl_msg(log, PL_LOG_FATAL, "pl_hip_create: stream creation failed: %s",
+                   plh_strerror(err));
+            free(p);
+            return NULL;
+        }
+        p->own_stream = true;
+    }
+
+    struct pl_gpu_t *gpu = &p->gpu;
+    gpu->log = log;
+    gpu->glsl = (struct pl_glsl_version) {
+        .version = 450,
+        .vulkan = true,
+        .compute = true,
+        .max_shmem_size = PL_DEF(params->max_shmem_size, 65536),
+        .max_group_threads = 1024,
+        .max_group_size = { 1024, 1024, 1024 },
+        .subgroup_size = 64,
+        .min_gather_offset = -32,
+        .max_gather_offset = 31,
+    };
+    gpu->limits = (struct pl_gpu_limits) {
+        .thread_safe = false,
+        .callbacks = false,
+        .max_buf_size = p->info.total_mem,
+        .max_ubo_size = 65536,
+        .max_ssbo_size = p->info.total_mem,
+        .max_tex_1d_dim = 1 << 16,
+        .max_tex_2d_dim = 1 << 16,
+        .max_tex_3d_dim = 0,
+        .buf_transfer = true,
+        .align_tex_xfer_pitch = 256,
+        .align_tex_xfer_offset = 256,
+        .max_variable_comps = 0,
+        .max_constants = 0,
+        .array_size_constants = true,
+        .max_pushc_size = 4096, // kernel arguments
+        .max_dispatch = { 1u << 31, 65535, 65535 },
+        .fragment_queues = 0,   // every pass is a compute pass (dispatch.c:1236)
+        .compute_queues = 1,
+    };
+    memcpy(gpu->uuid, p->info.uuid, 16);
+    gpu->pci = (struct pl_gpu_pci_address) {
+        .domain = p->info.pci_domain, .bus = p->info.pci_bus, .device = p->info.pci_device,
+    };
+
+    for (int i = 0; i < NUM_FMTS; i++)
+        p->fmts[i] = &fmt_table[i].pub;
+    qsort(p->fmts, NUM_FMTS, sizeof(p->fmts[0]), cmp_fmt);
+    gpu->formats = p->fmts;
+    gpu->num_formats = NUM_FMTS;
+
+    p->hip = (struct pl_hip_t) {
+        .gpu = gpu,
+        .device = p->device,
+        .stream = p->stream,
+        .arch = p->info.arch,
+        .compute_units = p->info.compute_units,
+    };
+
+    pl_msg(log, PL_LOG_INFO, "pl_hip: device %d '%s' (%s), %d CUs, %zu MiB",
+           p->device, p->info.name, p->info.arch, p->info.compute_units,
+           p->info.total_mem >> 20);
+    return &p->hip;
+}
+
+void pl_hip_destroy(pl_hip *hip)
+{
+    if (!hip || !*hip)
+        return;
+    struct gpu_priv *p = GPU_PRIV((*hip)->gpu);
+    plh_stream_sync(p->stream);
+    if (p->own_stream)
+        plh_stream_destroy(p->stream);
+    free(p);
+    *hip = NULL;
+}
+
+pl_hip pl_hip_get(pl_gpu gpu)
+{
+    return gpu ? &GPU_PRIV(gpu)->hip : NULL;
+}
+
+void pl_gpu_flush(pl_gpu gpu)
+{
+    (void) gpu; // HIP submits eagerly
+}
+
+void pl_gpu_finish(pl_gpu gpu)
+{
+    struct gpu_priv *p = GPU_PRIV(gpu);
+    const int err = plh_stream_sync(p->stream);
+    if (err) {
+        pl_msg(gpu->log, PL_LOG_ERR, "pl_gpu_finish: %s", plh_strerror(err));
+        p->failed = true;
+    }
+}
+
+bool pl_gpu_is_failed(pl_gpu gpu)
+{
+    return GPU_PRIV(gpu)->failed;
+}
+
+/* ------------------------------------------------------------------------ */
+/* textures                                                                  */
+
+static bool check_tex_params(pl_gpu gpu, const struct pl_tex_params *params)
+{
+    if (!params->format || params->w <= 0 || params->h < 0 || params->d != 0) {
+        pl_msg(gpu->log, PL_LOG_ERR, "pl_tex_create: invalid parameters "
+               "(need format, w > 0, d == 0; got %dx%dx%d)", params->w, params->h, params->d);
+        return false;
+    }
+    if ((uint32_t) params->w > gpu->limits.max_tex_2d_dim ||
+        (uint32_t) params->h > gpu->limits.max_tex_2d_dim) {
+        pl_msg(gpu->log, PL_LOG_ERR, "pl_tex_create: %dx%d exceeds max_tex_2d_dim",
+               params->w, params->h);
+        return false;
+    }
+    return true;
+}
+
+pl_tex pl_tex_create(pl_gpu gpu, const struct pl_tex_params *params)
+{
+    if (!check_tex_params(gpu, params))
+        return NULL;
+
+    struct gpu_priv *g = GPU_PRIV(gpu);
+    struct tex_priv *t = calloc(1, sizeof(*t));
+    if (!t)
+        return NULL;
+    t->tex.params = *params;
+    t->tex.params.initial_data = NULL;
+    t->tex.sampler_type = PL_SAMPLER_NORMAL;
+    t->gpu = gpu;
+    t->plh_fmt = FMT_PRIV(params->format)->plh;
+    const int rows = PL_MAX(params->h, 1);
+    const size_t row_bytes = (size_t) params->w * params->format->texel_size;
+    t->pitch = PL_ALIGN2(row_bytes, (size_t) 256);
+    t->ptr = plh_malloc(g->device, t->pitch * rows);
+    t->owned = true;
+    if (!t->ptr) {
+        pl_msg(gpu->log, PL_LOG_ERR, "pl_tex_create: out of device memory (%zu bytes)",
+               t->pitch * rows);
+        free(t);
+        return NULL;
+    }
+
+    if (params->initial_data) {
+        const int err = plh_copy2d_h2d(g->stream, t->ptr, t->pitch, params->initial_data,
+                                       row_bytes, row_bytes, rows);
+        // initial_data may be freed by the caller right away
+        if (err || plh_stream_sync(g->stream)) {
+            pl_msg(gpu->log, PL_LOG_ERR, "pl_tex_create: initial upload failed");
+            plh_free(t->ptr);
+            free(t);
+            return NULL;
+        }
+    }
+    return &t->tex;
+}
+
+pl_tex pl_hip_wrap(pl_gpu gpu, const struct pl_hip_wrap_params *params)
+{
+    if (!params || !params->ptr || !params->format || params->width <= 0 || params->height <= 0) {
+        pl_msg(gpu->log, PL_LOG_ERR, "pl_hip_wrap: invalid parameters");
+        return NULL;
+    }
+    struct tex_priv *t = calloc(1, sizeof(*t));
+    if (!t)
+        return NULL;
+    t->tex.params = (struct pl_tex_params) {
+        .w = params->width, .h = params->height, .format = params->format,
+        .sampleable = true, .renderable = true, .storable = true,
+        .blit_src = true, .blit_dst = true, .host_writable = true, .host_readable = true,
+    };
+    t->gpu = gpu;
+    t->plh_fmt = FMT_PRIV(params->format)->plh;
+    t->ptr = params->ptr;
+    t->pitch = PL_DEF(params->row_pitch, (size_t) params->width * params->format->texel_size);
+    t->owned = false;
+    return &t->tex;
+}
+
+void pl_tex_destroy(pl_gpu gpu, pl_tex *tex)
+{
+    if (!tex || !*tex)
+        return;
+    struct tex_priv *t = TEX_PRIV(*tex);
+    if (t->owned) {
+        // the allocation may still be referenced by queued work
+        plh_stream_sync(GPU_PRIV(gpu)->stream);
+        plh_free(t->ptr);
+    }
+    free(t);
+    *tex = NULL;
+}
+
+static bool tex_params_compat(const struct pl_tex_params *a, const struct pl_tex_params *b)
+{
+    return a->w == b->w && a->h == b->h && a->d == b->d && a->format == b->format &&
+           a->sampleable == b->sampleable && a->renderable == b->renderable &&
+           a->storable == b->storable && a->blit_src == b->blit_src &&
+           a->blit_dst == b->blit_dst && a->host_writable == b->host_writable &&
+           a->host_readable == b->host_readable;
+}
+
+bool pl_tex_recreate(pl_gpu gpu, pl_tex *tex, const struct pl_tex_params *params)
+{
+    if (params->initial_data) {
+        pl_msg(gpu->log, PL_LOG_ERR, "pl_tex_recreate may not be used with `initial_data`!");
+        return false;
+    }
+    if (*tex && tex_params_compat(&(*tex)->params, params)) {
+        pl_tex_invalidate(gpu, *tex);
+        return true;
+    }
+    pl_tex_destroy(gpu, tex);
+    *tex = pl_tex_create(gpu, params);
+    return !!*tex;
+}
+
+void pl_tex_invalidate(pl_gpu gpu, pl_tex tex)
+{
+    (void) gpu; (void) tex; // contents become undefined: nothing to do
+}
+
+void plh_tex_view(pl_tex tex, struct plh_view *out)
+{
+    const struct tex_priv *t = TEX_PRIV(tex);
+    *out = (struct plh_view) {
+        .ptr = t->ptr, .w = tex->params.w, .h = PL_MAX(tex->params.h, 1),
+        .pitch = (int32_t) t->pitch, .fmt = t->plh_fmt,
+    };
+}
+
+void *pl_hip_tex_ptr(pl_tex tex, size_t *out_row_pitch)
+{
+    const struct tex_priv *t = TEX_PRIV(tex);
+    if (out_row_pitch)
+        *out_row_pitch = t->pitch;
+    return t->ptr;
+}
+
+void pl_tex_clear_ex(pl_gpu gpu, pl_tex dst, const union pl_clear_color color)
+{
+    struct plh_view v;
+    plh_tex_view(dst, &v);
+    const int err = plh_launch_clear(GPU_PRIV(gpu)->stream, &v, color.f);
+    if (err)
+        pl_msg(gpu->log, PL_LOG_ERR, "pl_tex_clear: %s", plh_strerror(err));
+}
+
+void pl_tex_clear(pl_gpu gpu, pl_tex dst, const float color[4])
+{
+    union pl_clear_color c;
+    memcpy(c.f, color, sizeof(c.f));
+    pl_tex_clear_ex(gpu, dst, c);
+}
+
+static bool tex_transfer(pl_gpu gpu, const struct pl_tex_transfer_params *params, bool upload)
+{
+    struct gpu_priv *g = GPU_PRIV(gpu);
+    pl_tex tex = params->tex;
+    if (!tex || (!params->ptr && !params->buf)) {
+        pl_msg(gpu->log, PL_LOG_ERR, "pl_tex_%s: missing tex or ptr/buf",
+               upload ? "upload" : "download");
+        return false;
+    }
+    if (upload ? !tex->params.host_writable : !tex->params.host_readable) {
+        pl_msg(gpu->log, PL_LOG_ERR, "pl_tex_%s: texture lacks host_%s",
+               upload ? "upload" : "download", upload ? "writable" : "readable");
+        return false;
+    }
+
+    const struct tex_priv *t = TEX_PRIV(tex);
+    pl_rect3d rc = params->rc;
+    if (!rc.x0 && !rc.x1) rc.x1 = tex->params.w;
+    if (!rc.y0 && !rc.y1) rc.y1 = PL_MAX(tex->params.h, 1);
+    if (rc.x0 < 0 || rc.y0 < 0 || rc.x1 > tex->params.w || rc.y1 > PL_MAX(tex->params.h, 1) ||
+        rc.x1 <= rc.x0 || rc.y1 <= rc.y0) {
+        pl_msg(gpu->log, PL_LOG_ERR, "pl_tex_%s: invalid rect", upload ? "upload" : "download");
+        return false;
+    }
+
+    const size_t tsz = tex->params.format->texel_size;
+    const size_t row_bytes = (size_t) (rc.x1 - rc.x0) * tsz;
+    const size_t rows = rc.y1 - rc.y0;
+    const size_t host_pitch = PL_DEF(params->row_pitch, row_bytes);
+    uint8_t *dev = (uint8_t *) t->ptr + (size_t) rc.y0 * t->pitch + (size_t) rc.x0 * tsz;
+
+    if (params->timer)
+        plh_timer_begin(gpu, params->timer);
+
+    int err;
+    if (params->buf) {
+        uint8_t *bptr = (uint8_t *) BUF_PRIV(params->buf)->ptr + params->buf_offset;
+        err = upload ? plh_copy2d_d2d(g->stream, dev, t->pitch, bptr, host_pitch, row_bytes, rows)
+                     : plh_copy2d_d2d(g->stream, bptr, host_pitch, dev, t->pitch, row_bytes, rows);
+    } else {
+        err = upload ? plh_copy2d_h2d(g->stream, dev, t->pitch, params->ptr, host_pitch, row_bytes, rows)
+                     : plh_copy2d_d2h(g->stream, params->ptr, host_pitch, dev, t->pitch, row_bytes, rows);
+        // pageable host memory: the reference's contract is that `ptr` may be
+        // reused / is filled when the call returns (gpu.h, no callback given)
+        if (!err && !params->callback)
+            err = plh_stream_sync(g->stream);
+    }
+
+    if (params->timer)
+        plh_timer_end(gpu, params->timer);
+
+    if (err) {
+        pl_msg(gpu->log, PL_LOG_ERR, "pl_tex_%s: %s", upload ? "upload" : "download",
+               plh_strerror(err));
+        g->failed = true;
+        return false;
+    }
+    if (params->callback) {
+        plh_stream_sync(g->stream);
+        params->callback(params->priv);
+    }
+    return true;
+}
+
+bool pl_tex_upload(pl_gpu gpu, const struct pl_tex_transfer_params *params)
+{
+    return tex_transfer(gpu, params, true);
+}
+
+bool pl_tex_download(pl_gpu gpu, const struct pl_tex_transfer_params *params)
+{
+    return tex_transfer(gpu, params, false);
+}
+
+bool pl_tex_poll(pl_gpu gpu, pl_tex tex, uint64_t timeout)
+{
+    (void) tex;
+    // single in-order stream: a texture is busy iff the stream is
+    if (timeout)
+        pl_gpu_finish(gpu);
+    return false;
+}
+
+/* ------------------------------------------------------------------------ */
+/* buffers                                                                   */
+
+pl_buf pl_buf_create(pl_gpu gpu, const struct pl_buf_params *params)
+{
+    struct gpu_priv *g = GPU_PRIV(gpu);
+    if (!params->size) {
+        pl_msg(gpu->log, PL_LOG_ERR, "pl_buf_create: size must be > 0");
+        return NULL;
+    }
+    struct buf_priv *b = calloc(1, sizeof(*b));
+    if (!b)
+        return NULL;
+    b->buf.params = *params;
+    b->buf.params.initial_data = NULL;
+    b->ptr = plh_malloc(g->device, params->size);
+    if (!b->ptr) {
+        pl_msg(gpu->log, PL_LOG_ERR, "pl_buf_create: out of device memory");
+        free(b);
+        return NULL;
+    }
+    if (params->initial_data) {
+        plh_copy2d_h2d(g->stream, b->ptr, params->size, params->initial_data, params->size,
+                       params->size, 1);
+        plh_stream_sync(g->stream);
+    }
+    return &b->buf;
+}
+
+void pl_buf_destroy(pl_gpu gpu, pl_buf *buf)
+{
+    if (!buf || !*buf)
+        return;
+    plh_stream_sync(GPU_PRIV(gpu)->stream);
+    plh_free(BUF_PRIV(*buf)->ptr);
+    free(BUF_PRIV(*buf));
+    *buf = NULL;
+}
+
+bool pl_buf_recreate(pl_gpu gpu, pl_buf *buf, const struct pl_buf_params *params)
+{
+    if (*buf && (*buf)->params.size == params->size && !params->initial_data)
+        return true;
+    pl_buf_destroy(gpu, buf);
+    *buf = pl_buf_create(gpu, params);
+    return !!*buf;
+}
+
+void *pl_hip_buf_ptr(pl_buf buf)
+{
+    return BUF_PRIV(buf)->ptr;
+}
+
+void pl_buf_write(pl_gpu gpu, pl_buf buf, size_t buf_offset, const void *data, size_t size)
+{
+    struct gpu_priv *g = GPU_PRIV(gpu);
+    if (buf_offset + size > buf->params.size) {
+        pl_msg(gpu->log, PL_LOG_ERR, "pl_buf_write: out of range");
+        return;
+    }
+    plh_copy2d_h2d(g->stream, (uint8_t *) BUF_PRIV(buf)->ptr + buf_offset, size, data, size, size, 1);
+    plh_stream_sync(g->stream);
+}
+
+bool pl_buf_read(pl_gpu gpu, pl_buf buf, size_t buf_offset, void *dest, size_t size)
+{
+    struct gpu_priv *g = GPU_PRIV(gpu);
+    if (buf_offset + size > buf->params.size) {
+        pl_msg(gpu->log, PL_LOG_ERR, "pl_buf_read: out of range");
+        return false;
+    }
+    int err = plh_copy2d_d2h(g->stream, dest, size, (uint8_t *) BUF_PRIV(buf)->ptr + buf_offset,
+                             size, size, 1);
+    err = err ? err : plh_stream_sync(g->stream);
+    return !err;
+}
+
+void pl_buf_copy(pl_gpu gpu, pl_buf dst, size_t dst_offset, pl_buf src, size_t src_offset, size_t size)
+{
+    plh_copy2d_d2d(GPU_PRIV(gpu)->stream, (uint8_t *) BUF_PRIV(dst)->ptr + dst_offset, size,
+                   (uint8_t *) BUF_PRIV(src)->ptr + src_offset, size, size, 1);
+}
+
+bool pl_buf_poll(pl_gpu gpu, pl_buf buf, uint64_t timeout)
+{
+    (void) buf;
+    if (timeout)
+        pl_gpu_finish(gpu);
+    return false;
+}
+
+/* ------------------------------------------------------------------------ */
+/* timers: ring of hipEvent pairs                                            */
+
+pl_timer pl_timer_create(pl_gpu gpu)
+{
+    (void) gpu;
+    struct pl_timer_t *t = calloc(1, sizeof(*t));
+    if (!t)
+        return NULL;
+    for (int i = 0; i < PLH_TIMER_RING; i++) {
+        if (plh_event_create(&t->start[i]) || plh_event_create(&t->stop[i])) {
+            pl_timer_destroy(gpu, &t);
+            return NULL;
+        }
+    }
+    return t;
+}
+
+void pl_timer_destroy(pl_gpu gpu, pl_timer *timer)
+{
+    (void) gpu;
+    if (!timer || !*timer)
+        return;
+    for (int i = 0; i < PLH_TIMER_RING; i++) {
+        plh_event_destroy((*timer)->start[i]);
+        plh_event_destroy((*timer)->stop[i]);
+    }
+    free(*timer);
+    *timer = NULL;
+}
+
+void plh_timer_begin(pl_gpu gpu, pl_timer t)
+{
+    if (t->head - t->tail >= PLH_TIMER_RING)
+        t->tail++; // drop the oldest sample
+    plh_event_record(t->start[t->head % PLH_TIMER_RING], GPU_PRIV(gpu)->stream);
+}
+
+void plh_timer_end(pl_gpu gpu, pl_timer t)
+{
+    plh_event_record(t->stop[t->head % PLH_TIMER_RING], GPU_PRIV(gpu)->stream);
+    t->head++;
+}
+
+uint64_t pl_timer_query(pl_gpu gpu, pl_timer t)
+{
+    (void) gpu;
+    if (!t || t->tail == t->head)
+        return 0;
+    const int i = t->tail % PLH_TIMER_RING;
+    if (plh_event_query(t->stop[i]) != 1)
+        return 0;
+    uint64_t ns = 0;
+    plh_event_elapsed_ns(t->start[i], t->stop[i], &ns);
+    t->tail++;
+    return PL_MAX(ns, 1);
+}

@@ -1,0 +1,63 @@
+/*
+ * libplacebo-hip — private object layouts behind pl_gpu / pl_tex / pl_buf /
+ * pl_timer. Public struct first, private fields after (the reference uses the
+ * same "public + PL_PRIV" trick, src/pl_alloc.h:84-97).
+ */
+#ifndef PLH_GPU_PRIV_H_
+#define PLH_GPU_PRIV_H_
+
+#include <libplacebo/gpu.h>
+#include <libplacebo/hip.h>
+
+#include "host_common.h"
+#include "../hip/backend.h"
+
+struct fmt_priv {
+    struct pl_fmt_t pub;
+    int plh;            // enum plh_fmt
+};
+
+struct gpu_priv {
+    struct pl_gpu_t gpu;
+    struct pl_hip_t hip;
+    struct plh_dev_info info;
+    int device;
+    plh_stream stream;
+    bool own_stream;
+    bool failed;
+    pl_fmt fmts[16];
+};
+
+struct tex_priv {
+    struct pl_tex_t tex;
+    pl_gpu gpu;
+    void *ptr;
+    size_t pitch;
+    int plh_fmt;
+    bool owned;
+};
+
+struct buf_priv {
+    struct pl_buf_t buf;
+    void *ptr;
+};
+
+#define PLH_TIMER_RING 16
+struct pl_timer_t {
+    plh_event start[PLH_TIMER_RING], stop[PLH_TIMER_RING];
+    unsigned head, tail;
+};
+
+#define GPU_PRIV(g)  ((struct gpu_priv *) (g))
+#define TEX_PRIV(t)  ((struct tex_priv *) (t))
+#define BUF_PRIV(b)  ((struct buf_priv *) (b))
+#define FMT_PRIV(f)  ((const struct fmt_priv *) (f))
+
+void plh_tex_view(pl_tex tex, struct plh_view *out);
+void plh_timer_begin(pl_gpu gpu, pl_timer t);
+void plh_timer_end(pl_gpu gpu, pl_timer t);
+
+static inline plh_stream plh_gpu_stream(pl_gpu gpu) { return GPU_PRIV(gpu)->stream; }
+static inline int plh_gpu_device(pl_gpu gpu) { return GPU_PRIV(gpu)->device; }
+
+#endif // PLH_GPU_PRIV_H_

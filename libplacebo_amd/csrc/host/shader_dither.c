@@ -1,0 +1,173 @@
+/*
+ * libplacebo-hip — dithering stages: host half of src/shaders/dithering.c.
+ *   pl_shader_dither            dithering.c:109-274
+ *   pl_shader_error_diffusion   dithering.c:326-527 (see k_errdiff.hip)
+ */
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <libplacebo/shaders/dithering.h>
+
+#include "shaders_priv.h"
+
+const struct pl_dither_params pl_dither_default_params = { PL_DITHER_DEFAULTS };
+
+struct sh_dither_obj {
+    pl_buf lut;
+    int size;
+    enum pl_dither_method method;
+};
+
+static void sh_dither_uninit(pl_gpu gpu, void *ptr)
+{
+    struct sh_dither_obj *obj = ptr;
+    pl_buf_destroy(gpu, &obj->lut);
+    memset(obj, 0, sizeof(*obj));
+}
+
+// Representative gamma of a transfer curve (approx_gamma, dithering.c:77-107)
+static float approx_gamma(enum pl_color_transfer trc)
+{
+    switch (trc) {
+    case PL_COLOR_TRC_UNKNOWN:
+    case PL_COLOR_TRC_LINEAR:
+    case PL_COLOR_TRC_SCRGB:    return 1.0f;
+    case PL_COLOR_TRC_PRO_PHOTO:
+    case PL_COLOR_TRC_GAMMA18:  return 1.8f;
+    case PL_COLOR_TRC_GAMMA20:  return 2.0f;
+    case PL_COLOR_TRC_GAMMA24:  return 2.4f;
+    case PL_COLOR_TRC_GAMMA26:
+    case PL_COLOR_TRC_ST428:    return 2.6f;
+    case PL_COLOR_TRC_GAMMA28:  return 2.8f;
+    case PL_COLOR_TRC_SRGB:
+    case PL_COLOR_TRC_BT_1886:
+    case PL_COLOR_TRC_GAMMA22:  return 2.2f;
+    case PL_COLOR_TRC_PQ:
+    case PL_COLOR_TRC_HLG:
+    case PL_COLOR_TRC_V_LOG:
+    case PL_COLOR_TRC_S_LOG1:
+    case PL_COLOR_TRC_S_LOG2:   return 2.0f;
+    case PL_COLOR_TRC_COUNT:    break;
+    }
+    return 1.0f;
+}
+
+void pl_shader_dither(pl_shader sh, int new_depth, pl_shader_obj *dither_state,
+                      const struct pl_dither_params *params)
+{
+    if (!sh_require(sh, PL_SHADER_SIG_COLOR, 0, 0))
+        return;
+
+    if (new_depth <= 0 || new_depth > 256) {
+        pl_msg(sh->log, PL_LOG_WARN, "Invalid dither depth: %d.. ignoring", new_depth);
+        return;
+    }
+
+    params = PL_DEF(params, &pl_dither_default_params);
+    if (params->lut_size < 0 || params->lut_size > 8) {
+        SH_FAIL(sh, "Invalid `lut_size` specified: %d", params->lut_size);
+        return;
+    }
+
+    sh_describef(sh, "dithering (%d bits)", new_depth);
+    enum pl_dither_method method = params->method;
+    const bool is_lut = method == PL_DITHER_BLUE_NOISE || method == PL_DITHER_ORDERED_LUT;
+    struct sh_dither_obj *obj = NULL;
+    int lut_size = 0;
+
+    if (is_lut && !dither_state) {
+        pl_msg(sh->log, PL_LOG_WARN, "LUT-based dither method specified but no dither "
+               "state object given, falling back to non-LUT based methods.");
+        method = PL_DITHER_ORDERED_FIXED;
+    } else if (is_lut) {
+        obj = SH_OBJ(sh, dither_state, PL_SHADER_OBJ_DITHER, struct sh_dither_obj,
+                     sh_dither_uninit);
+        lut_size = 1 << PL_DEF(params->lut_size, pl_dither_default_params.lut_size);
+        if (obj && (!obj->lut || obj->size != lut_size || obj->method != method)) {
+            float *mat = malloc(sizeof(float) * lut_size * lut_size);
+            if (!mat)
+                return;
+            if (method == PL_DITHER_ORDERED_LUT) {
+                pl_generate_bayer_matrix(mat, lut_size);
+            } else {
+                pl_generate_blue_noise(mat, lut_size);
+            }
+            pl_buf_destroy(SH_GPU(sh), &obj->lut);
+            obj->lut = pl_buf_create(SH_GPU(sh), pl_buf_params(
+                .size = sizeof(float) * lut_size * lut_size, .storable = true,
+                .initial_data = mat));
+            free(mat);
+            obj->size = lut_size;
+            obj->method = method;
+        }
+        if (!obj || !obj->lut) {
+            obj = NULL;
+            method = PL_DITHER_ORDERED_FIXED; // the reference's fallback (:168-170)
+        }
+    }
+
+    if (method == PL_DITHER_WHITE_NOISE) {
+        SH_FAIL(sh, "PL_DITHER_WHITE_NOISE is not supported by the HIP backend yet");
+        return;
+    }
+
+    const int size = obj ? lut_size : 16;
+    struct plh_op *op = sh_op(sh, PLH_OP_DITHER);
+    if (!op)
+        return;
+    op->i0 = size;
+    op->i1 = obj ? 0 : 1;   // 0 = LUT, 1 = ordered-fixed bit tricks
+    op->i2 = params->temporal;
+    op->f[0] = (float) ((1LLU << new_depth) - 1);
+    op->f[1] = approx_gamma(params->transfer);
+    op->f[2] = 1.0f / (float) size;     // GLSL constant expression `1.0/size`
+    op->f[3] = new_depth;
+    op->f[8] = 1.0f / op->f[0];         // GLSL constant expression `1.0 / scale`
+    if (params->temporal) {
+        const int phase = sh->params.index % 8;
+        const float r = phase * (M_PI / 2);
+        const float m = phase < 4 ? 1 : -1;
+        // the reference uploads mat[2][2] = {{cos r, -sin r}, {sin r * m, cos r * m}}
+        // as a column-major mat2: column 0 = (cos r, -sin r), column 1 = (sin r*m, cos r*m)
+        // => (rot * pos).x = c0.x*pos.x + c1.x*pos.y, .y = c0.y*pos.x + c1.y*pos.y
+        op->f[4] = cos(r);  op->f[5] = sin(r) * m;
+        op->f[6] = -sin(r); op->f[7] = cos(r) * m;
+    }
+    if (obj) {
+        op->ptr = pl_hip_buf_ptr(obj->lut);
+        sh_hold(sh, *dither_state);
+    }
+    sh_listf(sh, "dither(depth=%d, method=%d, size=%d, gamma=%g, temporal=%d)\n",
+             new_depth, (int) method, size, op->f[1], (int) params->temporal);
+}
+
+// Right-most column (after the (y, x) -> (y, x + y*shift) skew) that the
+// current column spills error into (dithering.c:294-311)
+static int rightmost_shifted_column(const struct pl_error_diffusion_kernel *k)
+{
+    int ret = 0;
+    for (int y = 0; y <= PL_EDF_MAX_DY; y++) {
+        for (int x = PL_EDF_MIN_DX; x <= PL_EDF_MAX_DX; x++) {
+            if (k->pattern[y][x - PL_EDF_MIN_DX])
+                ret = PL_MAX(ret, x + y * k->shift);
+        }
+    }
+    return ret;
+}
+
+size_t pl_error_diffusion_shmem_req(const struct pl_error_diffusion_kernel *kernel, int height)
+{
+    // ring buffer: (height + MAX_DY) rows x (rightmost + 1) columns of one
+    // packed-RGB uint each (dithering.c:313-324)
+    const int rows = height + PL_EDF_MAX_DY;
+    const int cols = rightmost_shifted_column(kernel) + 1;
+    return (size_t) rows * cols * sizeof(uint32_t);
+}
+
+bool pl_shader_error_diffusion(pl_shader sh, const struct pl_error_diffusion_params *params)
+{
+    (void) params;
+    SH_FAIL(sh, "pl_shader_error_diffusion: not implemented yet");
+    return false;
+}

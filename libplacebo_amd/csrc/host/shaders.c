@@ -1,0 +1,285 @@
+/*
+ * libplacebo-hip — pl_shader core: lifetime, signature tracking, persistent
+ * objects. Counterpart of the reference's src/shaders.c (pl_shader_alloc :35,
+ * pl_shader_reset :91, sh_try_compute :214, sh_bind :513, sh_require :864,
+ * object ref-counting :909-963) with GLSL text replaced by typed ops.
+ */
+#include <stdarg.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "shaders_priv.h"
+
+static void sh_release(pl_shader sh)
+{
+    for (int i = 0; i < sh->num_held; i++)
+        pl_shader_obj_destroy(&sh->held[i]);
+    sh->num_held = 0;
+    free(sh->errdiff);
+    sh->errdiff = NULL;
+}
+
+pl_shader pl_shader_alloc(pl_log log, const struct pl_shader_params *params)
+{
+    struct pl_shader_t *sh = calloc(1, sizeof(*sh));
+    if (!sh)
+        return NULL;
+    sh->log = log;
+    pl_shader_reset(sh, params);
+    return sh;
+}
+
+void pl_shader_free(pl_shader *psh)
+{
+    pl_shader sh = psh ? *psh : NULL;
+    if (!sh)
+        return;
+    sh_release(sh);
+    free(sh->listing);
+    free(sh);
+    *psh = NULL;
+}
+
+void pl_shader_reset(pl_shader sh, const struct pl_shader_params *params)
+{
+    sh_release(sh);
+    pl_log log = sh->log;
+    char *listing = sh->listing;
+    const size_t cap = sh->listing_cap;
+    memset(sh, 0, sizeof(*sh));
+    sh->log = log;
+    sh->listing = listing;
+    sh->listing_cap = cap;
+    if (listing)
+        listing[0] = '\0';
+    sh->mutable_ = true;
+    if (params)
+        sh->params = *params;
+}
+
+bool pl_shader_is_failed(const pl_shader sh) { return sh->failed; }
+bool pl_shader_is_compute(const pl_shader sh) { return sh->is_compute; }
+
+bool pl_shader_output_size(const pl_shader sh, int *w, int *h)
+{
+    if (!sh->output_w || !sh->output_h)
+        return false;
+    *w = sh->transpose ? sh->output_h : sh->output_w;
+    *h = sh->transpose ? sh->output_w : sh->output_h;
+    return true;
+}
+
+bool sh_require(pl_shader sh, enum pl_shader_sig insig, int w, int h)
+{
+    if (sh->failed) {
+        SH_FAIL(sh, "Attempting to modify a failed shader!");
+        return false;
+    }
+    if (!sh->mutable_) {
+        SH_FAIL(sh, "Attempted to modify an immutable shader!");
+        return false;
+    }
+    if ((w && sh->output_w && sh->output_w != w) ||
+        (h && sh->output_h && sh->output_h != h)) {
+        SH_FAIL(sh, "Illegal sequence of shader operations: Incompatible output "
+                "size requirements %dx%d and %dx%d", sh->output_w, sh->output_h, w, h);
+        return false;
+    }
+
+    static const char *names[] = { "PL_SHADER_SIG_NONE", "PL_SHADER_SIG_COLOR",
+                                   "PL_SHADER_SIG_SAMPLER" };
+    if (!sh->output && insig) {
+        // nothing produced a colour yet: it becomes an explicit input
+        sh->input = insig;
+    } else if (sh->output != insig) {
+        SH_FAIL(sh, "Illegal sequence of shader operations! Current output signature "
+                "is '%s', but called operation expects '%s'!",
+                names[sh->output], names[insig]);
+        return false;
+    }
+
+    sh->output = PL_SHADER_SIG_COLOR;
+    sh->output_w = PL_DEF(sh->output_w, w);
+    sh->output_h = PL_DEF(sh->output_h, h);
+    return true;
+}
+
+bool sh_try_compute(pl_shader sh, int bw, int bh, bool flex, size_t mem)
+{
+    (void) flex;
+    const struct pl_glsl_version glsl = sh_glsl(sh);
+    if (!glsl.compute || sh->shmem + mem > glsl.max_shmem_size)
+        return false;
+    sh->shmem += mem;
+    sh->group_size[0] = bw;
+    sh->group_size[1] = bh;
+    sh->is_compute = true;
+    return true;
+}
+
+void sh_describef(pl_shader sh, const char *fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(sh->description, sizeof(sh->description), fmt, ap);
+    va_end(ap);
+}
+
+void sh_listf(pl_shader sh, const char *fmt, ...)
+{
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    const int n = vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    if (n <= 0)
+        return;
+    const size_t add = PL_MIN((size_t) n, sizeof(buf) - 1);
+    if (sh->listing_len + add + 1 > sh->listing_cap) {
+        const size_t cap = PL_MAX(sh->listing_cap * 2, sh->listing_len + add + 256);
+        char *nl = realloc(sh->listing, cap);
+        if (!nl)
+            return;
+        sh->listing = nl;
+        sh->listing_cap = cap;
+    }
+    memcpy(sh->listing + sh->listing_len, buf, add + 1);
+    sh->listing_len += add;
+}
+
+struct plh_op *sh_op(pl_shader sh, int kind)
+{
+    if (sh->pass.num_ops >= PLH_MAX_OPS) {
+        SH_FAIL(sh, "Too many colour stages in one shader (max %d)", PLH_MAX_OPS);
+        return NULL;
+    }
+    struct plh_op *op = &sh->pass.ops[sh->pass.num_ops++];
+    memset(op, 0, sizeof(*op));
+    op->kind = kind;
+    return op;
+}
+
+const struct pl_shader_res *pl_shader_finalize(pl_shader sh)
+{
+    if (sh->failed)
+        return NULL;
+    if (!sh->mutable_)
+        return &sh->res;
+    sh->res = (struct pl_shader_res) {
+        .glsl = sh->listing ? sh->listing : "",
+        .name = "main",
+        .description = sh->description[0] ? sh->description : "(unknown shader)",
+        .input = sh->input,
+        .output = sh->output,
+        .compute_group_size = { sh->group_size[0], sh->group_size[1] },
+        .compute_shmem = sh->shmem,
+        .num_ops = sh->pass.num_ops,
+    };
+    sh->mutable_ = false;
+    return &sh->res;
+}
+
+/* ------------------------------------------------------------------------ */
+/* persistent objects                                                        */
+
+void pl_shader_obj_destroy(pl_shader_obj *ptr)
+{
+    pl_shader_obj obj = ptr ? *ptr : NULL;
+    if (!obj)
+        return;
+    *ptr = NULL;
+    if (--obj->refcount > 0)
+        return;
+    if (obj->uninit)
+        obj->uninit(obj->gpu, obj->priv);
+    free(obj->priv);
+    free(obj);
+}
+
+void *sh_require_obj(pl_shader sh, pl_shader_obj *ptr, enum pl_shader_obj_type type,
+                     size_t priv_size, void (*uninit)(pl_gpu gpu, void *priv))
+{
+    if (!ptr)
+        return NULL;
+
+    pl_shader_obj obj = *ptr;
+    if (obj && obj->gpu != SH_GPU(sh)) {
+        SH_FAIL(sh, "Passed pl_shader_obj belongs to different GPU!");
+        return NULL;
+    }
+    if (obj && obj->type != type) {
+        SH_FAIL(sh, "Passed pl_shader_obj of wrong type! Shader objects must "
+                "always be used with the same type of shader.");
+        return NULL;
+    }
+    if (!obj) {
+        obj = calloc(1, sizeof(*obj));
+        if (!obj)
+            return NULL;
+        obj->refcount = 1;
+        obj->gpu = SH_GPU(sh);
+        obj->type = type;
+        obj->priv = calloc(1, priv_size);
+        obj->uninit = uninit;
+        if (!obj->priv) {
+            free(obj);
+            return NULL;
+        }
+    }
+    *ptr = obj;
+    return obj->priv;
+}
+
+void sh_hold(pl_shader sh, pl_shader_obj obj)
+{
+    if (!obj || sh->num_held >= (int) PL_ARRAY_SIZE(sh->held))
+        return;
+    for (int i = 0; i < sh->num_held; i++) {
+        if (sh->held[i] == obj)
+            return;
+    }
+    obj->refcount++;
+    sh->held[sh->num_held++] = obj;
+}
+
+/* ------------------------------------------------------------------------ */
+
+bool sh_bind(pl_shader sh, pl_tex tex, enum pl_tex_address_mode address_mode,
+             const pl_rect2df *rect)
+{
+    if (pl_tex_params_dimension(tex->params) != 2) {
+        SH_FAIL(sh, "Failed binding texture: not a 2D texture!");
+        return false;
+    }
+    if (!tex->params.sampleable) {
+        SH_FAIL(sh, "Failed binding texture: texture not sampleable!");
+        return false;
+    }
+
+    struct plh_sampler_args *s = &sh->pass.s;
+    plh_tex_view(tex, &s->src);
+    s->address_mode = address_mode;
+
+    // vertex attribute tex_coord = rect / tex_size at the 4 corners, in the
+    // reference's order {x0,y0}, {x1,y0}, {x0,y1}, {x1,y1} (shaders.c:497-502)
+    const float sx = 1.0 / tex->params.w, sy = 1.0 / tex->params.h;
+    const pl_rect2df full = { .x1 = tex->params.w, .y1 = tex->params.h };
+    rect = PL_DEF(rect, &full);
+    const float x0 = sx * rect->x0, y0 = sy * rect->y0,
+                x1 = sx * rect->x1, y1 = sy * rect->y1;
+    s->pos[0][0] = x0; s->pos[0][1] = y0;
+    s->pos[1][0] = x1; s->pos[1][1] = y0;
+    s->pos[2][0] = x0; s->pos[2][1] = y1;
+    s->pos[3][0] = x1; s->pos[3][1] = y1;
+    s->pt[0] = sx;
+    s->pt[1] = sy;
+    return true;
+}
+
+float plh_fmtf(double v)
+{
+    char buf[64];
+    snprintf(buf, sizeof(buf), "%f", v);
+    return strtof(buf, NULL);
+}

@@ -1,0 +1,102 @@
+/*
+ * libplacebo-hip — internals of the op-recording pl_shader.
+ * Counterpart of the reference's src/shaders.h (struct pl_shader_t :85-119,
+ * pl_shader_obj_t :147-160, SH_OBJ :175-180).
+ */
+#ifndef PLH_SHADERS_PRIV_H_
+#define PLH_SHADERS_PRIV_H_
+
+#include <libplacebo/shaders.h>
+#include <libplacebo/colorspace.h>
+
+#include "gpu_priv.h"
+
+enum pl_shader_obj_type {
+    PL_SHADER_OBJ_INVALID = 0,
+    PL_SHADER_OBJ_COLOR_MAP,
+    PL_SHADER_OBJ_SAMPLER,
+    PL_SHADER_OBJ_DITHER,
+    PL_SHADER_OBJ_LUT,
+};
+
+struct pl_shader_obj_t {
+    int refcount;
+    enum pl_shader_obj_type type;
+    pl_gpu gpu;
+    void (*uninit)(pl_gpu gpu, void *priv);
+    void *priv;
+};
+
+enum plh_shader_kind {
+    PLH_SHADER_PASS = 0,        // sampler + colour ops -> plh_launch_pass
+    PLH_SHADER_ERROR_DIFFUSION, // standalone compute (pl_dispatch_compute)
+};
+
+struct plh_errdiff_args;
+
+struct pl_shader_t {
+    pl_log log;
+    struct pl_shader_params params;
+    bool failed;
+    bool mutable_;
+    enum pl_shader_sig input, output;
+    int output_w, output_h;
+    bool transpose;
+    bool is_compute;
+    int group_size[2];
+    size_t shmem;
+
+    enum plh_shader_kind kind;
+    struct plh_pass pass;
+    // persistent objects whose device memory the recorded pass points at
+    pl_shader_obj held[16];
+    int num_held;
+    // peak detection request (K10), resolved by dispatch
+    bool detect_peak;
+
+    char description[256];
+    char *listing;
+    size_t listing_len, listing_cap;
+    struct pl_shader_res res;
+
+    struct plh_errdiff_args *errdiff;
+};
+
+#define SH_GPU(sh) ((sh)->params.gpu)
+
+#define SH_FAIL(sh, ...) do {                       \
+        (sh)->failed = true;                        \
+        pl_msg((sh)->log, PL_LOG_ERR, __VA_ARGS__); \
+    } while (0)
+
+static inline struct pl_glsl_version sh_glsl(const pl_shader sh)
+{
+    return SH_GPU(sh) ? SH_GPU(sh)->glsl : sh->params.glsl;
+}
+
+bool sh_require(pl_shader sh, enum pl_shader_sig insig, int w, int h);
+bool sh_try_compute(pl_shader sh, int bw, int bh, bool flex, size_t mem);
+void sh_describef(pl_shader sh, const char *fmt, ...) __attribute__((format(printf, 2, 3)));
+void sh_listf(pl_shader sh, const char *fmt, ...) __attribute__((format(printf, 2, 3)));
+
+// append a colour op; returns NULL (and fails the shader) if the chain is full
+struct plh_op *sh_op(pl_shader sh, int kind);
+
+void *sh_require_obj(pl_shader sh, pl_shader_obj *ptr, enum pl_shader_obj_type type,
+                     size_t priv_size, void (*uninit)(pl_gpu gpu, void *priv));
+#define SH_OBJ(sh, ptr, type, t, uninit) \
+    ((t *) sh_require_obj(sh, ptr, type, sizeof(t), uninit))
+
+// keep `obj` alive until the shader has been dispatched / reset
+void sh_hold(pl_shader sh, pl_shader_obj obj);
+
+// Bind a texture for sampling: fills src view + tex_coord corners + pt
+// (sh_bind, src/shaders.c:513-571)
+bool sh_bind(pl_shader sh, pl_tex tex, enum pl_tex_address_mode address_mode,
+             const pl_rect2df *rect);
+
+// The value the reference would embed for a constant printed with "%f"
+// (6 decimals), e.g. the PQ constants in shaders/colorspace.c
+float plh_fmtf(double v);
+
+#endif // PLH_SHADERS_PRIV_H_

@@ -1,0 +1,764 @@
+/*
+ * TEST INFRASTRUCTURE ONLY — CPU oracle for the pl_render_image hot path.
+ *
+ * Plain scalar C restatement of the reference's algorithm (haasn/libplacebo
+ * v7.365.0), one function per GPU stage, each citing the reference file:line it
+ * follows. Nothing in the product (libplacebo_amd/, include/) includes, links
+ * or calls this file; only tests/, __graft_entry__.smoke() and bench.py's
+ * cpu_baseline leg load the resulting oracle/libploracle.so.
+ *
+ * Pinning status:
+ *   - Tier-0 restatements (filter sampling/LUT generation, PQ, ...) are checked
+ *     against the reference's own known-answer tests (src/tests/filters.c:16-75,
+ *     tone_mapping.c:14-23) and bit-for-bit against the real reference CPU code
+ *     built by oracle/build_ref.sh (oracle/_ref/libplref.so) in
+ *     tests/test_oracle_pinning.py.
+ *   - The per-pixel GPU stages (sampling, polar EWA, dither, colour ops) have NO
+ *     full-frame golden data in the reference (src/tests/gpu_tests.c:1216
+ *     "TODO: embed a reference texture") and the reference's Vulkan execution
+ *     cannot run here: for those stages parity is "unpinned" beyond the small
+ *     gpu_tests.c vectors restated in tests/; see DESIGN.md §Oracle.
+ *
+ * Float semantics. GLSL leaves contraction, mix() and texture filtering
+ * precision open; this file fixes them (same choices as csrc/hip/devmath.hiph,
+ * which is what makes HIP output bit-comparable for the transcendental-free
+ * stages):
+ *   mix(x,y,a) = fma(y, a, fma(-x, a, x));  fract(x) = x - floor(x)
+ *   length(v)  = sqrtf(v.x*v.x + v.y*v.y);  accumulate: a = fma(w, c, a)
+ *   hardware bilinear / linear LUT = exact fp32 lerp (lut.c:700-715 form)
+ *   x / const  = x * (1.0f / const) only where noted
+ * Compiled with -ffp-contract=off so nothing else fuses.
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+#define ORC_API __attribute__((visibility("default")))
+
+static inline float mixf(float x, float y, float a) { return fmaf(y, a, fmaf(-x, a, x)); }
+static inline float fractf(float x) { return x - floorf(x); }
+static inline float clampf(float x, float lo, float hi) { return fminf(fmaxf(x, lo), hi); }
+
+/* ======================================================================== */
+/* texel formats                                                             */
+
+enum { FMT_R8 = 1, FMT_RG8, FMT_RGBA8, FMT_R16, FMT_RG16, FMT_RGBA16,
+       FMT_R16F, FMT_RG16F, FMT_RGBA16F, FMT_R32F, FMT_RG32F, FMT_RGBA32F };
+
+static int fmt_comps(int fmt) { return ((fmt - 1) % 3) == 0 ? 1 : ((fmt - 1) % 3) == 1 ? 2 : 4; }
+static int fmt_class(int fmt) { return (fmt - 1) / 3; } // 0 u8, 1 u16, 2 f16, 3 f32
+
+// IEEE binary16 <-> binary32 (round-to-nearest-even), bit-level
+static float half_to_float(uint16_t h)
+{
+    const uint32_t sign = (uint32_t) (h & 0x8000) << 16;
+    uint32_t exp = (h >> 10) & 0x1f, man = h & 0x3ff, bits;
+    if (exp == 0) {
+        if (!man) {
+            bits = sign;
+        } else { // subnormal
+            int e = -1;
+            do { e++; man <<= 1; } while (!(man & 0x400));
+            bits = sign | ((uint32_t) (127 - 15 - e) << 23) | ((man & 0x3ff) << 13);
+        }
+    } else if (exp == 31) {
+        bits = sign | 0x7f800000u | (man << 13);
+    } else {
+        bits = sign | ((exp + 112) << 23) | (man << 13);
+    }
+    float f;
+    memcpy(&f, &bits, 4);
+    return f;
+}
+
+static uint16_t float_to_half(float f)
+{
+    uint32_t x;
+    memcpy(&x, &f, 4);
+    const uint16_t sign = (x >> 16) & 0x8000;
+    x &= 0x7fffffffu;
+    if (x >= 0x7f800000u) // inf / nan
+        return sign | 0x7c00 | (x > 0x7f800000u ? 0x200 | ((x >> 13) & 0x3ff) : 0);
+    if (x >= 0x477ff000u) // rounds to >= 65520 -> inf
+        return sign | 0x7c00;
+    if (x < 0x33000001u) // rounds to zero (<= 2^-25)
+        return sign;
+    int exp = (int) (x >> 23) - 127;
+    uint32_t man = (x & 0x7fffffu) | 0x800000u;
+    int shift;
+    uint16_t base;
+    if (exp < -14) { // subnormal half
+        shift = 13 + (-14 - exp);
+        base = 0;
+    } else {
+        shift = 13;
+        base = (uint16_t) ((exp + 15) << 10);
+        man &= 0x7fffffu;
+    }
+    uint32_t q = man >> shift;
+    const uint32_t rem = man & ((1u << shift) - 1), half = 1u << (shift - 1);
+    if (rem > half || (rem == half && (q & 1)))
+        q++;
+    return sign | (uint16_t) (base + q); // carry into exponent is correct by construction
+}
+
+ORC_API float orc_round_f16(float f) { return half_to_float(float_to_half(f)); }
+
+// Texture fetch of every texel -> float RGBA; missing components (0,0,0,1)
+ORC_API void orc_tex_decode(const void *src, int fmt, int w, int h, size_t pitch, float *out)
+{
+    const int nc = fmt_comps(fmt), cls = fmt_class(fmt);
+    for (int y = 0; y < h; y++) {
+        const uint8_t *row = (const uint8_t *) src + (size_t) y * pitch;
+        for (int x = 0; x < w; x++) {
+            float *o = out + ((size_t) y * w + x) * 4;
+            o[0] = o[1] = o[2] = 0.0f; o[3] = 1.0f;
+            for (int c = 0; c < nc; c++) {
+                const int i = x * nc + c;
+                switch (cls) {
+                case 0: o[c] = row[i] / 255.0f; break;
+                case 1: o[c] = ((const uint16_t *) row)[i] / 65535.0f; break;
+                case 2: o[c] = half_to_float(((const uint16_t *) row)[i]); break;
+                case 3: o[c] = ((const float *) row)[i]; break;
+                }
+            }
+        }
+    }
+}
+
+// Image store with the target format's conversion (unorm: clamp, scale, RNE)
+ORC_API void orc_tex_encode(const float *img, int w, int h, int fmt, void *dst, size_t pitch)
+{
+    const int nc = fmt_comps(fmt), cls = fmt_class(fmt);
+    for (int y = 0; y < h; y++) {
+        uint8_t *row = (uint8_t *) dst + (size_t) y * pitch;
+        for (int x = 0; x < w; x++) {
+            const float *p = img + ((size_t) y * w + x) * 4;
+            for (int c = 0; c < nc; c++) {
+                const int i = x * nc + c;
+                const float v = p[c];
+                switch (cls) {
+                case 0: row[i] = (uint8_t) rintf(fminf(fmaxf(v, 0.0f), 1.0f) * 255.0f); break;
+                case 1: ((uint16_t *) row)[i] = (uint16_t) rintf(fminf(fmaxf(v, 0.0f), 1.0f) * 65535.0f); break;
+                case 2: ((uint16_t *) row)[i] = float_to_half(v); break;
+                case 3: ((float *) row)[i] = v; break;
+                }
+            }
+        }
+    }
+}
+
+/* ======================================================================== */
+/* texture unit + vertex attribute emulation                                 */
+
+enum { ADDR_CLAMP = 0, ADDR_REPEAT, ADDR_MIRROR };
+
+struct orc_src {
+    const float *tex;   // decoded RGBA float texels
+    int w, h;
+    float rect[4];      // x0 y0 x1 y1 in texels (sh_bind `rect`)
+    int address_mode;
+};
+
+static int wrap(int i, int n, int mode)
+{
+    if (mode == ADDR_CLAMP)
+        return i < 0 ? 0 : i > n - 1 ? n - 1 : i;
+    if (mode == ADDR_REPEAT) {
+        int m = i % n;
+        return m < 0 ? m + n : m;
+    }
+    int m = i % (2 * n);
+    if (m < 0)
+        m += 2 * n;
+    return m < n ? m : 2 * n - 1 - m;
+}
+
+static const float *texel(const struct orc_src *s, int x, int y)
+{
+    return s->tex + ((size_t) wrap(y, s->h, s->address_mode) * s->w +
+                     wrap(x, s->w, s->address_mode)) * 4;
+}
+
+// tex_coord corners: rect / tex_size (sh_bind, src/shaders.c:541-561)
+static void corners(const struct orc_src *s, float p[4][2], float pt[2])
+{
+    const float sx = 1.0 / s->w, sy = 1.0 / s->h;
+    const float x0 = sx * s->rect[0], y0 = sy * s->rect[1];
+    const float x1 = sx * s->rect[2], y1 = sy * s->rect[3];
+    p[0][0] = x0; p[0][1] = y0;
+    p[1][0] = x1; p[1][1] = y0;
+    p[2][0] = x0; p[2][1] = y1;
+    p[3][0] = x1; p[3][1] = y1;
+    pt[0] = sx; pt[1] = sy;
+}
+
+// Compute-shader emulation of the interpolated attribute (dispatch.c:1038-1062)
+static float attr(const float p[4][2], int c, float fx, float fy)
+{
+    return mixf(mixf(p[0][c], p[1][c], fx), mixf(p[2][c], p[3][c], fx), fy);
+}
+
+static void tex_nearest(const struct orc_src *s, float px, float py, float out[4])
+{
+    const int ix = (int) floorf(px * (float) s->w), iy = (int) floorf(py * (float) s->h);
+    memcpy(out, texel(s, ix, iy), 16);
+}
+
+static void tex_linear(const struct orc_src *s, float px, float py, float out[4])
+{
+    const float u = px * (float) s->w - 0.5f, v = py * (float) s->h - 0.5f;
+    const float fu = floorf(u), fv = floorf(v);
+    const float ax = u - fu, ay = v - fv;
+    const float *t00 = texel(s, (int) fu, (int) fv), *t10 = texel(s, (int) fu + 1, (int) fv);
+    const float *t01 = texel(s, (int) fu, (int) fv + 1), *t11 = texel(s, (int) fu + 1, (int) fv + 1);
+    for (int c = 0; c < 4; c++)
+        out[c] = mixf(mixf(t00[c], t10[c], ax), mixf(t01[c], t11[c], ax), ay);
+}
+
+/* ======================================================================== */
+/* K1 / K5: single-fetch samplers (src/shaders/sampling.c:277-471)            */
+
+enum { S_NEAREST = 1, S_BILINEAR, S_BICUBIC, S_HERMITE, S_GAUSSIAN, S_OVERSAMPLE };
+
+static float smoothstep01(float x)
+{
+    const float t = clampf(x, 0.0f, 1.0f);
+    return t * t * (3.0f - 2.0f * t);
+}
+
+static void fast4(const struct orc_src *s, const float pt[2], float px, float py,
+                  const float g[4], const float h[4], const float off[2], float scale,
+                  float out[4])
+{
+    // p = pos.xyxy + pt.xyxy * (h + off.xyxy); 4 bilinear taps, 3 mixes
+    const float p0 = px + pt[0] * (h[0] + off[0]), p1 = py + pt[1] * (h[1] + off[1]);
+    const float p2 = px + pt[0] * (h[2] + off[0]), p3 = py + pt[1] * (h[3] + off[1]);
+    float c00[4], c01[4], c10[4], c11[4];
+    tex_linear(s, p0, p1, c00);
+    tex_linear(s, p0, p3, c01);
+    tex_linear(s, p2, p1, c10);
+    tex_linear(s, p2, p3, c11);
+    for (int c = 0; c < 4; c++) {
+        const float c0 = mixf(c01[c], c00[c], g[1]);
+        const float c1 = mixf(c11[c], c10[c], g[1]);
+        out[c] = scale * mixf(c1, c0, g[0]);
+    }
+}
+
+ORC_API void orc_sample_simple(const struct orc_src *s, int type, float scale,
+                               float rx, float ry, float threshold,
+                               int out_w, int out_h, float *out)
+{
+    float p[4][2], pt[2];
+    corners(s, p, pt);
+    const float osx = 1.0 / out_w, osy = 1.0 / out_h;
+    const float size[2] = { (float) s->w, (float) s->h };
+    const float ratio[2] = { rx, ry };
+
+    // Identity fetch (1:1 on the texel grid, e.g. the renderer's img_sh ->
+    // pl_shader_sample_direct of an FBO/plane): hardware bilinear returns the
+    // texel itself; an exact fp32 lerp would not (rounding noise in `pos`), so
+    // both oracle and product treat it as a nearest fetch. Design decision,
+    // see DESIGN.md "texture unit emulation".
+    if (type == S_BILINEAR && fabsf(rx - 1.0f) < 1e-6f && fabsf(ry - 1.0f) < 1e-6f &&
+        s->rect[0] == truncf(s->rect[0]) && s->rect[1] == truncf(s->rect[1]))
+        type = S_NEAREST;
+
+    for (int y = 0; y < out_h; y++) {
+        for (int x = 0; x < out_w; x++) {
+            const float fx = osx * ((float) x + 0.5f), fy = osy * ((float) y + 0.5f);
+            float pos[2] = { attr(p, 0, fx, fy), attr(p, 1, fx, fy) };
+            float *o = out + ((size_t) y * out_w + x) * 4;
+            float c[4];
+            switch (type) {
+            case S_NEAREST: // sampling.c:290-302
+                tex_nearest(s, pos[0], pos[1], c);
+                for (int k = 0; k < 4; k++) o[k] = scale * c[k];
+                break;
+            case S_BILINEAR: // sampling.c:304-316
+                tex_linear(s, pos[0], pos[1], c);
+                for (int k = 0; k < 4; k++) o[k] = scale * c[k];
+                break;
+            case S_BICUBIC: { // sampling.c:335-361
+                float g[4], h[4];
+                const float off[2] = {0, 0};
+                for (int k = 0; k < 2; k++) {
+                    const float fr = fractf(pos[k] * size[k] + 0.5f);
+                    const float fr2 = fr * fr, inv = 1.0f - fr, inv2 = inv * inv;
+                    const float w0 = 1.0f / 6.0f * inv2 * inv;
+                    const float w1 = 2.0f / 3.0f - 0.5f * fr2 * (2.0f - fr);
+                    const float w2 = 2.0f / 3.0f - 0.5f * inv2 * (2.0f - inv);
+                    const float w3 = 1.0f / 6.0f * fr2 * fr;
+                    g[k] = w0 + w1;
+                    g[k + 2] = w2 + w3;
+                    h[k] = w1 / g[k] + inv - 2.0f;
+                    h[k + 2] = w3 / g[k + 2] + inv;
+                }
+                fast4(s, pt, pos[0], pos[1], g, h, off, scale, o);
+                break;
+            }
+            case S_HERMITE: { // sampling.c:379-387
+                for (int k = 0; k < 2; k++) {
+                    const float fr = fractf(pos[k] * size[k] + 0.5f);
+                    pos[k] += pt[k] * (smoothstep01(fr) - fr);
+                }
+                tex_linear(s, pos[0], pos[1], c);
+                for (int k = 0; k < 4; k++) o[k] = scale * c[k];
+                break;
+            }
+            case S_GAUSSIAN: { // sampling.c:405-431
+                float g[4], h[4], off[2];
+                for (int k = 0; k < 2; k++) {
+                    const float of = -fractf(pos[k] * size[k] + 0.5f);
+                    const float o2 = -2.0f * of * of;
+                    const float w0 = expf(o2 + 4.0f * of - 2.0f);
+                    const float w1 = expf(o2);
+                    const float w2 = expf(o2 - 4.0f * of - 2.0f);
+                    const float w3 = expf(o2 - 8.0f * of - 8.0f);
+                    g[k] = w0 + w1;
+                    g[k + 2] = w2 + w3;
+                    h[k] = w1 / g[k] - 1.0f;
+                    h[k + 2] = w3 / g[k + 2] + 1.0f;
+                    g[k] /= g[k] + g[k + 2];
+                    off[k] = of;
+                }
+                fast4(s, pt, pos[0], pos[1], g, h, off, scale, o);
+                break;
+            }
+            case S_OVERSAMPLE: { // sampling.c:446-468
+                const float thr = clampf(threshold, 0.0f, 0.5f);
+                for (int k = 0; k < 2; k++) {
+                    const float fc = fractf(pos[k] * size[k] - 0.5f);
+                    float coeff = (fc - 0.5f) * ratio[k];
+                    coeff = clampf(coeff + 0.5f, 0.0f, 1.0f);
+                    if (thr > 0) {
+                        coeff = coeff < thr ? 0.0f : coeff;
+                        coeff = coeff > 1.0f - thr ? 1.0f : coeff;
+                    }
+                    pos[k] += (coeff - fc) * pt[k];
+                }
+                tex_linear(s, pos[0], pos[1], c);
+                for (int k = 0; k < 4; k++) o[k] = scale * c[k];
+                break;
+            }
+            }
+        }
+    }
+}
+
+/* ======================================================================== */
+/* K2 / K3: polar EWA (src/shaders/sampling.c:503-558, 587-912)               */
+
+// Linear LUT lookup, the reference's own ALU form (src/shaders/lut.c:700-715)
+static float lut_lin(const float *lut, int n, float fpos)
+{
+    fpos = clampf(fpos, 0.0f, 1.0f) * (float) (n - 1);
+    const float fbase = floorf(fpos), fceil = ceilf(fpos);
+    return mixf(lut[(int) fbase], lut[(int) fceil], fpos - fbase);
+}
+
+struct polar_acc {
+    float color[4], wsum;
+    float ar[4][2], wwsum[4][2];
+};
+
+struct polar_cfg {
+    const float *lut;       // 256 radial weights
+    float radius, radius_zero, antiring, scale;
+    unsigned mask;
+    int use_ar;
+};
+
+// One tap: polar_sample(), sampling.c:503-558. Returns 0 if statically pruned.
+static void polar_tap(const struct orc_src *s, const struct polar_cfg *cfg, int bx, int by,
+                      float fcx, float fcy, int x, int y, struct polar_acc *a)
+{
+    const int yy = y > 0 ? y - 1 : y;
+    const int xx = x > 0 ? x - 1 : x;
+    const float dmin = sqrt(xx * xx + yy * yy);
+    if (dmin >= cfg->radius)
+        return; // generation-time pruning (:510-515)
+    const int maybe_skippable = dmin >= cfg->radius - M_SQRT2;
+    const int use_ar = cfg->use_ar && dmin < cfg->radius_zero;
+
+    const float dx = (float) x - fcx, dy = (float) y - fcy;
+    const float d = sqrtf(dx * dx + dy * dy);
+    if (maybe_skippable && !(d < cfg->radius))
+        return;
+    // w = lut(d * 1.0 / radius): division by a constant, folded the way an
+    // AMD Vulkan driver lowers a 2.5-ULP OpFDiv by a constant: d * (1/R)
+    const float w = lut_lin(cfg->lut, 256, d * (1.0f / cfg->radius));
+    a->wsum += w;
+    const float *c = texel(s, bx + x, by + y);
+    for (int k = 0; k < 4; k++) {
+        if (cfg->mask & (1u << k))
+            a->color[k] = fmaf(w, c[k], a->color[k]);
+    }
+    if (use_ar && d <= cfg->radius_zero) {
+        for (int k = 0; k < 4; k++) {
+            if (!(cfg->mask & (1u << k)))
+                continue;
+            float cc[2] = { cfg->scale * c[k], cfg->scale * c[k] };
+            cc[0] = 1.0f - cc[0];
+            for (int j = 0; j < 2; j++) {
+                float ww = cc[j] + 0.10f;
+                ww = ww * ww; ww = ww * ww; ww = ww * ww; ww = ww * ww; ww = ww * ww;
+                ww = w * ww;
+                a->ar[k][j] = fmaf(ww, cc[j], a->ar[k][j]);
+                a->wwsum[k][j] += ww;
+            }
+        }
+    }
+}
+
+ORC_API void orc_sample_polar(const struct orc_src *s, const float *lut, float radius,
+                              float radius_zero, float antiring, int gather_order,
+                              float scale, unsigned mask, int out_w, int out_h, float *out)
+{
+    float p[4][2], pt[2];
+    corners(s, p, pt);
+    const float osx = 1.0 / out_w, osy = 1.0 / out_h;
+    const struct polar_cfg cfg = { lut, radius, radius_zero, antiring, scale, mask,
+                                   antiring > 0 };
+    const int bound = ceil(radius);
+
+    for (int oy = 0; oy < out_h; oy++) {
+        for (int ox = 0; ox < out_w; ox++) {
+            const float fx = osx * ((float) ox + 0.5f), fy = osy * ((float) oy + 0.5f);
+            const float px = attr(p, 0, fx, fy), py = attr(p, 1, fx, fy);
+            // fcoord = fract(pos*size - 0.5); base = texel floor(pos*size - 0.5) (:639-640)
+            const float tx = px * (float) s->w - 0.5f, ty = py * (float) s->h - 0.5f;
+            const float flx = floorf(tx), fly = floorf(ty);
+            const float fcx = tx - flx, fcy = ty - fly;
+            const int bx = (int) flx, by = (int) fly;
+
+            struct polar_acc a;
+            memset(&a, 0, sizeof(a));
+
+            if (!gather_order) {
+                // compute-shader order (:776-783)
+                for (int y = 1 - bound; y <= bound; y++) {
+                    for (int x = 1 - bound; x <= bound; x++)
+                        polar_tap(s, &cfg, bx, by, fcx, fcy, x, y, &a);
+                }
+            } else {
+                // textureGather order (:798-893)
+                uint64_t gathered_cur = 0, gathered_next = 0;
+                const float radius2 = radius * radius;
+                const int base = bound - 1;
+                for (int y = 1 - bound; y <= bound; y++) {
+                    for (int x = 1 - bound; x <= bound; x++) {
+                        const uint64_t bit = 1llu << (base + x);
+                        if (gathered_cur & bit)
+                            continue;
+                        const int xx = x * x, xx1 = (x + 1) * (x + 1);
+                        const int yy = y * y, yy1 = (y + 1) * (y + 1);
+                        int use_gather = (xx > xx1 ? xx : xx1) + (yy > yy1 ? yy : yy1) < radius2;
+                        use_gather &= (x > y ? x : y) <= 31;
+                        use_gather &= (x < y ? x : y) >= -32;
+                        if (!use_gather) {
+                            polar_tap(s, &cfg, bx, by, fcx, fcy, x, y, &a);
+                            continue;
+                        }
+                        static const int xo[4] = {0, 1, 1, 0}, yo[4] = {1, 1, 0, 0};
+                        for (int q = 0; q < 4; q++) {
+                            if (x + xo[q] > bound || y + yo[q] > bound)
+                                continue;
+                            if (!yo[q] && (gathered_cur & (bit << xo[q])))
+                                continue;
+                            polar_tap(s, &cfg, bx, by, fcx, fcy, x + xo[q], y + yo[q], &a);
+                        }
+                        gathered_next |= bit | (bit << 1);
+                        x++;
+                    }
+                    gathered_cur = gathered_next;
+                    gathered_next = 0;
+                }
+            }
+
+            // color = scale / wsum * color; AR; alpha (:896-908)
+            float *o = out + ((size_t) oy * out_w + ox) * 4;
+            const float norm = scale / a.wsum;
+            for (int k = 0; k < 4; k++) {
+                float v = norm * a.color[k];
+                if (cfg.use_ar && (mask & (1u << k))) {
+                    float lo = a.ar[k][0] / a.wwsum[k][0];
+                    const float hi = a.ar[k][1] / a.wwsum[k][1];
+                    lo = 1.0f - lo;
+                    float w = fminf(fmaxf(v, lo), hi);
+                    w = lo > hi ? (lo * 0.5f + hi * 0.5f) : w;
+                    v = mixf(v, w, antiring);
+                }
+                o[k] = v;
+            }
+            if (!(mask & 8u))
+                o[3] = 1.0f;
+        }
+    }
+}
+
+/* ======================================================================== */
+/* colour ops on whole images                                                */
+
+ORC_API void orc_op_scale(float *img, size_t npix, const float s[4])
+{
+    for (size_t i = 0; i < npix; i++) {
+        for (int c = 0; c < 4; c++)
+            img[i * 4 + c] *= s[c];
+    }
+}
+
+ORC_API void orc_op_quant_f16(float *img, size_t npix)
+{
+    for (size_t i = 0; i < npix * 4; i++)
+        img[i] = orc_round_f16(img[i]);
+}
+
+ORC_API void orc_op_affine(float *img, size_t npix, const float m[9], const float c[3])
+{
+    // color.rgb = M * color.rgb + c (shaders/colorspace.c:308,569), row-wise
+    for (size_t i = 0; i < npix; i++) {
+        float *p = img + i * 4;
+        const float r = p[0], g = p[1], b = p[2];
+        p[0] = (m[0] * r + m[1] * g + m[2] * b) + c[0];
+        p[1] = (m[3] * r + m[4] * g + m[5] * b) + c[1];
+        p[2] = (m[6] * r + m[7] * g + m[8] * b) + c[2];
+    }
+}
+
+// pl_shader_dither (src/shaders/dithering.c:109-274); gl_FragCoord = id + 0.5
+// (rect-relative in compute passes, dispatch.c:1040). method: 0 = LUT (blue
+// noise / bayer: integer index path), 1 = PL_DITHER_ORDERED_FIXED.
+ORC_API void orc_dither(float *img, int w, int h, const float *matrix, int size, int method,
+                        int depth, float gamma, int temporal, int frame_index)
+{
+    const float scale = (float) ((1llu << depth) - 1);
+    float rot[4] = {1, 0, 0, 1};
+    if (temporal) {
+        const int phase = frame_index % 8;
+        const float r = phase * (M_PI / 2);
+        const float m = phase < 4 ? 1 : -1;
+        // column-major mat2 {{cos r, -sin r}, {sin r * m, cos r * m}} (:185-196)
+        rot[0] = cos(r); rot[1] = -sin(r); rot[2] = sin(r) * m; rot[3] = cos(r) * m;
+    }
+    for (int y = 0; y < h; y++) {
+        for (int x = 0; x < w; x++) {
+            const float fcx = (float) x + 0.5f, fcy = (float) y + 0.5f;
+            float px = fractf(fcx / (float) size), py = fractf(fcy / (float) size); // :183
+            if (temporal) {
+                const float qx = (rot[0] * px + rot[2] * py) + 1.0f;
+                const float qy = (rot[1] * px + rot[3] * py) + 1.0f;
+                px = fractf(qx); py = fractf(qy);                             // :199
+            }
+            float bias;
+            if (method == 0) {
+                bias = matrix[(int) (py * (float) size) * size + (int) (px * (float) size)]; // :230
+            } else {
+                uint32_t ux = (uint32_t) (px * 16.0f) % 16u, uy = (uint32_t) (py * 16.0f) % 16u;
+                ux = ux ^ uy;                                                  // :212-224
+                ux = (ux | ux << 2) & 0x33333333u; uy = (uy | uy << 2) & 0x33333333u;
+                ux = (ux | ux << 1) & 0x55555555u; uy = (uy | uy << 1) & 0x55555555u;
+                uint32_t b = ux + (uy << 1);
+                b = (b * 0x0802u & 0x22110u) | (b * 0x8020u & 0x88440u);
+                b = 0x10101u * b;
+                b = (b >> 16) & 0xFFu;
+                bias = (float) b * (1.0f / 256.0f);
+            }
+            float *p = img + ((size_t) y * w + x) * 4;
+            for (int c = 0; c < 4; c++) {
+                if (gamma != 1.0f && depth <= 4) {                             // :241-266
+                    const float v = p[c], lin = powf(v, gamma);
+                    float low, high, off;
+                    if (depth == 1) {
+                        low = 0; high = 1; off = lin;
+                    } else {
+                        low = floorf(v * scale) / scale;
+                        high = ceilf(v * scale) / scale;
+                        const float ll = powf(low, gamma), hl = powf(high, gamma);
+                        off = (lin - ll) / fmaxf(hl - ll, 1e-6f);
+                    }
+                    p[c] = off > bias ? high : low;
+                } else {
+                    p[c] = floorf(scale * p[c] + bias) * (1.0f / scale);       // :269-270
+                }
+            }
+        }
+    }
+}
+
+/* ======================================================================== */
+/* Tier-0 restatement: filter kernels (src/filters.c)                        */
+
+enum { K_BOX = 0, K_TRIANGLE, K_HANN, K_GAUSSIAN, K_SINC, K_JINC, K_CUBIC,
+       K_SPLINE16, K_SPLINE36, K_SPLINE64, K_NONE = -1 };
+
+struct orc_filter {
+    int kernel, window;         // K_* (window may be K_NONE)
+    double kparams[2];          // cubic (b, c) / gaussian
+    float kradius, wradius;     // natural radii of kernel / window function
+    int resizable;
+    float radius;               // config.radius (0 = natural)
+    float clamp, blur, taper;
+};
+
+static double kweight(int k, const double *prm, double radius, double x)
+{
+    switch (k) {
+    case K_BOX:      return 1.0;                                        // filters.c:254
+    case K_TRIANGLE: return 1.0 - x / radius;                           // :273
+    case K_HANN:     return 0.5 + 0.5 * cos(M_PI * x);                  // :296
+    case K_GAUSSIAN: return exp(-2.0 * x * x / prm[0]);                 // :392
+    case K_SINC:     if (x < 1e-8) return 1.0; x *= M_PI; return sin(x) / x;       // :427
+    case K_JINC:     if (x < 1e-8) return 1.0; x *= M_PI; return 2.0 * j1(x) / x;  // :442
+    case K_CUBIC: {                                                      // :472
+        const double b = prm[0], c = prm[1];
+        const double p0 = 6.0 - 2.0 * b, p2 = -18.0 + 12.0 * b + 6.0 * c,
+                     p3 = 12.0 - 9.0 * b - 6.0 * c, q0 = 8.0 * b + 24.0 * c,
+                     q1 = -12.0 * b - 48.0 * c, q2 = 6.0 * b + 30.0 * c, q3 = -b - 6.0 * c;
+        if (x < 1.0)
+            return (p0 + x * x * (p2 + x * p3)) / p0;
+        return (q0 + x * (q1 + x * (q2 + x * q3))) / p0;
+    }
+    case K_SPLINE16:                                                     // :553
+        if (x < 1.0) return ((x - 9.0/5.0 ) * x - 1.0/5.0 ) * x + 1.0;
+        return ((-1.0/3.0 * (x-1) + 4.0/5.0) * (x-1) - 7.0/15.0 ) * (x-1);
+    case K_SPLINE36:                                                     // :568
+        if (x < 1.0) return ((13.0/11.0 * x - 453.0/209.0) * x - 3.0/209.0) * x + 1.0;
+        if (x < 2.0) return ((-6.0/11.0 * (x-1) + 270.0/209.0) * (x-1) - 156.0/ 209.0) * (x-1);
+        return ((1.0/11.0 * (x-2) - 45.0/209.0) * (x-2) +  26.0/209.0) * (x-2);
+    case K_SPLINE64:                                                     // :585
+        if (x < 1.0) return ((49.0/41.0 * x - 6387.0/2911.0) * x - 3.0/2911.0) * x + 1.0;
+        if (x < 2.0) return ((-24.0/41.0 * (x-1) + 4032.0/2911.0) * (x-1) - 2328.0/2911.0) * (x-1);
+        if (x < 3.0) return ((6.0/41.0 * (x-2) - 1008.0/2911.0) * (x-2) + 582.0/2911.0) * (x-2);
+        return ((-1.0/41.0 * (x-3) + 168.0/2911.0) * (x-3) - 97.0/2911.0) * (x-3);
+    }
+    return 0.0;
+}
+
+static float radius_bound(const struct orc_filter *f)                   // src/filters.h:22-26
+{
+    const float r = f->radius && f->resizable ? f->radius : f->kradius;
+    return f->blur > 0.0 ? r * f->blur : r;
+}
+
+// pl_filter_sample, filters.c:82-124
+ORC_API double orc_filter_sample(const struct orc_filter *f, double x)
+{
+    const float radius = radius_bound(f);
+    x = fabs(x);
+    if (x > radius)
+        return 0.0;
+    double kx = x <= f->taper ? 0.0 : (x - f->taper) / (1.0 - f->taper / radius);
+    if (f->blur > 0.0)
+        kx /= f->blur;
+    double k = kweight(f->kernel, f->kparams, radius, kx);
+    if (f->window != K_NONE) {
+        const double wx = x / radius * f->wradius;
+        const double none[2] = {0, 0};
+        k *= kweight(f->window, none, f->wradius, wx);
+    }
+    return k < 0 ? (1 - f->clamp) * k : k;
+}
+
+// filter_cutoffs (filters.c:126-151) + polar branch of pl_filter_generate (:215-222)
+ORC_API void orc_filter_generate_polar(const struct orc_filter *f, float cutoff, int n,
+                                       float *weights, float *out_radius, float *out_radius_zero)
+{
+    const float bound = radius_bound(f);
+    float prev = 0.0, fprev = orc_filter_sample(f, prev);
+    int found = 0;
+    float radius = bound, radius_zero = bound;
+    const float step = 1e-2f;
+    for (float x = 0.0; x < bound + step; x += step) {
+        const float fx = orc_filter_sample(f, x);
+        if ((fprev > cutoff && fx <= cutoff) || (fprev < -cutoff && fx >= -cutoff)) {
+            float root = x - fx * (x - prev) / (fx - fprev);
+            root = fminf(root, bound);
+            radius = root;
+            if (!found)
+                radius_zero = root;
+            found = 1;
+        }
+        prev = x;
+        fprev = fx;
+    }
+    if (!found)
+        radius_zero = radius = bound;
+    for (int i = 0; i < n; i++) {
+        const double x = radius * i / (n - 1);
+        weights[i] = orc_filter_sample(f, x);
+    }
+    *out_radius = radius;
+    *out_radius_zero = radius_zero;
+}
+
+// compute_row + separable branch (filters.c:155-177, 224-241); returns row_size
+ORC_API int orc_filter_generate_ortho(const struct orc_filter *f, float cutoff, int n,
+                                      int stride_align, float *weights, int max_floats,
+                                      float *out_radius, float *out_radius_zero)
+{
+    float dummy[2];
+    orc_filter_generate_polar(f, cutoff, 2, dummy, out_radius, out_radius_zero);
+    const int row_size = ceilf(*out_radius) * 2;
+    const int stride = (row_size + stride_align - 1) / stride_align * stride_align;
+    if (n * stride > max_floats)
+        return -stride;
+    memset(weights, 0, sizeof(float) * n * stride);
+    for (int i = 0; i < n; i++) {
+        float *row = weights + (size_t) i * stride;
+        const double offset = i / (double) (n - 1);
+        const double center = (row_size / 2 - 1) + offset;
+        double wsum = 0.0;
+        for (int k = 0; k < row_size; k++) {
+            const double w = orc_filter_sample(f, k - center);
+            row[k] = w;
+            wsum += w;
+        }
+        for (int k = 0; k < row_size; k++)
+            row[k] /= wsum;
+    }
+    return row_size;
+}
+
+/* ------------------------------------------------------------------------ */
+/* CPU baseline driver: BASELINE.json configs[0] — EWA-Lanczos resample of a  */
+/* single-channel float image, (a) direct pl_filter_sample per tap,          */
+/* (b) 256-entry LUT + lerp (what the GPU path does).                         */
+
+ORC_API double orc_ewa_resample_r32f(const struct orc_filter *f, const float *src, int sw, int sh,
+                                     int dw, int dh, int use_lut, float *dst)
+{
+    float lut[256], radius, radius_zero;
+    orc_filter_generate_polar(f, 1e-3f, 256, lut, &radius, &radius_zero);
+    const int bound = ceil(radius);
+    double taps = 0;
+    for (int oy = 0; oy < dh; oy++) {
+        for (int ox = 0; ox < dw; ox++) {
+            const float px = ((float) ox + 0.5f) / dw, py = ((float) oy + 0.5f) / dh;
+            const float tx = px * sw - 0.5f, ty = py * sh - 0.5f;
+            const float flx = floorf(tx), fly = floorf(ty);
+            const float fcx = tx - flx, fcy = ty - fly;
+            float acc = 0, wsum = 0;
+            for (int y = 1 - bound; y <= bound; y++) {
+                for (int x = 1 - bound; x <= bound; x++) {
+                    const float dx = x - fcx, dy = y - fcy;
+                    const float d = sqrtf(dx * dx + dy * dy);
+                    if (!(d < radius))
+                        continue;
+                    const float w = use_lut ? lut_lin(lut, 256, d * (1.0f / radius))
+                                            : (float) orc_filter_sample(f, d);
+                    int xx = (int) flx + x, yy = (int) fly + y;
+                    xx = xx < 0 ? 0 : xx >= sw ? sw - 1 : xx;
+                    yy = yy < 0 ? 0 : yy >= sh ? sh - 1 : yy;
+                    acc = fmaf(w, src[(size_t) yy * sw + xx], acc);
+                    wsum += w;
+                    taps++;
+                }
+            }
+            dst[(size_t) oy * dw + ox] = acc / wsum;
+        }
+    }
+    return taps / ((double) dw * dh);
+}

@@ -1,0 +1,177 @@
+"""ctypes binding of the CPU oracle (oracle/libploracle.so) and of the real
+reference CPU half (oracle/_ref/libplref.so) — test infrastructure only."""
+import ctypes as C
+import os
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ORACLE_SO = os.path.join(ROOT, "oracle", "libploracle.so")
+REF_SO = os.path.join(ROOT, "oracle", "_ref", "libplref.so")
+
+FMT = {"r8": 1, "rg8": 2, "rgba8": 3, "r16": 4, "rg16": 5, "rgba16": 6,
+       "r16hf": 7, "rg16hf": 8, "rgba16hf": 9, "r32f": 10, "rg32f": 11, "rgba32f": 12}
+S_NEAREST, S_BILINEAR, S_BICUBIC, S_HERMITE, S_GAUSSIAN, S_OVERSAMPLE = 1, 2, 3, 4, 5, 6
+K = dict(box=0, triangle=1, hann=2, gaussian=3, sinc=4, jinc=5, cubic=6,
+         spline16=7, spline36=8, spline64=9, none=-1)
+
+_f32p = C.POINTER(C.c_float)
+
+
+class Src(C.Structure):
+    _fields_ = [("tex", _f32p), ("w", C.c_int), ("h", C.c_int),
+                ("rect", C.c_float * 4), ("address_mode", C.c_int)]
+
+
+class OrcFilter(C.Structure):
+    _fields_ = [("kernel", C.c_int), ("window", C.c_int), ("kparams", C.c_double * 2),
+                ("kradius", C.c_float), ("wradius", C.c_float), ("resizable", C.c_int),
+                ("radius", C.c_float), ("clamp", C.c_float), ("blur", C.c_float),
+                ("taper", C.c_float)]
+
+
+JINC_R3 = 3.2383154841662362076499
+
+
+def ewa_lanczos(blur=0.0):
+    return OrcFilter(kernel=K["jinc"], window=K["jinc"], kradius=1.2196698912665045,
+                     wradius=1.2196698912665045, resizable=1, radius=JINC_R3, blur=blur)
+
+
+def lanczos(blur=0.0):
+    return OrcFilter(kernel=K["sinc"], window=K["sinc"], kradius=1.0, wradius=1.0,
+                     resizable=1, radius=3.0, blur=blur)
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        L = C.CDLL(ORACLE_SO)
+        L.orc_round_f16.restype = C.c_float
+        L.orc_round_f16.argtypes = [C.c_float]
+        L.orc_filter_sample.restype = C.c_double
+        L.orc_filter_sample.argtypes = [C.POINTER(OrcFilter), C.c_double]
+        L.orc_ewa_resample_r32f.restype = C.c_double
+        _lib = L
+    return _lib
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def tex_decode(arr, fmt):
+    """Texture fetch of every texel -> float32 RGBA image (h, w, 4)."""
+    arr = np.ascontiguousarray(arr)
+    h, w = arr.shape[:2]
+    out = np.empty((h, w, 4), np.float32)
+    lib().orc_tex_decode(_p(arr), FMT[fmt], w, h, C.c_size_t(arr.strides[0]), _p(out))
+    return out
+
+
+def tex_encode(img, fmt):
+    from libplacebo_amd import _FMT_DTYPES
+    dt, nc = _FMT_DTYPES[fmt]
+    img = np.ascontiguousarray(img, np.float32)
+    h, w = img.shape[:2]
+    out = np.zeros((h, w, nc), dt)
+    lib().orc_tex_encode(_p(img), w, h, FMT[fmt], _p(out), C.c_size_t(out.strides[0]))
+    return out
+
+
+def _src(img, rect, address_mode):
+    img = np.ascontiguousarray(img, np.float32)
+    h, w = img.shape[:2]
+    s = Src(tex=img.ctypes.data_as(_f32p), w=w, h=h, address_mode=address_mode)
+    rect = rect if rect is not None else (0, 0, w, h)
+    s.rect = (C.c_float * 4)(*rect)
+    return s, img
+
+
+def sample_simple(img, kind, out_w, out_h, rect=None, scale=1.0, address_mode=0,
+                  threshold=0.0):
+    s, keep = _src(img, rect, address_mode)
+    out = np.empty((out_h, out_w, 4), np.float32)
+    rw = abs(s.rect[2] - s.rect[0]); rh = abs(s.rect[3] - s.rect[1])
+    lib().orc_sample_simple(C.byref(s), kind, C.c_float(scale), C.c_float(out_w / rw),
+                            C.c_float(out_h / rh), C.c_float(threshold), out_w, out_h, _p(out))
+    return out
+
+
+def sample_polar(img, lut, radius, radius_zero, out_w, out_h, rect=None, scale=1.0,
+                 antiring=0.0, gather_order=False, mask=0xF, address_mode=0):
+    s, keep = _src(img, rect, address_mode)
+    lut = np.ascontiguousarray(lut, np.float32)
+    assert lut.size == 256
+    out = np.empty((out_h, out_w, 4), np.float32)
+    lib().orc_sample_polar(C.byref(s), _p(lut), C.c_float(radius), C.c_float(radius_zero),
+                           C.c_float(antiring), int(gather_order), C.c_float(scale),
+                           C.c_uint(mask), out_w, out_h, _p(out))
+    return out
+
+
+def op_scale(img, s):
+    s = (C.c_float * 4)(*([s] * 4 if np.isscalar(s) else s))
+    lib().orc_op_scale(_p(img), C.c_size_t(img.size // 4), s)
+    return img
+
+
+def op_quant_f16(img):
+    lib().orc_op_quant_f16(_p(img), C.c_size_t(img.size // 4))
+    return img
+
+
+def dither(img, matrix, depth, method=0, gamma=1.0, temporal=False, frame_index=0):
+    h, w = img.shape[:2]
+    size = 16
+    m = None
+    if matrix is not None:
+        m = np.ascontiguousarray(matrix, np.float32)
+        size = int(round(m.size ** 0.5))
+    lib().orc_dither(_p(img), w, h, _p(m) if m is not None else None, size, method, depth,
+                     C.c_float(gamma), int(temporal), frame_index)
+    return img
+
+
+def filter_generate_polar(f, cutoff=1e-3, n=256):
+    w = np.empty(n, np.float32)
+    r, rz = C.c_float(), C.c_float()
+    lib().orc_filter_generate_polar(C.byref(f), C.c_float(cutoff), n, _p(w), C.byref(r), C.byref(rz))
+    return w, r.value, rz.value
+
+
+def filter_generate_ortho(f, cutoff=0.0, n=256, align=4):
+    buf = np.empty(n * 64, np.float32)
+    r, rz = C.c_float(), C.c_float()
+    row_size = lib().orc_filter_generate_ortho(C.byref(f), C.c_float(cutoff), n, align, _p(buf),
+                                               buf.size, C.byref(r), C.byref(rz))
+    assert row_size > 0
+    stride = (row_size + align - 1) // align * align
+    return buf[:n * stride].reshape(n, stride).copy(), row_size, r.value, rz.value
+
+
+def ewa_resample_r32f(f, src, dw, dh, use_lut):
+    src = np.ascontiguousarray(src, np.float32)
+    sh, sw = src.shape
+    dst = np.empty((dh, dw), np.float32)
+    taps = lib().orc_ewa_resample_r32f(C.byref(f), _p(src), sw, sh, dw, dh, int(use_lut), _p(dst))
+    return dst, taps
+
+
+def have_ref():
+    return os.path.exists(REF_SO)
+
+
+_ref = None
+
+
+def ref():
+    """The real reference CPU half (filters.c, tone_mapping.c, ... compiled from
+    /root/reference by oracle/build_ref.sh)."""
+    global _ref
+    if _ref is None:
+        _ref = C.CDLL(REF_SO)
+    return _ref
