@@ -58,8 +58,9 @@ DEV void pass_store(const plh_pass &p, int idx, int idy, const float4_t &c)
 }
 
 __global__ __launch_bounds__(PASS_BW * PASS_BH)
-void k_pass_generic(const plh_pass p)
+void k_pass_generic(const plh_pass p_)
 {
+    const plh_pass &p = plh_kernarg_pass();
     const int idx = blockIdx.x * PASS_BW + threadIdx.x;
     const int idy = blockIdx.y * PASS_BH + threadIdx.y;
     // whole groups are launched; lanes beyond the padded rect still run the

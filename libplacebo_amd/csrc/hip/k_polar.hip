@@ -64,8 +64,9 @@ struct ar_state {
 
 template <typename T, uint32_t MASK, bool USE_AR>
 __global__ __launch_bounds__(POLAR_BW * POLAR_BH)
-void k_polar(const plh_pass p)
+void k_polar(const plh_pass p_)
 {
+    const plh_pass &p = plh_kernarg_pass();
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     float2 *lut = (float2 *) smem;                              // 256 pairs = 2 KiB
     tile_px<T> *tile = (tile_px<T> *) (smem + 256 * sizeof(float2));
