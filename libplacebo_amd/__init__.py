@@ -45,6 +45,54 @@ def filter_config(name, usage=FILTER_UPSCALING):
     return p.contents
 
 
+# enum values (include/libplacebo/colorspace.h)
+PRIM = dict(unknown=0, bt601_525=1, bt601_625=2, bt709=3, bt470m=4, ebu3213=5, bt2020=6,
+            apple=7, adobe=8, prophoto=9, cie1931=10, dci_p3=11, display_p3=12, v_gamut=13,
+            s_gamut=14, film_c=15, aces_ap0=16, aces_ap1=17)
+TRC = dict(unknown=0, bt1886=1, srgb=2, linear=3, gamma18=4, gamma20=5, gamma22=6, gamma24=7,
+           gamma26=8, gamma28=9, prophoto=10, st428=11, pq=12, hlg=13, vlog=14, slog1=15,
+           slog2=16, scrgb=17)
+SYS = dict(unknown=0, bt601=1, bt709=2, smpte240m=3, bt2020nc=4, bt2020c=5, bt2100pq=6,
+           bt2100hlg=7, dolbyvision=8, ycgco=9, ycgco_re=10, ycgco_ro=11, rgb=12, xyz=13)
+LEVELS = dict(unknown=0, limited=1, full=2)
+ALPHA = dict(unknown=0, independent=1, premultiplied=2, none=3)
+HDR_NORM, HDR_SQRT, HDR_NITS, HDR_PQ = 0, 1, 2, 3
+
+
+def color_space(primaries="bt709", transfer="bt1886", min_luma=0.0, max_luma=0.0, **hdr):
+    cs = capi.ColorSpace(primaries=PRIM[primaries], transfer=TRC[transfer])
+    cs.hdr.min_luma, cs.hdr.max_luma = min_luma, max_luma
+    for k, v in hdr.items():
+        setattr(cs.hdr, k, v)
+    return cs
+
+
+def color_repr(sys="rgb", levels="full", alpha="unknown", sample_depth=0, color_depth=0,
+               bit_shift=0):
+    return capi.ColorRepr(sys=SYS[sys], levels=LEVELS[levels], alpha=ALPHA[alpha],
+                          bits=capi.BitEncoding(sample_depth, color_depth, bit_shift))
+
+
+def peak_detect_params(smoothing_period=20.0, scene_threshold_low=1.0, scene_threshold_high=3.0,
+                       percentile=100.0, black_cutoff=1.0, allow_delayed=False):
+    return capi.PeakDetectParams(smoothing_period, scene_threshold_low, scene_threshold_high,
+                                 percentile, black_cutoff, allow_delayed, 0.0)
+
+
+def color_map_params(tone="spline", gamut="perceptual", **kw):
+    p = capi.ColorMapParams(
+        gamut_mapping=lib().pl_find_gamut_map_function(gamut.encode()),
+        gamut_constants=capi.GamutMapConstants(*capi.GAMUT_MAP_CONSTANTS),
+        lut3d_size=(C.c_int * 3)(48, 32, 256),
+        tone_mapping_function=lib().pl_find_tone_map_function(tone.encode()),
+        tone_constants=capi.ToneMapConstants(*capi.TONE_MAP_CONSTANTS),
+        metadata=0, lut_size=256, contrast_smoothness=3.5,
+        visualize_rect=capi.Rect2df(0, 0, 1, 1))
+    for k, v in kw.items():
+        setattr(p, k, v)
+    return p
+
+
 def hip_device_count():
     return lib().pl_hip_device_count()
 
@@ -149,6 +197,39 @@ class Shader:
         lib().pl_shader_dither(self.sh, depth, C.byref(state_obj.slot) if state_obj else None,
                                C.byref(dp))
 
+    # ---- colour stages (shaders/colorspace.h) --------------------------------------------
+    def decode_color(self, repr_, adjustment=None):
+        lib().pl_shader_decode_color(self.sh, C.byref(repr_),
+                                     C.byref(adjustment) if adjustment else None)
+
+    def encode_color(self, repr_):
+        lib().pl_shader_encode_color(self.sh, C.byref(repr_))
+
+    def set_alpha(self, repr_, mode):
+        lib().pl_shader_set_alpha(self.sh, C.byref(repr_), mode)
+
+    def linearize(self, csp):
+        lib().pl_shader_linearize(self.sh, C.byref(csp))
+
+    def delinearize(self, csp):
+        lib().pl_shader_delinearize(self.sh, C.byref(csp))
+
+    def sigmoidize(self, center=0.75, slope=6.5, inverse=False):
+        sp = capi.SigmoidParams(center, slope)
+        fn = lib().pl_shader_unsigmoidize if inverse else lib().pl_shader_sigmoidize
+        fn(self.sh, C.byref(sp))
+
+    def detect_peak(self, csp, state_obj, **kw):
+        pp = peak_detect_params(**kw)
+        return lib().pl_shader_detect_peak(self.sh, csp, C.byref(state_obj.slot), C.byref(pp))
+
+    def color_map(self, src, dst, state_obj=None, params=None, prelinearized=False):
+        params = params or color_map_params()
+        args = capi.ColorMapArgs(src=src, dst=dst, prelinearized=prelinearized,
+                                 state=C.pointer(state_obj.slot) if state_obj else None)
+        self._keep.append((params, args))
+        lib().pl_shader_color_map_ex(self.sh, C.byref(params), C.byref(args))
+
     def listing(self):
         res = lib().pl_shader_finalize(self.sh)
         return res.contents.glsl.decode() if res else None
@@ -161,6 +242,11 @@ class Shader:
         if rect is not None:
             dp.rect = capi.Rect2d(*rect)
         return lib().pl_dispatch_finish(self.gpu.dp, C.byref(dp))
+
+    def compute(self, width=0, height=0, timer=None):
+        cp = capi.DispatchComputeParams(shader=C.pointer(self.sh), width=width, height=height,
+                                        timer=timer)
+        return lib().pl_dispatch_compute(self.gpu.dp, C.byref(cp))
 
     def abort(self):
         lib().pl_dispatch_abort(self.gpu.dp, C.byref(self.sh))

@@ -187,9 +187,99 @@ class DitherParams(C.Structure):
                 ("transfer", C.c_int)]
 
 
+class DispatchComputeParams(C.Structure):
+    _fields_ = [("shader", C.POINTER(C.c_void_p)), ("dispatch_size", C.c_int * 3),
+                ("width", C.c_int), ("height", C.c_int), ("timer", C.c_void_p)]
+
+
 class DispatchParams(C.Structure):
     _fields_ = [("shader", C.POINTER(C.c_void_p)), ("target", C.POINTER(Tex)),
                 ("rect", Rect2d), ("blend_params", C.c_void_p), ("timer", C.c_void_p)]
+
+
+# ---- colorspace.h / tone_mapping.h / gamut_mapping.h --------------------------------
+class CieXy(C.Structure):
+    _fields_ = [("x", C.c_float), ("y", C.c_float)]
+
+
+class RawPrimaries(C.Structure):
+    _fields_ = [("red", CieXy), ("green", CieXy), ("blue", CieXy), ("white", CieXy)]
+
+
+class HdrBezier(C.Structure):
+    _fields_ = [("target_luma", C.c_float), ("knee_x", C.c_float), ("knee_y", C.c_float),
+                ("anchors", C.c_float * 15), ("num_anchors", C.c_uint8)]
+
+
+class HdrMetadata(C.Structure):
+    _fields_ = [("prim", RawPrimaries), ("min_luma", C.c_float), ("max_luma", C.c_float),
+                ("max_cll", C.c_float), ("max_fall", C.c_float), ("scene_max", C.c_float * 3),
+                ("scene_avg", C.c_float), ("ootf", HdrBezier), ("max_pq_y", C.c_float),
+                ("avg_pq_y", C.c_float)]
+
+
+class ColorSpace(C.Structure):
+    _fields_ = [("primaries", C.c_int), ("transfer", C.c_int), ("hdr", HdrMetadata)]
+
+
+class BitEncoding(C.Structure):
+    _fields_ = [("sample_depth", C.c_int), ("color_depth", C.c_int), ("bit_shift", C.c_int)]
+
+
+class ColorRepr(C.Structure):
+    _fields_ = [("sys", C.c_int), ("levels", C.c_int), ("alpha", C.c_int),
+                ("bits", BitEncoding), ("dovi", C.c_void_p)]
+
+
+class ColorAdjustment(C.Structure):
+    _fields_ = [(n, C.c_float) for n in ("brightness", "contrast", "saturation", "hue", "gamma",
+                                         "temperature")]
+
+
+class ToneMapConstants(C.Structure):
+    _fields_ = [(n, C.c_float) for n in (
+        "knee_adaptation", "knee_minimum", "knee_maximum", "knee_default", "knee_offset",
+        "slope_tuning", "slope_offset", "spline_contrast", "reinhard_contrast", "linear_knee",
+        "exposure")]
+
+
+TONE_MAP_CONSTANTS = (0.4, 0.1, 0.8, 0.4, 1.0, 1.5, 0.2, 0.5, 0.5, 0.3, 1.0)
+
+
+class GamutMapConstants(C.Structure):
+    _fields_ = [(n, C.c_float) for n in ("perceptual_deadzone", "perceptual_strength",
+                                         "colorimetric_gamma", "softclip_knee", "softclip_desat")]
+
+
+GAMUT_MAP_CONSTANTS = (0.30, 0.80, 1.80, 0.70, 0.35)
+
+
+class SigmoidParams(C.Structure):
+    _fields_ = [("center", C.c_float), ("slope", C.c_float)]
+
+
+class PeakDetectParams(C.Structure):
+    _fields_ = [("smoothing_period", C.c_float), ("scene_threshold_low", C.c_float),
+                ("scene_threshold_high", C.c_float), ("percentile", C.c_float),
+                ("black_cutoff", C.c_float), ("allow_delayed", C.c_bool),
+                ("minimum_peak", C.c_float)]
+
+
+class ColorMapParams(C.Structure):
+    _fields_ = [("gamut_mapping", C.c_void_p), ("gamut_constants", GamutMapConstants),
+                ("lut3d_size", C.c_int * 3), ("lut3d_tricubic", C.c_bool),
+                ("gamut_expansion", C.c_bool), ("tone_mapping_function", C.c_void_p),
+                ("tone_constants", ToneMapConstants), ("inverse_tone_mapping", C.c_bool),
+                ("metadata", C.c_int), ("lut_size", C.c_int), ("contrast_recovery", C.c_float),
+                ("contrast_smoothness", C.c_float), ("force_tone_mapping_lut", C.c_bool),
+                ("visualize_lut", C.c_bool), ("visualize_rect", Rect2df),
+                ("visualize_hue", C.c_float), ("visualize_theta", C.c_float),
+                ("show_clipping", C.c_bool), ("tone_mapping_param", C.c_float)]
+
+
+class ColorMapArgs(C.Structure):
+    _fields_ = [("src", ColorSpace), ("dst", ColorSpace), ("prelinearized", C.c_bool),
+                ("state", C.POINTER(C.c_void_p)), ("feature_map", C.POINTER(Tex))]
 
 
 def declare(lib):
@@ -237,6 +327,7 @@ def declare(lib):
     fn("pl_dispatch_begin", vp, vp)
     fn("pl_dispatch_finish", C.c_bool, vp, P(DispatchParams))
     fn("pl_dispatch_abort", None, vp, P(vp))
+    fn("pl_dispatch_compute", C.c_bool, vp, P(DispatchComputeParams))
     fn("pl_shader_finalize", P(ShaderRes), vp)
     fn("pl_shader_is_failed", C.c_bool, vp)
     fn("pl_shader_obj_destroy", None, P(vp))
@@ -248,4 +339,29 @@ def declare(lib):
     fn("pl_shader_sample_ortho2", C.c_bool, vp, P(SampleSrc), P(SampleFilterParams))
     fn("pl_shader_deband", None, vp, P(SampleSrc), P(DebandParams))
     fn("pl_shader_dither", None, vp, C.c_int, P(vp), P(DitherParams))
+
+    fn("pl_shader_set_alpha", None, vp, P(ColorRepr), C.c_int)
+    fn("pl_shader_decode_color", None, vp, P(ColorRepr), P(ColorAdjustment))
+    fn("pl_shader_encode_color", None, vp, P(ColorRepr))
+    fn("pl_shader_linearize", None, vp, P(ColorSpace))
+    fn("pl_shader_delinearize", None, vp, P(ColorSpace))
+    fn("pl_shader_sigmoidize", None, vp, P(SigmoidParams))
+    fn("pl_shader_unsigmoidize", None, vp, P(SigmoidParams))
+    fn("pl_shader_detect_peak", C.c_bool, vp, ColorSpace, P(vp), P(PeakDetectParams))
+    fn("pl_get_detected_hdr_metadata", C.c_bool, vp, P(HdrMetadata))
+    fn("pl_reset_detected_peak", None, vp)
+    fn("pl_hip_peak_buffer", vp, vp, P(C.c_size_t))
+    fn("pl_shader_color_map_ex", None, vp, P(ColorMapParams), P(ColorMapArgs))
+    fn("pl_find_tone_map_function", vp, C.c_char_p)
+    fn("pl_find_gamut_map_function", vp, C.c_char_p)
+    fn("pl_color_space_nominal_luma_ex", None, vp)
+    fn("pl_color_space_infer", None, P(ColorSpace))
+    fn("pl_color_space_infer_map", None, P(ColorSpace), P(ColorSpace))
+    fn("pl_raw_primaries_get", P(RawPrimaries), C.c_int)
+    fn("pl_get_rgb2xyz_matrix", Matrix3x3, P(RawPrimaries))
+    fn("pl_ipt_rgb2lms", Matrix3x3, P(RawPrimaries))
+    fn("pl_ipt_lms2rgb", Matrix3x3, P(RawPrimaries))
+    fn("pl_color_repr_decode", Transform3x3, P(ColorRepr), P(ColorAdjustment))
+    fn("pl_color_repr_normalize", C.c_float, P(ColorRepr))
+    fn("pl_hdr_rescale", C.c_float, C.c_int, C.c_int, C.c_float)
     return lib

@@ -85,6 +85,7 @@ void k_pass_generic(const plh_pass p_)
 int plh_launch_polar(hipStream_t stream, const plh_pass *pass);
 int plh_launch_ortho(hipStream_t stream, const plh_pass *pass);
 int plh_launch_deband(hipStream_t stream, const plh_pass *pass);
+int plh_launch_peak(hipStream_t stream, const plh_pass *pass);
 
 extern "C" int plh_launch_pass(plh_stream stream_, const struct plh_pass *pass)
 {
@@ -101,6 +102,12 @@ extern "C" int plh_launch_pass(plh_stream stream_, const struct plh_pass *pass)
         return plh_launch_deband(stream, pass);
     default:
         break;
+    }
+
+    // a peak-detection stage needs the 16x16 tiling + LDS state of k_peak.hip
+    for (int i = 0; i < pass->num_ops; i++) {
+        if (pass->ops[i].kind == PLH_OP_PEAK_DETECT)
+            return plh_launch_peak(stream, pass);
     }
 
     const dim3 block(PASS_BW, PASS_BH);

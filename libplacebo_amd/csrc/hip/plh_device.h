@@ -120,12 +120,23 @@ enum plh_op_kind {
     PLH_OP_DITHER,          // ptr = size×size float matrix; i0 = size; i1 = method;
                             // f[0] = 2^depth-1; f[1] = gamma; i2 = depth; f[4..7] = temporal mat2
     PLH_OP_SWIZZLE,         // i0..i3 packed: output component c takes input comp map[c] (or -1 → 0/1)
-    PLH_OP_TONE_MAP,        // colour mapping (colorspace.c:1612), see k_colormap
     PLH_OP_CLAMP01,         // color = clamp(color, 0, 1)
-    PLH_OP_BT2020C_DEC, PLH_OP_BT2020C_ENC, // constant-luminance special cases
-    PLH_OP_ICTCP_DEC, PLH_OP_ICTCP_ENC,
-    PLH_OP_XYZ_DEC, PLH_OP_XYZ_ENC,
+    PLH_OP_BT2020C_DEC,     // BT.2020 constant luminance (colorspace.c:312-342)
+    PLH_OP_BT2020C_ENC,     //                            (colorspace.c:475-493)
+    PLH_OP_ICTCP_DEC,       // i0: 0 = PQ, 1 = HLG; f[] = curve constants (colorspace.c:344-390)
+    PLH_OP_ICTCP_ENC,       //                                            (colorspace.c:495-524)
+    PLH_OP_GAMMA,           // color.rgb = f[0] ? pow(max(color.rgb, 0), f[0]) : 0 (colorspace.c:447-456)
+    // colour mapping (colorspace.c:1612-2024), four ops sharing `aux` = i_orig:
+    PLH_OP_RGB2IPT,         // f[0..8] = rgb2lms, f[9..13] = 203/10000, m1, c1, c2, c3; f[14] = m2
+    PLH_OP_TONE_MAP,        // i0 = mode (0 clip, 1 linear, 2 LUT); f[] see k; ptr = LUT; i1 = size
+    PLH_OP_GAMUT_LUT,       // ptr = rgba16 3-D LUT; i0,i1,i2 = sizes; f[0]=scale f[1]=offset f[2]=0.5/pi
+    PLH_OP_IPT2RGB,         // f[0..8] = lms2rgb, f[9..14] = 1/m2, c1, c2, c3, 1/m1, 10000/203
+    PLH_OP_PEAK_DETECT,     // see k_peak.hip; only valid in the 16x16 peak kernel
 };
+
+// flags in plh_op.i1 of LINEARIZE / DELINEARIZE / PEAK_DETECT
+#define PLH_TRC_CLAMP0   1  // color.rgb = max(color.rgb, 0)
+#define PLH_TRC_RESCALE  2  // linearize: scale_out; delinearize: black-scaling prologue
 
 #define PLH_OP_NF 16
 struct plh_op {

@@ -248,9 +248,73 @@ done:
     return ok;
 }
 
+int plh_launch_errdiff(plh_stream stream, const struct plh_errdiff_args *args);
+
 bool pl_dispatch_compute(pl_dispatch dp, const struct pl_dispatch_compute_params *params)
 {
-    pl_msg(dp->log, PL_LOG_ERR, "pl_dispatch_compute: no standalone compute shaders yet");
+    pl_shader sh = *params->shader;
+    bool ok = false;
+
+    if (sh->failed) {
+        pl_msg(dp->log, PL_LOG_ERR, "Trying to dispatch a failed shader.");
+        goto done;
+    }
+    if (sh->input != PL_SHADER_SIG_NONE) {
+        pl_msg(dp->log, PL_LOG_ERR, "Trying to dispatch shader with incompatible signature!");
+        goto done;
+    }
+    if (!pl_shader_is_compute(sh)) {
+        pl_msg(dp->log, PL_LOG_ERR, "Trying to dispatch a non-compute shader using "
+               "`pl_dispatch_compute`!");
+        goto done;
+    }
+
+    struct pass_timing *timing = get_timing(dp, sh);
+    pl_timer timer = params->timer ? params->timer : timing ? timing->timer : NULL;
+    int err;
+
+    if (sh->kind == PLH_SHADER_ERROR_DIFFUSION) {
+        if (timer)
+            plh_timer_begin(dp->gpu, timer);
+        err = plh_launch_errdiff(plh_gpu_stream(dp->gpu), sh->errdiff);
+        if (timer)
+            plh_timer_end(dp->gpu, timer);
+    } else {
+        // targetless pass (e.g. sample + peak detection): the rendering area
+        // must be given, results leave through side buffers only
+        if (!params->width || !params->height) {
+            pl_msg(dp->log, PL_LOG_ERR, "Trying to dispatch a targetless compute shader "
+                   "that uses vertex attributes, this requires specifying the size of the "
+                   "effective rendering area!");
+            goto done;
+        }
+        struct plh_pass *pass = &sh->pass;
+        memset(&pass->dst, 0, sizeof(pass->dst)); // every store is out of bounds
+        pass->width = params->width;
+        pass->height = params->height;
+        pass->out_scale[0] = 1.0 / params->width;
+        pass->out_scale[1] = 1.0 / params->height;
+        pass->base_x = pass->base_y = 0;
+        pass->dir_x = pass->dir_y = 1;
+        pass->transpose = 0;
+        pass->frag_x0 = pass->frag_y0 = 0;
+        if (timer)
+            plh_timer_begin(dp->gpu, timer);
+        err = plh_launch_pass(plh_gpu_stream(dp->gpu), pass);
+        if (timer)
+            plh_timer_end(dp->gpu, timer);
+    }
+
+    if (err) {
+        pl_msg(dp->log, PL_LOG_ERR, "Failed launching compute shader '%s': %s",
+               sh->description, plh_strerror(err));
+        goto done;
+    }
+    if (!params->timer)
+        drain_timing(dp, timing);
+    ok = true;
+
+done:
     pl_dispatch_abort(dp, params->shader);
-    return false;
+    return ok;
 }

@@ -1,0 +1,1007 @@
+/*
+ * libplacebo-hip — colour stages: host half of src/shaders/colorspace.c.
+ *
+ * Every function records the op(s) whose device code lives in
+ * csrc/hip/{transfer,colormap}.hiph / k_peak.hip, computing the constants the
+ * way the reference embeds them into GLSL:
+ *   SH_FLOAT(x)  -> the float itself
+ *   "%f" printf  -> plh_fmtf(x): 6-decimal rounding (PQ / HLG / log constants!)
+ *   GLSL constant expressions (1.0/2.4, vec3(1.0/C)) -> folded in fp32
+ *
+ *   pl_shader_set_alpha            colorspace.c:26-49
+ *   pl_shader_decode/encode_color  :275-573
+ *   pl_shader_linearize/delinearize:589-847
+ *   pl_shader_sigmoidize/un        :851-894
+ *   pl_shader_detect_peak + host reduction  :1020-1381
+ *   pl_shader_color_map_ex         :1612-2024
+ */
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <libplacebo/shaders/colorspace.h>
+
+#include "shaders_priv.h"
+#include "colorspace_priv.h"
+
+#define MIXF(a, b, x) ((x) * (b) + (1 - (x)) * (a))
+
+const struct pl_sigmoid_params pl_sigmoid_default_params = { PL_SIGMOID_DEFAULTS };
+const struct pl_peak_detect_params pl_peak_detect_default_params = { PL_PEAK_DETECT_DEFAULTS };
+const struct pl_peak_detect_params pl_peak_detect_high_quality_params = { PL_PEAK_DETECT_HQ_DEFAULTS };
+const struct pl_color_map_params pl_color_map_default_params = { PL_COLOR_MAP_DEFAULTS };
+const struct pl_color_map_params pl_color_map_high_quality_params = { PL_COLOR_MAP_HQ_DEFAULTS };
+
+static struct plh_op *simple_op(pl_shader sh, int kind, const char *listing)
+{
+    struct plh_op *op = sh_op(sh, kind);
+    if (op)
+        sh_listf(sh, "%s\n", listing);
+    return op;
+}
+
+/* ------------------------------------------------------------------------ */
+
+void pl_shader_set_alpha(pl_shader sh, struct pl_color_repr *repr, enum pl_alpha_mode mode)
+{
+    const bool src_has_alpha = repr->alpha == PL_ALPHA_INDEPENDENT ||
+                               repr->alpha == PL_ALPHA_PREMULTIPLIED;
+    const bool dst_not_premul = mode == PL_ALPHA_INDEPENDENT || mode == PL_ALPHA_NONE;
+
+    if (repr->alpha == PL_ALPHA_PREMULTIPLIED && dst_not_premul) {
+        simple_op(sh, PLH_OP_UNPREMULTIPLY, "unpremultiply()");
+        repr->alpha = PL_ALPHA_INDEPENDENT;
+    }
+    if (repr->alpha == PL_ALPHA_INDEPENDENT && mode == PL_ALPHA_PREMULTIPLIED) {
+        simple_op(sh, PLH_OP_PREMULTIPLY, "premultiply()");
+        repr->alpha = PL_ALPHA_PREMULTIPLIED;
+    }
+    if (src_has_alpha && mode == PL_ALPHA_NONE) {
+        simple_op(sh, PLH_OP_ALPHA_ONE, "alpha_one()");
+        repr->alpha = PL_ALPHA_NONE;
+    }
+}
+
+static void op_affine(pl_shader sh, const pl_transform3x3 *tr, const char *what)
+{
+    struct plh_op *op = sh_op(sh, PLH_OP_AFFINE);
+    if (!op)
+        return;
+    for (int i = 0; i < 3; i++) {
+        for (int j = 0; j < 3; j++)
+            op->f[3 * i + j] = tr->mat.m[i][j];
+        op->f[9 + i] = tr->c[i];
+    }
+    sh_listf(sh, "affine(%s: [%g %g %g; %g %g %g; %g %g %g] + [%g %g %g])\n", what,
+             op->f[0], op->f[1], op->f[2], op->f[3], op->f[4], op->f[5],
+             op->f[6], op->f[7], op->f[8], op->f[9], op->f[10], op->f[11]);
+}
+
+static void ictcp_constants(struct plh_op *op, bool hlg)
+{
+    op->i0 = hlg;
+    if (!hlg) {
+        const float m1 = plh_fmtf(PQ_M1), m2 = plh_fmtf(PQ_M2);
+        op->f[0] = 1.0f / m2; op->f[1] = plh_fmtf(PQ_C1); op->f[2] = plh_fmtf(PQ_C2);
+        op->f[3] = plh_fmtf(PQ_C3); op->f[4] = 1.0f / m1;
+        op->f[5] = m1; op->f[6] = op->f[1]; op->f[7] = op->f[2]; op->f[8] = op->f[3];
+        op->f[9] = m2;
+    } else {
+        const float A = plh_fmtf(HLG_A), B = plh_fmtf(HLG_B), C = plh_fmtf(HLG_C);
+        op->f[5] = C; op->f[6] = 1.0f / A; op->f[7] = B;
+        op->f[8] = A; op->f[9] = B; op->f[10] = C;
+    }
+}
+
+void pl_shader_decode_color(pl_shader sh, struct pl_color_repr *repr,
+                            const struct pl_color_adjustment *params)
+{
+    if (!sh_require(sh, PL_SHADER_SIG_COLOR, 0, 0))
+        return;
+    if (repr->sys == PL_COLOR_SYSTEM_DOLBYVISION) {
+        SH_FAIL(sh, "Dolby Vision reshaping is not supported by the HIP backend");
+        return;
+    }
+
+    sh_describef(sh, "color decoding");
+    const enum pl_color_system orig_sys = repr->sys;
+    const pl_transform3x3 tr = pl_color_repr_decode(repr, params);
+    if (memcmp(&tr, &pl_transform3x3_identity, sizeof(tr)))
+        op_affine(sh, &tr, "decode");
+
+    switch (orig_sys) {
+    case PL_COLOR_SYSTEM_BT_2020_C:
+        simple_op(sh, PLH_OP_BT2020C_DEC, "bt2020c_decode()");
+        break;
+    case PL_COLOR_SYSTEM_BT_2100_PQ:
+    case PL_COLOR_SYSTEM_BT_2100_HLG: {
+        struct plh_op *op = simple_op(sh, PLH_OP_ICTCP_DEC, "ictcp_decode()");
+        if (op)
+            ictcp_constants(op, orig_sys == PL_COLOR_SYSTEM_BT_2100_HLG);
+        break;
+    }
+    default:
+        break;
+    }
+
+    if (params && params->gamma == 0) {
+        struct plh_op *op = simple_op(sh, PLH_OP_GAMMA, "gamma(0)");
+        if (op)
+            op->f[0] = 0.0f;
+    } else if (params && params->gamma != 1) {
+        struct plh_op *op = simple_op(sh, PLH_OP_GAMMA, "gamma()");
+        if (op)
+            op->f[0] = 1 / params->gamma;
+    }
+
+    pl_shader_set_alpha(sh, repr, PL_ALPHA_INDEPENDENT);
+}
+
+void pl_shader_encode_color(pl_shader sh, const struct pl_color_repr *repr)
+{
+    if (!sh_require(sh, PL_SHADER_SIG_COLOR, 0, 0))
+        return;
+    if (repr->sys == PL_COLOR_SYSTEM_DOLBYVISION) {
+        SH_FAIL(sh, "Cannot un-apply dolbyvision yet (no inverse reshaping)!");
+        return;
+    }
+
+    sh_describef(sh, "color encoding");
+    if (repr->alpha == PL_ALPHA_PREMULTIPLIED)
+        simple_op(sh, PLH_OP_PREMULTIPLY, "premultiply()");
+
+    switch (repr->sys) {
+    case PL_COLOR_SYSTEM_BT_2020_C:
+        simple_op(sh, PLH_OP_BT2020C_ENC, "bt2020c_encode()");
+        break;
+    case PL_COLOR_SYSTEM_BT_2100_PQ:
+    case PL_COLOR_SYSTEM_BT_2100_HLG: {
+        struct plh_op *op = simple_op(sh, PLH_OP_ICTCP_ENC, "ictcp_encode()");
+        if (op)
+            ictcp_constants(op, repr->sys == PL_COLOR_SYSTEM_BT_2100_HLG);
+        break;
+    }
+    default:
+        break;
+    }
+
+    // skip the matrix when it is the identity by construction
+    bool skip = true;
+    skip &= PL_DEF(repr->sys, PL_COLOR_SYSTEM_RGB) == PL_COLOR_SYSTEM_RGB;
+    skip &= PL_DEF(repr->levels, PL_COLOR_LEVELS_FULL) == PL_COLOR_LEVELS_FULL;
+    skip &= !repr->bits.sample_depth || !repr->bits.color_depth ||
+             repr->bits.sample_depth == repr->bits.color_depth;
+    skip &= !repr->bits.bit_shift;
+    if (!skip) {
+        struct pl_color_repr copy = *repr;
+        pl_transform3x3 tr = pl_color_repr_decode(&copy, NULL);
+        pl_transform3x3_invert(&tr);
+        op_affine(sh, &tr, "encode");
+    }
+}
+
+/* ------------------------------------------------------------------------ */
+/* transfer functions                                                        */
+
+static void nominal_norm(const struct pl_color_space *csp, float *min, float *max)
+{
+    pl_color_space_nominal_luma_ex(pl_nominal_luma_params(
+        .color = csp, .metadata = PL_HDR_METADATA_HDR10, .scaling = PL_HDR_NORM,
+        .out_min = min, .out_max = max,
+    ));
+}
+
+static void luma_coeffs(const struct pl_color_space *csp, float out[3])
+{
+    const pl_matrix3x3 rgb2xyz = pl_get_rgb2xyz_matrix(pl_raw_primaries_get(csp->primaries));
+    out[0] = rgb2xyz.m[1][0];
+    out[1] = rgb2xyz.m[1][1];
+    out[2] = rgb2xyz.m[1][2];
+}
+
+static float gamma_of(enum pl_color_transfer trc)
+{
+    switch (trc) {
+    case PL_COLOR_TRC_GAMMA18: return 1.8f;
+    case PL_COLOR_TRC_GAMMA20: return 2.0f;
+    case PL_COLOR_TRC_GAMMA24: return 2.4f;
+    case PL_COLOR_TRC_GAMMA26: return 2.6f;
+    case PL_COLOR_TRC_GAMMA28: return 2.8f;
+    default:                   return 2.2f; // UNKNOWN, GAMMA22
+    }
+}
+
+// Fills op->i0/i1/f[] for a linearize stage (shared with peak detection)
+void plh_fill_linearize(struct plh_op *op, const struct pl_color_space *csp)
+{
+    const enum pl_color_transfer trc = csp->transfer;
+    float csp_min, csp_max;
+    nominal_norm(csp, &csp_min, &csp_max);
+
+    float *f = op->f;
+    op->i0 = trc;
+    op->i1 = trc != PL_COLOR_TRC_SCRGB ? PLH_TRC_CLAMP0 : 0;
+    bool scale_out = true;
+
+    switch (trc) {
+    case PL_COLOR_TRC_BT_1886:
+        plh_bt1886_params(csp_min, csp_max, &f[2], &f[3]);
+        scale_out = false;
+        break;
+    case PL_COLOR_TRC_UNKNOWN:
+    case PL_COLOR_TRC_GAMMA18: case PL_COLOR_TRC_GAMMA20: case PL_COLOR_TRC_GAMMA22:
+    case PL_COLOR_TRC_GAMMA24: case PL_COLOR_TRC_GAMMA26: case PL_COLOR_TRC_GAMMA28:
+        f[2] = gamma_of(trc);
+        break;
+    case PL_COLOR_TRC_PQ: {
+        const float m2 = plh_fmtf(PQ_M2), m1 = plh_fmtf(PQ_M1);
+        f[2] = 1.0f / m2;
+        f[3] = plh_fmtf(PQ_C1); f[4] = plh_fmtf(PQ_C2); f[5] = plh_fmtf(PQ_C3);
+        f[6] = 1.0f / m1;
+        f[7] = plh_fmtf(10000.0 / PL_COLOR_SDR_WHITE);
+        scale_out = false;
+        break;
+    }
+    case PL_COLOR_TRC_HLG: {
+        float y, b;
+        plh_hlg_params(csp_min, csp_max, &y, &b);
+        f[2] = 1 - b; f[3] = b;
+        f[4] = plh_fmtf(HLG_C); f[5] = 1.0f / plh_fmtf(HLG_A); f[6] = plh_fmtf(HLG_B);
+        f[7] = csp_max;
+        luma_coeffs(csp, &f[8]);
+        f[11] = y - 1;
+        scale_out = false;
+        break;
+    }
+    case PL_COLOR_TRC_V_LOG:
+        f[2] = plh_fmtf(VLOG_D); f[3] = 1.0f / plh_fmtf(VLOG_C); f[4] = plh_fmtf(VLOG_B);
+        scale_out = false;
+        break;
+    case PL_COLOR_TRC_S_LOG1:
+        f[2] = plh_fmtf(SLOG_C); f[3] = 1.0f / plh_fmtf(SLOG_A); f[4] = plh_fmtf(SLOG_B);
+        scale_out = false;
+        break;
+    case PL_COLOR_TRC_S_LOG2:
+        f[2] = plh_fmtf(SLOG_Q); f[3] = 1.0f / plh_fmtf(SLOG_P); f[4] = plh_fmtf(SLOG_C);
+        f[5] = 1.0f / plh_fmtf(SLOG_A); f[6] = plh_fmtf(SLOG_B);
+        f[7] = 1.0f / plh_fmtf(SLOG_K2); f[8] = plh_fmtf(SLOG_Q);
+        scale_out = false;
+        break;
+    case PL_COLOR_TRC_SCRGB:
+        f[2] = plh_fmtf(PL_COLOR_SCRGB_WHITE / PL_COLOR_SDR_WHITE);
+        scale_out = false;
+        break;
+    default: // SRGB, PRO_PHOTO, ST428: literal constants in the kernel
+        break;
+    }
+
+    if (scale_out && (csp_max != 1 || csp_min != 0)) {
+        op->i1 |= PLH_TRC_RESCALE;
+        f[0] = csp_max - csp_min;
+        f[1] = csp_min;
+    }
+}
+
+void pl_shader_linearize(pl_shader sh, const struct pl_color_space *csp)
+{
+    if (!sh_require(sh, PL_SHADER_SIG_COLOR, 0, 0))
+        return;
+    if (csp->transfer == PL_COLOR_TRC_LINEAR)
+        return;
+
+    struct plh_op *op = sh_op(sh, PLH_OP_LINEARIZE);
+    if (!op)
+        return;
+    plh_fill_linearize(op, csp);
+    sh_listf(sh, "linearize(%s)\n", pl_color_transfer_name(csp->transfer));
+}
+
+void pl_shader_delinearize(pl_shader sh, const struct pl_color_space *csp)
+{
+    if (!sh_require(sh, PL_SHADER_SIG_COLOR, 0, 0))
+        return;
+    const enum pl_color_transfer trc = csp->transfer;
+    if (trc == PL_COLOR_TRC_LINEAR)
+        return;
+
+    float csp_min, csp_max;
+    nominal_norm(csp, &csp_min, &csp_max);
+
+    struct plh_op *op = sh_op(sh, PLH_OP_DELINEARIZE);
+    if (!op)
+        return;
+    float *f = op->f;
+    op->i0 = trc;
+    op->i1 = trc != PL_COLOR_TRC_SCRGB ? PLH_TRC_CLAMP0 : 0;
+    if (pl_color_space_is_black_scaled(csp) && trc != PL_COLOR_TRC_HLG &&
+        (csp_max != 1 || csp_min != 0)) {
+        op->i1 |= PLH_TRC_RESCALE;
+        f[0] = 1 / (csp_max - csp_min);
+        f[1] = -csp_min / (csp_max - csp_min);
+    }
+
+    switch (trc) {
+    case PL_COLOR_TRC_BT_1886: {
+        float a, b;
+        plh_bt1886_params(csp_min, csp_max, &a, &b);
+        f[2] = 1.0 / a;
+        f[3] = b;
+        break;
+    }
+    case PL_COLOR_TRC_UNKNOWN:
+    case PL_COLOR_TRC_GAMMA18: case PL_COLOR_TRC_GAMMA20: case PL_COLOR_TRC_GAMMA22:
+    case PL_COLOR_TRC_GAMMA24: case PL_COLOR_TRC_GAMMA26: case PL_COLOR_TRC_GAMMA28:
+        f[2] = 1.0f / gamma_of(trc); // GLSL constant expression 1.0/2.2 etc.
+        break;
+    case PL_COLOR_TRC_PQ:
+        f[2] = 1.0f / plh_fmtf(10000 / PL_COLOR_SDR_WHITE);
+        f[3] = plh_fmtf(PQ_M1); f[4] = plh_fmtf(PQ_C1); f[5] = plh_fmtf(PQ_C2);
+        f[6] = plh_fmtf(PQ_C3); f[7] = plh_fmtf(PQ_M2);
+        break;
+    case PL_COLOR_TRC_HLG: {
+        float y, b;
+        plh_hlg_params(csp_min, csp_max, &y, &b);
+        f[2] = 1.0f / csp_max;
+        luma_coeffs(csp, &f[3]);
+        f[6] = (1 - y) / y;
+        f[7] = plh_fmtf(HLG_A); f[8] = plh_fmtf(HLG_B); f[9] = plh_fmtf(HLG_C);
+        f[10] = 1 / (1 - b);
+        f[11] = -b / (1 - b);
+        break;
+    }
+    case PL_COLOR_TRC_V_LOG:
+        f[2] = plh_fmtf(VLOG_C / M_LN10); f[3] = plh_fmtf(VLOG_B); f[4] = plh_fmtf(VLOG_D);
+        break;
+    case PL_COLOR_TRC_S_LOG1:
+        f[2] = plh_fmtf(SLOG_A / M_LN10); f[3] = plh_fmtf(SLOG_B); f[4] = plh_fmtf(SLOG_C);
+        break;
+    case PL_COLOR_TRC_S_LOG2:
+        f[2] = plh_fmtf(SLOG_P); f[3] = plh_fmtf(SLOG_Q); f[4] = plh_fmtf(SLOG_A / M_LN10);
+        f[5] = plh_fmtf(SLOG_K2); f[6] = plh_fmtf(SLOG_B); f[7] = plh_fmtf(SLOG_C);
+        break;
+    case PL_COLOR_TRC_SCRGB:
+        f[2] = plh_fmtf(PL_COLOR_SDR_WHITE / PL_COLOR_SCRGB_WHITE);
+        break;
+    default:
+        break;
+    }
+    sh_listf(sh, "delinearize(%s)\n", pl_color_transfer_name(trc));
+}
+
+void pl_shader_sigmoidize(pl_shader sh, const struct pl_sigmoid_params *params)
+{
+    if (!sh_require(sh, PL_SHADER_SIG_COLOR, 0, 0))
+        return;
+    params = PL_DEF(params, &pl_sigmoid_default_params);
+    const float center = PL_DEF(params->center, pl_sigmoid_default_params.center);
+    const float slope  = PL_DEF(params->slope, pl_sigmoid_default_params.slope);
+
+    // the curve must pass through (0,0) and (1,1)
+    const float offset = 1.0 / (1 + expf(slope * center));
+    const float scale  = 1.0 / (1 + expf(slope * (center - 1))) - offset;
+
+    struct plh_op *op = sh_op(sh, PLH_OP_SIGMOIDIZE);
+    if (!op)
+        return;
+    op->f[0] = center;
+    op->f[1] = 1.0 / slope;
+    op->f[2] = scale;
+    op->f[3] = offset;
+    sh_listf(sh, "sigmoidize(center=%g, slope=%g)\n", center, slope);
+}
+
+void pl_shader_unsigmoidize(pl_shader sh, const struct pl_sigmoid_params *params)
+{
+    if (!sh_require(sh, PL_SHADER_SIG_COLOR, 0, 0))
+        return;
+    params = PL_DEF(params, &pl_sigmoid_default_params);
+    const float center = PL_DEF(params->center, pl_sigmoid_default_params.center);
+    const float slope  = PL_DEF(params->slope, pl_sigmoid_default_params.slope);
+    const float offset = 1.0 / (1 + expf(slope * center));
+    const float scale  = 1.0 / (1 + expf(slope * (center - 1))) - offset;
+
+    struct plh_op *op = sh_op(sh, PLH_OP_UNSIGMOIDIZE);
+    if (!op)
+        return;
+    op->f[0] = 1.0 / scale;
+    op->f[1] = slope;
+    op->f[2] = center;
+    op->f[3] = offset / scale;
+    sh_listf(sh, "unsigmoidize(center=%g, slope=%g)\n", center, slope);
+}
+
+/* ------------------------------------------------------------------------ */
+/* peak detection                                                            */
+
+enum {
+    SLICES    = 12,
+    PQ_BITS   = 14,
+    PQ_MAX    = (1 << PQ_BITS) - 1,
+    HIST_BITS = 7,
+    HIST_BIAS = 1 << (HIST_BITS - 1),
+    HIST_BINS = (1 << HIST_BITS) - HIST_BIAS,
+};
+
+#define HIST_PQ(bin) (((bin) + HIST_BIAS) << (PQ_BITS - HIST_BITS))
+
+struct peak_buf_data {
+    unsigned frame_wg_count[SLICES];
+    unsigned frame_wg_active[SLICES];
+    unsigned frame_sum_pq[SLICES];
+    unsigned frame_max_pq[SLICES];
+    unsigned frame_hist[SLICES][HIST_BINS];
+};
+
+struct sh_color_map_obj {
+    struct {
+        struct pl_tone_map_params params;
+        pl_buf lut;
+        int lut_size;
+    } tone;
+
+    struct {
+        struct pl_gamut_map_params params;
+        pl_buf lut;
+        bool valid;
+    } gamut;
+
+    struct {
+        struct pl_peak_detect_params params;
+        pl_buf buf;         // pending measurement
+        pl_buf consts;      // per-pass constant block of the detect stage
+        float avg_pq, max_pq;
+    } peak;
+};
+
+static void sh_color_map_uninit(pl_gpu gpu, void *ptr)
+{
+    struct sh_color_map_obj *obj = ptr;
+    pl_buf_destroy(gpu, &obj->tone.lut);
+    pl_buf_destroy(gpu, &obj->gamut.lut);
+    pl_buf_destroy(gpu, &obj->peak.buf);
+    pl_buf_destroy(gpu, &obj->peak.consts);
+    memset(obj, 0, sizeof(*obj));
+}
+
+static bool peak_params_eq(const struct pl_peak_detect_params *a,
+                           const struct pl_peak_detect_params *b)
+{
+    // allow_delayed does not change the measurement
+    return a->smoothing_period == b->smoothing_period &&
+           a->scene_threshold_low == b->scene_threshold_low &&
+           a->scene_threshold_high == b->scene_threshold_high &&
+           a->percentile == b->percentile;
+}
+
+static inline float smoothstepf(float edge0, float edge1, float x)
+{
+    if (edge0 == edge1)
+        return x >= edge0;
+    x = (x - edge0) / (edge1 - edge0);
+    x = PL_CLAMP(x, 0.0f, 1.0f);
+    return x * x * (3.0f - 2.0f * x);
+}
+
+// Frame peak from the max / the percentile of the 64-bin histogram
+static float measure_peak(const struct peak_buf_data *data, float percentile)
+{
+    unsigned frame_max_pq = data->frame_max_pq[0];
+    for (int k = 1; k < SLICES; k++)
+        frame_max_pq = PL_MAX(frame_max_pq, data->frame_max_pq[k]);
+    const float frame_max = (float) frame_max_pq / PQ_MAX;
+    if (percentile <= 0 || percentile >= 100)
+        return frame_max;
+
+    unsigned total_pixels = 0;
+    for (int k = 0; k < SLICES; k++) {
+        for (int i = 0; i < HIST_BINS; i++)
+            total_pixels += data->frame_hist[k][i];
+    }
+    if (!total_pixels)
+        return frame_max;
+
+    const unsigned target_pixel = ceilf(percentile / 100.0f * total_pixels);
+    if (target_pixel >= total_pixels)
+        return frame_max;
+
+    unsigned sum = 0;
+    for (int i = 0; i < HIST_BINS; i++) {
+        unsigned next = sum;
+        for (int k = 0; k < SLICES; k++)
+            next += data->frame_hist[k][i];
+        if (next < target_pixel) {
+            sum = next;
+            continue;
+        }
+
+        // interpolate inside the bin that contains the target pixel
+        const unsigned count_low  = sum;
+        const unsigned count_high = next + 1;
+        const float pq_low = (float) HIST_PQ(i) / PQ_MAX;
+        float pq_high      = (float) HIST_PQ(i + 1) / PQ_MAX;
+        if (count_high > total_pixels)
+            pq_high = frame_max; // last occupied bin
+        const float ratio = (float) (target_pixel - count_low) / (count_high - count_low);
+        return MIXF(pq_low, pq_high, ratio);
+    }
+
+    return frame_max; // unreachable
+}
+
+// Read the pending measurement (if any) and fold it into the smoothed state
+static void update_peak_buf(pl_gpu gpu, struct sh_color_map_obj *obj, bool force)
+{
+    const struct pl_peak_detect_params *params = &obj->peak.params;
+    if (!obj->peak.buf)
+        return;
+    if (!force && params->allow_delayed && pl_buf_poll(gpu, obj->peak.buf, 0))
+        return;
+
+    struct peak_buf_data data = {0};
+    const bool ok = pl_buf_read(gpu, obj->peak.buf, 0, &data, sizeof(data));
+    if (ok && data.frame_wg_count[0] > 0) {
+        pl_buf_destroy(gpu, &obj->peak.buf);
+    } else {
+        if (!ok) {
+            pl_msg(gpu->log, PL_LOG_ERR, "Failed reading peak detection buffer!");
+        } else if (!params->allow_delayed) {
+            pl_msg(gpu->log, PL_LOG_WARN, "Peak detection usage error: attempted detecting "
+                   "peak and using detected peak in the same shader program, but "
+                   "`params->allow_delayed` is false! Ignoring, but expect incorrect output.");
+        }
+        if (force || !ok)
+            pl_buf_destroy(gpu, &obj->peak.buf);
+        return;
+    }
+
+    uint64_t frame_sum_pq = 0u, frame_wg_count = 0u, frame_wg_active = 0u;
+    for (int k = 0; k < SLICES; k++) {
+        frame_sum_pq    += data.frame_sum_pq[k];
+        frame_wg_count  += data.frame_wg_count[k];
+        frame_wg_active += data.frame_wg_active[k];
+    }
+
+    float avg_pq, max_pq;
+    if (frame_wg_active) {
+        avg_pq = (float) frame_sum_pq / (frame_wg_active * PQ_MAX);
+        max_pq = measure_peak(&data, params->percentile);
+    } else {
+        avg_pq = max_pq = PL_COLOR_HDR_BLACK; // solid black frame
+    }
+
+    if (!obj->peak.avg_pq) {
+        obj->peak.avg_pq = avg_pq;
+        obj->peak.max_pq = max_pq;
+    } else {
+        // ignore sub-LSB jitter
+        static const float epsilon = 1.0f / PQ_MAX;
+        if (fabsf(avg_pq - obj->peak.avg_pq) < epsilon)
+            avg_pq = obj->peak.avg_pq;
+        if (fabsf(max_pq - obj->peak.max_pq) < epsilon)
+            max_pq = obj->peak.max_pq;
+    }
+
+    // IIR low-pass
+    const float coeff = params->smoothing_period ? 1.0f - expf(-1.0f / params->smoothing_period)
+                                                 : 1.0f;
+    obj->peak.avg_pq += coeff * (avg_pq - obj->peak.avg_pq);
+    obj->peak.max_pq += coeff * (max_pq - obj->peak.max_pq);
+
+    // scene change: snap towards the new measurement
+    if (params->scene_threshold_low > 0 && params->scene_threshold_high > 0) {
+        const float log10_pq = 1e-2f;
+        const float thresh_low = params->scene_threshold_low * log10_pq;
+        const float thresh_high = params->scene_threshold_high * log10_pq;
+        const float bias = (float) frame_wg_active / frame_wg_count;
+        const float delta = bias * fabsf(avg_pq - obj->peak.avg_pq);
+        const float mix_coeff = smoothstepf(thresh_low, thresh_high, delta);
+        obj->peak.avg_pq = MIXF(obj->peak.avg_pq, avg_pq, mix_coeff);
+        obj->peak.max_pq = MIXF(obj->peak.max_pq, max_pq, mix_coeff);
+    }
+}
+
+bool pl_shader_detect_peak(pl_shader sh, struct pl_color_space csp, pl_shader_obj *state,
+                           const struct pl_peak_detect_params *params)
+{
+    params = PL_DEF(params, &pl_peak_detect_default_params);
+    if (!sh_require(sh, PL_SHADER_SIG_COLOR, 0, 0))
+        return false;
+
+    pl_gpu gpu = SH_GPU(sh);
+    if (!gpu) {
+        pl_msg(sh->log, PL_LOG_ERR, "HDR peak detection requires a GPU");
+        return false;
+    }
+    if (sh->pass.s.type == PLH_SAMPLE_POLAR || sh->pass.s.type == PLH_SAMPLE_ORTHO ||
+        sh->pass.s.type == PLH_SAMPLE_DEBAND) {
+        // those samplers own the workgroup shape; measure in a separate pass
+        pl_msg(sh->log, PL_LOG_ERR, "pl_shader_detect_peak cannot be merged into a "
+               "polar/ortho/deband pass on the HIP backend (materialise it first)");
+        return false;
+    }
+
+    const bool use_histogram = params->percentile > 0 && params->percentile < 100;
+    size_t shmem_req = 3 * sizeof(uint32_t);
+    if (use_histogram)
+        shmem_req += sizeof(uint32_t[HIST_BINS]);
+    if (!sh_try_compute(sh, 16, 16, true, shmem_req))
+        return false;
+
+    struct sh_color_map_obj *obj = SH_OBJ(sh, state, PL_SHADER_OBJ_COLOR_MAP,
+                                          struct sh_color_map_obj, sh_color_map_uninit);
+    if (!obj)
+        return false;
+
+    if (peak_params_eq(&obj->peak.params, params)) {
+        update_peak_buf(gpu, obj, true); // consume the previous frame first
+    } else {
+        pl_reset_detected_peak(*state);
+    }
+
+    static const struct peak_buf_data zero = {0};
+    obj->peak.buf = pl_buf_create(gpu, pl_buf_params(
+        .size = sizeof(struct peak_buf_data), .host_readable = true, .storable = true,
+        .initial_data = &zero));
+    if (!obj->peak.buf) {
+        SH_FAIL(sh, "Failed creating peak detection SSBO!");
+        return false;
+    }
+    obj->peak.params = *params;
+
+    struct plh_op *op = sh_op(sh, PLH_OP_PEAK_DETECT);
+    if (!op)
+        return false;
+
+    // the measurement linearizes a *copy* of the colour
+    pl_color_space_infer(&csp);
+    if (csp.transfer != PL_COLOR_TRC_LINEAR) {
+        plh_fill_linearize(op, &csp);
+    } else {
+        op->i0 = PL_COLOR_TRC_LINEAR;
+    }
+    op->i2 = use_histogram;
+
+    float consts[16] = {0};
+    luma_coeffs(&csp, &consts[0]);
+    consts[3] = PL_COLOR_SDR_WHITE / 10000.0;
+    consts[4] = PQ_M1; consts[5] = PQ_C1; consts[6] = PQ_C2; consts[7] = PQ_C3; consts[8] = PQ_M2;
+    consts[9] = fmaxf(params->black_cutoff, 0.0f) * 1e-2f;
+    if (!obj->peak.consts) {
+        obj->peak.consts = pl_buf_create(gpu, pl_buf_params(.size = sizeof(consts),
+                                                            .storable = true));
+        if (!obj->peak.consts)
+            return false;
+    }
+    pl_buf_write(gpu, obj->peak.consts, 0, consts, sizeof(consts));
+    op->ptr2 = pl_hip_buf_ptr(obj->peak.consts);
+    sh->pass.peak_buf = pl_hip_buf_ptr(obj->peak.buf);
+    sh->detect_peak = true;
+    sh_hold(sh, *state);
+
+    sh_describef(sh, "peak detection");
+    sh_listf(sh, "detect_peak(trc=%s, histogram=%d, cutoff=%g)\n",
+             pl_color_transfer_name(csp.transfer), (int) use_histogram, consts[9]);
+    return true;
+}
+
+bool pl_get_detected_hdr_metadata(const pl_shader_obj state, struct pl_hdr_metadata *out)
+{
+    if (!state || state->type != PL_SHADER_OBJ_COLOR_MAP)
+        return false;
+
+    struct sh_color_map_obj *obj = state->priv;
+    update_peak_buf(state->gpu, obj, false);
+    if (!obj->peak.avg_pq)
+        return false;
+
+    out->max_pq_y = obj->peak.max_pq;
+    out->avg_pq_y = obj->peak.avg_pq;
+    return true;
+}
+
+void pl_reset_detected_peak(pl_shader_obj state)
+{
+    if (!state || state->type != PL_SHADER_OBJ_COLOR_MAP)
+        return;
+
+    struct sh_color_map_obj *obj = state->priv;
+    pl_buf consts = obj->peak.consts;
+    pl_buf_destroy(state->gpu, &obj->peak.buf);
+    memset(&obj->peak, 0, sizeof(obj->peak));
+    obj->peak.consts = consts;
+}
+
+void *pl_hip_peak_buffer(const pl_shader_obj state, size_t *out_size)
+{
+    if (!state || state->type != PL_SHADER_OBJ_COLOR_MAP)
+        return NULL;
+    struct sh_color_map_obj *obj = state->priv;
+    if (!obj->peak.buf)
+        return NULL;
+    if (out_size)
+        *out_size = sizeof(struct peak_buf_data);
+    return pl_hip_buf_ptr(obj->peak.buf);
+}
+
+/* ------------------------------------------------------------------------ */
+/* colour mapping                                                            */
+
+static void mat_to_f(float *f, const pl_matrix3x3 *m)
+{
+    for (int i = 0; i < 3; i++) {
+        for (int j = 0; j < 3; j++)
+            f[3 * i + j] = m->m[i][j];
+    }
+}
+
+// 48x32x256 IPT LUT -> rgba16 unorm with a +32767 chroma bias (fill_gamut_lut,
+// colorspace.c:1589-1610)
+static pl_buf make_gamut_lut(pl_gpu gpu, const struct pl_gamut_map_params *gamut)
+{
+    const size_t n = (size_t) gamut->lut_size_I * gamut->lut_size_C * gamut->lut_size_h;
+    float *tmp = malloc(n * 3 * sizeof(float));
+    uint16_t *packed = malloc(n * 4 * sizeof(uint16_t));
+    pl_buf buf = NULL;
+    if (tmp && packed) {
+        pl_gamut_map_generate(tmp, gamut);
+        const float *in = tmp;
+        uint16_t *out = packed;
+        for (size_t i = 0; i < n; i++) {
+            out[0] = roundf(in[0] * UINT16_MAX);
+            out[1] = roundf(in[1] * UINT16_MAX + (UINT16_MAX >> 1));
+            out[2] = roundf(in[2] * UINT16_MAX + (UINT16_MAX >> 1));
+            out[3] = 0;
+            in += 3;
+            out += 4;
+        }
+        buf = pl_buf_create(gpu, pl_buf_params(.size = n * 4 * sizeof(uint16_t),
+                                               .storable = true, .initial_data = packed));
+    }
+    free(tmp);
+    free(packed);
+    return buf;
+}
+
+void pl_shader_color_map_ex(pl_shader sh, const struct pl_color_map_params *params,
+                            const struct pl_color_map_args *args)
+{
+    if (!sh_require(sh, PL_SHADER_SIG_COLOR, 0, 0))
+        return;
+
+    pl_gpu gpu = SH_GPU(sh);
+    struct pl_color_space src = args->src, dst = args->dst;
+    struct sh_color_map_obj *obj = NULL;
+    if (args->state) {
+        pl_get_detected_hdr_metadata(*args->state, &src.hdr);
+        obj = SH_OBJ(sh, args->state, PL_SHADER_OBJ_COLOR_MAP, struct sh_color_map_obj,
+                     sh_color_map_uninit);
+        if (!obj)
+            return;
+    }
+
+    pl_color_space_infer_map(&src, &dst);
+    if (pl_color_space_equal(&src, &dst)) {
+        if (args->prelinearized)
+            pl_shader_delinearize(sh, &dst);
+        return;
+    }
+
+    params = PL_DEF(params, &pl_color_map_default_params);
+
+    struct pl_tone_map_params tone = {
+        .function       = PL_DEF(params->tone_mapping_function, &pl_tone_map_clip),
+        .constants      = params->tone_constants,
+        .param          = params->tone_mapping_param,
+        .input_scaling  = PL_HDR_PQ,
+        .output_scaling = PL_HDR_PQ,
+        .lut_size       = PL_DEF(params->lut_size, pl_color_map_default_params.lut_size),
+        .hdr            = src.hdr,
+    };
+
+    pl_color_space_nominal_luma_ex(pl_nominal_luma_params(
+        .color = &src, .metadata = params->metadata, .scaling = tone.input_scaling,
+        .out_min = &tone.input_min, .out_max = &tone.input_max, .out_avg = &tone.input_avg,
+    ));
+    pl_color_space_nominal_luma_ex(pl_nominal_luma_params(
+        .color = &dst, .metadata = PL_HDR_METADATA_HDR10, .scaling = tone.output_scaling,
+        .out_min = &tone.output_min, .out_max = &tone.output_max,
+    ));
+    pl_tone_map_params_infer(&tone);
+
+    // merge near-identical end points
+    if (fabs(tone.input_max - tone.output_max) < 1e-6)
+        tone.output_max = tone.input_max;
+    if (fabs(tone.input_min - tone.output_min) < 1e-6)
+        tone.output_min = tone.input_min;
+    if (!params->inverse_tone_mapping)
+        tone.output_max = PL_MIN(tone.output_max, tone.input_max);
+
+    const int *lut3d_def = pl_color_map_default_params.lut3d_size;
+    struct pl_gamut_map_params gamut = {
+        .function     = PL_DEF(params->gamut_mapping, &pl_gamut_map_clip),
+        .constants    = params->gamut_constants,
+        .input_gamut  = src.hdr.prim,
+        .output_gamut = dst.hdr.prim,
+        .lut_size_I   = PL_DEF(params->lut3d_size[0], lut3d_def[0]),
+        .lut_size_C   = PL_DEF(params->lut3d_size[1], lut3d_def[1]),
+        .lut_size_h   = PL_DEF(params->lut3d_size[2], lut3d_def[2]),
+        .lut_stride   = 3,
+    };
+
+    pl_color_space_nominal_luma_ex(pl_nominal_luma_params(
+        .color = &dst, .metadata = PL_HDR_METADATA_HDR10, .scaling = PL_HDR_PQ,
+        .out_min = &gamut.min_luma, .out_max = &gamut.max_luma,
+    ));
+
+    // without expansion, clip the target gamut to the source gamut
+    if (!params->gamut_expansion && gamut.function->bidirectional) {
+        if (pl_primaries_compatible(&gamut.input_gamut, &gamut.output_gamut))
+            gamut.output_gamut = pl_primaries_clip(&gamut.output_gamut, &gamut.input_gamut);
+    }
+
+    bool can_fast = !params->force_tone_mapping_lut;
+    if (!args->state) {
+        // no state object: only stateless methods
+        can_fast = true;
+        if (tone.function != &pl_tone_map_clip)
+            tone.function = &pl_tone_map_linear;
+        if (gamut.function != &pl_gamut_map_clip)
+            gamut.function = &pl_gamut_map_saturation;
+    }
+
+    const bool need_tone_map = !pl_tone_map_params_noop(&tone);
+    bool need_gamut_map = !pl_gamut_map_params_noop(&gamut);
+
+    if (!args->prelinearized)
+        pl_shader_linearize(sh, &src);
+
+    pl_matrix3x3 rgb2lms = pl_ipt_rgb2lms(pl_raw_primaries_get(src.primaries));
+    pl_matrix3x3 lms2rgb = pl_ipt_lms2rgb(pl_raw_primaries_get(dst.primaries));
+
+    if (need_gamut_map && gamut.function == &pl_gamut_map_saturation && can_fast) {
+        const pl_matrix3x3 lms2src = pl_ipt_lms2rgb(&gamut.input_gamut);
+        const pl_matrix3x3 dst2lms = pl_ipt_rgb2lms(&gamut.output_gamut);
+        sh_describef(sh, "gamut map (saturation)");
+        pl_matrix3x3_mul(&lms2rgb, &dst2lms);
+        pl_matrix3x3_mul(&lms2rgb, &lms2src);
+        need_gamut_map = false;
+    }
+
+    if (!need_tone_map && !need_gamut_map) {
+        // fast path: a single 3x3
+        if (src.primaries != dst.primaries) {
+            sh_describef(sh, "colorspace conversion");
+            pl_matrix3x3_mul(&lms2rgb, &rgb2lms);
+            const pl_transform3x3 tr = { .mat = lms2rgb };
+            op_affine(sh, &tr, "primaries");
+        }
+        goto done;
+    }
+
+    // ---- full path through IPT ------------------------------------------------------
+    struct plh_op *op = sh_op(sh, PLH_OP_RGB2IPT);
+    if (!op)
+        return;
+    mat_to_f(op->f, &rgb2lms);
+    op->f[9]  = plh_fmtf(PL_COLOR_SDR_WHITE / 10000);
+    op->f[10] = plh_fmtf(PQ_M1); op->f[11] = plh_fmtf(PQ_C1); op->f[12] = plh_fmtf(PQ_C2);
+    op->f[13] = plh_fmtf(PQ_C3); op->f[14] = plh_fmtf(PQ_M2);
+    sh_listf(sh, "rgb2ipt()\n");
+
+    if (need_tone_map) {
+        const struct pl_tone_map_function *fun = tone.function;
+        sh_describef(sh, "%s tone map (%.0f -> %.0f)", fun->name,
+                     pl_hdr_rescale(PL_HDR_PQ, PL_HDR_NITS, tone.input_max),
+                     pl_hdr_rescale(PL_HDR_PQ, PL_HDR_NITS, tone.output_max));
+
+        op = sh_op(sh, PLH_OP_TONE_MAP);
+        if (!op)
+            return;
+        if (fun == &pl_tone_map_clip && can_fast) {
+            op->i0 = 0;
+            op->f[0] = tone.input_min;
+            op->f[1] = tone.input_max;
+        } else if (fun == &pl_tone_map_linear && can_fast) {
+            const float gain = tone.constants.exposure;
+            const float scale = tone.input_max - tone.input_min;
+            op->i0 = 1;
+            op->f[0] = gain / scale;
+            op->f[1] = -gain / scale * tone.input_min;
+            op->f[2] = tone.output_max - tone.output_min;
+            op->f[3] = tone.output_min;
+        } else {
+            if (!obj) {
+                SH_FAIL(sh, "Tone-mapping LUT requires a state object");
+                return;
+            }
+            const bool update = !obj->tone.lut || obj->tone.lut_size != (int) tone.lut_size ||
+                                !pl_tone_map_params_equal(&tone, &obj->tone.params);
+            if (update) {
+                float *lut = malloc(tone.lut_size * sizeof(float));
+                if (!lut)
+                    return;
+                pl_tone_map_generate(lut, &tone);
+                if (!obj->tone.lut || obj->tone.lut_size != (int) tone.lut_size) {
+                    pl_buf_destroy(gpu, &obj->tone.lut);
+                    obj->tone.lut = pl_buf_create(gpu, pl_buf_params(
+                        .size = tone.lut_size * sizeof(float), .storable = true,
+                        .initial_data = lut));
+                } else {
+                    pl_buf_write(gpu, obj->tone.lut, 0, lut, tone.lut_size * sizeof(float));
+                }
+                free(lut);
+                obj->tone.lut_size = tone.lut_size;
+            }
+            obj->tone.params = tone;
+            if (!obj->tone.lut) {
+                SH_FAIL(sh, "Failed generating tone-mapping LUT!");
+                return;
+            }
+            const float lut_range = tone.input_max - tone.input_min;
+            op->i0 = 2;
+            op->i1 = tone.lut_size;
+            op->f[0] = 1.0f / lut_range;
+            op->f[1] = -tone.input_min / lut_range;
+            op->ptr = pl_hip_buf_ptr(obj->tone.lut);
+        }
+        sh_listf(sh, "tone_map(%s, mode=%d, in=[%g,%g] avg=%g, out=[%g,%g])\n", fun->name,
+                 op->i0, tone.input_min, tone.input_max, tone.input_avg, tone.output_min,
+                 tone.output_max);
+    }
+
+    if (need_gamut_map) {
+        if (!obj) {
+            SH_FAIL(sh, "Gamut-mapping LUT requires a state object");
+            return;
+        }
+        sh_describef(sh, "gamut map (%s)", gamut.function->name);
+        if (!obj->gamut.valid || !obj->gamut.lut ||
+            !pl_gamut_map_params_equal(&gamut, &obj->gamut.params)) {
+            pl_buf_destroy(gpu, &obj->gamut.lut);
+            obj->gamut.lut = make_gamut_lut(gpu, &gamut);
+            obj->gamut.params = gamut;
+            obj->gamut.valid = !!obj->gamut.lut;
+        }
+        if (!obj->gamut.lut) {
+            SH_FAIL(sh, "Failed generating gamut-mapping LUT!");
+            return;
+        }
+
+        op = sh_op(sh, PLH_OP_GAMUT_LUT);
+        if (!op)
+            return;
+        const float lut_range = gamut.max_luma - gamut.min_luma;
+        op->i0 = gamut.lut_size_I;
+        op->i1 = gamut.lut_size_C;
+        op->i2 = gamut.lut_size_h;
+        op->f[0] = 1.0f / lut_range;
+        op->f[1] = -gamut.min_luma / lut_range;
+        op->f[2] = plh_fmtf(0.5f / M_PI);
+        op->ptr = pl_hip_buf_ptr(obj->gamut.lut);
+        sh_listf(sh, "gamut_lut(%s, %dx%dx%d)\n", gamut.function->name, op->i0, op->i1, op->i2);
+    }
+
+    op = sh_op(sh, PLH_OP_IPT2RGB);
+    if (!op)
+        return;
+    mat_to_f(op->f, &lms2rgb);
+    op->f[9]  = 1.0f / plh_fmtf(PQ_M2);
+    op->f[10] = plh_fmtf(PQ_C1); op->f[11] = plh_fmtf(PQ_C2); op->f[12] = plh_fmtf(PQ_C3);
+    op->f[13] = 1.0f / plh_fmtf(PQ_M1);
+    op->f[14] = plh_fmtf(10000 / PL_COLOR_SDR_WHITE);
+    sh_listf(sh, "ipt2rgb()\n");
+    if (args->state)
+        sh_hold(sh, *args->state);
+
+done:
+    pl_shader_delinearize(sh, &dst);
+}
+
+void pl_shader_color_map(pl_shader sh, const struct pl_color_map_params *params,
+                         struct pl_color_space src, struct pl_color_space dst,
+                         pl_shader_obj *state, bool prelinearized)
+{
+    pl_shader_color_map_ex(sh, params, pl_color_map_args(
+        .src = src, .dst = dst, .prelinearized = prelinearized, .state = state,
+    ));
+}

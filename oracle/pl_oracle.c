@@ -762,3 +762,448 @@ ORC_API double orc_ewa_resample_r32f(const struct orc_filter *f, const float *sr
     }
     return taps / ((double) dw * dh);
 }
+
+/* ======================================================================== */
+/* K8 / K9: transfer functions and sigmoid (src/shaders/colorspace.c:589-894) */
+/*                                                                            */
+/* GLSL constants: SH_FLOAT(x) embeds the float exactly, but many constants   */
+/* are printed with "%f" (6 decimals) — pf() reproduces that rounding.        */
+/* pow/exp/log are libm here; the GPU uses native approximations, so these    */
+/* stages are compared within a tolerance (tests/test_gpu_color.py).          */
+
+#include <stdio.h>
+
+static float pf(double v)
+{
+    char buf[64];
+    snprintf(buf, sizeof(buf), "%f", v);
+    return strtof(buf, NULL);
+}
+
+enum { T_UNKNOWN = 0, T_BT1886, T_SRGB, T_LINEAR, T_G18, T_G20, T_G22, T_G24, T_G26, T_G28,
+       T_PROPHOTO, T_ST428, T_PQ, T_HLG, T_VLOG, T_SLOG1, T_SLOG2, T_SCRGB };
+
+static const float O_PQ_M1 = 2610./4096 * 1./4, O_PQ_M2 = 2523./4096 * 128,
+                   O_PQ_C1 = 3424./4096, O_PQ_C2 = 2413./4096 * 32, O_PQ_C3 = 2392./4096 * 32;
+static const float O_HLG_A = 0.17883277, O_HLG_B = 0.28466892, O_HLG_C = 0.55991073;
+static const float O_VLOG_B = 0.00873, O_VLOG_C = 0.241514, O_VLOG_D = 0.598206;
+static const float O_SLOG_A = 0.432699, O_SLOG_B = 0.037584, O_SLOG_C = 0.616596 + 0.03,
+                   O_SLOG_P = 3.538813, O_SLOG_Q = 0.030001, O_SLOG_K2 = 155.0 / 219.0;
+
+static float trc_gamma(int trc)
+{
+    switch (trc) {
+    case T_G18: return 1.8f; case T_G20: return 2.0f; case T_G24: return 2.4f;
+    case T_G26: return 2.6f; case T_G28: return 2.8f; default: return 2.2f;
+    }
+}
+
+static int black_scaled(int trc)
+{
+    switch (trc) {
+    case T_BT1886: case T_PQ: case T_SCRGB: case T_VLOG: case T_SLOG1: case T_SLOG2: return 0;
+    default: return 1;
+    }
+}
+
+// pl_shader_linearize, colorspace.c:589-720. csp_min/max = nominal luma (NORM).
+ORC_API void orc_linearize(float *img, size_t npix, int trc, float csp_min, float csp_max,
+                           const float luma[3])
+{
+    if (trc == T_LINEAR)
+        return;
+    for (size_t i = 0; i < npix; i++) {
+        float *c = img + i * 4;
+        if (trc != T_SCRGB) {
+            for (int k = 0; k < 3; k++)
+                c[k] = fmaxf(c[k], 0.0f);                                  // :613
+        }
+        int scale_out = 1;
+        switch (trc) {
+        case T_SRGB:                                                        // :617-620
+            for (int k = 0; k < 3; k++)
+                c[k] = 0.04045f < c[k] ? powf((c[k] + 0.055f) / 1.055f, 2.4f)
+                                       : c[k] * (1.0f / 12.92f);
+            break;
+        case T_BT1886: {                                                    // :622-629
+            const float lb = powf(csp_min, 1 / 2.4f), lw = powf(csp_max, 1 / 2.4f);
+            const float a = powf(lw - lb, 2.4f), b = lb / (lw - lb);
+            for (int k = 0; k < 3; k++)
+                c[k] = a * powf(c[k] + b, 2.4f);
+            scale_out = 0;
+            break;
+        }
+        case T_UNKNOWN: case T_G18: case T_G20: case T_G22: case T_G24: case T_G26: case T_G28:
+            for (int k = 0; k < 3; k++)
+                c[k] = powf(c[k], trc_gamma(trc));                         // :631-649
+            break;
+        case T_PROPHOTO:                                                    // :651-653
+            for (int k = 0; k < 3; k++)
+                c[k] = 0.03125f < c[k] ? powf(c[k], 1.8f) : c[k] * (1.0f / 16.0f);
+            break;
+        case T_ST428:                                                       // :656
+            for (int k = 0; k < 3; k++)
+                c[k] = (52.37f / 48.0f) * powf(c[k], 2.6f);
+            break;
+        case T_PQ: {                                                        // :659-666
+            const float im2 = 1.0f / pf(O_PQ_M2), c1 = pf(O_PQ_C1), c2 = pf(O_PQ_C2),
+                        c3 = pf(O_PQ_C3), im1 = 1.0f / pf(O_PQ_M1), k10 = pf(10000.0 / 203.0f);
+            for (int k = 0; k < 3; k++) {
+                float v = powf(c[k], im2);
+                v = fmaxf(v - c1, 0.0f) / (c2 - c3 * v);
+                v = powf(v, im1);
+                c[k] = v * k10;
+            }
+            scale_out = 0;
+            break;
+        }
+        case T_HLG: {                                                       // :668-683
+            const float y = 1.2f * powf(1.111f, log2f(csp_max / (1000.0f / 203.0f)));
+            const float b = sqrtf(3 * powf(csp_min / csp_max, 1 / y));
+            const float hc = pf(O_HLG_C), ia = 1.0f / pf(O_HLG_A), hb = pf(O_HLG_B);
+            for (int k = 0; k < 3; k++) {
+                float v = (1 - b) * c[k] + b;
+                v = 0.5f < v ? expf((v - hc) * ia) + hb : 4.0f * v * v;
+                c[k] = v * (1.0f / 12.0f);
+            }
+            const float l = luma[0] * c[0] + luma[1] * c[1] + luma[2] * c[2];
+            const float g = csp_max * powf(fmaxf(l, 0.0f), y - 1);
+            for (int k = 0; k < 3; k++)
+                c[k] *= g;
+            scale_out = 0;
+            break;
+        }
+        case T_VLOG:                                                        // :686-690
+            for (int k = 0; k < 3; k++)
+                c[k] = 0.181f <= c[k]
+                    ? powf(10.0f, (c[k] - pf(O_VLOG_D)) * (1.0f / pf(O_VLOG_C))) - pf(O_VLOG_B)
+                    : (c[k] - 0.125f) * (1.0f / 5.6f);
+            scale_out = 0;
+            break;
+        case T_SLOG1:                                                       // :693-695
+            for (int k = 0; k < 3; k++)
+                c[k] = powf(10.0f, (c[k] - pf(O_SLOG_C)) * (1.0f / pf(O_SLOG_A))) - pf(O_SLOG_B);
+            scale_out = 0;
+            break;
+        case T_SLOG2:                                                       // :698-702
+            for (int k = 0; k < 3; k++)
+                c[k] = pf(O_SLOG_Q) <= c[k]
+                    ? (powf(10.0f, (c[k] - pf(O_SLOG_C)) * (1.0f / pf(O_SLOG_A))) - pf(O_SLOG_B))
+                      * (1.0f / pf(O_SLOG_K2))
+                    : (c[k] - pf(O_SLOG_Q)) * (1.0f / pf(O_SLOG_P));
+            scale_out = 0;
+            break;
+        case T_SCRGB:                                                       // :705
+            for (int k = 0; k < 3; k++)
+                c[k] *= pf(80.0f / 203.0f);
+            scale_out = 0;
+            break;
+        }
+        if (scale_out && (csp_max != 1 || csp_min != 0)) {                  // :715-719
+            for (int k = 0; k < 3; k++)
+                c[k] = (csp_max - csp_min) * c[k] + csp_min;
+        }
+    }
+}
+
+// pl_shader_delinearize, colorspace.c:722-847
+ORC_API void orc_delinearize(float *img, size_t npix, int trc, float csp_min, float csp_max,
+                             const float luma[3])
+{
+    if (trc == T_LINEAR)
+        return;
+    for (size_t i = 0; i < npix; i++) {
+        float *c = img + i * 4;
+        if (black_scaled(trc) && trc != T_HLG && (csp_max != 1 || csp_min != 0)) {   // :740-747
+            const float m = 1 / (csp_max - csp_min), a = -csp_min / (csp_max - csp_min);
+            for (int k = 0; k < 3; k++)
+                c[k] = m * c[k] + a;
+        }
+        if (trc != T_SCRGB) {
+            for (int k = 0; k < 3; k++)
+                c[k] = fmaxf(c[k], 0.0f);                                  // :750
+        }
+        switch (trc) {
+        case T_SRGB:
+            for (int k = 0; k < 3; k++)
+                c[k] = 0.0031308f <= c[k] ? 1.055f * powf(c[k], 1.0f / 2.4f) - 0.055f
+                                          : c[k] * 12.92f;
+            break;
+        case T_BT1886: {
+            const float lb = powf(csp_min, 1 / 2.4f), lw = powf(csp_max, 1 / 2.4f);
+            const float a = powf(lw - lb, 2.4f), b = lb / (lw - lb);
+            const float ia = 1.0 / a;
+            for (int k = 0; k < 3; k++)
+                c[k] = powf(ia * c[k], 1.0f / 2.4f) - b;
+            break;
+        }
+        case T_UNKNOWN: case T_G18: case T_G20: case T_G22: case T_G24: case T_G26: case T_G28:
+            for (int k = 0; k < 3; k++)
+                c[k] = powf(c[k], 1.0f / trc_gamma(trc));
+            break;
+        case T_ST428:
+            for (int k = 0; k < 3; k++)
+                c[k] = powf(c[k] * (48.0f / 52.37f), 1.0f / 2.6f);
+            break;
+        case T_PROPHOTO:
+            for (int k = 0; k < 3; k++)
+                c[k] = 0.001953f <= c[k] ? powf(c[k], 1.0f / 1.8f) : c[k] * 16.0f;
+            break;
+        case T_PQ: {
+            const float ik = 1.0f / pf(10000 / 203.0f), m1 = pf(O_PQ_M1), c1 = pf(O_PQ_C1),
+                        c2 = pf(O_PQ_C2), c3 = pf(O_PQ_C3), m2 = pf(O_PQ_M2);
+            for (int k = 0; k < 3; k++) {
+                float v = c[k] * ik;
+                v = powf(v, m1);
+                v = (c1 + c2 * v) / (1.0f + c3 * v);
+                c[k] = powf(v, m2);
+            }
+            break;
+        }
+        case T_HLG: {
+            const float y = 1.2f * powf(1.111f, log2f(csp_max / (1000.0f / 203.0f)));
+            const float b = sqrtf(3 * powf(csp_min / csp_max, 1 / y));
+            const float imax = 1.0f / csp_max, ex = (1 - y) / y;
+            const float ha = pf(O_HLG_A), hb = pf(O_HLG_B), hc = pf(O_HLG_C);
+            const float m = 1 / (1 - b), a = -b / (1 - b);
+            for (int k = 0; k < 3; k++)
+                c[k] *= imax;
+            const float l = luma[0] * c[0] + luma[1] * c[1] + luma[2] * c[2];
+            const float g = 12.0f * powf(fmaxf(1e-6f, l), ex);
+            for (int k = 0; k < 3; k++) {
+                float v = c[k] * g;
+                v = 1.0f < v ? ha * logf(v - hb) + hc : 0.5f * sqrtf(v);
+                c[k] = m * v + a;
+            }
+            break;
+        }
+        case T_VLOG:
+            for (int k = 0; k < 3; k++)
+                c[k] = 0.01f <= c[k] ? pf(O_VLOG_C / M_LN10) * logf(c[k] + pf(O_VLOG_B)) + pf(O_VLOG_D)
+                                     : 5.6f * c[k] + 0.125f;
+            break;
+        case T_SLOG1:
+            for (int k = 0; k < 3; k++)
+                c[k] = pf(O_SLOG_A / M_LN10) * logf(c[k] + pf(O_SLOG_B)) + pf(O_SLOG_C);
+            break;
+        case T_SLOG2:
+            for (int k = 0; k < 3; k++)
+                c[k] = 0.0f <= c[k]
+                    ? pf(O_SLOG_A / M_LN10) * logf(pf(O_SLOG_K2) * c[k] + pf(O_SLOG_B)) + pf(O_SLOG_C)
+                    : pf(O_SLOG_P) * c[k] + pf(O_SLOG_Q);
+            break;
+        case T_SCRGB:
+            for (int k = 0; k < 3; k++)
+                c[k] *= pf(203.0f / 80.0f);
+            break;
+        }
+    }
+}
+
+// pl_shader_sigmoidize / unsigmoidize, colorspace.c:851-894
+ORC_API void orc_sigmoid(float *img, size_t npix, float center, float slope, int inverse)
+{
+    const float offset = 1.0 / (1 + expf(slope * center));
+    const float scale = 1.0 / (1 + expf(slope * (center - 1))) - offset;
+    const float inv_slope = 1.0 / slope, inv_scale = 1.0 / scale, off_scale = offset / scale;
+    for (size_t i = 0; i < npix; i++) {
+        float *c = img + i * 4;
+        for (int k = 0; k < 3; k++) {
+            const float v = clampf(c[k], 0.0f, 1.0f);
+            c[k] = inverse ? inv_scale / (1.0f + expf(slope * (center - v))) - off_scale
+                           : center - inv_slope * logf(1.0f / (v * scale + offset) - 1.0f);
+        }
+    }
+}
+
+// pl_shader_set_alpha pieces, colorspace.c:34-47
+ORC_API void orc_alpha(float *img, size_t npix, int mode)
+{
+    for (size_t i = 0; i < npix; i++) {
+        float *c = img + i * 4;
+        if (mode == 0) {        // premultiply
+            for (int k = 0; k < 3; k++) c[k] *= c[3];
+        } else if (mode == 1) { // un-premultiply
+            if (c[3] > 1e-6f)
+                for (int k = 0; k < 3; k++) c[k] /= c[3];
+        } else {                // alpha = 1
+            c[3] = 1.0f;
+        }
+    }
+}
+
+/* ======================================================================== */
+/* K10: peak detection (src/shaders/colorspace.c:1155-1353)                   */
+
+enum { O_SLICES = 12, O_HIST_BINS = 64, O_PQ_BITS = 14, O_HIST_BITS = 7,
+       O_HIST_BIAS = 1 << (O_HIST_BITS - 1) };
+
+struct orc_peak_buf {
+    uint32_t frame_wg_count[O_SLICES], frame_wg_active[O_SLICES];
+    uint32_t frame_sum_pq[O_SLICES], frame_max_pq[O_SLICES];
+    uint32_t frame_hist[O_SLICES][O_HIST_BINS];
+};
+
+// `img` holds the colour each compute invocation sees, INCLUDING the padding
+// invocations of edge workgroups: it must be ceil(w/16)*16 x ceil(h/16)*16
+// (the caller samples those positions like the pass does). `precise` selects
+// correctly rounded pow (double) instead of float libm.
+ORC_API void orc_detect_peak(const float *img, int pw, int ph, int trc, float csp_min,
+                             float csp_max, const float luma[3], float black_cutoff,
+                             int use_hist, struct orc_peak_buf *out)
+{
+    memset(out, 0, sizeof(*out));
+    const int nwx = pw / 16, nwy = ph / 16;
+    const float cutoff = fmaxf(black_cutoff, 0.0f) * 1e-2f;
+    for (int wy = 0; wy < nwy; wy++) {
+        for (int wx = 0; wx < nwx; wx++) {
+            const uint32_t wg_idx = wy * nwx + wx, slice = wg_idx % O_SLICES;
+            uint32_t wg_sum = 0, wg_max = 0, wg_black = 0, wg_hist[O_HIST_BINS] = {0};
+            for (int ly = 0; ly < 16; ly++) {
+                for (int lx = 0; lx < 16; lx++) {
+                    float c[4];
+                    memcpy(c, img + ((size_t) (wy * 16 + ly) * pw + wx * 16 + lx) * 4, 16);
+                    orc_linearize(c, 1, trc, csp_min, csp_max, luma);        // :1274-1275
+                    float l = luma[0] * c[0] + luma[1] * c[1] + luma[2] * c[2];
+                    l *= (float) (203.0f / 10000.0);                         // :1281
+                    l = powf(clampf(l, 0.0f, 1.0f), O_PQ_M1);
+                    l = (O_PQ_C1 + O_PQ_C2 * l) / (1.0f + O_PQ_C3 * l);
+                    l = powf(l, O_PQ_M2);
+                    if (cutoff) {                                            // :1286-1287
+                        const float t = clampf(l / cutoff, 0.0f, 1.0f);
+                        l *= t * t * (3.0f - 2.0f * t);
+                    }
+                    const uint32_t y_pq = (uint32_t) (16383.0f * l);         // :1288
+                    if (use_hist) {                                          // :1292-1294
+                        int bin = (int) y_pq >> (O_PQ_BITS - O_HIST_BITS);
+                        bin -= O_HIST_BIAS;
+                        bin = bin < 0 ? 0 : bin > O_HIST_BINS - 1 ? O_HIST_BINS - 1 : bin;
+                        wg_hist[bin]++;
+                    }
+                    wg_sum += y_pq;
+                    wg_max = y_pq > wg_max ? y_pq : wg_max;
+                    if (cutoff && y_pq == 0)
+                        wg_black++;
+                }
+            }
+            if (use_hist) {                                                  // :1329-1337
+                if (cutoff)
+                    wg_hist[0] -= wg_black;
+                for (int i = 0; i < O_HIST_BINS; i++)
+                    out->frame_hist[slice][i] += wg_hist[i];
+            }
+            const uint32_t num = 256 - wg_black;                             // :1340-1347
+            out->frame_wg_count[slice] += 1;
+            out->frame_wg_active[slice] += num < 1 ? num : 1;
+            if (num > 0) {
+                out->frame_sum_pq[slice] += wg_sum / num;
+                if (wg_max > out->frame_max_pq[slice])
+                    out->frame_max_pq[slice] = wg_max;
+            }
+        }
+    }
+}
+
+/* ======================================================================== */
+/* K11: colour mapping (src/shaders/colorspace.c:1791-1995)                    */
+
+struct orc_color_map {
+    float rgb2lms[9], lms2rgb[9];
+    int tone_mode;              // -1 none, 0 clip, 1 linear, 2 LUT
+    float tone_p[4];            // clip: min,max; linear: a,b,c,d; LUT: scale,offset
+    const float *tone_lut;
+    int tone_lut_size;
+    const uint16_t *gamut_lut;  // rgba16, NULL = none
+    int gamut_size[3];
+    float gamut_scale, gamut_offset;
+};
+
+static float o_lut1d(const float *lut, int n, float x)
+{
+    const float fpos = clampf(x, 0.0f, 1.0f) * (float) (n - 1);
+    const float fb = floorf(fpos), fc = ceilf(fpos);
+    return mixf(lut[(int) fb], lut[(int) fc], fpos - fb);
+}
+
+ORC_API void orc_color_map(float *img, size_t npix, const struct orc_color_map *m)
+{
+    const float k203 = pf(203.0f / 10000), m1 = pf(O_PQ_M1), m2 = pf(O_PQ_M2),
+                c1 = pf(O_PQ_C1), c2 = pf(O_PQ_C2), c3 = pf(O_PQ_C3),
+                im1 = 1.0f / pf(O_PQ_M1), im2 = 1.0f / pf(O_PQ_M2), k10 = pf(10000 / 203.0f),
+                hpi = pf(0.5f / M_PI);
+    for (size_t i = 0; i < npix; i++) {
+        float *c = img + i * 4;
+        // lms = rgb2lms * rgb; lmspq = PQ(k * lms); ipt = lms2ipt * lmspq         :1792-1799
+        float lms[3];
+        for (int r = 0; r < 3; r++)
+            lms[r] = m->rgb2lms[3*r] * c[0] + m->rgb2lms[3*r+1] * c[1] + m->rgb2lms[3*r+2] * c[2];
+        for (int r = 0; r < 3; r++) {
+            float v = powf(fmaxf(k203 * lms[r], 0.0f), m1);
+            v = (c1 + c2 * v) / (1.0f + c3 * v);
+            lms[r] = powf(v, m2);
+        }
+        float I = 0.4000f * lms[0] + 0.4000f * lms[1] + 0.2000f * lms[2];
+        float P = 4.4550f * lms[0] + -4.8510f * lms[1] + 0.3960f * lms[2];
+        float T = 0.8056f * lms[0] + 0.3572f * lms[1] + -1.1628f * lms[2];
+        const float i_orig = I;
+
+        if (m->tone_mode >= 0) {
+            switch (m->tone_mode) {
+            case 0: I = clampf(I, m->tone_p[0], m->tone_p[1]); break;            // :1826
+            case 1:                                                                // :1836-1842
+                I = m->tone_p[0] * I + m->tone_p[1];
+                I = clampf(I, 0.0f, 1.0f);
+                I = m->tone_p[2] * I + m->tone_p[3];
+                break;
+            default:                                                               // :1873
+                I = o_lut1d(m->tone_lut, m->tone_lut_size, m->tone_p[0] * I + m->tone_p[1]);
+            }
+            const float hx = ((i_orig - 6.0f) * i_orig + 9.0f) * i_orig;         // :1930-1932
+            const float hy = ((I - 6.0f) * I + 9.0f) * I;
+            const float k = fminf(i_orig / I, hy / hx);
+            P *= k;
+            T *= k;
+        }
+
+        if (m->gamut_lut) {                                                       // :1962-1967
+            const float idx[3] = { m->gamut_scale * I + m->gamut_offset,
+                                   2.0f * sqrtf(P * P + T * T),
+                                   hpi * atan2f(T, P) + 0.5f };
+            int i0[3], i1[3];
+            float fr[3];
+            for (int k = 0; k < 3; k++) {
+                const float pos = clampf(idx[k], 0.0f, 1.0f) * (float) (m->gamut_size[k] - 1);
+                const float fl = floorf(pos);
+                i0[k] = (int) fl;
+                i1[k] = i0[k] + 1 < m->gamut_size[k] ? i0[k] + 1 : m->gamut_size[k] - 1;
+                fr[k] = pos - fl;
+            }
+            const int sx = m->gamut_size[0], sy = m->gamut_size[1];
+#define GT(x, y, z, ch) (m->gamut_lut[(((size_t) (z) * sy + (y)) * sx + (x)) * 4 + (ch)] / 65535.0f)
+            float o[3];
+            for (int ch = 0; ch < 3; ch++) {
+                const float c00 = mixf(GT(i0[0], i0[1], i0[2], ch), GT(i1[0], i0[1], i0[2], ch), fr[0]);
+                const float c10 = mixf(GT(i0[0], i1[1], i0[2], ch), GT(i1[0], i1[1], i0[2], ch), fr[0]);
+                const float c01 = mixf(GT(i0[0], i0[1], i1[2], ch), GT(i1[0], i0[1], i1[2], ch), fr[0]);
+                const float c11 = mixf(GT(i0[0], i1[1], i1[2], ch), GT(i1[0], i1[1], i1[2], ch), fr[0]);
+                o[ch] = mixf(mixf(c00, c10, fr[1]), mixf(c01, c11, fr[1]), fr[2]);
+            }
+#undef GT
+            I = o[0];
+            P = o[1] - 32768.0f / 65535.0f;
+            T = o[2] - 32768.0f / 65535.0f;
+        }
+
+        // back to linear RGB                                                      :1985-1995
+        float l3[3] = { 1.0f * I + 0.0975689f * P + 0.205226f * T,
+                        1.0f * I + -0.1138760f * P + 0.133217f * T,
+                        1.0f * I + 0.0326151f * P + -0.676887f * T };
+        for (int r = 0; r < 3; r++) {
+            float v = powf(fmaxf(l3[r], 0.0f), im2);
+            v = fmaxf(v - c1, 0.0f) / (c2 - c3 * v);
+            l3[r] = powf(v, im1) * k10;
+        }
+        for (int r = 0; r < 3; r++)
+            c[r] = m->lms2rgb[3*r] * l3[0] + m->lms2rgb[3*r+1] * l3[1] + m->lms2rgb[3*r+2] * l3[2];
+    }
+}

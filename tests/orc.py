@@ -175,3 +175,80 @@ def ref():
     if _ref is None:
         _ref = C.CDLL(REF_SO)
     return _ref
+
+
+# ---- colour stages -----------------------------------------------------------------
+def _luma(l):
+    return (C.c_float * 3)(*(l if l is not None else (0.2126, 0.7152, 0.0722)))
+
+
+def linearize(img, trc, csp_min, csp_max, luma=None):
+    lib().orc_linearize(_p(img), C.c_size_t(img.size // 4), trc, C.c_float(csp_min),
+                        C.c_float(csp_max), _luma(luma))
+    return img
+
+
+def delinearize(img, trc, csp_min, csp_max, luma=None):
+    lib().orc_delinearize(_p(img), C.c_size_t(img.size // 4), trc, C.c_float(csp_min),
+                          C.c_float(csp_max), _luma(luma))
+    return img
+
+
+def sigmoid(img, center=0.75, slope=6.5, inverse=False):
+    lib().orc_sigmoid(_p(img), C.c_size_t(img.size // 4), C.c_float(center), C.c_float(slope),
+                      int(inverse))
+    return img
+
+
+def alpha(img, mode):
+    lib().orc_alpha(_p(img), C.c_size_t(img.size // 4), mode)
+    return img
+
+
+def op_affine(img, m9, c3):
+    lib().orc_op_affine(_p(img), C.c_size_t(img.size // 4), (C.c_float * 9)(*m9),
+                        (C.c_float * 3)(*c3))
+    return img
+
+
+class PeakBuf(C.Structure):
+    _fields_ = [("frame_wg_count", C.c_uint32 * 12), ("frame_wg_active", C.c_uint32 * 12),
+                ("frame_sum_pq", C.c_uint32 * 12), ("frame_max_pq", C.c_uint32 * 12),
+                ("frame_hist", (C.c_uint32 * 64) * 12)]
+
+
+def detect_peak(img_padded, trc, csp_min, csp_max, luma, black_cutoff=1.0, use_hist=False):
+    img = np.ascontiguousarray(img_padded, np.float32)
+    ph, pw = img.shape[:2]
+    assert pw % 16 == 0 and ph % 16 == 0
+    out = PeakBuf()
+    lib().orc_detect_peak(_p(img), pw, ph, trc, C.c_float(csp_min), C.c_float(csp_max),
+                          _luma(luma), C.c_float(black_cutoff), int(use_hist), C.byref(out))
+    return np.frombuffer(bytes(out), np.uint32).copy()
+
+
+class ColorMap(C.Structure):
+    _fields_ = [("rgb2lms", C.c_float * 9), ("lms2rgb", C.c_float * 9), ("tone_mode", C.c_int),
+                ("tone_p", C.c_float * 4), ("tone_lut", C.c_void_p), ("tone_lut_size", C.c_int),
+                ("gamut_lut", C.c_void_p), ("gamut_size", C.c_int * 3),
+                ("gamut_scale", C.c_float), ("gamut_offset", C.c_float)]
+
+
+def color_map(img, rgb2lms, lms2rgb, tone_mode=-1, tone_p=(0, 0, 0, 0), tone_lut=None,
+              gamut_lut=None, gamut_size=(48, 32, 256), gamut_scale=0.0, gamut_offset=0.0):
+    cm = ColorMap(tone_mode=tone_mode, gamut_scale=gamut_scale, gamut_offset=gamut_offset)
+    cm.rgb2lms = (C.c_float * 9)(*rgb2lms)
+    cm.lms2rgb = (C.c_float * 9)(*lms2rgb)
+    cm.tone_p = (C.c_float * 4)(*tone_p)
+    keep = []
+    if tone_lut is not None:
+        tl = np.ascontiguousarray(tone_lut, np.float32)
+        keep.append(tl)
+        cm.tone_lut, cm.tone_lut_size = tl.ctypes.data, tl.size
+    if gamut_lut is not None:
+        gl = np.ascontiguousarray(gamut_lut, np.uint16)
+        keep.append(gl)
+        cm.gamut_lut = gl.ctypes.data
+        cm.gamut_size = (C.c_int * 3)(*gamut_size)
+    lib().orc_color_map(_p(img), C.c_size_t(img.size // 4), C.byref(cm))
+    return img
