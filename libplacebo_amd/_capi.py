@@ -20,7 +20,7 @@ def load():
         raise BuildError(
             f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
             "(or `make -C libplacebo_amd/csrc`). There is no Python/CPU fallback.")
-    return C.CDLL(LIB_PATH, mode=C.RTLD_GLOBAL)
+    return C.CDLL(LIB_PATH)  # RTLD_LOCAL: never interpose on the checker libraries
 
 
 # ---- common.h ---------------------------------------------------------------

@@ -20,7 +20,8 @@ pytestmark = pytest.mark.skipif(not orc.have_ref(), reason="oracle/_ref not buil
 
 @pytest.fixture(scope="module")
 def libs(built):
-    return declare(orc.ref()), declare(pl.lib())
+    # a private handle of the product, so these raw struct bindings never clash with _capi's
+    return declare(orc.ref()), declare(C.CDLL(capi.LIB_PATH))
 
 
 def bits_equal(a, b):
@@ -42,6 +43,7 @@ class RefFilter(C.Structure):
 def test_every_filter_config_lut_bit_identical(libs):
     ref, our = libs
     ref.pl_filter_generate.restype = C.POINTER(RefFilter)
+    our.pl_filter_generate.restype = C.POINTER(capi.Filter)
     n = C.c_int.in_dll(ref, "pl_num_filter_configs").value
     assert n == C.c_int.in_dll(our, "pl_num_filter_configs").value
     RA = (C.POINTER(capi.FilterConfig) * (n + 1)).in_dll(ref, "pl_filter_configs")
