@@ -58,6 +58,42 @@ DEV float4_t tile_get(const tile_px<float> &t)
     return c;
 }
 
+
+// fcoord / base texel of output pixel (idx, idy) — the one place this is spelled
+DEV void polar_coord(const plh_pass &p, int idx, int idy, float &fcx, float &fcy,
+                     int &bx, int &by)
+{
+    const plh_sampler_args &s = p.s;
+    const float mx = p.out_scale[0] * ((float) idx + 0.5f);
+    const float my = p.out_scale[1] * ((float) idy + 0.5f);
+    const float px = plh_attr(s.pos, 0, mx, my);
+    const float py = plh_attr(s.pos, 1, mx, my);
+    const float tx = px * (float) s.src.w - 0.5f, ty = py * (float) s.src.h - 0.5f;
+    const float flx = __builtin_floorf(tx), fly = __builtin_floorf(ty);
+    fcx = tx - flx;
+    fcy = ty - fly;
+    bx = (int) flx;
+    by = (int) fly;
+}
+
+// weight of one tap for a given fcoord (0 when the tap is skipped)
+template <typename LUT>
+DEV float polar_weight(const plh_sampler_args &s, const LUT lut, uint32_t tap,
+                       float fcx, float fcy, float &d, bool &live)
+{
+    const int x = (int8_t) (tap & 0xff), y = (int8_t) ((tap >> 8) & 0xff);
+    const uint32_t fl = tap >> 16;
+    const float dx = (float) x - fcx, dy = (float) y - fcy;
+    d = __builtin_sqrtf(dx * dx + dy * dy);                     // length()
+    live = !(fl & PLH_TAP_SKIPPABLE) || d < s.radius;
+    // w = lut(d / R): linear LUT lookup, lut.c:700-715 semantics
+    const float fpos = plh_clamp(d * s.rcp_radius, 0.0f, 1.0f) * 255.0f;
+    const float fbase = __builtin_floorf(fpos);
+    const float2 l = lut[(int) fbase];
+    const float w = plh_mix(l.x, l.y, fpos - fbase);
+    return live ? w : 0.0f;     // adding zeros == skipping the tap
+}
+
 struct ar_state {
     float ar[4][2], wwsum[4][2];
 };
@@ -152,16 +188,9 @@ void k_polar(const plh_pass p_)
             const int x = (int8_t) (tap & 0xff), y = (int8_t) ((tap >> 8) & 0xff);
             const uint32_t fl = tap >> 16;
 
-            const float dx = (float) x - fcx, dy = (float) y - fcy;
-            const float d = __builtin_sqrtf(dx * dx + dy * dy);     // length()
-            const bool live = !(fl & PLH_TAP_SKIPPABLE) || d < s.radius;
-
-            // w = lut(d / R): linear LUT lookup, lut.c:700-715 semantics
-            const float fpos = plh_clamp(d * s.rcp_radius, 0.0f, 1.0f) * 255.0f;
-            const float fbase = __builtin_floorf(fpos);
-            const float2 l = lut[(int) fbase];
-            float w = plh_mix(l.x, l.y, fpos - fbase);
-            w = live ? w : 0.0f;   // adding zeros == skipping the tap
+            float d;
+            bool live;
+            const float w = polar_weight(s, lut, tap, fcx, fcy, d, live);
             wsum += w;
 
             const float4_t c = tile_get(tp[y * tw + x]);
@@ -225,6 +254,332 @@ void k_polar(const plh_pass p_)
     }
 }
 
+
+/* ------------------------------------------------------------------------------------
+ * Phase-class formulation (struct plh_polar_pp, plh_device.h)
+ *
+ * The per-pixel path above spends ~35 VALU instructions per tap on the weight
+ * (IEEE sqrt, LUT address, lerp) and 5 on the accumulation, which makes it
+ * ALU-bound at ~3 % of the HBM roofline. But the weight of a tap is a pure
+ * function of fcoord, fcoord.x only depends on the output column and fcoord.y
+ * on the row, and only a few dozen distinct fp32 values of each occur per
+ * frame. So the weights are tabulated once per (class pair, tap) — by
+ * k_polar_weights, with the *same* device arithmetic (polar_weight) — and the
+ * frame kernel keeps only the FMAs: a lane owns an n x n block of output pixels
+ * that share one base texel (n = 2 for a 2x upscale), reads each source texel of
+ * the footprint once from LDS and feeds it to the n*n accumulators with weights
+ * fetched from an LDS copy of the tile's slice of the table.
+ *
+ * Exactness: every lane still evaluates its own fcoord/base (polar_coord) and
+ * compares them with the tables; a pixel that disagrees (a rounding tie in the
+ * degenerate bilinear attribute interpolation) takes the per-pixel path
+ * inline. Summation order, fma usage and the final `scale / wsum` are those of
+ * k_polar, so results are bit-identical to it.
+ */
+__global__ void k_polar_classify(const plh_pass p_, float *out)
+{
+    const plh_pass &p = plh_kernarg_pass();
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    float *colfc = out;
+    int *colbase = (int *) (out + p.width);
+    float *rowfc = out + 2 * p.width;
+    int *rowbase = (int *) (out + 2 * p.width + p.height);
+    float fcx, fcy;
+    int bx, by;
+    if (i < p.width) {
+        polar_coord(p, i, 0, fcx, fcy, bx, by);
+        colfc[i] = fcx;
+        colbase[i] = bx;
+    }
+    if (i < p.height) {
+        polar_coord(p, 0, i, fcx, fcy, bx, by);
+        rowfc[i] = fcy;
+        rowbase[i] = by;
+    }
+}
+
+__global__ void k_polar_weights(const plh_pass p_, const float *clsx, int ncx,
+                                const float *clsy, int ncy, float *weights)
+{
+    const plh_pass &p = plh_kernarg_pass();
+    const plh_sampler_args &s = p.s;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= ncx * ncy)
+        return;
+    const int cy = i / ncx, cx = i - cy * ncx;
+    const float fcx = clsx[cx], fcy = clsy[cy];
+    float *w = weights + (size_t) i * (s.num_taps + 1);
+    float wsum = 0.0f;
+    for (int t = 0; t < s.num_taps; t++) {
+        float d;
+        bool live;
+        const float wt = polar_weight(s, (const float2 *) s.lut, s.taps[t], fcx, fcy, d, live);
+        wsum += wt;
+        w[t] = wt;
+    }
+    w[s.num_taps] = s.scale / wsum;     // color = scale / wsum * color, sampling.c:897
+}
+
+// Uniform read-only tables are read through the constant address space so that
+// they become s_load_* (SGPR) instead of per-lane flat loads in the tap loop.
+#define PLH_CONST(T, ptr) ((const T __attribute__((address_space(4))) *) (uintptr_t) (ptr))
+
+typedef _Float16 half4_t __attribute__((ext_vector_type(4)));
+typedef float floatv4_t __attribute__((ext_vector_type(4)));
+
+DEV floatv4_t tile_vec(const tile_px<__half> &t)
+{
+    const half4_t h = *(const half4_t *) &t;
+    // written as conversions feeding fmas so that they fold into v_fma_mix_f32
+    return __builtin_convertvector(h, floatv4_t);
+}
+
+DEV floatv4_t tile_vec(const tile_px<float> &t)
+{
+    return *(const floatv4_t *) &t;
+}
+
+// the per-pixel weights path for one pixel, on the staged tile (no anti-ringing)
+template <typename T, uint32_t MASK>
+DEV void polar_pixel_generic(const plh_sampler_args &s, const float2 *lut, const tile_px<T> *tp,
+                             int tw, float fcx, float fcy, float col[4], float &norm)
+{
+    float wsum = 0.0f;
+    col[0] = col[1] = col[2] = col[3] = 0.0f;
+    for (int t = 0; t < s.num_taps; t++) {
+        const uint32_t tap = s.taps[t];
+        const int x = (int8_t) (tap & 0xff), y = (int8_t) ((tap >> 8) & 0xff);
+        float d;
+        bool live;
+        const float w = polar_weight(s, lut, tap, fcx, fcy, d, live);
+        wsum += w;
+        const float4_t c = tile_get(tp[y * tw + x]);
+        const float cv[4] = { c.x, c.y, c.z, c.w };
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            if (MASK & (1u << k))
+                col[k] = __builtin_fmaf(w, cv[k], col[k]);
+        }
+    }
+    norm = s.scale / wsum;
+}
+
+template <typename T, uint32_t MASK, int N>
+__global__ __launch_bounds__(POLAR_BW * POLAR_BH)
+void k_polar_pp(const plh_pass p_)
+{
+    const plh_pass &p = plh_kernarg_pass();
+    const plh_sampler_args &s = p.s;
+    const plh_polar_pp &pp = *s.pp;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    float2 *lut = (float2 *) smem;                              // 256 pairs = 2 KiB
+    float *ws = (float *) (smem + 256 * sizeof(float2));        // weight sub-table
+    tile_px<T> *tile = (tile_px<T> *) (smem + 256 * sizeof(float2) + s.pp_lds_weights);
+
+    const int tid = threadIdx.y * POLAR_BW + threadIdx.x;
+    const int rows = s.tile_rows;
+    const int tw = s.tile_w, th = s.tile_h;
+    const int ox = pp.colorg[blockIdx.x], oy = pp.roworg[blockIdx.y];
+    const int nx = pp.coln[blockIdx.x], ny = pp.rown[blockIdx.y];
+    const int tp = pp.tp, ntaps = pp.ntaps;
+
+    // ---- stage LUT pairs, the tile's slice of the weight table, the source tile ---------
+    for (int i = tid; i < 256; i += POLAR_BW * POLAR_BH)
+        lut[i] = ((const float2 *) s.lut)[i];
+    {
+        const uint16_t *cl = pp.collist + blockIdx.x * PLH_PP_LMAX;
+        const uint16_t *rl = pp.rowlist + blockIdx.y * PLH_PP_LMAX;
+        for (int ly = 0; ly < ny; ly++) {
+            const int gy = rl[ly];
+            for (int lx = threadIdx.y; lx < nx; lx += POLAR_BH) {
+                const float *src = pp.weights + ((size_t) gy * pp.ncx + cl[lx]) * tp;
+                float *dst = ws + (ly * nx + lx) * tp;
+                for (int t = threadIdx.x; t < tp; t += POLAR_BW)
+                    dst[t] = src[t];
+            }
+        }
+    }
+    for (int i = tid; i < tw * th; i += POLAR_BW * POLAR_BH) {
+        const int ty = i / tw, tx = i - ty * tw;
+        const int sx = plh_wrap(ox + tx, s.src.w, s.address_mode);
+        const int sy = plh_wrap(oy + ty, s.src.h, s.address_mode);
+        float4_t c = plh_fetch(s.src, sx, sy);
+        if (p.num_pre_ops) {
+            const frag_t fc = { (float) sx + 0.5f, (float) sy + 0.5f };
+            apply_ops(c, p.ops, 0, p.num_pre_ops, fc);
+        }
+        tile_put(tile[i], c);
+    }
+    __syncthreads();
+
+    // ---- per-lane column state ------------------------------------------------------------
+    const int cellx = blockIdx.x * POLAR_BW + threadIdx.x;
+    int colx[N];            // output columns of this lane (may lie outside the image)
+    int cwoff[N];           // offset of the column's class in the weight sub-table
+    float cfc[N];
+    int cbase;
+    {
+        int b = 0;
+#pragma unroll
+        for (int i = 0; i < N; i++) {
+            colx[i] = N * cellx - pp.padx + i;
+            const int xc = min(max(colx[i], 0), p.width - 1);
+            cwoff[i] = pp.colloc[xc] * tp;
+            cfc[i] = pp.colfc[xc];
+            // the lane's base texel: that of its first in-range column
+            if (i == 0 || colx[i - 1] < 0)
+                b = pp.colbase[xc];
+        }
+        cbase = b;
+    }
+
+#pragma unroll 1
+    for (int r = 0; r < rows; r++) {
+        const int celly = (blockIdx.y * rows + r) * POLAR_BH + threadIdx.y;
+        int rowy[N], rwoff[N];
+        float rfc[N];
+        int rbase = 0;
+#pragma unroll
+        for (int j = 0; j < N; j++) {
+            rowy[j] = N * celly - pp.pady + j;
+            const int yc = min(max(rowy[j], 0), p.height - 1);
+            rwoff[j] = pp.rowloc[yc] * nx * tp;
+            rfc[j] = pp.rowfc[yc];
+            if (j == 0 || rowy[j - 1] < 0)
+                rbase = pp.rowbase[yc];
+        }
+
+        // lanes of padding cells are clamped so their LDS reads stay inside the tile
+        const int relx = min(max(cbase - ox, s.bound - 1), tw - s.bound - 1);
+        const int rely = min(max(rbase - oy, s.bound - 1), th - s.bound - 1);
+        const tile_px<T> *tp0 = tile + rely * tw + relx;
+
+        floatv4_t acc[N][N];
+        const float *wp[N][N];
+#pragma unroll
+        for (int j = 0; j < N; j++) {
+#pragma unroll
+            for (int i = 0; i < N; i++) {
+                acc[j][i] = (floatv4_t) (0.0f);
+                wp[j][i] = ws + rwoff[j] + cwoff[i];
+            }
+        }
+
+        const auto *tapoff = PLH_CONST(int32_t, pp.tapoff);
+#pragma unroll 4
+        for (int t = 0; t < ntaps; t++) {
+            // byte offset of the tap inside the tile (host: (y * tile_w + x) * sizeof(texel))
+            const floatv4_t c = tile_vec(*(const tile_px<T> *) ((const char *) tp0 + tapoff[t]));
+#pragma unroll
+            for (int j = 0; j < N; j++) {
+#pragma unroll
+                for (int i = 0; i < N; i++) {
+                    const float w = wp[j][i][t];
+#pragma unroll
+                    for (int k = 0; k < 4; k++) {
+                        if (MASK & (1u << k))
+                            acc[j][i][k] = __builtin_fmaf(w, c[k], acc[j][i][k]);
+                    }
+                }
+            }
+        }
+
+        // ---- normalise, verify, post-ops, store ------------------------------------------
+        // (a rolled loop over the lane's n*n pixels: the post-ops are large)
+#pragma unroll 1
+        for (int q = 0; q < N * N; q++) {
+            floatv4_t a = acc[0][0];
+            const float *w = wp[0][0];
+            int idx = colx[0], idy = rowy[0];
+            float tfx = cfc[0], tfy = rfc[0];
+#pragma unroll
+            for (int j = 0; j < N; j++) {
+#pragma unroll
+                for (int i = 0; i < N; i++) {
+                    if (j * N + i == q) {
+                        a = acc[j][i]; w = wp[j][i];
+                        idx = colx[i]; idy = rowy[j];
+                        tfx = cfc[i]; tfy = rfc[j];
+                    }
+                }
+            }
+            if (idx < 0 || idy < 0 || idx >= p.width || idy >= p.height)
+                continue;
+            float col[4] = { a[0], a[1], a[2], a[3] };
+            float norm = w[ntaps];
+
+            float fcx, fcy;
+            int bx, by;
+            polar_coord(p, idx, idy, fcx, fcy, bx, by);
+            if (__float_as_uint(fcx) != __float_as_uint(tfx) ||
+                __float_as_uint(fcy) != __float_as_uint(tfy) || bx != cbase || by != rbase) {
+                // not the tabulated phase after all: per-pixel weights (the tile has one
+                // texel of slack per side for a base that is off by one)
+                const int rx = min(max(bx - ox, s.bound - 1), tw - s.bound - 1);
+                const int ry = min(max(by - oy, s.bound - 1), th - s.bound - 1);
+                polar_pixel_generic<T, MASK>(s, lut, tile + ry * tw + rx, tw, fcx, fcy, col, norm);
+            }
+
+            float4_t out = { norm * col[0], norm * col[1], norm * col[2], norm * col[3] };
+            if (!(MASK & 8u))
+                out.w = 1.0f;
+            const frag_t fc = { (float) (idx + p.frag_x0) + 0.5f, (float) (idy + p.frag_y0) + 0.5f };
+            apply_ops(out, p.ops, p.num_pre_ops, p.num_ops, fc);
+
+            // guarded store (dispatch.c:1126-1142)
+            const float gx = p.out_scale[0] * (float) idx, gy = p.out_scale[1] * (float) idy;
+            if (gx < 1.0f && gy < 1.0f) {
+                const int oxp = p.base_x + p.dir_x * (p.transpose ? idy : idx);
+                const int oyp = p.base_y + p.dir_y * (p.transpose ? idx : idy);
+                if (oxp >= 0 && oyp >= 0 && oxp < p.dst.w && oyp < p.dst.h)
+                    plh_store(p.dst, oxp, oyp, out);
+            }
+        }
+    }
+}
+
+template <typename T, uint32_t MASK>
+static int launch_pp(hipStream_t stream, const plh_pass *pass, dim3 grid, dim3 block, size_t shmem,
+                     int n)
+{
+    if (n == 2)
+        hipLaunchKernelGGL((k_polar_pp<T, MASK, 2>), grid, block, shmem, stream, *pass);
+    else
+        hipLaunchKernelGGL((k_polar_pp<T, MASK, 1>), grid, block, shmem, stream, *pass);
+    const hipError_t err = hipGetLastError();
+    return err == hipSuccess ? 0 : -(int) err;
+}
+
+template <typename T>
+static int launch_pp_mask(hipStream_t stream, const plh_pass *pass, dim3 grid, dim3 block,
+                          size_t shmem, int n)
+{
+    switch (pass->s.comp_mask & 0xf) {
+    case 0x1: return launch_pp<T, 0x1>(stream, pass, grid, block, shmem, n);
+    case 0x3: return launch_pp<T, 0x3>(stream, pass, grid, block, shmem, n);
+    case 0x7: return launch_pp<T, 0x7>(stream, pass, grid, block, shmem, n);
+    default:  return launch_pp<T, 0xf>(stream, pass, grid, block, shmem, n);
+    }
+}
+
+int plh_launch_polar_classify(plh_stream stream, const plh_pass *pass, void *out)
+{
+    const int n = pass->width > pass->height ? pass->width : pass->height;
+    hipLaunchKernelGGL(k_polar_classify, dim3((n + 255) / 256), dim3(256), 0,
+                       (hipStream_t) stream, *pass, (float *) out);
+    const hipError_t err = hipGetLastError();
+    return err == hipSuccess ? 0 : -(int) err;
+}
+
+int plh_launch_polar_weights(plh_stream stream, const plh_pass *pass, const float *clsx, int ncx,
+                             const float *clsy, int ncy, float *weights)
+{
+    hipLaunchKernelGGL(k_polar_weights, dim3((ncx * ncy + 63) / 64), dim3(64), 0,
+                       (hipStream_t) stream, *pass, clsx, ncx, clsy, ncy, weights);
+    const hipError_t err = hipGetLastError();
+    return err == hipSuccess ? 0 : -(int) err;
+}
+
 template <typename T, uint32_t MASK>
 static int launch_ar(hipStream_t stream, const plh_pass *pass, dim3 grid, dim3 block, size_t shmem)
 {
@@ -250,6 +605,19 @@ static int launch_mask(hipStream_t stream, const plh_pass *pass, dim3 grid, dim3
 int plh_launch_polar(hipStream_t stream, const plh_pass *pass)
 {
     const dim3 block(POLAR_BW, POLAR_BH);
+    if (pass->s.pp) {
+        const int n = pass->s.pp_n, cw = pass->s.pp_cells_w, ch = pass->s.pp_cells_h;
+        const int cth = POLAR_BH * pass->s.tile_rows;
+        const dim3 grid((cw + POLAR_BW - 1) / POLAR_BW, (ch + cth - 1) / cth);
+        const size_t px = pass->s.tile_fp32 ? sizeof(float4) : sizeof(uint2);
+        const size_t shmem = 256 * sizeof(float2) + pass->s.pp_lds_weights +
+                             (size_t) pass->s.tile_w * pass->s.tile_h * px;
+        if (shmem > 160 * 1024)
+            return -1000;
+        if (pass->s.tile_fp32)
+            return launch_pp_mask<float>(stream, pass, grid, block, shmem, n);
+        return launch_pp_mask<__half>(stream, pass, grid, block, shmem, n);
+    }
     const int th = POLAR_BH * pass->s.tile_rows;
     const dim3 grid((pass->width + POLAR_BW - 1) / POLAR_BW, (pass->height + th - 1) / th);
     const size_t px = pass->s.tile_fp32 ? sizeof(float4) : sizeof(uint2);

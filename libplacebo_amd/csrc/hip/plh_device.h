@@ -63,6 +63,31 @@ enum plh_address_mode {     // gpu.h pl_tex_address_mode
     ((uint32_t) ((uint8_t) (int8_t) (x)) | ((uint32_t) ((uint8_t) (int8_t) (y)) << 8) | \
      ((uint32_t) (fl) << 16))
 
+// POLAR phase-class tables (k_polar.hip, k_polar_pp): the weights of a polar tap
+// depend on the output pixel only through fcoord = fract(pos*size - 0.5). For an
+// axis-aligned rect fcoord.x is a function of the output column and fcoord.y of
+// the row, and over a whole frame only a few dozen distinct fp32 values occur
+// (2 canonical phases x fp32 rounding noise for a 2x upscale). The host builds,
+// once per geometry, the exact per-(class pair, tap) weights with the same device
+// arithmetic the per-pixel path uses; the kernel then only does the FMAs.
+#define PLH_PP_LMAX 16      // distinct classes per tile column / row
+struct plh_polar_pp {
+    int32_t n;              // output pixels per lane and axis (share one base texel)
+    int32_t padx, pady;     // cell c covers outputs [n*c - pad, n*c - pad + n)
+    int32_t cells_w, cells_h;
+    int32_t ncx, ncy;       // number of global classes per axis
+    int32_t ntaps;          // compacted tap count
+    int32_t tp;             // floats per class pair: ntaps weights + norm (+ padding)
+    const float *colfc, *rowfc;         // [width], [height]: fcoord of every column / row
+    const int32_t *colbase, *rowbase;   // base texel of every column / row
+    const uint8_t *colloc, *rowloc;     // class index local to the tile column / row
+    const uint16_t *collist, *rowlist;  // [tiles][PLH_PP_LMAX] local -> global class
+    const uint8_t *coln, *rown;         // [tiles] number of local classes
+    const int32_t *colorg, *roworg;     // [tiles] LDS tile origin (texels)
+    const float *weights;               // [ncy][ncx][tp]
+    const int32_t *tapoff;              // [ntaps] byte offset of the tap in the LDS tile
+};
+
 struct plh_sampler_args {
     int32_t type;           // enum plh_sampler
     struct plh_view src;
@@ -85,6 +110,9 @@ struct plh_sampler_args {
     int32_t tile_w, tile_h; // LDS tile (texels)
     int32_t tile_rows;      // output rows per lane (output tile = 32 x 8*rows)
     int32_t tile_fp32;      // tile kept as float4 instead of half4
+    const struct plh_polar_pp *pp;  // device; NULL = per-pixel weights
+    int32_t pp_lds_weights; // bytes of LDS for the staged weight sub-table
+    int32_t pp_n, pp_cells_w, pp_cells_h;   // host copies of pp->n, cells_w, cells_h
 
     // ORTHO: weights[256][row_stride] rows; N taps along `dir`
     const float *weights;   // device
@@ -175,6 +203,16 @@ typedef void *plh_stream;
 
 // returns 0 on success, a negative hipError otherwise
 int plh_launch_pass(plh_stream stream, const struct plh_pass *pass);
+
+// POLAR phase-class setup helpers (k_polar.hip). `out` = width floats (fcoord.x
+// of every output column on row 0), width ints (base texel), then height floats
+// and height ints for the rows (on column 0).
+int plh_launch_polar_classify(plh_stream stream, const struct plh_pass *pass, void *out);
+// weights[(cy * ncx + cx) * (num_taps + 1) + t] for every tap of pass->s.taps,
+// followed by the normalisation factor scale / wsum
+int plh_launch_polar_weights(plh_stream stream, const struct plh_pass *pass,
+                             const float *clsx, int ncx, const float *clsy, int ncy,
+                             float *weights);
 
 #ifdef __cplusplus
 }

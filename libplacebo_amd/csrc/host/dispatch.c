@@ -227,6 +227,9 @@ bool pl_dispatch_finish(pl_dispatch dp, const struct pl_dispatch_params *params)
     pass->transpose = sh->transpose;
     pass->frag_x0 = pass->frag_y0 = 0; // compute passes: rect-relative gl_FragCoord
 
+    if (pass->s.type == PLH_SAMPLE_POLAR && sh->polar_obj)
+        plh_polar_pp_setup(dp->gpu, dp->log, sh->polar_obj, pass);
+
     struct pass_timing *timing = get_timing(dp, sh);
     pl_timer timer = params->timer ? params->timer : timing ? timing->timer : NULL;
     if (timer)

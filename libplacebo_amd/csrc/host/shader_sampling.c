@@ -177,6 +177,15 @@ bool pl_shader_sample_oversample(pl_shader sh, const struct pl_sample_src *src, 
 #define SCALER_LUT_SIZE     256
 #define SCALER_LUT_CUTOFF   1e-3f
 
+// Geometry a set of polar phase-class tables was built for (plh_polar_pp_setup)
+struct polar_pp_key {
+    float pos[4][2];
+    int src_w, src_h, width, height;
+    int bound, num_taps, fp32_tile;
+    float scale, radius;
+    uint64_t filter_gen;
+};
+
 struct sh_sampler_obj {
     pl_filter filter;
     pl_buf lut;         // polar: 256 {L[i], L[i+1]} pairs; ortho: rows
@@ -184,6 +193,15 @@ struct sh_sampler_obj {
     int num_taps;
     bool taps_gather;   // tap order the list was generated for
     pl_shader_obj pass2; // second ortho pass
+
+    // polar phase classes (k_polar_pp): one device blob holding struct plh_polar_pp
+    // and every table it points to
+    uint64_t filter_gen;            // bumped whenever lut/taps are regenerated
+    struct polar_pp_key pp_key;
+    int pp_state;                   // 0 = not built, 1 = usable, -1 = not applicable
+    pl_buf pp_blob;
+    struct plh_polar_pp pp_host;    // host copy (device pointers)
+    int pp_tile_w, pp_tile_h, pp_rows, pp_lds_weights;
 };
 
 static void sh_sampler_uninit(pl_gpu gpu, void *ptr)
@@ -191,6 +209,7 @@ static void sh_sampler_uninit(pl_gpu gpu, void *ptr)
     struct sh_sampler_obj *obj = ptr;
     pl_buf_destroy(gpu, &obj->lut);
     pl_buf_destroy(gpu, &obj->taps);
+    pl_buf_destroy(gpu, &obj->pp_blob);
     pl_shader_obj_destroy(&obj->pass2);
     pl_filter_free(&obj->filter);
     memset(obj, 0, sizeof(*obj));
@@ -370,6 +389,7 @@ bool pl_shader_sample_polar(pl_shader sh, const struct pl_sample_src *src,
         obj->num_taps = gather_order ? polar_taps_gather(taps, filter, bound, use_ar, &glsl)
                                      : polar_taps_compute(taps, filter, bound, use_ar);
         obj->taps_gather = gather_order;
+        obj->filter_gen++;
 
         pl_buf_destroy(gpu, &obj->lut);
         pl_buf_destroy(gpu, &obj->taps);
@@ -422,6 +442,8 @@ bool pl_shader_sample_polar(pl_shader sh, const struct pl_sample_src *src,
     s->tile_h = tile_h;
     s->tile_rows = rows;
     s->tile_fp32 = fp32_tile;
+    s->pp = NULL;
+    sh->polar_obj = use_ar ? NULL : obj;    // anti-ringing needs per-pixel d, see k_polar
     sh_hold(sh, *params->lut);
 
     sh_listf(sh, "sample_polar(filter=%s, radius=%f, radius_zero=%f, taps=%d (%s order), "
@@ -430,6 +452,369 @@ bool pl_shader_sample_polar(pl_shader sh, const struct pl_sample_src *src,
              gather_order ? "gather" : "compute", tile_w, tile_h, fp32_tile ? "f32" : "f16",
              rows, cfg.antiring, info.scale, info.comp_mask);
     return true;
+}
+
+
+/* ---- polar phase classes (device side: k_polar.hip, struct plh_polar_pp) ---------------- */
+
+static int cmp_u32(const void *a, const void *b)
+{
+    const uint32_t x = *(const uint32_t *) a, y = *(const uint32_t *) b;
+    return x < y ? -1 : x > y;
+}
+
+// distinct bit patterns of fc[0..n) -> sorted class values; ids[i] = class of element i
+static int classify_axis(const float *fc, int n, float *cls, uint16_t *ids, int max_cls)
+{
+    uint32_t *tmp = malloc(n * sizeof(uint32_t));
+    if (!tmp)
+        return -1;
+    memcpy(tmp, fc, n * sizeof(uint32_t));
+    qsort(tmp, n, sizeof(uint32_t), cmp_u32);
+    int nc = 0;
+    for (int i = 0; i < n; i++) {
+        if (i && tmp[i] == tmp[i - 1])
+            continue;
+        if (nc == max_cls) {
+            free(tmp);
+            return -1;
+        }
+        memcpy(&cls[nc++], &tmp[i], 4);
+    }
+    free(tmp);
+    for (int i = 0; i < n; i++) {
+        uint32_t key;
+        memcpy(&key, &fc[i], 4);
+        int lo = 0, hi = nc - 1;
+        while (lo < hi) {
+            const int mid = (lo + hi) / 2;
+            uint32_t v;
+            memcpy(&v, &cls[mid], 4);
+            if (v < key)
+                lo = mid + 1;
+            else
+                hi = mid;
+        }
+        ids[i] = lo;
+    }
+    return nc;
+}
+
+// Can `n` consecutive outputs [n*c - pad, n*c - pad + n) always share a base texel?
+static bool cells_share_base(const int32_t *base, int len, int n, int pad)
+{
+    for (int c0 = -pad; c0 < len; c0 += n) {
+        int b = 0;
+        bool have = false;
+        for (int i = 0; i < n; i++) {
+            const int x = c0 + i;
+            if (x < 0 || x >= len)
+                continue;
+            if (have && base[x] != b)
+                return false;
+            b = base[x];
+            have = true;
+        }
+    }
+    return true;
+}
+
+struct axis_tiles {
+    int ntiles;
+    uint8_t *loc;       // [len]
+    uint16_t *list;     // [ntiles][PLH_PP_LMAX]
+    uint8_t *cnt;       // [ntiles]
+    int32_t *org;       // [ntiles]
+    int extent;         // LDS tile extent needed along this axis (texels)
+    int max_cnt;
+};
+
+// Split an axis of `len` outputs into tiles of `tile_cells` cells of `n` outputs
+static bool build_axis_tiles(struct axis_tiles *t, const uint16_t *ids, const int32_t *base,
+                             int len, int n, int pad, int tile_cells, int bound)
+{
+    const int cells = (len + pad + n - 1) / n;
+    t->ntiles = (cells + tile_cells - 1) / tile_cells;
+    t->loc = calloc(len, 1);
+    t->list = calloc((size_t) t->ntiles * PLH_PP_LMAX, sizeof(uint16_t));
+    t->cnt = calloc(t->ntiles, 1);
+    t->org = calloc(t->ntiles, sizeof(int32_t));
+    t->extent = 0;
+    t->max_cnt = 0;
+    if (!t->loc || !t->list || !t->cnt || !t->org)
+        return false;
+    for (int ti = 0; ti < t->ntiles; ti++) {
+        const int x0 = PL_MAX(ti * tile_cells * n - pad, 0);
+        const int x1 = PL_MIN((ti + 1) * tile_cells * n - pad, len);
+        uint16_t *list = t->list + (size_t) ti * PLH_PP_LMAX;
+        int cnt = 0, bmin = INT32_MAX, bmax = INT32_MIN;
+        for (int x = x0; x < x1; x++) {
+            int l = 0;
+            while (l < cnt && list[l] != ids[x])
+                l++;
+            if (l == cnt) {
+                if (cnt == PLH_PP_LMAX)
+                    return false;
+                list[cnt++] = ids[x];
+            }
+            t->loc[x] = l;
+            bmin = PL_MIN(bmin, base[x]);
+            bmax = PL_MAX(bmax, base[x]);
+        }
+        if (x1 <= x0) {
+            bmin = bmax = 0;
+            cnt = 1;
+        }
+        t->cnt[ti] = cnt;
+        t->max_cnt = PL_MAX(t->max_cnt, cnt);
+        // taps span [base - (bound-1), base + bound]; one texel of slack per side for the
+        // rare pixel whose own base is off by one (per-pixel path inside k_polar_pp)
+        t->org[ti] = bmin - (bound - 1) - 1;
+        t->extent = PL_MAX(t->extent, bmax - bmin + 2 * bound + 2);
+    }
+    return true;
+}
+
+static void free_axis_tiles(struct axis_tiles *t)
+{
+    free(t->loc);
+    free(t->list);
+    free(t->cnt);
+    free(t->org);
+    memset(t, 0, sizeof(*t));
+}
+
+static inline size_t align16(size_t x)
+{
+    return (x + 15) & ~(size_t) 15;
+}
+
+int plh_launch_polar_classify(plh_stream stream, const struct plh_pass *pass, void *out);
+int plh_launch_polar_weights(plh_stream stream, const struct plh_pass *pass, const float *clsx,
+                             int ncx, const float *clsy, int ncy, float *weights);
+
+static bool polar_pp_build(pl_gpu gpu, pl_log log, struct sh_sampler_obj *obj,
+                           const struct plh_pass *pass)
+{
+    const struct plh_sampler_args *s = &pass->s;
+    const int W = pass->width, H = pass->height, ntaps = s->num_taps;
+    const plh_stream stream = plh_gpu_stream(gpu);
+    bool ok = false;
+    pl_buf tmp = NULL, wbuf = NULL;
+    float *host = NULL, *clsx = NULL, *clsy = NULL, *wall = NULL;
+    uint16_t *idx = NULL, *idy = NULL;
+    uint8_t *blob = NULL;
+    struct axis_tiles tx = {0}, ty = {0};
+    enum { MAX_CLS = 96 };
+
+    // ---- 1. fcoord / base of every column and row, evaluated by the device ------------------
+    const size_t cls_bytes = (size_t) 2 * (W + H) * 4;
+    tmp = pl_buf_create(gpu, pl_buf_params(.size = cls_bytes, .storable = true,
+                                           .host_readable = true));
+    host = malloc(cls_bytes);
+    clsx = malloc(MAX_CLS * sizeof(float));
+    clsy = malloc(MAX_CLS * sizeof(float));
+    idx = malloc(W * sizeof(uint16_t));
+    idy = malloc(H * sizeof(uint16_t));
+    if (!tmp || !host || !clsx || !clsy || !idx || !idy)
+        goto done;
+    if (plh_launch_polar_classify(stream, pass, pl_hip_buf_ptr(tmp)) ||
+        !pl_buf_read(gpu, tmp, 0, host, cls_bytes))
+        goto done;
+    const float *colfc = host, *rowfc = host + 2 * W;
+    const int32_t *colbase = (const int32_t *) (host + W);
+    const int32_t *rowbase = (const int32_t *) (host + 2 * W + H);
+
+    // ---- 2. classes ---------------------------------------------------------------------------
+    const int ncx = classify_axis(colfc, W, clsx, idx, MAX_CLS);
+    const int ncy = classify_axis(rowfc, H, clsy, idy, MAX_CLS);
+    if (ncx < 0 || ncy < 0)
+        goto done; // arbitrary (non-rational) ratio: every column has its own phase
+
+    // ---- 3. outputs per lane: 2x2 when pairs of outputs share their base texel --------------
+    int n = 1, padx = 0, pady = 0;
+    for (int px = 0; px < 2 && n == 1; px++) {
+        if (!cells_share_base(colbase, W, 2, px))
+            continue;
+        for (int py = 0; py < 2; py++) {
+            if (cells_share_base(rowbase, H, 2, py)) {
+                n = 2; padx = px; pady = py;
+                break;
+            }
+        }
+    }
+
+    // ---- 4. tiles: 32 x 8*rows cells, LDS = lut + weights + source tile ----------------------
+    const size_t texel = s->tile_fp32 ? 16 : 8;
+    const size_t max_lds = 64 * 1024;   // >= 2 workgroups per CU
+    int rows = 4, tp = 0, ntc = 0;
+    size_t lds_w = 0;
+    for (;; rows >>= 1) {
+        free_axis_tiles(&tx);
+        free_axis_tiles(&ty);
+        if (!build_axis_tiles(&tx, idx, colbase, W, n, padx, POLAR_BW, s->bound) ||
+            !build_axis_tiles(&ty, idy, rowbase, H, n, pady, POLAR_BH * rows, s->bound))
+            goto done;
+        // worst-case weights slice; the compacted tap count is only known later
+        lds_w = align16((size_t) tx.max_cnt * ty.max_cnt * (ntaps + 2) * 4);
+        if (2048 + lds_w + (size_t) tx.extent * ty.extent * texel <= max_lds)
+            break;
+        if (rows == 1)
+            goto done;
+    }
+
+    // ---- 5. weights of every class pair, by the device; compaction of dead taps -------------
+    const size_t wall_bytes = (size_t) ncx * ncy * (ntaps + 1) * 4;
+    wbuf = pl_buf_create(gpu, pl_buf_params(.size = wall_bytes + (ncx + ncy) * 4, .storable = true,
+                                            .host_readable = true, .host_writable = true));
+    wall = malloc(wall_bytes);
+    if (!wbuf || !wall)
+        goto done;
+    pl_buf_write(gpu, wbuf, wall_bytes, clsx, ncx * 4);
+    pl_buf_write(gpu, wbuf, wall_bytes + ncx * 4, clsy, ncy * 4);
+    const float *dcls = (const float *) ((const char *) pl_hip_buf_ptr(wbuf) + wall_bytes);
+    if (plh_launch_polar_weights(stream, pass, dcls, ncx, dcls + ncx, ncy, pl_hip_buf_ptr(wbuf)) ||
+        !pl_buf_read(gpu, wbuf, 0, wall, wall_bytes))
+        goto done;
+
+    uint32_t *taps_all = malloc(PL_MAX(ntaps, 1) * sizeof(uint32_t));
+    int *keep = malloc(PL_MAX(ntaps, 1) * sizeof(int));
+    if (!taps_all || !keep || !pl_buf_read(gpu, obj->taps, 0, taps_all, ntaps * sizeof(uint32_t))) {
+        free(taps_all);
+        free(keep);
+        goto done;
+    }
+    for (int t = 0; t < ntaps; t++) {
+        bool used = false;
+        for (int pr = 0; pr < ncx * ncy && !used; pr++)
+            used = wall[(size_t) pr * (ntaps + 1) + t] != 0.0f;
+        if (used)
+            keep[ntc++] = t;
+    }
+    tp = (ntc + 1 + 3) & ~3;    // weights + norm, padded to 16 bytes
+    lds_w = align16((size_t) tx.max_cnt * ty.max_cnt * tp * 4);
+
+    // ---- 6. one device blob: struct + tables ---------------------------------------------------
+    size_t off = align16(sizeof(struct plh_polar_pp));
+#define PLACE(name, bytes) const size_t o_##name = off; off = align16(off + (bytes))
+    PLACE(colfc, (size_t) W * 4);   PLACE(rowfc, (size_t) H * 4);
+    PLACE(colbase, (size_t) W * 4); PLACE(rowbase, (size_t) H * 4);
+    PLACE(colloc, W);               PLACE(rowloc, H);
+    PLACE(collist, (size_t) tx.ntiles * PLH_PP_LMAX * 2);
+    PLACE(rowlist, (size_t) ty.ntiles * PLH_PP_LMAX * 2);
+    PLACE(coln, tx.ntiles);         PLACE(rown, ty.ntiles);
+    PLACE(colorg, (size_t) tx.ntiles * 4); PLACE(roworg, (size_t) ty.ntiles * 4);
+    PLACE(weights, (size_t) ncx * ncy * tp * 4);
+    PLACE(tapoff, (size_t) PL_MAX(ntc, 1) * 4);
+#undef PLACE
+    blob = calloc(1, off);
+    if (!blob) {
+        free(taps_all);
+        free(keep);
+        goto done;
+    }
+    memcpy(blob + o_colfc, colfc, (size_t) W * 4);
+    memcpy(blob + o_rowfc, rowfc, (size_t) H * 4);
+    memcpy(blob + o_colbase, colbase, (size_t) W * 4);
+    memcpy(blob + o_rowbase, rowbase, (size_t) H * 4);
+    memcpy(blob + o_colloc, tx.loc, W);
+    memcpy(blob + o_rowloc, ty.loc, H);
+    memcpy(blob + o_collist, tx.list, (size_t) tx.ntiles * PLH_PP_LMAX * 2);
+    memcpy(blob + o_rowlist, ty.list, (size_t) ty.ntiles * PLH_PP_LMAX * 2);
+    memcpy(blob + o_coln, tx.cnt, tx.ntiles);
+    memcpy(blob + o_rown, ty.cnt, ty.ntiles);
+    memcpy(blob + o_colorg, tx.org, (size_t) tx.ntiles * 4);
+    memcpy(blob + o_roworg, ty.org, (size_t) ty.ntiles * 4);
+    float *wc = (float *) (blob + o_weights);
+    for (int pr = 0; pr < ncx * ncy; pr++) {
+        const float *src = wall + (size_t) pr * (ntaps + 1);
+        float *dst = wc + (size_t) pr * tp;
+        for (int k = 0; k < ntc; k++)
+            dst[k] = src[keep[k]];
+        dst[ntc] = src[ntaps];      // scale / wsum
+    }
+    int32_t *tapoff = (int32_t *) (blob + o_tapoff);
+    for (int k = 0; k < ntc; k++) {
+        const uint32_t tap = taps_all[keep[k]];
+        const int x = (int8_t) (tap & 0xff), y = (int8_t) ((tap >> 8) & 0xff);
+        tapoff[k] = (y * tx.extent + x) * (int) texel;
+    }
+    free(taps_all);
+    free(keep);
+
+    pl_buf_destroy(gpu, &obj->pp_blob);
+    obj->pp_blob = pl_buf_create(gpu, pl_buf_params(.size = off, .storable = true,
+                                                    .host_writable = true));
+    if (!obj->pp_blob)
+        goto done;
+    const char *d = pl_hip_buf_ptr(obj->pp_blob);
+    struct plh_polar_pp *pp = &obj->pp_host;
+    *pp = (struct plh_polar_pp) {
+        .n = n, .padx = padx, .pady = pady,
+        .cells_w = (W + padx + n - 1) / n, .cells_h = (H + pady + n - 1) / n,
+        .ncx = ncx, .ncy = ncy, .ntaps = ntc, .tp = tp,
+        .colfc = (const float *) (d + o_colfc), .rowfc = (const float *) (d + o_rowfc),
+        .colbase = (const int32_t *) (d + o_colbase), .rowbase = (const int32_t *) (d + o_rowbase),
+        .colloc = (const uint8_t *) (d + o_colloc), .rowloc = (const uint8_t *) (d + o_rowloc),
+        .collist = (const uint16_t *) (d + o_collist), .rowlist = (const uint16_t *) (d + o_rowlist),
+        .coln = (const uint8_t *) (d + o_coln), .rown = (const uint8_t *) (d + o_rown),
+        .colorg = (const int32_t *) (d + o_colorg), .roworg = (const int32_t *) (d + o_roworg),
+        .weights = (const float *) (d + o_weights), .tapoff = (const int32_t *) (d + o_tapoff),
+    };
+    memcpy(blob, pp, sizeof(*pp));
+    pl_buf_write(gpu, obj->pp_blob, 0, blob, off);
+
+    obj->pp_tile_w = tx.extent;
+    obj->pp_tile_h = ty.extent;
+    obj->pp_rows = rows;
+    obj->pp_lds_weights = lds_w;
+    pl_msg(log, PL_LOG_DEBUG, "polar phase classes: %dx%d classes, %d/%d live taps, %dx%d px per "
+           "lane, tile %dx%d, %d rows, %zu B of weights in LDS", ncx, ncy, ntc, ntaps, n, n,
+           tx.extent, ty.extent, rows, lds_w);
+    ok = true;
+
+done:
+    pl_buf_destroy(gpu, &tmp);
+    pl_buf_destroy(gpu, &wbuf);
+    free_axis_tiles(&tx);
+    free_axis_tiles(&ty);
+    free(host); free(clsx); free(clsy); free(idx); free(idy); free(wall); free(blob);
+    return ok;
+}
+
+void plh_polar_pp_setup(pl_gpu gpu, pl_log log, void *polar_obj, struct plh_pass *pass)
+{
+    struct sh_sampler_obj *obj = polar_obj;
+    struct plh_sampler_args *s = &pass->s;
+    s->pp = NULL;
+    const char *env = getenv("PL_HIP_POLAR_PER_PIXEL");
+    if (env && env[0] == '1')
+        return;
+
+    struct polar_pp_key key = {
+        .src_w = s->src.w, .src_h = s->src.h, .width = pass->width, .height = pass->height,
+        .bound = s->bound, .num_taps = s->num_taps, .fp32_tile = s->tile_fp32,
+        .scale = s->scale, .radius = s->radius, .filter_gen = obj->filter_gen,
+    };
+    memcpy(key.pos, s->pos, sizeof(key.pos));
+    if (!obj->pp_state || memcmp(&key, &obj->pp_key, sizeof(key))) {
+        obj->pp_key = key;
+        obj->pp_state = polar_pp_build(gpu, log, obj, pass) ? 1 : -1;
+        if (obj->pp_state < 0)
+            pl_msg(log, PL_LOG_DEBUG, "polar phase classes not applicable to this geometry; "
+                   "using per-pixel weights");
+    }
+    if (obj->pp_state != 1)
+        return;
+
+    s->pp = pl_hip_buf_ptr(obj->pp_blob);
+    s->pp_n = obj->pp_host.n;
+    s->pp_cells_w = obj->pp_host.cells_w;
+    s->pp_cells_h = obj->pp_host.cells_h;
+    s->pp_lds_weights = obj->pp_lds_weights;
+    s->tile_w = obj->pp_tile_w;
+    s->tile_h = obj->pp_tile_h;
+    s->tile_rows = obj->pp_rows;
 }
 
 bool pl_shader_sample_ortho2(pl_shader sh, const struct pl_sample_src *src,

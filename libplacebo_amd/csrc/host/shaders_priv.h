@@ -60,7 +60,12 @@ struct pl_shader_t {
     struct pl_shader_res res;
 
     struct plh_errdiff_args *errdiff;
+    // polar sampler state, for the launch-time phase-class setup (shader_sampling.c)
+    void *polar_obj;
 };
+
+// called by the dispatch once the target geometry of a POLAR pass is known
+void plh_polar_pp_setup(pl_gpu gpu, pl_log log, void *polar_obj, struct plh_pass *pass);
 
 #define SH_GPU(sh) ((sh)->params.gpu)
 
