@@ -141,10 +141,19 @@ void k_polar(const plh_pass p_)
         lut[i] = ((const float2 *) s.lut)[i];
 
     const int tw = s.tile_w, th = s.tile_h;
+    // an rgba16hf source without pre-ops is copied bit for bit (the f16 -> f32 -> f16 round
+    // trip of the generic path is the identity)
+    const bool raw16 = sizeof(tile_px<T>) == 8 && s.src.fmt == PLH_FMT_RGBA16F && !p.num_pre_ops;
+    const float rcp_tw = 1.0f / (float) tw;
     for (int i = tid; i < tw * th; i += POLAR_BW * POLAR_BH) {
-        const int ty = i / tw, tx = i - ty * tw;
+        const int ty = (int) (((float) i + 0.5f) * rcp_tw), tx = i - ty * tw;  // exact: i < 2^22
         const int sx = plh_wrap(ox + tx, s.src.w, s.address_mode);
         const int sy = plh_wrap(oy + ty, s.src.h, s.address_mode);
+        if (raw16) {
+            *(uint2 *) &tile[i] = *(const uint2 *) ((const char *) s.src.ptr +
+                                                    (size_t) sy * s.src.pitch + (size_t) sx * 8);
+            continue;
+        }
         float4_t c = plh_fetch(s.src, sx, sy);
         if (p.num_pre_ops) {
             const frag_t fc = { (float) sx + 0.5f, (float) sy + 0.5f };
@@ -364,7 +373,12 @@ DEV void polar_pixel_generic(const plh_sampler_args &s, const float2 *lut, const
     norm = s.scale / wsum;
 }
 
-template <typename T, uint32_t MASK, int N>
+// per output row of the workgroup, staged in LDS: class value, base texel, offset of the
+// row class in the weight sub-table
+struct pp_rowinfo { float fc; int32_t base; int32_t woff; int32_t pad; };
+#define PP_LDS_FIXED (2048 + 1024)
+
+template <typename T, uint32_t MASK, int N, bool LITE>
 __global__ __launch_bounds__(POLAR_BW * POLAR_BH)
 void k_polar_pp(const plh_pass p_)
 {
@@ -373,8 +387,9 @@ void k_polar_pp(const plh_pass p_)
     const plh_polar_pp &pp = *s.pp;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     float2 *lut = (float2 *) smem;                              // 256 pairs = 2 KiB
-    float *ws = (float *) (smem + 256 * sizeof(float2));        // weight sub-table
-    tile_px<T> *tile = (tile_px<T> *) (smem + 256 * sizeof(float2) + s.pp_lds_weights);
+    pp_rowinfo *rinfo = (pp_rowinfo *) (smem + 2048);           // <= 64 output rows, 1 KiB
+    float *ws = (float *) (smem + PP_LDS_FIXED);                // weight sub-table
+    tile_px<T> *tile = (tile_px<T> *) (smem + PP_LDS_FIXED + s.pp_lds_weights);
 
     const int tid = threadIdx.y * POLAR_BW + threadIdx.x;
     const int rows = s.tile_rows;
@@ -399,30 +414,64 @@ void k_polar_pp(const plh_pass p_)
             }
         }
     }
+    {
+        int32_t *toff = (int32_t *) (ws + (s.pp_lds_weights >> 2)) - ((ntaps + 3) & ~3);
+        for (int t = tid; t < ntaps; t += POLAR_BW * POLAR_BH)
+            toff[t] = pp.tapoff[t];     // tail of the weights area (reserved by the host)
+        const int y0 = N * (blockIdx.y * rows * POLAR_BH) - pp.pady;
+        for (int j = tid; j < N * rows * POLAR_BH; j += POLAR_BW * POLAR_BH) {
+            const int yc = min(max(y0 + j, 0), p.height - 1);
+            pp_rowinfo ri = { pp.rowfc[yc], pp.rowbase[yc], pp.rowloc[yc] * nx * tp, 0 };
+            rinfo[j] = ri;
+        }
+    }
+    // an rgba16hf source without pre-ops is copied bit for bit (the f16 -> f32 -> f16 round
+    // trip of the generic path is the identity)
+    const bool raw16 = sizeof(tile_px<T>) == 8 && s.src.fmt == PLH_FMT_RGBA16F && !p.num_pre_ops;
+    const float rcp_tw = 1.0f / (float) tw;
     for (int i = tid; i < tw * th; i += POLAR_BW * POLAR_BH) {
-        const int ty = i / tw, tx = i - ty * tw;
+        const int ty = (int) (((float) i + 0.5f) * rcp_tw), tx = i - ty * tw;  // exact: i < 2^22
         const int sx = plh_wrap(ox + tx, s.src.w, s.address_mode);
         const int sy = plh_wrap(oy + ty, s.src.h, s.address_mode);
+        if (raw16) {
+            *(uint2 *) &tile[i] = *(const uint2 *) ((const char *) s.src.ptr +
+                                                    (size_t) sy * s.src.pitch + (size_t) sx * 8);
+            continue;
+        }
         float4_t c = plh_fetch(s.src, sx, sy);
-        if (p.num_pre_ops) {
-            const frag_t fc = { (float) sx + 0.5f, (float) sy + 0.5f };
-            apply_ops(c, p.ops, 0, p.num_pre_ops, fc);
+        if constexpr (!LITE) {
+            if (p.num_pre_ops) {
+                const frag_t fc = { (float) sx + 0.5f, (float) sy + 0.5f };
+                apply_ops(c, p.ops, 0, p.num_pre_ops, fc);
+            }
         }
         tile_put(tile[i], c);
     }
     __syncthreads();
+
+    int dither_op = -1;     // uniform
+    for (int i = p.num_pre_ops; i < p.num_ops; i++) {
+        if (p.ops[i].kind == PLH_OP_DITHER)
+            dither_op = i;
+    }
 
     // ---- per-lane column state ------------------------------------------------------------
     const int cellx = blockIdx.x * POLAR_BW + threadIdx.x;
     int colx[N];            // output columns of this lane (may lie outside the image)
     int cwoff[N];           // offset of the column's class in the weight sub-table
     float cfc[N];
+    float attr[N][4];       // the fx halves of the attribute interpolation (plh_attr)
     int cbase;
     {
         int b = 0;
 #pragma unroll
         for (int i = 0; i < N; i++) {
             colx[i] = N * cellx - pp.padx + i;
+            const float mx = p.out_scale[0] * ((float) colx[i] + 0.5f);
+            attr[i][0] = plh_mix(s.pos[0][0], s.pos[1][0], mx);
+            attr[i][1] = plh_mix(s.pos[2][0], s.pos[3][0], mx);
+            attr[i][2] = plh_mix(s.pos[0][1], s.pos[1][1], mx);
+            attr[i][3] = plh_mix(s.pos[2][1], s.pos[3][1], mx);
             const int xc = min(max(colx[i], 0), p.width - 1);
             cwoff[i] = pp.colloc[xc] * tp;
             cfc[i] = pp.colfc[xc];
@@ -442,11 +491,23 @@ void k_polar_pp(const plh_pass p_)
 #pragma unroll
         for (int j = 0; j < N; j++) {
             rowy[j] = N * celly - pp.pady + j;
-            const int yc = min(max(rowy[j], 0), p.height - 1);
-            rwoff[j] = pp.rowloc[yc] * nx * tp;
-            rfc[j] = pp.rowfc[yc];
+            const pp_rowinfo ri = rinfo[N * (r * POLAR_BH + threadIdx.y) + j];
+            rwoff[j] = ri.woff;
+            rfc[j] = ri.fc;
             if (j == 0 || rowy[j - 1] < 0)
-                rbase = pp.rowbase[yc];
+                rbase = ri.base;
+        }
+
+        // fetch the dither values now; they are consumed after the tap loop
+        float bias[N][N];
+#pragma unroll
+        for (int j = 0; j < N; j++) {
+#pragma unroll
+            for (int i = 0; i < N; i++) {
+                const frag_t fc = { (float) (colx[i] + p.frag_x0) + 0.5f,
+                                    (float) (rowy[j] + p.frag_y0) + 0.5f };
+                bias[j][i] = dither_op >= 0 ? dither_bias(p.ops[dither_op], fc) : 0.0f;
+            }
         }
 
         // lanes of padding cells are clamped so their LDS reads stay inside the tile
@@ -465,10 +526,12 @@ void k_polar_pp(const plh_pass p_)
             }
         }
 
-        const auto *tapoff = PLH_CONST(int32_t, pp.tapoff);
+        const int32_t *tapoff = (const int32_t *) (ws + (s.pp_lds_weights >> 2)) -
+                                ((ntaps + 3) & ~3);
 #pragma unroll 4
         for (int t = 0; t < ntaps; t++) {
-            // byte offset of the tap inside the tile (host: (y * tile_w + x) * sizeof(texel))
+            // byte offset of the tap inside the tile (host: (y * tile_w + x) * sizeof(texel));
+            // an LDS broadcast read keeps the loop free of scalar-memory waits
             const floatv4_t c = tile_vec(*(const tile_px<T> *) ((const char *) tp0 + tapoff[t]));
 #pragma unroll
             for (int j = 0; j < N; j++) {
@@ -485,54 +548,72 @@ void k_polar_pp(const plh_pass p_)
         }
 
         // ---- normalise, verify, post-ops, store ------------------------------------------
-        // (a rolled loop over the lane's n*n pixels: the post-ops are large)
+        // (rolled over the lane's rows, unrolled over its columns: the post-ops are large)
 #pragma unroll 1
-        for (int q = 0; q < N * N; q++) {
-            floatv4_t a = acc[0][0];
-            const float *w = wp[0][0];
-            int idx = colx[0], idy = rowy[0];
-            float tfx = cfc[0], tfy = rfc[0];
+        for (int j = 0; j < N; j++) {
+            floatv4_t a[N];
+            const float *w[N];
+            float bs[N];
+            int idy = rowy[0];
+            float tfy = rfc[0];
 #pragma unroll
-            for (int j = 0; j < N; j++) {
+            for (int i = 0; i < N; i++) {
+                a[i] = acc[0][i]; w[i] = wp[0][i]; bs[i] = bias[0][i];
+            }
 #pragma unroll
-                for (int i = 0; i < N; i++) {
-                    if (j * N + i == q) {
-                        a = acc[j][i]; w = wp[j][i];
-                        idx = colx[i]; idy = rowy[j];
-                        tfx = cfc[i]; tfy = rfc[j];
+            for (int jj = 1; jj < N; jj++) {
+                if (jj == j) {
+                    idy = rowy[jj]; tfy = rfc[jj];
+#pragma unroll
+                    for (int i = 0; i < N; i++) {
+                        a[i] = acc[jj][i]; w[i] = wp[jj][i]; bs[i] = bias[jj][i];
                     }
                 }
             }
-            if (idx < 0 || idy < 0 || idx >= p.width || idy >= p.height)
+            if (idy < 0 || idy >= p.height)
                 continue;
-            float col[4] = { a[0], a[1], a[2], a[3] };
-            float norm = w[ntaps];
+            const float my = p.out_scale[1] * ((float) idy + 0.5f);
+            const float gy = p.out_scale[1] * (float) idy;
 
-            float fcx, fcy;
-            int bx, by;
-            polar_coord(p, idx, idy, fcx, fcy, bx, by);
-            if (__float_as_uint(fcx) != __float_as_uint(tfx) ||
-                __float_as_uint(fcy) != __float_as_uint(tfy) || bx != cbase || by != rbase) {
-                // not the tabulated phase after all: per-pixel weights (the tile has one
-                // texel of slack per side for a base that is off by one)
-                const int rx = min(max(bx - ox, s.bound - 1), tw - s.bound - 1);
-                const int ry = min(max(by - oy, s.bound - 1), th - s.bound - 1);
-                polar_pixel_generic<T, MASK>(s, lut, tile + ry * tw + rx, tw, fcx, fcy, col, norm);
-            }
+#pragma unroll
+            for (int i = 0; i < N; i++) {
+                const int idx = colx[i];
+                if (idx < 0 || idx >= p.width)
+                    continue;
+                float col[4] = { a[i][0], a[i][1], a[i][2], a[i][3] };
+                float norm = w[i][ntaps];
 
-            float4_t out = { norm * col[0], norm * col[1], norm * col[2], norm * col[3] };
-            if (!(MASK & 8u))
-                out.w = 1.0f;
-            const frag_t fc = { (float) (idx + p.frag_x0) + 0.5f, (float) (idy + p.frag_y0) + 0.5f };
-            apply_ops(out, p.ops, p.num_pre_ops, p.num_ops, fc);
+                // this pixel's own fcoord / base: polar_coord() with the fx halves hoisted
+                const float tx_ = plh_mix(attr[i][0], attr[i][1], my) * (float) s.src.w - 0.5f;
+                const float ty_ = plh_mix(attr[i][2], attr[i][3], my) * (float) s.src.h - 0.5f;
+                const float flx = __builtin_floorf(tx_), fly = __builtin_floorf(ty_);
+                const float fcx = tx_ - flx, fcy = ty_ - fly;
+                const int bx = (int) flx, by = (int) fly;
+                if (__float_as_uint(fcx) != __float_as_uint(cfc[i]) ||
+                    __float_as_uint(fcy) != __float_as_uint(tfy) || bx != cbase || by != rbase) {
+                    // not the tabulated phase after all: per-pixel weights (the tile has one
+                    // texel of slack per side for a base that is off by one)
+                    const int rx = min(max(bx - ox, s.bound - 1), tw - s.bound - 1);
+                    const int ry = min(max(by - oy, s.bound - 1), th - s.bound - 1);
+                    polar_pixel_generic<T, MASK>(s, lut, tile + ry * tw + rx, tw, fcx, fcy,
+                                                 col, norm);
+                }
 
-            // guarded store (dispatch.c:1126-1142)
-            const float gx = p.out_scale[0] * (float) idx, gy = p.out_scale[1] * (float) idy;
-            if (gx < 1.0f && gy < 1.0f) {
-                const int oxp = p.base_x + p.dir_x * (p.transpose ? idy : idx);
-                const int oyp = p.base_y + p.dir_y * (p.transpose ? idx : idy);
-                if (oxp >= 0 && oyp >= 0 && oxp < p.dst.w && oyp < p.dst.h)
-                    plh_store(p.dst, oxp, oyp, out);
+                float4_t out = { norm * col[0], norm * col[1], norm * col[2], norm * col[3] };
+                if (!(MASK & 8u))
+                    out.w = 1.0f;
+                const frag_t fc = { (float) (idx + p.frag_x0) + 0.5f,
+                                    (float) (idy + p.frag_y0) + 0.5f, bs[i], dither_op >= 0 };
+                apply_ops<false, LITE>(out, p.ops, p.num_pre_ops, p.num_ops, fc);
+
+                // guarded store (dispatch.c:1126-1142)
+                const float gx = p.out_scale[0] * (float) idx;
+                if (gx < 1.0f && gy < 1.0f) {
+                    const int oxp = p.base_x + p.dir_x * (p.transpose ? idy : idx);
+                    const int oyp = p.base_y + p.dir_y * (p.transpose ? idx : idy);
+                    if (oxp >= 0 && oyp >= 0 && oxp < p.dst.w && oyp < p.dst.h)
+                        plh_store(p.dst, oxp, oyp, out);
+                }
             }
         }
     }
@@ -542,10 +623,15 @@ template <typename T, uint32_t MASK>
 static int launch_pp(hipStream_t stream, const plh_pass *pass, dim3 grid, dim3 block, size_t shmem,
                      int n)
 {
-    if (n == 2)
-        hipLaunchKernelGGL((k_polar_pp<T, MASK, 2>), grid, block, shmem, stream, *pass);
+    const bool lite = !pass->num_pre_ops && plh_ops_lite(pass, 0, pass->num_ops);
+    if (n == 2 && lite)
+        hipLaunchKernelGGL((k_polar_pp<T, MASK, 2, true>), grid, block, shmem, stream, *pass);
+    else if (n == 2)
+        hipLaunchKernelGGL((k_polar_pp<T, MASK, 2, false>), grid, block, shmem, stream, *pass);
+    else if (lite)
+        hipLaunchKernelGGL((k_polar_pp<T, MASK, 1, true>), grid, block, shmem, stream, *pass);
     else
-        hipLaunchKernelGGL((k_polar_pp<T, MASK, 1>), grid, block, shmem, stream, *pass);
+        hipLaunchKernelGGL((k_polar_pp<T, MASK, 1, false>), grid, block, shmem, stream, *pass);
     const hipError_t err = hipGetLastError();
     return err == hipSuccess ? 0 : -(int) err;
 }
@@ -554,12 +640,13 @@ template <typename T>
 static int launch_pp_mask(hipStream_t stream, const plh_pass *pass, dim3 grid, dim3 block,
                           size_t shmem, int n)
 {
-    switch (pass->s.comp_mask & 0xf) {
-    case 0x1: return launch_pp<T, 0x1>(stream, pass, grid, block, shmem, n);
-    case 0x3: return launch_pp<T, 0x3>(stream, pass, grid, block, shmem, n);
-    case 0x7: return launch_pp<T, 0x7>(stream, pass, grid, block, shmem, n);
-    default:  return launch_pp<T, 0xf>(stream, pass, grid, block, shmem, n);
-    }
+    // (the host only builds phase classes for 3- and 4-component passes; 1- and 2-component
+    // planes use the per-pixel kernel, which keeps the number of variants down)
+    if ((pass->s.comp_mask & 0xf) == 0x7)
+        return launch_pp<T, 0x7>(stream, pass, grid, block, shmem, n);
+    if ((pass->s.comp_mask & 0xf) == 0xf)
+        return launch_pp<T, 0xf>(stream, pass, grid, block, shmem, n);
+    return -1001;
 }
 
 int plh_launch_polar_classify(plh_stream stream, const plh_pass *pass, void *out)
@@ -605,12 +692,13 @@ static int launch_mask(hipStream_t stream, const plh_pass *pass, dim3 grid, dim3
 int plh_launch_polar(hipStream_t stream, const plh_pass *pass)
 {
     const dim3 block(POLAR_BW, POLAR_BH);
-    if (pass->s.pp) {
+    const uint32_t cm = pass->s.comp_mask & 0xf;
+    if (pass->s.pp && (cm == 0x7 || cm == 0xf)) {
         const int n = pass->s.pp_n, cw = pass->s.pp_cells_w, ch = pass->s.pp_cells_h;
         const int cth = POLAR_BH * pass->s.tile_rows;
         const dim3 grid((cw + POLAR_BW - 1) / POLAR_BW, (ch + cth - 1) / cth);
         const size_t px = pass->s.tile_fp32 ? sizeof(float4) : sizeof(uint2);
-        const size_t shmem = 256 * sizeof(float2) + pass->s.pp_lds_weights +
+        const size_t shmem = PP_LDS_FIXED + pass->s.pp_lds_weights +
                              (size_t) pass->s.tile_w * pass->s.tile_h * px;
         if (shmem > 160 * 1024)
             return -1000;

@@ -656,8 +656,8 @@ static bool polar_pp_build(pl_gpu gpu, pl_log log, struct sh_sampler_obj *obj,
             !build_axis_tiles(&ty, idy, rowbase, H, n, pady, POLAR_BH * rows, s->bound))
             goto done;
         // worst-case weights slice; the compacted tap count is only known later
-        lds_w = align16((size_t) tx.max_cnt * ty.max_cnt * (ntaps + 2) * 4);
-        if (2048 + lds_w + (size_t) tx.extent * ty.extent * texel <= max_lds)
+        lds_w = align16((size_t) tx.max_cnt * ty.max_cnt * (ntaps + 4) * 4) + align16(ntaps * 4);
+        if (2048 + 1024 + lds_w + (size_t) tx.extent * ty.extent * texel <= max_lds)
             break;
         if (rows == 1)
             goto done;
@@ -692,7 +692,8 @@ static bool polar_pp_build(pl_gpu gpu, pl_log log, struct sh_sampler_obj *obj,
             keep[ntc++] = t;
     }
     tp = (ntc + 1 + 3) & ~3;    // weights + norm, padded to 16 bytes
-    lds_w = align16((size_t) tx.max_cnt * ty.max_cnt * tp * 4);
+    // + the compacted tap offsets, staged at the tail of this area (k_polar_pp)
+    lds_w = align16((size_t) tx.max_cnt * ty.max_cnt * tp * 4) + align16(ntc * 4);
 
     // ---- 6. one device blob: struct + tables ---------------------------------------------------
     size_t off = align16(sizeof(struct plh_polar_pp));
@@ -790,6 +791,8 @@ void plh_polar_pp_setup(pl_gpu gpu, pl_log log, void *polar_obj, struct plh_pass
     const char *env = getenv("PL_HIP_POLAR_PER_PIXEL");
     if (env && env[0] == '1')
         return;
+    if ((s->comp_mask & 0xf) != 0x7 && (s->comp_mask & 0xf) != 0xf)
+        return; // k_polar_pp is only instantiated for RGB / RGBA
 
     struct polar_pp_key key = {
         .src_w = s->src.w, .src_h = s->src.h, .width = pass->width, .height = pass->height,
