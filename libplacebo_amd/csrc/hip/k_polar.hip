@@ -350,7 +350,7 @@ DEV floatv4_t tile_vec(const tile_px<float> &t)
 
 // the per-pixel weights path for one pixel, on the staged tile (no anti-ringing)
 template <typename T, uint32_t MASK>
-DEV void polar_pixel_generic(const plh_sampler_args &s, const float2 *lut, const tile_px<T> *tp,
+__attribute__((noinline)) __device__ void polar_pixel_generic(const plh_sampler_args &s, const float2 *lut, const tile_px<T> *tp,
                              int tw, float fcx, float fcy, float col[4], float &norm)
 {
     float wsum = 0.0f;
@@ -376,7 +376,7 @@ DEV void polar_pixel_generic(const plh_sampler_args &s, const float2 *lut, const
 // per output row of the workgroup, staged in LDS: class value, base texel, offset of the
 // row class in the weight sub-table
 struct pp_rowinfo { float fc; int32_t base; int32_t woff; int32_t pad; };
-#define PP_LDS_FIXED (2048 + 1024)
+#define PP_LDS_FIXED (2048 + 1024 + 64)   // lut pairs, row info, class lists
 
 template <typename T, uint32_t MASK, int N, bool LITE>
 __global__ __launch_bounds__(POLAR_BW * POLAR_BH)
@@ -399,20 +399,15 @@ void k_polar_pp(const plh_pass p_)
     const int tp = pp.tp, ntaps = pp.ntaps;
 
     // ---- stage LUT pairs, the tile's slice of the weight table, the source tile ---------
+    // Every staging step is written as "issue a batch of independent loads, then store":
+    // a load -> wait -> store loop pays one memory round trip (~1 us) per iteration.
     for (int i = tid; i < 256; i += POLAR_BW * POLAR_BH)
         lut[i] = ((const float2 *) s.lut)[i];
-    {
-        const uint16_t *cl = pp.collist + blockIdx.x * PLH_PP_LMAX;
-        const uint16_t *rl = pp.rowlist + blockIdx.y * PLH_PP_LMAX;
-        for (int ly = 0; ly < ny; ly++) {
-            const int gy = rl[ly];
-            for (int lx = threadIdx.y; lx < nx; lx += POLAR_BH) {
-                const float *src = pp.weights + ((size_t) gy * pp.ncx + cl[lx]) * tp;
-                float *dst = ws + (ly * nx + lx) * tp;
-                for (int t = threadIdx.x; t < tp; t += POLAR_BW)
-                    dst[t] = src[t];
-            }
-        }
+    uint16_t *lists = (uint16_t *) (smem + 2048 + 1024);    // 2 x PLH_PP_LMAX local -> global ids
+    if (tid < 2 * PLH_PP_LMAX) {
+        lists[tid] = tid < PLH_PP_LMAX
+            ? pp.collist[blockIdx.x * PLH_PP_LMAX + tid]
+            : pp.rowlist[blockIdx.y * PLH_PP_LMAX + tid - PLH_PP_LMAX];
     }
     {
         int32_t *toff = (int32_t *) (ws + (s.pp_lds_weights >> 2)) - ((ntaps + 3) & ~3);
@@ -429,23 +424,66 @@ void k_polar_pp(const plh_pass p_)
     // trip of the generic path is the identity)
     const bool raw16 = sizeof(tile_px<T>) == 8 && s.src.fmt == PLH_FMT_RGBA16F && !p.num_pre_ops;
     const float rcp_tw = 1.0f / (float) tw;
-    for (int i = tid; i < tw * th; i += POLAR_BW * POLAR_BH) {
-        const int ty = (int) (((float) i + 0.5f) * rcp_tw), tx = i - ty * tw;  // exact: i < 2^22
-        const int sx = plh_wrap(ox + tx, s.src.w, s.address_mode);
-        const int sy = plh_wrap(oy + ty, s.src.h, s.address_mode);
-        if (raw16) {
-            *(uint2 *) &tile[i] = *(const uint2 *) ((const char *) s.src.ptr +
-                                                    (size_t) sy * s.src.pitch + (size_t) sx * 8);
-            continue;
-        }
-        float4_t c = plh_fetch(s.src, sx, sy);
-        if constexpr (!LITE) {
-            if (p.num_pre_ops) {
-                const frag_t fc = { (float) sx + 0.5f, (float) sy + 0.5f };
-                apply_ops(c, p.ops, 0, p.num_pre_ops, fc);
+    if (s.pp_debug & 8) {
+    } else if (raw16) {
+        // batches of 4 independent 8-byte loads per lane, so that a tile costs two memory
+        // round trips instead of one per texel
+        for (int i0 = tid; i0 < tw * th; i0 += 4 * POLAR_BW * POLAR_BH) {
+            uint2 v[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const int i = min(i0 + u * POLAR_BW * POLAR_BH, tw * th - 1);
+                const int ty = (int) (((float) i + 0.5f) * rcp_tw), tx = i - ty * tw;
+                const int sx = plh_wrap(ox + tx, s.src.w, s.address_mode);
+                const int sy = plh_wrap(oy + ty, s.src.h, s.address_mode);
+                v[u] = *(const uint2 *) ((const char *) s.src.ptr + (size_t) sy * s.src.pitch +
+                                         (size_t) sx * 8);
+            }
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const int i = i0 + u * POLAR_BW * POLAR_BH;
+                if (i < tw * th)
+                    *(uint2 *) &tile[i] = v[u];
             }
         }
-        tile_put(tile[i], c);
+    } else {
+        for (int i = tid; i < tw * th; i += POLAR_BW * POLAR_BH) {
+            const int ty = (int) (((float) i + 0.5f) * rcp_tw), tx = i - ty * tw;  // exact: i < 2^22
+            const int sx = plh_wrap(ox + tx, s.src.w, s.address_mode);
+            const int sy = plh_wrap(oy + ty, s.src.h, s.address_mode);
+            float4_t c = plh_fetch(s.src, sx, sy);
+            if constexpr (!LITE) {
+                if (p.num_pre_ops) {
+                    const frag_t fc = { (float) sx + 0.5f, (float) sy + 0.5f };
+                    apply_ops(c, p.ops, 0, p.num_pre_ops, fc);
+                }
+            }
+            tile_put(tile[i], c);
+        }
+    }
+    __syncthreads();
+
+    {
+        // the tile's slice of the weight table: float4 units, 4 in flight per lane
+        const int tp4 = tp >> 2, units = nx * ny * tp4;
+        const float rcp_tp4 = 1.0f / (float) tp4, rcp_nx = 1.0f / (float) nx;
+        for (int u0 = tid; u0 < ((s.pp_debug & 16) ? 0 : units); u0 += 4 * POLAR_BW * POLAR_BH) {
+            float4 v[4];
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const int u = min(u0 + k * POLAR_BW * POLAR_BH, units - 1);
+                const int pair = (int) (((float) u + 0.5f) * rcp_tp4), t4 = u - pair * tp4;
+                const int ly = (int) (((float) pair + 0.5f) * rcp_nx), lx = pair - ly * nx;
+                const size_t g = (size_t) lists[PLH_PP_LMAX + ly] * pp.ncx + lists[lx];
+                v[k] = *(const float4 *) (pp.weights + g * tp + t4 * 4);
+            }
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const int u = u0 + k * POLAR_BW * POLAR_BH;
+                if (u < units)
+                    *(float4 *) (ws + u * 4) = v[k];
+            }
+        }
     }
     __syncthreads();
 
@@ -461,7 +499,18 @@ void k_polar_pp(const plh_pass p_)
     int cwoff[N];           // offset of the column's class in the weight sub-table
     float cfc[N];
     float attr[N][4];       // the fx halves of the attribute interpolation (plh_attr)
+    float refx[N];          // pos.x of the column as the tables saw it (row 0)
+    bool cgood[N];          // refx reproduces the column's tabulated fcoord/base, and the
+                            // column's fy halves are those the row tables were built with
+    bool cok[N];            // column passes the store guards
+    int cpos[N];            // target coordinate contributed by the column
+    float fragx[N];
     int cbase;
+    const float sw = (float) s.src.w, sh = (float) s.src.h;
+    // attribute halves of column 0 (the row tables were evaluated there) and fy of row 0
+    const float mx0 = p.out_scale[0] * 0.5f, my0 = p.out_scale[1] * 0.5f;
+    const float y0a = plh_mix(s.pos[0][1], s.pos[1][1], mx0);
+    const float y0b = plh_mix(s.pos[2][1], s.pos[3][1], mx0);
     {
         int b = 0;
 #pragma unroll
@@ -480,10 +529,25 @@ void k_polar_pp(const plh_pass p_)
                 b = pp.colbase[xc];
         }
         cbase = b;
+#pragma unroll
+        for (int i = 0; i < N; i++) {
+            refx[i] = plh_mix(attr[i][0], attr[i][1], my0);
+            const float tx_ = refx[i] * sw - 0.5f, flx = __builtin_floorf(tx_);
+            cgood[i] = __float_as_uint(tx_ - flx) == __float_as_uint(cfc[i]) &&
+                       (int) flx == cbase &&
+                       __float_as_uint(attr[i][2]) == __float_as_uint(y0a) &&
+                       __float_as_uint(attr[i][3]) == __float_as_uint(y0b);
+            const int idx = colx[i];
+            cpos[i] = p.transpose ? p.base_y + p.dir_y * idx : p.base_x + p.dir_x * idx;
+            cok[i] = idx >= 0 && idx < p.width && p.out_scale[0] * (float) idx < 1.0f &&
+                     cpos[i] >= 0 && cpos[i] < (p.transpose ? p.dst.h : p.dst.w) &&
+                     !(s.pp_debug & 4);
+            fragx[i] = (float) (idx + p.frag_x0) + 0.5f;
+        }
     }
 
 #pragma unroll 1
-    for (int r = 0; r < rows; r++) {
+    for (int r = 0; r < ((s.pp_debug & 64) ? 0 : rows); r++) {
         const int celly = (blockIdx.y * rows + r) * POLAR_BH + threadIdx.y;
         int rowy[N], rwoff[N];
         float rfc[N];
@@ -528,8 +592,9 @@ void k_polar_pp(const plh_pass p_)
 
         const int32_t *tapoff = (const int32_t *) (ws + (s.pp_lds_weights >> 2)) -
                                 ((ntaps + 3) & ~3);
+        const int nt_run = (s.pp_debug & 1) ? 0 : ntaps;
 #pragma unroll 4
-        for (int t = 0; t < ntaps; t++) {
+        for (int t = 0; t < nt_run; t++) {
             // byte offset of the tap inside the tile (host: (y * tile_w + x) * sizeof(texel));
             // an LDS broadcast read keeps the loop free of scalar-memory waits
             const floatv4_t c = tile_vec(*(const tile_px<T> *) ((const char *) tp0 + tapoff[t]));
@@ -548,74 +613,61 @@ void k_polar_pp(const plh_pass p_)
         }
 
         // ---- normalise, verify, post-ops, store ------------------------------------------
-        // (rolled over the lane's rows, unrolled over its columns: the post-ops are large)
-#pragma unroll 1
+        if (s.pp_debug & 32)
+            continue;
+        float4_t outs[N * N];
+        frag_t fcs[N * N];
+        int sx[N * N], sy[N * N];
+        bool ok[N * N];
+#pragma unroll
         for (int j = 0; j < N; j++) {
-            floatv4_t a[N];
-            const float *w[N];
-            float bs[N];
-            int idy = rowy[0];
-            float tfy = rfc[0];
-#pragma unroll
-            for (int i = 0; i < N; i++) {
-                a[i] = acc[0][i]; w[i] = wp[0][i]; bs[i] = bias[0][i];
-            }
-#pragma unroll
-            for (int jj = 1; jj < N; jj++) {
-                if (jj == j) {
-                    idy = rowy[jj]; tfy = rfc[jj];
-#pragma unroll
-                    for (int i = 0; i < N; i++) {
-                        a[i] = acc[jj][i]; w[i] = wp[jj][i]; bs[i] = bias[jj][i];
-                    }
-                }
-            }
-            if (idy < 0 || idy >= p.height)
-                continue;
+            const int idy = rowy[j];
             const float my = p.out_scale[1] * ((float) idy + 0.5f);
-            const float gy = p.out_scale[1] * (float) idy;
-
+            // the row as the tables saw it (column 0): pos.y -> fcoord.y / base
+            const float ty_ = plh_mix(y0a, y0b, my) * sh - 0.5f, fly = __builtin_floorf(ty_);
+            const bool rgood = __float_as_uint(ty_ - fly) == __float_as_uint(rfc[j]) &&
+                               (int) fly == rbase;
+            const int rpos = p.transpose ? p.base_x + p.dir_x * idy : p.base_y + p.dir_y * idy;
+            const bool rok = idy >= 0 && idy < p.height && p.out_scale[1] * (float) idy < 1.0f &&
+                             rpos >= 0 && rpos < (p.transpose ? p.dst.w : p.dst.h);
+            const float fragy = (float) (idy + p.frag_y0) + 0.5f;
 #pragma unroll
             for (int i = 0; i < N; i++) {
-                const int idx = colx[i];
-                if (idx < 0 || idx >= p.width)
-                    continue;
-                float col[4] = { a[i][0], a[i][1], a[i][2], a[i][3] };
-                float norm = w[i][ntaps];
+                const int q = j * N + i;
+                float col[4] = { acc[j][i][0], acc[j][i][1], acc[j][i][2], acc[j][i][3] };
+                float norm = wp[j][i][ntaps];
 
-                // this pixel's own fcoord / base: polar_coord() with the fx halves hoisted
-                const float tx_ = plh_mix(attr[i][0], attr[i][1], my) * (float) s.src.w - 0.5f;
-                const float ty_ = plh_mix(attr[i][2], attr[i][3], my) * (float) s.src.h - 0.5f;
-                const float flx = __builtin_floorf(tx_), fly = __builtin_floorf(ty_);
-                const float fcx = tx_ - flx, fcy = ty_ - fly;
-                const int bx = (int) flx, by = (int) fly;
-                if (__float_as_uint(fcx) != __float_as_uint(cfc[i]) ||
-                    __float_as_uint(fcy) != __float_as_uint(tfy) || bx != cbase || by != rbase) {
-                    // not the tabulated phase after all: per-pixel weights (the tile has one
-                    // texel of slack per side for a base that is off by one)
+                // Is this pixel's own fcoord/base the tabulated one? pos.x must equal the
+                // column's reference (the fy interpolation of two equal halves is the identity
+                // except for rounding ties); pos.y equals the row's reference by construction
+                // when the column's fy halves are those of column 0 (cgood).
+                const float px = plh_mix(attr[i][0], attr[i][1], my);
+                const bool same = __float_as_uint(px) == __float_as_uint(refx[i]) && cgood[i] &&
+                                  rgood;
+                if (cok[i] && rok && !same && !(s.pp_debug & 2)) {
+                    // no: per-pixel weights (the tile has one texel of slack per side for a
+                    // base that is off by one)
+                    float fcx, fcy;
+                    int bx, by;
+                    polar_coord(p, colx[i], idy, fcx, fcy, bx, by);
                     const int rx = min(max(bx - ox, s.bound - 1), tw - s.bound - 1);
                     const int ry = min(max(by - oy, s.bound - 1), th - s.bound - 1);
                     polar_pixel_generic<T, MASK>(s, lut, tile + ry * tw + rx, tw, fcx, fcy,
                                                  col, norm);
                 }
 
-                float4_t out = { norm * col[0], norm * col[1], norm * col[2], norm * col[3] };
+                outs[q] = { norm * col[0], norm * col[1], norm * col[2], norm * col[3] };
                 if (!(MASK & 8u))
-                    out.w = 1.0f;
-                const frag_t fc = { (float) (idx + p.frag_x0) + 0.5f,
-                                    (float) (idy + p.frag_y0) + 0.5f, bs[i], dither_op >= 0 };
-                apply_ops<false, LITE>(out, p.ops, p.num_pre_ops, p.num_ops, fc);
-
-                // guarded store (dispatch.c:1126-1142)
-                const float gx = p.out_scale[0] * (float) idx;
-                if (gx < 1.0f && gy < 1.0f) {
-                    const int oxp = p.base_x + p.dir_x * (p.transpose ? idy : idx);
-                    const int oyp = p.base_y + p.dir_y * (p.transpose ? idx : idy);
-                    if (oxp >= 0 && oyp >= 0 && oxp < p.dst.w && oyp < p.dst.h)
-                        plh_store(p.dst, oxp, oyp, out);
-                }
+                    outs[q].w = 1.0f;
+                fcs[q] = { fragx[i], fragy, bias[j][i], dither_op >= 0 };
+                // guarded store (dispatch.c:1126-1142), guards hoisted per column / row
+                sx[q] = p.transpose ? rpos : cpos[i];
+                sy[q] = p.transpose ? cpos[i] : rpos;
+                ok[q] = cok[i] && rok;
             }
         }
+        apply_ops_n<N * N, false, LITE>(outs, p.ops, p.num_pre_ops, p.num_ops, fcs);
+        plh_store_n<N * N>(p.dst, sx, sy, ok, outs);
     }
 }
 

@@ -113,6 +113,7 @@ struct plh_sampler_args {
     const struct plh_polar_pp *pp;  // device; NULL = per-pixel weights
     int32_t pp_lds_weights; // bytes of LDS for the staged weight sub-table
     int32_t pp_n, pp_cells_w, pp_cells_h;   // host copies of pp->n, cells_w, cells_h
+    int32_t pp_debug;       // profiling aid (PL_HIP_PP_DEBUG): 1 = no taps, 2 = no verify, 4 = no store
 
     // ORTHO: weights[256][row_stride] rows; N taps along `dir`
     const float *weights;   // device

@@ -657,7 +657,7 @@ static bool polar_pp_build(pl_gpu gpu, pl_log log, struct sh_sampler_obj *obj,
             goto done;
         // worst-case weights slice; the compacted tap count is only known later
         lds_w = align16((size_t) tx.max_cnt * ty.max_cnt * (ntaps + 4) * 4) + align16(ntaps * 4);
-        if (2048 + 1024 + lds_w + (size_t) tx.extent * ty.extent * texel <= max_lds)
+        if (2048 + 1024 + 64 + lds_w + (size_t) tx.extent * ty.extent * texel <= max_lds)
             break;
         if (rows == 1)
             goto done;
@@ -815,6 +815,8 @@ void plh_polar_pp_setup(pl_gpu gpu, pl_log log, void *polar_obj, struct plh_pass
     s->pp_cells_w = obj->pp_host.cells_w;
     s->pp_cells_h = obj->pp_host.cells_h;
     s->pp_lds_weights = obj->pp_lds_weights;
+    const char *dbg = getenv("PL_HIP_PP_DEBUG");
+    s->pp_debug = dbg ? atoi(dbg) : 0;
     s->tile_w = obj->pp_tile_w;
     s->tile_h = obj->pp_tile_h;
     s->tile_rows = obj->pp_rows;
