@@ -7,10 +7,7 @@
  * all. The sampled colour then runs through the recorded colour-op chain and
  * is stored with the target format's conversion.
  *
- * Launch shape: 64x4 threads, one output pixel per lane; consecutive lanes
- * write consecutive texels (512 B per wave row at rgba16). Memory-bound: every
- * source texel and every target texel crosses HBM once (bilinear re-reads hit
- * L1/L2).
+ * Memory-bound: every source texel and every target texel crosses HBM once.
  */
 #include "colorops.hiph"
 #include "samplers.hiph"
@@ -44,40 +41,113 @@ DEV float4_t run_sampler(const plh_sampler_args &s, float px, float py)
     return c;
 }
 
-// Guarded store of translate_compute_shader (dispatch.c:1126-1142)
-DEV void pass_store(const plh_pass &p, int idx, int idy, const float4_t &c)
+// Bilinear footprint of one output pixel (tex_linear, samplers.hiph)
+struct lin_fp { int x0, x1, y0, y1; float ax, ay; };
+
+DEV lin_fp lin_footprint(const plh_view &v, int mode, float px, float py)
 {
-    const float fx = p.out_scale[0] * (float) idx, fy = p.out_scale[1] * (float) idy;
-    if (!(fx < 1.0f && fy < 1.0f))
-        return;
-    const int ox = p.base_x + p.dir_x * (p.transpose ? idy : idx);
-    const int oy = p.base_y + p.dir_y * (p.transpose ? idx : idy);
-    if (ox < 0 || oy < 0 || ox >= p.dst.w || oy >= p.dst.h)
-        return; // imageStore outside the image is a no-op
-    plh_store(p.dst, ox, oy, c);
+    const float u = px * (float) v.w - 0.5f, w = py * (float) v.h - 0.5f;
+    const float fu = __builtin_floorf(u), fw = __builtin_floorf(w);
+    lin_fp f;
+    f.ax = u - fu; f.ay = w - fw;
+    f.x0 = plh_wrap((int) fu, v.w, mode); f.x1 = plh_wrap((int) fu + 1, v.w, mode);
+    f.y0 = plh_wrap((int) fw, v.h, mode); f.y1 = plh_wrap((int) fw + 1, v.h, mode);
+    return f;
 }
 
+/*
+ * Launch shape: 64x4 lanes, each lane owns a 2x2 block of output pixels (cell), so a
+ * workgroup writes 128x8 pixels and a lane stores two adjacent texels per row (16 B at
+ * rgba16). Owning four pixels lets the lane
+ *   - decode the recorded colour ops once for four pixels (apply_ops_n), and
+ *   - for BILINEAR upscaling, fetch and decode the 2x2 source footprint once when the four
+ *     pixels share it (always the case for a 2x upscale with the host-chosen cell phase):
+ *     8 B/pixel through L1 instead of 32.
+ * LITE: pass only uses the cheap ops (plh_ops_lite) -> smaller kernel, more waves.
+ */
+template <bool LITE>
 __global__ __launch_bounds__(PASS_BW * PASS_BH)
 void k_pass_generic(const plh_pass p_)
 {
     const plh_pass &p = plh_kernarg_pass();
-    const int idx = blockIdx.x * PASS_BW + threadIdx.x;
-    const int idy = blockIdx.y * PASS_BH + threadIdx.y;
-    // whole groups are launched; lanes beyond the padded rect still run the
-    // maths in the reference and are dropped by the store guard
-    const float mx = p.out_scale[0] * ((float) idx + 0.5f);
-    const float my = p.out_scale[1] * ((float) idy + 0.5f);
+    const plh_sampler_args &s = p.s;
+    const int cx = blockIdx.x * PASS_BW + threadIdx.x;
+    const int cy = blockIdx.y * PASS_BH + threadIdx.y;
 
-    float4_t c = {0.0f, 0.0f, 0.0f, 1.0f};
-    if (p.s.type != PLH_SAMPLE_NONE) {
-        const float px = plh_attr(p.s.pos, 0, mx, my);
-        const float py = plh_attr(p.s.pos, 1, mx, my);
-        c = run_sampler(p.s, px, py);
+    float4_t c[4];
+    frag_t fcs[4];
+    int sx[4], sy[4];
+    bool ok[4];
+    float px[4], py[4];
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+        const int idx = 2 * cx - p.cell_padx + (q & 1), idy = 2 * cy - p.cell_pady + (q >> 1);
+        // lanes beyond the rect still run the maths in the reference and are dropped by the
+        // store guard (dispatch.c:1126-1142)
+        const float mx = p.out_scale[0] * ((float) idx + 0.5f);
+        const float my = p.out_scale[1] * ((float) idy + 0.5f);
+        px[q] = plh_attr(s.pos, 0, mx, my);
+        py[q] = plh_attr(s.pos, 1, mx, my);
+        fcs[q] = { (float) (idx + p.frag_x0) + 0.5f, (float) (idy + p.frag_y0) + 0.5f, 0.0f, 0 };
+        sx[q] = p.base_x + p.dir_x * (p.transpose ? idy : idx);
+        sy[q] = p.base_y + p.dir_y * (p.transpose ? idx : idy);
+        ok[q] = idx >= 0 && idy >= 0 && p.out_scale[0] * (float) idx < 1.0f &&
+                p.out_scale[1] * (float) idy < 1.0f && sx[q] >= 0 && sy[q] >= 0 &&
+                sx[q] < p.dst.w && sy[q] < p.dst.h;
+        c[q] = {0.0f, 0.0f, 0.0f, 1.0f};
     }
 
-    const frag_t fc = { (float) (idx + p.frag_x0) + 0.5f, (float) (idy + p.frag_y0) + 0.5f };
-    apply_ops(c, p.ops, 0, p.num_ops, fc);
-    pass_store(p, idx, idy, c);
+    switch (s.type) {
+    case PLH_SAMPLE_NONE:
+        break;
+    case PLH_SAMPLE_NEAREST:
+#pragma unroll
+        for (int q = 0; q < 4; q++)
+            c[q] = scale4(tex_nearest(s.src, s.address_mode, px[q], py[q]), s.scale);
+        break;
+    case PLH_SAMPLE_BILINEAR: {
+        lin_fp f[4];
+#pragma unroll
+        for (int q = 0; q < 4; q++)
+            f[q] = lin_footprint(s.src, s.address_mode, px[q], py[q]);
+        bool shared = true;
+#pragma unroll
+        for (int q = 1; q < 4; q++) {
+            shared = shared && f[q].x0 == f[0].x0 && f[q].x1 == f[0].x1 &&
+                     f[q].y0 == f[0].y0 && f[q].y1 == f[0].y1;
+        }
+        if (shared) {
+            const float4_t t00 = plh_fetch(s.src, f[0].x0, f[0].y0);
+            const float4_t t10 = plh_fetch(s.src, f[0].x1, f[0].y0);
+            const float4_t t01 = plh_fetch(s.src, f[0].x0, f[0].y1);
+            const float4_t t11 = plh_fetch(s.src, f[0].x1, f[0].y1);
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                c[q] = scale4(mix4(mix4(t00, t10, f[q].ax), mix4(t01, t11, f[q].ax), f[q].ay),
+                              s.scale);
+            }
+        } else {
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                const float4_t t00 = plh_fetch(s.src, f[q].x0, f[q].y0);
+                const float4_t t10 = plh_fetch(s.src, f[q].x1, f[q].y0);
+                const float4_t t01 = plh_fetch(s.src, f[q].x0, f[q].y1);
+                const float4_t t11 = plh_fetch(s.src, f[q].x1, f[q].y1);
+                c[q] = scale4(mix4(mix4(t00, t10, f[q].ax), mix4(t01, t11, f[q].ax), f[q].ay),
+                              s.scale);
+            }
+        }
+        break;
+    }
+    default:
+#pragma unroll
+        for (int q = 0; q < 4; q++)
+            c[q] = run_sampler(s, px[q], py[q]);
+        break;
+    }
+
+    apply_ops_n<4, false, LITE>(c, p.ops, 0, p.num_ops, fcs);
+    plh_store_n<4>(p.dst, sx, sy, ok, c);
 }
 
 /* ------------------------------------------------------------------------ */
@@ -111,9 +181,13 @@ extern "C" int plh_launch_pass(plh_stream stream_, const struct plh_pass *pass)
     }
 
     const dim3 block(PASS_BW, PASS_BH);
-    const dim3 grid((pass->width + PASS_BW - 1) / PASS_BW,
-                    (pass->height + PASS_BH - 1) / PASS_BH);
-    hipLaunchKernelGGL(k_pass_generic, grid, block, 0, stream, *pass);
+    const int cells_w = (pass->width + pass->cell_padx + 1) / 2;
+    const int cells_h = (pass->height + pass->cell_pady + 1) / 2;
+    const dim3 grid((cells_w + PASS_BW - 1) / PASS_BW, (cells_h + PASS_BH - 1) / PASS_BH);
+    if (plh_ops_lite(pass, 0, pass->num_ops))
+        hipLaunchKernelGGL(k_pass_generic<true>, grid, block, 0, stream, *pass);
+    else
+        hipLaunchKernelGGL(k_pass_generic<false>, grid, block, 0, stream, *pass);
     const hipError_t err = hipGetLastError();
     return err == hipSuccess ? 0 : -(int) err;
 }

@@ -194,6 +194,9 @@ struct plh_pass {
     float out_scale[2];     // 1/width, 1/height (dispatch.c:1032-1036)
     int32_t transpose;
     int32_t frag_x0, frag_y0; // offset added to gl_FragCoord (0 for compute passes)
+    // k_pass: a lane owns the 2x2 outputs [2c - pad, 2c - pad + 2) per axis; the pad that
+    // makes the four bilinear footprints of a 2x upscale coincide is chosen by the host
+    int32_t cell_padx, cell_pady;
 
     // peak detection side output (k_peak)
     void *peak_buf;

@@ -10,6 +10,7 @@
  *   - blending is not supported (never used on the pl_render_image path with
  *     blend_params == NULL)
  */
+#include <math.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -158,6 +159,32 @@ static void drain_timing(pl_dispatch dp, struct pass_timing *t)
     }
 }
 
+// k_pass lanes own 2x2 output cells. For a bilinear upscale, pick the cell phase for which
+// the outputs of a cell share their 2x2 source footprint (an efficiency hint only: the kernel
+// checks the footprints itself).
+static void plh_pass_choose_cells(struct plh_pass *pass)
+{
+    pass->cell_padx = pass->cell_pady = 0;
+    if (pass->s.type != PLH_SAMPLE_BILINEAR)
+        return;
+    const struct plh_sampler_args *s = &pass->s;
+    for (int axis = 0; axis < 2; axis++) {
+        const int n = axis ? pass->height : pass->width;
+        if (n < 2)
+            continue;
+        // texel-space coordinate of the first two outputs along this axis
+        const double p0 = s->pos[0][axis], p1 = axis ? s->pos[2][axis] : s->pos[1][axis];
+        const double size = axis ? s->src.h : s->src.w;
+        const double u0 = (p0 + (p1 - p0) * (0.5 / n)) * size - 0.5;
+        const double u1 = (p0 + (p1 - p0) * (1.5 / n)) * size - 0.5;
+        const int pad = floor(u0) != floor(u1);
+        if (axis)
+            pass->cell_pady = pad;
+        else
+            pass->cell_padx = pad;
+    }
+}
+
 bool pl_dispatch_finish(pl_dispatch dp, const struct pl_dispatch_params *params)
 {
     pl_shader sh = *params->shader;
@@ -229,6 +256,7 @@ bool pl_dispatch_finish(pl_dispatch dp, const struct pl_dispatch_params *params)
 
     if (pass->s.type == PLH_SAMPLE_POLAR && sh->polar_obj)
         plh_polar_pp_setup(dp->gpu, dp->log, sh->polar_obj, pass);
+    plh_pass_choose_cells(pass);
 
     struct pass_timing *timing = get_timing(dp, sh);
     pl_timer timer = params->timer ? params->timer : timing ? timing->timer : NULL;
@@ -293,6 +321,7 @@ bool pl_dispatch_compute(pl_dispatch dp, const struct pl_dispatch_compute_params
         }
         struct plh_pass *pass = &sh->pass;
         memset(&pass->dst, 0, sizeof(pass->dst)); // every store is out of bounds
+        pass->cell_padx = pass->cell_pady = 0;
         pass->width = params->width;
         pass->height = params->height;
         pass->out_scale[0] = 1.0 / params->width;
