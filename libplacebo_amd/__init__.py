@@ -190,6 +190,15 @@ class Shader:
         self._keep.append(fp)
         return lib().pl_shader_sample_ortho2(self.sh, C.byref(s), C.byref(fp))
 
+    def deband(self, tex, iterations=1, threshold=3.0, radius=16.0, grain=4.0,
+               grain_neutral=(0.0, 0.0, 0.0), **kw):
+        s = self._src(tex, **kw)
+        dp = capi.DebandParams(iterations, threshold, radius, grain,
+                               (C.c_float * 3)(*grain_neutral))
+        self._keep.append(dp)
+        lib().pl_shader_deband(self.sh, C.byref(s), C.byref(dp))
+        return not self.failed()
+
     def dither(self, depth, state_obj, method=DITHER_BLUE_NOISE, lut_size=6, temporal=False,
                transfer=3):
         dp = capi.DitherParams(method=method, lut_size=lut_size, temporal=temporal,

@@ -1,0 +1,127 @@
+/*
+ * libplacebo-hip — debanding kernel (K6).
+ *
+ * Device half of pl_shader_deband (src/shaders/sampling.c:183-275) with the
+ * pcg3d PRNG of sh_prng (src/shaders.c:965-998):
+ *
+ *   color = texel(pos);  res = color.<mask>
+ *   for i = 1 .. iterations:
+ *       d   = rand().xy * (i * radius, 2*pi);  d = d.x * (cos d.y, sin d.y)
+ *       avg = 0.25 * (T(+dx,+dy) + T(-dx,+dy) + T(-dx,-dy) + T(+dx,-dy))   (nearest fetches)
+ *       res = |res - avg| > threshold / i ? res : avg
+ *   res += min(|res - neutral|, grain) * (rand() - 0.5)
+ *   color.<mask> = res;  color *= scale
+ *
+ * The PRNG state is uvec3(gl_FragCoord.xy, frame index); integer arithmetic
+ * mod 2^32, i.e. bit-exact. sin/cos use the accurate (ocml) versions so that
+ * the sample positions agree with the libm oracle except on texel boundaries.
+ *
+ * Launch shape: 64x4 lanes, one pixel per lane. 4*iterations + 1 data-dependent
+ * 8..16-byte gathers per pixel within `radius` texels of it: served by L2/MALL,
+ * HBM traffic stays one read + one write of the plane.
+ */
+#include "colorops.hiph"
+#include "samplers.hiph"
+
+#define DEBAND_BW 64
+#define DEBAND_BH 4
+
+struct prng3 { uint32_t x, y, z; };
+
+DEV void pcg3d(prng3 &s, float out[3])
+{
+    s.x = 1664525u * s.x + 1013904223u;
+    s.y = 1664525u * s.y + 1013904223u;
+    s.z = 1664525u * s.z + 1013904223u;
+    s.x += s.y * s.z; s.y += s.z * s.x; s.z += s.x * s.y;
+    s.x ^= s.x >> 16; s.y ^= s.y >> 16; s.z ^= s.z >> 16;
+    s.x += s.y * s.z; s.y += s.z * s.x; s.z += s.x * s.y;
+    // vec3(s) * 1.0/float(0xFFFFFFFFu): float(0xFFFFFFFF) rounds to 2^32
+    const float k = 1.0f / 4294967296.0f;
+    out[0] = (float) s.x * k; out[1] = (float) s.y * k; out[2] = (float) s.z * k;
+}
+
+template <bool LITE>
+__global__ __launch_bounds__(DEBAND_BW * DEBAND_BH)
+void k_deband(const plh_pass p_)
+{
+    const plh_pass &p = plh_kernarg_pass();
+    const plh_sampler_args &s = p.s;
+    const int idx = blockIdx.x * DEBAND_BW + threadIdx.x;
+    const int idy = blockIdx.y * DEBAND_BH + threadIdx.y;
+    const float mx = p.out_scale[0] * ((float) idx + 0.5f);
+    const float my = p.out_scale[1] * ((float) idy + 0.5f);
+    const float px = plh_attr(s.pos, 0, mx, my), py = plh_attr(s.pos, 1, mx, my);
+    const frag_t fc = { (float) (idx + p.frag_x0) + 0.5f, (float) (idy + p.frag_y0) + 0.5f, 0.0f, 0 };
+
+    float4_t color = tex_nearest(s.src, s.address_mode, px, py);
+    float res[3] = { color.x, color.y, color.z };
+    const uint32_t mask = s.comp_mask & 7u;
+
+    prng3 st = { (uint32_t) fc.x, (uint32_t) fc.y, s.prng_seed };
+    float rnd[3];
+    for (int i = 1; i <= s.iterations; i++) {
+        pcg3d(st, rnd);
+        float dx = rnd[0] * ((float) i * s.db_radius);
+        const float ang = rnd[1] * 6.283185f;       // "%f" of 2*pi
+        const float dy = dx * sinf(ang);
+        dx = dx * cosf(ang);
+        float avg[3] = {0.0f, 0.0f, 0.0f};
+        const float ox[4] = { dx, -dx, -dx, dx }, oy[4] = { dy, dy, -dy, -dy };
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const float4_t t = tex_nearest(s.src, s.address_mode, px + s.pt[0] * ox[k],
+                                           py + s.pt[1] * oy[k]);
+            avg[0] += t.x; avg[1] += t.y; avg[2] += t.z;
+        }
+        const float bound = s.db_threshold / (float) i;
+#pragma unroll
+        for (int c = 0; c < 3; c++) {
+            const float a = avg[c] * 0.25f;
+            const float diff = __builtin_fabsf(res[c] - a);
+            if (mask & (1u << c))
+                res[c] = diff > bound ? res[c] : a;
+        }
+    }
+
+    if (s.db_grain > 0.0f) {
+        pcg3d(st, rnd);
+        // T(rand): the first num_comps components of the vec3, in enabled-component order
+        int k = 0;
+#pragma unroll
+        for (int c = 0; c < 3; c++) {
+            if (!(mask & (1u << c)))
+                continue;
+            const float strength = fminf(__builtin_fabsf(res[c] - s.db_neutral[c]), s.db_grain);
+            res[c] += strength * (rnd[k++] - 0.5f);
+        }
+    }
+
+    if (mask & 1u) color.x = res[0];
+    if (mask & 2u) color.y = res[1];
+    if (mask & 4u) color.z = res[2];
+    color.x *= s.scale; color.y *= s.scale; color.z *= s.scale; color.w *= s.scale;
+
+    float4_t outs[1] = { color };
+    const frag_t fcs[1] = { fc };
+    apply_ops_n<1, false, LITE>(outs, p.ops, 0, p.num_ops, fcs);
+
+    const int sx[1] = { p.base_x + p.dir_x * (p.transpose ? idy : idx) };
+    const int sy[1] = { p.base_y + p.dir_y * (p.transpose ? idx : idy) };
+    const bool ok[1] = { p.out_scale[0] * (float) idx < 1.0f && p.out_scale[1] * (float) idy < 1.0f &&
+                         sx[0] >= 0 && sy[0] >= 0 && sx[0] < p.dst.w && sy[0] < p.dst.h };
+    plh_store_n<1>(p.dst, sx, sy, ok, outs);
+}
+
+int plh_launch_deband(hipStream_t stream, const plh_pass *pass)
+{
+    const dim3 block(DEBAND_BW, DEBAND_BH);
+    const dim3 grid((pass->width + DEBAND_BW - 1) / DEBAND_BW,
+                    (pass->height + DEBAND_BH - 1) / DEBAND_BH);
+    if (plh_ops_lite(pass, 0, pass->num_ops))
+        hipLaunchKernelGGL(k_deband<true>, grid, block, 0, stream, *pass);
+    else
+        hipLaunchKernelGGL(k_deband<false>, grid, block, 0, stream, *pass);
+    const hipError_t err = hipGetLastError();
+    return err == hipSuccess ? 0 : -(int) err;
+}

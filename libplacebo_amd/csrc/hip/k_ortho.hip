@@ -1,0 +1,143 @@
+/*
+ * libplacebo-hip — separable (orthogonal) resampling kernel (K4).
+ *
+ * Device half of pl_shader_sample_ortho2 (src/shaders/sampling.c:950-1104): one
+ * 1-D convolution along `dir` with N = row_size taps,
+ *
+ *   fcoord = fract(pos*size - 0.5)[dir];  first tap = floor(pos*size - 0.5)[dir] - (N/2 - 1)
+ *   ws     = LUT row at fcoord (256 rows, linearly interpolated between rows)
+ *   ca    += ws[n] * texel(first + n)                      n = 0 .. N-1
+ *   "linear trick" filters (radius == radius_zero): taps come in pairs that one
+ *   bilinear fetch evaluates: ca += (w0+w1) * mix(t[n], t[n+1], w1/(w0+w1))
+ *   anti-ringing: clamp to [min, max] of the two centre taps, mixed by strength
+ *   color = scale * ca
+ *
+ * Texture-unit emulation: every tap sits on a texel centre along `dir`, where a
+ * TMU returns the texel itself; across `dir` the host tells us whether the pass
+ * is on the texel grid (nearest) or needs the exact-fp32 bilinear blend.
+ *
+ * Launch shape: 64x4 lanes, one output pixel per lane. Consecutive lanes read
+ * consecutive texels for every tap (vertical pass) or overlapping windows
+ * (horizontal pass, served by L1), so HBM sees each source row once.
+ */
+#include "colorops.hiph"
+#include "samplers.hiph"
+
+#define ORTHO_BW 64
+#define ORTHO_BH 4
+
+// texel (i along dir, `o` across it) with the across-axis filtering rule
+DEV float4_t ortho_fetch(const plh_sampler_args &s, int i, int o0, int o1, float ofrac)
+{
+    const int n = s.dir ? s.src.h : s.src.w;
+    const int iw = plh_wrap(i, n, s.address_mode);
+    if (!s.linear)
+        return s.dir ? plh_fetch(s.src, o0, iw) : plh_fetch(s.src, iw, o0);
+    const float4_t a = s.dir ? plh_fetch(s.src, o0, iw) : plh_fetch(s.src, iw, o0);
+    const float4_t b = s.dir ? plh_fetch(s.src, o1, iw) : plh_fetch(s.src, iw, o1);
+    return mix4(a, b, ofrac);
+}
+
+template <bool LITE>
+__global__ __launch_bounds__(ORTHO_BW * ORTHO_BH)
+void k_ortho(const plh_pass p_)
+{
+    const plh_pass &p = plh_kernarg_pass();
+    const plh_sampler_args &s = p.s;
+    const int idx = blockIdx.x * ORTHO_BW + threadIdx.x;
+    const int idy = blockIdx.y * ORTHO_BH + threadIdx.y;
+    const float mx = p.out_scale[0] * ((float) idx + 0.5f);
+    const float my = p.out_scale[1] * ((float) idy + 0.5f);
+    const float px = plh_attr(s.pos, 0, mx, my), py = plh_attr(s.pos, 1, mx, my);
+
+    const float pa = s.dir ? py : px, po = s.dir ? px : py;
+    const int na = s.dir ? s.src.h : s.src.w, no = s.dir ? s.src.w : s.src.h;
+    const float ta = pa * (float) na - 0.5f;
+    const float fla = __builtin_floorf(ta);
+    const float fcoord = ta - fla;
+    const int N = s.row_size;
+    const int first = (int) fla - (N / 2 - 1);
+
+    // across the filtered axis
+    int o0, o1 = 0;
+    float ofrac = 0.0f;
+    if (!s.linear) {
+        o0 = plh_wrap((int) __builtin_floorf(po * (float) no), no, s.address_mode);
+    } else {
+        const float to = po * (float) no - 0.5f, flo = __builtin_floorf(to);
+        ofrac = to - flo;
+        o0 = plh_wrap((int) flo, no, s.address_mode);
+        o1 = plh_wrap((int) flo + 1, no, s.address_mode);
+    }
+
+    // LUT rows bracketing fcoord (linear LUT, lut.c:700-715 semantics)
+    const float fpos = plh_clamp(fcoord, 0.0f, 1.0f) * 255.0f;
+    const float fbase = __builtin_floorf(fpos);
+    const float fr = fpos - fbase;
+    const float *r0 = s.weights + (size_t) (int) fbase * s.row_stride;
+    const float *r1 = s.weights + (size_t) min((int) fbase + 1, 255) * s.row_stride;
+
+    float ca[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+    float lo[4] = {1e9f, 1e9f, 1e9f, 1e9f}, hi[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+    const int step = s.use_linear ? 2 : 1;
+    for (int n = 0; n < N; n += step) {
+        const float w = plh_mix(r0[n], r1[n], fr);
+        float4_t c;
+        if (s.use_linear) {
+            // off = n + ws[n % 4 + 1]: one bilinear fetch between taps n and n + 1
+            const float f = plh_mix(r0[n + 1], r1[n + 1], fr);
+            c = mix4(ortho_fetch(s, first + n, o0, o1, ofrac),
+                     ortho_fetch(s, first + n + 1, o0, o1, ofrac), f);
+        } else {
+            c = ortho_fetch(s, first + n, o0, o1, ofrac);
+        }
+        const float cv[4] = { c.x, c.y, c.z, c.w };
+        if (s.use_ar && (n == N / 2 - 1 || n == N / 2)) {
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                lo[k] = fminf(lo[k], cv[k]);
+                hi[k] = fmaxf(hi[k], cv[k]);
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < 4; k++)
+            ca[k] = __builtin_fmaf(w, cv[k], ca[k]);
+    }
+    if (s.use_ar) {
+#pragma unroll
+        for (int k = 0; k < 4; k++)
+            ca[k] = plh_mix(ca[k], plh_clamp(ca[k], lo[k], hi[k]), s.antiring);
+    }
+
+    // vec4 color = vec4(0, 0, 0, 1); color.<comps> = scale * ca
+    float4_t out = { 0.0f, 0.0f, 0.0f, 1.0f };
+    if (s.comp_mask & 1u) out.x = s.scale * ca[0];
+    if (s.comp_mask & 2u) out.y = s.scale * ca[1];
+    if (s.comp_mask & 4u) out.z = s.scale * ca[2];
+    if (s.comp_mask & 8u) out.w = s.scale * ca[3];
+
+    float4_t outs[1] = { out };
+    const frag_t fcs[1] = { { (float) (idx + p.frag_x0) + 0.5f, (float) (idy + p.frag_y0) + 0.5f,
+                              0.0f, 0 } };
+    apply_ops_n<1, false, LITE>(outs, p.ops, 0, p.num_ops, fcs);
+
+    // guarded store (dispatch.c:1126-1142)
+    const int sx[1] = { p.base_x + p.dir_x * (p.transpose ? idy : idx) };
+    const int sy[1] = { p.base_y + p.dir_y * (p.transpose ? idx : idy) };
+    const bool ok[1] = { p.out_scale[0] * (float) idx < 1.0f && p.out_scale[1] * (float) idy < 1.0f &&
+                         sx[0] >= 0 && sy[0] >= 0 && sx[0] < p.dst.w && sy[0] < p.dst.h };
+    plh_store_n<1>(p.dst, sx, sy, ok, outs);
+}
+
+int plh_launch_ortho(hipStream_t stream, const plh_pass *pass)
+{
+    const dim3 block(ORTHO_BW, ORTHO_BH);
+    const dim3 grid((pass->width + ORTHO_BW - 1) / ORTHO_BW,
+                    (pass->height + ORTHO_BH - 1) / ORTHO_BH);
+    if (plh_ops_lite(pass, 0, pass->num_ops))
+        hipLaunchKernelGGL(k_ortho<true>, grid, block, 0, stream, *pass);
+    else
+        hipLaunchKernelGGL(k_ortho<false>, grid, block, 0, stream, *pass);
+    const hipError_t err = hipGetLastError();
+    return err == hipSuccess ? 0 : -(int) err;
+}

@@ -75,9 +75,6 @@ void k_pass_generic(const plh_pass p_)
     const int cy = blockIdx.y * PASS_BH + threadIdx.y;
 
     float4_t c[4];
-    frag_t fcs[4];
-    int sx[4], sy[4];
-    bool ok[4];
     float px[4], py[4];
 #pragma unroll
     for (int q = 0; q < 4; q++) {
@@ -88,12 +85,6 @@ void k_pass_generic(const plh_pass p_)
         const float my = p.out_scale[1] * ((float) idy + 0.5f);
         px[q] = plh_attr(s.pos, 0, mx, my);
         py[q] = plh_attr(s.pos, 1, mx, my);
-        fcs[q] = { (float) (idx + p.frag_x0) + 0.5f, (float) (idy + p.frag_y0) + 0.5f, 0.0f, 0 };
-        sx[q] = p.base_x + p.dir_x * (p.transpose ? idy : idx);
-        sy[q] = p.base_y + p.dir_y * (p.transpose ? idx : idy);
-        ok[q] = idx >= 0 && idy >= 0 && p.out_scale[0] * (float) idx < 1.0f &&
-                p.out_scale[1] * (float) idy < 1.0f && sx[q] >= 0 && sy[q] >= 0 &&
-                sx[q] < p.dst.w && sy[q] < p.dst.h;
         c[q] = {0.0f, 0.0f, 0.0f, 1.0f};
     }
 
@@ -146,6 +137,21 @@ void k_pass_generic(const plh_pass p_)
         break;
     }
 
+    // (store coordinates and gl_FragCoord are computed only now: short live ranges keep the
+    // kernel at <= 96 VGPRs while the texel loads are in flight)
+    frag_t fcs[4];
+    int sx[4], sy[4];
+    bool ok[4];
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+        const int idx = 2 * cx - p.cell_padx + (q & 1), idy = 2 * cy - p.cell_pady + (q >> 1);
+        fcs[q] = { (float) (idx + p.frag_x0) + 0.5f, (float) (idy + p.frag_y0) + 0.5f, 0.0f, 0 };
+        sx[q] = p.base_x + p.dir_x * (p.transpose ? idy : idx);
+        sy[q] = p.base_y + p.dir_y * (p.transpose ? idx : idy);
+        ok[q] = idx >= 0 && idy >= 0 && p.out_scale[0] * (float) idx < 1.0f &&
+                p.out_scale[1] * (float) idy < 1.0f && sx[q] >= 0 && sy[q] >= 0 &&
+                sx[q] < p.dst.w && sy[q] < p.dst.h;
+    }
     apply_ops_n<4, false, LITE>(c, p.ops, 0, p.num_ops, fcs);
     plh_store_n<4>(p.dst, sx, sy, ok, c);
 }

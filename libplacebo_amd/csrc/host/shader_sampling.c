@@ -822,17 +822,162 @@ void plh_polar_pp_setup(pl_gpu gpu, pl_log log, void *polar_obj, struct plh_pass
     s->tile_rows = obj->pp_rows;
 }
 
+/* ---- separable (orthogonal) filters: pl_shader_sample_ortho2, sampling.c:950-1104 -------- */
+
 bool pl_shader_sample_ortho2(pl_shader sh, const struct pl_sample_src *src,
                              const struct pl_sample_filter_params *params)
 {
-    (void) src; (void) params;
-    SH_FAIL(sh, "pl_shader_sample_ortho2: not implemented yet");
-    return false;
+    if (params->filter.polar) {
+        SH_FAIL(sh, "Trying to use separated sampling with a polar filter?");
+        return false;
+    }
+
+    struct src_info info;
+    if (!setup_src(sh, src, &info, false, REQ_LINEAR))
+        return false;
+
+    int pass;
+    if (fabs(info.ratio_x - 1.0f) < 1e-6f) {
+        pass = 0; // SEP_VERT
+    } else if (fabs(info.ratio_y - 1.0f) < 1e-6f) {
+        pass = 1; // SEP_HORIZ
+    } else {
+        SH_FAIL(sh, "Trying to use pl_shader_sample_ortho with a pl_sample_src that requires "
+                "scaling in multiple directions (rx=%f, ry=%f), this is not possible!",
+                info.ratio_x, info.ratio_y);
+        return false;
+    }
+    const float ratio = pass ? info.ratio_x : info.ratio_y;
+
+    pl_gpu gpu = SH_GPU(sh);
+    struct sh_sampler_obj *obj = SH_OBJ(sh, params->lut, PL_SHADER_OBJ_SAMPLER,
+                                        struct sh_sampler_obj, sh_sampler_uninit);
+    if (!obj)
+        return false;
+    if (pass != 0) {
+        // one sampler object per dimension (anamorphic content, sampling.c:985-995)
+        obj = SH_OBJ(sh, &obj->pass2, PL_SHADER_OBJ_SAMPLER, struct sh_sampler_obj,
+                     sh_sampler_uninit);
+        if (!obj)
+            return false;
+    }
+
+    float inv_scale = 1.0 / ratio;
+    inv_scale = PL_MAX(inv_scale, 1.0);
+    if (params->no_widening)
+        inv_scale = 1.0;
+
+    struct pl_filter_config cfg = params->filter;
+    cfg.antiring = PL_DEF(cfg.antiring, params->antiring);
+    cfg.blur = PL_DEF(cfg.blur, 1.0f) * inv_scale;
+    const bool update = !obj->filter || !pl_filter_config_eq(&obj->filter->params.config, &cfg);
+    if (update) {
+        pl_filter_free(&obj->filter);
+        obj->filter = pl_filter_generate(sh->log, pl_filter_params(
+            .config             = cfg,
+            .lut_entries        = SCALER_LUT_SIZE,
+            .max_row_size       = gpu->limits.max_tex_2d_dim / 4,
+            .row_stride_align   = 4,
+        ));
+        if (!obj->filter) {
+            SH_FAIL(sh, "Failed initializing separated filter!");
+            return false;
+        }
+    }
+
+    pl_filter filt = obj->filter;
+    const int N = filt->row_size, stride = filt->row_stride;
+    const bool use_linear = filt->radius == filt->radius_zero;
+    bool use_ar = cfg.antiring > 0 && ratio > 1.0;
+    use_ar &= !use_linear; // filter has no negative weights
+
+    if (update || !obj->lut) {
+        // fill_ortho_lut (sampling.c:914-942)
+        const size_t entries = (size_t) SCALER_LUT_SIZE * stride;
+        float *rows = malloc(entries * sizeof(float));
+        if (!rows)
+            return false;
+        if (use_linear) {
+            for (int n = 0; n < SCALER_LUT_SIZE; n++) {
+                const float *weights = filt->weights + (size_t) n * stride;
+                float *row = rows + (size_t) n * stride;
+                int i = 0;
+                for (; i < N; i += 2) {
+                    const float w0 = weights[i], w1 = weights[i + 1];
+                    row[i] = w0 + w1;
+                    row[i + 1] = w1 / (w0 + w1);
+                }
+                for (; i < stride; i++)
+                    row[i] = i >= 4 ? row[i - 4] : 0;
+            }
+        } else {
+            memcpy(rows, filt->weights, entries * sizeof(float));
+        }
+        pl_buf_destroy(gpu, &obj->lut);
+        obj->lut = pl_buf_create(gpu, pl_buf_params(
+            .size = entries * sizeof(float), .storable = true, .initial_data = rows));
+        free(rows);
+        if (!obj->lut) {
+            SH_FAIL(sh, "Failed initializing separated LUT!");
+            return false;
+        }
+    }
+
+    describe_filter(sh, &cfg, pass ? "ortho (horiz)" : "ortho (vert)", ratio, ratio);
+
+    // A texture unit returns the texel itself at texel centres (its fixed-point weights snap
+    // to zero). Along the filtered axis every tap is fetched at a centre by construction;
+    // across it the fetch is at a centre when the pass is 1:1 on the texel grid there.
+    const float r0 = pass ? src->rect.y0 : src->rect.x0;
+    const bool aligned = r0 == truncf(r0);
+
+    struct plh_sampler_args *s = &sh->pass.s;
+    s->type = PLH_SAMPLE_ORTHO;
+    s->weights = pl_hip_buf_ptr(obj->lut);
+    s->row_size = N;
+    s->row_stride = stride;
+    s->dir = pass ? 0 : 1;      // 0 = horizontal, 1 = vertical
+    s->use_linear = use_linear;
+    s->use_ar = use_ar;
+    s->antiring = cfg.antiring;
+    s->linear = !aligned;       // bilinear across the filtered axis
+    sh_hold(sh, *params->lut);
+
+    sh_listf(sh, "sample_ortho(filter=%s, dir=%s, taps=%d, stride=%d, linear_trick=%d, "
+             "antiring=%g, scale=%g, mask=0x%x, across=%s)\n", PL_DEF(cfg.name, "custom"),
+             pass ? "horiz" : "vert", N, stride, use_linear, use_ar ? cfg.antiring : 0.0f,
+             info.scale, info.comp_mask, aligned ? "nearest" : "linear");
+    return true;
 }
+
+/* ---- debanding: pl_shader_deband, sampling.c:183-275 ---------------------------------------- */
 
 void pl_shader_deband(pl_shader sh, const struct pl_sample_src *src,
                       const struct pl_deband_params *params)
 {
-    (void) src; (void) params;
-    SH_FAIL(sh, "pl_shader_deband: not implemented yet");
+    struct src_info info;
+    if (!setup_src(sh, src, &info, false, REQ_NEAREST))
+        return;
+
+    params = PL_DEF(params, &pl_deband_default_params);
+    sh_describef(sh, "debanding");
+
+    struct plh_sampler_args *s = &sh->pass.s;
+    s->type = PLH_SAMPLE_DEBAND;
+    s->linear = false;
+    s->comp_mask = info.comp_mask & ~0x8u; // ignore alpha channel
+    s->iterations = s->comp_mask ? PL_MAX(params->iterations, 0) : 0;
+    s->db_radius = params->radius;
+    s->db_threshold = params->threshold / (1000 * info.scale);
+    s->db_grain = s->comp_mask && params->grain > 0 ? params->grain / (1000.0 * info.scale) : 0.0f;
+    for (int c = 0, k = 0; c < 3; c++) {
+        // grain_neutral is indexed by *enabled* component (sampling.c:258-261)
+        if (s->comp_mask & (1u << c))
+            s->db_neutral[c] = params->grain_neutral[k++] / info.scale;
+    }
+    s->prng_seed = sh->params.index;
+
+    sh_listf(sh, "deband(iterations=%d, threshold=%g, radius=%g, grain=%g, scale=%g, "
+             "mask=0x%x, seed=%u)\n", s->iterations, params->threshold, params->radius,
+             params->grain, info.scale, s->comp_mask, s->prng_seed);
 }

@@ -1207,3 +1207,169 @@ ORC_API void orc_color_map(float *img, size_t npix, const struct orc_color_map *
             c[r] = m->lms2rgb[3*r] * l3[0] + m->lms2rgb[3*r+1] * l3[1] + m->lms2rgb[3*r+2] * l3[2];
     }
 }
+
+/* ======================================================================== */
+/* K4: separable filters (src/shaders/sampling.c:950-1104, fill_ortho_lut :914-942) */
+
+// `rows`: 256 x row_stride LUT rows as uploaded (i.e. after fill_ortho_lut: raw weights,
+// or {w0+w1, w1/(w0+w1)} pairs when use_linear). dir: 0 = horizontal, 1 = vertical.
+// Texture-unit rule: taps sit on texel centres along `dir` -> the texel itself;
+// across `dir`: nearest when the rect starts on the texel grid there, exact bilinear otherwise.
+ORC_API void orc_sample_ortho(const struct orc_src *s, const float *rows, int row_size,
+                              int row_stride, int dir, int use_linear, int use_ar,
+                              float antiring, float scale, unsigned mask,
+                              int out_w, int out_h, float *out)
+{
+    float p[4][2], pt[2];
+    corners(s, p, pt);
+    const float osx = 1.0 / out_w, osy = 1.0 / out_h;
+    const int N = row_size;
+    const float r0v = dir ? s->rect[0] : s->rect[1];
+    const int across_linear = r0v != truncf(r0v);
+    const int na = dir ? s->h : s->w, no = dir ? s->w : s->h;
+
+    for (int y = 0; y < out_h; y++) {
+        for (int x = 0; x < out_w; x++) {
+            const float fx = osx * ((float) x + 0.5f), fy = osy * ((float) y + 0.5f);
+            const float px = attr(p, 0, fx, fy), py = attr(p, 1, fx, fy);
+            const float pa = dir ? py : px, po = dir ? px : py;
+            const float ta = pa * (float) na - 0.5f, fla = floorf(ta);
+            const float fcoord = ta - fla;                                    // :1060-1061
+            const int first = (int) fla - (N / 2 - 1);                        // :1062
+
+            int o0, o1 = 0;
+            float ofrac = 0.0f;
+            if (!across_linear) {
+                o0 = (int) floorf(po * (float) no);
+            } else {
+                const float to = po * (float) no - 0.5f, flo = floorf(to);
+                ofrac = to - flo;
+                o0 = (int) flo;
+                o1 = o0 + 1;
+            }
+
+            const float fpos = clampf(fcoord, 0.0f, 1.0f) * 255.0f;
+            const float fbase = floorf(fpos), fr = fpos - fbase;
+            const float *ra = rows + (size_t) (int) fbase * row_stride;
+            const float *rb = rows + (size_t) ((int) fbase + 1 > 255 ? 255 : (int) fbase + 1) * row_stride;
+
+            float ca[4] = {0, 0, 0, 0}, lo[4] = {1e9f, 1e9f, 1e9f, 1e9f}, hi[4] = {0, 0, 0, 0};
+            for (int n = 0; n < N; n += use_linear ? 2 : 1) {
+                const float w = mixf(ra[n], rb[n], fr);
+                float c[4];
+                for (int half = 0; half < (use_linear ? 2 : 1); half++) {
+                    const int i = first + n + half;
+                    float t[4];
+                    const float *a = dir ? texel(s, o0, i) : texel(s, i, o0);
+                    if (across_linear) {
+                        const float *b = dir ? texel(s, o1, i) : texel(s, i, o1);
+                        for (int k = 0; k < 4; k++)
+                            t[k] = mixf(a[k], b[k], ofrac);
+                    } else {
+                        memcpy(t, a, 16);
+                    }
+                    if (!half) {
+                        memcpy(c, t, 16);
+                    } else {
+                        const float f = mixf(ra[n + 1], rb[n + 1], fr);      // :1072-1073
+                        for (int k = 0; k < 4; k++)
+                            c[k] = mixf(c[k], t[k], f);
+                    }
+                }
+                if (use_ar && (n == N / 2 - 1 || n == N / 2)) {               // :1076-1079
+                    for (int k = 0; k < 4; k++) {
+                        lo[k] = fminf(lo[k], c[k]);
+                        hi[k] = fmaxf(hi[k], c[k]);
+                    }
+                }
+                for (int k = 0; k < 4; k++)
+                    ca[k] = fmaf(w, c[k], ca[k]);                             // :1082
+            }
+            float *o = out + ((size_t) y * out_w + x) * 4;
+            const float def[4] = {0, 0, 0, 1};
+            for (int k = 0; k < 4; k++) {
+                if (use_ar)
+                    ca[k] = mixf(ca[k], clampf(ca[k], lo[k], hi[k]), antiring); // :1085
+                o[k] = (mask & (1u << k)) ? scale * ca[k] : def[k];            // :1086
+            }
+        }
+    }
+}
+
+/* ======================================================================== */
+/* K6: debanding (src/shaders/sampling.c:183-275), PRNG src/shaders.c:965-998  */
+
+static void o_pcg3d(uint32_t s[3], float out[3])
+{
+    for (int k = 0; k < 3; k++)
+        s[k] = 1664525u * s[k] + 1013904223u;
+    s[0] += s[1] * s[2]; s[1] += s[2] * s[0]; s[2] += s[0] * s[1];
+    for (int k = 0; k < 3; k++)
+        s[k] ^= s[k] >> 16;
+    s[0] += s[1] * s[2]; s[1] += s[2] * s[0]; s[2] += s[0] * s[1];
+    const float k32 = 1.0f / (float) 0xFFFFFFFFu;    // float(0xFFFFFFFF) == 2^32
+    for (int k = 0; k < 3; k++)
+        out[k] = (float) s[k] * k32;
+}
+
+ORC_API void orc_deband(const struct orc_src *s, int iterations, float threshold, float radius,
+                        float grain, const float grain_neutral[3], float scale, unsigned mask,
+                        unsigned frame_index, int out_w, int out_h, float *out)
+{
+    float p[4][2], pt[2];
+    corners(s, p, pt);
+    const float osx = 1.0 / out_w, osy = 1.0 / out_h;
+    mask &= 7u;                                                               // :201
+    const float thr = threshold / (1000 * scale);                             // :225
+    const float two_pi = pf(M_PI * 2);                                        // "%f"
+    for (int y = 0; y < out_h; y++) {
+        for (int x = 0; x < out_w; x++) {
+            const float fx = osx * ((float) x + 0.5f), fy = osy * ((float) y + 0.5f);
+            const float px = attr(p, 0, fx, fy), py = attr(p, 1, fx, fy);
+            float color[4], res[3];
+            tex_nearest(s, px, py, color);
+            memcpy(res, color, 12);
+            uint32_t st[3] = { (uint32_t) ((float) x + 0.5f), (uint32_t) ((float) y + 0.5f),
+                               frame_index };
+            float rnd[3];
+            for (int i = 1; mask && i <= iterations; i++) {
+                o_pcg3d(st, rnd);
+                float dx = rnd[0] * ((float) i * radius);                     // :232
+                const float ang = rnd[1] * two_pi;
+                const float dy = dx * sinf(ang);
+                dx = dx * cosf(ang);                                          // :233
+                const float ox[4] = { dx, -dx, -dx, dx }, oy[4] = { dy, dy, -dy, -dy };
+                float avg[3] = {0, 0, 0};
+                for (int k = 0; k < 4; k++) {                                 // :236-239
+                    float t[4];
+                    tex_nearest(s, px + pt[0] * ox[k], py + pt[1] * oy[k], t);
+                    for (int c = 0; c < 3; c++)
+                        avg[c] += t[c];
+                }
+                const float bound = thr / (float) i;                          // :244
+                for (int c = 0; c < 3; c++) {
+                    const float a = avg[c] * 0.25f;
+                    if ((mask & (1u << c)) && !(fabsf(res[c] - a) > bound))   // :247-250
+                        res[c] = a;
+                }
+            }
+            if (mask && grain > 0) {                                          // :255-268
+                o_pcg3d(st, rnd);
+                const float g = grain / (1000.0 * scale);
+                int k = 0;
+                for (int c = 0; c < 3; c++) {
+                    if (!(mask & (1u << c)))
+                        continue;
+                    const float neutral = grain_neutral[k] / scale;
+                    const float strength = fminf(fabsf(res[c] - neutral), g);
+                    res[c] += strength * (rnd[k] - 0.5f);
+                    k++;
+                }
+            }
+            float *o = out + ((size_t) y * out_w + x) * 4;
+            for (int c = 0; c < 3; c++)
+                o[c] = ((mask & (1u << c)) ? res[c] : color[c]) * scale;      // :270-271
+            o[3] = color[3] * scale;
+        }
+    }
+}

@@ -252,3 +252,55 @@ def color_map(img, rgb2lms, lms2rgb, tone_mode=-1, tone_p=(0, 0, 0, 0), tone_lut
         cm.gamut_size = (C.c_int * 3)(*gamut_size)
     lib().orc_color_map(_p(img), C.c_size_t(img.size // 4), C.byref(cm))
     return img
+
+
+# ---- separable filters / debanding ---------------------------------------------------------
+def triangle(blur=0.0):
+    return OrcFilter(kernel=K["triangle"], window=K["none"], kradius=1.0, wradius=1.0,
+                     resizable=1, radius=1.0, blur=blur)
+
+
+def mitchell(blur=0.0):
+    f = OrcFilter(kernel=K["cubic"], window=K["none"], kradius=2.0, wradius=1.0,
+                  resizable=0, radius=2.0, blur=blur)
+    f.kparams[0], f.kparams[1] = 1 / 3.0, 1 / 3.0
+    return f
+
+
+def ortho_lut_rows(rows, row_size, use_linear):
+    """fill_ortho_lut (sampling.c:914-942): the LUT as uploaded."""
+    if not use_linear:
+        return rows
+    out = rows.copy()
+    n, stride = rows.shape
+    one = np.float32
+    i = 0
+    while i < row_size:
+        w0, w1 = rows[:, i].astype(one), rows[:, i + 1].astype(one)
+        out[:, i] = w0 + w1
+        out[:, i + 1] = w1 / (w0 + w1)
+        i += 2
+    for j in range(i, stride):
+        out[:, j] = out[:, j - 4] if j >= 4 else 0
+    return out
+
+
+def sample_ortho(img, rows, row_size, direction, out_w, out_h, rect=None, scale=1.0,
+                 use_linear=False, use_ar=False, antiring=0.0, mask=0xF, address_mode=0):
+    s, keep = _src(img, rect, address_mode)
+    rows = np.ascontiguousarray(rows, np.float32)
+    out = np.empty((out_h, out_w, 4), np.float32)
+    lib().orc_sample_ortho(C.byref(s), _p(rows), row_size, rows.shape[1], direction,
+                           int(use_linear), int(use_ar), C.c_float(antiring), C.c_float(scale),
+                           C.c_uint(mask), out_w, out_h, _p(out))
+    return out
+
+
+def deband(img, out_w, out_h, iterations=1, threshold=3.0, radius=16.0, grain=4.0,
+           grain_neutral=(0, 0, 0), scale=1.0, mask=0x7, frame_index=0, rect=None, address_mode=0):
+    s, keep = _src(img, rect, address_mode)
+    out = np.empty((out_h, out_w, 4), np.float32)
+    lib().orc_deband(C.byref(s), iterations, C.c_float(threshold), C.c_float(radius),
+                     C.c_float(grain), (C.c_float * 3)(*grain_neutral), C.c_float(scale),
+                     C.c_uint(mask), C.c_uint(frame_index), out_w, out_h, _p(out))
+    return out

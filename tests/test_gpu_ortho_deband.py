@@ -1,0 +1,194 @@
+"""Separable (ortho) scalers and debanding on the GPU against the CPU oracle.
+
+ortho: no transcendental on the device path -> bit-exact.
+deband: integer PRNG bit-exact; the sample offsets go through sin/cos (ocml on the GPU,
+libm in the oracle), so a sample that lands within an ulp of a texel boundary may pick the
+neighbouring texel: the test demands >= 99.9 % identical pixels and bounds the rest by the
+debanding threshold.
+"""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import libplacebo_amd as pl
+import orc
+import util
+
+pytestmark = pytest.mark.gpu
+
+FILTERS = {
+    # name: (product config name, oracle filter, uses linear trick)
+    "lanczos": ("lanczos", orc.lanczos, False),
+    "mitchell": ("mitchell", orc.mitchell, False),
+    "bilinear": ("bilinear", orc.triangle, True),
+}
+
+
+def run_ortho(g, img16, name, direction, new, rect=None, antiring=0.0, comps=4, fmt="rgba16hf"):
+    h, w = img16.shape[:2]
+    t = g.tex_create(w, h, "rgba16", img16)
+    ow, oh = (new, h) if direction == 0 else (w, new)
+    d = g.tex_create(ow, oh, fmt)
+    lut = pl.ShaderObj()
+    sh = g.begin()
+    kw = dict(new_w=ow, new_h=oh, components=comps)
+    if rect is not None:
+        kw["rect"] = rect
+    assert sh.sample_ortho(t, pl.filter_config(FILTERS[name][0]), lut, antiring=antiring, **kw), \
+        g.messages[-3:]
+    assert sh.finish(d), g.messages[-3:]
+    out = d.download()
+    t.destroy(); d.destroy(); lut.destroy()
+    return out
+
+
+def oracle_ortho(img16, name, direction, new, rect=None, antiring=0.0, comps=4, fmt="rgba16hf"):
+    h, w = img16.shape[:2]
+    tex = orc.tex_decode(img16, "rgba16")
+    ow, oh = (new, h) if direction == 0 else (w, new)
+    rect = rect if rect is not None else (0, 0, w, h)
+    src_len = abs(rect[2] - rect[0]) if direction == 0 else abs(rect[3] - rect[1])
+    ratio = float(np.float32(new / src_len))            # setup_src: float ratio = out / |src|
+    inv_scale = float(np.float32(1.0 / ratio))          # sampling.c:1001
+    f = FILTERS[name][1](blur=inv_scale if inv_scale > 1.0 else 0.0)
+    rows, n, radius, rz = orc.filter_generate_ortho(f)
+    use_linear = radius == rz
+    assert use_linear == FILTERS[name][2]
+    rows = orc.ortho_lut_rows(rows, n, use_linear)
+    use_ar = antiring > 0 and ratio > 1 and not use_linear
+    out = orc.sample_ortho(tex, rows, n, direction, ow, oh, rect=rect, use_linear=use_linear,
+                           use_ar=use_ar, antiring=antiring, mask=(1 << comps) - 1)
+    return orc.tex_decode(orc.tex_encode(out, fmt), fmt)
+
+
+@pytest.mark.parametrize("name", list(FILTERS))
+@pytest.mark.parametrize("direction,new", [(0, 160), (1, 120), (0, 37), (1, 29)])
+def test_ortho_bit_exact(gpu, name, direction, new):
+    img = util.random_rgba16(80, 60, seed=direction * 7 + new)
+    got = run_ortho(gpu, img, name, direction, new)
+    ref = oracle_ortho(img, name, direction, new)
+    assert np.array_equal(got, ref), util.diff_stats(got, ref)
+
+
+@pytest.mark.parametrize("direction", [0, 1])
+def test_ortho_antiring_and_rect(gpu, direction):
+    img = util.chirp_rgba16(96, 64)
+    rect = (8.0, 4.0, 72.5, 52.0) if direction == 0 else (8.0, 4.0, 72.0, 51.25)
+    new = 150 if direction == 0 else 111
+    # crop the other axis 1:1 so that only `direction` scales
+    if direction == 0:
+        rect = (rect[0], 4.0, rect[2], 52.0)
+        shape_other = 48
+    else:
+        rect = (8.0, rect[1], 72.0, rect[3])
+        shape_other = 64
+    h, w = img.shape[:2]
+    t = gpu.tex_create(w, h, "rgba16", img)
+    ow, oh = (new, shape_other) if direction == 0 else (shape_other, new)
+    d = gpu.tex_create(ow, oh, "rgba32f")
+    lut = pl.ShaderObj()
+    sh = gpu.begin()
+    assert sh.sample_ortho(t, pl.filter_config("lanczos"), lut, antiring=0.8, rect=rect,
+                           new_w=ow, new_h=oh, components=3), gpu.messages[-3:]
+    assert sh.finish(d), gpu.messages[-3:]
+    got = d.download()
+    rows, n, radius, rz = orc.filter_generate_ortho(orc.lanczos())
+    ref = orc.sample_ortho(orc.tex_decode(img, "rgba16"), rows, n, direction, ow, oh, rect=rect,
+                           use_ar=True, antiring=0.8, mask=0x7)
+    assert np.array_equal(got, ref), util.diff_stats(got, ref)
+    t.destroy(); d.destroy(); lut.destroy()
+
+
+def test_ortho_two_pass_upscale_matches_oracle(gpu):
+    """The renderer's composition (renderer.c:745-772): vertical pass into an rgba16hf FBO,
+    then horizontal pass."""
+    img = util.chirp_rgba16(64, 48)
+    t = gpu.tex_create(64, 48, "rgba16", img)
+    fbo = gpu.tex_create(64, 96, "rgba16hf")
+    dst = gpu.tex_create(128, 96, "rgba16")
+    lut = pl.ShaderObj()
+    cfg = pl.filter_config("lanczos")
+    a = gpu.begin()
+    assert a.sample_ortho(t, cfg, lut, new_w=64, new_h=96)
+    assert a.finish(fbo)
+    b = gpu.begin()
+    assert b.sample_ortho(fbo, cfg, lut, new_w=128, new_h=96)
+    assert b.finish(dst)
+    got = dst.download()
+    rows, n, _, _ = orc.filter_generate_ortho(orc.lanczos())
+    p1 = orc.sample_ortho(orc.tex_decode(img, "rgba16"), rows, n, 1, 64, 96)
+    p1 = orc.op_quant_f16(p1)
+    p2 = orc.sample_ortho(p1, rows, n, 0, 128, 96)
+    ref = orc.tex_encode(p2, "rgba16")
+    assert np.array_equal(got, ref), util.diff_stats(got.astype(np.float32), ref.astype(np.float32))
+    t.destroy(); fbo.destroy(); dst.destroy(); lut.destroy()
+
+
+def test_ortho_rejects_two_axis_scaling(gpu):
+    t = gpu.tex_create(32, 32, "rgba16", util.random_rgba16(32, 32))
+    lut = pl.ShaderObj()
+    sh = gpu.begin()
+    assert not sh.sample_ortho(t, pl.filter_config("lanczos"), lut, new_w=64, new_h=64)
+    sh.abort()
+    t.destroy(); lut.destroy()
+
+
+# ---- debanding ---------------------------------------------------------------------------
+def banded(w, h):
+    """Smooth gradients quantised to 6 bits: the banding the filter is for."""
+    y, x = np.mgrid[0:h, 0:w].astype(np.float32)
+    img = np.zeros((h, w, 4), np.float32)
+    img[..., 0] = np.floor((x / w) * 63) / 63
+    img[..., 1] = np.floor(((x + y) / (w + h)) * 63) / 63
+    img[..., 2] = np.floor((y / h) * 63) / 63
+    img[..., 3] = 1.0
+    return (img * 65535 + 0.5).astype(np.uint16)
+
+
+@pytest.mark.parametrize("kw", [dict(), dict(iterations=3, grain=0.0), dict(iterations=0),
+                                dict(iterations=2, threshold=6.0, radius=8.0, grain=8.0,
+                                     grain_neutral=(0.1, 0.2, 0.0)),
+                                dict(components=1), dict(component_mask=0x5)])
+def test_deband_vs_oracle(gpu, kw):
+    w, h = 128, 96
+    img = banded(w, h)
+    t = gpu.tex_create(w, h, "rgba16", img)
+    d = gpu.tex_create(w, h, "rgba32f")
+    pkw = dict(kw)
+    src_kw = {k: pkw.pop(k) for k in ("components", "component_mask") if k in pkw}
+    for frame in range(2):
+        gpu.reset_frame()       # bumps the PRNG seed (dispatch.c:1618)
+    sh = gpu.begin()
+    assert sh.deband(t, **pkw, **src_kw), gpu.messages[-3:]
+    listing = sh.listing()
+    seed = int(listing.split("seed=")[1].split(")")[0])
+    assert sh.finish(d), gpu.messages[-3:]
+    got = d.download()
+    mask = src_kw.get("component_mask") or (1 << src_kw.get("components", 4)) - 1
+    ref = orc.deband(orc.tex_decode(img, "rgba16"), w, h, mask=mask, frame_index=seed, **pkw)
+    same = np.all(got == ref, axis=2).mean()
+    assert same >= 0.999, same
+    thr = pkw.get("threshold", 3.0) / 1000 + pkw.get("grain", 4.0) / 1000
+    assert np.abs(got - ref).max() <= thr + 1e-6
+    if pkw.get("iterations", 1) > 0 and not src_kw:
+        # and it must actually deband: the 64 quantised levels get in-between values
+        src = orc.tex_decode(img, "rgba16")
+        assert len(np.unique(got[..., 0])) > 2 * len(np.unique(src[..., 0]))
+    t.destroy(); d.destroy()
+
+
+def test_deband_prng_is_temporal(gpu):
+    w, h = 64, 64
+    img = banded(w, h)
+    t = gpu.tex_create(w, h, "rgba16", img)
+    d = gpu.tex_create(w, h, "rgba32f")
+    outs = []
+    for frame in range(2):
+        gpu.reset_frame()
+        sh = gpu.begin()
+        assert sh.deband(t)
+        assert sh.finish(d)
+        outs.append(d.download())
+    assert not np.array_equal(outs[0], outs[1])
+    t.destroy(); d.destroy()
