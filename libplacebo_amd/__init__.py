@@ -206,6 +206,15 @@ class Shader:
         lib().pl_shader_dither(self.sh, depth, C.byref(state_obj.slot) if state_obj else None,
                                C.byref(dp))
 
+    def error_diffusion(self, src_tex, dst_tex, depth, kernel="sierra-lite"):
+        k = lib().pl_find_error_diffusion_kernel(kernel.encode())
+        if not k:
+            raise KeyError(kernel)
+        ep = capi.ErrorDiffusionParams(C.cast(src_tex.ptr, C.c_void_p), C.cast(dst_tex.ptr, C.c_void_p),
+                                       depth, k)
+        self._keep.append(ep)
+        return lib().pl_shader_error_diffusion(self.sh, C.byref(ep))
+
     # ---- colour stages (shaders/colorspace.h) --------------------------------------------
     def decode_color(self, repr_, adjustment=None):
         lib().pl_shader_decode_color(self.sh, C.byref(repr_),

@@ -187,6 +187,16 @@ class DitherParams(C.Structure):
                 ("transfer", C.c_int)]
 
 
+class ErrorDiffusionKernel(C.Structure):
+    _fields_ = [("name", C.c_char_p), ("description", C.c_char_p), ("shift", C.c_int),
+                ("pattern", (C.c_int * 5) * 3), ("divisor", C.c_int)]
+
+
+class ErrorDiffusionParams(C.Structure):
+    _fields_ = [("input_tex", C.c_void_p), ("output_tex", C.c_void_p), ("new_depth", C.c_int),
+                ("kernel", C.POINTER(ErrorDiffusionKernel))]
+
+
 class DispatchComputeParams(C.Structure):
     _fields_ = [("shader", C.POINTER(C.c_void_p)), ("dispatch_size", C.c_int * 3),
                 ("width", C.c_int), ("height", C.c_int), ("timer", C.c_void_p)]
@@ -339,6 +349,9 @@ def declare(lib):
     fn("pl_shader_sample_ortho2", C.c_bool, vp, P(SampleSrc), P(SampleFilterParams))
     fn("pl_shader_deband", None, vp, P(SampleSrc), P(DebandParams))
     fn("pl_shader_dither", None, vp, C.c_int, P(vp), P(DitherParams))
+    fn("pl_shader_error_diffusion", C.c_bool, vp, P(ErrorDiffusionParams))
+    fn("pl_find_error_diffusion_kernel", P(ErrorDiffusionKernel), C.c_char_p)
+    fn("pl_error_diffusion_shmem_req", C.c_size_t, P(ErrorDiffusionKernel), C.c_int)
 
     fn("pl_shader_set_alpha", None, vp, P(ColorRepr), C.c_int)
     fn("pl_shader_decode_color", None, vp, P(ColorRepr), P(ColorAdjustment))

@@ -202,11 +202,23 @@ struct plh_pass {
     void *peak_buf;
 };
 
+/* ---- error diffusion (k_errdiff.hip) ------------------------------------------ */
+struct plh_errdiff_args {
+    struct plh_view src, dst;
+    int32_t width, height;
+    int32_t quant;              // 2^depth - 1
+    int32_t shift, divisor;     // pl_error_diffusion_kernel
+    int32_t pattern[3][5];      // [dy][dx + 2]
+    int32_t ring_rows, ring_cols;
+    int32_t block_size, blocks; // one workgroup, `blocks` sequential steps
+};
+
 /* ---- launch entry points (implemented in *.hip) --------------------------- */
 typedef void *plh_stream;
 
 // returns 0 on success, a negative hipError otherwise
 int plh_launch_pass(plh_stream stream, const struct plh_pass *pass);
+int plh_launch_errdiff(plh_stream stream, const struct plh_errdiff_args *args);
 
 // POLAR phase-class setup helpers (k_polar.hip). `out` = width floats (fcoord.x
 // of every output column on row 0), width ints (base texel), then height floats

@@ -175,7 +175,7 @@ pl_hip pl_hip_create(pl_log log, const struct pl_hip_params *params)
         .version = 450,
         .vulkan = true,
         .compute = true,
-        .max_shmem_size = PL_DEF(params->max_shmem_size, 65536),
+        .max_shmem_size = PL_DEF(params->max_shmem_size, 160 * 1024), // CDNA4 LDS per CU
         .max_group_threads = 1024,
         .max_group_size = { 1024, 1024, 1024 },
         .subgroup_size = 64,

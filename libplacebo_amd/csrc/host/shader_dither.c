@@ -167,7 +167,69 @@ size_t pl_error_diffusion_shmem_req(const struct pl_error_diffusion_kernel *kern
 
 bool pl_shader_error_diffusion(pl_shader sh, const struct pl_error_diffusion_params *params)
 {
-    (void) params;
-    SH_FAIL(sh, "pl_shader_error_diffusion: not implemented yet");
-    return false;
+    if (!params->input_tex || !params->output_tex) {
+        SH_FAIL(sh, "pl_shader_error_diffusion: missing input/output texture");
+        return false;
+    }
+    const int width = params->input_tex->params.w, height = params->input_tex->params.h;
+    const struct pl_glsl_version glsl = sh_glsl(sh);
+    const struct pl_error_diffusion_kernel *kernel =
+        PL_DEF(params->kernel, &pl_error_diffusion_sierra_lite);
+
+    if (params->output_tex->params.w != width || params->output_tex->params.h != height) {
+        SH_FAIL(sh, "pl_shader_error_diffusion: input and output sizes differ");
+        return false;
+    }
+    if (!params->output_tex->params.storable) {
+        SH_FAIL(sh, "pl_shader_error_diffusion: output texture must be storable");
+        return false;
+    }
+    if (!sh_require(sh, PL_SHADER_SIG_NONE, width, height))
+        return false;
+    if (params->new_depth <= 0 || params->new_depth > 256) {
+        pl_msg(sh->log, PL_LOG_WARN, "Invalid dither depth: %d.. ignoring", params->new_depth);
+        return false;
+    }
+
+    // one workgroup walks the sheared columns (dithering.c:352-378)
+    const int shifted_width = width + (height - 1) * kernel->shift;
+    const int block_size = PL_MIN((int) glsl.max_group_threads, height);
+    const int blocks = (height * shifted_width + block_size - 1) / block_size;
+    const int ring_rows = height + PL_EDF_MAX_DY;
+    const int ring_cols = rightmost_shifted_column(kernel) + 1;
+    const size_t shmem_req = (size_t) ring_rows * ring_cols * sizeof(uint32_t);
+    if (!sh_try_compute(sh, block_size, 1, false, shmem_req)) {
+        pl_msg(sh->log, PL_LOG_ERR, "Cannot execute error diffusion kernel: insufficient "
+               "compute shader memory (%zu bytes)!", shmem_req);
+        sh->failed = true;
+        return false;
+    }
+
+    struct plh_errdiff_args *a = calloc(1, sizeof(*a));
+    if (!a) {
+        sh->failed = true;
+        return false;
+    }
+    plh_tex_view(params->input_tex, &a->src);
+    plh_tex_view(params->output_tex, &a->dst);
+    a->width = width;
+    a->height = height;
+    a->quant = (1 << params->new_depth) - 1;
+    a->shift = kernel->shift;
+    a->divisor = kernel->divisor;
+    memcpy(a->pattern, kernel->pattern, sizeof(a->pattern));
+    a->ring_rows = ring_rows;
+    a->ring_cols = ring_cols;
+    a->block_size = block_size;
+    a->blocks = blocks;
+
+    free(sh->errdiff);
+    sh->errdiff = a;
+    sh->kind = PLH_SHADER_ERROR_DIFFUSION;
+    sh->output = PL_SHADER_SIG_NONE;
+    sh_describef(sh, "error diffusion (%s, %d bits)", kernel->name, params->new_depth);
+    sh_listf(sh, "error_diffusion(kernel=%s, depth=%d, %dx%d, block=%d, steps=%d, "
+             "ring=%dx%d (%zu B LDS))\n", kernel->name, params->new_depth, width, height,
+             block_size, blocks, ring_rows, ring_cols, shmem_req);
+    return true;
 }

@@ -1373,3 +1373,72 @@ ORC_API void orc_deband(const struct orc_src *s, int iterations, float threshold
         }
     }
 }
+
+/* ======================================================================== */
+/* K14: error diffusion (src/shaders/dithering.c:326-527)                       */
+
+// Sequential walk of the same sheared-column order with the same packed ring buffer
+// (ids of one workgroup step never touch each other's slots, see k_errdiff.hip, so the
+// serial order reproduces the parallel result exactly). pattern[dy][dx + 2].
+ORC_API void orc_error_diffusion(const float *img, int w, int h, int depth, int shift,
+                                 int divisor, const int pattern[3][5], float *out)
+{
+    int ring_cols = 0;
+    for (int dy = 0; dy <= 2; dy++) {
+        for (int dx = -2; dx <= 2; dx++) {
+            if (pattern[dy][dx + 2] && dx + dy * shift > ring_cols)
+                ring_cols = dx + dy * shift;
+        }
+    }
+    ring_cols += 1;
+    const int ring_rows = h + 2;
+    const uint32_t ring_size = (uint32_t) ring_rows * ring_cols;
+    uint32_t *ring = calloc(ring_size, sizeof(uint32_t));
+    const int shifted_width = w + (h - 1) * shift;
+    const float quant = (float) ((1 << depth) - 1);
+
+    for (int64_t id = 0; id < (int64_t) h * shifted_width; id++) {
+        const int y = (int) (id % h), xs = (int) (id / h);
+        const int x = xs - y * shift;
+        if (x < 0 || x >= w)
+            continue;
+        const uint32_t idx = (uint32_t) (xs * ring_rows + y) % ring_size;
+        const float *po = img + ((size_t) y * w + x) * 4;
+        const uint32_t e32 = ring[idx] + ((128u << 24) | (128u << 12) | 128u);
+        ring[idx] = 0;
+        const int e[3] = { (int) ((e32 >> 24) & 0xFF) - 128, (int) ((e32 >> 12) & 0xFF) - 128,
+                           (int) (e32 & 0xFF) - 128 };
+        float pix[3], dith[3], ediv[3];
+        float *o = out + ((size_t) y * w + x) * 4;
+        for (int c = 0; c < 3; c++) {
+            pix[c] = po[c] * quant + (float) e[c] / 254.0f;                  // :462-465
+            dith[c] = rintf(pix[c]);                                         // round(): half-even
+            o[c] = dith[c] / quant;
+            ediv[c] = (pix[c] - dith[c]) * 254.0f / (float) divisor;         // :470
+        }
+        o[3] = po[3];
+        for (int dividend = 1; dividend <= divisor; dividend++) {
+            int assigned = 0;
+            uint32_t packed = 0;
+            for (int dy = 0; dy <= 2; dy++) {
+                for (int dx = -2; dx <= 2; dx++) {
+                    if (pattern[dy][dx + 2] != dividend)
+                        continue;
+                    if (!assigned) {
+                        assigned = 1;
+                        const int t[3] = { (int) rintf(ediv[0] * (float) dividend),
+                                           (int) rintf(ediv[1] * (float) dividend),
+                                           (int) rintf(ediv[2] * (float) dividend) };
+                        packed = ((uint32_t) (t[0] & 0xFF) << 24) | ((uint32_t) (t[1] & 0xFF) << 12) |
+                                 (uint32_t) (t[2] & 0xFF);
+                    }
+                    if (dx < 0 && x < -dx)                                   // :508-509
+                        continue;
+                    const uint32_t delta = (uint32_t) ((dx + dy * shift) * ring_rows + dy);
+                    ring[(idx + delta) % ring_size] += packed;
+                }
+            }
+        }
+    }
+    free(ring);
+}

@@ -304,3 +304,12 @@ def deband(img, out_w, out_h, iterations=1, threshold=3.0, radius=16.0, grain=4.
                      C.c_float(grain), (C.c_float * 3)(*grain_neutral), C.c_float(scale),
                      C.c_uint(mask), C.c_uint(frame_index), out_w, out_h, _p(out))
     return out
+
+
+def error_diffusion(img, depth, shift, divisor, pattern):
+    img = np.ascontiguousarray(img, np.float32)
+    h, w = img.shape[:2]
+    out = np.zeros_like(img)
+    pat = ((C.c_int * 5) * 3)(*[(C.c_int * 5)(*row) for row in pattern])
+    lib().orc_error_diffusion(_p(img), w, h, depth, shift, divisor, pat, _p(out))
+    return out
