@@ -1,0 +1,196 @@
+/*
+ * libplacebo-hip: high-level renderer, the pl_render_image hot path.
+ * API-compatible subset of the reference's src/include/libplacebo/renderer.h
+ * (pl_renderer :38-80, pl_render_params :130-380, pl_plane :404-472,
+ * pl_frame :528-655, pl_render_image :731).
+ *
+ * Field names, meanings and defaults are the reference's. Not provided (out of the
+ * hot-path scope): hooks, custom LUTs, ICC, overlays, film grain,
+ * deinterlacing, frame mixing, distortion / cone distortion, blurred borders, rotation;
+ * multi-plane (planar / subsampled) frames are the next component.
+ */
+#ifndef LIBPLACEBO_RENDERER_H_
+#define LIBPLACEBO_RENDERER_H_
+
+#include <libplacebo/colorspace.h>
+#include <libplacebo/dispatch.h>
+#include <libplacebo/filters.h>
+#include <libplacebo/gpu.h>
+#include <libplacebo/shaders/colorspace.h>
+#include <libplacebo/shaders/dithering.h>
+#include <libplacebo/shaders/sampling.h>
+
+PL_API_BEGIN
+
+// Thread-safety: Unsafe (one renderer per stream / GPU, like the reference)
+typedef struct pl_renderer_t *pl_renderer;
+
+enum pl_render_error {
+    PL_RENDER_ERR_NONE              = 0,
+    PL_RENDER_ERR_FBO               = 1 << 0,
+    PL_RENDER_ERR_SAMPLING          = 1 << 1,
+    PL_RENDER_ERR_DEBANDING         = 1 << 2,
+    PL_RENDER_ERR_BLENDING          = 1 << 3,
+    PL_RENDER_ERR_OVERLAY           = 1 << 4,
+    PL_RENDER_ERR_PEAK_DETECT       = 1 << 5,
+    PL_RENDER_ERR_FILM_GRAIN        = 1 << 6,
+    PL_RENDER_ERR_FRAME_MIXING      = 1 << 7,
+    PL_RENDER_ERR_DEINTERLACING     = 1 << 8,
+    PL_RENDER_ERR_ERROR_DIFFUSION   = 1 << 9,
+    PL_RENDER_ERR_HOOKS             = 1 << 10,
+    PL_RENDER_ERR_CONTRAST_RECOVERY = 1 << 11,
+    PL_RENDER_ERR_BLUR              = 1 << 12,
+};
+
+struct pl_render_errors {
+    enum pl_render_error errors;
+    const struct pl_hook * const *disabled_hooks; // always NULL here
+    int num_disabled_hooks;
+};
+
+PL_API pl_renderer pl_renderer_create(pl_log log, pl_gpu gpu);
+PL_API void pl_renderer_destroy(pl_renderer *rr);
+PL_API struct pl_render_errors pl_renderer_get_errors(pl_renderer rr);
+PL_API void pl_renderer_reset_errors(pl_renderer rr, const struct pl_render_errors *errors);
+
+enum pl_clear_mode {
+    PL_CLEAR_COLOR = 0, // set to the background colour
+    PL_CLEAR_TILES,     // (treated as PL_CLEAR_COLOR by this backend)
+    PL_CLEAR_SKIP,      // leave untouched
+    PL_CLEAR_BLUR,      // (unsupported: treated as PL_CLEAR_COLOR)
+    PL_CLEAR_MODE_COUNT,
+};
+
+enum pl_render_stage {
+    PL_RENDER_STAGE_FRAME,
+    PL_RENDER_STAGE_BLEND,
+    PL_RENDER_STAGE_COUNT,
+};
+
+struct pl_render_info {
+    const struct pl_dispatch_info *pass;
+    enum pl_render_stage stage;
+    int index;
+    int count;
+};
+
+struct pl_render_params {
+    // Scalers: NULL = built-in bilinear ("free" sampling in the final pass)
+    const struct pl_filter_config *upscaler;
+    const struct pl_filter_config *downscaler;
+    const struct pl_filter_config *plane_upscaler;      // accepted, unused (single plane)
+    const struct pl_filter_config *plane_downscaler;    // accepted, unused (single plane)
+    float antiringing_strength;
+    const struct pl_filter_config *frame_mixer;         // unsupported
+
+    const struct pl_deband_params *deband_params;
+    const struct pl_sigmoid_params *sigmoid_params;
+    const struct pl_color_adjustment *color_adjustment;
+    const struct pl_peak_detect_params *peak_detect_params;
+    const struct pl_color_map_params *color_map_params;
+    const struct pl_dither_params *dither_params;
+    const struct pl_error_diffusion_kernel *error_diffusion;
+
+    const void *cone_params;            // unsupported, must be NULL
+    const void *blend_params;           // unsupported, must be NULL
+    const void *deinterlace_params;     // unsupported, must be NULL
+    const void *distort_params;         // unsupported, must be NULL
+    const void * const *hooks;          // unsupported, must be NULL
+    int num_hooks;
+    const void *lut;                    // unsupported, must be NULL
+    int lut_type;
+
+    enum pl_clear_mode background;
+    enum pl_clear_mode border;
+    float background_color[3];
+    float background_transparency;
+    float tile_colors[2][3];
+    int tile_size;
+    float blur_radius;
+    float corner_rounding;              // unsupported (ignored)
+
+    bool skip_anti_aliasing;
+    bool preserve_mixing_cache;
+    bool skip_caching_single_frame;
+    bool disable_linear_scaling;
+    bool disable_builtin_scalers;
+    bool correct_subpixel_offsets;
+    bool force_dither;
+    bool disable_dither_gamma_correction;
+    bool disable_fbos;
+    bool force_low_bit_depth_fbos;
+    bool dynamic_constants;
+
+    void (*info_callback)(void *priv, const struct pl_render_info *info);
+    void *info_priv;
+};
+
+#define PL_RENDER_DEFAULTS                              \
+    .color_map_params   = &pl_color_map_default_params, \
+    .color_adjustment   = &pl_color_adjustment_neutral, \
+    .tile_colors        = {{0.93, 0.93, 0.93},          \
+                           {0.87, 0.87, 0.87}},         \
+    .tile_size          = 32,                           \
+    .blur_radius        = 16.0,
+
+#define pl_render_params(...) (&(struct pl_render_params) { PL_RENDER_DEFAULTS __VA_ARGS__ })
+PL_API extern const struct pl_render_params pl_render_fast_params;
+PL_API extern const struct pl_render_params pl_render_default_params;
+PL_API extern const struct pl_render_params pl_render_high_quality_params;
+
+#define PL_MAX_PLANES 4
+
+struct pl_plane {
+    pl_tex texture;
+    enum pl_tex_address_mode address_mode;
+    bool flipped;
+    int components;           // number of relevant components
+    int component_mapping[4]; // semantic index of each component
+    float shift_x, shift_y;   // (must be 0: single reference plane)
+};
+
+typedef int pl_rotation;
+enum {
+    PL_ROTATION_0 = 0, PL_ROTATION_90, PL_ROTATION_180, PL_ROTATION_270, PL_ROTATION_360,
+};
+
+struct pl_frame {
+    int num_planes;           // 1 on this backend (packed RGB(A) / XYZ / single-plane YCbCr)
+    struct pl_plane planes[PL_MAX_PLANES];
+
+    bool (*acquire)(pl_gpu gpu, struct pl_frame *frame);
+    void (*release)(pl_gpu gpu, struct pl_frame *frame);
+
+    struct pl_color_repr repr;
+    struct pl_color_space color;
+
+    pl_rect2df crop;          // 0 = whole frame; flipped rects flip the image
+    pl_rotation rotation;     // must be PL_ROTATION_0
+    void *user_data;
+};
+
+// true if the frame's crop does not cover its whole reference plane
+PL_API bool pl_frame_is_cropped(const struct pl_frame *frame);
+
+// Fill in what pl_render_image would infer (crop, bit depths, colour spaces)
+PL_API void pl_frames_infer(pl_renderer rr, struct pl_frame *image, struct pl_frame *target);
+
+// Render `image` to `target`. Returns false on hard failure; soft failures
+// disable the offending stage and are reported by pl_renderer_get_errors.
+PL_API bool pl_render_image(pl_renderer rr, const struct pl_frame *image,
+                            const struct pl_frame *target,
+                            const struct pl_render_params *params);
+
+// Drop cached FBOs / LUT state
+PL_API void pl_renderer_flush_cache(pl_renderer rr);
+
+// HDR metadata measured by the last frame's peak detection, if any
+PL_API bool pl_renderer_get_hdr_metadata(pl_renderer rr, struct pl_hdr_metadata *metadata);
+
+// HIP extension (multi-GPU): the renderer's tone-mapping state object, whose
+// pending peak measurement can be all-reduced across ranks through pl_hip_peak_buffer().
+PL_API pl_shader_obj pl_hip_renderer_tone_map_state(pl_renderer rr);
+
+PL_API_END
+
+#endif // LIBPLACEBO_RENDERER_H_

@@ -351,3 +351,59 @@ class HipGpu:
 
     def __exit__(self, *exc):
         self.close()
+
+
+# ---- renderer.h ----------------------------------------------------------------------------
+def frame(tex, repr_=None, color=None, crop=None, components=None, mapping=None,
+          flipped=False):
+    """A single-plane pl_frame around `tex` (a Texture)."""
+    f = capi.Frame(num_planes=1)
+    pl_ = f.planes[0]
+    pl_.texture = tex.ptr
+    comps = components or tex.ptr.contents.params.format.contents.num_components
+    pl_.components = comps
+    pl_.flipped = flipped
+    m = list(mapping) if mapping is not None else list(range(comps))
+    for c in range(4):
+        pl_.component_mapping[c] = m[c] if c < len(m) else -1
+    f.repr = repr_ if repr_ is not None else color_repr("rgb", "full")
+    f.color = color if color is not None else color_space("bt709", "srgb")
+    if crop is not None:
+        f.crop = capi.Rect2df(*crop)
+    return f
+
+
+def render_params(preset="fast", **kw):
+    """pl_render_{fast,default,high_quality}_params with overrides; pointer fields accept
+    ctypes structs (kept alive on the returned object)."""
+    src = capi.RenderParams.in_dll(lib(), f"pl_render_{preset}_params")
+    p = capi.RenderParams()
+    C.memmove(C.byref(p), C.byref(src), C.sizeof(p))
+    p._keep = []
+    for k, v in kw.items():
+        if isinstance(v, C.Structure):
+            p._keep.append(v)
+            v = C.pointer(v)
+        elif v is None:
+            ftype = dict(capi.RenderParams._fields_)[k]
+            v = ftype()
+        setattr(p, k, v)
+    return p
+
+
+class Renderer:
+    def __init__(self, gpu):
+        self.gpu = gpu
+        self.rr = C.c_void_p(lib().pl_renderer_create(gpu.log, gpu.gpu))
+        assert self.rr
+
+    def render(self, image, target, params=None):
+        return lib().pl_render_image(self.rr, C.byref(image), C.byref(target),
+                                     C.byref(params) if params is not None else None)
+
+    def errors(self):
+        return lib().pl_renderer_get_errors(self.rr).errors
+
+    def destroy(self):
+        if self.rr:
+            lib().pl_renderer_destroy(C.byref(self.rr))

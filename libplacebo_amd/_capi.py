@@ -292,6 +292,53 @@ class ColorMapArgs(C.Structure):
                 ("state", C.POINTER(C.c_void_p)), ("feature_map", C.POINTER(Tex))]
 
 
+# ---- renderer.h ----------------------------------------------------------------------------
+class Plane(C.Structure):
+    _fields_ = [("texture", C.POINTER(Tex)), ("address_mode", C.c_int), ("flipped", C.c_bool),
+                ("components", C.c_int), ("component_mapping", C.c_int * 4),
+                ("shift_x", C.c_float), ("shift_y", C.c_float)]
+
+
+class Frame(C.Structure):
+    _fields_ = [("num_planes", C.c_int), ("planes", Plane * 4),
+                ("acquire", C.c_void_p), ("release", C.c_void_p),
+                ("repr", ColorRepr), ("color", ColorSpace), ("crop", Rect2df),
+                ("rotation", C.c_int), ("user_data", C.c_void_p)]
+
+
+class RenderParams(C.Structure):
+    _fields_ = [("upscaler", C.POINTER(FilterConfig)), ("downscaler", C.POINTER(FilterConfig)),
+                ("plane_upscaler", C.POINTER(FilterConfig)),
+                ("plane_downscaler", C.POINTER(FilterConfig)),
+                ("antiringing_strength", C.c_float), ("frame_mixer", C.c_void_p),
+                ("deband_params", C.POINTER(DebandParams)),
+                ("sigmoid_params", C.POINTER(SigmoidParams)),
+                ("color_adjustment", C.POINTER(ColorAdjustment)),
+                ("peak_detect_params", C.POINTER(PeakDetectParams)),
+                ("color_map_params", C.POINTER(ColorMapParams)),
+                ("dither_params", C.POINTER(DitherParams)),
+                ("error_diffusion", C.POINTER(ErrorDiffusionKernel)),
+                ("cone_params", C.c_void_p), ("blend_params", C.c_void_p),
+                ("deinterlace_params", C.c_void_p), ("distort_params", C.c_void_p),
+                ("hooks", C.c_void_p), ("num_hooks", C.c_int), ("lut", C.c_void_p),
+                ("lut_type", C.c_int), ("background", C.c_int), ("border", C.c_int),
+                ("background_color", C.c_float * 3), ("background_transparency", C.c_float),
+                ("tile_colors", (C.c_float * 3) * 2), ("tile_size", C.c_int),
+                ("blur_radius", C.c_float), ("corner_rounding", C.c_float),
+                ("skip_anti_aliasing", C.c_bool), ("preserve_mixing_cache", C.c_bool),
+                ("skip_caching_single_frame", C.c_bool), ("disable_linear_scaling", C.c_bool),
+                ("disable_builtin_scalers", C.c_bool), ("correct_subpixel_offsets", C.c_bool),
+                ("force_dither", C.c_bool), ("disable_dither_gamma_correction", C.c_bool),
+                ("disable_fbos", C.c_bool), ("force_low_bit_depth_fbos", C.c_bool),
+                ("dynamic_constants", C.c_bool), ("info_callback", C.c_void_p),
+                ("info_priv", C.c_void_p)]
+
+
+class RenderErrors(C.Structure):
+    _fields_ = [("errors", C.c_int), ("disabled_hooks", C.c_void_p),
+                ("num_disabled_hooks", C.c_int)]
+
+
 def declare(lib):
     """Attach argtypes/restypes."""
     P = C.POINTER
@@ -353,6 +400,15 @@ def declare(lib):
     fn("pl_find_error_diffusion_kernel", P(ErrorDiffusionKernel), C.c_char_p)
     fn("pl_error_diffusion_shmem_req", C.c_size_t, P(ErrorDiffusionKernel), C.c_int)
 
+    fn("pl_renderer_create", vp, vp, P(Gpu))
+    fn("pl_renderer_destroy", None, P(vp))
+    fn("pl_renderer_get_errors", RenderErrors, vp)
+    fn("pl_renderer_reset_errors", None, vp, P(RenderErrors))
+    fn("pl_render_image", C.c_bool, vp, P(Frame), P(Frame), P(RenderParams))
+    fn("pl_frames_infer", None, vp, P(Frame), P(Frame))
+    fn("pl_renderer_get_hdr_metadata", C.c_bool, vp, P(HdrMetadata))
+    fn("pl_renderer_flush_cache", None, vp)
+    fn("pl_hip_renderer_tone_map_state", vp, vp)
     fn("pl_shader_set_alpha", None, vp, P(ColorRepr), C.c_int)
     fn("pl_shader_decode_color", None, vp, P(ColorRepr), P(ColorAdjustment))
     fn("pl_shader_encode_color", None, vp, P(ColorRepr))

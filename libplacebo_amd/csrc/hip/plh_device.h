@@ -99,6 +99,10 @@ struct plh_sampler_args {
     float scale;            // multiplied into the sampled colour
     uint32_t comp_mask;     // components actually sampled
     int32_t linear;         // texture bound with LINEAR filtering (for deband etc.)
+    // BILINEAR only: |rect| in texels, and whether the rect starts on the texel grid. The
+    // dispatch lowers a 1:1 on-grid fetch to NEAREST once the output size is known.
+    float rect_w, rect_h;
+    int32_t rect_on_grid;
 
     // POLAR: 256-entry radial LUT, as {L[i], L[i+1]} pairs; tap list
     const float *lut;       // device, 2*256 floats (pairs)
@@ -161,6 +165,9 @@ enum plh_op_kind {
     PLH_OP_GAMUT_LUT,       // ptr = rgba16 3-D LUT; i0,i1,i2 = sizes; f[0]=scale f[1]=offset f[2]=0.5/pi
     PLH_OP_IPT2RGB,         // f[0..8] = lms2rgb, f[9..14] = 1/m2, c1, c2, c3, 1/m1, 10000/203
     PLH_OP_PEAK_DETECT,     // see k_peak.hip; only valid in the 16x16 peak kernel
+    // renderer glue (renderer.c)
+    PLH_OP_PLANE_MAP,       // color = f[0..3]; color[map[c]] = tmp[c], c < i1; i0 packs map (0xff = none)
+    PLH_OP_BLEND_BG,        // color += (1 - color.a) * f[0..3]   (renderer.c:2722-2728)
 };
 
 // flags in plh_op.i1 of LINEARIZE / DELINEARIZE / PEAK_DETECT

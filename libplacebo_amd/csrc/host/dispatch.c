@@ -167,6 +167,13 @@ static void plh_pass_choose_cells(struct plh_pass *pass)
     pass->cell_padx = pass->cell_pady = 0;
     if (pass->s.type != PLH_SAMPLE_BILINEAR)
         return;
+    // identity fetch (1:1, on the texel grid): what a texture unit returns is the texel
+    if (pass->s.rect_on_grid && fabsf(pass->width / pass->s.rect_w - 1.0f) < 1e-6f &&
+        fabsf(pass->height / pass->s.rect_h - 1.0f) < 1e-6f)
+    {
+        pass->s.type = PLH_SAMPLE_NEAREST;
+        return;
+    }
     const struct plh_sampler_args *s = &pass->s;
     for (int axis = 0; axis < 2; axis++) {
         const int n = axis ? pass->height : pass->width;
@@ -321,7 +328,6 @@ bool pl_dispatch_compute(pl_dispatch dp, const struct pl_dispatch_compute_params
         }
         struct plh_pass *pass = &sh->pass;
         memset(&pass->dst, 0, sizeof(pass->dst)); // every store is out of bounds
-        pass->cell_padx = pass->cell_pady = 0;
         pass->width = params->width;
         pass->height = params->height;
         pass->out_scale[0] = 1.0 / params->width;
@@ -330,6 +336,7 @@ bool pl_dispatch_compute(pl_dispatch dp, const struct pl_dispatch_compute_params
         pass->dir_x = pass->dir_y = 1;
         pass->transpose = 0;
         pass->frag_x0 = pass->frag_y0 = 0;
+        plh_pass_choose_cells(pass);
         if (timer)
             plh_timer_begin(dp->gpu, timer);
         err = plh_launch_pass(plh_gpu_stream(dp->gpu), pass);

@@ -1,0 +1,1354 @@
+/*
+ * libplacebo-hip — pl_renderer: the pl_render_image hot path.
+ *
+ * Host-side pass graph of the reference's src/renderer.c, restated for the op-recording
+ * shaders of this backend. Same stages, same order, same decisions:
+ *
+ *   pass_fix_frames     crop rounding, bit-depth / colour-space inference   renderer.c:3068-3293
+ *   pass_read_image     [deband] -> sample plane -> decode -> premultiply  :1553-1960
+ *   pass_scale_main     sampler choice, [peak detect], linearize/sigmoidize,
+ *                       PASS A into an FBO, main scaler, unsigmoidize       :597-682, :1964-2087
+ *   pass_convert_colors [PASS B for same-frame peak], colour mapping        :2157-2280
+ *   pass_output_target  background, encode, dither / error diffusion,
+ *                       1/scale, swizzle, final pass into the target        :2586-2960
+ *
+ * A pass boundary (FBO) appears exactly where the reference has one; everything between two
+ * boundaries runs fused in one HIP launch (sampler + colour ops).
+ *
+ * Scope: frames with ONE plane (packed RGB(A), or any single-plane representation). Planar /
+ * subsampled frames, rotation, hooks, LUTs, ICC, overlays, blending, deinterlacing and frame
+ * mixing are outside this round's hot path and rejected with an error.
+ */
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <libplacebo/renderer.h>
+
+#include "shaders_priv.h"
+
+#define MAX_FBOS 16
+
+struct sampler {
+    pl_shader_obj upscaler_state;
+    pl_shader_obj downscaler_state;
+};
+
+struct pl_renderer_t {
+    pl_gpu gpu;
+    pl_dispatch dp;
+    pl_log log;
+    enum pl_render_error errors;
+
+    pl_tex fbos[MAX_FBOS];
+    int num_fbos;
+
+    struct sampler sampler_main;
+    struct sampler sampler_src;
+    pl_shader_obj tone_map_state;
+    pl_shader_obj dither_state;
+    int prev_dither;
+};
+
+enum sampler_type {
+    SAMPLER_DIRECT,     // pick based on texture caps
+    SAMPLER_NEAREST,
+    SAMPLER_BICUBIC,
+    SAMPLER_HERMITE,
+    SAMPLER_GAUSSIAN,
+    SAMPLER_COMPLEX,    // polar / separable filters
+    SAMPLER_OVERSAMPLE,
+};
+
+enum sampler_dir { SAMPLER_NOOP, SAMPLER_UP, SAMPLER_DOWN };
+enum sampler_usage { SAMPLER_MAIN, SAMPLER_PLANE };
+
+struct sampler_info {
+    const struct pl_filter_config *config;
+    enum sampler_usage usage;
+    enum sampler_type type;
+    enum sampler_dir dir;
+    enum sampler_dir dir_sep[2];
+};
+
+// An image in flight: either a recorded-but-not-yet-dispatched shader or a texture
+struct img {
+    pl_shader sh;
+    pl_tex tex;
+    int w, h;
+    pl_rect2df rect;
+    struct pl_color_repr repr;
+    struct pl_color_space color;
+    int comps;
+    pl_fmt fmt;             // FBO format override
+    const char *err_msg;
+    enum pl_render_error err_enum;
+    pl_tex err_tex;
+};
+
+struct pass_state {
+    pl_renderer rr;
+    const struct pl_render_params *params;
+    struct pl_frame image, target;
+    pl_rect2d dst_rect;
+    pl_rect2df ref_rect;
+    struct img img;
+    pl_fmt fbofmt[5];
+    bool fbos_used[MAX_FBOS];
+    bool need_peak_fbo;
+    bool acquired_image, acquired_target;
+};
+
+#define RR_ERR(rr, ...)  pl_msg((rr)->log, PL_LOG_ERR, __VA_ARGS__)
+#define RR_WARN(rr, ...) pl_msg((rr)->log, PL_LOG_WARN, __VA_ARGS__)
+#define RR_INFO(rr, ...) pl_msg((rr)->log, PL_LOG_INFO, __VA_ARGS__)
+
+const struct pl_render_params pl_render_fast_params = { PL_RENDER_DEFAULTS };
+const struct pl_render_params pl_render_default_params = {
+    PL_RENDER_DEFAULTS
+    .upscaler           = &pl_filter_lanczos,
+    .downscaler         = &pl_filter_hermite,
+    .sigmoid_params     = &pl_sigmoid_default_params,
+    .dither_params      = &pl_dither_default_params,
+    .peak_detect_params = &pl_peak_detect_default_params,
+};
+const struct pl_render_params pl_render_high_quality_params = {
+    PL_RENDER_DEFAULTS
+    .upscaler           = &pl_filter_ewa_lanczossharp,
+    .downscaler         = &pl_filter_hermite,
+    .sigmoid_params     = &pl_sigmoid_default_params,
+    .peak_detect_params = &pl_peak_detect_high_quality_params,
+    .color_map_params   = &pl_color_map_high_quality_params,
+    .dither_params      = &pl_dither_default_params,
+    .deband_params      = &pl_deband_default_params,
+};
+
+pl_renderer pl_renderer_create(pl_log log, pl_gpu gpu)
+{
+    pl_renderer rr = calloc(1, sizeof(*rr));
+    if (!rr)
+        return NULL;
+    rr->gpu = gpu;
+    rr->log = log;
+    rr->dp = pl_dispatch_create(log, gpu);
+    if (!rr->dp) {
+        free(rr);
+        return NULL;
+    }
+    return rr;
+}
+
+static void sampler_destroy(struct sampler *s)
+{
+    pl_shader_obj_destroy(&s->upscaler_state);
+    pl_shader_obj_destroy(&s->downscaler_state);
+}
+
+void pl_renderer_flush_cache(pl_renderer rr)
+{
+    for (int i = 0; i < rr->num_fbos; i++)
+        pl_tex_destroy(rr->gpu, &rr->fbos[i]);
+    rr->num_fbos = 0;
+    pl_reset_detected_peak(rr->tone_map_state);
+}
+
+void pl_renderer_destroy(pl_renderer *p_rr)
+{
+    pl_renderer rr = *p_rr;
+    if (!rr)
+        return;
+    pl_gpu_finish(rr->gpu);
+    pl_renderer_flush_cache(rr);
+    sampler_destroy(&rr->sampler_main);
+    sampler_destroy(&rr->sampler_src);
+    pl_shader_obj_destroy(&rr->tone_map_state);
+    pl_shader_obj_destroy(&rr->dither_state);
+    pl_dispatch_destroy(&rr->dp);
+    free(rr);
+    *p_rr = NULL;
+}
+
+struct pl_render_errors pl_renderer_get_errors(pl_renderer rr)
+{
+    return (struct pl_render_errors) { .errors = rr->errors };
+}
+
+void pl_renderer_reset_errors(pl_renderer rr, const struct pl_render_errors *errors)
+{
+    if (!errors) {
+        rr->errors = PL_RENDER_ERR_NONE;
+        return;
+    }
+    rr->errors &= ~errors->errors;
+}
+
+bool pl_renderer_get_hdr_metadata(pl_renderer rr, struct pl_hdr_metadata *metadata)
+{
+    return pl_get_detected_hdr_metadata(rr->tone_map_state, metadata);
+}
+
+pl_shader_obj pl_hip_renderer_tone_map_state(pl_renderer rr)
+{
+    return rr->tone_map_state;
+}
+
+/* ---- FBOs (find_fbo_format :383-434, get_fbo :448-503) ----------------------------------- */
+
+static void find_fbo_format(struct pass_state *pass)
+{
+    const struct pl_render_params *params = pass->params;
+    pl_renderer rr = pass->rr;
+    if (params->disable_fbos || (rr->errors & PL_RENDER_ERR_FBO) || pass->fbofmt[4])
+        return;
+
+    static const struct { enum pl_fmt_type type; int depth; enum pl_fmt_caps caps; } configs[] = {
+        {PL_FMT_FLOAT, 16, PL_FMT_CAP_LINEAR},
+        {PL_FMT_FLOAT, 16, PL_FMT_CAP_SAMPLEABLE},
+        {PL_FMT_UNORM, 16, PL_FMT_CAP_LINEAR},
+        {PL_FMT_SNORM, 16, PL_FMT_CAP_LINEAR},
+        {PL_FMT_UNORM, 16, PL_FMT_CAP_SAMPLEABLE},
+        {PL_FMT_SNORM, 16, PL_FMT_CAP_SAMPLEABLE},
+        {PL_FMT_UNORM, 8, PL_FMT_CAP_LINEAR},
+        {PL_FMT_UNORM, 8, PL_FMT_CAP_SAMPLEABLE},
+    };
+
+    for (size_t i = 0; i < sizeof(configs) / sizeof(configs[0]); i++) {
+        if (params->force_low_bit_depth_fbos && configs[i].depth > 8)
+            continue;
+        pl_fmt fmt = pl_find_fmt(rr->gpu, configs[i].type, 4, configs[i].depth, 0,
+                                 PL_FMT_CAP_RENDERABLE | configs[i].caps);
+        if (!fmt)
+            continue;
+        pass->fbofmt[4] = fmt;
+        for (int c = 3; c >= 1; c--) {
+            pass->fbofmt[c] = pl_find_fmt(rr->gpu, configs[i].type, c, configs[i].depth, 0,
+                                          fmt->caps);
+            pass->fbofmt[c] = PL_DEF(pass->fbofmt[c], pass->fbofmt[c + 1]);
+        }
+        return;
+    }
+
+    RR_WARN(rr, "Found no renderable FBO format! Most features disabled");
+    rr->errors |= PL_RENDER_ERR_FBO;
+}
+
+static pl_tex get_fbo(struct pass_state *pass, int w, int h, pl_fmt fmt, int comps)
+{
+    pl_renderer rr = pass->rr;
+    comps = PL_DEF(comps, 4);
+    fmt = PL_DEF(fmt, pass->fbofmt[comps]);
+    if (!fmt)
+        return NULL;
+
+    const struct pl_tex_params params = {
+        .w = w, .h = h, .format = fmt,
+        .sampleable = true, .renderable = true,
+        .storable = fmt->caps & PL_FMT_CAP_STORABLE,
+    };
+
+    // best fit among the unused FBOs: |dw| + |dh| + 1000 * (format mismatch)
+    int best_idx = -1, best_diff = 0;
+    for (int i = 0; i < rr->num_fbos; i++) {
+        if (pass->fbos_used[i])
+            continue;
+        const int diff = abs(rr->fbos[i]->params.w - w) + abs(rr->fbos[i]->params.h - h) +
+                         (rr->fbos[i]->params.format != fmt ? 1000 : 0);
+        if (best_idx < 0 || diff < best_diff) {
+            best_idx = i;
+            best_diff = diff;
+        }
+    }
+    if (best_idx < 0) {
+        if (rr->num_fbos == MAX_FBOS)
+            return NULL;
+        best_idx = rr->num_fbos++;
+        rr->fbos[best_idx] = NULL;
+    }
+    if (!pl_tex_recreate(rr->gpu, &rr->fbos[best_idx], &params))
+        return NULL;
+    pass->fbos_used[best_idx] = true;
+    return rr->fbos[best_idx];
+}
+
+// Forcibly convert an img to `tex`, dispatching where necessary (:505-547)
+static pl_tex img_tex(struct pass_state *pass, struct img *img)
+{
+    if (img->tex)
+        return img->tex;
+
+    pl_renderer rr = pass->rr;
+    pl_tex tex = get_fbo(pass, img->w, img->h, img->fmt, img->comps);
+    img->fmt = NULL;
+    if (!tex) {
+        RR_ERR(rr, "Failed creating FBO texture! Disabling advanced rendering..");
+        memset(pass->fbofmt, 0, sizeof(pass->fbofmt));
+        pl_dispatch_abort(rr->dp, &img->sh);
+        rr->errors |= PL_RENDER_ERR_FBO;
+        return img->err_tex;
+    }
+
+    const bool ok = pl_dispatch_finish(rr->dp, pl_dispatch_params(
+        .shader = &img->sh,
+        .target = tex,
+    ));
+
+    const char *err_msg = img->err_msg;
+    const enum pl_render_error err_enum = img->err_enum;
+    pl_tex err_tex = img->err_tex;
+    img->err_msg = NULL;
+    img->err_enum = PL_RENDER_ERR_NONE;
+    img->err_tex = NULL;
+
+    if (!ok) {
+        RR_ERR(rr, "%s", PL_DEF(err_msg, "Failed dispatching intermediate pass!"));
+        rr->errors |= err_enum;
+        img->sh = pl_dispatch_begin(rr->dp);
+        img->tex = err_tex;
+        return img->tex;
+    }
+
+    img->tex = tex;
+    return img->tex;
+}
+
+// Forcibly convert an img to `sh`, sampling where necessary (:552-567)
+static pl_shader img_sh(struct pass_state *pass, struct img *img)
+{
+    if (img->sh)
+        return img->sh;
+    img->sh = pl_dispatch_begin(pass->rr->dp);
+    pl_shader_sample_direct(img->sh, pl_sample_src( .tex = img->tex ));
+    img->tex = NULL;
+    return img->sh;
+}
+
+/* ---- samplers (sample_src_info :597-682, dispatch_sampler :684-789) ------------------------ */
+
+static struct sampler_info sample_src_info(struct pass_state *pass, const struct pl_sample_src *src,
+                                           enum sampler_usage usage)
+{
+    const struct pl_render_params *params = pass->params;
+    struct sampler_info info = { .usage = usage };
+    pl_renderer rr = pass->rr;
+
+    const float rx = src->new_w / fabsf(pl_rect_w(src->rect));
+    if (rx < 1.0 - 1e-6) {
+        info.dir_sep[0] = SAMPLER_DOWN;
+    } else if (rx > 1.0 + 1e-6) {
+        info.dir_sep[0] = SAMPLER_UP;
+    }
+    const float ry = src->new_h / fabsf(pl_rect_h(src->rect));
+    if (ry < 1.0 - 1e-6) {
+        info.dir_sep[1] = SAMPLER_DOWN;
+    } else if (ry > 1.0 + 1e-6) {
+        info.dir_sep[1] = SAMPLER_UP;
+    }
+
+    if (params->correct_subpixel_offsets) {
+        if (!info.dir_sep[0] && fabsf(src->rect.x0) > 1e-6f)
+            info.dir_sep[0] = SAMPLER_UP;
+        if (!info.dir_sep[1] && fabsf(src->rect.y0) > 1e-6f)
+            info.dir_sep[1] = SAMPLER_UP;
+    }
+
+    // downscaling overrides upscaling when choosing scalers
+    info.dir = PL_MAX(info.dir_sep[0], info.dir_sep[1]);
+    switch (info.dir) {
+    case SAMPLER_DOWN:
+        info.config = usage == SAMPLER_PLANE && params->plane_downscaler
+                        ? params->plane_downscaler : params->downscaler;
+        break;
+    case SAMPLER_UP:
+        info.config = usage == SAMPLER_PLANE && params->plane_upscaler
+                        ? params->plane_upscaler : params->upscaler;
+        break;
+    case SAMPLER_NOOP:
+        info.type = SAMPLER_NEAREST;
+        return info;
+    }
+
+    if ((rr->errors & PL_RENDER_ERR_SAMPLING) || !info.config) {
+        info.type = SAMPLER_DIRECT;
+    } else if (info.config->kernel == &pl_filter_function_oversample) {
+        info.type = SAMPLER_OVERSAMPLE;
+    } else {
+        info.type = SAMPLER_COMPLEX;
+
+        // faster replacements for the scalers a texture unit provides
+        pl_fmt texfmt = src->tex ? src->tex->params.format : pass->fbofmt[4];
+        const bool can_linear = texfmt->caps & PL_FMT_CAP_LINEAR;
+        const bool can_fast = info.dir == SAMPLER_UP || params->skip_anti_aliasing;
+        if (can_fast && !params->disable_builtin_scalers) {
+            if (can_linear && pl_filter_config_eq(info.config, &pl_filter_bicubic))
+                info.type = SAMPLER_BICUBIC;
+            if (can_linear && pl_filter_config_eq(info.config, &pl_filter_hermite))
+                info.type = SAMPLER_HERMITE;
+            if (can_linear && pl_filter_config_eq(info.config, &pl_filter_gaussian))
+                info.type = SAMPLER_GAUSSIAN;
+            if (can_linear && pl_filter_config_eq(info.config, &pl_filter_bilinear))
+                info.type = SAMPLER_DIRECT;
+            if (pl_filter_config_eq(info.config, &pl_filter_nearest))
+                info.type = can_linear ? SAMPLER_NEAREST : SAMPLER_DIRECT;
+        }
+    }
+
+    // no advanced scaling without FBOs
+    if (!pass->fbofmt[4] && info.type == SAMPLER_COMPLEX)
+        info.type = SAMPLER_DIRECT;
+    return info;
+}
+
+static void dispatch_sampler(struct pass_state *pass, pl_shader sh, struct sampler *sampler,
+                             enum sampler_usage usage, const struct pl_sample_src *src)
+{
+    const struct pl_render_params *params = pass->params;
+    pl_renderer rr = pass->rr;
+    if (!sampler)
+        goto fallback;
+
+    const struct sampler_info info = sample_src_info(pass, src, usage);
+    pl_shader_obj *lut = NULL;
+    switch (info.dir) {
+    case SAMPLER_NOOP:
+        goto fallback;
+    case SAMPLER_DOWN:
+        lut = &sampler->downscaler_state;
+        break;
+    case SAMPLER_UP:
+        lut = &sampler->upscaler_state;
+        break;
+    }
+
+    switch (info.type) {
+    case SAMPLER_DIRECT:
+        goto fallback;
+    case SAMPLER_NEAREST:
+        pl_shader_sample_nearest(sh, src);
+        return;
+    case SAMPLER_OVERSAMPLE:
+        pl_shader_sample_oversample(sh, src, info.config->kernel->params[0]);
+        return;
+    case SAMPLER_BICUBIC:
+        pl_shader_sample_bicubic(sh, src);
+        return;
+    case SAMPLER_HERMITE:
+        pl_shader_sample_hermite(sh, src);
+        return;
+    case SAMPLER_GAUSSIAN:
+        pl_shader_sample_gaussian(sh, src);
+        return;
+    case SAMPLER_COMPLEX:
+        break;
+    }
+
+    struct pl_sample_filter_params fparams = {
+        .filter      = *info.config,
+        .antiring    = params->antiringing_strength,
+        .no_widening = params->skip_anti_aliasing,
+        .lut         = lut,
+    };
+
+    bool ok;
+    if (info.config->polar) {
+        ok = pl_shader_sample_polar(sh, src, &fparams);
+    } else if (info.dir_sep[0] && info.dir_sep[1]) {
+        // both directions: vertical pass into an FBO, then the horizontal pass (:745-772)
+        struct pl_sample_src src1 = *src, src2 = *src;
+        src1.new_w = src->tex->params.w;
+        src1.rect.x0 = 0;
+        src1.rect.x1 = src1.new_w;
+        src2.rect.y0 = 0;
+        src2.rect.y1 = src1.new_h;
+
+        pl_shader tsh = pl_dispatch_begin(rr->dp);
+        ok = pl_shader_sample_ortho2(tsh, &src1, &fparams);
+        if (!ok) {
+            pl_dispatch_abort(rr->dp, &tsh);
+            goto done;
+        }
+        struct img img = {
+            .sh = tsh, .w = src1.new_w, .h = src1.new_h, .comps = src->components,
+        };
+        src2.tex = img_tex(pass, &img);
+        src2.scale = 1.0;
+        ok = src2.tex && pl_shader_sample_ortho2(sh, &src2, &fparams);
+    } else {
+        ok = pl_shader_sample_ortho2(sh, src, &fparams);
+    }
+
+done:
+    if (!ok) {
+        RR_ERR(rr, "Failed dispatching scaler.. disabling");
+        rr->errors |= PL_RENDER_ERR_SAMPLING;
+        goto fallback;
+    }
+    return;
+
+fallback:
+    pl_shader_sample_direct(sh, src);
+}
+
+/* ---- frame fix-ups (:3068-3293) -------------------------------------------------------------- */
+
+static void default_rect(pl_rect2df *rc, const pl_rect2df *backup)
+{
+    if (!rc->x0 && !rc->y0 && !rc->x1 && !rc->y1)
+        *rc = *backup;
+}
+
+bool pl_frame_is_cropped(const struct pl_frame *frame)
+{
+    if (!frame->num_planes || !frame->planes[0].texture)
+        return false;
+    pl_tex ref = frame->planes[0].texture;
+    pl_rect2df crop = frame->crop;
+    default_rect(&crop, &(pl_rect2df) { 0, 0, ref->params.w, ref->params.h });
+    pl_rect2df_normalize(&crop);
+    const int x0 = roundf(crop.x0), y0 = roundf(crop.y0),
+              x1 = roundf(crop.x1), y1 = roundf(crop.y1);
+    return x0 > 0 || y0 > 0 || x1 < ref->params.w || y1 < ref->params.h;
+}
+
+static void fix_refs_and_rects(struct pass_state *pass)
+{
+    struct pl_frame *target = &pass->target, *image = &pass->image;
+    pl_rect2df *dst = &target->crop, *src = &image->crop;
+    pl_tex dst_ref = target->planes[0].texture, src_ref = image->planes[0].texture;
+    const int dst_w = dst_ref->params.w, dst_h = dst_ref->params.h;
+
+    if ((!dst->x0 && !dst->x1) || (!dst->y0 && !dst->y1)) {
+        dst->x1 = dst_w;
+        dst->y1 = dst_h;
+    }
+    if ((!src->x0 && !src->x1) || (!src->y0 && !src->y1)) {
+        src->x1 = src_ref->params.w;
+        src->y1 = src_ref->params.h;
+    }
+
+    // is the end-to-end rendering flipped?
+    const bool flipped_x = (src->x0 > src->x1) != (dst->x0 > dst->x1),
+               flipped_y = (src->y0 > src->y1) != (dst->y0 > dst->y1);
+    pl_rect2df_normalize(src);
+    pl_rect2df_normalize(dst);
+
+    // round the output rect and clip it to the framebuffer
+    const float rx0 = roundf(PL_CLAMP(dst->x0, 0.0, dst_w)),
+                ry0 = roundf(PL_CLAMP(dst->y0, 0.0, dst_h)),
+                rx1 = roundf(PL_CLAMP(dst->x1, 0.0, dst_w)),
+                ry1 = roundf(PL_CLAMP(dst->y1, 0.0, dst_h));
+
+    // adjust the src rect for the rounded crop
+    const float scale_x = pl_rect_w(*src) / pl_rect_w(*dst),
+                scale_y = pl_rect_h(*src) / pl_rect_h(*dst),
+                base_x = src->x0, base_y = src->y0;
+    src->x0 = base_x + (rx0 - dst->x0) * scale_x;
+    src->x1 = base_x + (rx1 - dst->x0) * scale_x;
+    src->y0 = base_y + (ry0 - dst->y0) * scale_y;
+    src->y1 = base_y + (ry1 - dst->y0) * scale_y;
+
+    // flips always go to the dst rect (keeps compute samplers usable)
+    *dst = (pl_rect2df) {
+        .x0 = flipped_x ? rx1 : rx0,
+        .y0 = flipped_y ? ry1 : ry0,
+        .x1 = flipped_x ? rx0 : rx1,
+        .y1 = flipped_y ? ry0 : ry1,
+    };
+    pass->ref_rect = *src;
+    pass->dst_rect = (pl_rect2d) { dst->x0, dst->y0, dst->x1, dst->y1 };
+}
+
+static void fix_frame(struct pl_frame *frame)
+{
+    pl_tex tex = frame->planes[0].texture;
+    if (frame->repr.sys == PL_COLOR_SYSTEM_XYZ) {
+        // XYZ is implicitly converted to linear DCI-P3 in pl_color_repr_decode
+        frame->color.primaries = PL_COLOR_PRIM_DCI_P3;
+        frame->color.transfer = PL_COLOR_TRC_ST428;
+    }
+    if (tex && !frame->color.primaries)
+        frame->color.primaries = pl_color_primaries_guess(tex->params.w, tex->params.h);
+
+    bool has_alpha = false;
+    for (int p = 0; p < frame->num_planes; p++) {
+        for (int c = 0; c < frame->planes[p].components; c++)
+            has_alpha |= frame->planes[p].component_mapping[c] == PL_CHANNEL_A;
+    }
+    if (!has_alpha)
+        frame->repr.alpha = PL_ALPHA_NONE;
+
+    // UNORM textures tell us the sampled bit depth
+    struct pl_bit_encoding *bits = &frame->repr.bits;
+    if (!bits->sample_depth && tex && tex->params.format->type == PL_FMT_UNORM) {
+        bits->sample_depth = tex->params.format->component_depth[0];
+        bits->color_depth = PL_DEF(bits->color_depth, bits->sample_depth);
+        bits->color_depth = PL_MIN(bits->color_depth, bits->sample_depth);
+        bits->bit_shift += bits->sample_depth - bits->color_depth;
+    }
+}
+
+static void pass_fix_frames(struct pass_state *pass)
+{
+    struct pl_frame *image = &pass->image, *target = &pass->target;
+    fix_refs_and_rects(pass);
+    fix_frame(image);
+    pl_color_space_infer_map(&image->color, &target->color);
+    fix_frame(target); // only after infer_map
+    if (image->repr.alpha == PL_ALPHA_UNKNOWN)
+        image->repr.alpha = PL_ALPHA_INDEPENDENT;
+    if (target->repr.alpha == PL_ALPHA_UNKNOWN)
+        target->repr.alpha = PL_ALPHA_PREMULTIPLIED;
+}
+
+static bool validate_frame(pl_renderer rr, const struct pl_frame *f, const char *what, bool dst)
+{
+    if (f->num_planes != 1 || !f->planes[0].texture) {
+        RR_ERR(rr, "%s frame has %d planes: only single-plane frames are supported by this "
+               "backend for now (planar input/output is the next component)", what,
+               f->num_planes);
+        return false;
+    }
+    const struct pl_plane *pl = &f->planes[0];
+    if (pl->components < 1 || pl->components > 4) {
+        RR_ERR(rr, "%s plane has an invalid number of components: %d", what, pl->components);
+        return false;
+    }
+    if (pl->shift_x || pl->shift_y) {
+        RR_ERR(rr, "%s reference plane must have no shift", what);
+        return false;
+    }
+    if (f->rotation % PL_ROTATION_360 != PL_ROTATION_0) {
+        RR_ERR(rr, "Rotation is not supported by this backend yet");
+        return false;
+    }
+    if (dst && !pl->texture->params.storable) {
+        RR_ERR(rr, "Target texture must be storable (every pass is a compute pass)");
+        return false;
+    }
+    if (!dst && !pl->texture->params.sampleable) {
+        RR_ERR(rr, "Image texture must be sampleable");
+        return false;
+    }
+    return true;
+}
+
+void pl_frames_infer(pl_renderer rr, struct pl_frame *image, struct pl_frame *target)
+{
+    struct pass_state pass = { .rr = rr, .image = *image, .target = *target };
+    if (!validate_frame(rr, image, "Image", false) || !validate_frame(rr, target, "Target", true))
+        return;
+    pass_fix_frames(&pass);
+    *image = pass.image;
+    *target = pass.target;
+}
+
+/* ---- peak detection (hdr_update_peak :1183-1250) --------------------------------------------- */
+
+static void hdr_update_peak(struct pass_state *pass)
+{
+    const struct pl_render_params *params = pass->params;
+    pl_renderer rr = pass->rr;
+    if (!params->peak_detect_params || !pl_color_space_is_hdr(&pass->image.color))
+        goto cleanup;
+    if (rr->errors & PL_RENDER_ERR_PEAK_DETECT)
+        goto cleanup;
+    if (pass->fbofmt[4] && !(pass->fbofmt[4]->caps & PL_FMT_CAP_STORABLE))
+        goto cleanup;
+
+    float max_peak = pl_color_transfer_nominal_peak(pass->image.color.transfer) *
+                     PL_COLOR_SDR_WHITE;
+    if (pass->image.color.transfer == PL_COLOR_TRC_HLG)
+        max_peak = pass->img.color.hdr.max_luma;
+    if (max_peak <= pass->target.color.hdr.max_luma + 1e-6)
+        goto cleanup; // no adaptation needed
+    if (pass->img.color.hdr.avg_pq_y)
+        goto cleanup; // dynamic metadata already present
+
+    enum pl_hdr_metadata_type metadata = PL_HDR_METADATA_ANY;
+    if (params->color_map_params)
+        metadata = params->color_map_params->metadata;
+    if (metadata && metadata != PL_HDR_METADATA_CIE_Y)
+        goto cleanup; // measurement would be unused
+
+    const struct pl_color_map_params *cpars = params->color_map_params;
+    const bool uses_ootf = cpars && cpars->tone_mapping_function == &pl_tone_map_st2094_40;
+    if (uses_ootf && pass->img.color.hdr.ootf.num_anchors)
+        goto cleanup; // HDR10+ OOTF is being used
+
+    if (!pass->fbofmt[4] && !params->peak_detect_params->allow_delayed) {
+        RR_WARN(rr, "Disabling peak detection because `pl_peak_detect_params.allow_delayed` "
+                "is false, but lack of FBOs forces the result to be delayed.");
+        rr->errors |= PL_RENDER_ERR_PEAK_DETECT;
+        goto cleanup;
+    }
+
+    const bool ok = pl_shader_detect_peak(img_sh(pass, &pass->img), pass->img.color,
+                                          &rr->tone_map_state, params->peak_detect_params);
+    if (!ok) {
+        RR_WARN(rr, "Failed creating HDR peak detection shader.. disabling");
+        rr->errors |= PL_RENDER_ERR_PEAK_DETECT;
+        goto cleanup;
+    }
+    pass->need_peak_fbo = !params->peak_detect_params->allow_delayed;
+    return;
+
+cleanup:
+    pl_reset_detected_peak(rr->tone_map_state);
+}
+
+/* ---- pass_read_image (:1553-1960) ------------------------------------------------------------ */
+
+static bool plane_deband(struct pass_state *pass, struct img *img, const float neutral[3])
+{
+    const struct pl_render_params *params = pass->params;
+    pl_renderer rr = pass->rr;
+    if ((rr->errors & PL_RENDER_ERR_DEBANDING) || !params->deband_params || !pass->fbofmt[4])
+        return false;
+
+    struct pl_color_repr repr = img->repr;
+    struct pl_sample_src src = {
+        .tex = img_tex(pass, img),
+        .components = img->comps,
+        .scale = pl_color_repr_normalize(&repr),
+    };
+
+    // keep the grain intensity independent of the source's nominal peak (:1337-1342)
+    struct pl_deband_params dparams = *params->deband_params;
+    dparams.grain /= pass->image.color.hdr.max_luma / PL_COLOR_SDR_WHITE;
+    memcpy(dparams.grain_neutral, neutral, sizeof(dparams.grain_neutral));
+
+    img->tex = NULL;
+    img->sh = pl_dispatch_begin(rr->dp);
+    pl_shader_deband(img->sh, &src, &dparams);
+    img->err_msg = "Failed applying debanding... disabling!";
+    img->err_enum = PL_RENDER_ERR_DEBANDING;
+    img->err_tex = src.tex;
+    img->repr = repr;
+    return true;
+}
+
+static bool pass_read_image(struct pass_state *pass)
+{
+    const struct pl_render_params *params = pass->params;
+    struct pl_frame *image = &pass->image;
+    pl_renderer rr = pass->rr;
+    struct pl_plane plane = image->planes[0];
+
+    struct img pimg = {
+        .w = plane.texture->params.w,
+        .h = plane.texture->params.h,
+        .tex = plane.texture,
+        .repr = image->repr,
+        .color = image->color,
+        .comps = plane.components,
+    };
+
+    // an overridden alpha mode drops the alpha channel
+    if (image->repr.alpha == PL_ALPHA_NONE) {
+        for (int j = 0; j < plane.components; j++) {
+            if (plane.component_mapping[j] == PL_CHANNEL_A)
+                plane.component_mapping[j] = PL_CHANNEL_NONE;
+        }
+    }
+
+    const int bits = image->repr.bits.sample_depth;
+    const float out_scale = bits ? (1llu << bits) / ((1llu << bits) - 1.0f) : 1.0f;
+    float neutral_luma = 0.0, neutral_chroma = 0.5f * out_scale;
+    if (pl_color_levels_guess(&image->repr) == PL_COLOR_LEVELS_LIMITED)
+        neutral_luma = 16 / 256.0f * out_scale;
+    if (!pl_color_system_is_ycbcr_like(image->repr.sys))
+        neutral_chroma = neutral_luma;
+
+    pimg.rect = image->crop; // single reference plane: rrx = rry = 1, no shift
+
+    float neutral[3] = {0.0};
+    for (int c = 0, idx = 0; c < plane.components; c++) {
+        switch (plane.component_mapping[c]) {
+        case PL_CHANNEL_Y: neutral[idx++] = neutral_luma; break;
+        case PL_CHANNEL_U: // fall through
+        case PL_CHANNEL_V: neutral[idx++] = neutral_chroma; break;
+        }
+    }
+    plane_deband(pass, &pimg, neutral);
+
+    // Drop subpixel offsets from the ref rect and re-add them as part of `pass->img.rect`,
+    // always rounding towards 0; drop anamorphic subpixel mismatches (:1810-1828)
+    const pl_rect2df ref_rc = pimg.rect;
+    pl_rect2d ref_rounded;
+    ref_rounded.x0 = truncf(ref_rc.x0);
+    ref_rounded.y0 = truncf(ref_rc.y0);
+    ref_rounded.x1 = ref_rounded.x0 + roundf(pl_rect_w(ref_rc));
+    ref_rounded.y1 = ref_rounded.y0 + roundf(pl_rect_h(ref_rc));
+    const float off_x = ref_rc.x0 - ref_rounded.x0, off_y = ref_rc.y0 - ref_rounded.y0,
+                stretch_x = pl_rect_w(ref_rounded) / pl_rect_w(ref_rc),
+                stretch_y = pl_rect_h(ref_rounded) / pl_rect_h(ref_rc);
+
+    const float base_x = pimg.rect.x0 - off_x, base_y = pimg.rect.y0 - off_y;
+    struct pl_sample_src src = {
+        .components = plane.components,
+        .address_mode = plane.address_mode,
+        .scale      = pl_color_repr_normalize(&pimg.repr),
+        .new_w      = pl_rect_w(ref_rounded),
+        .new_h      = pl_rect_h(ref_rounded),
+        .rect = {
+            base_x, base_y,
+            base_x + stretch_x * pl_rect_w(pimg.rect),
+            base_y + stretch_y * pl_rect_h(pimg.rect),
+        },
+    };
+    if (plane.flipped) {
+        src.rect.y0 = plane.texture->params.h - src.rect.y0;
+        src.rect.y1 = plane.texture->params.h - src.rect.y1;
+    }
+
+    const bool unscaled = src.rect.x0 == 0 && src.rect.y0 == 0 &&
+                          src.rect.x1 == src.new_w && src.rect.y1 == src.new_h;
+    if (pimg.sh && pimg.w == src.new_w && pimg.h == src.new_h && unscaled) {
+        // image rects are already equal, no indirect scaling needed
+    } else {
+        src.tex = img_tex(pass, &pimg);
+        if (!src.tex)
+            return false;
+        pimg.tex = NULL;
+        pimg.sh = pl_dispatch_begin(rr->dp);
+        dispatch_sampler(pass, pimg.sh, &rr->sampler_src, SAMPLER_PLANE, &src);
+        pimg.err_enum |= PL_RENDER_ERR_SAMPLING;
+        pimg.rect.x0 = pimg.rect.y0 = 0.0f;
+        pimg.w = pimg.rect.x1 = src.new_w;
+        pimg.h = pimg.rect.y1 = src.new_h;
+        src.scale = 1.0;
+    }
+
+    // "pass_read_image": color = (neutral_luma, neutral_chroma x2, 1); tmp = scale * plane();
+    // color[mapping[c]] = tmp[c]                                                  (:1790-1890)
+    pl_shader sh = img_sh(pass, &pimg);
+    if (src.scale != 1.0f) {
+        struct plh_op *op = sh_op(sh, PLH_OP_SCALE);
+        if (!op)
+            return false;
+        op->f[0] = op->f[1] = op->f[2] = op->f[3] = src.scale;
+        sh_listf(sh, "scale(%g)\n", src.scale);
+    }
+    bool trivial = plane.components == 4;
+    for (int c = 0; c < plane.components; c++)
+        trivial &= plane.component_mapping[c] == c;
+    if (!trivial) {
+        struct plh_op *op = sh_op(sh, PLH_OP_PLANE_MAP);
+        if (!op)
+            return false;
+        op->f[0] = neutral_luma;
+        op->f[1] = op->f[2] = neutral_chroma;
+        op->f[3] = 1.0f;
+        op->i1 = plane.components;
+        op->i0 = 0;
+        for (int c = 0; c < 4; c++) {
+            const int m = c < plane.components ? plane.component_mapping[c] : -1;
+            op->i0 |= (m < 0 ? 0xff : m) << (8 * c);
+        }
+        sh_listf(sh, "plane_map(comps=%d, map=0x%08x, neutral=%g/%g)\n", plane.components,
+                 (unsigned) op->i0, neutral_luma, neutral_chroma);
+    }
+
+    pass->img = (struct img) {
+        .sh     = sh,
+        .w      = pl_rect_w(ref_rounded),
+        .h      = pl_rect_h(ref_rounded),
+        .repr   = pimg.repr,
+        .color  = image->color,
+        .comps  = pimg.repr.alpha == PL_ALPHA_NONE ? 3 : 4,
+        .rect   = { off_x, off_y, off_x + pl_rect_w(ref_rc), off_y + pl_rect_h(ref_rc) },
+        .err_msg = pimg.err_msg, .err_enum = pimg.err_enum, .err_tex = pimg.err_tex,
+    };
+    pass->ref_rect = pass->img.rect;
+
+    if (pass->img.repr.sys == PL_COLOR_SYSTEM_XYZ) {
+        pl_shader_linearize(sh, &pass->img.color);
+        pass->img.color.transfer = PL_COLOR_TRC_LINEAR;
+    }
+    pl_shader_decode_color(sh, &pass->img.repr, params->color_adjustment);
+
+    // pre-multiply alpha before the rest of the pipeline, to avoid bleeding colours from
+    // transparent regions into opaque ones
+    pl_shader_set_alpha(sh, &pass->img.repr, PL_ALPHA_PREMULTIPLIED);
+    return !pl_shader_is_failed(sh);
+}
+
+/* ---- pass_scale_main (:1964-2087) ------------------------------------------------------------- */
+
+static bool pass_scale_main(struct pass_state *pass)
+{
+    const struct pl_render_params *params = pass->params;
+    pl_renderer rr = pass->rr;
+    pl_fmt fbofmt = pass->fbofmt[pass->img.comps];
+    if (!fbofmt)
+        return true; // no FBOs: skip the main scaler
+
+    const pl_rect2df new_rect = {
+        .x1 = abs(pl_rect_w(pass->dst_rect)),
+        .y1 = abs(pl_rect_h(pass->dst_rect)),
+    };
+
+    struct img *img = &pass->img;
+    struct pl_sample_src src = {
+        .components = img->comps,
+        .new_w      = pl_rect_w(new_rect),
+        .new_h      = pl_rect_h(new_rect),
+        .rect       = img->rect,
+    };
+
+    const struct pl_frame *image = &pass->image;
+    bool need_fbo = false;
+
+    // force FBO indirection if this shader is non-resizable
+    int out_w, out_h;
+    if (img->sh && pl_shader_output_size(img->sh, &out_w, &out_h))
+        need_fbo |= out_w != src.new_w || out_h != src.new_h;
+
+    const struct sampler_info info = sample_src_info(pass, &src, SAMPLER_MAIN);
+    bool use_sigmoid = info.dir == SAMPLER_UP && params->sigmoid_params;
+    bool use_linear  = info.dir == SAMPLER_DOWN;
+
+    // opportunistically measure the peak here if that saves a pass
+    if (info.dir == SAMPLER_UP)
+        hdr_update_peak(pass);
+
+    if (info.dir == SAMPLER_NOOP && !need_fbo)
+        goto done; // no-op
+
+    if (info.type == SAMPLER_DIRECT && !need_fbo) {
+        // "free" sampling: the final pass samples the source at the output size
+        img->w = src.new_w;
+        img->h = src.new_h;
+        img->rect = new_rect;
+        goto done;
+    }
+
+    // hard-disable sigmoidization and linearization when required
+    if (params->disable_linear_scaling || fbofmt->component_depth[0] < 16)
+        use_sigmoid = use_linear = false;
+
+    // sigmoidization clips to [0,1]: not for HDR; linear HDR needs a float FBO
+    if (pl_color_space_is_hdr(&img->color)) {
+        use_sigmoid = false;
+        if (fbofmt->type != PL_FMT_FLOAT)
+            use_linear = false;
+    }
+
+    if (!(use_linear || use_sigmoid) && img->color.transfer == PL_COLOR_TRC_LINEAR) {
+        img->color.transfer = image->color.transfer;
+        if (image->color.transfer == PL_COLOR_TRC_LINEAR)
+            img->color.transfer = PL_COLOR_TRC_GAMMA22; // arbitrary fallback
+        pl_shader_delinearize(img_sh(pass, img), &img->color);
+    }
+
+    if (use_linear || use_sigmoid) {
+        pl_shader_linearize(img_sh(pass, img), &img->color);
+        img->color.transfer = PL_COLOR_TRC_LINEAR;
+    }
+    if (use_sigmoid)
+        pl_shader_sigmoidize(img_sh(pass, img), params->sigmoid_params);
+
+    // ---- PASS A: everything recorded so far lands in an FBO ----
+    src.tex = img_tex(pass, img);
+    if (!src.tex)
+        return false;
+    pass->need_peak_fbo = false;
+
+    pl_shader sh = pl_dispatch_begin(rr->dp);
+    dispatch_sampler(pass, sh, &rr->sampler_main, SAMPLER_MAIN, &src);
+    img->tex  = NULL;
+    img->sh   = sh;
+    img->w    = src.new_w;
+    img->h    = src.new_h;
+    img->rect = new_rect;
+
+    if (use_sigmoid)
+        pl_shader_unsigmoidize(img_sh(pass, img), params->sigmoid_params);
+
+done:
+    if (info.dir != SAMPLER_UP)
+        hdr_update_peak(pass);
+    return true;
+}
+
+/* ---- pass_convert_colors (:2157-2280) ---------------------------------------------------------- */
+
+static void pass_convert_colors(struct pass_state *pass)
+{
+    const struct pl_render_params *params = pass->params;
+    const struct pl_frame *image = &pass->image, *target = &pass->target;
+    pl_renderer rr = pass->rr;
+    struct img *img = &pass->img;
+    pl_shader sh = img_sh(pass, img);
+
+    bool prelinearized = false;
+    if (img->color.transfer == PL_COLOR_TRC_LINEAR) {
+        if (img->repr.alpha == PL_ALPHA_PREMULTIPLIED) {
+            // prelinearization happened with premultiplied alpha, colour mapping wants
+            // independent alpha: go back to the non-linear representation *before* the alpha
+            // mode conversion, to avoid distortion
+            img->color.transfer = image->color.transfer;
+            pl_shader_delinearize(sh, &img->color);
+        } else {
+            prelinearized = true;
+        }
+    } else if (img->color.transfer != image->color.transfer) {
+        if (image->color.transfer == PL_COLOR_TRC_LINEAR) {
+            pl_shader_linearize(sh, &img->color);
+            img->color.transfer = PL_COLOR_TRC_LINEAR;
+        }
+    }
+
+    // all processing in independent alpha, to avoid nonlinear distortions
+    pl_shader_set_alpha(sh, &img->repr, PL_ALPHA_INDEPENDENT);
+
+    // ---- PASS B: a same-frame peak measurement must finish before it is consumed ----
+    if (pass->need_peak_fbo && !img_tex(pass, img))
+        return;
+    sh = img_sh(pass, img);
+
+    pl_shader_color_map_ex(sh, params->color_map_params, pl_color_map_args(
+        .src           = image->color,
+        .dst           = target->color,
+        .prelinearized = prelinearized,
+        .state         = &rr->tone_map_state,
+    ));
+    img->color = target->color;
+}
+
+/* ---- pass_output_target (:2586-2960) ------------------------------------------------------------ */
+
+// sRGB background colour -> target colour space (translate_srgb_color :2557-2584)
+static void translate_srgb_color(float out[3], const float in[3], const struct pl_color_space *csp)
+{
+    memcpy(out, in, 3 * sizeof(float));
+    if (csp->primaries == PL_COLOR_PRIM_BT_709 && csp->transfer == PL_COLOR_TRC_SRGB)
+        return;
+    struct pl_color_space srgb = pl_color_space_srgb;
+    pl_color_linearize(&srgb, out);
+    if (csp->primaries != PL_COLOR_PRIM_BT_709) {
+        const pl_matrix3x3 m = pl_get_color_mapping_matrix(
+            pl_raw_primaries_get(PL_COLOR_PRIM_BT_709), pl_raw_primaries_get(csp->primaries),
+            PL_INTENT_RELATIVE_COLORIMETRIC);
+        pl_matrix3x3_apply(&m, out);
+    }
+    pl_color_delinearize(csp, out);
+}
+
+static void record_swizzle(pl_shader sh, int comps, const int mapping[4])
+{
+    // swizzle_color (:791-808): color = (0,0,0,1); color[c] = orig[mapping[c]]
+    bool trivial = comps == 4;
+    for (int c = 0; c < comps; c++)
+        trivial &= mapping[c] == c;
+    if (trivial)
+        return;
+    struct plh_op *op = sh_op(sh, PLH_OP_SWIZZLE);
+    if (!op)
+        return;
+    op->i1 = comps;
+    op->i0 = 0;
+    for (int c = 0; c < 4; c++) {
+        const int m = c < comps ? mapping[c] : -1;
+        op->i0 |= (m < 0 ? 0xff : m) << (8 * c);
+    }
+    sh_listf(sh, "swizzle(comps=%d, map=0x%08x)\n", comps, (unsigned) op->i0);
+}
+
+// Returns true if error diffusion was performed (pass_error_diffusion :2282-2344)
+static bool pass_error_diffusion(struct pass_state *pass, pl_shader *sh, int new_depth,
+                                 int comps, int out_w, int out_h)
+{
+    const struct pl_render_params *params = pass->params;
+    pl_renderer rr = pass->rr;
+    if (!params->error_diffusion || (rr->errors & PL_RENDER_ERR_ERROR_DIFFUSION))
+        return false;
+
+    const size_t shmem_req = pl_error_diffusion_shmem_req(params->error_diffusion, out_h);
+    if (shmem_req > rr->gpu->glsl.max_shmem_size)
+        return false;
+
+    pl_fmt fmt = pass->fbofmt[comps];
+    if (!fmt || !(fmt->caps & PL_FMT_CAP_STORABLE)) {
+        RR_ERR(rr, "Error diffusion requires storable FBOs.. disabling!");
+        goto error;
+    }
+
+    struct pl_error_diffusion_params edpars = {
+        .new_depth = new_depth,
+        .kernel = params->error_diffusion,
+    };
+    edpars.input_tex = get_fbo(pass, out_w, out_h, fmt, comps);
+    edpars.output_tex = get_fbo(pass, out_w, out_h, fmt, comps);
+    if (!edpars.input_tex || !edpars.output_tex)
+        goto error;
+
+    pl_shader dsh = pl_dispatch_begin(rr->dp);
+    if (!pl_shader_error_diffusion(dsh, &edpars)) {
+        pl_dispatch_abort(rr->dp, &dsh);
+        goto error;
+    }
+
+    bool ok = pl_dispatch_finish(rr->dp, pl_dispatch_params(
+        .shader = sh,
+        .target = edpars.input_tex,
+    ));
+    if (ok) {
+        ok = pl_dispatch_compute(rr->dp, pl_dispatch_compute_params(
+            .shader = &dsh,
+            .dispatch_size = {1, 1, 1},
+        ));
+    } else {
+        pl_dispatch_abort(rr->dp, &dsh);
+    }
+
+    *sh = pl_dispatch_begin(rr->dp);
+    pl_shader_sample_direct(*sh, pl_sample_src(
+        .tex = ok ? edpars.output_tex : edpars.input_tex,
+    ));
+    return ok;
+
+error:
+    rr->errors |= PL_RENDER_ERR_ERROR_DIFFUSION;
+    return false;
+}
+
+static bool pass_output_target(struct pass_state *pass)
+{
+    const struct pl_render_params *params = pass->params;
+    const struct pl_frame *target = &pass->target;
+    const struct pl_plane *plane = &target->planes[0];
+    pl_renderer rr = pass->rr;
+    struct img *img = &pass->img;
+    pl_shader sh = img_sh(pass, img);
+    const pl_rect2d dst_rect = pass->dst_rect;
+    const bool need_clear = pl_frame_is_cropped(target);
+
+    enum pl_clear_mode background = params->background;
+    if (background == PL_CLEAR_TILES || background == PL_CLEAR_BLUR)
+        background = PL_CLEAR_COLOR; // (unsupported modes degrade to a plain colour)
+
+    // avoid an unnecessary round trip through premultiplied alpha
+    const bool has_alpha = target->repr.alpha != PL_ALPHA_NONE;
+    if (params->background_transparency >= 1.0 && has_alpha)
+        background = PL_CLEAR_SKIP;
+
+    const bool need_blend = background != PL_CLEAR_SKIP || !has_alpha;
+    if (img->comps == 4 && need_blend) {
+        pl_shader_set_alpha(sh, &img->repr, PL_ALPHA_PREMULTIPLIED);
+        if (background == PL_CLEAR_COLOR) {
+            float bg[3];
+            translate_srgb_color(bg, params->background_color, &target->color);
+            struct plh_op *op = sh_op(sh, PLH_OP_BLEND_BG);
+            if (!op)
+                return false;
+            op->f[0] = bg[0]; op->f[1] = bg[1]; op->f[2] = bg[2];
+            op->f[3] = 1.0 - params->background_transparency;
+            sh_listf(sh, "blend_background(%g %g %g %g)\n", bg[0], bg[1], bg[2], op->f[3]);
+            if (!params->background_transparency || !has_alpha) {
+                img->repr.alpha = PL_ALPHA_NONE;
+                img->comps = 3;
+            }
+        }
+    }
+
+    // the colour scale is applied separately, after encoding, so that an intermediate FBO
+    // (error diffusion) has the right precision
+    struct pl_color_repr repr = target->repr;
+    const float scale = pl_color_repr_normalize(&repr);
+
+    // don't double-apply an alpha mode that is already in effect
+    if (img->repr.alpha == repr.alpha || img->comps < 4) {
+        repr.alpha = PL_ALPHA_NONE;
+    } else {
+        pl_shader_set_alpha(sh, &img->repr, PL_ALPHA_INDEPENDENT);
+    }
+
+    pl_shader_encode_color(sh, &repr);
+    if (repr.sys == PL_COLOR_SYSTEM_XYZ) {
+        img->color.transfer = PL_COLOR_TRC_ST428;
+        pl_shader_delinearize(sh, &img->color);
+    }
+
+    const bool flipped_x = dst_rect.x1 < dst_rect.x0, flipped_y = dst_rect.y1 < dst_rect.y0;
+
+    if (need_clear && params->border != PL_CLEAR_SKIP) {
+        // clear_target (:2410-2555), PL_CLEAR_COLOR flavour
+        float bg[3], clear[4];
+        translate_srgb_color(bg, params->background_color, &target->color);
+        float enc[3] = { bg[0], bg[1], bg[2] };
+        struct pl_color_repr crepr = target->repr;
+        pl_transform3x3 tr = pl_color_repr_decode(&crepr, NULL);
+        pl_transform3x3_invert(&tr);
+        pl_transform3x3_apply(&tr, enc);
+        const float alpha = 1.0 - params->background_transparency;
+        const int *map = plane->component_mapping;
+        for (int c = 0; c < 4; c++) {
+            const int m = c < plane->components ? map[c] : -1;
+            clear[c] = m == PL_CHANNEL_A ? alpha : m >= 0 && m < 3 ? enc[m] / scale : 0.0f;
+        }
+        pl_tex_clear(rr->gpu, plane->texture, clear);
+    }
+
+    pl_rect2df plane_rectf = { dst_rect.x0, dst_rect.y0, dst_rect.x1, dst_rect.y1 };
+    pl_rect2df_normalize(&plane_rectf);
+    const int rx0 = floorf(plane_rectf.x0), ry0 = floorf(plane_rectf.y0),
+              rx1 =  ceilf(plane_rectf.x1), ry1 =  ceilf(plane_rectf.y1);
+
+    img->sh = NULL;
+
+    // > 16-bit outputs are not dithered by default (:2884-2900)
+    const int depth = target->repr.bits.color_depth;
+    int applied_dither = 0;
+    if (depth && (depth < 16 || params->force_dither)) {
+        if (pass_error_diffusion(pass, &sh, depth, plane->components, rx1 - rx0, ry1 - ry0)) {
+            applied_dither = depth;
+        } else if (params->dither_params) {
+            struct pl_dither_params dparams = *params->dither_params;
+            if (!params->disable_dither_gamma_correction)
+                dparams.transfer = target->color.transfer;
+            pl_shader_dither(sh, depth, &rr->dither_state, &dparams);
+            applied_dither = depth;
+        }
+    }
+    if (applied_dither != rr->prev_dither) {
+        if (applied_dither) {
+            RR_INFO(rr, "Dithering to %d bit depth", applied_dither);
+        } else {
+            RR_INFO(rr, "Dithering disabled");
+        }
+        rr->prev_dither = applied_dither;
+    }
+
+    // color *= 1 / scale                                                              (:2911)
+    struct plh_op *op = sh_op(sh, PLH_OP_SCALE);
+    if (!op) {
+        pl_dispatch_abort(rr->dp, &sh);
+        return false;
+    }
+    op->f[0] = op->f[1] = op->f[2] = op->f[3] = 1.0f / scale;
+    sh_listf(sh, "scale(1/%g)\n", scale);
+
+    record_swizzle(sh, plane->components, plane->component_mapping);
+
+    pl_rect2d plane_rect = {
+        .x0 = flipped_x ? rx1 : rx0,
+        .x1 = flipped_x ? rx0 : rx1,
+        .y0 = flipped_y ? ry1 : ry0,
+        .y1 = flipped_y ? ry0 : ry1,
+    };
+    if (plane->flipped) {
+        const int plane_h = plane->texture->params.h;
+        plane_rect.y0 = plane_h - plane_rect.y0;
+        plane_rect.y1 = plane_h - plane_rect.y1;
+    }
+
+    const bool ok = pl_dispatch_finish(rr->dp, pl_dispatch_params(
+        .shader = &sh,
+        .target = plane->texture,
+        .rect = plane_rect,
+    ));
+    *img = (struct img) {0};
+    return ok;
+}
+
+/* ---- entry point (:3433-3480) --------------------------------------------------------------------- */
+
+static void pass_uninit(struct pass_state *pass)
+{
+    pl_renderer rr = pass->rr;
+    pl_dispatch_abort(rr->dp, &pass->img.sh);
+    if (pass->acquired_image && pass->image.release)
+        pass->image.release(rr->gpu, &pass->image);
+    if (pass->acquired_target && pass->target.release)
+        pass->target.release(rr->gpu, &pass->target);
+}
+
+static bool unsupported(pl_renderer rr, const struct pl_render_params *p)
+{
+    if (p->cone_params || p->blend_params || p->deinterlace_params || p->distort_params ||
+        p->num_hooks || p->lut || p->frame_mixer)
+    {
+        RR_ERR(rr, "pl_render_params requests a stage outside this backend's hot path "
+               "(cone / blend / deinterlace / distort / hooks / LUT / frame mixing)");
+        return true;
+    }
+    return false;
+}
+
+bool pl_render_image(pl_renderer rr, const struct pl_frame *pimage, const struct pl_frame *ptarget,
+                     const struct pl_render_params *params)
+{
+    params = PL_DEF(params, &pl_render_default_params);
+    if (!pimage || !ptarget) {
+        RR_ERR(rr, "pl_render_image: image and target are required (overlay-only rendering is "
+               "not supported)");
+        return false;
+    }
+    if (unsupported(rr, params))
+        return false;
+
+    struct pass_state pass = {
+        .rr = rr,
+        .params = params,
+        .image = *pimage,
+        .target = *ptarget,
+    };
+
+    if (pass.target.acquire) {
+        if (!pass.target.acquire(rr->gpu, &pass.target))
+            return false;
+        pass.acquired_target = true;
+    }
+    if (pass.image.acquire) {
+        if (!pass.image.acquire(rr->gpu, &pass.image)) {
+            pass_uninit(&pass);
+            return false;
+        }
+        pass.acquired_image = true;
+    }
+    if (!validate_frame(rr, &pass.image, "Image", false) ||
+        !validate_frame(rr, &pass.target, "Target", true))
+    {
+        pass_uninit(&pass);
+        return false;
+    }
+
+    find_fbo_format(&pass);
+    pass_fix_frames(&pass);
+
+    // no-op (empty crop)
+    if (!pl_rect_w(pass.dst_rect) || !pl_rect_h(pass.dst_rect)) {
+        pass_uninit(&pass);
+        return true;
+    }
+
+    pl_dispatch_reset_frame(rr->dp);
+    if (!pass_read_image(&pass))
+        goto error;
+    if (!pass_scale_main(&pass))
+        goto error;
+    pass_convert_colors(&pass);
+    if (!pass.img.sh && !pass.img.tex)
+        goto error;
+    if (!pass_output_target(&pass))
+        goto error;
+
+    pass_uninit(&pass);
+    return true;
+
+error:
+    RR_ERR(rr, "Failed rendering image!");
+    pass_uninit(&pass);
+    return false;
+}
+
+/* Test hook: record `color *= s` the way pass_output_target does (there is no public
+ * pl_shader_* entry point for it); used by tests/test_gpu_renderer.py to rebuild the
+ * renderer's passes by hand. */
+PL_API void plh_test_op_scale(pl_shader sh, float s);
+void plh_test_op_scale(pl_shader sh, float s)
+{
+    struct plh_op *op = sh_op(sh, PLH_OP_SCALE);
+    if (op)
+        op->f[0] = op->f[1] = op->f[2] = op->f[3] = s;
+}

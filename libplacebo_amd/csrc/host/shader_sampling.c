@@ -100,15 +100,17 @@ static bool sample_simple(pl_shader sh, const struct pl_sample_src *src, enum fi
     struct src_info info;
     if (!setup_src(sh, src, &info, true, req))
         return false;
-    // 1:1 sampling on the texel grid (what img_sh()/PASS A does): a texture unit
-    // returns the texel itself there (its fixed-point lerp weights snap to 0),
-    // whereas an exact fp32 lerp would blend in ~1e-5 of a neighbour from the
-    // rounding noise in `pos`. Lower such identity fetches to nearest.
-    const bool identity = fabsf(info.ratio_x - 1.0f) < 1e-6f && fabsf(info.ratio_y - 1.0f) < 1e-6f &&
-                          src->rect.x0 == truncf(src->rect.x0) &&
-                          src->rect.y0 == truncf(src->rect.y0);
-    sh->pass.s.type = info.linear && !identity ? PLH_SAMPLE_BILINEAR : PLH_SAMPLE_NEAREST;
-    info.linear &= !identity;
+    // 1:1 sampling on the texel grid (what img_sh()/PASS A does): a texture unit returns the
+    // texel itself there (its fixed-point lerp weights snap to 0), whereas an exact fp32 lerp
+    // would blend in ~1e-5 of a neighbour from the rounding noise in `pos`. Such identity
+    // fetches are lowered to nearest - by the dispatch, because these shaders are resizable
+    // and only the final output size tells whether the fetch is 1:1 (dispatch.c here).
+    sh->pass.s.type = info.linear ? PLH_SAMPLE_BILINEAR : PLH_SAMPLE_NEAREST;
+    float rw = pl_rect_w(src->rect), rh = pl_rect_h(src->rect);
+    sh->pass.s.rect_w = fabsf(PL_DEF(rw, (float) src->tex->params.w));
+    sh->pass.s.rect_h = fabsf(PL_DEF(rh, (float) src->tex->params.h));
+    sh->pass.s.rect_on_grid = src->rect.x0 == truncf(src->rect.x0) &&
+                              src->rect.y0 == truncf(src->rect.y0);
     if (desc)
         sh_describef(sh, "%s", desc);
     sh_listf(sh, "sample_%s(tex=%dx%d %s, scale=%g)\n", info.linear ? "bilinear" : "nearest",

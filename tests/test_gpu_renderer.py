@@ -1,0 +1,257 @@
+"""pl_render_image against (a) the oracle composed stage by stage the way renderer.c composes
+them, where every stage is transcendental-free (bit-exact), and (b) the same pipeline recorded
+by hand through the pl_shader_* API (the renderer must add nothing but glue)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import libplacebo_amd as pl
+import orc
+import util
+from libplacebo_amd import _capi as capi
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture()
+def rr(gpu):
+    r = pl.Renderer(gpu)
+    yield r
+    r.destroy()
+
+
+def normalize(repr_):
+    """pl_color_repr_normalize (pinned against the reference in test_tier0_ref.py)"""
+    fn = pl.lib().pl_color_repr_normalize
+    fn.restype = C.c_float
+    return fn(C.byref(repr_))
+
+
+def test_cfg2_bilinear_free_sampling_bit_exact(gpu, rr):
+    """BASELINE cfg 2: 2x bilinear upscale, sRGB -> sRGB passthrough. One pass: the source is
+    sampled at the output size in the final pass (renderer.c:2025-2031)."""
+    sw, sh = 96, 54
+    img = util.chirp_rgba16(sw, sh)
+    src = gpu.tex_create(sw, sh, "rgba16", img)
+    dst = gpu.tex_create(2 * sw, 2 * sh, "rgba16")
+    image = pl.frame(src, components=3)
+    target = pl.frame(dst, components=4, mapping=[0, 1, 2, 3])
+    assert rr.render(image, target, pl.render_params("fast")), gpu.messages[-4:]
+    assert rr.errors() == 0
+    got = dst.download()
+    ref = orc.sample_simple(orc.tex_decode(img, "rgba16"), orc.S_BILINEAR, 2 * sw, 2 * sh)
+    ref[..., 3] = 1.0   # 3-component image: alpha is not sampled
+    ref16 = orc.tex_encode(ref, "rgba16")
+    assert np.array_equal(got, ref16), util.diff_stats(got, ref16)
+    src.destroy(); dst.destroy()
+
+
+def test_cfg3_ewa_upscale_dither10_bit_exact(gpu, rr):
+    """BASELINE cfg 3: EWA-Lanczos 2x upscale + blue-noise dither to 10 bit in a 16-bit target.
+    Pass structure (renderer.c:2064): PASS A (plane -> rgba16hf FBO), polar + dither + 1/scale."""
+    sw, sh = 96, 64
+    img = util.chirp_rgba16(sw, sh)
+    src = gpu.tex_create(sw, sh, "rgba16", img)
+    dst = gpu.tex_create(2 * sw, 2 * sh, "rgba16")
+    image = pl.frame(src, components=3)
+    target = pl.frame(dst, repr_=pl.color_repr("rgb", "full", sample_depth=16, color_depth=10,
+                                                bit_shift=6))
+    params = pl.render_params("fast", upscaler=pl.filter_config("ewa_lanczos"),
+                              dither_params=capi.DitherParams(method=pl.DITHER_BLUE_NOISE,
+                                                              lut_size=6, transfer=0),
+                              disable_dither_gamma_correction=True)
+    util.srand(1)   # blue noise generation draws from rand()
+    assert rr.render(image, target, params), gpu.messages[-4:]
+    assert rr.errors() == 0
+    got = dst.download()
+
+    tex = orc.tex_decode(img, "rgba16")
+    a = orc.sample_simple(tex, orc.S_BILINEAR, sw, sh)      # identity fetch -> nearest
+    a[..., 3] = 1.0
+    a = orc.op_quant_f16(a)                                 # rgb16hf FBO (4 comps, alpha = 1)
+    w, r, rz = orc.filter_generate_polar(orc.ewa_lanczos())
+    out = orc.sample_polar(a, w, r, rz, 2 * sw, 2 * sh, mask=0x7)
+    orc.dither(out, util.blue_noise(pl), 10)
+    # color *= 1/scale: 10 bits in a 16-bit container, shifted left by 6
+    scale = np.float32(normalize(pl.color_repr("rgb", "full", sample_depth=16, color_depth=10,
+                                               bit_shift=6)))
+    out[..., :] = out * (np.float32(1.0) / scale)
+    ref16 = orc.tex_encode(out, "rgba16")
+    d = np.abs(got.astype(np.int64) - ref16.astype(np.int64))
+    assert np.array_equal(got[..., :3], ref16[..., :3]), (int(d.max()), int((d > 0).sum()))
+    # the codes are 10-bit values shifted into the container
+    r = got[..., :3] % 64       # (+-1: `k/1023 * (1/scale)` is not exact in fp32)
+    assert np.all((r <= 1) | (r >= 63))
+    src.destroy(); dst.destroy()
+
+
+def test_default_params_match_manual_composition(gpu, rr):
+    """pl_render_default_params (lanczos ortho upscale with sigmoidization, dither) against the
+    same passes recorded by hand. Must be identical: the renderer is glue."""
+    sw, sh, dw, dh = 64, 48, 160, 100
+    img = util.chirp_rgba16(sw, sh)
+    src = gpu.tex_create(sw, sh, "rgba16", img)
+    dst = gpu.tex_create(dw, dh, "rgba16")
+    csp = pl.color_space("bt709", "bt1886")
+    image = pl.frame(src, components=3, color=csp)
+    target = pl.frame(dst, color=csp,
+                      repr_=pl.color_repr("rgb", "full", sample_depth=16, color_depth=8,
+                                          bit_shift=8))
+    util.srand(1)
+    assert rr.render(image, target, pl.render_params("default")), gpu.messages[-4:]
+    assert rr.errors() == 0
+    got = dst.download()
+
+    # by hand
+    lib = pl.lib()
+    fbo_a = gpu.tex_create(sw, sh, "rgba16hf")
+    fbo_v = gpu.tex_create(sw, dh, "rgba16hf")
+    out = gpu.tex_create(dw, dh, "rgba16")
+    csp_i = pl.color_space("bt709", "bt1886")
+    lib.pl_color_space_infer(C.byref(csp_i))
+    a = gpu.begin()
+    assert a.sample("direct", src, components=3)
+    a.linearize(csp_i)
+    a.sigmoidize()
+    assert a.finish(fbo_a)
+    lut, ds = pl.ShaderObj(), pl.ShaderObj()
+    cfg = pl.filter_config("lanczos")
+    v = gpu.begin()
+    assert v.sample_ortho(fbo_a, cfg, lut, new_w=sw, new_h=dh, components=3)
+    assert v.finish(fbo_v)
+    h = gpu.begin()
+    assert h.sample_ortho(fbo_v, cfg, lut, new_w=dw, new_h=dh, components=3)
+    h.sigmoidize(inverse=True)
+    h.delinearize(csp_i)
+    util.srand(1)
+    h.dither(8, ds, transfer=pl.TRC["bt1886"])
+    scale = np.float32(normalize(pl.color_repr("rgb", "full", sample_depth=16, color_depth=8,
+                                               bit_shift=8)))
+    op_scale(h, float(np.float32(1.0) / scale))
+    assert h.finish(out)
+    ref = out.download()
+    assert np.array_equal(got, ref), util.diff_stats(got, ref)
+    for t in (src, dst, fbo_a, fbo_v, out):
+        t.destroy()
+    lut.destroy(); ds.destroy()
+
+
+def op_scale(sh, s):
+    """color *= s, as the renderer's `color *= 1/scale` (no public API for it)."""
+    pl.lib().plh_test_op_scale.argtypes = [C.c_void_p, C.c_float]
+    pl.lib().plh_test_op_scale(sh.sh, C.c_float(s))
+
+
+def test_hdr10_to_sdr_peak_detect_and_tone_map(gpu, rr):
+    """BASELINE cfg 4: PQ/BT.2020 -> BT.709 SDR with same-frame peak detection. The renderer
+    must (1) run the detection pass into an FBO, (2) consume the measurement in the same frame,
+    (3) agree with the hand-recorded passes."""
+    from test_gpu_color import hdr_test_frame
+    w, h = 64, 48
+    img16 = (hdr_test_frame(w, h) * 65535 + 0.5).astype(np.uint16)
+    src = gpu.tex_create(w, h, "rgba16", img16)
+    dst = gpu.tex_create(w, h, "rgba16")
+    hdr = pl.color_space("bt2020", "pq", max_luma=4000.0)
+    sdr = pl.color_space("bt709", "bt1886")
+    image = pl.frame(src, components=3, color=hdr)
+    target = pl.frame(dst, color=sdr)
+    params = pl.render_params("default", dither_params=None)
+    assert rr.render(image, target, params), gpu.messages[-4:]
+    assert rr.errors() == 0
+    got = dst.download()
+    meta = capi.HdrMetadata()
+    assert pl.lib().pl_renderer_get_hdr_metadata(rr.rr, C.byref(meta))
+    assert 0.5 < meta.max_pq_y < 0.76 and 0.0 < meta.avg_pq_y < meta.max_pq_y
+
+    # by hand: detect into an FBO, then map with the shared state
+    fbo = gpu.tex_create(w, h, "rgba16hf")
+    out = gpu.tex_create(w, h, "rgba16")
+    state = pl.ShaderObj()
+    hdr_i, sdr_i = pl.color_space("bt2020", "pq", max_luma=4000.0), pl.color_space("bt709", "bt1886")
+    pl.lib().pl_color_space_infer_map(C.byref(hdr_i), C.byref(sdr_i))
+    a = gpu.begin()
+    assert a.sample("direct", src, components=3)
+    assert a.detect_peak(hdr_i, state)
+    assert a.finish(fbo)
+    b = gpu.begin()
+    assert b.sample("direct", fbo)
+    b.color_map(hdr_i, sdr_i, state, None)
+    op_scale(b, 1.0)
+    assert b.finish(out)
+    ref = out.download()
+    assert np.array_equal(got, ref), util.diff_stats(got, ref)
+    assert 0.02 < orc.tex_decode(got, "rgba16")[..., :3].mean() < 0.9
+    for t in (src, dst, fbo, out):
+        t.destroy()
+    state.destroy()
+
+
+def test_crop_flip_and_border_clear(gpu, rr):
+    sw, sh = 64, 48
+    img = util.random_rgba16(sw, sh, seed=5)
+    src = gpu.tex_create(sw, sh, "rgba16", img)
+    dst = gpu.tex_create(100, 80, "rgba16", np.full((80, 100, 4), 1234, np.uint16))
+    image = pl.frame(src, crop=(8, 4, 40, 36), components=3)   # (alpha would be blended)
+    # flipped horizontally, 32x32 -> 32x32 region at (10, 20)
+    target = pl.frame(dst, crop=(42, 20, 10, 52))
+    params = pl.render_params("fast")
+    assert rr.render(image, target, params), gpu.messages[-4:]
+    got = dst.download()
+    ref = np.zeros((80, 100, 4), np.uint16)
+    ref[..., 3] = 65535     # border: black, opaque
+    ref[20:52, 10:42] = img[4:36, 8:40][:, ::-1]
+    ref[..., 3] = 65535
+    assert np.array_equal(got, ref), util.diff_stats(got, ref)
+    src.destroy(); dst.destroy()
+
+
+def test_rejects_what_it_does_not_do(gpu, rr):
+    t = gpu.tex_create(16, 16, "rgba16")
+    f = pl.frame(t)
+    f2 = pl.frame(t)
+    f2.num_planes = 2
+    assert not rr.render(f2, f, pl.render_params("fast"))
+    f3 = pl.frame(t)
+    f3.rotation = 1
+    assert not rr.render(f3, f, pl.render_params("fast"))
+    t.destroy()
+
+
+def test_alpha_is_blended_against_the_background(gpu, rr):
+    """An image with (independent) alpha rendered to an opaque target: premultiply, blend against
+    the background colour (renderer.c:2717-2728), alpha becomes 1."""
+    w, h = 32, 16
+    img = util.random_rgba16(w, h, seed=9)
+    src = gpu.tex_create(w, h, "rgba16", img)
+    dst = gpu.tex_create(w, h, "rgba32f")
+    image = pl.frame(src, repr_=pl.color_repr("rgb", "full", alpha="independent"))
+    target = pl.frame(dst, components=3)
+    params = pl.render_params("fast")
+    params.background_color = (C.c_float * 3)(0.0, 0.0, 0.0)
+    assert rr.render(image, target, params), gpu.messages[-4:]
+    got = dst.download()
+    t = orc.tex_decode(img, "rgba16")
+    ref = t.copy()
+    ref[..., :3] = t[..., :3] * t[..., 3:4]     # premultiply; background is black
+    ref[..., 3] = 1.0
+    assert np.abs(got - ref).max() <= 1e-6
+    src.destroy(); dst.destroy()
+
+
+def test_hq_params_polar_deband_runs_clean(gpu, rr):
+    """pl_render_high_quality_params: deband + EWA (ewa_lanczossharp) + sigmoid + dither, all
+    stages enabled, no stage may get disabled."""
+    sw, sh = 80, 60
+    src = gpu.tex_create(sw, sh, "rgba16", util.chirp_rgba16(sw, sh))
+    dst = gpu.tex_create(200, 150, "rgba16")
+    image = pl.frame(src, components=3, color=pl.color_space("bt709", "bt1886"))
+    target = pl.frame(dst, color=pl.color_space("bt709", "bt1886"),
+                      repr_=pl.color_repr("rgb", "full", sample_depth=16, color_depth=10,
+                                          bit_shift=6))
+    for _ in range(2):
+        assert rr.render(image, target, pl.render_params("high_quality")), gpu.messages[-4:]
+    assert rr.errors() == 0
+    got = orc.tex_decode(dst.download(), "rgba16")
+    assert 0.2 < got[..., :3].mean() < 0.8
+    src.destroy(); dst.destroy()
