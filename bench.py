@@ -1,19 +1,28 @@
 #!/usr/bin/env python3
 """bench.py — throughput of the pl_render_image hot path on MI355X.
 
-Contract (see the task statement): `python bench.py --gpus N --steps K --warmup W`
-prints ONE JSON line on rank 0. A "step" is one frame through the hot path on
-synthetic input that is already resident in HBM.
+Contract (see the task statement): `python bench.py --gpus N --steps K --warmup W` prints ONE
+JSON line on rank 0. A "step" is one frame through `pl_render_image` on synthetic input that is
+already resident in HBM.
 
-Default workload (BASELINE.json configs[2], the one the north-star target is
-quoted on): 1920x1080 RGBA16 -> 3840x2160, EWA-Lanczos (Jinc) polar upscale +
-blue-noise dither to 10 bit, written as RGBA16. Frames rotate over a pool of
-source/target textures larger than the 256 MiB Infinity Cache so that every
-frame's compulsory traffic really crosses HBM.
+Workloads (BASELINE.json `configs`):
+  ewa_lanczos_1080p_to_4k_dither10   configs[2], the default: the configuration the north-star
+        target (">= 70 % of HBM roofline on EWA-Lanczos 1080p->4K") and the metric are quoted on.
+        1920x1080 RGBA16 -> 3840x2160, EWA-Lanczos (Jinc) polar upscale + blue-noise dither to
+        10 bit in an RGBA16 target. Passes: plane -> rgba16hf FBO (the reference's PASS A,
+        renderer.c:2064), polar + dither + store.
+  bilinear_1080p_to_4k               configs[1]: bilinear + sRGB passthrough, one pass.
+  hdr10_4k_tonemap                   configs[3]: 4K BT.2020/PQ -> BT.709 SDR, same-frame peak
+        detection (histogram) + spline tone mapping + perceptual gamut mapping 3D-LUT.
+  ewa_8k_to_4k_deband_tonemap        configs[4], one stream: 8K HDR -> 4K SDR, deband + EWA
+        downscale + tone map.
 
-Multi-GPU (--gpus N>1, launched by torch.distributed.run): streams are
-independent, one per GPU, no data-path collective -> weak
-scaling; value = frames of all ranks / max-over-ranks time.
+Frames rotate over a pool of source/target textures larger than the 256 MiB Infinity Cache so
+that every frame's compulsory traffic really crosses HBM.
+
+Multi-GPU (--gpus N>1, launched by torch.distributed.run): streams are independent, one per
+GPU, no data-path collective -> weak scaling; value = frames of all ranks /
+max-over-ranks time.
 """
 import argparse
 import ctypes as C
@@ -29,95 +38,136 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 import libplacebo_amd as pl  # noqa: E402
+from libplacebo_amd import _capi as capi  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # MI355X spec (MI355X_MICROARCH.md); ~6.3 TB/s achievable
 
+P1080, P4K, P8K = (1920, 1080), (3840, 2160), (7680, 4320)
+
+
+def px(dim):
+    return dim[0] * dim[1]
+
+
 WORKLOADS = {
-    # name: (src w, src h, dst w, dst h, algorithmic bytes per frame)
-    "ewa_lanczos_1080p_to_4k_dither10": (1920, 1080, 3840, 2160,
-                                         1920 * 1080 * 8 + 3840 * 2160 * 8),
-    "bilinear_1080p_to_4k": (1920, 1080, 3840, 2160, 1920 * 1080 * 8 + 3840 * 2160 * 8),
+    # name: (src dims, dst dims, algorithmic bytes per frame, dominant pass)
+    "ewa_lanczos_1080p_to_4k_dither10": (P1080, P4K, px(P1080) * 8 + px(P4K) * 8, "polar"),
+    "bilinear_1080p_to_4k": (P1080, P4K, px(P1080) * 8 + px(P4K) * 8, None),
+    "hdr10_4k_tonemap": (P4K, P4K, 3 * px(P4K) * 8, "tone map"),
+    "ewa_8k_to_4k_deband_tonemap": (P8K, P4K, px(P8K) * 8 + px(P4K) * 8, "polar"),
 }
 
 
-def chirp(w, h):
+def synthetic_frame(workload, w, h):
     import util
+    if "hdr" in workload or "tonemap" in workload:
+        # PQ-coded BT.2020: the chirp, scaled so that the peak is ~1000 nits (PQ 0.75)
+        f = util.chirp_rgba16(w, h).astype(np.float32) * 0.75
+        f[..., 3] = 65535
+        return f.astype(np.uint16)
     return util.chirp_rgba16(w, h)
 
 
 class Stream:
-    """One independent video stream on one GPU."""
+    """One independent video stream on one GPU: a pl_hip backend + a pl_renderer."""
 
     def __init__(self, device, workload, pool):
         self.g = pl.HipGpu(device)
+        self.rr = pl.Renderer(self.g)
         self.workload = workload
-        sw, sh, dw, dh, _ = WORKLOADS[workload]
-        self.dims = (sw, sh, dw, dh)
-        frame = chirp(sw, sh)
+        (sw, sh), (dw, dh), _, _ = WORKLOADS[workload]
+        frame = synthetic_frame(workload, sw, sh)
         self.srcs = [self.g.tex_create(sw, sh, "rgba16", np.roll(frame, 7 * i, axis=1))
                      for i in range(pool)]
-        self.fbos = [self.g.tex_create(sw, sh, "rgba16hf") for _ in range(pool)]
         self.dsts = [self.g.tex_create(dw, dh, "rgba16") for _ in range(pool)]
-        self.lut, self.dstate = pl.ShaderObj(), pl.ShaderObj()
-        self.cfg = pl.filter_config("ewa_lanczos")
         self.pool = pool
         self.i = 0
+        self.pass_ns = {}
 
-    def step(self, timer=None):
-        g, i = self.g, self.i % self.pool
-        sw, sh, dw, dh = self.dims
+        sdr = pl.color_space("bt709", "srgb")
+        hdr = pl.color_space("bt2020", "pq", max_luma=1000.0)
+        bt1886 = pl.color_space("bt709", "bt1886")
+        dither = capi.DitherParams(method=pl.DITHER_BLUE_NOISE, lut_size=6, transfer=0)
+        ten_bit = pl.color_repr("rgb", "full", sample_depth=16, color_depth=10, bit_shift=6)
+        if workload == "bilinear_1080p_to_4k":
+            self.params = pl.render_params("fast")
+            icsp, tcsp, trepr = sdr, sdr, None
+        elif workload == "ewa_lanczos_1080p_to_4k_dither10":
+            self.params = pl.render_params("fast", upscaler=pl.filter_config("ewa_lanczos"),
+                                           dither_params=dither,
+                                           disable_dither_gamma_correction=True)
+            icsp, tcsp, trepr = sdr, sdr, ten_bit
+        elif workload == "hdr10_4k_tonemap":
+            self.params = pl.render_params(
+                "default", peak_detect_params=pl.peak_detect_params(percentile=99.995))
+            icsp, tcsp, trepr = hdr, bt1886, None
+        else:
+            self.params = pl.render_params(
+                "high_quality", downscaler=pl.filter_config("ewa_lanczos"),
+                peak_detect_params=pl.peak_detect_params(percentile=99.995))
+            icsp, tcsp, trepr = hdr, bt1886, ten_bit
+
+        self._cb = capi.RENDER_INFO_CB(self._info)
+        self.params.info_callback = C.cast(self._cb, C.c_void_p)
+        self.images = [pl.frame(t, components=3, color=icsp) for t in self.srcs]
+        self.targets = [pl.frame(t, color=tcsp, repr_=trepr) for t in self.dsts]
+
+    def _info(self, _priv, info):
+        d = info.contents.pass_.contents
+        self.pass_ns.setdefault(d.description.decode(), []).append(d.last)
+
+    def step(self):
+        i = self.i % self.pool
         self.i += 1
-        g.reset_frame()
-        if self.workload == "bilinear_1080p_to_4k":
-            s = g.begin()
-            s.sample("bilinear", self.srcs[i], new_w=dw, new_h=dh)
-            assert s.finish(self.dsts[i], timer=timer)
-            return
-        # PASS A (plane -> rgba16hf FBO), as the reference always does before a
-        # complex scaler (renderer.c:2064), then polar + dither into the target
-        a = g.begin()
-        a.sample("direct", self.srcs[i])
-        assert a.finish(self.fbos[i])
-        b = g.begin()
-        assert b.sample_polar(self.fbos[i], self.cfg, self.lut, new_w=dw, new_h=dh, components=3)
-        b.dither(10, self.dstate)
-        assert b.finish(self.dsts[i], timer=timer)
+        assert self.rr.render(self.images[i], self.targets[i], self.params), self.g.messages[-3:]
 
     def close(self):
         self.g.finish()
-        for t in self.srcs + self.fbos + self.dsts:
+        self.rr.destroy()
+        for t in self.srcs + self.dsts:
             t.destroy()
-        self.lut.destroy()
-        self.dstate.destroy()
         self.g.close()
 
 
 def cpu_baseline(workload):
-    """The CPU oracle (a scalar port of the reference's algorithm) timed on the
-    host, single thread, on a bounded crop of the same workload."""
+    """The CPU oracle (a scalar port of the reference's algorithm) timed on the host, single
+    thread, on a bounded sample of the same workload."""
     import orc
     import util
-    sw, sh, dw, dh, _ = WORKLOADS[workload]
-    cw, ch = sw, sh  # one whole frame: ~10-20 s of scalar CPU work
-    src = chirp(sw, sh)[:ch, :cw]
-    tex = orc.tex_decode(src, "rgba16")
-    t0 = time.perf_counter()
-    if workload.startswith("bilinear"):
-        out = orc.sample_simple(tex, orc.S_BILINEAR, cw * 2, ch * 2)
+    (sw, sh), (dw, dh), _, _ = WORKLOADS[workload]
+    if workload.startswith("bilinear") or workload.startswith("ewa_lanczos"):
+        cw, ch = sw, sh  # one whole frame: ~10 s of scalar CPU work
+        src = util.chirp_rgba16(sw, sh)
+        tex = orc.tex_decode(src, "rgba16")
+        t0 = time.perf_counter()
+        if workload.startswith("bilinear"):
+            out = orc.sample_simple(tex, orc.S_BILINEAR, cw * 2, ch * 2)
+        else:
+            img = orc.op_quant_f16(orc.sample_simple(tex, orc.S_BILINEAR, cw, ch))
+            w, r, rz = orc.filter_generate_polar(orc.ewa_lanczos())
+            out = orc.sample_polar(img, w, r, rz, cw * 2, ch * 2, mask=0x7)
+            orc.dither(out, util.blue_noise(pl), 10)
+        orc.tex_encode(out, "rgba16")
+        dt = time.perf_counter() - t0
+        npx, sample = cw * 2 * ch * 2, f"1 frame {cw}x{ch}->{cw * 2}x{ch * 2}"
     else:
-        img = orc.op_quant_f16(orc.sample_simple(tex, orc.S_BILINEAR, cw, ch))
-        w, r, rz = orc.filter_generate_polar(orc.ewa_lanczos())
-        out = orc.sample_polar(img, w, r, rz, cw * 2, ch * 2, mask=0x7)
-        orc.dither(out, util.blue_noise(pl), 10)
-    orc.tex_encode(out, "rgba16")
-    dt = time.perf_counter() - t0
+        # colour-mapping workloads: a 1920x1080 crop through linearize -> IPT/PQ -> tone LUT
+        # -> gamut 3D-LUT -> delinearize (the per-pixel part of the pass structure)
+        import colormap_ref as cr
+        cw, ch = 1920, 1080
+        img = (synthetic_frame(workload, cw, ch).astype(np.float32) / 65535.0)
+        r = cr.resolve(cr.make_csp(pl.PRIM["bt2020"], pl.TRC["pq"], max_luma=1000.0),
+                       cr.make_csp(pl.PRIM["bt709"], pl.TRC["bt1886"]))
+        t0 = time.perf_counter()
+        cr.apply(img, r)
+        dt = time.perf_counter() - t0
+        npx, sample = cw * ch, f"{cw}x{ch} crop, colour-mapping stage only"
     return {
-        "value": round(cw * 2 * ch * 2 / dt / 1e6, 4),
+        "value": round(npx / dt / 1e6, 4),
         "unit": "Mpixels/s",
         "cores": 1,
         "kind": "port",
-        "sample": f"1 frame {cw}x{ch}->{cw * 2}x{ch * 2} of the same workload, "
-                  f"oracle/pl_oracle.c (scalar C, -O2), {dt:.1f} s",
+        "sample": f"{sample} of the same workload, oracle/pl_oracle.c (scalar C, -O2), {dt:.1f} s",
     }
 
 
@@ -128,8 +178,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--workload", default="ewa_lanczos_1080p_to_4k_dither10",
                     choices=sorted(WORKLOADS))
-    ap.add_argument("--pool", type=int, default=12,
-                    help="rotating source/FBO/target textures per stream")
+    ap.add_argument("--pool", type=int, default=0,
+                    help="rotating source/target textures per stream (0 = enough to exceed "
+                         "the 256 MiB Infinity Cache)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -150,8 +201,10 @@ def main():
         if dist is not None:
             dist.barrier()
 
-    st = Stream(local_rank, args.workload, args.pool)
-    sw, sh, dw, dh, alg_bytes = WORKLOADS[args.workload]
+    (sw, sh), (dw, dh), alg_bytes, dominant = WORKLOADS[args.workload]
+    per_frame = (sw * sh + dw * dh) * 8
+    pool = args.pool or max(4, -(-800_000_000 // per_frame))
+    st = Stream(local_rank, args.workload, pool)
 
     for _ in range(args.warmup):
         st.step()
@@ -172,27 +225,24 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
-    # ---- dominant-kernel time, HIP events on the pass' own stream -----------------
+    # ---- per-pass GPU time: HIP events recorded around every launch on the stream the
+    # launches go to (pl_timer), reported through pl_render_params.info_callback ------------
     roofline = None
     if rank == 0:
-        timer = st.g.timer()
-        samples = []
-        for _ in range(64):
-            st.step(timer=timer)
-            if len(samples) < 64 and (_ % 8) == 7:
-                st.g.finish()
-                while True:
-                    ns = st.g.timer_query(timer)
-                    if not ns:
-                        break
-                    samples.append(ns)
+        st.pass_ns.clear()
+        for _ in range(48):
+            st.step()
         st.g.finish()
-        while True:
-            ns = st.g.timer_query(timer)
-            if not ns:
-                break
-            samples.append(ns)
-        kern_s = float(np.mean(samples)) * 1e-9
+        st.step()           # drains the last timers
+        st.g.finish()
+        passes = {k: float(np.mean(v)) for k, v in st.pass_ns.items() if v}
+        if dominant:
+            name = max((k for k in passes if dominant in k), key=lambda k: passes[k],
+                       default=max(passes, key=passes.get))
+        else:
+            name = max(passes, key=passes.get)
+        kern_s = passes[name] * 1e-9
+        frame_s = sum(passes.values()) * 1e-9
         achieved = alg_bytes / kern_s / 1e9
         traffic = None
         prof = os.path.join(ROOT, "profiles", "hbm_traffic.json")
@@ -201,7 +251,7 @@ def main():
                 traffic = json.load(f).get(args.workload)
         roofline = {
             "bound": "hbm",
-            "kernel": "k_pass_generic" if args.workload.startswith("bilinear") else "k_polar",
+            "kernel": name,
             "achieved": round(achieved, 1),
             "peak": HBM_PEAK_GBS,
             "unit": "GB/s",
@@ -209,12 +259,15 @@ def main():
             "traffic": traffic,
             "kernel_us": round(kern_s * 1e6, 2),
             "algorithmic_bytes": alg_bytes,
+            "passes_us": {k: round(v / 1e3, 2) for k, v in passes.items()},
+            "frame_gpu_us": round(frame_s * 1e6, 2),
+            "frame_frac": round(alg_bytes / frame_s / 1e9 / HBM_PEAK_GBS, 4),
         }
 
     if rank == 0:
         frames = args.steps * world
         out = {
-            "metric": "Mpixels/s (output) EWA-Lanczos 1080p->4K upscale + dither, per-GPU streams",
+            "metric": "Mpixels/s (output) through pl_render_image, per-GPU streams",
             "value": round(frames * dw * dh / elapsed / 1e6, 1),
             "unit": "Mpixels/s",
             "n_gpus": world,
@@ -229,17 +282,17 @@ def main():
             "data": "synthetic",
             "config": {
                 "workload": args.workload,
-                "src": f"{sw}x{sh} rgba16", "dst": f"{dw}x{dh} rgba16",
-                "pool": args.pool,
-                "passes": "sample->rgba16hf FBO, polar EWA + dither" if not
-                          args.workload.startswith("bilinear") else "bilinear",
+                "src": f"{sw}x{sh} rgba16",
+                "dst": f"{dw}x{dh} rgba16",
+                "pool": pool,
+                "api": "pl_render_image",
                 "parallelism": f"{world} independent stream(s), one per GPU",
             },
             "roofline": roofline,
         }
-        if not args.no_cpu_baseline and world == 1:
+        if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.workload)
-        print(json.dumps(out))
+        print(json.dumps(out), flush=True)
 
     st.close()
     if dist is not None:

@@ -334,6 +334,20 @@ class RenderParams(C.Structure):
                 ("info_priv", C.c_void_p)]
 
 
+class DispatchInfo(C.Structure):
+    _fields_ = [("description", C.c_char_p), ("signature", C.c_uint64),
+                ("samples", C.c_uint64 * 256), ("num_samples", C.c_int), ("last", C.c_uint64),
+                ("peak", C.c_uint64), ("average", C.c_uint64)]
+
+
+class RenderInfo(C.Structure):
+    _fields_ = [("pass_", C.POINTER(DispatchInfo)), ("stage", C.c_int), ("index", C.c_int),
+                ("count", C.c_int)]
+
+
+RENDER_INFO_CB = C.CFUNCTYPE(None, C.c_void_p, C.POINTER(RenderInfo))
+
+
 class RenderErrors(C.Structure):
     _fields_ = [("errors", C.c_int), ("disabled_hooks", C.c_void_p),
                 ("num_disabled_hooks", C.c_int)]

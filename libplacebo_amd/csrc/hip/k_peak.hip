@@ -100,13 +100,22 @@ DEV void op_peak_detect(const float4_t &c_in, const plh_op &op, const peak_ctx &
     const uint32_t local_idx = threadIdx.y * PEAK_BW + threadIdx.x;
     const uint32_t wg_idx = blockIdx.y * gridDim.x + blockIdx.x;
     const uint32_t slice = wg_idx % PEAK_SLICES;
-    peak_buf *frame = (peak_buf *) pk.frame;
+    // All workgroups of a frame would hammer the same 48 words (two cache lines) of the
+    // measurement buffer with atomics, which serialises them (~4.5 ns each, 0.6 ms at 4K).
+    // They go to one of PLH_PEAK_COPIES scratch copies instead; k_peak_fold adds the copies
+    // into the real buffer afterwards. Integer sums / maxima: the result is identical.
+    peak_buf *frame = (peak_buf *) pk.frame + (wg_idx / PEAK_SLICES) % PLH_PEAK_COPIES;
     if (op.i2) {
         if (cutoff != 0.0f && local_idx == 0)
             pk.wg_hist[0] -= *pk.wg_black;
         __syncthreads();
-        for (uint32_t i = local_idx; i < PEAK_HIST_BINS; i += PEAK_BW * PEAK_BH)
-            atomicAdd(&frame->frame_hist[slice][i], pk.wg_hist[i]);
+        // (a workgroup typically populates 1-3 of the 64 bins: adding the zeros of the others
+        // would only queue ~20x more atomics on the 12 x 64 hot words)
+        for (uint32_t i = local_idx; i < PEAK_HIST_BINS; i += PEAK_BW * PEAK_BH) {
+            const uint32_t n = pk.wg_hist[i];
+            if (n)
+                atomicAdd(&frame->frame_hist[slice][i], n);
+        }
     }
 
     if (local_idx == 0) {
@@ -150,7 +159,7 @@ void k_pass_peak(const plh_pass p_)
         wg_state[local_idx] = 0u;
     __syncthreads();
 
-    const peak_ctx pk = { &wg_state[0], &wg_state[1], &wg_state[2], &wg_state[4], p.peak_buf };
+    const peak_ctx pk = { &wg_state[0], &wg_state[1], &wg_state[2], &wg_state[4], p.peak_scratch };
 
     const int idx = blockIdx.x * PEAK_BW + threadIdx.x;
     const int idy = blockIdx.y * PEAK_BH + threadIdx.y;
@@ -176,11 +185,33 @@ void k_pass_peak(const plh_pass p_)
     }
 }
 
+__global__ void k_peak_fold(uint32_t *dst, uint32_t *scratch)
+{
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= PLH_PEAK_WORDS)
+        return;
+    const bool is_max = t >= 3 * PEAK_SLICES && t < 4 * PEAK_SLICES;   // frame_max_pq
+    uint32_t acc = 0;
+    for (int c = 0; c < PLH_PEAK_COPIES; c++) {
+        const uint32_t v = scratch[c * PLH_PEAK_WORDS + t];
+        acc = is_max ? max(acc, v) : acc + v;
+        scratch[c * PLH_PEAK_WORDS + t] = 0u;
+    }
+    if (is_max)
+        atomicMax(&dst[t], acc);
+    else if (acc)
+        atomicAdd(&dst[t], acc);
+}
+
 int plh_launch_peak(hipStream_t stream, const plh_pass *pass)
 {
     const dim3 block(PEAK_BW, PEAK_BH);
     const dim3 grid((pass->width + PEAK_BW - 1) / PEAK_BW, (pass->height + PEAK_BH - 1) / PEAK_BH);
+    if (!pass->peak_buf || !pass->peak_scratch)
+        return -1002;
     hipLaunchKernelGGL(k_pass_peak, grid, block, 0, stream, *pass);
+    hipLaunchKernelGGL(k_peak_fold, dim3((PLH_PEAK_WORDS + 255) / 256), dim3(256), 0, stream,
+                       (uint32_t *) pass->peak_buf, (uint32_t *) pass->peak_scratch);
     const hipError_t err = hipGetLastError();
     return err == hipSuccess ? 0 : -(int) err;
 }

@@ -184,6 +184,8 @@ struct plh_op {
 };
 
 #define PLH_MAX_OPS 20
+#define PLH_PEAK_WORDS 816
+#define PLH_PEAK_COPIES 64
 
 struct plh_pass {
     struct plh_sampler_args s;
@@ -205,8 +207,10 @@ struct plh_pass {
     // makes the four bilinear footprints of a 2x upscale coincide is chosen by the host
     int32_t cell_padx, cell_pady;
 
-    // peak detection side output (k_peak)
+    // peak detection side output (k_peak): the 816-word measurement buffer and a zeroed
+    // scratch area of PLH_PEAK_COPIES such buffers that spreads the per-workgroup atomics
     void *peak_buf;
+    void *peak_scratch;
 };
 
 /* ---- error diffusion (k_errdiff.hip) ------------------------------------------ */

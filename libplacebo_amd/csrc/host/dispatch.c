@@ -123,7 +123,9 @@ static struct pass_timing *get_timing(pl_dispatch dp, pl_shader sh)
     if (!dp->info_cb)
         return NULL;
     const struct pl_shader_res *res = pl_shader_finalize(sh);
-    const uint64_t sig = hash_str(res->glsl) ^ hash_str(res->description);
+    // keyed by what the pass does, not by its per-frame values (PRNG seeds, LUT contents)
+    const uint64_t sig = hash_str(res->description) ^ ((uint64_t) res->num_ops << 56) ^
+                         ((uint64_t) sh->pass.s.type << 48);
     for (int i = 0; i < dp->num_timings; i++) {
         if (dp->timings[i].signature == sig)
             return &dp->timings[i];
@@ -134,7 +136,16 @@ static struct pass_timing *get_timing(pl_dispatch dp, pl_shader sh)
     memset(t, 0, sizeof(*t));
     t->signature = sig;
     t->timer = pl_timer_create(dp->gpu);
-    snprintf(t->desc, sizeof(t->desc), "%s", res->description);
+    static const char *const samplers[] = {
+        [PLH_SAMPLE_NONE] = "", [PLH_SAMPLE_NEAREST] = "nearest + ",
+        [PLH_SAMPLE_BILINEAR] = "bilinear + ", [PLH_SAMPLE_BICUBIC] = "bicubic + ",
+        [PLH_SAMPLE_HERMITE] = "hermite + ", [PLH_SAMPLE_GAUSSIAN] = "gaussian + ",
+        [PLH_SAMPLE_OVERSAMPLE] = "oversample + ", [PLH_SAMPLE_POLAR] = "polar + ",
+        [PLH_SAMPLE_ORTHO] = "ortho + ", [PLH_SAMPLE_DEBAND] = "deband + ",
+    };
+    // the shader's description is that of its last stage; prefix the sampler that feeds it
+    snprintf(t->desc, sizeof(t->desc), "%s%s",
+             sh->kind == PLH_SHADER_PASS ? samplers[sh->pass.s.type] : "", res->description);
     t->info.description = t->desc;
     t->info.signature = sig;
     return t;

@@ -97,7 +97,19 @@ struct pass_state {
     bool fbos_used[MAX_FBOS];
     bool need_peak_fbo;
     bool acquired_image, acquired_target;
+    struct pl_render_info info;
 };
+
+static void info_callback(void *priv, const struct pl_dispatch_info *dinfo)
+{
+    struct pass_state *pass = priv;
+    const struct pl_render_params *params = pass->params;
+    if (!params->info_callback)
+        return;
+    pass->info.pass = dinfo;
+    params->info_callback(params->info_priv, &pass->info);
+    pass->info.index++;
+}
 
 #define RR_ERR(rr, ...)  pl_msg((rr)->log, PL_LOG_ERR, __VA_ARGS__)
 #define RR_WARN(rr, ...) pl_msg((rr)->log, PL_LOG_WARN, __VA_ARGS__)
@@ -1257,6 +1269,7 @@ static void pass_uninit(struct pass_state *pass)
 {
     pl_renderer rr = pass->rr;
     pl_dispatch_abort(rr->dp, &pass->img.sh);
+    pl_dispatch_callback(rr->dp, NULL, NULL);
     if (pass->acquired_image && pass->image.release)
         pass->image.release(rr->gpu, &pass->image);
     if (pass->acquired_target && pass->target.release)
@@ -1323,6 +1336,7 @@ bool pl_render_image(pl_renderer rr, const struct pl_frame *pimage, const struct
     }
 
     pl_dispatch_reset_frame(rr->dp);
+    pl_dispatch_callback(rr->dp, &pass, info_callback);
     if (!pass_read_image(&pass))
         goto error;
     if (!pass_scale_main(&pass))

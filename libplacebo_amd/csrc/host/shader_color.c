@@ -449,6 +449,7 @@ struct sh_color_map_obj {
         struct pl_peak_detect_params params;
         pl_buf buf;         // pending measurement
         pl_buf consts;      // per-pass constant block of the detect stage
+        pl_buf scratch;     // PLH_PEAK_COPIES zeroed copies of the buffer (k_peak.hip)
         float avg_pq, max_pq;
     } peak;
 };
@@ -460,6 +461,7 @@ static void sh_color_map_uninit(pl_gpu gpu, void *ptr)
     pl_buf_destroy(gpu, &obj->gamut.lut);
     pl_buf_destroy(gpu, &obj->peak.buf);
     pl_buf_destroy(gpu, &obj->peak.consts);
+    pl_buf_destroy(gpu, &obj->peak.scratch);
     memset(obj, 0, sizeof(*obj));
 }
 
@@ -674,7 +676,17 @@ bool pl_shader_detect_peak(pl_shader sh, struct pl_color_space csp, pl_shader_ob
     }
     pl_buf_write(gpu, obj->peak.consts, 0, consts, sizeof(consts));
     op->ptr2 = pl_hip_buf_ptr(obj->peak.consts);
+    if (!obj->peak.scratch) {
+        const size_t size = (size_t) PLH_PEAK_COPIES * sizeof(struct peak_buf_data);
+        void *zeros = calloc(1, size);
+        obj->peak.scratch = zeros ? pl_buf_create(gpu, pl_buf_params(
+            .size = size, .storable = true, .initial_data = zeros)) : NULL;
+        free(zeros);
+        if (!obj->peak.scratch)
+            return false;
+    }
     sh->pass.peak_buf = pl_hip_buf_ptr(obj->peak.buf);
+    sh->pass.peak_scratch = pl_hip_buf_ptr(obj->peak.scratch);
     sh->detect_peak = true;
     sh_hold(sh, *state);
 
@@ -705,10 +717,11 @@ void pl_reset_detected_peak(pl_shader_obj state)
         return;
 
     struct sh_color_map_obj *obj = state->priv;
-    pl_buf consts = obj->peak.consts;
+    pl_buf consts = obj->peak.consts, scratch = obj->peak.scratch;
     pl_buf_destroy(state->gpu, &obj->peak.buf);
     memset(&obj->peak, 0, sizeof(obj->peak));
     obj->peak.consts = consts;
+    obj->peak.scratch = scratch;
 }
 
 void *pl_hip_peak_buffer(const pl_shader_obj state, size_t *out_size)
