@@ -1442,3 +1442,36 @@ ORC_API void orc_error_diffusion(const float *img, int w, int h, int depth, int 
     }
     free(ring);
 }
+
+/* ======================================================================== */
+/* Self-checks of arithmetic identities the product relies on (tests/test_host.py) */
+
+// plh_un8 / plh_un16 (csrc/hip/devmath.hiph): q = v*(1/d); q += fma(-q, d, v)*(1/d) must be
+// the correctly rounded v/d for every code value. Returns the number of mismatches.
+ORC_API int orc_check_unorm_decode(int bits)
+{
+    const float d = bits == 8 ? 255.0f : 65535.0f;
+    const int n = bits == 8 ? 255 : 65535;
+    const float r = 1.0f / d;
+    int bad = 0;
+    for (int i = 0; i <= n; i++) {
+        const float x = (float) i, q = x * r;
+        const float q2 = fmaf(fmaf(-q, d, x), r, q);
+        bad += q2 != x / d;
+    }
+    return bad;
+}
+
+// (int) fract((n + 0.5) / size) * size == n mod size for power-of-two `size`: the integer
+// shortcut of the dither matrix index (colorops.hiph, dither_bias). Returns mismatches.
+ORC_API int orc_check_dither_index(int size, int limit)
+{
+    int bad = 0;
+    const float inv = (float) (1.0 / size);
+    for (int n = 0; n < limit; n++) {
+        const float f = ((float) n + 0.5f) * inv;
+        const float p = f - floorf(f);
+        bad += (int) (p * (float) size) != (n & (size - 1));
+    }
+    return bad;
+}

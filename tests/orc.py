@@ -263,7 +263,8 @@ def triangle(blur=0.0):
 def mitchell(blur=0.0):
     f = OrcFilter(kernel=K["cubic"], window=K["none"], kradius=2.0, wradius=1.0,
                   resizable=0, radius=2.0, blur=blur)
-    f.kparams[0], f.kparams[1] = 1 / 3.0, 1 / 3.0
+    # pl_filter_config.params are floats (promoted to double by the kernel)
+    f.kparams[0] = f.kparams[1] = float(np.float32(1 / 3.0))
     return f
 
 

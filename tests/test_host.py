@@ -1,0 +1,108 @@
+"""CPU-only checks: arithmetic identities the kernels rely on, and the oracle pinned against
+the reference's own known answers / the real reference build where it is present."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import orc
+import util
+
+
+def test_fast_unorm_decode_is_the_correctly_rounded_quotient():
+    # devmath.hiph plh_un8 / plh_un16: mul + 2 fma == IEEE division, for every code value
+    assert orc.lib().orc_check_unorm_decode(8) == 0
+    assert orc.lib().orc_check_unorm_decode(16) == 0
+
+
+@pytest.mark.parametrize("size", [2, 8, 16, 64, 256])
+def test_dither_index_shortcut_is_exact(size):
+    # colorops.hiph dither_bias: (int)(fract((n + .5) / size) * size) == n & (size - 1)
+    assert orc.lib().orc_check_dither_index(size, 1 << 15) == 0
+
+
+def test_cfg1_ewa_lanczos_cpu_reference_case():
+    """BASELINE configs[0]: pl_filter_sample EWA-Lanczos weights on a synthetic frame, pure CPU.
+    Direct evaluation (every tap = pl_filter_sample) vs the 256-entry LUT + lerp the GPU path
+    uses: the LUT resampler must agree with the direct one to the LUT's interpolation error."""
+    rng = np.random.default_rng(0)
+    src = rng.random((48, 48)).astype(np.float32)
+    direct, taps_d = orc.ewa_resample_r32f(orc.ewa_lanczos(), src, 96, 96, use_lut=False)
+    lut, taps_l = orc.ewa_resample_r32f(orc.ewa_lanczos(), src, 96, 96, use_lut=True)
+    assert taps_d == taps_l and 25 < taps_d < 45    # taps per pixel inside the radius (~30)
+    assert np.abs(direct - lut).max() < 2e-4
+    # a constant image is reproduced exactly by a normalised filter
+    flat, _ = orc.ewa_resample_r32f(orc.ewa_lanczos(), np.full((32, 32), 0.25, np.float32),
+                                    64, 64, use_lut=True)
+    assert np.abs(flat - 0.25).max() < 1e-6
+
+
+@pytest.mark.skipif(not orc.have_ref(), reason="oracle/_ref not built")
+def test_oracle_filter_sample_matches_reference_pl_filter_sample():
+    import ref_structs as R
+    from libplacebo_amd import _capi as capi
+    ref = R.declare(orc.ref())
+    ref.pl_filter_sample.restype = C.c_double
+    ref.pl_filter_sample.argtypes = [C.POINTER(capi.FilterConfig), C.c_double]
+    ref.pl_find_filter_config.restype = C.POINTER(capi.FilterConfig)
+    ref.pl_find_filter_config.argtypes = [C.c_char_p, C.c_int]
+    orc.lib().orc_filter_sample.restype = C.c_double
+    for name, mk in (("ewa_lanczos", orc.ewa_lanczos), ("lanczos", orc.lanczos),
+                     ("mitchell", orc.mitchell), ("bilinear", orc.triangle)):
+        cfg = ref.pl_find_filter_config(name.encode(), 1)
+        f = mk()
+        for x in np.linspace(0, 3.5, 141):
+            a = ref.pl_filter_sample(cfg, float(x))
+            b = orc.lib().orc_filter_sample(C.byref(f), C.c_double(float(x)))
+            assert a == b, (name, x, a, b)
+
+
+def test_oracle_samplers_basic_invariants():
+    img = orc.tex_decode(util.random_rgba16(24, 16, seed=3), "rgba16")
+    # identity fetches return the texels
+    assert np.array_equal(orc.sample_simple(img, orc.S_NEAREST, 24, 16), img)
+    assert np.array_equal(orc.sample_simple(img, orc.S_BILINEAR, 24, 16), img)
+    # a constant image survives every sampler
+    flat = np.full((16, 24, 4), 0.375, np.float32)
+    for kind in (orc.S_BILINEAR, orc.S_BICUBIC, orc.S_HERMITE, orc.S_GAUSSIAN):
+        out = orc.sample_simple(flat, kind, 37, 29)
+        assert np.abs(out - 0.375).max() < 1e-6
+    w, r, rz = orc.filter_generate_polar(orc.ewa_lanczos())
+    assert np.abs(orc.sample_polar(flat, w, r, rz, 48, 32) - 0.375).max() < 1e-6
+    rows, n, _, _ = orc.filter_generate_ortho(orc.lanczos())
+    assert np.abs(orc.sample_ortho(flat, rows, n, 0, 48, 16) - 0.375).max() < 1e-6
+
+
+def test_oracle_error_diffusion_preserves_the_mean():
+    img = orc.tex_decode(util.chirp_rgba16(64, 48), "rgba16")
+    out = orc.error_diffusion(img, 3, 2, 4, [[0, 0, 0, 2, 0], [0, 1, 1, 0, 0], [0, 0, 0, 0, 0]])
+    q = out[..., :3] * 7
+    assert np.abs(q - np.round(q)).max() < 1e-5
+    assert abs(out[..., :3].mean() - img[..., :3].mean()) < 2e-3
+
+
+def test_oracle_peak_detection_matches_the_reference_formula():
+    """src/tests/gpu_tests.c:753-785: avg / max PQ luminance of the (x, y, 0) ramp through
+    gamma 2.2, against the closed form."""
+    W = H = 16
+    y, x = np.mgrid[0:H, 0:W].astype(np.float32)
+    img = np.zeros((H, W, 4), np.float32)
+    img[..., 0], img[..., 1], img[..., 3] = (x + 0.5) / W, (y + 0.5) / H, 1.0
+    luma_c = (0.212639, 0.715169, 0.072192)
+    buf = orc.detect_peak(img, 6, 0.0, 1.0, luma_c, black_cutoff=0.0)   # TRC gamma22
+    wg_count, wg_active, sum_pq, max_pq = buf[0:12], buf[12:24], buf[24:36], buf[36:48]
+    assert wg_count.sum() == 1 and wg_active.sum() == 1
+    lin = luma_c[0] * img[..., 0] ** 2.2 + luma_c[1] * img[..., 1] ** 2.2
+    m1, m2, c1, c2, c3 = 2610 / 16384, 2523 / 32, 3424 / 4096, 2413 / 128, 2392 / 128
+    yv = (lin * 203 / 10000) ** m1
+    pq = ((c1 + c2 * yv) / (1 + c3 * yv)) ** m2
+    assert abs(max_pq.max() / 16383.0 - pq.max()) <= 1e-4
+    assert abs(sum_pq.sum() / 16383.0 - pq.mean()) <= 1e-3
+
+
+def test_multi_gpu_sharding_plan():
+    """Streams are independent units: stream s runs on rank s % world."""
+    for world in (1, 2, 4, 8):
+        owners = [s % world for s in range(16)]
+        for r in range(world):
+            assert owners.count(r) == 16 // world
