@@ -350,7 +350,7 @@ DEV floatv4_t tile_vec(const tile_px<float> &t)
 
 // the per-pixel weights path for one pixel, on the staged tile (no anti-ringing)
 template <typename T, uint32_t MASK>
-__attribute__((noinline)) __device__ void polar_pixel_generic(const plh_sampler_args &s, const float2 *lut, const tile_px<T> *tp,
+DEV void polar_pixel_generic(const plh_sampler_args &s, const float2 *lut, const tile_px<T> *tp,
                              int tw, float fcx, float fcy, float col[4], float &norm)
 {
     float wsum = 0.0f;
@@ -467,22 +467,26 @@ void k_polar_pp(const plh_pass p_)
         // the tile's slice of the weight table: float4 units, 4 in flight per lane
         const int tp4 = tp >> 2, units = nx * ny * tp4;
         const float rcp_tp4 = 1.0f / (float) tp4, rcp_nx = 1.0f / (float) nx;
-        for (int u0 = tid; u0 < ((s.pp_debug & 16) ? 0 : units); u0 += 4 * POLAR_BW * POLAR_BH) {
-            float4 v[4];
-#pragma unroll
-            for (int k = 0; k < 4; k++) {
-                const int u = min(u0 + k * POLAR_BW * POLAR_BH, units - 1);
-                const int pair = (int) (((float) u + 0.5f) * rcp_tp4), t4 = u - pair * tp4;
-                const int ly = (int) (((float) pair + 0.5f) * rcp_nx), lx = pair - ly * nx;
-                const size_t g = (size_t) lists[PLH_PP_LMAX + ly] * pp.ncx + lists[lx];
-                v[k] = *(const float4 *) (pp.weights + g * tp + t4 * 4);
-            }
-#pragma unroll
-            for (int k = 0; k < 4; k++) {
-                const int u = u0 + k * POLAR_BW * POLAR_BH;
-                if (u < units)
-                    *(float4 *) (ws + u * 4) = v[k];
-            }
+        // (four named registers rather than an array: the compiler demotes a conditionally
+        // consumed array to scratch memory, ~27 MB of spurious HBM writes per 4K frame)
+        auto wload = [&](int u) {
+            u = min(u, units - 1);
+            const int pair = (int) (((float) u + 0.5f) * rcp_tp4), t4 = u - pair * tp4;
+            const int ly = (int) (((float) pair + 0.5f) * rcp_nx), lx = pair - ly * nx;
+            const size_t g = (size_t) lists[PLH_PP_LMAX + ly] * pp.ncx + lists[lx];
+            return *(const float4 *) (pp.weights + g * tp + t4 * 4);
+        };
+        const int stride = POLAR_BW * POLAR_BH;
+        for (int u0 = tid; u0 < ((s.pp_debug & 16) ? 0 : units); u0 += 4 * stride) {
+            const float4 v0 = wload(u0), v1 = wload(u0 + stride), v2 = wload(u0 + 2 * stride),
+                         v3 = wload(u0 + 3 * stride);
+            *(float4 *) (ws + u0 * 4) = v0;
+            if (u0 + stride < units)
+                *(float4 *) (ws + (u0 + stride) * 4) = v1;
+            if (u0 + 2 * stride < units)
+                *(float4 *) (ws + (u0 + 2 * stride) * 4) = v2;
+            if (u0 + 3 * stride < units)
+                *(float4 *) (ws + (u0 + 3 * stride) * 4) = v3;
         }
     }
     __syncthreads();
@@ -619,6 +623,7 @@ void k_polar_pp(const plh_pass p_)
         frag_t fcs[N * N];
         int sx[N * N], sy[N * N];
         bool ok[N * N];
+        uint32_t redo = 0;
 #pragma unroll
         for (int j = 0; j < N; j++) {
             const int idy = rowy[j];
@@ -644,17 +649,10 @@ void k_polar_pp(const plh_pass p_)
                 const float px = plh_mix(attr[i][0], attr[i][1], my);
                 const bool same = __float_as_uint(px) == __float_as_uint(refx[i]) && cgood[i] &&
                                   rgood;
-                if (cok[i] && rok && !same && !(s.pp_debug & 2)) {
-                    // no: per-pixel weights (the tile has one texel of slack per side for a
-                    // base that is off by one)
-                    float fcx, fcy;
-                    int bx, by;
-                    polar_coord(p, colx[i], idy, fcx, fcy, bx, by);
-                    const int rx = min(max(bx - ox, s.bound - 1), tw - s.bound - 1);
-                    const int ry = min(max(by - oy, s.bound - 1), th - s.bound - 1);
-                    polar_pixel_generic<T, MASK>(s, lut, tile + ry * tw + rx, tw, fcx, fcy,
-                                                 col, norm);
-                }
+                // no -> recomputed with per-pixel weights after the regular stores (rare: a
+                // rounding tie in the attribute interpolation)
+                if (cok[i] && rok && !same && !(s.pp_debug & 2))
+                    redo |= 1u << q;
 
                 outs[q] = { norm * col[0], norm * col[1], norm * col[2], norm * col[3] };
                 if (!(MASK & 8u))
@@ -668,6 +666,36 @@ void k_polar_pp(const plh_pass p_)
         }
         apply_ops_n<N * N, false, LITE>(outs, p.ops, p.num_pre_ops, p.num_ops, fcs);
         plh_store_n<N * N>(p.dst, sx, sy, ok, outs);
+
+        // ---- pixels whose own phase is not the tabulated one: the per-pixel path, one inlined
+        // copy for all of the lane's pixels (a function call would cost scratch traffic) ------
+        while (redo) {
+            const int q = __builtin_ctz(redo);
+            redo &= redo - 1;
+            const int i = q % N, j = q / N;
+            int idx = colx[0], idy = rowy[0];
+#pragma unroll
+            for (int k = 1; k < N; k++) {
+                idx = i == k ? colx[k] : idx;
+                idy = j == k ? rowy[k] : idy;
+            }
+            float fcx, fcy, col[4], norm;
+            int bx, by;
+            polar_coord(p, idx, idy, fcx, fcy, bx, by);
+            const int rx = min(max(bx - ox, s.bound - 1), tw - s.bound - 1);
+            const int ry = min(max(by - oy, s.bound - 1), th - s.bound - 1);
+            polar_pixel_generic<T, MASK>(s, lut, tile + ry * tw + rx, tw, fcx, fcy, col, norm);
+            float4_t o1[1] = { { norm * col[0], norm * col[1], norm * col[2], norm * col[3] } };
+            if (!(MASK & 8u))
+                o1[0].w = 1.0f;
+            const frag_t f1[1] = { { (float) (idx + p.frag_x0) + 0.5f,
+                                     (float) (idy + p.frag_y0) + 0.5f, 0.0f, 0 } };
+            apply_ops_n<1, false, LITE>(o1, p.ops, p.num_pre_ops, p.num_ops, f1);
+            const int x1[1] = { p.base_x + p.dir_x * (p.transpose ? idy : idx) };
+            const int y1[1] = { p.base_y + p.dir_y * (p.transpose ? idx : idy) };
+            const bool k1[1] = { true };    // (only pixels that passed the store guards get here)
+            plh_store_n<1>(p.dst, x1, y1, k1, o1);
+        }
     }
 }
 
