@@ -9,11 +9,16 @@
  *
  * Memory-bound: every source texel and every target texel crosses HBM once.
  */
+#include <stdlib.h>
+
 #include "colorops.hiph"
 #include "samplers.hiph"
 
 #define PASS_BW 64
 #define PASS_BH 4
+#ifndef PASS_ITERS
+#define PASS_ITERS 1
+#endif
 
 DEV float4_t run_sampler(const plh_sampler_args &s, float px, float py)
 {
@@ -65,20 +70,28 @@ DEV lin_fp lin_footprint(const plh_view &v, int mode, float px, float py)
  *     8 B/pixel through L1 instead of 32.
  * LITE: pass only uses the cheap ops (plh_ops_lite) -> smaller kernel, more waves.
  */
-template <bool LITE>
+// SIMPLE: the sampler is none / nearest / bilinear (the hot cases); the closed-form fast
+// samplers are only instantiated in the !SIMPLE variants, whose register budget they set.
+// CH: rows per cell (cells are 2 wide): 2x2 amortises most, 2x1 needs fewer registers
+template <bool LITE, bool SIMPLE, int CH>
 __global__ __launch_bounds__(PASS_BW * PASS_BH)
 void k_pass_generic(const plh_pass p_)
 {
     const plh_pass &p = plh_kernarg_pass();
     const plh_sampler_args &s = p.s;
     const int cx = blockIdx.x * PASS_BW + threadIdx.x;
-    const int cy = blockIdx.y * PASS_BH + threadIdx.y;
+    constexpr int NPX = 2 * CH;
+    // PASS_ITERS cells per lane, PASS_BH cell rows apart: amortises the wave launch and the
+    // scalar prologue (the pass descriptor is ~2.5 KB of kernel arguments)
+#pragma unroll 1
+    for (int it = 0; it < PASS_ITERS; it++) {
+    const int cy = (blockIdx.y * PASS_ITERS + it) * PASS_BH + threadIdx.y;
 
-    float4_t c[4];
-    float px[4], py[4];
+    float4_t c[NPX];
+    float px[NPX], py[NPX];
 #pragma unroll
-    for (int q = 0; q < 4; q++) {
-        const int idx = 2 * cx - p.cell_padx + (q & 1), idy = 2 * cy - p.cell_pady + (q >> 1);
+    for (int q = 0; q < NPX; q++) {
+        const int idx = 2 * cx - p.cell_padx + (q & 1), idy = CH * cy - (CH == 2 ? p.cell_pady : 0) + (q >> 1);
         // lanes beyond the rect still run the maths in the reference and are dropped by the
         // store guard (dispatch.c:1126-1142)
         const float mx = p.out_scale[0] * ((float) idx + 0.5f);
@@ -93,17 +106,17 @@ void k_pass_generic(const plh_pass p_)
         break;
     case PLH_SAMPLE_NEAREST:
 #pragma unroll
-        for (int q = 0; q < 4; q++)
+        for (int q = 0; q < NPX; q++)
             c[q] = scale4(tex_nearest(s.src, s.address_mode, px[q], py[q]), s.scale);
         break;
     case PLH_SAMPLE_BILINEAR: {
-        lin_fp f[4];
+        lin_fp f[NPX];
 #pragma unroll
-        for (int q = 0; q < 4; q++)
+        for (int q = 0; q < NPX; q++)
             f[q] = lin_footprint(s.src, s.address_mode, px[q], py[q]);
         bool shared = true;
 #pragma unroll
-        for (int q = 1; q < 4; q++) {
+        for (int q = 1; q < NPX; q++) {
             shared = shared && f[q].x0 == f[0].x0 && f[q].x1 == f[0].x1 &&
                      f[q].y0 == f[0].y0 && f[q].y1 == f[0].y1;
         }
@@ -113,13 +126,13 @@ void k_pass_generic(const plh_pass p_)
             const float4_t t01 = plh_fetch(s.src, f[0].x0, f[0].y1);
             const float4_t t11 = plh_fetch(s.src, f[0].x1, f[0].y1);
 #pragma unroll
-            for (int q = 0; q < 4; q++) {
+            for (int q = 0; q < NPX; q++) {
                 c[q] = scale4(mix4(mix4(t00, t10, f[q].ax), mix4(t01, t11, f[q].ax), f[q].ay),
                               s.scale);
             }
         } else {
 #pragma unroll
-            for (int q = 0; q < 4; q++) {
+            for (int q = 0; q < NPX; q++) {
                 const float4_t t00 = plh_fetch(s.src, f[q].x0, f[q].y0);
                 const float4_t t10 = plh_fetch(s.src, f[q].x1, f[q].y0);
                 const float4_t t01 = plh_fetch(s.src, f[q].x0, f[q].y1);
@@ -131,20 +144,22 @@ void k_pass_generic(const plh_pass p_)
         break;
     }
     default:
+        if constexpr (!SIMPLE) {
 #pragma unroll
-        for (int q = 0; q < 4; q++)
-            c[q] = run_sampler(s, px[q], py[q]);
+            for (int q = 0; q < NPX; q++)
+                c[q] = run_sampler(s, px[q], py[q]);
+        }
         break;
     }
 
     // (store coordinates and gl_FragCoord are computed only now: short live ranges keep the
     // kernel at <= 96 VGPRs while the texel loads are in flight)
-    frag_t fcs[4];
-    int sx[4], sy[4];
-    bool ok[4];
+    frag_t fcs[NPX];
+    int sx[NPX], sy[NPX];
+    bool ok[NPX];
 #pragma unroll
-    for (int q = 0; q < 4; q++) {
-        const int idx = 2 * cx - p.cell_padx + (q & 1), idy = 2 * cy - p.cell_pady + (q >> 1);
+    for (int q = 0; q < NPX; q++) {
+        const int idx = 2 * cx - p.cell_padx + (q & 1), idy = CH * cy - (CH == 2 ? p.cell_pady : 0) + (q >> 1);
         fcs[q] = { (float) (idx + p.frag_x0) + 0.5f, (float) (idy + p.frag_y0) + 0.5f, 0.0f, 0 };
         sx[q] = p.base_x + p.dir_x * (p.transpose ? idy : idx);
         sy[q] = p.base_y + p.dir_y * (p.transpose ? idx : idy);
@@ -152,8 +167,9 @@ void k_pass_generic(const plh_pass p_)
                 p.out_scale[1] * (float) idy < 1.0f && sx[q] >= 0 && sy[q] >= 0 &&
                 sx[q] < p.dst.w && sy[q] < p.dst.h;
     }
-    apply_ops_n<4, false, LITE>(c, p.ops, 0, p.num_ops, fcs);
-    plh_store_n<4>(p.dst, sx, sy, ok, c);
+    apply_ops_n<NPX, false, LITE>(c, p.ops, 0, p.num_ops, fcs);
+    plh_store_n<NPX>(p.dst, sx, sy, ok, c);
+    }
 }
 
 /* ------------------------------------------------------------------------ */
@@ -187,13 +203,35 @@ extern "C" int plh_launch_pass(plh_stream stream_, const struct plh_pass *pass)
     }
 
     const dim3 block(PASS_BW, PASS_BH);
+    const bool lite = plh_ops_lite(pass, 0, pass->num_ops);
+    const bool simple = pass->s.type == PLH_SAMPLE_NONE || pass->s.type == PLH_SAMPLE_NEAREST ||
+                        pass->s.type == PLH_SAMPLE_BILINEAR;
+    static int rows_override = -1;  // PL_HIP_PASS_ROWS=1|2 (profiling aid)
+    if (rows_override < 0) {
+        const char *e = getenv("PL_HIP_PASS_ROWS");
+        rows_override = e ? atoi(e) : 0;
+    }
+    // 2x2 cells share the bilinear footprint; every other lite pass prefers the lighter 2x1
+    int ch = pass->s.type == PLH_SAMPLE_BILINEAR || !lite ? 2 : 1;
+    if (rows_override == 1 || rows_override == 2)
+        ch = rows_override;
     const int cells_w = (pass->width + pass->cell_padx + 1) / 2;
-    const int cells_h = (pass->height + pass->cell_pady + 1) / 2;
-    const dim3 grid((cells_w + PASS_BW - 1) / PASS_BW, (cells_h + PASS_BH - 1) / PASS_BH);
-    if (plh_ops_lite(pass, 0, pass->num_ops))
-        hipLaunchKernelGGL(k_pass_generic<true>, grid, block, 0, stream, *pass);
-    else
-        hipLaunchKernelGGL(k_pass_generic<false>, grid, block, 0, stream, *pass);
+    const int cells_h = ch == 2 ? (pass->height + pass->cell_pady + 1) / 2 : pass->height;
+    const int bh = PASS_BH * PASS_ITERS;
+    const dim3 grid((cells_w + PASS_BW - 1) / PASS_BW, (cells_h + bh - 1) / bh);
+#define LAUNCH(L, S, C) hipLaunchKernelGGL((k_pass_generic<L, S, C>), grid, block, 0, stream, *pass)
+    if (ch == 2) {
+        if (lite && simple) LAUNCH(true, true, 2);
+        else if (lite)      LAUNCH(true, false, 2);
+        else if (simple)    LAUNCH(false, true, 2);
+        else                LAUNCH(false, false, 2);
+    } else {
+        if (lite && simple) LAUNCH(true, true, 1);
+        else if (lite)      LAUNCH(true, false, 1);
+        else if (simple)    LAUNCH(false, true, 1);
+        else                LAUNCH(false, false, 1);
+    }
+#undef LAUNCH
     const hipError_t err = hipGetLastError();
     return err == hipSuccess ? 0 : -(int) err;
 }
