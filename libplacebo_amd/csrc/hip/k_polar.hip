@@ -378,7 +378,9 @@ DEV void polar_pixel_generic(const plh_sampler_args &s, const float2 *lut, const
 struct pp_rowinfo { float fc; int32_t base; int32_t woff; int32_t pad; };
 #define PP_LDS_FIXED (2048 + 1024 + 64)   // lut pairs, row info, class lists
 
-template <typename T, uint32_t MASK, int N, bool LITE>
+// LITE: the recorded ops only use the cheap cases (plh_ops_lite). FAST (implies LITE): the
+// post-ops are the fused epilogue described by p.epi and the target is rgba16.
+template <typename T, uint32_t MASK, int N, bool LITE, bool FAST>
 __global__ __launch_bounds__(POLAR_BW * POLAR_BH)
 void k_polar_pp(const plh_pass p_)
 {
@@ -572,9 +574,15 @@ void k_polar_pp(const plh_pass p_)
         for (int j = 0; j < N; j++) {
 #pragma unroll
             for (int i = 0; i < N; i++) {
-                const frag_t fc = { (float) (colx[i] + p.frag_x0) + 0.5f,
-                                    (float) (rowy[j] + p.frag_y0) + 0.5f };
-                bias[j][i] = dither_op >= 0 ? dither_bias(p.ops[dither_op], fc) : 0.0f;
+                if constexpr (FAST) {
+                    const int ix = (colx[i] + p.frag_x0) & p.epi.mask;
+                    const int iy = (rowy[j] + p.frag_y0) & p.epi.mask;
+                    bias[j][i] = p.epi.has_dither ? p.epi.matrix[iy * p.epi.size + ix] : 0.0f;
+                } else {
+                    const frag_t fc = { (float) (colx[i] + p.frag_x0) + 0.5f,
+                                        (float) (rowy[j] + p.frag_y0) + 0.5f };
+                    bias[j][i] = dither_op >= 0 ? dither_bias(p.ops[dither_op], fc) : 0.0f;
+                }
             }
         }
 
@@ -657,6 +665,20 @@ void k_polar_pp(const plh_pass p_)
                 outs[q] = { norm * col[0], norm * col[1], norm * col[2], norm * col[3] };
                 if (!(MASK & 8u))
                     outs[q].w = 1.0f;
+                if constexpr (FAST) {
+                    // op_dither (non-gamma path) and the SCALE op, parameters in SGPRs
+                    float4_t &o = outs[q];
+                    if (p.epi.has_dither) {
+                        const float b = bias[j][i], ds = p.epi.dscale, di = p.epi.dinv;
+                        o.x = __builtin_floorf(ds * o.x + b) * di;
+                        o.y = __builtin_floorf(ds * o.y + b) * di;
+                        o.z = __builtin_floorf(ds * o.z + b) * di;
+                        o.w = __builtin_floorf(ds * o.w + b) * di;
+                    }
+                    if (p.epi.has_scale) {
+                        o.x *= p.epi.scale; o.y *= p.epi.scale; o.z *= p.epi.scale; o.w *= p.epi.scale;
+                    }
+                }
                 fcs[q] = { fragx[i], fragy, bias[j][i], dither_op >= 0 };
                 // guarded store (dispatch.c:1126-1142), guards hoisted per column / row
                 sx[q] = p.transpose ? rpos : cpos[i];
@@ -664,8 +686,14 @@ void k_polar_pp(const plh_pass p_)
                 ok[q] = cok[i] && rok;
             }
         }
-        apply_ops_n<N * N, false, LITE>(outs, p.ops, p.num_pre_ops, p.num_ops, fcs);
-        plh_store_n<N * N>(p.dst, sx, sy, ok, outs);
+        if constexpr (FAST && (N * N) % 2 == 0) {
+            plh_store_rgba16_n<N * N>(p.dst, sx, sy, ok, outs);
+        } else if constexpr (FAST) {
+            plh_store_n<N * N>(p.dst, sx, sy, ok, outs);
+        } else {
+            apply_ops_n<N * N, false, LITE>(outs, p.ops, p.num_pre_ops, p.num_ops, fcs);
+            plh_store_n<N * N>(p.dst, sx, sy, ok, outs);
+        }
 
         // ---- pixels whose own phase is not the tabulated one: the per-pixel path, one inlined
         // copy for all of the lane's pixels (a function call would cost scratch traffic) ------
@@ -703,17 +731,56 @@ template <typename T, uint32_t MASK>
 static int launch_pp(hipStream_t stream, const plh_pass *pass, dim3 grid, dim3 block, size_t shmem,
                      int n)
 {
-    const bool lite = !pass->num_pre_ops && plh_ops_lite(pass, 0, pass->num_ops);
-    if (n == 2 && lite)
-        hipLaunchKernelGGL((k_polar_pp<T, MASK, 2, true>), grid, block, shmem, stream, *pass);
-    else if (n == 2)
-        hipLaunchKernelGGL((k_polar_pp<T, MASK, 2, false>), grid, block, shmem, stream, *pass);
-    else if (lite)
-        hipLaunchKernelGGL((k_polar_pp<T, MASK, 1, true>), grid, block, shmem, stream, *pass);
-    else
-        hipLaunchKernelGGL((k_polar_pp<T, MASK, 1, false>), grid, block, shmem, stream, *pass);
+    const bool lite = plh_ops_lite(pass, 0, pass->num_ops);
+    const bool fast = lite && pass->epi.enabled;
+#define LAUNCH(N, L, F) \
+    hipLaunchKernelGGL((k_polar_pp<T, MASK, N, L, F>), grid, block, shmem, stream, *pass)
+    if (n == 2) {
+        if (fast)      LAUNCH(2, true, true);
+        else if (lite) LAUNCH(2, true, false);
+        else           LAUNCH(2, false, false);
+    } else {
+        if (fast)      LAUNCH(1, true, true);
+        else if (lite) LAUNCH(1, true, false);
+        else           LAUNCH(1, false, false);
+    }
+#undef LAUNCH
     const hipError_t err = hipGetLastError();
     return err == hipSuccess ? 0 : -(int) err;
+}
+
+// Does the post-op chain match the fused epilogue (struct plh_fast_epi)?
+static void match_fast_epilogue(plh_pass *pass)
+{
+    plh_fast_epi &e = pass->epi;
+    e = plh_fast_epi{};
+    if (pass->dst.fmt != PLH_FMT_RGBA16 || pass->transpose)
+        return;
+    int i = pass->num_pre_ops;
+    if (i < pass->num_ops && pass->ops[i].kind == PLH_OP_DITHER) {
+        const plh_op &op = pass->ops[i];
+        const int size = op.i0;
+        const bool plain = op.i1 == 0 && !op.i2 && size > 0 && !(size & (size - 1)) &&
+                           !(op.f[1] != 1.0f && (int) op.f[3] <= 4);
+        if (!plain)
+            return;
+        e.has_dither = 1;
+        e.size = size;
+        e.mask = size - 1;
+        e.matrix = (const float *) op.ptr;
+        e.dscale = op.f[0];
+        e.dinv = op.f[8];
+        i++;
+    }
+    if (i < pass->num_ops && pass->ops[i].kind == PLH_OP_SCALE) {
+        const float *f = pass->ops[i].f;
+        if (f[0] != f[1] || f[0] != f[2] || f[0] != f[3])
+            return;
+        e.has_scale = 1;
+        e.scale = f[0];
+        i++;
+    }
+    e.enabled = i == pass->num_ops;
 }
 
 template <typename T>
@@ -769,8 +836,11 @@ static int launch_mask(hipStream_t stream, const plh_pass *pass, dim3 grid, dim3
     }
 }
 
-int plh_launch_polar(hipStream_t stream, const plh_pass *pass)
+int plh_launch_polar(hipStream_t stream, const plh_pass *pass_in)
 {
+    plh_pass local = *pass_in;
+    match_fast_epilogue(&local);
+    const plh_pass *pass = &local;
     const dim3 block(POLAR_BW, POLAR_BH);
     const uint32_t cm = pass->s.comp_mask & 0xf;
     if (pass->s.pp && (cm == 0x7 || cm == 0xf)) {

@@ -187,6 +187,19 @@ struct plh_op {
 #define PLH_PEAK_WORDS 816
 #define PLH_PEAK_COPIES 64
 
+// Fused epilogue of the polar kernel for the renderer's common output tail
+// ([dither (LUT, power-of-two matrix, not temporal)] [uniform scale] -> rgba16 store):
+// parameters at fixed offsets, so they live in SGPRs for the whole kernel instead of being
+// decoded by the op interpreter for every pixel. Filled by plh_launch_polar.
+struct plh_fast_epi {
+    int32_t enabled;
+    int32_t has_dither, has_scale;
+    int32_t size, mask;         // dither matrix size (power of two) and size - 1
+    const float *matrix;
+    float dscale, dinv;         // 2^depth - 1 and its reciprocal
+    float scale;                // color *= scale
+};
+
 struct plh_pass {
     struct plh_sampler_args s;
 
@@ -206,6 +219,8 @@ struct plh_pass {
     // k_pass: a lane owns the 2x2 outputs [2c - pad, 2c - pad + 2) per axis; the pad that
     // makes the four bilinear footprints of a 2x upscale coincide is chosen by the host
     int32_t cell_padx, cell_pady;
+
+    struct plh_fast_epi epi;
 
     // peak detection side output (k_peak): the 816-word measurement buffer and a zeroed
     // scratch area of PLH_PEAK_COPIES such buffers that spreads the per-workgroup atomics
