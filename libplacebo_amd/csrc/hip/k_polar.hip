@@ -454,11 +454,10 @@ void k_polar_pp(const plh_pass p_)
             const int sx = plh_wrap(ox + tx, s.src.w, s.address_mode);
             const int sy = plh_wrap(oy + ty, s.src.h, s.address_mode);
             float4_t c = plh_fetch(s.src, sx, sy);
-            if constexpr (!LITE) {
-                if (p.num_pre_ops) {
-                    const frag_t fc = { (float) sx + 0.5f, (float) sy + 0.5f };
-                    apply_ops(c, p.ops, 0, p.num_pre_ops, fc);
-                }
+            if (p.num_pre_ops) {
+                // fused "PASS A": the ops the reference runs in a separate pass before the scaler
+                const frag_t fc = { (float) sx + 0.5f, (float) sy + 0.5f };
+                apply_ops<false, LITE>(c, p.ops, 0, p.num_pre_ops, fc);
             }
             tile_put(tile[i], c);
         }

@@ -500,6 +500,44 @@ fallback:
     pl_shader_sample_direct(sh, src);
 }
 
+// PASS A fusion (not in the reference, which always renders `pre` into an FBO before a complex
+// scaler, renderer.c:2064): if the main scaler is a polar one and `pre` - everything recorded
+// so far - is a plain fetch of the whole plane followed by colour ops, the polar kernel runs
+// those ops on the source texels while it stages them, with the FBO's rgba16hf rounding, and
+// the intermediate pass (one full-frame write + read) disappears. Same values, one pass less.
+static bool try_fused_polar(struct pass_state *pass, pl_shader sh, const struct pl_sample_src *src,
+                            pl_shader pre, int fbo_w, int fbo_h)
+{
+    const struct pl_render_params *params = pass->params;
+    pl_renderer rr = pass->rr;
+    const char *env = getenv("PL_HIP_NO_FUSION");
+    if (!pre || (env && env[0] == '1'))
+        return false;
+    pl_fmt fbofmt = pass->fbofmt[pass->img.comps];
+    if (!fbofmt || fbofmt->type != PL_FMT_FLOAT || fbofmt->component_depth[0] != 16)
+        return false; // the fused tile rounds to f16: only valid if the FBO would too
+
+    // sample_src_info wants a texture for its format checks: the FBO that would be used
+    struct pl_sample_src probe = *src;
+    const struct pl_tex_params tp = { .w = fbo_w, .h = fbo_h, .format = fbofmt };
+    const struct pl_tex_t fake = { .params = tp };
+    probe.tex = &fake;
+    const struct sampler_info info = sample_src_info(pass, &probe, SAMPLER_MAIN);
+    if (info.type != SAMPLER_COMPLEX || !info.config->polar || info.dir == SAMPLER_NOOP)
+        return false;
+    if (PL_DEF(info.config->antiring, params->antiringing_strength) > 0)
+        return false;
+
+    struct pl_sample_filter_params fparams = {
+        .filter      = *info.config,
+        .antiring    = params->antiringing_strength,
+        .no_widening = params->skip_anti_aliasing,
+        .lut         = info.dir == SAMPLER_UP ? &rr->sampler_main.upscaler_state
+                                              : &rr->sampler_main.downscaler_state,
+    };
+    return plh_shader_sample_polar_fused(sh, pre, &probe, &fparams);
+}
+
 /* ---- frame fix-ups (:3068-3293) -------------------------------------------------------------- */
 
 static void default_rect(pl_rect2df *rc, const pl_rect2df *backup)
@@ -959,14 +997,20 @@ static bool pass_scale_main(struct pass_state *pass)
     if (use_sigmoid)
         pl_shader_sigmoidize(img_sh(pass, img), params->sigmoid_params);
 
-    // ---- PASS A: everything recorded so far lands in an FBO ----
-    src.tex = img_tex(pass, img);
-    if (!src.tex)
-        return false;
+    // ---- PASS A: everything recorded so far lands in an FBO (or is fused, see above) ----
+    pl_shader sh = pl_dispatch_begin(rr->dp);
+    if (img->sh && try_fused_polar(pass, sh, &src, img->sh, img->w, img->h)) {
+        pl_dispatch_abort(rr->dp, &img->sh);
+    } else {
+        src.tex = img_tex(pass, img);
+        if (!src.tex) {
+            pl_dispatch_abort(rr->dp, &sh);
+            return false;
+        }
+        dispatch_sampler(pass, sh, &rr->sampler_main, SAMPLER_MAIN, &src);
+    }
     pass->need_peak_fbo = false;
 
-    pl_shader sh = pl_dispatch_begin(rr->dp);
-    dispatch_sampler(pass, sh, &rr->sampler_main, SAMPLER_MAIN, &src);
     img->tex  = NULL;
     img->sh   = sh;
     img->w    = src.new_w;

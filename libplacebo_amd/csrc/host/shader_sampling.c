@@ -319,8 +319,17 @@ static int polar_taps_gather(uint32_t *taps, pl_filter filter, int bound, bool u
 #define POLAR_BW 32
 #define POLAR_BH 8
 
+static bool sample_polar(pl_shader sh, const struct pl_sample_src *src,
+                         const struct pl_sample_filter_params *params, bool force_f16_tile);
+
 bool pl_shader_sample_polar(pl_shader sh, const struct pl_sample_src *src,
                             const struct pl_sample_filter_params *params)
+{
+    return sample_polar(sh, src, params, false);
+}
+
+static bool sample_polar(pl_shader sh, const struct pl_sample_src *src,
+                         const struct pl_sample_filter_params *params, bool force_f16_tile)
 {
     if (!params->filter.polar) {
         SH_FAIL(sh, "Trying to use polar sampling with a non-polar filter?");
@@ -411,7 +420,7 @@ bool pl_shader_sample_polar(pl_shader sh, const struct pl_sample_src *src,
     // (+2: one texel of rounding slack per side, see k_polar.hip)
     const int padding = 2 * bound - 1;
     const float margin = 1e-5;
-    const bool fp32_tile = src->tex->params.format->component_depth[0] > 16;
+    const bool fp32_tile = !force_f16_tile && src->tex->params.format->component_depth[0] > 16;
     const size_t texel = fp32_tile ? 16 : 8;
     const size_t max_lds = 160 * 1024 / 2; // keep two workgroups per CU resident
     int rows = 4, tile_w, tile_h;
@@ -822,6 +831,62 @@ void plh_polar_pp_setup(pl_gpu gpu, pl_log log, void *polar_obj, struct plh_pass
     s->tile_w = obj->pp_tile_w;
     s->tile_h = obj->pp_tile_h;
     s->tile_rows = obj->pp_rows;
+}
+
+
+/* ---- PASS A fusion ------------------------------------------------------------------------------ */
+
+bool plh_shader_sample_polar_fused(pl_shader sh, const pl_shader pre,
+                                   const struct pl_sample_src *src,
+                                   const struct pl_sample_filter_params *params)
+{
+    const struct plh_pass *pp = &pre->pass;
+    pl_tex tex = pre->src_tex;
+    if (!tex || pre->failed || pre->kind != PLH_SHADER_PASS || pre->detect_peak)
+        return false;
+    // `pre` must be an identity fetch of the whole texture: then FBO texel (i, j) would hold
+    // f16(ops(texel (i, j))), including what clamped reads beyond the edges see
+    if (pp->s.type != PLH_SAMPLE_NEAREST && !(pp->s.type == PLH_SAMPLE_BILINEAR && pp->s.rect_on_grid))
+        return false;
+    const pl_rect2df *rc = &pre->src_rect;
+    if (rc->x0 != 0 || rc->y0 != 0 || rc->x1 != tex->params.w || rc->y1 != tex->params.h)
+        return false;
+    int ow, oh;
+    if (pl_shader_output_size(pre, &ow, &oh) && (ow != tex->params.w || oh != tex->params.h))
+        return false;
+    if (src->tex->params.w != tex->params.w || src->tex->params.h != tex->params.h)
+        return false; // `src->tex` is the FBO the caller would have rendered `pre` into
+    const bool scaled = pp->s.scale != 1.0f;
+    if (pp->num_pre_ops || pp->num_ops + scaled > PLH_MAX_OPS - 6)
+        return false;
+    for (int i = 0; i < pp->num_ops; i++) {
+        if (pp->ops[i].kind == PLH_OP_DITHER || pp->ops[i].kind == PLH_OP_PEAK_DETECT)
+            return false; // position dependent / needs its own kernel
+    }
+
+    struct pl_sample_src fsrc = *src;
+    fsrc.tex = tex;
+    fsrc.address_mode = pp->s.address_mode;
+    if (!sample_polar(sh, &fsrc, params, true))
+        return false;
+
+    // sample -> * scale -> ops, per source texel; the f16 tile rounds like the FBO store would
+    struct plh_pass *p = &sh->pass;
+    int n = 0;
+    if (scaled) {
+        struct plh_op *op = &p->ops[n++];
+        memset(op, 0, sizeof(*op));
+        op->kind = PLH_OP_SCALE;
+        op->f[0] = op->f[1] = op->f[2] = op->f[3] = pp->s.scale;
+    }
+    memcpy(&p->ops[n], pp->ops, pp->num_ops * sizeof(struct plh_op));
+    n += pp->num_ops;
+    p->num_pre_ops = p->num_ops = n;
+    for (int i = 0; i < pre->num_held; i++)
+        sh_hold(sh, pre->held[i]);
+    sh_listf(sh, "fused_pre_ops(%d ops of '%s' run per source texel, f16 tile)\n", n,
+             pre->description);
+    return true;
 }
 
 /* ---- separable (orthogonal) filters: pl_shader_sample_ortho2, sampling.c:950-1104 -------- */

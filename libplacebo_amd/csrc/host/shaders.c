@@ -260,12 +260,14 @@ bool sh_bind(pl_shader sh, pl_tex tex, enum pl_tex_address_mode address_mode,
     struct plh_sampler_args *s = &sh->pass.s;
     plh_tex_view(tex, &s->src);
     s->address_mode = address_mode;
+    sh->src_tex = tex;
 
     // vertex attribute tex_coord = rect / tex_size at the 4 corners, in the
     // reference's order {x0,y0}, {x1,y0}, {x0,y1}, {x1,y1} (shaders.c:497-502)
     const float sx = 1.0 / tex->params.w, sy = 1.0 / tex->params.h;
     const pl_rect2df full = { .x1 = tex->params.w, .y1 = tex->params.h };
     rect = PL_DEF(rect, &full);
+    sh->src_rect = *rect;
     const float x0 = sx * rect->x0, y0 = sy * rect->y0,
                 x1 = sx * rect->x1, y1 = sy * rect->y1;
     s->pos[0][0] = x0; s->pos[0][1] = y0;

@@ -62,7 +62,21 @@ struct pl_shader_t {
     struct plh_errdiff_args *errdiff;
     // polar sampler state, for the launch-time phase-class setup (shader_sampling.c)
     void *polar_obj;
+    // texture and rect bound by the sampling stage (sh_bind), for pass fusion
+    pl_tex src_tex;
+    pl_rect2df src_rect;
 };
+
+struct pl_sample_src;
+struct pl_sample_filter_params;
+
+// pl_shader_sample_polar with `pre` (a recorded 1:1 on-grid fetch of a whole texture followed
+// by colour ops: the reference's PASS A) folded in as per-source-texel pre-ops: the FBO round
+// trip disappears, the numerics (ops, then rgba16hf rounding) stay. Returns false without
+// touching `sh` if `pre` cannot be fused. See renderer.c pass_scale_main.
+bool plh_shader_sample_polar_fused(pl_shader sh, const pl_shader pre,
+                                   const struct pl_sample_src *src,
+                                   const struct pl_sample_filter_params *params);
 
 // called by the dispatch once the target geometry of a POLAR pass is known
 void plh_polar_pp_setup(pl_gpu gpu, pl_log log, void *polar_obj, struct plh_pass *pass);
