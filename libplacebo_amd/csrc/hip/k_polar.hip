@@ -448,6 +448,37 @@ void k_polar_pp(const plh_pass p_)
                     *(uint2 *) &tile[i] = v[u];
             }
         }
+    } else if (s.src.fmt == PLH_FMT_RGBA16) {
+        // packed unorm16 source (the fused-PASS-A case): same batching, decode + pre-ops after
+        for (int i0 = tid; i0 < tw * th; i0 += 4 * POLAR_BW * POLAR_BH) {
+            uint2 v[4];
+            int px[4], py[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const int i = min(i0 + u * POLAR_BW * POLAR_BH, tw * th - 1);
+                const int ty = (int) (((float) i + 0.5f) * rcp_tw), tx = i - ty * tw;
+                px[u] = plh_wrap(ox + tx, s.src.w, s.address_mode);
+                py[u] = plh_wrap(oy + ty, s.src.h, s.address_mode);
+                v[u] = *(const uint2 *) ((const char *) s.src.ptr + (size_t) py[u] * s.src.pitch +
+                                         (size_t) px[u] * 8);
+            }
+            float4_t c[4];
+            frag_t fcs[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                c[u] = { plh_un16(v[u].x & 0xffff), plh_un16(v[u].x >> 16),
+                         plh_un16(v[u].y & 0xffff), plh_un16(v[u].y >> 16) };
+                fcs[u] = { (float) px[u] + 0.5f, (float) py[u] + 0.5f, 0.0f, 0 };
+            }
+            if (p.num_pre_ops)
+                apply_ops_n<4, false, LITE>(c, p.ops, 0, p.num_pre_ops, fcs);
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const int i = i0 + u * POLAR_BW * POLAR_BH;
+                if (i < tw * th)
+                    tile_put(tile[i], c[u]);
+            }
+        }
     } else {
         for (int i = tid; i < tw * th; i += POLAR_BW * POLAR_BH) {
             const int ty = (int) (((float) i + 0.5f) * rcp_tw), tx = i - ty * tw;  // exact: i < 2^22
