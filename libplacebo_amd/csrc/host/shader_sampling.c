@@ -659,6 +659,10 @@ static bool polar_pp_build(pl_gpu gpu, pl_log log, struct sh_sampler_obj *obj,
     const size_t texel = s->tile_fp32 ? 16 : 8;
     const size_t max_lds = 64 * 1024;   // >= 2 workgroups per CU
     int rows = 4, tp = 0, ntc = 0;
+    const char *env_rows = getenv("PL_HIP_PP_ROWS");     // profiling aid
+    if (env_rows && atoi(env_rows) > 0)
+        rows = PL_MIN(atoi(env_rows), 8);
+    rows = PL_MIN(rows, 64 / (POLAR_BH * n));   // the kernel stages <= 64 output rows of info
     size_t lds_w = 0;
     for (;; rows >>= 1) {
         free_axis_tiles(&tx);
