@@ -6,8 +6,8 @@
  *
  * Field names, meanings and defaults are the reference's. Not provided (out of the
  * hot-path scope): hooks, custom LUTs, ICC, overlays, film grain,
- * deinterlacing, frame mixing, distortion / cone distortion, blurred borders, rotation;
- * multi-plane (planar / subsampled) frames are the next component.
+ * deinterlacing, frame mixing, distortion / cone distortion, blurred borders, rotation.
+ * Images may be planar / subsampled; targets are single-plane.
  */
 #ifndef LIBPLACEBO_RENDERER_H_
 #define LIBPLACEBO_RENDERER_H_
@@ -146,7 +146,7 @@ struct pl_plane {
     bool flipped;
     int components;           // number of relevant components
     int component_mapping[4]; // semantic index of each component
-    float shift_x, shift_y;   // (must be 0: single reference plane)
+    float shift_x, shift_y;   // sample position relative to the reference plane's grid
 };
 
 typedef int pl_rotation;
@@ -155,7 +155,7 @@ enum {
 };
 
 struct pl_frame {
-    int num_planes;           // 1 on this backend (packed RGB(A) / XYZ / single-plane YCbCr)
+    int num_planes;           // images: 1..4 (packed, semi-planar, planar); targets: 1
     struct pl_plane planes[PL_MAX_PLANES];
 
     bool (*acquire)(pl_gpu gpu, struct pl_frame *frame);
@@ -168,6 +168,10 @@ struct pl_frame {
     pl_rotation rotation;     // must be PL_ROTATION_0
     void *user_data;
 };
+
+// Set plane shifts from a chroma sample location (applies to subsampled planes)
+PL_API void pl_frame_set_chroma_location(struct pl_frame *frame,
+                                         enum pl_chroma_location chroma_loc);
 
 // true if the frame's crop does not cover its whole reference plane
 PL_API bool pl_frame_is_cropped(const struct pl_frame *frame);

@@ -52,7 +52,8 @@ void k_deband(const plh_pass p_)
     const float mx = p.out_scale[0] * ((float) idx + 0.5f);
     const float my = p.out_scale[1] * ((float) idy + 0.5f);
     const float px = plh_attr(s.pos, 0, mx, my), py = plh_attr(s.pos, 1, mx, my);
-    const frag_t fc = { (float) (idx + p.frag_x0) + 0.5f, (float) (idy + p.frag_y0) + 0.5f, 0.0f, 0 };
+    const frag_t fc = { (float) (idx + p.frag_x0) + 0.5f, (float) (idy + p.frag_y0) + 0.5f, 0.0f, 0,
+                        mx, my };
 
     float4_t color = tex_nearest(s.src, s.address_mode, px, py);
     float res[3] = { color.x, color.y, color.z };

@@ -160,7 +160,8 @@ void k_pass_generic(const plh_pass p_)
 #pragma unroll
     for (int q = 0; q < NPX; q++) {
         const int idx = 2 * cx - p.cell_padx + (q & 1), idy = CH * cy - (CH == 2 ? p.cell_pady : 0) + (q >> 1);
-        fcs[q] = { (float) (idx + p.frag_x0) + 0.5f, (float) (idy + p.frag_y0) + 0.5f, 0.0f, 0 };
+        fcs[q] = { (float) (idx + p.frag_x0) + 0.5f, (float) (idy + p.frag_y0) + 0.5f, 0.0f, 0,
+                   p.out_scale[0] * ((float) idx + 0.5f), p.out_scale[1] * ((float) idy + 0.5f) };
         sx[q] = p.base_x + p.dir_x * (p.transpose ? idy : idx);
         sy[q] = p.base_y + p.dir_y * (p.transpose ? idx : idy);
         ok[q] = idx >= 0 && idy >= 0 && p.out_scale[0] * (float) idx < 1.0f &&

@@ -173,7 +173,8 @@ void k_pass_peak(const plh_pass p_)
         c = run_sampler_pk(p.s, px, py);
     }
 
-    const frag_t fc = { (float) (idx + p.frag_x0) + 0.5f, (float) (idy + p.frag_y0) + 0.5f };
+    const frag_t fc = { (float) (idx + p.frag_x0) + 0.5f, (float) (idy + p.frag_y0) + 0.5f, 0.0f, 0,
+                        mx, my };
     apply_ops<true>(c, p.ops, 0, p.num_ops, fc, &pk);
 
     const float fx = p.out_scale[0] * (float) idx, fy = p.out_scale[1] * (float) idy;

@@ -168,6 +168,12 @@ enum plh_op_kind {
     // renderer glue (renderer.c)
     PLH_OP_PLANE_MAP,       // color = f[0..3]; color[map[c]] = tmp[c], c < i1; i0 packs map (0xff = none)
     PLH_OP_BLEND_BG,        // color += (1 - color.a) * f[0..3]   (renderer.c:2722-2728)
+    // Another plane of the same frame, sampled at this output position (the reference's
+    // sh_subpass of a plane shader into pass_read_image, renderer.c:1874-1891):
+    //   color[map[c]] = f[8] * texel[c], c < comps. ptr = texels; i0 = w | h << 16; i1 = pitch;
+    //   i2 = fmt | comps << 8 | linear << 12 | address << 13 | on_grid << 15 | map << 16 (4 x 4
+    //   bits, 0xf = none); f[0..7] = tex_coord at the 4 corners; f[9], f[10] = |rect| in texels
+    PLH_OP_PLANE_FETCH,
 };
 
 // flags in plh_op.i1 of LINEARIZE / DELINEARIZE / PEAK_DETECT

@@ -176,6 +176,15 @@ static void drain_timing(pl_dispatch dp, struct pass_timing *t)
 static void plh_pass_choose_cells(struct plh_pass *pass)
 {
     pass->cell_padx = pass->cell_pady = 0;
+    // extra planes (PLANE_FETCH): the same identity-fetch rule as for the main sampler
+    for (int i = 0; i < pass->num_ops; i++) {
+        struct plh_op *op = &pass->ops[i];
+        if (op->kind != PLH_OP_PLANE_FETCH || !((op->i2 >> 12) & 1) || !((op->i2 >> 15) & 1))
+            continue;
+        if (fabsf(pass->width / op->f[9] - 1.0f) < 1e-6f &&
+            fabsf(pass->height / op->f[10] - 1.0f) < 1e-6f)
+            op->i2 &= ~(1 << 12);
+    }
     if (pass->s.type != PLH_SAMPLE_BILINEAR)
         return;
     // identity fetch (1:1, on the texel grid): what a texture unit returns is the texel

@@ -45,6 +45,7 @@ struct pl_renderer_t {
 
     struct sampler sampler_main;
     struct sampler sampler_src;
+    struct sampler samplers_aux[PL_MAX_PLANES];  // chroma / alpha plane scalers
     pl_shader_obj tone_map_state;
     pl_shader_obj dither_state;
     int prev_dither;
@@ -173,6 +174,8 @@ void pl_renderer_destroy(pl_renderer *p_rr)
     pl_renderer_flush_cache(rr);
     sampler_destroy(&rr->sampler_main);
     sampler_destroy(&rr->sampler_src);
+    for (int i = 0; i < PL_MAX_PLANES; i++)
+        sampler_destroy(&rr->samplers_aux[i]);
     pl_shader_obj_destroy(&rr->tone_map_state);
     pl_shader_obj_destroy(&rr->dither_state);
     pl_dispatch_destroy(&rr->dp);
@@ -538,6 +541,44 @@ static bool try_fused_polar(struct pass_state *pass, pl_shader sh, const struct 
     return plh_shader_sample_polar_fused(sh, pre, &probe, &fparams);
 }
 
+/* ---- planes (detect_plane_type :287-335, frame_ref :3048-3066) -------------------------------- */
+
+enum plane_type { PLANE_INVALID = 0, PLANE_ALPHA, PLANE_CHROMA, PLANE_LUMA, PLANE_RGB, PLANE_XYZ };
+
+static enum plane_type detect_plane_type(const struct pl_plane *plane,
+                                         const struct pl_color_repr *repr)
+{
+    if (pl_color_system_is_ycbcr_like(repr->sys)) {
+        int t = PLANE_INVALID;
+        for (int c = 0; c < plane->components; c++) {
+            switch (plane->component_mapping[c]) {
+            case PL_CHANNEL_Y: t = PL_MAX(t, PLANE_LUMA); continue;
+            case PL_CHANNEL_A: t = PL_MAX(t, PLANE_ALPHA); continue;
+            case PL_CHANNEL_CB:
+            case PL_CHANNEL_CR: t = PL_MAX(t, PLANE_CHROMA); continue;
+            default: continue;
+            }
+        }
+        return t;
+    }
+    if (plane->components == 1 && plane->component_mapping[0] == PL_CHANNEL_A)
+        return PLANE_ALPHA;
+    return repr->sys == PL_COLOR_SYSTEM_XYZ ? PLANE_XYZ : PLANE_RGB;
+}
+
+static int frame_ref(const struct pl_frame *frame)
+{
+    for (int i = 0; i < frame->num_planes; i++) {
+        switch (detect_plane_type(&frame->planes[i], &frame->repr)) {
+        case PLANE_RGB: case PLANE_LUMA: case PLANE_XYZ:
+            return i;
+        default:
+            continue;
+        }
+    }
+    return 0;
+}
+
 /* ---- frame fix-ups (:3068-3293) -------------------------------------------------------------- */
 
 static void default_rect(pl_rect2df *rc, const pl_rect2df *backup)
@@ -548,9 +589,9 @@ static void default_rect(pl_rect2df *rc, const pl_rect2df *backup)
 
 bool pl_frame_is_cropped(const struct pl_frame *frame)
 {
-    if (!frame->num_planes || !frame->planes[0].texture)
+    if (!frame->num_planes || !frame->planes[frame_ref(frame)].texture)
         return false;
-    pl_tex ref = frame->planes[0].texture;
+    pl_tex ref = frame->planes[frame_ref(frame)].texture;
     pl_rect2df crop = frame->crop;
     default_rect(&crop, &(pl_rect2df) { 0, 0, ref->params.w, ref->params.h });
     pl_rect2df_normalize(&crop);
@@ -563,7 +604,8 @@ static void fix_refs_and_rects(struct pass_state *pass)
 {
     struct pl_frame *target = &pass->target, *image = &pass->image;
     pl_rect2df *dst = &target->crop, *src = &image->crop;
-    pl_tex dst_ref = target->planes[0].texture, src_ref = image->planes[0].texture;
+    pl_tex dst_ref = target->planes[frame_ref(target)].texture,
+           src_ref = image->planes[frame_ref(image)].texture;
     const int dst_w = dst_ref->params.w, dst_h = dst_ref->params.h;
 
     if ((!dst->x0 && !dst->x1) || (!dst->y0 && !dst->y1)) {
@@ -609,7 +651,7 @@ static void fix_refs_and_rects(struct pass_state *pass)
 
 static void fix_frame(struct pl_frame *frame)
 {
-    pl_tex tex = frame->planes[0].texture;
+    pl_tex tex = frame->planes[frame_ref(frame)].texture;
     if (frame->repr.sys == PL_COLOR_SYSTEM_XYZ) {
         // XYZ is implicitly converted to linear DCI-P3 in pl_color_repr_decode
         frame->color.primaries = PL_COLOR_PRIM_DCI_P3;
@@ -651,17 +693,24 @@ static void pass_fix_frames(struct pass_state *pass)
 
 static bool validate_frame(pl_renderer rr, const struct pl_frame *f, const char *what, bool dst)
 {
-    if (f->num_planes != 1 || !f->planes[0].texture) {
-        RR_ERR(rr, "%s frame has %d planes: only single-plane frames are supported by this "
-               "backend for now (planar input/output is the next component)", what,
-               f->num_planes);
+    if (f->num_planes < 1 || f->num_planes > PL_MAX_PLANES || (dst && f->num_planes != 1)) {
+        RR_ERR(rr, "%s frame has %d planes: %s", what, f->num_planes,
+               dst ? "planar output is not supported by this backend yet (next component)"
+                   : "invalid number of planes");
         return false;
     }
-    const struct pl_plane *pl = &f->planes[0];
-    if (pl->components < 1 || pl->components > 4) {
-        RR_ERR(rr, "%s plane has an invalid number of components: %d", what, pl->components);
-        return false;
+    for (int i = 0; i < f->num_planes; i++) {
+        const struct pl_plane *pi = &f->planes[i];
+        if (!pi->texture || pi->components < 1 || pi->components > 4) {
+            RR_ERR(rr, "%s plane %d: missing texture or invalid number of components", what, i);
+            return false;
+        }
+        if (!dst && !pi->texture->params.sampleable) {
+            RR_ERR(rr, "Image textures must be sampleable");
+            return false;
+        }
     }
+    const struct pl_plane *pl = &f->planes[frame_ref(f)];
     if (pl->shift_x || pl->shift_y) {
         RR_ERR(rr, "%s reference plane must have no shift", what);
         return false;
@@ -674,11 +723,21 @@ static bool validate_frame(pl_renderer rr, const struct pl_frame *f, const char 
         RR_ERR(rr, "Target texture must be storable (every pass is a compute pass)");
         return false;
     }
-    if (!dst && !pl->texture->params.sampleable) {
-        RR_ERR(rr, "Image texture must be sampleable");
-        return false;
-    }
     return true;
+}
+
+void pl_frame_set_chroma_location(struct pl_frame *frame, enum pl_chroma_location chroma_loc)
+{
+    pl_tex ref = frame->planes[frame_ref(frame)].texture;
+    for (int i = 0; i < frame->num_planes; i++) {
+        struct pl_plane *plane = &frame->planes[i];
+        pl_tex tex = plane->texture;
+        const bool apply = ref && tex
+            ? tex->params.w < ref->params.w || tex->params.h < ref->params.h
+            : detect_plane_type(plane, &frame->repr) == PLANE_CHROMA;
+        if (apply)
+            pl_chroma_location_offset(chroma_loc, &plane->shift_x, &plane->shift_y);
+    }
 }
 
 void pl_frames_infer(pl_renderer rr, struct pl_frame *image, struct pl_frame *target)
@@ -776,29 +835,84 @@ static bool plane_deband(struct pass_state *pass, struct img *img, const float n
     return true;
 }
 
+struct plane_state {
+    enum plane_type type;
+    struct pl_plane plane;
+    struct img img;
+    float plane_w, plane_h; // logical plane dimensions
+};
+
+// color = scale * texel of another shader's plain fetch, merged into `sh` (the reference's
+// sh_subpass). Returns false if `psh` is more than a plain fetch.
+static bool merge_plane_fetch(pl_shader sh, const pl_shader psh, const struct pl_plane *plane)
+{
+    const struct plh_sampler_args *ps = &psh->pass.s;
+    if (psh->pass.num_ops || psh->kind != PLH_SHADER_PASS ||
+        (ps->type != PLH_SAMPLE_NEAREST && ps->type != PLH_SAMPLE_BILINEAR))
+        return false;
+    if (ps->src.w > 0xffff || ps->src.h > 0xffff)
+        return false;
+    struct plh_op *op = sh_op(sh, PLH_OP_PLANE_FETCH);
+    if (!op)
+        return false;
+    memcpy(op->f, ps->pos, sizeof(ps->pos));
+    op->f[8] = ps->scale;
+    op->f[9] = ps->rect_w;
+    op->f[10] = ps->rect_h;
+    op->ptr = ps->src.ptr;
+    op->i0 = ps->src.w | (ps->src.h << 16);
+    op->i1 = ps->src.pitch;
+    uint32_t map = 0;
+    for (int c = 0; c < 4; c++) {
+        const int m = c < plane->components ? plane->component_mapping[c] : -1;
+        map |= (uint32_t) (m < 0 ? 0xf : m) << (4 * c);
+    }
+    op->i2 = ps->src.fmt | (plane->components << 8) |
+             ((ps->type == PLH_SAMPLE_BILINEAR) << 12) | (ps->address_mode << 13) |
+             ((ps->type == PLH_SAMPLE_BILINEAR && ps->rect_on_grid) << 15) | (map << 16);
+    sh_listf(sh, "plane_fetch(tex=%dx%d, %s, scale=%g, comps=%d, map=0x%04x)\n", ps->src.w,
+             ps->src.h, ps->type == PLH_SAMPLE_BILINEAR ? "bilinear" : "nearest", ps->scale,
+             plane->components, map);
+    for (int i = 0; i < psh->num_held; i++)
+        sh_hold(sh, psh->held[i]);
+    return true;
+}
+
 static bool pass_read_image(struct pass_state *pass)
 {
     const struct pl_render_params *params = pass->params;
     struct pl_frame *image = &pass->image;
     pl_renderer rr = pass->rr;
-    struct pl_plane plane = image->planes[0];
+    const int src_ref = frame_ref(image);
 
-    struct img pimg = {
-        .w = plane.texture->params.w,
-        .h = plane.texture->params.h,
-        .tex = plane.texture,
-        .repr = image->repr,
-        .color = image->color,
-        .comps = plane.components,
-    };
-
-    // an overridden alpha mode drops the alpha channel
-    if (image->repr.alpha == PL_ALPHA_NONE) {
-        for (int j = 0; j < plane.components; j++) {
-            if (plane.component_mapping[j] == PL_CHANNEL_A)
-                plane.component_mapping[j] = PL_CHANNEL_NONE;
+    struct plane_state planes[PL_MAX_PLANES];
+    struct plane_state *ref = &planes[src_ref];
+    for (int i = 0; i < image->num_planes; i++) {
+        planes[i] = (struct plane_state) {
+            .type = detect_plane_type(&image->planes[i], &image->repr),
+            .plane = image->planes[i],
+            .img = {
+                .w = image->planes[i].texture->params.w,
+                .h = image->planes[i].texture->params.h,
+                .tex = image->planes[i].texture,
+                .repr = image->repr,
+                .color = image->color,
+                .comps = image->planes[i].components,
+            },
+        };
+        // an overridden alpha mode drops the alpha channel / plane
+        if (image->repr.alpha == PL_ALPHA_NONE) {
+            if (planes[i].type == PLANE_ALPHA) {
+                planes[i].type = PLANE_INVALID;
+                continue;
+            }
+            for (int j = 0; j < planes[i].plane.components; j++) {
+                if (planes[i].plane.component_mapping[j] == PL_CHANNEL_A)
+                    planes[i].plane.component_mapping[j] = PL_CHANNEL_NONE;
+            }
         }
     }
+    pl_tex ref_tex = ref->plane.texture;
 
     const int bits = image->repr.bits.sample_depth;
     const float out_scale = bits ? (1llu << bits) / ((1llu << bits) - 1.0f) : 1.0f;
@@ -808,21 +922,40 @@ static bool pass_read_image(struct pass_state *pass)
     if (!pl_color_system_is_ycbcr_like(image->repr.sys))
         neutral_chroma = neutral_luma;
 
-    pimg.rect = image->crop; // single reference plane: rrx = rry = 1, no shift
+    // sampling rect of every plane (:1724-1790)
+    for (int i = 0; i < image->num_planes; i++) {
+        struct plane_state *st = &planes[i];
+        if (!st->type)
+            continue;
+        const float rx = (float) st->plane.texture->params.w / ref_tex->params.w,
+                    ry = (float) st->plane.texture->params.h / ref_tex->params.h;
+        // integer subsampling ratios only (fractionally subsampled planes are rounded up)
+        const float rrx = rx >= 1 ? roundf(rx) : 1.0 / roundf(1.0 / rx),
+                    rry = ry >= 1 ? roundf(ry) : 1.0 / roundf(1.0 / ry);
+        const float sx = st->plane.shift_x, sy = st->plane.shift_y;
+        st->img.rect = (pl_rect2df) {
+            .x0 = (image->crop.x0 - sx) * rrx,
+            .y0 = (image->crop.y0 - sy) * rry,
+            .x1 = (image->crop.x1 - sx) * rrx,
+            .y1 = (image->crop.y1 - sy) * rry,
+        };
+        st->plane_w = ref_tex->params.w * rrx;
+        st->plane_h = ref_tex->params.h * rry;
 
-    float neutral[3] = {0.0};
-    for (int c = 0, idx = 0; c < plane.components; c++) {
-        switch (plane.component_mapping[c]) {
-        case PL_CHANNEL_Y: neutral[idx++] = neutral_luma; break;
-        case PL_CHANNEL_U: // fall through
-        case PL_CHANNEL_V: neutral[idx++] = neutral_chroma; break;
+        float neutral[3] = {0.0};
+        for (int c = 0, idx = 0; c < st->plane.components; c++) {
+            switch (st->plane.component_mapping[c]) {
+            case PL_CHANNEL_Y: neutral[idx++] = neutral_luma; break;
+            case PL_CHANNEL_U: // fall through
+            case PL_CHANNEL_V: neutral[idx++] = neutral_chroma; break;
+            }
         }
+        plane_deband(pass, &st->img, neutral);
     }
-    plane_deband(pass, &pimg, neutral);
 
     // Drop subpixel offsets from the ref rect and re-add them as part of `pass->img.rect`,
     // always rounding towards 0; drop anamorphic subpixel mismatches (:1810-1828)
-    const pl_rect2df ref_rc = pimg.rect;
+    const pl_rect2df ref_rc = ref->img.rect;
     pl_rect2d ref_rounded;
     ref_rounded.x0 = truncf(ref_rc.x0);
     ref_rounded.y0 = truncf(ref_rc.y0);
@@ -832,55 +965,72 @@ static bool pass_read_image(struct pass_state *pass)
                 stretch_x = pl_rect_w(ref_rounded) / pl_rect_w(ref_rc),
                 stretch_y = pl_rect_h(ref_rounded) / pl_rect_h(ref_rc);
 
-    const float base_x = pimg.rect.x0 - off_x, base_y = pimg.rect.y0 - off_y;
-    struct pl_sample_src src = {
-        .components = plane.components,
-        .address_mode = plane.address_mode,
-        .scale      = pl_color_repr_normalize(&pimg.repr),
-        .new_w      = pl_rect_w(ref_rounded),
-        .new_h      = pl_rect_h(ref_rounded),
-        .rect = {
-            base_x, base_y,
-            base_x + stretch_x * pl_rect_w(pimg.rect),
-            base_y + stretch_y * pl_rect_h(pimg.rect),
-        },
-    };
-    if (plane.flipped) {
-        src.rect.y0 = plane.texture->params.h - src.rect.y0;
-        src.rect.y1 = plane.texture->params.h - src.rect.y1;
+    // every plane becomes a shader producing it on the (rounded) reference grid (:1830-1872)
+    float plane_scale[PL_MAX_PLANES];
+    for (int i = 0; i < image->num_planes; i++) {
+        struct plane_state *st = &planes[i];
+        const struct pl_plane *plane = &st->plane;
+        if (!st->type)
+            continue;
+
+        const float scale_x = pl_rect_w(st->img.rect) / pl_rect_w(ref_rc),
+                    scale_y = pl_rect_h(st->img.rect) / pl_rect_h(ref_rc),
+                    base_x = st->img.rect.x0 - scale_x * off_x,
+                    base_y = st->img.rect.y0 - scale_y * off_y;
+        struct pl_sample_src src = {
+            .components = plane->components,
+            .address_mode = plane->address_mode,
+            .scale      = pl_color_repr_normalize(&st->img.repr),
+            .new_w      = pl_rect_w(ref_rounded),
+            .new_h      = pl_rect_h(ref_rounded),
+            .rect = {
+                base_x, base_y,
+                base_x + stretch_x * pl_rect_w(st->img.rect),
+                base_y + stretch_y * pl_rect_h(st->img.rect),
+            },
+        };
+        if (plane->flipped) {
+            src.rect.y0 = st->plane_h - src.rect.y0;
+            src.rect.y1 = st->plane_h - src.rect.y1;
+        }
+
+        const bool unscaled = src.rect.x0 == 0 && src.rect.y0 == 0 &&
+                              src.rect.x1 == src.new_w && src.rect.y1 == src.new_h;
+        if (st->img.sh && st->img.w == src.new_w && st->img.h == src.new_h && unscaled) {
+            // image rects are already equal, no indirect scaling needed
+        } else {
+            src.tex = img_tex(pass, &st->img);
+            if (!src.tex)
+                return false;
+            st->img.tex = NULL;
+            st->img.sh = pl_dispatch_begin(rr->dp);
+            dispatch_sampler(pass, st->img.sh, i == src_ref ? &rr->sampler_src : &rr->samplers_aux[i],
+                             SAMPLER_PLANE, &src);
+            st->img.err_enum |= PL_RENDER_ERR_SAMPLING;
+            st->img.rect.x0 = st->img.rect.y0 = 0.0f;
+            st->img.w = st->img.rect.x1 = src.new_w;
+            st->img.h = st->img.rect.y1 = src.new_h;
+            src.scale = 1.0;
+        }
+        plane_scale[i] = src.scale;
     }
 
-    const bool unscaled = src.rect.x0 == 0 && src.rect.y0 == 0 &&
-                          src.rect.x1 == src.new_w && src.rect.y1 == src.new_h;
-    if (pimg.sh && pimg.w == src.new_w && pimg.h == src.new_h && unscaled) {
-        // image rects are already equal, no indirect scaling needed
-    } else {
-        src.tex = img_tex(pass, &pimg);
-        if (!src.tex)
-            return false;
-        pimg.tex = NULL;
-        pimg.sh = pl_dispatch_begin(rr->dp);
-        dispatch_sampler(pass, pimg.sh, &rr->sampler_src, SAMPLER_PLANE, &src);
-        pimg.err_enum |= PL_RENDER_ERR_SAMPLING;
-        pimg.rect.x0 = pimg.rect.y0 = 0.0f;
-        pimg.w = pimg.rect.x1 = src.new_w;
-        pimg.h = pimg.rect.y1 = src.new_h;
-        src.scale = 1.0;
-    }
-
-    // "pass_read_image": color = (neutral_luma, neutral_chroma x2, 1); tmp = scale * plane();
-    // color[mapping[c]] = tmp[c]                                                  (:1790-1890)
-    pl_shader sh = img_sh(pass, &pimg);
-    if (src.scale != 1.0f) {
+    // "pass_read_image": color = (neutral_luma, neutral_chroma x2, 1); per plane
+    // tmp = scale * plane(); color[mapping[c]] = tmp[c]                            (:1790-1890)
+    // The reference plane's shader is the pass itself; the other planes are fetched into it.
+    pl_shader sh = img_sh(pass, &ref->img);
+    ref->img.sh = NULL;
+    if (plane_scale[src_ref] != 1.0f) {
         struct plh_op *op = sh_op(sh, PLH_OP_SCALE);
         if (!op)
             return false;
-        op->f[0] = op->f[1] = op->f[2] = op->f[3] = src.scale;
-        sh_listf(sh, "scale(%g)\n", src.scale);
+        op->f[0] = op->f[1] = op->f[2] = op->f[3] = plane_scale[src_ref];
+        sh_listf(sh, "scale(%g)\n", plane_scale[src_ref]);
     }
-    bool trivial = plane.components == 4;
-    for (int c = 0; c < plane.components; c++)
-        trivial &= plane.component_mapping[c] == c;
+    const struct pl_plane *rplane = &ref->plane;
+    bool trivial = rplane->components == 4 && image->num_planes == 1;
+    for (int c = 0; c < rplane->components; c++)
+        trivial &= rplane->component_mapping[c] == c;
     if (!trivial) {
         struct plh_op *op = sh_op(sh, PLH_OP_PLANE_MAP);
         if (!op)
@@ -888,25 +1038,54 @@ static bool pass_read_image(struct pass_state *pass)
         op->f[0] = neutral_luma;
         op->f[1] = op->f[2] = neutral_chroma;
         op->f[3] = 1.0f;
-        op->i1 = plane.components;
+        op->i1 = rplane->components;
         op->i0 = 0;
         for (int c = 0; c < 4; c++) {
-            const int m = c < plane.components ? plane.component_mapping[c] : -1;
+            const int m = c < rplane->components ? rplane->component_mapping[c] : -1;
             op->i0 |= (m < 0 ? 0xff : m) << (8 * c);
         }
-        sh_listf(sh, "plane_map(comps=%d, map=0x%08x, neutral=%g/%g)\n", plane.components,
+        sh_listf(sh, "plane_map(comps=%d, map=0x%08x, neutral=%g/%g)\n", rplane->components,
                  (unsigned) op->i0, neutral_luma, neutral_chroma);
+    }
+
+    for (int i = 0; i < image->num_planes; i++) {
+        struct plane_state *st = &planes[i];
+        if (!st->type || i == src_ref)
+            continue;
+        pl_shader psh = img_sh(pass, &st->img);
+        if (plane_scale[i] != 1.0f || !merge_plane_fetch(sh, psh, &st->plane)) {
+            // not a plain fetch (debanded / scaled by a complex filter): render it, fetch 1:1
+            st->img.sh = psh;
+            if (plane_scale[i] != 1.0f) {
+                struct plh_op *op = sh_op(psh, PLH_OP_SCALE);
+                if (op)
+                    op->f[0] = op->f[1] = op->f[2] = op->f[3] = plane_scale[i];
+            }
+            st->img.comps = st->plane.components;
+            if (!img_tex(pass, &st->img)) {
+                pl_dispatch_abort(rr->dp, &sh);
+                return false;
+            }
+            psh = img_sh(pass, &st->img);
+            if (!merge_plane_fetch(sh, psh, &st->plane)) {
+                pl_dispatch_abort(rr->dp, &psh);
+                pl_dispatch_abort(rr->dp, &sh);
+                return false;
+            }
+        }
+        pl_dispatch_abort(rr->dp, &psh);
+        st->img.sh = NULL;
     }
 
     pass->img = (struct img) {
         .sh     = sh,
         .w      = pl_rect_w(ref_rounded),
         .h      = pl_rect_h(ref_rounded),
-        .repr   = pimg.repr,
+        .repr   = ref->img.repr,
         .color  = image->color,
-        .comps  = pimg.repr.alpha == PL_ALPHA_NONE ? 3 : 4,
+        .comps  = ref->img.repr.alpha == PL_ALPHA_NONE ? 3 : 4,
         .rect   = { off_x, off_y, off_x + pl_rect_w(ref_rc), off_y + pl_rect_h(ref_rc) },
-        .err_msg = pimg.err_msg, .err_enum = pimg.err_enum, .err_tex = pimg.err_tex,
+        .err_msg = ref->img.err_msg, .err_enum = ref->img.err_enum, .err_tex = ref->img.err_tex,
     };
     pass->ref_rect = pass->img.rect;
 

@@ -864,7 +864,8 @@ bool plh_shader_sample_polar_fused(pl_shader sh, const pl_shader pre,
     if (pp->num_pre_ops || pp->num_ops + scaled > PLH_MAX_OPS - 6)
         return false;
     for (int i = 0; i < pp->num_ops; i++) {
-        if (pp->ops[i].kind == PLH_OP_DITHER || pp->ops[i].kind == PLH_OP_PEAK_DETECT)
+        if (pp->ops[i].kind == PLH_OP_DITHER || pp->ops[i].kind == PLH_OP_PEAK_DETECT ||
+            pp->ops[i].kind == PLH_OP_PLANE_FETCH)
             return false; // position dependent / needs its own kernel
     }
 
