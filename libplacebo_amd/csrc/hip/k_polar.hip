@@ -380,8 +380,14 @@ struct pp_rowinfo { float fc; int32_t base; int32_t woff; int32_t pad; };
 
 // LITE: the recorded ops only use the cheap cases (plh_ops_lite). FAST (implies LITE): the
 // post-ops are the fused epilogue described by p.epi and the target is rgba16.
+#ifdef PLH_PP_WAVES6
+#define PP_WAVES __attribute__((amdgpu_waves_per_eu(6, 8)))
+#else
+#define PP_WAVES
+#endif
+
 template <typename T, uint32_t MASK, int N, bool LITE, bool FAST>
-__global__ __launch_bounds__(POLAR_BW * POLAR_BH)
+__global__ __launch_bounds__(POLAR_BW * POLAR_BH) PP_WAVES
 void k_polar_pp(const plh_pass p_)
 {
     const plh_pass &p = plh_kernarg_pass();

@@ -1040,9 +1040,12 @@ static bool pass_read_image(struct pass_state *pass)
         op->f[3] = 1.0f;
         op->i1 = rplane->components;
         op->i0 = 0;
+        op->i2 = 1; // identity prefix?
         for (int c = 0; c < 4; c++) {
             const int m = c < rplane->components ? rplane->component_mapping[c] : -1;
             op->i0 |= (m < 0 ? 0xff : m) << (8 * c);
+            if (c < rplane->components && m != c)
+                op->i2 = 0;
         }
         sh_listf(sh, "plane_map(comps=%d, map=0x%08x, neutral=%g/%g)\n", rplane->components,
                  (unsigned) op->i0, neutral_luma, neutral_chroma);
