@@ -13,8 +13,9 @@
  *   color.<mask> = res;  color *= scale
  *
  * The PRNG state is uvec3(gl_FragCoord.xy, frame index); integer arithmetic
- * mod 2^32, i.e. bit-exact. sin/cos use the accurate (ocml) versions so that
- * the sample positions agree with the libm oracle except on texel boundaries.
+ * mod 2^32, i.e. bit-exact. sin/cos are the native v_sin_f32 / v_cos_f32 (as a Vulkan driver
+ * would emit); sample positions agree with the libm oracle except within ~1e-5 px of a texel
+ * boundary, where the neighbouring texel may be picked (tests: >= 99.9 % identical pixels).
  *
  * Launch shape: 64x4 lanes, one pixel per lane. 4*iterations + 1 data-dependent
  * 8..16-byte gathers per pixel within `radius` texels of it: served by L2/MALL,
@@ -65,8 +66,16 @@ void k_deband(const plh_pass p_)
         pcg3d(st, rnd);
         float dx = rnd[0] * ((float) i * s.db_radius);
         const float ang = rnd[1] * 6.283185f;       // "%f" of 2*pi
+#ifdef PLH_DEBAND_OCML_SINCOS
         const float dy = dx * sinf(ang);
         dx = dx * cosf(ang);
+#else
+        // v_sin_f32 / v_cos_f32 take revolutions: what a GLSL sin()/cos() compiles to on this
+        // hardware (mul by 1/2pi + the native instruction)
+        const float rev = ang * 0.15915494309189532f;
+        const float dy = dx * __builtin_amdgcn_sinf(rev);
+        dx = dx * __builtin_amdgcn_cosf(rev);
+#endif
         float avg[3] = {0.0f, 0.0f, 0.0f};
         const float ox[4] = { dx, -dx, -dx, dx }, oy[4] = { dy, dy, -dy, -dy };
 #pragma unroll
