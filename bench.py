@@ -286,6 +286,7 @@ def main():
                 "dst": f"{dw}x{dh} rgba16",
                 "pool": pool,
                 "api": "pl_render_image",
+                "render_errors": st.rr.errors(),   # pl_render_error bits: no stage may be disabled
                 "parallelism": f"{world} independent stream(s), one per GPU",
             },
             "roofline": roofline,

@@ -790,6 +790,38 @@ static void hdr_update_peak(struct pass_state *pass)
         goto cleanup;
     }
 
+    // The polar / separable / deband kernels own their workgroup shape, so a measurement cannot
+    // ride on them (the reference merges it into the scaler's compute shader): materialise the
+    // image and measure it with a target-less pass that only reads it. Same 16x16 tiling of the
+    // same image; the values it sees went through the FBO's f16 rounding.
+    struct img *img = &pass->img;
+    if (img->sh && pass->fbofmt[4] &&
+        (img->sh->pass.s.type == PLH_SAMPLE_POLAR || img->sh->pass.s.type == PLH_SAMPLE_ORTHO ||
+         img->sh->pass.s.type == PLH_SAMPLE_DEBAND))
+    {
+        pl_tex tex = img_tex(pass, img);
+        if (!tex)
+            goto cleanup;
+        pl_shader msh = pl_dispatch_begin(rr->dp);
+        bool mok = pl_shader_sample_direct(msh, pl_sample_src( .tex = tex )) &&
+                   pl_shader_detect_peak(msh, img->color, &rr->tone_map_state,
+                                         params->peak_detect_params);
+        if (mok) {
+            mok = pl_dispatch_compute(rr->dp, pl_dispatch_compute_params(
+                .shader = &msh, .width = tex->params.w, .height = tex->params.h,
+            ));
+        } else {
+            pl_dispatch_abort(rr->dp, &msh);
+        }
+        if (!mok) {
+            RR_WARN(rr, "Failed measuring the HDR peak.. disabling");
+            rr->errors |= PL_RENDER_ERR_PEAK_DETECT;
+            goto cleanup;
+        }
+        pass->need_peak_fbo = false; // already complete (stream order)
+        return;
+    }
+
     const bool ok = pl_shader_detect_peak(img_sh(pass, &pass->img), pass->img.color,
                                           &rr->tone_map_state, params->peak_detect_params);
     if (!ok) {

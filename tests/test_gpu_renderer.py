@@ -351,3 +351,24 @@ def test_planar_input_with_complex_chroma_scaler_and_main_upscale(gpu, rr):
     for t in texs:
         t.destroy()
     dst.destroy()
+
+
+def test_hdr_downscale_with_polar_scaler_still_measures_the_peak(gpu, rr):
+    """cfg 5 shape: HDR content through a polar *downscaler*: peak detection comes after the
+    scaler (renderer.c:2083-2084) and must not get disabled."""
+    from test_gpu_color import hdr_test_frame
+    w, h = 128, 96
+    img16 = (np.tile(hdr_test_frame(64, 48), (2, 2, 1)) * 65535 + 0.5).astype(np.uint16)
+    src = gpu.tex_create(w, h, "rgba16", img16)
+    dst = gpu.tex_create(w // 2, h // 2, "rgba16")
+    image = pl.frame(src, components=3, color=pl.color_space("bt2020", "pq", max_luma=4000.0))
+    target = pl.frame(dst, color=pl.color_space("bt709", "bt1886"))
+    params = pl.render_params("high_quality", downscaler=pl.filter_config("ewa_lanczos"))
+    assert rr.render(image, target, params), gpu.messages[-4:]
+    assert rr.errors() == 0, rr.errors()
+    meta = capi.HdrMetadata()
+    assert pl.lib().pl_renderer_get_hdr_metadata(rr.rr, C.byref(meta))
+    assert 0.4 < meta.max_pq_y < 0.76
+    out = orc.tex_decode(dst.download(), "rgba16")
+    assert 0.02 < out[..., :3].mean() < 0.9
+    src.destroy(); dst.destroy()
