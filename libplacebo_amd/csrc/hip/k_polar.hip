@@ -709,7 +709,9 @@ void k_polar_pp(const plh_pass p_)
                         o.x = __builtin_floorf(ds * o.x + b) * di;
                         o.y = __builtin_floorf(ds * o.y + b) * di;
                         o.z = __builtin_floorf(ds * o.z + b) * di;
-                        o.w = __builtin_floorf(ds * o.w + b) * di;
+                        // alpha: when it is not sampled it is 1.0, and floor(ds * 1 + b) == ds for
+                        // every bias in [0, 1) (ds = 2^depth - 1 is an integer): no per-pixel work
+                        o.w = (MASK & 8u) ? __builtin_floorf(ds * o.w + b) * di : ds * di;
                     }
                     if (p.epi.has_scale) {
                         o.x *= p.epi.scale; o.y *= p.epi.scale; o.z *= p.epi.scale; o.w *= p.epi.scale;
