@@ -46,6 +46,7 @@ struct pl_renderer_t {
     struct sampler sampler_main;
     struct sampler sampler_src;
     struct sampler samplers_aux[PL_MAX_PLANES];  // chroma / alpha plane scalers
+    struct sampler samplers_dst[PL_MAX_PLANES];  // planar output
     pl_shader_obj tone_map_state;
     pl_shader_obj dither_state;
     int prev_dither;
@@ -174,8 +175,10 @@ void pl_renderer_destroy(pl_renderer *p_rr)
     pl_renderer_flush_cache(rr);
     sampler_destroy(&rr->sampler_main);
     sampler_destroy(&rr->sampler_src);
-    for (int i = 0; i < PL_MAX_PLANES; i++)
+    for (int i = 0; i < PL_MAX_PLANES; i++) {
         sampler_destroy(&rr->samplers_aux[i]);
+        sampler_destroy(&rr->samplers_dst[i]);
+    }
     pl_shader_obj_destroy(&rr->tone_map_state);
     pl_shader_obj_destroy(&rr->dither_state);
     pl_dispatch_destroy(&rr->dp);
@@ -693,10 +696,8 @@ static void pass_fix_frames(struct pass_state *pass)
 
 static bool validate_frame(pl_renderer rr, const struct pl_frame *f, const char *what, bool dst)
 {
-    if (f->num_planes < 1 || f->num_planes > PL_MAX_PLANES || (dst && f->num_planes != 1)) {
-        RR_ERR(rr, "%s frame has %d planes: %s", what, f->num_planes,
-               dst ? "planar output is not supported by this backend yet (next component)"
-                   : "invalid number of planes");
+    if (f->num_planes < 1 || f->num_planes > PL_MAX_PLANES) {
+        RR_ERR(rr, "%s frame has an invalid number of planes: %d", what, f->num_planes);
         return false;
     }
     for (int i = 0; i < f->num_planes; i++) {
@@ -709,6 +710,10 @@ static bool validate_frame(pl_renderer rr, const struct pl_frame *f, const char 
             RR_ERR(rr, "Image textures must be sampleable");
             return false;
         }
+        if (dst && !pi->texture->params.storable) {
+            RR_ERR(rr, "Target textures must be storable (every pass is a compute pass)");
+            return false;
+        }
     }
     const struct pl_plane *pl = &f->planes[frame_ref(f)];
     if (pl->shift_x || pl->shift_y) {
@@ -717,10 +722,6 @@ static bool validate_frame(pl_renderer rr, const struct pl_frame *f, const char 
     }
     if (f->rotation % PL_ROTATION_360 != PL_ROTATION_0) {
         RR_ERR(rr, "Rotation is not supported by this backend yet");
-        return false;
-    }
-    if (dst && !pl->texture->params.storable) {
-        RR_ERR(rr, "Target texture must be storable (every pass is a compute pass)");
         return false;
     }
     return true;
@@ -1386,7 +1387,7 @@ static bool pass_output_target(struct pass_state *pass)
 {
     const struct pl_render_params *params = pass->params;
     const struct pl_frame *target = &pass->target;
-    const struct pl_plane *plane = &target->planes[0];
+    const struct pl_plane *plane = &target->planes[frame_ref(target)];
     pl_renderer rr = pass->rr;
     struct img *img = &pass->img;
     pl_shader sh = img_sh(pass, img);
@@ -1442,8 +1443,8 @@ static bool pass_output_target(struct pass_state *pass)
     const bool flipped_x = dst_rect.x1 < dst_rect.x0, flipped_y = dst_rect.y1 < dst_rect.y0;
 
     if (need_clear && params->border != PL_CLEAR_SKIP) {
-        // clear_target (:2410-2555), PL_CLEAR_COLOR flavour
-        float bg[3], clear[4];
+        // clear_target (:2410-2555), PL_CLEAR_COLOR flavour, every plane
+        float bg[3];
         translate_srgb_color(bg, params->background_color, &target->color);
         float enc[3] = { bg[0], bg[1], bg[2] };
         struct pl_color_repr crepr = target->repr;
@@ -1451,72 +1452,126 @@ static bool pass_output_target(struct pass_state *pass)
         pl_transform3x3_invert(&tr);
         pl_transform3x3_apply(&tr, enc);
         const float alpha = 1.0 - params->background_transparency;
-        const int *map = plane->component_mapping;
-        for (int c = 0; c < 4; c++) {
-            const int m = c < plane->components ? map[c] : -1;
-            clear[c] = m == PL_CHANNEL_A ? alpha : m >= 0 && m < 3 ? enc[m] / scale : 0.0f;
-        }
-        pl_tex_clear(rr->gpu, plane->texture, clear);
-    }
-
-    pl_rect2df plane_rectf = { dst_rect.x0, dst_rect.y0, dst_rect.x1, dst_rect.y1 };
-    pl_rect2df_normalize(&plane_rectf);
-    const int rx0 = floorf(plane_rectf.x0), ry0 = floorf(plane_rectf.y0),
-              rx1 =  ceilf(plane_rectf.x1), ry1 =  ceilf(plane_rectf.y1);
-
-    img->sh = NULL;
-
-    // > 16-bit outputs are not dithered by default (:2884-2900)
-    const int depth = target->repr.bits.color_depth;
-    int applied_dither = 0;
-    if (depth && (depth < 16 || params->force_dither)) {
-        if (pass_error_diffusion(pass, &sh, depth, plane->components, rx1 - rx0, ry1 - ry0)) {
-            applied_dither = depth;
-        } else if (params->dither_params) {
-            struct pl_dither_params dparams = *params->dither_params;
-            if (!params->disable_dither_gamma_correction)
-                dparams.transfer = target->color.transfer;
-            pl_shader_dither(sh, depth, &rr->dither_state, &dparams);
-            applied_dither = depth;
+        for (int pi = 0; pi < target->num_planes; pi++) {
+            const struct pl_plane *cp = &target->planes[pi];
+            float clear[4];
+            for (int c = 0; c < 4; c++) {
+                const int m = c < cp->components ? cp->component_mapping[c] : -1;
+                clear[c] = m == PL_CHANNEL_A ? alpha : m >= 0 && m < 3 ? enc[m] / scale : 0.0f;
+            }
+            pl_tex_clear(rr->gpu, cp->texture, clear);
         }
     }
-    if (applied_dither != rr->prev_dither) {
-        if (applied_dither) {
-            RR_INFO(rr, "Dithering to %d bit depth", applied_dither);
-        } else {
-            RR_INFO(rr, "Dithering disabled");
+
+    pl_tex ref_tex = target->planes[frame_ref(target)].texture;
+    pl_tex img_fbo = NULL;
+    if (target->num_planes > 1) {
+        // planar output: every plane samples the finished image from an intermediate FBO
+        img->sh = sh;
+        img_fbo = img_tex(pass, img);
+        sh = NULL;
+        if (!img_fbo) {
+            RR_ERR(rr, "Output requires multiple planes, but FBOs are unavailable.");
+            return false;
         }
-        rr->prev_dither = applied_dither;
+    } else {
+        img->sh = NULL;
     }
 
-    // color *= 1 / scale                                                              (:2911)
-    struct plh_op *op = sh_op(sh, PLH_OP_SCALE);
-    if (!op) {
-        pl_dispatch_abort(rr->dp, &sh);
-        return false;
+    bool ok = true;
+    for (int pi = 0; pi < target->num_planes && ok; pi++) {
+        plane = &target->planes[pi];
+        const float prx = (float) plane->texture->params.w / ref_tex->params.w,
+                    pry = (float) plane->texture->params.h / ref_tex->params.h;
+        // integer subsampling ratios only (fractional sizes are rounded up: over-render)
+        const float rrx = prx >= 1 ? roundf(prx) : 1.0 / roundf(1.0 / prx),
+                    rry = pry >= 1 ? roundf(pry) : 1.0 / roundf(1.0 / pry);
+        const float psx = plane->shift_x, psy = plane->shift_y;
+
+        pl_rect2df plane_rectf = {
+            .x0 = (dst_rect.x0 - psx) * rrx,
+            .y0 = (dst_rect.y0 - psy) * rry,
+            .x1 = (dst_rect.x1 - psx) * rrx,
+            .y1 = (dst_rect.y1 - psy) * rry,
+        };
+        pl_rect2df_normalize(&plane_rectf);
+        const int rx0 = floorf(plane_rectf.x0), ry0 = floorf(plane_rectf.y0),
+                  rx1 =  ceilf(plane_rectf.x1), ry1 =  ceilf(plane_rectf.y1);
+
+        if (target->num_planes > 1) {
+            uint8_t mask = 0;
+            for (int c = 0; c < plane->components; c++) {
+                if (plane->component_mapping[c] >= 0)
+                    mask |= 1 << plane->component_mapping[c];
+            }
+            struct pl_sample_src src = {
+                .tex        = img_fbo,
+                .new_w      = rx1 - rx0,
+                .new_h      = ry1 - ry0,
+                .rect = {
+                    .x0 = (rx0 - plane_rectf.x0) / rrx,
+                    .x1 = (rx1 - plane_rectf.x0) / rrx,
+                    .y0 = (ry0 - plane_rectf.y0) / rry,
+                    .y1 = (ry1 - plane_rectf.y0) / rry,
+                },
+                .component_mask = mask,
+            };
+            sh = pl_dispatch_begin(rr->dp);
+            dispatch_sampler(pass, sh, &rr->samplers_dst[pi], SAMPLER_PLANE, &src);
+        }
+
+        // > 16-bit outputs are not dithered by default (:2884-2900)
+        const int depth = target->repr.bits.color_depth;
+        int applied_dither = 0;
+        if (depth && (depth < 16 || params->force_dither)) {
+            if (pass_error_diffusion(pass, &sh, depth, plane->components, rx1 - rx0, ry1 - ry0)) {
+                applied_dither = depth;
+            } else if (params->dither_params) {
+                struct pl_dither_params dparams = *params->dither_params;
+                if (!params->disable_dither_gamma_correction)
+                    dparams.transfer = target->color.transfer;
+                pl_shader_dither(sh, depth, &rr->dither_state, &dparams);
+                applied_dither = depth;
+            }
+        }
+        if (applied_dither != rr->prev_dither) {
+            if (applied_dither) {
+                RR_INFO(rr, "Dithering to %d bit depth", applied_dither);
+            } else {
+                RR_INFO(rr, "Dithering disabled");
+            }
+            rr->prev_dither = applied_dither;
+        }
+
+        // color *= 1 / scale                                                          (:2911)
+        struct plh_op *op = sh_op(sh, PLH_OP_SCALE);
+        if (!op) {
+            pl_dispatch_abort(rr->dp, &sh);
+            return false;
+        }
+        op->f[0] = op->f[1] = op->f[2] = op->f[3] = 1.0f / scale;
+        sh_listf(sh, "scale(1/%g)\n", scale);
+
+        record_swizzle(sh, plane->components, plane->component_mapping);
+
+        pl_rect2d plane_rect = {
+            .x0 = flipped_x ? rx1 : rx0,
+            .x1 = flipped_x ? rx0 : rx1,
+            .y0 = flipped_y ? ry1 : ry0,
+            .y1 = flipped_y ? ry0 : ry1,
+        };
+        if (plane->flipped) {
+            const int plane_h = rry * ref_tex->params.h;
+            plane_rect.y0 = plane_h - plane_rect.y0;
+            plane_rect.y1 = plane_h - plane_rect.y1;
+        }
+
+        ok = pl_dispatch_finish(rr->dp, pl_dispatch_params(
+            .shader = &sh,
+            .target = plane->texture,
+            .rect = plane_rect,
+        ));
     }
-    op->f[0] = op->f[1] = op->f[2] = op->f[3] = 1.0f / scale;
-    sh_listf(sh, "scale(1/%g)\n", scale);
-
-    record_swizzle(sh, plane->components, plane->component_mapping);
-
-    pl_rect2d plane_rect = {
-        .x0 = flipped_x ? rx1 : rx0,
-        .x1 = flipped_x ? rx0 : rx1,
-        .y0 = flipped_y ? ry1 : ry0,
-        .y1 = flipped_y ? ry0 : ry1,
-    };
-    if (plane->flipped) {
-        const int plane_h = plane->texture->params.h;
-        plane_rect.y0 = plane_h - plane_rect.y0;
-        plane_rect.y1 = plane_h - plane_rect.y1;
-    }
-
-    const bool ok = pl_dispatch_finish(rr->dp, pl_dispatch_params(
-        .shader = &sh,
-        .target = plane->texture,
-        .rect = plane_rect,
-    ));
     *img = (struct img) {0};
     return ok;
 }

@@ -210,7 +210,7 @@ def test_rejects_what_it_does_not_do(gpu, rr):
     t = gpu.tex_create(16, 16, "rgba16")
     f = pl.frame(t)
     f2 = pl.frame(t)
-    f2.num_planes = 2       # planar *output* is not supported (input is)
+    f2.num_planes = 5
     assert not rr.render(f, f2, pl.render_params("fast"))
     f3 = pl.frame(t)
     f3.rotation = 1
@@ -372,3 +372,74 @@ def test_hdr_downscale_with_polar_scaler_still_measures_the_peak(gpu, rr):
     out = orc.tex_decode(dst.download(), "rgba16")
     assert 0.02 < out[..., :3].mean() < 0.9
     src.destroy(); dst.destroy()
+
+
+def test_kat_ycbcr_planar_roundtrip(gpu, rr):
+    """src/tests/gpu_tests.c:1599-1731 (pl_ycbcr_tests): 4:2:0 16-bit planar -> RGB -> 4:2:0
+    planar with co-sited (top-left) chroma must round-trip within 150 / 65535."""
+    sizes = [(323, 255), (162, 128), (162, 128)]
+    src_data, src_tex, dst_tex = [], [], []
+    for i, (w, h) in enumerate(sizes):
+        y, x = np.mgrid[0:h, 0:w]
+        gx, gy = 200 + 100 * i, 300 + 150 * i
+        d = (((gx * x) ^ (gy * y)) & 0xffff).astype(np.uint16)[..., None]
+        src_data.append(d)
+        src_tex.append(gpu.tex_create(w, h, "r16", d))
+        dst_tex.append(gpu.tex_create(w, h, "r16"))
+
+    def planar(texs):
+        f = capi.Frame(num_planes=3)
+        for i, t in enumerate(texs):
+            f.planes[i].texture = t.ptr
+            f.planes[i].components = 1
+            f.planes[i].component_mapping[0] = i
+            for c in range(1, 4):
+                f.planes[i].component_mapping[c] = -1
+        f.repr = pl.color_repr("bt709", "limited")       # pl_color_repr_hdtv
+        f.color = pl.color_space("bt709", "bt1886")
+        return f
+
+    img = planar(src_tex)
+    pl.lib().pl_frame_set_chroma_location.argtypes = [C.POINTER(capi.Frame), C.c_int]
+    pl.lib().pl_frame_set_chroma_location(C.byref(img), 3)     # PL_CHROMA_TOP_LEFT
+    target = planar(dst_tex)
+    for i in range(3):
+        target.planes[i].shift_x = img.planes[i].shift_x
+        target.planes[i].shift_y = img.planes[i].shift_y
+    assert rr.render(img, target, pl.render_params("fast", dither_params=None)), gpu.messages[-4:]
+    assert rr.errors() == 0
+    for i in range(3):
+        got = dst_tex[i].download().astype(np.int64)
+        diff = np.abs(got - src_data[i].astype(np.int64))
+        assert diff.max() <= 150, (i, int(diff.max()))
+    for t in src_tex + dst_tex:
+        t.destroy()
+
+
+def test_planar_output_nv12_from_rgb(gpu, rr):
+    """RGB -> semi-planar 8-bit BT.709 limited (NV12-like), bilinear chroma downsampling."""
+    w, h = 64, 48
+    img16 = util.chirp_rgba16(w, h)
+    src = gpu.tex_create(w, h, "rgba16", img16)
+    ty, tuv = gpu.tex_create(w, h, "r8"), gpu.tex_create(w // 2, h // 2, "rg8")
+    image = pl.frame(src, components=3, color=pl.color_space("bt709", "bt1886"))
+    f = capi.Frame(num_planes=2)
+    f.planes[0].texture, f.planes[0].components = ty.ptr, 1
+    f.planes[1].texture, f.planes[1].components = tuv.ptr, 2
+    for c in range(4):
+        f.planes[0].component_mapping[c] = 0 if c == 0 else -1
+        f.planes[1].component_mapping[c] = c + 1 if c < 2 else -1
+    f.repr = pl.color_repr("bt709", "limited")
+    f.color = pl.color_space("bt709", "bt1886")
+    pl.lib().pl_frame_set_chroma_location.argtypes = [C.POINTER(capi.Frame), C.c_int]
+    pl.lib().pl_frame_set_chroma_location(C.byref(f), 1)
+    assert rr.render(image, f, pl.render_params("fast", dither_params=None)), gpu.messages[-4:]
+    assert rr.errors() == 0
+    y = ty.download()[..., 0].astype(np.float64)
+    uv = tuv.download().astype(np.float64)
+    rgb = orc.tex_decode(img16, "rgba16")[..., :3].astype(np.float64)
+    ref_y = 16 + 219 * (0.2126 * rgb[..., 0] + 0.7152 * rgb[..., 1] + 0.0722 * rgb[..., 2])
+    assert np.abs(y - ref_y).max() <= 0.6           # 8-bit rounding + the f16 intermediate
+    assert 16 <= uv.min() and uv.max() <= 240
+    for t in (src, ty, tuv):
+        t.destroy()
