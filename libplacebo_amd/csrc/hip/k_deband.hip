@@ -78,11 +78,19 @@ void k_deband(const plh_pass p_)
 #endif
         float avg[3] = {0.0f, 0.0f, 0.0f};
         const float ox[4] = { dx, -dx, -dx, dx }, oy[4] = { dy, dy, -dy, -dy };
+        int tx[4], ty[4];
 #pragma unroll
         for (int k = 0; k < 4; k++) {
-            const float4_t t = tex_nearest(s.src, s.address_mode, px + s.pt[0] * ox[k],
-                                           py + s.pt[1] * oy[k]);
-            avg[0] += t.x; avg[1] += t.y; avg[2] += t.z;
+            // textureLod(tex, pos + pt * vec2(X, Y)) with NEAREST filtering
+            const float qx = px + s.pt[0] * ox[k], qy = py + s.pt[1] * oy[k];
+            tx[k] = plh_wrap((int) __builtin_floorf(qx * (float) s.src.w), s.src.w, s.address_mode);
+            ty[k] = plh_wrap((int) __builtin_floorf(qy * (float) s.src.h), s.src.h, s.address_mode);
+        }
+        float4_t t[4];
+        plh_fetch_n<4>(s.src, tx, ty, t);   // the four gathers in flight together
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            avg[0] += t[k].x; avg[1] += t[k].y; avg[2] += t[k].z;
         }
         const float bound = s.db_threshold / (float) i;
 #pragma unroll

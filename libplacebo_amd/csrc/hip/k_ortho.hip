@@ -79,29 +79,67 @@ void k_ortho(const plh_pass p_)
 
     float ca[4] = {0.0f, 0.0f, 0.0f, 0.0f};
     float lo[4] = {1e9f, 1e9f, 1e9f, 1e9f}, hi[4] = {0.0f, 0.0f, 0.0f, 0.0f};
-    const int step = s.use_linear ? 2 : 1;
-    for (int n = 0; n < N; n += step) {
-        const float w = plh_mix(r0[n], r1[n], fr);
-        float4_t c;
-        if (s.use_linear) {
-            // off = n + ws[n % 4 + 1]: one bilinear fetch between taps n and n + 1
-            const float f = plh_mix(r0[n + 1], r1[n + 1], fr);
-            c = mix4(ortho_fetch(s, first + n, o0, o1, ofrac),
-                     ortho_fetch(s, first + n + 1, o0, o1, ofrac), f);
-        } else {
-            c = ortho_fetch(s, first + n, o0, o1, ofrac);
-        }
-        const float cv[4] = { c.x, c.y, c.z, c.w };
-        if (s.use_ar && (n == N / 2 - 1 || n == N / 2)) {
+    if (!s.use_linear && !s.linear) {
+        // common case: one texel per tap. Eight taps per batch so that their loads overlap
+        // (a per-tap plh_fetch costs one memory round trip per tap).
+        const int n_axis = s.dir ? s.src.h : s.src.w;
+        for (int n0 = 0; n0 < N; n0 += 8) {
+            int tx[8], ty[8];
+            float w[8];
 #pragma unroll
-            for (int k = 0; k < 4; k++) {
-                lo[k] = fminf(lo[k], cv[k]);
-                hi[k] = fmaxf(hi[k], cv[k]);
+            for (int u = 0; u < 8; u++) {
+                const int n = min(n0 + u, N - 1);
+                const int iw = plh_wrap(first + n, n_axis, s.address_mode);
+                tx[u] = s.dir ? o0 : iw;
+                ty[u] = s.dir ? iw : o0;
+                w[u] = plh_mix(r0[n], r1[n], fr);
+            }
+            float4_t t[8];
+            plh_fetch_n<8>(s.src, tx, ty, t);
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+                const int n = n0 + u;
+                if (n >= N)
+                    continue;
+                const float cv[4] = { t[u].x, t[u].y, t[u].z, t[u].w };
+                if (s.use_ar && (n == N / 2 - 1 || n == N / 2)) {
+#pragma unroll
+                    for (int k = 0; k < 4; k++) {
+                        lo[k] = fminf(lo[k], cv[k]);
+                        hi[k] = fmaxf(hi[k], cv[k]);
+                    }
+                }
+#pragma unroll
+                for (int k = 0; k < 4; k++)
+                    ca[k] = __builtin_fmaf(w[u], cv[k], ca[k]);
             }
         }
+    } else {
+        // linear-trick filters and passes that are off the texel grid across the axis
+        const int step = s.use_linear ? 2 : 1;
+        for (int n = 0; n < N; n += step) {
+            const float w = plh_mix(r0[n], r1[n], fr);
+            float4_t c;
+            if (s.use_linear) {
+                // off = n + ws[n % 4 + 1]: one bilinear fetch between taps n and n + 1
+                const float f = plh_mix(r0[n + 1], r1[n + 1], fr);
+                c = mix4(ortho_fetch(s, first + n, o0, o1, ofrac),
+                         ortho_fetch(s, first + n + 1, o0, o1, ofrac), f);
+            } else {
+                c = ortho_fetch(s, first + n, o0, o1, ofrac);
+            }
+            const float cv[4] = { c.x, c.y, c.z, c.w };
+            if (s.use_ar && (n == N / 2 - 1 || n == N / 2)) {
 #pragma unroll
-        for (int k = 0; k < 4; k++)
-            ca[k] = __builtin_fmaf(w, cv[k], ca[k]);
+                for (int k = 0; k < 4; k++) {
+                    lo[k] = fminf(lo[k], cv[k]);
+                    hi[k] = fmaxf(hi[k], cv[k]);
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < 4; k++)
+                ca[k] = __builtin_fmaf(w, cv[k], ca[k]);
+        }
     }
     if (s.use_ar) {
 #pragma unroll

@@ -104,11 +104,19 @@ void k_pass_generic(const plh_pass p_)
     switch (s.type) {
     case PLH_SAMPLE_NONE:
         break;
-    case PLH_SAMPLE_NEAREST:
+    case PLH_SAMPLE_NEAREST: {
+        int tx[NPX], ty[NPX];
+#pragma unroll
+        for (int q = 0; q < NPX; q++) {
+            tx[q] = plh_wrap((int) __builtin_floorf(px[q] * (float) s.src.w), s.src.w, s.address_mode);
+            ty[q] = plh_wrap((int) __builtin_floorf(py[q] * (float) s.src.h), s.src.h, s.address_mode);
+        }
+        plh_fetch_n<NPX>(s.src, tx, ty, c);
 #pragma unroll
         for (int q = 0; q < NPX; q++)
-            c[q] = scale4(tex_nearest(s.src, s.address_mode, px[q], py[q]), s.scale);
+            c[q] = scale4(c[q], s.scale);
         break;
+    }
     case PLH_SAMPLE_BILINEAR: {
         lin_fp f[NPX];
 #pragma unroll
@@ -121,23 +129,23 @@ void k_pass_generic(const plh_pass p_)
                      f[q].y0 == f[0].y0 && f[q].y1 == f[0].y1;
         }
         if (shared) {
-            const float4_t t00 = plh_fetch(s.src, f[0].x0, f[0].y0);
-            const float4_t t10 = plh_fetch(s.src, f[0].x1, f[0].y0);
-            const float4_t t01 = plh_fetch(s.src, f[0].x0, f[0].y1);
-            const float4_t t11 = plh_fetch(s.src, f[0].x1, f[0].y1);
+            const int tx[4] = { f[0].x0, f[0].x1, f[0].x0, f[0].x1 };
+            const int ty[4] = { f[0].y0, f[0].y0, f[0].y1, f[0].y1 };
+            float4_t t[4];
+            plh_fetch_n<4>(s.src, tx, ty, t);
 #pragma unroll
             for (int q = 0; q < NPX; q++) {
-                c[q] = scale4(mix4(mix4(t00, t10, f[q].ax), mix4(t01, t11, f[q].ax), f[q].ay),
+                c[q] = scale4(mix4(mix4(t[0], t[1], f[q].ax), mix4(t[2], t[3], f[q].ax), f[q].ay),
                               s.scale);
             }
         } else {
 #pragma unroll
             for (int q = 0; q < NPX; q++) {
-                const float4_t t00 = plh_fetch(s.src, f[q].x0, f[q].y0);
-                const float4_t t10 = plh_fetch(s.src, f[q].x1, f[q].y0);
-                const float4_t t01 = plh_fetch(s.src, f[q].x0, f[q].y1);
-                const float4_t t11 = plh_fetch(s.src, f[q].x1, f[q].y1);
-                c[q] = scale4(mix4(mix4(t00, t10, f[q].ax), mix4(t01, t11, f[q].ax), f[q].ay),
+                const int tx[4] = { f[q].x0, f[q].x1, f[q].x0, f[q].x1 };
+                const int ty[4] = { f[q].y0, f[q].y0, f[q].y1, f[q].y1 };
+                float4_t t[4];
+                plh_fetch_n<4>(s.src, tx, ty, t);
+                c[q] = scale4(mix4(mix4(t[0], t[1], f[q].ax), mix4(t[2], t[3], f[q].ax), f[q].ay),
                               s.scale);
             }
         }
