@@ -9,13 +9,16 @@ Workloads (BASELINE.json `configs`):
   ewa_lanczos_1080p_to_4k_dither10   configs[2], the default: the configuration the north-star
         target (">= 70 % of HBM roofline on EWA-Lanczos 1080p->4K") and the metric are quoted on.
         1920x1080 RGBA16 -> 3840x2160, EWA-Lanczos (Jinc) polar upscale + blue-noise dither to
-        10 bit in an RGBA16 target. Passes: plane -> rgba16hf FBO (the reference's PASS A,
-        renderer.c:2064), polar + dither + store.
+        10 bit in an RGBA16 target. One launch per frame: the reference's PASS A (plane ->
+        rgba16hf FBO, renderer.c:2064) is folded into the polar kernel as per-source-texel
+        pre-ops (same values, PL_HIP_NO_FUSION=1 restores the two-pass structure).
   bilinear_1080p_to_4k               configs[1]: bilinear + sRGB passthrough, one pass.
   hdr10_4k_tonemap                   configs[3]: 4K BT.2020/PQ -> BT.709 SDR, same-frame peak
         detection (histogram) + spline tone mapping + perceptual gamut mapping 3D-LUT.
   ewa_8k_to_4k_deband_tonemap        configs[4], one stream: 8K HDR -> 4K SDR, deband + EWA
         downscale + tone map.
+  ewa_1080p_to_4k_hdr_tonemap        both halves of the metric's name in one frame: 1080p HDR10
+        -> peak detect -> EWA-Lanczos 2x -> tone/gamut map -> dither -> 4K SDR.
 
 Frames rotate over a pool of source/target textures larger than the 256 MiB Infinity Cache so
 that every frame's compulsory traffic really crosses HBM.
@@ -55,6 +58,8 @@ WORKLOADS = {
     "bilinear_1080p_to_4k": (P1080, P4K, px(P1080) * 8 + px(P4K) * 8, None),
     "hdr10_4k_tonemap": (P4K, P4K, 3 * px(P4K) * 8, "tone map"),
     "ewa_8k_to_4k_deband_tonemap": (P8K, P4K, px(P8K) * 8 + px(P4K) * 8, "polar"),
+    # the metric's two halves in one frame: 1080p HDR10 -> EWA 2x upscale -> tone map -> 4K SDR
+    "ewa_1080p_to_4k_hdr_tonemap": (P1080, P4K, 2 * px(P1080) * 8 + px(P4K) * 8, "polar"),
 }
 
 
@@ -101,6 +106,11 @@ class Stream:
             self.params = pl.render_params(
                 "default", peak_detect_params=pl.peak_detect_params(percentile=99.995))
             icsp, tcsp, trepr = hdr, bt1886, None
+        elif workload == "ewa_1080p_to_4k_hdr_tonemap":
+            self.params = pl.render_params(
+                "default", upscaler=pl.filter_config("ewa_lanczos"), dither_params=dither,
+                peak_detect_params=pl.peak_detect_params(percentile=99.995))
+            icsp, tcsp, trepr = hdr, bt1886, ten_bit
         else:
             self.params = pl.render_params(
                 "high_quality", downscaler=pl.filter_config("ewa_lanczos"),
