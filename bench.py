@@ -259,9 +259,13 @@ def main():
         if os.path.exists(prof):
             with open(prof) as f:
                 traffic = json.load(f).get(args.workload)
+        symbol = ("k_pass_peak" if "peak detection" in name else
+                  "k_polar_pp" if name.startswith("polar") else
+                  "k_ortho" if name.startswith("ortho") else
+                  "k_deband" if name.startswith("deband") else "k_pass_generic")
         roofline = {
             "bound": "hbm",
-            "kernel": name,
+            "kernel": f"{symbol} ({name})",   # HIP kernel (rocprofv3 name) + pass description
             "achieved": round(achieved, 1),
             "peak": HBM_PEAK_GBS,
             "unit": "GB/s",
