@@ -7,7 +7,7 @@
  * Field names, meanings and defaults are the reference's. Not provided (out of the
  * hot-path scope): hooks, custom LUTs, ICC, overlays, film grain,
  * deinterlacing, frame mixing, distortion / cone distortion, blurred borders, rotation.
- * Images may be planar / subsampled; targets are single-plane.
+ * Images and targets may be packed, semi-planar or planar / subsampled.
  */
 #ifndef LIBPLACEBO_RENDERER_H_
 #define LIBPLACEBO_RENDERER_H_
@@ -78,8 +78,8 @@ struct pl_render_params {
     // Scalers: NULL = built-in bilinear ("free" sampling in the final pass)
     const struct pl_filter_config *upscaler;
     const struct pl_filter_config *downscaler;
-    const struct pl_filter_config *plane_upscaler;      // accepted, unused (single plane)
-    const struct pl_filter_config *plane_downscaler;    // accepted, unused (single plane)
+    const struct pl_filter_config *plane_upscaler;      // chroma planes; NULL = upscaler
+    const struct pl_filter_config *plane_downscaler;    // chroma planes; NULL = downscaler
     float antiringing_strength;
     const struct pl_filter_config *frame_mixer;         // unsupported
 
@@ -155,7 +155,7 @@ enum {
 };
 
 struct pl_frame {
-    int num_planes;           // images: 1..4 (packed, semi-planar, planar); targets: 1
+    int num_planes;           // 1..4 (packed, semi-planar, planar)
     struct pl_plane planes[PL_MAX_PLANES];
 
     bool (*acquire)(pl_gpu gpu, struct pl_frame *frame);
