@@ -373,6 +373,51 @@ def frame(tex, repr_=None, color=None, crop=None, components=None, mapping=None,
     return f
 
 
+FMT_UNORM, FMT_SNORM, FMT_UINT, FMT_SINT, FMT_FLOAT = 1, 2, 3, 4, 5
+
+
+def plane_data(arr, comp_bits, comp_map=None, comp_pad=None, fmt_type=FMT_UNORM, swapped=False,
+               row_stride=0, pixel_stride=0):
+    """pl_plane_data (utils/upload.h) describing the numpy array `arr` (H x W x bytes...).
+    The array is kept alive by the returned struct (`_keep`)."""
+    arr = np.ascontiguousarray(arr)
+    d = capi.PlaneData(type=fmt_type, width=arr.shape[1], height=arr.shape[0], swapped=swapped)
+    n = len(comp_bits)
+    for c in range(4):
+        d.component_size[c] = comp_bits[c] if c < n else 0
+        d.component_pad[c] = comp_pad[c] if comp_pad and c < n else 0
+        d.component_map[c] = (comp_map[c] if comp_map else c) if c < n else 0
+    d.pixel_stride = pixel_stride or arr.strides[1]
+    d.row_stride = row_stride
+    d.pixels = arr.ctypes.data
+    d._keep = arr
+    return d
+
+
+def upload_plane(gpu, data, tex=None):
+    """pl_upload_plane: returns (capi.Plane, Texture); `tex` is reused when compatible."""
+    t = tex.ptr if tex is not None else C.POINTER(capi.Tex)()
+    out = capi.Plane()
+    if not lib().pl_upload_plane(gpu.gpu, C.byref(out), C.byref(t), C.byref(data)):
+        raise RuntimeError("pl_upload_plane failed")
+    if tex is not None:
+        tex.ptr = t
+        return out, tex
+    return out, Texture(gpu, t)
+
+
+def recreate_plane(gpu, data, tex=None):
+    """pl_recreate_plane: a renderable plane texture matching `data` (no upload)."""
+    t = tex.ptr if tex is not None else C.POINTER(capi.Tex)()
+    out = capi.Plane()
+    if not lib().pl_recreate_plane(gpu.gpu, C.byref(out), C.byref(t), C.byref(data)):
+        raise RuntimeError("pl_recreate_plane failed")
+    if tex is not None:
+        tex.ptr = t
+        return out, tex
+    return out, Texture(gpu, t)
+
+
 def render_params(preset="fast", **kw):
     """pl_render_{fast,default,high_quality}_params with overrides; pointer fields accept
     ctypes structs (kept alive on the returned object)."""

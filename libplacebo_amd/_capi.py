@@ -299,6 +299,15 @@ class Plane(C.Structure):
                 ("shift_x", C.c_float), ("shift_y", C.c_float)]
 
 
+class PlaneData(C.Structure):  # utils/upload.h
+    _fields_ = [("type", C.c_int), ("width", C.c_int), ("height", C.c_int),
+                ("component_size", C.c_int * 4), ("component_pad", C.c_int * 4),
+                ("component_map", C.c_int * 4), ("pixel_stride", C.c_size_t),
+                ("row_stride", C.c_size_t), ("swapped", C.c_bool), ("pixels", C.c_void_p),
+                ("buf", C.c_void_p), ("buf_offset", C.c_size_t), ("callback", C.c_void_p),
+                ("priv", C.c_void_p)]
+
+
 class Frame(C.Structure):
     _fields_ = [("num_planes", C.c_int), ("planes", Plane * 4),
                 ("acquire", C.c_void_p), ("release", C.c_void_p),
@@ -420,6 +429,13 @@ def declare(lib):
     fn("pl_renderer_reset_errors", None, vp, P(RenderErrors))
     fn("pl_render_image", C.c_bool, vp, P(Frame), P(Frame), P(RenderParams))
     fn("pl_frames_infer", None, vp, P(Frame), P(Frame))
+    fn("pl_frame_set_chroma_location", None, P(Frame), C.c_int)
+    fn("pl_plane_data_from_mask", None, P(PlaneData), P(C.c_uint64))
+    fn("pl_plane_data_from_comps", None, P(PlaneData), P(C.c_int), P(C.c_int))
+    fn("pl_plane_data_align", C.c_bool, P(PlaneData), P(BitEncoding))
+    fn("pl_plane_find_fmt", P(Fmt), P(Gpu), P(C.c_int), P(PlaneData))
+    fn("pl_upload_plane", C.c_bool, P(Gpu), P(Plane), P(P(Tex)), P(PlaneData))
+    fn("pl_recreate_plane", C.c_bool, P(Gpu), P(Plane), P(P(Tex)), P(PlaneData))
     fn("pl_renderer_get_hdr_metadata", C.c_bool, vp, P(HdrMetadata))
     fn("pl_renderer_flush_cache", None, vp)
     fn("pl_hip_renderer_tone_map_state", vp, vp)

@@ -37,6 +37,9 @@ for s in $SRCS; do
     gcc $CFLAGS -c "$REF/src/$s.c" -o "$OUT/obj/$s.o"
     OBJS="$OBJS $OUT/obj/$s.o"
 done
+# pure helpers of the plane-upload utility (GPU entry points stubbed by ref_shim.c)
+gcc $CFLAGS -c "$REF/src/utils/upload.c" -o "$OUT/obj/utils_upload.o"
+OBJS="$OBJS $OUT/obj/utils_upload.o"
 g++ -std=c++20 -O2 -fPIC -w -DPL_STATIC -I$OUT/gen -I$REF/src/include -I$REF/src \
     -c "$REF/src/convert.cc" -o "$OUT/obj/convert.o"
 # ref_shim.c is OUR glue (exposes a few internals as plain C-ABI for ctypes)
