@@ -262,7 +262,9 @@ def main():
         symbol = ("k_pass_peak" if "peak detection" in name else
                   "k_polar_pp" if name.startswith("polar") else
                   "k_ortho" if name.startswith("ortho") else
-                  "k_deband" if name.startswith("deband") else "k_pass_generic")
+                  "k_deband" if name.startswith("deband") else
+                  # (bilinear + fused epilogue -> rgba16 has its own kernel, k_pass.hip)
+                  "k_bilinear_fast" if args.workload == "bilinear_1080p_to_4k" else "k_pass_generic")
         roofline = {
             "bound": "hbm",
             "kernel": f"{symbol} ({name})",   # HIP kernel (rocprofv3 name) + pass description

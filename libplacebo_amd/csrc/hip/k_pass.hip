@@ -9,15 +9,20 @@
  *
  * Memory-bound: every source texel and every target texel crosses HBM once.
  */
+#include <stdio.h>
 #include <stdlib.h>
 
 #include "colorops.hiph"
 #include "samplers.hiph"
+#include "fastepi.hiph"
 
 #define PASS_BW 64
 #define PASS_BH 4
 #ifndef PASS_ITERS
 #define PASS_ITERS 1
+#endif
+#ifndef BF_DEFAULT_ITERS
+#define BF_DEFAULT_ITERS 1
 #endif
 
 DEV float4_t run_sampler(const plh_sampler_args &s, float px, float py)
@@ -177,8 +182,218 @@ void k_pass_generic(const plh_pass p_)
                 sx[q] < p.dst.w && sy[q] < p.dst.h;
     }
     apply_ops_n<NPX, false, LITE>(c, p.ops, 0, p.num_ops, fcs);
-    plh_store_n<NPX>(p.dst, sx, sy, ok, c);
+    plh_store_n<NPX>(p.dst, sx, sy, ok, c, p.nt_store);
     }
+}
+
+
+/* ------------------------------------------------------------------------ */
+/*
+ * k_bilinear_fast: the renderer's commonest final pass as one small kernel --
+ * bilinear sample of an 8-byte texel source (rgba16 / rgba16hf), the fused epilogue
+ * (fastepi.hiph: [dither] [uniform scale]) and an rgba16 store. Same arithmetic as
+ * k_pass_generic's BILINEAR case + apply_ops_n (bit-identical; tests/test_gpu_renderer.py
+ * runs both), without the op interpreter: ~1/2 of the instructions and of the registers.
+ *
+ * A lane owns ITERS 2x2 output cells, BF_BH cell rows apart, software-pipelined: the four
+ * texel loads (and the dither fetches) of cell k+1 are in flight while cell k is blended,
+ * encoded and stored. The attribute interpolation is split into its per-column halves
+ * (computed once per lane) and the per-pixel fy blend -- the same fma sequence as plh_attr.
+ */
+#define BF_BW 64
+#define BF_BH 4
+
+DEV uint2 bf_load(const plh_view &v, int x, int y)
+{
+    return *(const uint2 *) ((const char *) v.ptr + (size_t) y * v.pitch + (size_t) x * 8);
+}
+
+template <bool F16SRC>
+DEV float4_t bf_decode(const uint2 v)
+{
+    float4_t c;
+    if (F16SRC) {
+        c = { plh_h2f(v.x & 0xffff), plh_h2f(v.x >> 16), plh_h2f(v.y & 0xffff), plh_h2f(v.y >> 16) };
+    } else {
+        c = { plh_un16(v.x & 0xffff), plh_un16(v.x >> 16), plh_un16(v.y & 0xffff), plh_un16(v.y >> 16) };
+    }
+    return c;
+}
+
+struct bf_cell {
+    uint2 raw[4];       // the shared 2x2 footprint: (x0,y0) (x1,y0) (x0,y1) (x1,y1)
+    float ax[4], ay[4]; // blend factors of the cell's four pixels
+    float bias[4];      // dither matrix values
+    int idy0;
+    bool shared;
+};
+
+template <bool F16SRC, int ITERS>
+__global__ __launch_bounds__(BF_BW * BF_BH)
+void k_bilinear_fast(const plh_pass p_)
+{
+    const plh_pass &p = plh_kernarg_pass();
+    const plh_sampler_args &s = p.s;
+    const int cx = blockIdx.x * BF_BW + threadIdx.x;
+    const int idx0 = 2 * cx - p.cell_padx;
+    const float sw = (float) s.src.w, sh = (float) s.src.h;
+
+    // per-column state: fx halves of the attributes, store guard, target column
+    float a0[2], a1[2], b0[2], b1[2];
+    int sx[2];
+    bool cok[2];
+#pragma unroll
+    for (int i = 0; i < 2; i++) {
+        const int idx = idx0 + i;
+        const float mx = p.out_scale[0] * ((float) idx + 0.5f);
+        a0[i] = plh_mix(s.pos[0][0], s.pos[1][0], mx);
+        a1[i] = plh_mix(s.pos[2][0], s.pos[3][0], mx);
+        b0[i] = plh_mix(s.pos[0][1], s.pos[1][1], mx);
+        b1[i] = plh_mix(s.pos[2][1], s.pos[3][1], mx);
+        sx[i] = p.base_x + p.dir_x * idx;
+        cok[i] = idx >= 0 && p.out_scale[0] * (float) idx < 1.0f && sx[i] >= 0 && sx[i] < p.dst.w;
+    }
+
+    // stage A: coordinates, footprint, loads
+    auto stage_a = [&](int it, bf_cell &c) {
+        const int cy = (blockIdx.y * ITERS + it) * BF_BH + threadIdx.y;
+        c.idy0 = 2 * cy - p.cell_pady;
+        float fu0 = 0.0f, fw0 = 0.0f;
+        bool shared = true;
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const int i = q & 1, j = q >> 1;
+            const float my = p.out_scale[1] * ((float) (c.idy0 + j) + 0.5f);
+            const float px = plh_mix(a0[i], a1[i], my), py = plh_mix(b0[i], b1[i], my);
+            const float u = px * sw - 0.5f, w = py * sh - 0.5f;
+            const float fu = __builtin_floorf(u), fw = __builtin_floorf(w);
+            c.ax[q] = u - fu;
+            c.ay[q] = w - fw;
+            if (q == 0) {
+                fu0 = fu; fw0 = fw;
+            } else {
+                shared = shared && fu == fu0 && fw == fw0;
+            }
+            if (p.epi.has_dither) {
+                const int ix = (idx0 + i + p.frag_x0) & p.epi.mask;
+                const int iy = (c.idy0 + j + p.frag_y0) & p.epi.mask;
+                c.bias[q] = p.epi.matrix[iy * p.epi.size + ix];
+            } else {
+                c.bias[q] = 0.0f;
+            }
+        }
+        c.shared = shared;
+        const int x0 = plh_wrap((int) fu0, s.src.w, s.address_mode);
+        const int x1 = plh_wrap((int) fu0 + 1, s.src.w, s.address_mode);
+        const int y0 = plh_wrap((int) fw0, s.src.h, s.address_mode);
+        const int y1 = plh_wrap((int) fw0 + 1, s.src.h, s.address_mode);
+        c.raw[0] = bf_load(s.src, x0, y0);
+        c.raw[1] = bf_load(s.src, x1, y0);
+        c.raw[2] = bf_load(s.src, x0, y1);
+        c.raw[3] = bf_load(s.src, x1, y1);
+    };
+
+    // stage B: decode, blend, epilogue, store
+    auto stage_b = [&](const bf_cell &c) {
+        float4_t t[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++)
+            t[k] = bf_decode<F16SRC>(c.raw[k]);
+        float4_t o[4];
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            o[q] = scale4(mix4(mix4(t[0], t[1], c.ax[q]), mix4(t[2], t[3], c.ax[q]), c.ay[q]),
+                          s.scale);
+        }
+        if (!c.shared) {
+            // pixels of this cell straddle a texel boundary (not a 2x upscale on the cell
+            // phase): every pixel fetches its own footprint
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                const int i = q & 1, j = q >> 1;
+                const float my = p.out_scale[1] * ((float) (c.idy0 + j) + 0.5f);
+                const float px = plh_mix(a0[i], a1[i], my), py = plh_mix(b0[i], b1[i], my);
+                const lin_fp f = lin_footprint(s.src, s.address_mode, px, py);
+                const uint2 r0 = bf_load(s.src, f.x0, f.y0), r1 = bf_load(s.src, f.x1, f.y0);
+                const uint2 r2 = bf_load(s.src, f.x0, f.y1), r3 = bf_load(s.src, f.x1, f.y1);
+                o[q] = scale4(mix4(mix4(bf_decode<F16SRC>(r0), bf_decode<F16SRC>(r1), f.ax),
+                                   mix4(bf_decode<F16SRC>(r2), bf_decode<F16SRC>(r3), f.ax), f.ay),
+                              s.scale);
+            }
+        }
+        int ox[4], oy[4];
+        bool ok[4];
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const int i = q & 1, j = q >> 1;
+            const int idy = c.idy0 + j;
+            if (p.epi.has_alpha)
+                o[q].w = p.epi.alpha;
+            // op_dither (non-gamma path) and the SCALE op (colorops.hiph)
+            if (p.epi.has_dither) {
+                const float b = c.bias[q], ds = p.epi.dscale, di = p.epi.dinv;
+                o[q].x = __builtin_floorf(ds * o[q].x + b) * di;
+                o[q].y = __builtin_floorf(ds * o[q].y + b) * di;
+                o[q].z = __builtin_floorf(ds * o[q].z + b) * di;
+                o[q].w = __builtin_floorf(ds * o[q].w + b) * di;
+            }
+            if (p.epi.has_scale)
+                o[q] = scale4(o[q], p.epi.scale);
+            ox[q] = sx[i];
+            oy[q] = p.base_y + p.dir_y * idy;
+            ok[q] = cok[i] && idy >= 0 && p.out_scale[1] * (float) idy < 1.0f &&
+                    oy[q] >= 0 && oy[q] < p.dst.h;
+        }
+        plh_store_rgba16_n<4>(p.dst, ox, oy, ok, o, p.nt_store);
+    };
+
+    if constexpr (ITERS == 1) {
+        bf_cell c;
+        stage_a(0, c);
+        stage_b(c);
+    } else {
+        bf_cell c[2];
+        stage_a(0, c[0]);
+#pragma unroll
+        for (int it = 0; it < ITERS; it++) {
+            if (it + 1 < ITERS)
+                stage_a(it + 1, c[(it + 1) & 1]);
+            stage_b(c[it & 1]);
+        }
+    }
+}
+
+// 0: not eligible, else the number of cells per lane
+static int bilinear_fast_iters(plh_pass *pass)
+{
+    static int iters_env = -1;  // PL_HIP_BILIN_ITERS=0 (off) | 1 | 2 | 4
+    if (iters_env < 0) {
+        const char *e = getenv("PL_HIP_BILIN_ITERS");
+        iters_env = e ? atoi(e) : BF_DEFAULT_ITERS;
+    }
+    if (!iters_env || pass->s.type != PLH_SAMPLE_BILINEAR || pass->num_pre_ops || pass->transpose ||
+        (pass->s.src.fmt != PLH_FMT_RGBA16 && pass->s.src.fmt != PLH_FMT_RGBA16F))
+        return 0;
+    plh_match_fast_epilogue(pass, true);
+    if (!pass->epi.enabled)
+        return 0;
+    return iters_env == 2 || iters_env == 4 ? iters_env : 1;
+}
+
+template <bool F16SRC>
+static void launch_bilinear_fast(hipStream_t stream, const plh_pass *pass, int iters)
+{
+    const int cells_w = (pass->width + pass->cell_padx + 1) / 2;
+    const int cells_h = (pass->height + pass->cell_pady + 1) / 2;
+    const dim3 block(BF_BW, BF_BH);
+    const int bh = BF_BH * iters;
+    const dim3 grid((cells_w + BF_BW - 1) / BF_BW, (cells_h + bh - 1) / bh);
+    if (iters == 4)
+        hipLaunchKernelGGL((k_bilinear_fast<F16SRC, 4>), grid, block, 0, stream, *pass);
+    else if (iters == 2)
+        hipLaunchKernelGGL((k_bilinear_fast<F16SRC, 2>), grid, block, 0, stream, *pass);
+    else
+        hipLaunchKernelGGL((k_bilinear_fast<F16SRC, 1>), grid, block, 0, stream, *pass);
 }
 
 /* ------------------------------------------------------------------------ */
@@ -193,6 +408,18 @@ extern "C" int plh_launch_pass(plh_stream stream_, const struct plh_pass *pass)
     hipStream_t stream = (hipStream_t) stream_;
     if (pass->width <= 0 || pass->height <= 0)
         return 0;
+
+    static int trace = -1;      // PL_HIP_PASS_TRACE=1: one line per launch on stderr
+    if (trace < 0)
+        trace = getenv("PL_HIP_PASS_TRACE") ? 1 : 0;
+    if (trace) {
+        fprintf(stderr, "[plh] pass %dx%d sampler=%d src.fmt=%d dst.fmt=%d transpose=%d pre=%d ops:",
+                pass->width, pass->height, pass->s.type, pass->s.src.fmt, pass->dst.fmt,
+                pass->transpose, pass->num_pre_ops);
+        for (int i = 0; i < pass->num_ops; i++)
+            fprintf(stderr, " %d", pass->ops[i].kind);
+        fprintf(stderr, "\n");
+    }
 
     switch (pass->s.type) {
     case PLH_SAMPLE_POLAR:
@@ -209,6 +436,19 @@ extern "C" int plh_launch_pass(plh_stream stream_, const struct plh_pass *pass)
     for (int i = 0; i < pass->num_ops; i++) {
         if (pass->ops[i].kind == PLH_OP_PEAK_DETECT)
             return plh_launch_peak(stream, pass);
+    }
+
+    {
+        plh_pass local = *pass;
+        const int iters = bilinear_fast_iters(&local);
+        if (iters) {
+            if (local.s.src.fmt == PLH_FMT_RGBA16F)
+                launch_bilinear_fast<true>(stream, &local, iters);
+            else
+                launch_bilinear_fast<false>(stream, &local, iters);
+            const hipError_t err = hipGetLastError();
+            return err == hipSuccess ? 0 : -(int) err;
+        }
     }
 
     const dim3 block(PASS_BW, PASS_BH);

@@ -24,6 +24,7 @@
  * write+read from the frame.
  */
 #include "colorops.hiph"
+#include "fastepi.hiph"
 
 #define POLAR_BW 32
 #define POLAR_BH 8
@@ -380,6 +381,15 @@ struct pp_rowinfo { float fc; int32_t base; int32_t woff; int32_t pad; };
 
 // LITE: the recorded ops only use the cheap cases (plh_ops_lite). FAST (implies LITE): the
 // post-ops are the fused epilogue described by p.epi and the target is rgba16.
+// profiling switches (PL_HIP_PP_DEBUG bits: 1 no taps, 2 no verification, 4 no stores, 8 no tile
+// staging, 16 no weight staging, 32 no epilogue, 64 no rows) only exist in -DPLH_PP_DEBUG builds:
+// each one is a scalar load + branch inside the row loop otherwise
+#ifdef PLH_PP_DEBUG
+#define PP_DBG(bit) (s.pp_debug & (bit))
+#else
+#define PP_DBG(bit) false
+#endif
+
 #ifdef PLH_PP_WAVES6
 #define PP_WAVES __attribute__((amdgpu_waves_per_eu(6, 8)))
 #else
@@ -405,6 +415,8 @@ void k_polar_pp(const plh_pass p_)
     const int ox = pp.colorg[blockIdx.x], oy = pp.roworg[blockIdx.y];
     const int nx = pp.coln[blockIdx.x], ny = pp.rown[blockIdx.y];
     const int tp = pp.tp, ntaps = pp.ntaps;
+    // (the fused epilogue is only matched for untransposed passes)
+    const bool tr = FAST ? false : (bool) p.transpose;
 
     // ---- stage LUT pairs, the tile's slice of the weight table, the source tile ---------
     // Every staging step is written as "issue a batch of independent loads, then store":
@@ -432,7 +444,7 @@ void k_polar_pp(const plh_pass p_)
     // trip of the generic path is the identity)
     const bool raw16 = sizeof(tile_px<T>) == 8 && s.src.fmt == PLH_FMT_RGBA16F && !p.num_pre_ops;
     const float rcp_tw = 1.0f / (float) tw;
-    if (s.pp_debug & 8) {
+    if (PP_DBG(8)) {
     } else if (raw16) {
         // batches of 4 independent 8-byte loads per lane, so that a tile costs two memory
         // round trips instead of one per texel
@@ -515,7 +527,7 @@ void k_polar_pp(const plh_pass p_)
             return *(const float4 *) (pp.weights + g * tp + t4 * 4);
         };
         const int stride = POLAR_BW * POLAR_BH;
-        for (int u0 = tid; u0 < ((s.pp_debug & 16) ? 0 : units); u0 += 4 * stride) {
+        for (int u0 = tid; u0 < ((PP_DBG(16)) ? 0 : units); u0 += 4 * stride) {
             const float4 v0 = wload(u0), v1 = wload(u0 + stride), v2 = wload(u0 + 2 * stride),
                          v3 = wload(u0 + 3 * stride);
             *(float4 *) (ws + u0 * 4) = v0;
@@ -580,16 +592,16 @@ void k_polar_pp(const plh_pass p_)
                        __float_as_uint(attr[i][2]) == __float_as_uint(y0a) &&
                        __float_as_uint(attr[i][3]) == __float_as_uint(y0b);
             const int idx = colx[i];
-            cpos[i] = p.transpose ? p.base_y + p.dir_y * idx : p.base_x + p.dir_x * idx;
+            cpos[i] = tr ? p.base_y + p.dir_y * idx : p.base_x + p.dir_x * idx;
             cok[i] = idx >= 0 && idx < p.width && p.out_scale[0] * (float) idx < 1.0f &&
-                     cpos[i] >= 0 && cpos[i] < (p.transpose ? p.dst.h : p.dst.w) &&
-                     !(s.pp_debug & 4);
+                     cpos[i] >= 0 && cpos[i] < (tr ? p.dst.h : p.dst.w) &&
+                     !(PP_DBG(4));
             fragx[i] = (float) (idx + p.frag_x0) + 0.5f;
         }
     }
 
 #pragma unroll 1
-    for (int r = 0; r < ((s.pp_debug & 64) ? 0 : rows); r++) {
+    for (int r = 0; r < ((PP_DBG(64)) ? 0 : rows); r++) {
         const int celly = (blockIdx.y * rows + r) * POLAR_BH + threadIdx.y;
         int rowy[N], rwoff[N];
         float rfc[N];
@@ -640,7 +652,7 @@ void k_polar_pp(const plh_pass p_)
 
         const int32_t *tapoff = (const int32_t *) (ws + (s.pp_lds_weights >> 2)) -
                                 ((ntaps + 3) & ~3);
-        const int nt_run = (s.pp_debug & 1) ? 0 : ntaps;
+        const int nt_run = (PP_DBG(1)) ? 0 : ntaps;
 #pragma unroll 4
         for (int t = 0; t < nt_run; t++) {
             // byte offset of the tap inside the tile (host: (y * tile_w + x) * sizeof(texel));
@@ -661,7 +673,7 @@ void k_polar_pp(const plh_pass p_)
         }
 
         // ---- normalise, verify, post-ops, store ------------------------------------------
-        if (s.pp_debug & 32)
+        if (PP_DBG(32))
             continue;
         float4_t outs[N * N];
         frag_t fcs[N * N];
@@ -676,9 +688,9 @@ void k_polar_pp(const plh_pass p_)
             const float ty_ = plh_mix(y0a, y0b, my) * sh - 0.5f, fly = __builtin_floorf(ty_);
             const bool rgood = __float_as_uint(ty_ - fly) == __float_as_uint(rfc[j]) &&
                                (int) fly == rbase;
-            const int rpos = p.transpose ? p.base_x + p.dir_x * idy : p.base_y + p.dir_y * idy;
+            const int rpos = tr ? p.base_x + p.dir_x * idy : p.base_y + p.dir_y * idy;
             const bool rok = idy >= 0 && idy < p.height && p.out_scale[1] * (float) idy < 1.0f &&
-                             rpos >= 0 && rpos < (p.transpose ? p.dst.w : p.dst.h);
+                             rpos >= 0 && rpos < (tr ? p.dst.w : p.dst.h);
             const float fragy = (float) (idy + p.frag_y0) + 0.5f;
 #pragma unroll
             for (int i = 0; i < N; i++) {
@@ -695,7 +707,7 @@ void k_polar_pp(const plh_pass p_)
                                   rgood;
                 // no -> recomputed with per-pixel weights after the regular stores (rare: a
                 // rounding tie in the attribute interpolation)
-                if (cok[i] && rok && !same && !(s.pp_debug & 2))
+                if (cok[i] && rok && !same && !(PP_DBG(2)))
                     redo |= 1u << q;
 
                 outs[q] = { norm * col[0], norm * col[1], norm * col[2], norm * col[3] };
@@ -719,18 +731,18 @@ void k_polar_pp(const plh_pass p_)
                 }
                 fcs[q] = { fragx[i], fragy, bias[j][i], dither_op >= 0 };
                 // guarded store (dispatch.c:1126-1142), guards hoisted per column / row
-                sx[q] = p.transpose ? rpos : cpos[i];
-                sy[q] = p.transpose ? cpos[i] : rpos;
+                sx[q] = tr ? rpos : cpos[i];
+                sy[q] = tr ? cpos[i] : rpos;
                 ok[q] = cok[i] && rok;
             }
         }
         if constexpr (FAST && (N * N) % 2 == 0) {
-            plh_store_rgba16_n<N * N>(p.dst, sx, sy, ok, outs);
+            plh_store_rgba16_n<N * N>(p.dst, sx, sy, ok, outs, p.nt_store);
         } else if constexpr (FAST) {
-            plh_store_n<N * N>(p.dst, sx, sy, ok, outs);
+            plh_store_n<N * N>(p.dst, sx, sy, ok, outs, p.nt_store);
         } else {
             apply_ops_n<N * N, false, LITE>(outs, p.ops, p.num_pre_ops, p.num_ops, fcs);
-            plh_store_n<N * N>(p.dst, sx, sy, ok, outs);
+            plh_store_n<N * N>(p.dst, sx, sy, ok, outs, p.nt_store);
         }
 
         // ---- pixels whose own phase is not the tabulated one: the per-pixel path, one inlined
@@ -757,8 +769,8 @@ void k_polar_pp(const plh_pass p_)
             const frag_t f1[1] = { { (float) (idx + p.frag_x0) + 0.5f,
                                      (float) (idy + p.frag_y0) + 0.5f, 0.0f, 0 } };
             apply_ops_n<1, false, LITE>(o1, p.ops, p.num_pre_ops, p.num_ops, f1);
-            const int x1[1] = { p.base_x + p.dir_x * (p.transpose ? idy : idx) };
-            const int y1[1] = { p.base_y + p.dir_y * (p.transpose ? idx : idy) };
+            const int x1[1] = { p.base_x + p.dir_x * (tr ? idy : idx) };
+            const int y1[1] = { p.base_y + p.dir_y * (tr ? idx : idy) };
             const bool k1[1] = { true };    // (only pixels that passed the store guards get here)
             plh_store_n<1>(p.dst, x1, y1, k1, o1);
         }
@@ -785,40 +797,6 @@ static int launch_pp(hipStream_t stream, const plh_pass *pass, dim3 grid, dim3 b
 #undef LAUNCH
     const hipError_t err = hipGetLastError();
     return err == hipSuccess ? 0 : -(int) err;
-}
-
-// Does the post-op chain match the fused epilogue (struct plh_fast_epi)?
-static void match_fast_epilogue(plh_pass *pass)
-{
-    plh_fast_epi &e = pass->epi;
-    e = plh_fast_epi{};
-    if (pass->dst.fmt != PLH_FMT_RGBA16 || pass->transpose)
-        return;
-    int i = pass->num_pre_ops;
-    if (i < pass->num_ops && pass->ops[i].kind == PLH_OP_DITHER) {
-        const plh_op &op = pass->ops[i];
-        const int size = op.i0;
-        const bool plain = op.i1 == 0 && !op.i2 && size > 0 && !(size & (size - 1)) &&
-                           !(op.f[1] != 1.0f && (int) op.f[3] <= 4);
-        if (!plain)
-            return;
-        e.has_dither = 1;
-        e.size = size;
-        e.mask = size - 1;
-        e.matrix = (const float *) op.ptr;
-        e.dscale = op.f[0];
-        e.dinv = op.f[8];
-        i++;
-    }
-    if (i < pass->num_ops && pass->ops[i].kind == PLH_OP_SCALE) {
-        const float *f = pass->ops[i].f;
-        if (f[0] != f[1] || f[0] != f[2] || f[0] != f[3])
-            return;
-        e.has_scale = 1;
-        e.scale = f[0];
-        i++;
-    }
-    e.enabled = i == pass->num_ops;
 }
 
 template <typename T>
@@ -877,7 +855,7 @@ static int launch_mask(hipStream_t stream, const plh_pass *pass, dim3 grid, dim3
 int plh_launch_polar(hipStream_t stream, const plh_pass *pass_in)
 {
     plh_pass local = *pass_in;
-    match_fast_epilogue(&local);
+    plh_match_fast_epilogue(&local);
     const plh_pass *pass = &local;
     const dim3 block(POLAR_BW, POLAR_BH);
     const uint32_t cm = pass->s.comp_mask & 0xf;

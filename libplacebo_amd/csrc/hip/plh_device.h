@@ -204,6 +204,8 @@ struct plh_fast_epi {
     const float *matrix;
     float dscale, dinv;         // 2^depth - 1 and its reciprocal
     float scale;                // color *= scale
+    int32_t has_alpha;          // color.a = alpha before the dither (identity PLANE_MAP of rgb)
+    float alpha;
 };
 
 struct plh_pass {
@@ -225,6 +227,7 @@ struct plh_pass {
     // k_pass: a lane owns the 2x2 outputs [2c - pad, 2c - pad + 2) per axis; the pad that
     // makes the four bilinear footprints of a 2x upscale coincide is chosen by the host
     int32_t cell_padx, cell_pady;
+    int32_t nt_store;       // streaming target stores (host: unorm targets = final frames)
 
     struct plh_fast_epi epi;
 

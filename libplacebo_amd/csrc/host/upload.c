@@ -191,6 +191,8 @@ bool pl_upload_plane(pl_gpu gpu, struct pl_plane *out_plane, pl_tex *tex,
     if (!pl_tex_recreate(gpu, tex, pl_tex_params(
             .w = data->width, .h = data->height, .format = fmt,
             .sampleable = true, .host_writable = true,
+            // (beyond the reference: every HIP texture can be read back)
+            .host_readable = !!(fmt->caps & PL_FMT_CAP_HOST_READABLE),
             .blit_src = !!(fmt->caps & PL_FMT_CAP_BLITTABLE))))
     {
         pl_msg(gpu->log, PL_LOG_ERR, "Failed initializing plane texture!");
