@@ -653,23 +653,51 @@ void k_polar_pp(const plh_pass p_)
         const int32_t *tapoff = (const int32_t *) (ws + (s.pp_lds_weights >> 2)) -
                                 ((ntaps + 3) & ~3);
         const int nt_run = (PP_DBG(1)) ? 0 : ntaps;
-#pragma unroll 4
-        for (int t = 0; t < nt_run; t++) {
-            // byte offset of the tap inside the tile (host: (y * tile_w + x) * sizeof(texel));
-            // an LDS broadcast read keeps the loop free of scalar-memory waits
-            const floatv4_t c = tile_vec(*(const tile_px<T> *) ((const char *) tp0 + tapoff[t]));
+        auto tap = [&](int off, const float (&w)[N][N]) {
+            // byte offset of the tap inside the tile (host: (y * tile_w + x) * sizeof(texel))
+            const floatv4_t c = tile_vec(*(const tile_px<T> *) ((const char *) tp0 + off));
 #pragma unroll
             for (int j = 0; j < N; j++) {
 #pragma unroll
                 for (int i = 0; i < N; i++) {
-                    const float w = wp[j][i][t];
 #pragma unroll
                     for (int k = 0; k < 4; k++) {
                         if (MASK & (1u << k))
-                            acc[j][i][k] = __builtin_fmaf(w, c[k], acc[j][i][k]);
+                            acc[j][i][k] = __builtin_fmaf(w[j][i], c[k], acc[j][i][k]);
                     }
                 }
             }
+        };
+        // four taps per step: one 16-byte LDS read per cell for the weights (rows of the weight
+        // table are 16-byte aligned) and one broadcast read for the tap offsets
+        int t = 0;
+#pragma unroll 1
+        for (; t + 4 <= nt_run; t += 4) {
+            const int4 off = *(const int4 *) (tapoff + t);
+            float4 w4[N][N];
+#pragma unroll
+            for (int j = 0; j < N; j++) {
+#pragma unroll
+                for (int i = 0; i < N; i++)
+                    w4[j][i] = *(const float4 *) (wp[j][i] + t);
+            }
+            float w[N][N];
+#define PP_TAP(o, m) \
+            _Pragma("unroll") for (int j = 0; j < N; j++) \
+                _Pragma("unroll") for (int i = 0; i < N; i++) w[j][i] = w4[j][i].m; \
+            tap(o, w)
+            PP_TAP(off.x, x); PP_TAP(off.y, y); PP_TAP(off.z, z); PP_TAP(off.w, w);
+#undef PP_TAP
+        }
+        for (; t < nt_run; t++) {
+            float w[N][N];
+#pragma unroll
+            for (int j = 0; j < N; j++) {
+#pragma unroll
+                for (int i = 0; i < N; i++)
+                    w[j][i] = wp[j][i][t];
+            }
+            tap(tapoff[t], w);
         }
 
         // ---- normalise, verify, post-ops, store ------------------------------------------
