@@ -8,7 +8,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libplacebo_hip.so")
+# PL_HIP_LIB: load another build of the library (A/B kernel experiments, tools/ab.sh)
+LIB_PATH = os.environ.get("PL_HIP_LIB") or os.path.join(_HERE, "libplacebo_hip.so")
 
 
 class BuildError(RuntimeError):
