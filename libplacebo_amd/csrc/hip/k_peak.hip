@@ -48,11 +48,19 @@ DEV uint32_t wave_max(uint32_t v)
     return v;
 }
 
+// One wavefront owns one of the reference's 16x16 workgroups: lane l measures the pixels
+// (l & 15, (l >> 4) + 4k), k = 0..3. Nothing crosses waves, so there is no __syncthreads and
+// no LDS state besides the wave's 64-bin histogram; a block is PEAK_WAVES independent tiles.
+// (The 256-lane / 1 px per lane version spent half of its time in barriers and LDS atomics:
+// 4K 127 us -> see DESIGN.md section 7.)
+#define PEAK_WAVES 4
+#define PEAK_NPX 4
+
 // op: i0 = transfer (already inferred), i1 = TRC flags, i2 = use_histogram;
 // f[0..11] = linearize params (as PLH_OP_LINEARIZE); ptr2 -> extra block:
 //   e[0..2] = luma coeffs, e[3] = 203/10000, e[4] = m1, e[5..7] = c1 c2 c3, e[8] = m2,
 //   e[9] = cutoff (0 = none)
-DEV void op_peak_detect(const float4_t &c_in, const plh_op &op, const peak_ctx &pk)
+DEV uint32_t peak_pq14(const float4_t &c_in, const plh_op &op)
 {
     const float *e = (const float *) op.ptr2;
     float4_t c = c_in;
@@ -70,61 +78,80 @@ DEV void op_peak_detect(const float4_t &c_in, const plh_op &op, const peak_ctx &
         const float t = plh_clamp(luma / cutoff, 0.0f, 1.0f);
         luma *= t * t * (3.0f - 2.0f * t);
     }
-    const uint32_t y_pq = (uint32_t) (16383.0f * luma);
+    return (uint32_t) (16383.0f * luma);
+}
 
-    const int lane = (threadIdx.y * PEAK_BW + threadIdx.x) & 63;
+DEV void wave_lds_fence()
+{
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+
+// the workgroup-level part of the measurement (colorspace.c:1279-1348) for one tile
+DEV void peak_measure(const float4_t (&c)[PEAK_NPX], const plh_op &op, uint32_t *hist,
+                      uint32_t wg_idx, void *scratch)
+{
+    const int lane = threadIdx.x & 63;
+    const float cutoff = ((const float *) op.ptr2)[9];
+    uint32_t y_pq[PEAK_NPX];
+#pragma unroll
+    for (int k = 0; k < PEAK_NPX; k++)
+        y_pq[k] = peak_pq14(c[k], op);
+
     if (op.i2) {
-        int bin = (int) y_pq >> (PQ_BITS - HIST_BITS);
-        bin -= HIST_BIAS;
-        bin = min(max(bin, 0), PEAK_HIST_BINS - 1);
-        const int first = __shfl(bin, 0, 64);
-        if (__all(bin == first)) {
-            if (lane == 0)
-                atomicAdd(&pk.wg_hist[bin], 64u);
-        } else {
-            atomicAdd(&pk.wg_hist[bin], 1u);
+        hist[lane] = 0u;
+        wave_lds_fence();
+#pragma unroll
+        for (int k = 0; k < PEAK_NPX; k++) {
+            int bin = (int) y_pq[k] >> (PQ_BITS - HIST_BITS);
+            bin -= HIST_BIAS;
+            bin = min(max(bin, 0), PEAK_HIST_BINS - 1);
+            const int first = __shfl(bin, 0, 64);
+            if (__all(bin == first)) {
+                if (lane == 0)
+                    atomicAdd(&hist[bin], 64u);
+            } else {
+                atomicAdd(&hist[bin], 1u);
+            }
         }
     }
 
-    const uint32_t group_sum = wave_sum(y_pq);
-    const uint32_t group_max = wave_max(y_pq);
-    const unsigned long long black = cutoff != 0.0f ? __ballot(y_pq == 0u) : 0ull;
-    if (lane == 0) {
-        atomicAdd(pk.wg_sum, group_sum);
-        atomicMax(pk.wg_max, group_max);
+    uint32_t lane_sum = 0, lane_max = 0, nblack = 0;
+#pragma unroll
+    for (int k = 0; k < PEAK_NPX; k++) {
+        lane_sum += y_pq[k];
+        lane_max = max(lane_max, y_pq[k]);
         if (cutoff != 0.0f)
-            atomicAdd(pk.wg_black, (uint32_t) __popcll(black));
+            nblack += (uint32_t) __popcll(__ballot(y_pq[k] == 0u));
     }
-    __syncthreads();
+    const uint32_t wg_sum = wave_sum(lane_sum);
+    const uint32_t wg_max = wave_max(lane_max);
 
-    const uint32_t local_idx = threadIdx.y * PEAK_BW + threadIdx.x;
-    const uint32_t wg_idx = blockIdx.y * gridDim.x + blockIdx.x;
     const uint32_t slice = wg_idx % PEAK_SLICES;
     // All workgroups of a frame would hammer the same 48 words (two cache lines) of the
     // measurement buffer with atomics, which serialises them (~4.5 ns each, 0.6 ms at 4K).
     // They go to one of PLH_PEAK_COPIES scratch copies instead; k_peak_fold adds the copies
     // into the real buffer afterwards. Integer sums / maxima: the result is identical.
-    peak_buf *frame = (peak_buf *) pk.frame + (wg_idx / PEAK_SLICES) % PLH_PEAK_COPIES;
+    peak_buf *frame = (peak_buf *) scratch + (wg_idx / PEAK_SLICES) % PLH_PEAK_COPIES;
     if (op.i2) {
-        if (cutoff != 0.0f && local_idx == 0)
-            pk.wg_hist[0] -= *pk.wg_black;
-        __syncthreads();
+        wave_lds_fence();
+        if (cutoff != 0.0f && lane == 0)
+            hist[0] -= nblack;
+        wave_lds_fence();
         // (a workgroup typically populates 1-3 of the 64 bins: adding the zeros of the others
         // would only queue ~20x more atomics on the 12 x 64 hot words)
-        for (uint32_t i = local_idx; i < PEAK_HIST_BINS; i += PEAK_BW * PEAK_BH) {
-            const uint32_t n = pk.wg_hist[i];
-            if (n)
-                atomicAdd(&frame->frame_hist[slice][i], n);
-        }
+        const uint32_t n = hist[lane];  // 64 lanes = 64 bins
+        if (n)
+            atomicAdd(&frame->frame_hist[slice][lane], n);
     }
 
-    if (local_idx == 0) {
-        const uint32_t num = PEAK_BW * PEAK_BH - *pk.wg_black;
+    if (lane == 0) {
+        const uint32_t num = PEAK_BW * PEAK_BH - nblack;
         atomicAdd(&frame->frame_wg_count[slice], 1u);
         atomicAdd(&frame->frame_wg_active[slice], min(num, 1u));
         if (num > 0u) {
-            atomicAdd(&frame->frame_sum_pq[slice], *pk.wg_sum / num);
-            atomicMax(&frame->frame_max_pq[slice], *pk.wg_max);
+            atomicAdd(&frame->frame_sum_pq[slice], wg_sum / num);
+            atomicMax(&frame->frame_max_pq[slice], wg_max);
         }
     }
 }
@@ -149,41 +176,80 @@ DEV float4_t run_sampler_pk(const plh_sampler_args &s, float px, float py)
     return c;
 }
 
-__global__ __launch_bounds__(PEAK_BW * PEAK_BH)
+__global__ __launch_bounds__(64 * PEAK_WAVES)
 void k_pass_peak(const plh_pass p_)
 {
     const plh_pass &p = plh_kernarg_pass();
-    __shared__ uint32_t wg_state[4 + PEAK_HIST_BINS];
-    const uint32_t local_idx = threadIdx.y * PEAK_BW + threadIdx.x;
-    if (local_idx < 4 + PEAK_HIST_BINS)
-        wg_state[local_idx] = 0u;
-    __syncthreads();
+    const plh_sampler_args &s = p.s;
+    __shared__ uint32_t hists[PEAK_WAVES][PEAK_HIST_BINS];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int tiles_x = (p.width + PEAK_BW - 1) / PEAK_BW;
+    const int tiles_y = (p.height + PEAK_BH - 1) / PEAK_BH;
+    // the reference's gl_WorkGroupID.y * gl_NumWorkGroups.x + gl_WorkGroupID.x
+    const uint32_t wg_idx = blockIdx.x * PEAK_WAVES + wave;
+    if (wg_idx >= (uint32_t) (tiles_x * tiles_y))
+        return;     // whole wave
+    const int tx = wg_idx % tiles_x, ty = wg_idx / tiles_x;
 
-    const peak_ctx pk = { &wg_state[0], &wg_state[1], &wg_state[2], &wg_state[4], p.peak_scratch };
-
-    const int idx = blockIdx.x * PEAK_BW + threadIdx.x;
-    const int idy = blockIdx.y * PEAK_BH + threadIdx.y;
-    const float mx = p.out_scale[0] * ((float) idx + 0.5f);
-    const float my = p.out_scale[1] * ((float) idy + 0.5f);
-
-    float4_t c = {0.0f, 0.0f, 0.0f, 1.0f};
-    if (p.s.type != PLH_SAMPLE_NONE) {
-        const float px = plh_attr(p.s.pos, 0, mx, my);
-        const float py = plh_attr(p.s.pos, 1, mx, my);
-        c = run_sampler_pk(p.s, px, py);
+    float4_t c[PEAK_NPX];
+    frag_t fcs[PEAK_NPX];
+    int idx[PEAK_NPX], idy[PEAK_NPX];
+    float px[PEAK_NPX], py[PEAK_NPX];
+#pragma unroll
+    for (int k = 0; k < PEAK_NPX; k++) {
+        idx[k] = tx * PEAK_BW + (lane & 15);
+        idy[k] = ty * PEAK_BH + (lane >> 4) + 4 * k;
+        const float mx = p.out_scale[0] * ((float) idx[k] + 0.5f);
+        const float my = p.out_scale[1] * ((float) idy[k] + 0.5f);
+        fcs[k] = { (float) (idx[k] + p.frag_x0) + 0.5f, (float) (idy[k] + p.frag_y0) + 0.5f, 0.0f, 0,
+                   mx, my };
+        px[k] = plh_attr(s.pos, 0, mx, my);
+        py[k] = plh_attr(s.pos, 1, mx, my);
+        c[k] = {0.0f, 0.0f, 0.0f, 1.0f};
+    }
+    if (s.type == PLH_SAMPLE_NEAREST) {
+        int txl[PEAK_NPX], tyl[PEAK_NPX];
+#pragma unroll
+        for (int k = 0; k < PEAK_NPX; k++) {
+            txl[k] = plh_wrap((int) __builtin_floorf(px[k] * (float) s.src.w), s.src.w, s.address_mode);
+            tyl[k] = plh_wrap((int) __builtin_floorf(py[k] * (float) s.src.h), s.src.h, s.address_mode);
+        }
+        plh_fetch_n<PEAK_NPX>(s.src, txl, tyl, c);
+#pragma unroll
+        for (int k = 0; k < PEAK_NPX; k++)
+            c[k] = scale4(c[k], s.scale);
+    } else if (s.type != PLH_SAMPLE_NONE) {
+#pragma unroll
+        for (int k = 0; k < PEAK_NPX; k++)
+            c[k] = run_sampler_pk(s, px[k], py[k]);
     }
 
-    const frag_t fc = { (float) (idx + p.frag_x0) + 0.5f, (float) (idy + p.frag_y0) + 0.5f, 0.0f, 0,
-                        mx, my };
-    apply_ops<true>(c, p.ops, 0, p.num_ops, fc, &pk);
-
-    const float fx = p.out_scale[0] * (float) idx, fy = p.out_scale[1] * (float) idy;
-    if (fx < 1.0f && fy < 1.0f) {
-        const int ox = p.base_x + p.dir_x * (p.transpose ? idy : idx);
-        const int oy = p.base_y + p.dir_y * (p.transpose ? idx : idy);
-        if (ox >= 0 && oy >= 0 && ox < p.dst.w && oy < p.dst.h)
-            plh_store(p.dst, ox, oy, c);
+    // ops before the measurement, the measurement, ops after it
+    int pk_op = p.num_ops;
+    for (int i = 0; i < p.num_ops; i++) {
+        if (p.ops[i].kind == PLH_OP_PEAK_DETECT) {
+            pk_op = i;
+            break;
+        }
     }
+    apply_ops_n<PEAK_NPX>(c, p.ops, 0, pk_op, fcs);
+    if (pk_op < p.num_ops) {
+        peak_measure(c, p.ops[pk_op], hists[wave], wg_idx, p.peak_scratch);
+        apply_ops_n<PEAK_NPX>(c, p.ops, pk_op + 1, p.num_ops, fcs);
+    }
+
+    if (!p.dst.ptr)
+        return;     // target-less measurement pass
+    int sx[PEAK_NPX], sy[PEAK_NPX];
+    bool ok[PEAK_NPX];
+#pragma unroll
+    for (int k = 0; k < PEAK_NPX; k++) {
+        sx[k] = p.base_x + p.dir_x * (p.transpose ? idy[k] : idx[k]);
+        sy[k] = p.base_y + p.dir_y * (p.transpose ? idx[k] : idy[k]);
+        ok[k] = p.out_scale[0] * (float) idx[k] < 1.0f && p.out_scale[1] * (float) idy[k] < 1.0f &&
+                sx[k] >= 0 && sy[k] >= 0 && sx[k] < p.dst.w && sy[k] < p.dst.h;
+    }
+    plh_store_n<PEAK_NPX>(p.dst, sx, sy, ok, c, p.nt_store);
 }
 
 __global__ void k_peak_fold(uint32_t *dst, uint32_t *scratch)
@@ -206,8 +272,9 @@ __global__ void k_peak_fold(uint32_t *dst, uint32_t *scratch)
 
 int plh_launch_peak(hipStream_t stream, const plh_pass *pass)
 {
-    const dim3 block(PEAK_BW, PEAK_BH);
-    const dim3 grid((pass->width + PEAK_BW - 1) / PEAK_BW, (pass->height + PEAK_BH - 1) / PEAK_BH);
+    const int tiles = ((pass->width + PEAK_BW - 1) / PEAK_BW) * ((pass->height + PEAK_BH - 1) / PEAK_BH);
+    const dim3 block(64 * PEAK_WAVES);
+    const dim3 grid((tiles + PEAK_WAVES - 1) / PEAK_WAVES);
     if (!pass->peak_buf || !pass->peak_scratch)
         return -1002;
     hipLaunchKernelGGL(k_pass_peak, grid, block, 0, stream, *pass);

@@ -26,8 +26,10 @@
 #include "colorops.hiph"
 #include "fastepi.hiph"
 
+#ifndef POLAR_BW
 #define POLAR_BW 32
 #define POLAR_BH 8
+#endif
 
 template <typename T> struct tile_px;
 template <> struct tile_px<__half> { uint2 v; };    // 4 x f16

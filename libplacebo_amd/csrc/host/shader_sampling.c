@@ -316,8 +316,10 @@ static int polar_taps_gather(uint32_t *taps, pl_filter filter, int bound, bool u
 
 // Output tile of the polar kernel (csrc/hip/k_polar.hip): 32 columns, 8 lanes
 // rows x `rows` rows per lane
+#ifndef POLAR_BW
 #define POLAR_BW 32
 #define POLAR_BH 8
+#endif
 
 static bool sample_polar(pl_shader sh, const struct pl_sample_src *src,
                          const struct pl_sample_filter_params *params, bool force_f16_tile);
