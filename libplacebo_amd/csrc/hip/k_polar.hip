@@ -384,7 +384,7 @@ struct pp_rowinfo { float fc; int32_t base; int32_t woff; int32_t pad; };
 // LITE: the recorded ops only use the cheap cases (plh_ops_lite). FAST (implies LITE): the
 // post-ops are the fused epilogue described by p.epi and the target is rgba16.
 // profiling switches (PL_HIP_PP_DEBUG bits: 1 no taps, 2 no verification, 4 no stores, 8 no tile
-// staging, 16 no weight staging, 32 no epilogue, 64 no rows) only exist in -DPLH_PP_DEBUG builds:
+// staging, 16 no weight staging, 32 no epilogue, 64 no rows, 128 no weight reads, 256 one texel) only exist in -DPLH_PP_DEBUG builds:
 // each one is a scalar load + branch inside the row loop otherwise
 #ifdef PLH_PP_DEBUG
 #define PP_DBG(bit) (s.pp_debug & (bit))
@@ -411,7 +411,7 @@ void k_polar_pp(const plh_pass p_)
 {
     const plh_pass &p = plh_kernarg_pass();
     const plh_sampler_args &s = p.s;
-    const plh_polar_pp &pp = *s.pp;
+    const plh_polar_pp &pp = s.ppv;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     float2 *lut = (float2 *) smem;                              // 256 pairs = 2 KiB
     pp_rowinfo *rinfo = (pp_rowinfo *) (smem + 2048);           // <= 64 output rows, 1 KiB
@@ -432,11 +432,26 @@ void k_polar_pp(const plh_pass p_)
     // a load -> wait -> store loop pays one memory round trip (~1 us) per iteration.
     for (int i = tid; i < 256; i += POLAR_BW * POLAR_BH)
         lut[i] = ((const float2 *) s.lut)[i];
-    uint16_t *lists = (uint16_t *) (smem + 2048 + 1024);    // 2 x PLH_PP_LMAX local -> global ids
-    if (tid < 2 * PLH_PP_LMAX) {
-        lists[tid] = tid < PLH_PP_LMAX
-            ? pp.collist[blockIdx.x * PLH_PP_LMAX + tid]
-            : pp.rowlist[blockIdx.y * PLH_PP_LMAX + tid - PLH_PP_LMAX];
+    // The tile's slice of the weight table (float4 units, 4 per lane in flight) is requested
+    // first: its address chain (class lists -> weights) then overlaps the tile loads below.
+    // (four named registers rather than an array: the compiler demotes a conditionally
+    // consumed array to scratch memory, ~27 MB of spurious HBM writes per 4K frame)
+    const int tp4 = tp >> 2, units = nx * ny * tp4;
+    const int wstride = POLAR_BW * POLAR_BH;
+    float4 wv0, wv1, wv2, wv3;
+    {
+        const float rcp_tp4 = 1.0f / (float) tp4, rcp_nx = 1.0f / (float) nx;
+        const uint16_t *cl = pp.collist + blockIdx.x * PLH_PP_LMAX;
+        const uint16_t *rl = pp.rowlist + blockIdx.y * PLH_PP_LMAX;
+        auto wload = [&](int u) {
+            u = min(u, units - 1);
+            const int pair = (int) (((float) u + 0.5f) * rcp_tp4), t4 = u - pair * tp4;
+            const int ly = (int) (((float) pair + 0.5f) * rcp_nx), lx = pair - ly * nx;
+            const size_t g = (size_t) rl[ly] * pp.ncx + cl[lx];
+            return *(const float4 *) (pp.weights + g * tp + t4 * 4);
+        };
+        wv0 = wload(tid); wv1 = wload(tid + wstride);
+        wv2 = wload(tid + 2 * wstride); wv3 = wload(tid + 3 * wstride);
     }
     {
         int32_t *toff = (int32_t *) (ws + (s.pp_lds_weights >> 2)) - ((ntaps + 3) & ~3);
@@ -520,32 +535,26 @@ void k_polar_pp(const plh_pass p_)
             tile_put(tile[i], c);
         }
     }
-    __syncthreads();
-
     {
-        // the tile's slice of the weight table: float4 units, 4 in flight per lane
-        const int tp4 = tp >> 2, units = nx * ny * tp4;
-        const float rcp_tp4 = 1.0f / (float) tp4, rcp_nx = 1.0f / (float) nx;
-        // (four named registers rather than an array: the compiler demotes a conditionally
-        // consumed array to scratch memory, ~27 MB of spurious HBM writes per 4K frame)
-        auto wload = [&](int u) {
-            u = min(u, units - 1);
-            const int pair = (int) (((float) u + 0.5f) * rcp_tp4), t4 = u - pair * tp4;
-            const int ly = (int) (((float) pair + 0.5f) * rcp_nx), lx = pair - ly * nx;
-            const size_t g = (size_t) lists[PLH_PP_LMAX + ly] * pp.ncx + lists[lx];
-            return *(const float4 *) (pp.weights + g * tp + t4 * 4);
-        };
-        const int stride = POLAR_BW * POLAR_BH;
-        for (int u0 = tid; u0 < ((PP_DBG(16)) ? 0 : units); u0 += 4 * stride) {
-            const float4 v0 = wload(u0), v1 = wload(u0 + stride), v2 = wload(u0 + 2 * stride),
-                         v3 = wload(u0 + 3 * stride);
-            *(float4 *) (ws + u0 * 4) = v0;
-            if (u0 + stride < units)
-                *(float4 *) (ws + (u0 + stride) * 4) = v1;
-            if (u0 + 2 * stride < units)
-                *(float4 *) (ws + (u0 + 2 * stride) * 4) = v2;
-            if (u0 + 3 * stride < units)
-                *(float4 *) (ws + (u0 + 3 * stride) * 4) = v3;
+        // weight slice: the first four units of every lane were requested above
+        if (!PP_DBG(16)) {
+            if (tid < units)
+                *(float4 *) (ws + tid * 4) = wv0;
+            if (tid + wstride < units)
+                *(float4 *) (ws + (tid + wstride) * 4) = wv1;
+            if (tid + 2 * wstride < units)
+                *(float4 *) (ws + (tid + 2 * wstride) * 4) = wv2;
+            if (tid + 3 * wstride < units)
+                *(float4 *) (ws + (tid + 3 * wstride) * 4) = wv3;
+            // (slices beyond 4 units per lane: many classes per tile, irrational ratios)
+            const float rcp_tp4 = 1.0f / (float) tp4, rcp_nx = 1.0f / (float) nx;
+            for (int u = tid + 4 * wstride; u < units; u += wstride) {
+                const int pair = (int) (((float) u + 0.5f) * rcp_tp4), t4 = u - pair * tp4;
+                const int ly = (int) (((float) pair + 0.5f) * rcp_nx), lx = pair - ly * nx;
+                const size_t g = (size_t) pp.rowlist[blockIdx.y * PLH_PP_LMAX + ly] * pp.ncx +
+                                 pp.collist[blockIdx.x * PLH_PP_LMAX + lx];
+                *(float4 *) (ws + u * 4) = *(const float4 *) (pp.weights + g * tp + t4 * 4);
+            }
         }
     }
     __syncthreads();
@@ -682,13 +691,18 @@ void k_polar_pp(const plh_pass p_)
         int t = 0;
 PP_TAP_UNROLL
         for (; t + 4 <= nt_run; t += 4) {
-            const int4 off = *(const int4 *) (tapoff + t);
+            int4 off = *(const int4 *) (tapoff + t);
+            if (PP_DBG(256))    // (profiling: every tap reads the same texel)
+                off = make_int4(0, 0, 0, 0);
             float4 w4[N][N];
 #pragma unroll
             for (int j = 0; j < N; j++) {
 #pragma unroll
-                for (int i = 0; i < N; i++)
-                    w4[j][i] = *(const float4 *) (wp[j][i] + t);
+                for (int i = 0; i < N; i++) {
+                    // (profiling bit 128: weights from registers instead of LDS)
+                    w4[j][i] = PP_DBG(128) ? make_float4(cfc[i], rfc[j], cfc[i], rfc[j])
+                                           : *(const float4 *) (wp[j][i] + t);
+                }
             }
             float w[N][N];
 #define PP_TAP(o, m) \

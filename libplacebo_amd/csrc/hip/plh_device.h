@@ -115,6 +115,8 @@ struct plh_sampler_args {
     int32_t tile_rows;      // output rows per lane (output tile = 32 x 8*rows)
     int32_t tile_fp32;      // tile kept as float4 instead of half4
     const struct plh_polar_pp *pp;  // device; NULL = per-pixel weights
+    struct plh_polar_pp ppv;        // the same by value: kernel arguments, one memory round
+                                    // trip less at the head of every workgroup
     int32_t pp_lds_weights; // bytes of LDS for the staged weight sub-table
     int32_t pp_n, pp_cells_w, pp_cells_h;   // host copies of pp->n, cells_w, cells_h
     int32_t pp_debug;       // profiling aid (PL_HIP_PP_DEBUG): 1 = no taps, 2 = no verify, 4 = no store

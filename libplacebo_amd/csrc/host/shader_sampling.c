@@ -828,6 +828,7 @@ void plh_polar_pp_setup(pl_gpu gpu, pl_log log, void *polar_obj, struct plh_pass
         return;
 
     s->pp = pl_hip_buf_ptr(obj->pp_blob);
+    s->ppv = obj->pp_host;
     s->pp_n = obj->pp_host.n;
     s->pp_cells_w = obj->pp_host.cells_w;
     s->pp_cells_h = obj->pp_host.cells_h;
