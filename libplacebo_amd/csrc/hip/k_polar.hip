@@ -399,6 +399,14 @@ struct pp_rowinfo { float fc; int32_t base; int32_t woff; int32_t pad; };
 #define PP_TAP_UNROLL _Pragma("unroll 2")
 #endif
 
+// texels per lane and staging batch (one memory round trip per batch; a 40x32 tile is 5 per lane)
+#ifndef PP_SB
+#define PP_SB 6       // decode + pre-ops path (measured: 4 -> 61.8 us, 6 -> 60.6, 8 -> 68)
+#endif
+#ifndef PP_SB_RAW
+#define PP_SB_RAW 8   // bit-copy path (8K -> 4K: 6 -> 286 us, 8 -> 279)
+#endif
+
 #ifdef PLH_PP_WAVES6
 #define PP_WAVES __attribute__((amdgpu_waves_per_eu(6, 8)))
 #else
@@ -470,12 +478,12 @@ void k_polar_pp(const plh_pass p_)
     const float rcp_tw = 1.0f / (float) tw;
     if (PP_DBG(8)) {
     } else if (raw16) {
-        // batches of 4 independent 8-byte loads per lane, so that a tile costs two memory
-        // round trips instead of one per texel
-        for (int i0 = tid; i0 < tw * th; i0 += 4 * POLAR_BW * POLAR_BH) {
-            uint2 v[4];
+        // batches of PP_SB_RAW independent 8-byte loads per lane, so that a tile costs one memory
+        // round trip instead of one per texel
+        for (int i0 = tid; i0 < tw * th; i0 += PP_SB_RAW * POLAR_BW * POLAR_BH) {
+            uint2 v[PP_SB_RAW];
 #pragma unroll
-            for (int u = 0; u < 4; u++) {
+            for (int u = 0; u < PP_SB_RAW; u++) {
                 const int i = min(i0 + u * POLAR_BW * POLAR_BH, tw * th - 1);
                 const int ty = (int) (((float) i + 0.5f) * rcp_tw), tx = i - ty * tw;
                 const int sx = plh_wrap(ox + tx, s.src.w, s.address_mode);
@@ -484,7 +492,7 @@ void k_polar_pp(const plh_pass p_)
                                          (size_t) sx * 8);
             }
 #pragma unroll
-            for (int u = 0; u < 4; u++) {
+            for (int u = 0; u < PP_SB_RAW; u++) {
                 const int i = i0 + u * POLAR_BW * POLAR_BH;
                 if (i < tw * th)
                     *(uint2 *) &tile[i] = v[u];
@@ -492,11 +500,11 @@ void k_polar_pp(const plh_pass p_)
         }
     } else if (s.src.fmt == PLH_FMT_RGBA16) {
         // packed unorm16 source (the fused-PASS-A case): same batching, decode + pre-ops after
-        for (int i0 = tid; i0 < tw * th; i0 += 4 * POLAR_BW * POLAR_BH) {
-            uint2 v[4];
-            int px[4], py[4];
+        for (int i0 = tid; i0 < tw * th; i0 += PP_SB * POLAR_BW * POLAR_BH) {
+            uint2 v[PP_SB];
+            int px[PP_SB], py[PP_SB];
 #pragma unroll
-            for (int u = 0; u < 4; u++) {
+            for (int u = 0; u < PP_SB; u++) {
                 const int i = min(i0 + u * POLAR_BW * POLAR_BH, tw * th - 1);
                 const int ty = (int) (((float) i + 0.5f) * rcp_tw), tx = i - ty * tw;
                 px[u] = plh_wrap(ox + tx, s.src.w, s.address_mode);
@@ -504,18 +512,18 @@ void k_polar_pp(const plh_pass p_)
                 v[u] = *(const uint2 *) ((const char *) s.src.ptr + (size_t) py[u] * s.src.pitch +
                                          (size_t) px[u] * 8);
             }
-            float4_t c[4];
-            frag_t fcs[4];
+            float4_t c[PP_SB];
+            frag_t fcs[PP_SB];
 #pragma unroll
-            for (int u = 0; u < 4; u++) {
+            for (int u = 0; u < PP_SB; u++) {
                 c[u] = { plh_un16(v[u].x & 0xffff), plh_un16(v[u].x >> 16),
                          plh_un16(v[u].y & 0xffff), plh_un16(v[u].y >> 16) };
                 fcs[u] = { (float) px[u] + 0.5f, (float) py[u] + 0.5f, 0.0f, 0 };
             }
             if (p.num_pre_ops)
-                apply_ops_n<4, false, LITE>(c, p.ops, 0, p.num_pre_ops, fcs);
+                apply_ops_n<PP_SB, false, LITE>(c, p.ops, 0, p.num_pre_ops, fcs);
 #pragma unroll
-            for (int u = 0; u < 4; u++) {
+            for (int u = 0; u < PP_SB; u++) {
                 const int i = i0 + u * POLAR_BW * POLAR_BH;
                 if (i < tw * th)
                     tile_put(tile[i], c[u]);
