@@ -421,7 +421,7 @@ void k_polar_pp(const plh_pass p_)
     const plh_sampler_args &s = p.s;
     const plh_polar_pp &pp = s.ppv;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    float2 *lut = (float2 *) smem;                              // 256 pairs = 2 KiB
+    const float2 *lut = (const float2 *) s.lut;                 // 256 pairs (global)
     pp_rowinfo *rinfo = (pp_rowinfo *) (smem + 2048);           // <= 64 output rows, 1 KiB
     float *ws = (float *) (smem + PP_LDS_FIXED);                // weight sub-table
     tile_px<T> *tile = (tile_px<T> *) (smem + PP_LDS_FIXED + s.pp_lds_weights);
@@ -438,8 +438,7 @@ void k_polar_pp(const plh_pass p_)
     // ---- stage LUT pairs, the tile's slice of the weight table, the source tile ---------
     // Every staging step is written as "issue a batch of independent loads, then store":
     // a load -> wait -> store loop pays one memory round trip (~1 us) per iteration.
-    for (int i = tid; i < 256; i += POLAR_BW * POLAR_BH)
-        lut[i] = ((const float2 *) s.lut)[i];
+    // (the LUT is only read by the rare per-pixel fixups below: straight from global memory)
     // The tile's slice of the weight table (float4 units, 4 per lane in flight) is requested
     // first: its address chain (class lists -> weights) then overlaps the tile loads below.
     // (four named registers rather than an array: the compiler demotes a conditionally
