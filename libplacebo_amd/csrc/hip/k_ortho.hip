@@ -22,6 +22,8 @@
  */
 #include "colorops.hiph"
 #include "samplers.hiph"
+#include "fastepi.hiph"
+#include <stdlib.h>
 
 #define ORTHO_BW 64
 #define ORTHO_BH 4
@@ -167,8 +169,254 @@ void k_ortho(const plh_pass p_)
     plh_store_n<1>(p.dst, sx, sy, ok, outs);
 }
 
+
+/* ------------------------------------------------------------------------ */
+/*
+ * k_ortho_fast: the same convolution for the hot configuration -- an 8-byte texel source
+ * (rgba16 / rgba16hf: the plane or the first pass' FBO), at most 8 taps, one texel per tap
+ * (no linear trick), on the texel grid across the axis. Same fma order as k_ortho, so both
+ * are bit-identical (tests run both: PL_HIP_ORTHO_FAST=0).
+ *   - two horizontally adjacent pixels per lane: one 16-byte store per lane and row
+ *   - weights: the two LUT rows bracketing fcoord as 16-byte loads (rows are 16-byte aligned)
+ *   - all texel loads of both pixels in flight before the first fma
+ *   - EPI 0: no colour ops; 1: fused epilogue (fastepi.hiph) -> rgba16; 2: LITE op interpreter
+ */
+DEV uint2 of_load(const plh_view &v, int x, int y)
+{
+    return *(const uint2 *) ((const char *) v.ptr + (size_t) y * v.pitch + (size_t) x * 8);
+}
+
+template <bool F16SRC>
+DEV float4_t of_decode(const uint2 v)
+{
+    float4_t c;
+    if (F16SRC) {
+        c = { plh_h2f(v.x & 0xffff), plh_h2f(v.x >> 16), plh_h2f(v.y & 0xffff), plh_h2f(v.y >> 16) };
+    } else {
+        c = { plh_un16(v.x & 0xffff), plh_un16(v.x >> 16), plh_un16(v.y & 0xffff), plh_un16(v.y >> 16) };
+    }
+    return c;
+}
+
+#define OF_MAXN 8
+
+template <bool F16SRC, int EPI>
+__global__ __launch_bounds__(ORTHO_BW * ORTHO_BH)
+void k_ortho_fast(const plh_pass p_)
+{
+    const plh_pass &p = plh_kernarg_pass();
+    const plh_sampler_args &s = p.s;
+    const int cx = blockIdx.x * ORTHO_BW + threadIdx.x;
+    const int idy = blockIdx.y * ORTHO_BH + threadIdx.y;
+    const int N = s.row_size;
+    const int na = s.dir ? s.src.h : s.src.w, no = s.dir ? s.src.w : s.src.h;
+    const float my = p.out_scale[1] * ((float) idy + 0.5f);
+
+    uint2 raw[2][OF_MAXN];
+    float w[2][OF_MAXN];
+    int first[2], o0[2];
+    float fcoord[2];
+#pragma unroll
+    for (int q = 0; q < 2; q++) {
+        const int idx = 2 * cx + q;
+        const float mx = p.out_scale[0] * ((float) idx + 0.5f);
+        const float px = plh_attr(s.pos, 0, mx, my), py = plh_attr(s.pos, 1, mx, my);
+        const float pa = s.dir ? py : px, po = s.dir ? px : py;
+        const float ta = pa * (float) na - 0.5f;
+        const float fla = __builtin_floorf(ta);
+        fcoord[q] = ta - fla;
+        first[q] = (int) fla - (N / 2 - 1);
+        o0[q] = plh_wrap((int) __builtin_floorf(po * (float) no), no, s.address_mode);
+    }
+
+    // texels. Horizontal 2x upscales: the two windows are the same or one texel apart, so
+    // the second pixel's taps are the first one's shifted -> N + 1 loads instead of 2N.
+    const int shift = first[1] - first[0];
+    const bool overlap = !s.dir && o0[1] == o0[0] && (shift == 0 || shift == 1);
+    uint2 extra = make_uint2(0, 0);
+#pragma unroll
+    for (int n = 0; n < OF_MAXN; n++) {
+        if (n < N) {
+            const int iw = plh_wrap(first[0] + n, na, s.address_mode);
+            raw[0][n] = s.dir ? of_load(s.src, o0[0], iw) : of_load(s.src, iw, o0[0]);
+        } else {
+            raw[0][n] = make_uint2(0, 0);
+        }
+    }
+    if (overlap) {
+        extra = of_load(s.src, plh_wrap(first[0] + N, na, s.address_mode), o0[0]);
+    } else {
+#pragma unroll
+        for (int n = 0; n < OF_MAXN; n++) {
+            if (n < N) {
+                const int iw = plh_wrap(first[1] + n, na, s.address_mode);
+                raw[1][n] = s.dir ? of_load(s.src, o0[1], iw) : of_load(s.src, iw, o0[1]);
+            }
+        }
+    }
+
+    // weights: LUT rows bracketing fcoord (linear LUT, lut.c:700-715 semantics). Pixels with
+    // the same fcoord (every pair of a vertical pass, bar rounding ties) share them.
+    const bool same_w = __float_as_uint(fcoord[1]) == __float_as_uint(fcoord[0]);
+#pragma unroll
+    for (int q = 0; q < 2; q++) {
+        if (q == 1 && same_w)
+            break;
+        const float fpos = plh_clamp(fcoord[q], 0.0f, 1.0f) * 255.0f;
+        const float fbase = __builtin_floorf(fpos);
+        const float fr = fpos - fbase;
+        const float4 *r0 = (const float4 *) (s.weights + (size_t) (int) fbase * s.row_stride);
+        const float4 *r1 = (const float4 *) (s.weights + (size_t) min((int) fbase + 1, 255) * s.row_stride);
+        const float4 a0 = r0[0], b0 = r1[0];
+        float4 a1 = a0, b1 = b0;
+        if (N > 4) {
+            a1 = r0[1]; b1 = r1[1];
+        }
+        const float ra[8] = { a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w };
+        const float rb[8] = { b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w };
+#pragma unroll
+        for (int n = 0; n < OF_MAXN; n++)
+            w[q][n] = plh_mix(ra[n], rb[n], fr);
+    }
+    if (same_w) {
+#pragma unroll
+        for (int n = 0; n < OF_MAXN; n++)
+            w[1][n] = w[0][n];
+    }
+    if (overlap) {
+        // raw[1][n] = texel first[0] + shift + n
+#pragma unroll
+        for (int n = 0; n < OF_MAXN; n++) {
+            const uint2 nxt = n + 1 < OF_MAXN ? raw[0][n + 1] : extra;
+            raw[1][n] = shift ? (n + 1 == N ? extra : nxt) : raw[0][n];
+        }
+    }
+
+    float4_t outs[2];
+#pragma unroll
+    for (int q = 0; q < 2; q++) {
+        float ca[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+        float lo[4] = {1e9f, 1e9f, 1e9f, 1e9f}, hi[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+        for (int n = 0; n < OF_MAXN; n++) {
+            if (n >= N)
+                continue;
+            const float4_t t = of_decode<F16SRC>(raw[q][n]);
+            const float cv[4] = { t.x, t.y, t.z, t.w };
+            if (s.use_ar && (n == N / 2 - 1 || n == N / 2)) {
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    lo[k] = fminf(lo[k], cv[k]);
+                    hi[k] = fmaxf(hi[k], cv[k]);
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < 4; k++)
+                ca[k] = __builtin_fmaf(w[q][n], cv[k], ca[k]);
+        }
+        if (s.use_ar) {
+#pragma unroll
+            for (int k = 0; k < 4; k++)
+                ca[k] = plh_mix(ca[k], plh_clamp(ca[k], lo[k], hi[k]), s.antiring);
+        }
+        // vec4 color = vec4(0, 0, 0, 1); color.<comps> = scale * ca
+        float4_t out = { 0.0f, 0.0f, 0.0f, 1.0f };
+        if (s.comp_mask & 1u) out.x = s.scale * ca[0];
+        if (s.comp_mask & 2u) out.y = s.scale * ca[1];
+        if (s.comp_mask & 4u) out.z = s.scale * ca[2];
+        if (s.comp_mask & 8u) out.w = s.scale * ca[3];
+        outs[q] = out;
+    }
+
+    int sx[2], sy[2];
+    bool ok[2];
+    frag_t fcs[2];
+#pragma unroll
+    for (int q = 0; q < 2; q++) {
+        const int idx = 2 * cx + q;
+        fcs[q] = { (float) (idx + p.frag_x0) + 0.5f, (float) (idy + p.frag_y0) + 0.5f, 0.0f, 0 };
+        sx[q] = p.base_x + p.dir_x * (p.transpose ? idy : idx);
+        sy[q] = p.base_y + p.dir_y * (p.transpose ? idx : idy);
+        ok[q] = p.out_scale[0] * (float) idx < 1.0f && p.out_scale[1] * (float) idy < 1.0f &&
+                sx[q] >= 0 && sy[q] >= 0 && sx[q] < p.dst.w && sy[q] < p.dst.h;
+    }
+    if constexpr (EPI == 1) {
+#pragma unroll
+        for (int q = 0; q < 2; q++) {
+            float4_t &o = outs[q];
+            if (p.epi.has_alpha)
+                o.w = p.epi.alpha;
+            // op_dither (non-gamma path) and the SCALE op (colorops.hiph)
+            if (p.epi.has_dither) {
+                const int ix = (2 * cx + q + p.frag_x0) & p.epi.mask;
+                const int iy = (idy + p.frag_y0) & p.epi.mask;
+                const float b = p.epi.matrix[iy * p.epi.size + ix];
+                const float ds = p.epi.dscale, di = p.epi.dinv;
+                o.x = __builtin_floorf(ds * o.x + b) * di;
+                o.y = __builtin_floorf(ds * o.y + b) * di;
+                o.z = __builtin_floorf(ds * o.z + b) * di;
+                o.w = __builtin_floorf(ds * o.w + b) * di;
+            }
+            if (p.epi.has_scale)
+                o = scale4(o, p.epi.scale);
+        }
+        plh_store_rgba16_n<2>(p.dst, sx, sy, ok, outs, p.nt_store);
+    } else {
+        if constexpr (EPI == 2)
+            apply_ops_n<2, false, true>(outs, p.ops, 0, p.num_ops, fcs);
+        plh_store_n<2>(p.dst, sx, sy, ok, outs, p.nt_store);
+    }
+}
+
+template <bool F16SRC>
+static void launch_ortho_fast(hipStream_t stream, const plh_pass *pass, int epi)
+{
+    const dim3 block(ORTHO_BW, ORTHO_BH);
+    const dim3 grid(((pass->width + 1) / 2 + ORTHO_BW - 1) / ORTHO_BW,
+                    (pass->height + ORTHO_BH - 1) / ORTHO_BH);
+    if (epi == 0)
+        hipLaunchKernelGGL((k_ortho_fast<F16SRC, 0>), grid, block, 0, stream, *pass);
+    else if (epi == 1)
+        hipLaunchKernelGGL((k_ortho_fast<F16SRC, 1>), grid, block, 0, stream, *pass);
+    else
+        hipLaunchKernelGGL((k_ortho_fast<F16SRC, 2>), grid, block, 0, stream, *pass);
+}
+
+// -1: not eligible, else the epilogue variant
+static int ortho_fast_variant(plh_pass *pass)
+{
+    static int enabled = -1;    // PL_HIP_ORTHO_FAST=0: always the generic kernel
+    if (enabled < 0) {
+        const char *e = getenv("PL_HIP_ORTHO_FAST");
+        enabled = e ? atoi(e) : 1;
+    }
+    const plh_sampler_args &s = pass->s;
+    if (!enabled || s.use_linear || s.linear || s.row_size > OF_MAXN || s.row_size < 2 ||
+        (s.row_stride & 3) || pass->num_pre_ops ||
+        (s.src.fmt != PLH_FMT_RGBA16 && s.src.fmt != PLH_FMT_RGBA16F))
+        return -1;
+    if (!pass->num_ops)
+        return 0;
+    plh_match_fast_epilogue(pass, true);
+    if (pass->epi.enabled)
+        return 1;
+    return plh_ops_lite(pass, 0, pass->num_ops) ? 2 : -1;
+}
+
 int plh_launch_ortho(hipStream_t stream, const plh_pass *pass)
 {
+    {
+        plh_pass local = *pass;
+        const int epi = ortho_fast_variant(&local);
+        if (epi >= 0) {
+            if (local.s.src.fmt == PLH_FMT_RGBA16F)
+                launch_ortho_fast<true>(stream, &local, epi);
+            else
+                launch_ortho_fast<false>(stream, &local, epi);
+            const hipError_t err = hipGetLastError();
+            return err == hipSuccess ? 0 : -(int) err;
+        }
+    }
     const dim3 block(ORTHO_BW, ORTHO_BH);
     const dim3 grid((pass->width + ORTHO_BW - 1) / ORTHO_BW,
                     (pass->height + ORTHO_BH - 1) / ORTHO_BH);
