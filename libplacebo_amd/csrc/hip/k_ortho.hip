@@ -200,7 +200,10 @@ DEV float4_t of_decode(const uint2 v)
 
 #define OF_MAXN 8
 
-template <bool F16SRC, int EPI>
+DEV int of_clamp(int i, int n) { return min(max(i, 0), n - 1); }
+
+// (clamp addressing only: the other modes cost an integer modulo per tap -> generic kernel)
+template <bool F16SRC, int EPI, int DIR>
 __global__ __launch_bounds__(ORTHO_BW * ORTHO_BH)
 void k_ortho_fast(const plh_pass p_)
 {
@@ -209,7 +212,7 @@ void k_ortho_fast(const plh_pass p_)
     const int cx = blockIdx.x * ORTHO_BW + threadIdx.x;
     const int idy = blockIdx.y * ORTHO_BH + threadIdx.y;
     const int N = s.row_size;
-    const int na = s.dir ? s.src.h : s.src.w, no = s.dir ? s.src.w : s.src.h;
+    const int na = DIR ? s.src.h : s.src.w, no = DIR ? s.src.w : s.src.h;
     const float my = p.out_scale[1] * ((float) idy + 0.5f);
 
     uint2 raw[2][OF_MAXN];
@@ -221,36 +224,49 @@ void k_ortho_fast(const plh_pass p_)
         const int idx = 2 * cx + q;
         const float mx = p.out_scale[0] * ((float) idx + 0.5f);
         const float px = plh_attr(s.pos, 0, mx, my), py = plh_attr(s.pos, 1, mx, my);
-        const float pa = s.dir ? py : px, po = s.dir ? px : py;
+        const float pa = DIR ? py : px, po = DIR ? px : py;
         const float ta = pa * (float) na - 0.5f;
         const float fla = __builtin_floorf(ta);
         fcoord[q] = ta - fla;
         first[q] = (int) fla - (N / 2 - 1);
-        o0[q] = plh_wrap((int) __builtin_floorf(po * (float) no), no, s.address_mode);
+        o0[q] = of_clamp((int) __builtin_floorf(po * (float) no), no);
     }
 
     // texels. Horizontal 2x upscales: the two windows are the same or one texel apart, so
     // the second pixel's taps are the first one's shifted -> N + 1 loads instead of 2N.
     const int shift = first[1] - first[0];
-    const bool overlap = !s.dir && o0[1] == o0[0] && (shift == 0 || shift == 1);
+    const bool overlap = !DIR && o0[1] == o0[0] && (shift == 0 || shift == 1);
     uint2 extra = make_uint2(0, 0);
 #pragma unroll
     for (int n = 0; n < OF_MAXN; n++) {
         if (n < N) {
-            const int iw = plh_wrap(first[0] + n, na, s.address_mode);
-            raw[0][n] = s.dir ? of_load(s.src, o0[0], iw) : of_load(s.src, iw, o0[0]);
+            const int iw = of_clamp(first[0] + n, na);
+            raw[0][n] = DIR ? of_load(s.src, o0[0], iw) : of_load(s.src, iw, o0[0]);
         } else {
             raw[0][n] = make_uint2(0, 0);
         }
     }
     if (overlap) {
-        extra = of_load(s.src, plh_wrap(first[0] + N, na, s.address_mode), o0[0]);
+        extra = of_load(s.src, of_clamp(first[0] + N, na), o0[0]);
     } else {
 #pragma unroll
         for (int n = 0; n < OF_MAXN; n++) {
             if (n < N) {
-                const int iw = plh_wrap(first[1] + n, na, s.address_mode);
-                raw[1][n] = s.dir ? of_load(s.src, o0[1], iw) : of_load(s.src, iw, o0[1]);
+                const int iw = of_clamp(first[1] + n, na);
+                raw[1][n] = DIR ? of_load(s.src, o0[1], iw) : of_load(s.src, iw, o0[1]);
+            }
+        }
+    }
+
+    // (the dither values are requested now, not after the convolution: one round trip less)
+    float bias[2] = { 0.0f, 0.0f };
+    if constexpr (EPI == 1) {
+        if (p.epi.has_dither) {
+#pragma unroll
+            for (int q = 0; q < 2; q++) {
+                const int ix = (2 * cx + q + p.frag_x0) & p.epi.mask;
+                const int iy = (idy + p.frag_y0) & p.epi.mask;
+                bias[q] = p.epi.matrix[iy * p.epi.size + ix];
             }
         }
     }
@@ -348,9 +364,7 @@ void k_ortho_fast(const plh_pass p_)
                 o.w = p.epi.alpha;
             // op_dither (non-gamma path) and the SCALE op (colorops.hiph)
             if (p.epi.has_dither) {
-                const int ix = (2 * cx + q + p.frag_x0) & p.epi.mask;
-                const int iy = (idy + p.frag_y0) & p.epi.mask;
-                const float b = p.epi.matrix[iy * p.epi.size + ix];
+                const float b = bias[q];
                 const float ds = p.epi.dscale, di = p.epi.dinv;
                 o.x = __builtin_floorf(ds * o.x + b) * di;
                 o.y = __builtin_floorf(ds * o.y + b) * di;
@@ -374,12 +388,14 @@ static void launch_ortho_fast(hipStream_t stream, const plh_pass *pass, int epi)
     const dim3 block(ORTHO_BW, ORTHO_BH);
     const dim3 grid(((pass->width + 1) / 2 + ORTHO_BW - 1) / ORTHO_BW,
                     (pass->height + ORTHO_BH - 1) / ORTHO_BH);
-    if (epi == 0)
-        hipLaunchKernelGGL((k_ortho_fast<F16SRC, 0>), grid, block, 0, stream, *pass);
-    else if (epi == 1)
-        hipLaunchKernelGGL((k_ortho_fast<F16SRC, 1>), grid, block, 0, stream, *pass);
-    else
-        hipLaunchKernelGGL((k_ortho_fast<F16SRC, 2>), grid, block, 0, stream, *pass);
+#define LAUNCH(E) do { \
+        if (pass->s.dir) hipLaunchKernelGGL((k_ortho_fast<F16SRC, E, 1>), grid, block, 0, stream, *pass); \
+        else             hipLaunchKernelGGL((k_ortho_fast<F16SRC, E, 0>), grid, block, 0, stream, *pass); \
+    } while (0)
+    if (epi == 0)      LAUNCH(0);
+    else if (epi == 1) LAUNCH(1);
+    else               LAUNCH(2);
+#undef LAUNCH
 }
 
 // -1: not eligible, else the epilogue variant
@@ -391,7 +407,7 @@ static int ortho_fast_variant(plh_pass *pass)
         enabled = e ? atoi(e) : 1;
     }
     const plh_sampler_args &s = pass->s;
-    if (!enabled || s.use_linear || s.linear || s.row_size > OF_MAXN || s.row_size < 2 ||
+    if (!enabled || s.address_mode != PLH_ADDRESS_CLAMP || s.use_linear || s.linear || s.row_size > OF_MAXN || s.row_size < 2 ||
         (s.row_stride & 3) || pass->num_pre_ops ||
         (s.src.fmt != PLH_FMT_RGBA16 && s.src.fmt != PLH_FMT_RGBA16F))
         return -1;
