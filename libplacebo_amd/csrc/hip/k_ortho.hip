@@ -181,9 +181,9 @@ void k_ortho(const plh_pass p_)
  *   - all texel loads of both pixels in flight before the first fma
  *   - EPI 0: no colour ops; 1: fused epilogue (fastepi.hiph) -> rgba16; 2: LITE op interpreter
  */
-DEV uint2 of_load(const plh_view &v, int x, int y)
+DEV uint2 of_load(const char *base, int pitch, int x, int y)
 {
-    return *(const uint2 *) ((const char *) v.ptr + (size_t) y * v.pitch + (size_t) x * 8);
+    return *(const uint2 *) (base + (size_t) y * pitch + (size_t) x * 8);
 }
 
 template <bool F16SRC>
@@ -198,12 +198,12 @@ DEV float4_t of_decode(const uint2 v)
     return c;
 }
 
-#define OF_MAXN 8
 
 DEV int of_clamp(int i, int n) { return min(max(i, 0), n - 1); }
 
 // (clamp addressing only: the other modes cost an integer modulo per tap -> generic kernel)
-template <bool F16SRC, int EPI, int DIR>
+// NT: number of taps (row_size), 4 / 6 / 8
+template <bool F16SRC, int EPI, int DIR, int NT>
 __global__ __launch_bounds__(ORTHO_BW * ORTHO_BH)
 void k_ortho_fast(const plh_pass p_)
 {
@@ -211,12 +211,17 @@ void k_ortho_fast(const plh_pass p_)
     const plh_sampler_args &s = p.s;
     const int cx = blockIdx.x * ORTHO_BW + threadIdx.x;
     const int idy = blockIdx.y * ORTHO_BH + threadIdx.y;
-    const int N = s.row_size;
+    constexpr int N = NT;
+    // source base / pitch pinned in SGPRs: left alone the compiler re-loads them from the
+    // kernel arguments in front of every texel load, each time with a full scalar wait
+    const char *sp = (const char *) s.src.ptr;
+    int spitch = s.src.pitch;
+    asm volatile("" : "+s"(sp), "+s"(spitch));
     const int na = DIR ? s.src.h : s.src.w, no = DIR ? s.src.w : s.src.h;
     const float my = p.out_scale[1] * ((float) idy + 0.5f);
 
-    uint2 raw[2][OF_MAXN];
-    float w[2][OF_MAXN];
+    uint2 raw[2][NT];
+    float w[2][NT];
     int first[2], o0[2];
     float fcoord[2];
 #pragma unroll
@@ -238,23 +243,17 @@ void k_ortho_fast(const plh_pass p_)
     const bool overlap = !DIR && o0[1] == o0[0] && (shift == 0 || shift == 1);
     uint2 extra = make_uint2(0, 0);
 #pragma unroll
-    for (int n = 0; n < OF_MAXN; n++) {
-        if (n < N) {
-            const int iw = of_clamp(first[0] + n, na);
-            raw[0][n] = DIR ? of_load(s.src, o0[0], iw) : of_load(s.src, iw, o0[0]);
-        } else {
-            raw[0][n] = make_uint2(0, 0);
-        }
+    for (int n = 0; n < NT; n++) {
+        const int iw = of_clamp(first[0] + n, na);
+        raw[0][n] = DIR ? of_load(sp, spitch, o0[0], iw) : of_load(sp, spitch, iw, o0[0]);
     }
     if (overlap) {
-        extra = of_load(s.src, of_clamp(first[0] + N, na), o0[0]);
+        extra = of_load(sp, spitch, of_clamp(first[0] + N, na), o0[0]);
     } else {
 #pragma unroll
-        for (int n = 0; n < OF_MAXN; n++) {
-            if (n < N) {
-                const int iw = of_clamp(first[1] + n, na);
-                raw[1][n] = DIR ? of_load(s.src, o0[1], iw) : of_load(s.src, iw, o0[1]);
-            }
+        for (int n = 0; n < NT; n++) {
+            const int iw = of_clamp(first[1] + n, na);
+            raw[1][n] = DIR ? of_load(sp, spitch, o0[1], iw) : of_load(sp, spitch, iw, o0[1]);
         }
     }
 
@@ -291,19 +290,19 @@ void k_ortho_fast(const plh_pass p_)
         const float ra[8] = { a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w };
         const float rb[8] = { b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w };
 #pragma unroll
-        for (int n = 0; n < OF_MAXN; n++)
+        for (int n = 0; n < NT; n++)
             w[q][n] = plh_mix(ra[n], rb[n], fr);
     }
     if (same_w) {
 #pragma unroll
-        for (int n = 0; n < OF_MAXN; n++)
+        for (int n = 0; n < NT; n++)
             w[1][n] = w[0][n];
     }
     if (overlap) {
         // raw[1][n] = texel first[0] + shift + n
 #pragma unroll
-        for (int n = 0; n < OF_MAXN; n++) {
-            const uint2 nxt = n + 1 < OF_MAXN ? raw[0][n + 1] : extra;
+        for (int n = 0; n < NT; n++) {
+            const uint2 nxt = n + 1 < NT ? raw[0][n + 1] : extra;
             raw[1][n] = shift ? (n + 1 == N ? extra : nxt) : raw[0][n];
         }
     }
@@ -314,9 +313,7 @@ void k_ortho_fast(const plh_pass p_)
         float ca[4] = {0.0f, 0.0f, 0.0f, 0.0f};
         float lo[4] = {1e9f, 1e9f, 1e9f, 1e9f}, hi[4] = {0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll
-        for (int n = 0; n < OF_MAXN; n++) {
-            if (n >= N)
-                continue;
+        for (int n = 0; n < NT; n++) {
             const float4_t t = of_decode<F16SRC>(raw[q][n]);
             const float cv[4] = { t.x, t.y, t.z, t.w };
             if (s.use_ar && (n == N / 2 - 1 || n == N / 2)) {
@@ -388,14 +385,20 @@ static void launch_ortho_fast(hipStream_t stream, const plh_pass *pass, int epi)
     const dim3 block(ORTHO_BW, ORTHO_BH);
     const dim3 grid(((pass->width + 1) / 2 + ORTHO_BW - 1) / ORTHO_BW,
                     (pass->height + ORTHO_BH - 1) / ORTHO_BH);
+#define LAUNCH_N(E, NT) do { \
+        if (pass->s.dir) hipLaunchKernelGGL((k_ortho_fast<F16SRC, E, 1, NT>), grid, block, 0, stream, *pass); \
+        else             hipLaunchKernelGGL((k_ortho_fast<F16SRC, E, 0, NT>), grid, block, 0, stream, *pass); \
+    } while (0)
 #define LAUNCH(E) do { \
-        if (pass->s.dir) hipLaunchKernelGGL((k_ortho_fast<F16SRC, E, 1>), grid, block, 0, stream, *pass); \
-        else             hipLaunchKernelGGL((k_ortho_fast<F16SRC, E, 0>), grid, block, 0, stream, *pass); \
+        if (pass->s.row_size == 4)      LAUNCH_N(E, 4); \
+        else if (pass->s.row_size == 6) LAUNCH_N(E, 6); \
+        else                            LAUNCH_N(E, 8); \
     } while (0)
     if (epi == 0)      LAUNCH(0);
     else if (epi == 1) LAUNCH(1);
     else               LAUNCH(2);
 #undef LAUNCH
+#undef LAUNCH_N
 }
 
 // -1: not eligible, else the epilogue variant
@@ -407,7 +410,8 @@ static int ortho_fast_variant(plh_pass *pass)
         enabled = e ? atoi(e) : 1;
     }
     const plh_sampler_args &s = pass->s;
-    if (!enabled || s.address_mode != PLH_ADDRESS_CLAMP || s.use_linear || s.linear || s.row_size > OF_MAXN || s.row_size < 2 ||
+    if (!enabled || s.address_mode != PLH_ADDRESS_CLAMP || s.use_linear || s.linear ||
+        (s.row_size != 4 && s.row_size != 6 && s.row_size != 8) ||
         (s.row_stride & 3) || pass->num_pre_ops ||
         (s.src.fmt != PLH_FMT_RGBA16 && s.src.fmt != PLH_FMT_RGBA16F))
         return -1;
