@@ -203,9 +203,9 @@ void k_pass_generic(const plh_pass p_)
 #define BF_BW 64
 #define BF_BH 4
 
-DEV uint2 bf_load(const plh_view &v, int x, int y)
+DEV uint2 bf_load(const char *base, int pitch, int x, int y)
 {
-    return *(const uint2 *) ((const char *) v.ptr + (size_t) y * v.pitch + (size_t) x * 8);
+    return *(const uint2 *) (base + (size_t) y * pitch + (size_t) x * 8);
 }
 
 template <bool F16SRC>
@@ -237,6 +237,15 @@ void k_bilinear_fast(const plh_pass p_)
     const int cx = blockIdx.x * BF_BW + threadIdx.x;
     const int idx0 = 2 * cx - p.cell_padx;
     const float sw = (float) s.src.w, sh = (float) s.src.h;
+    // Uniforms used under control flow, pinned in SGPRs: left alone the compiler re-loads them
+    // from the kernel arguments at every use, each load followed by a full scalar wait.
+    const char *sp = (const char *) s.src.ptr;
+    const float *dmat = p.epi.matrix;
+    int spitch = s.src.pitch, srcw = s.src.w, srch = s.src.h;
+    int dmask = p.epi.mask, dsize = p.epi.size, has_dither = p.epi.has_dither;
+    int fx0 = p.frag_x0, fy0 = p.frag_y0;
+    asm volatile("" : "+s"(sp), "+s"(dmat), "+s"(spitch), "+s"(srcw), "+s"(srch), "+s"(dmask),
+                      "+s"(dsize), "+s"(has_dither), "+s"(fx0), "+s"(fy0));
 
     // per-column state: fx halves of the attributes, store guard, target column
     float a0[2], a1[2], b0[2], b1[2];
@@ -274,23 +283,21 @@ void k_bilinear_fast(const plh_pass p_)
             } else {
                 shared = shared && fu == fu0 && fw == fw0;
             }
-            if (p.epi.has_dither) {
-                const int ix = (idx0 + i + p.frag_x0) & p.epi.mask;
-                const int iy = (c.idy0 + j + p.frag_y0) & p.epi.mask;
-                c.bias[q] = p.epi.matrix[iy * p.epi.size + ix];
-            } else {
-                c.bias[q] = 0.0f;
+            c.bias[q] = 0.0f;
+            if (has_dither) {
+                const int ix = (idx0 + i + fx0) & dmask;
+                const int iy = (c.idy0 + j + fy0) & dmask;
+                c.bias[q] = dmat[iy * dsize + ix];
             }
         }
         c.shared = shared;
-        const int x0 = plh_wrap((int) fu0, s.src.w, s.address_mode);
-        const int x1 = plh_wrap((int) fu0 + 1, s.src.w, s.address_mode);
-        const int y0 = plh_wrap((int) fw0, s.src.h, s.address_mode);
-        const int y1 = plh_wrap((int) fw0 + 1, s.src.h, s.address_mode);
-        c.raw[0] = bf_load(s.src, x0, y0);
-        c.raw[1] = bf_load(s.src, x1, y0);
-        c.raw[2] = bf_load(s.src, x0, y1);
-        c.raw[3] = bf_load(s.src, x1, y1);
+        // (clamp addressing only; the other modes take the generic kernel)
+        const int x0 = min(max((int) fu0, 0), srcw - 1), x1 = min(max((int) fu0 + 1, 0), srcw - 1);
+        const int y0 = min(max((int) fw0, 0), srch - 1), y1 = min(max((int) fw0 + 1, 0), srch - 1);
+        c.raw[0] = bf_load(sp, spitch, x0, y0);
+        c.raw[1] = bf_load(sp, spitch, x1, y0);
+        c.raw[2] = bf_load(sp, spitch, x0, y1);
+        c.raw[3] = bf_load(sp, spitch, x1, y1);
     };
 
     // stage B: decode, blend, epilogue, store
@@ -314,8 +321,8 @@ void k_bilinear_fast(const plh_pass p_)
                 const float my = p.out_scale[1] * ((float) (c.idy0 + j) + 0.5f);
                 const float px = plh_mix(a0[i], a1[i], my), py = plh_mix(b0[i], b1[i], my);
                 const lin_fp f = lin_footprint(s.src, s.address_mode, px, py);
-                const uint2 r0 = bf_load(s.src, f.x0, f.y0), r1 = bf_load(s.src, f.x1, f.y0);
-                const uint2 r2 = bf_load(s.src, f.x0, f.y1), r3 = bf_load(s.src, f.x1, f.y1);
+                const uint2 r0 = bf_load(sp, spitch, f.x0, f.y0), r1 = bf_load(sp, spitch, f.x1, f.y0);
+                const uint2 r2 = bf_load(sp, spitch, f.x0, f.y1), r3 = bf_load(sp, spitch, f.x1, f.y1);
                 o[q] = scale4(mix4(mix4(bf_decode<F16SRC>(r0), bf_decode<F16SRC>(r1), f.ax),
                                    mix4(bf_decode<F16SRC>(r2), bf_decode<F16SRC>(r3), f.ax), f.ay),
                               s.scale);
@@ -371,7 +378,8 @@ static int bilinear_fast_iters(plh_pass *pass)
         const char *e = getenv("PL_HIP_BILIN_ITERS");
         iters_env = e ? atoi(e) : BF_DEFAULT_ITERS;
     }
-    if (!iters_env || pass->s.type != PLH_SAMPLE_BILINEAR || pass->num_pre_ops || pass->transpose ||
+    if (!iters_env || pass->s.type != PLH_SAMPLE_BILINEAR ||
+        pass->s.address_mode != PLH_ADDRESS_CLAMP || pass->num_pre_ops || pass->transpose ||
         (pass->s.src.fmt != PLH_FMT_RGBA16 && pass->s.src.fmt != PLH_FMT_RGBA16F))
         return 0;
     plh_match_fast_epilogue(pass, true);
