@@ -82,7 +82,7 @@ struct plh_polar_pp {
     const int32_t *colbase, *rowbase;   // base texel of every column / row
     const uint8_t *colloc, *rowloc;     // class index local to the tile column / row
     const uint16_t *collist, *rowlist;  // [tiles][PLH_PP_LMAX] local -> global class
-    const uint8_t *coln, *rown;         // [tiles] number of local classes
+    const int32_t *coln, *rown;         // [tiles] number of local classes (dwords: scalar loads)
     const int32_t *colorg, *roworg;     // [tiles] LDS tile origin (texels)
     const float *weights;               // [ncy][ncx][tp]
     const int32_t *tapoff;              // [ntaps] byte offset of the tap in the LDS tile

@@ -720,7 +720,7 @@ static bool polar_pp_build(pl_gpu gpu, pl_log log, struct sh_sampler_obj *obj,
     PLACE(colloc, W);               PLACE(rowloc, H);
     PLACE(collist, (size_t) tx.ntiles * PLH_PP_LMAX * 2);
     PLACE(rowlist, (size_t) ty.ntiles * PLH_PP_LMAX * 2);
-    PLACE(coln, tx.ntiles);         PLACE(rown, ty.ntiles);
+    PLACE(coln, (size_t) tx.ntiles * 4); PLACE(rown, (size_t) ty.ntiles * 4);
     PLACE(colorg, (size_t) tx.ntiles * 4); PLACE(roworg, (size_t) ty.ntiles * 4);
     PLACE(weights, (size_t) ncx * ncy * tp * 4);
     PLACE(tapoff, (size_t) PL_MAX(ntc, 1) * 4);
@@ -739,8 +739,10 @@ static bool polar_pp_build(pl_gpu gpu, pl_log log, struct sh_sampler_obj *obj,
     memcpy(blob + o_rowloc, ty.loc, H);
     memcpy(blob + o_collist, tx.list, (size_t) tx.ntiles * PLH_PP_LMAX * 2);
     memcpy(blob + o_rowlist, ty.list, (size_t) ty.ntiles * PLH_PP_LMAX * 2);
-    memcpy(blob + o_coln, tx.cnt, tx.ntiles);
-    memcpy(blob + o_rown, ty.cnt, ty.ntiles);
+    for (int i = 0; i < tx.ntiles; i++)
+        ((int32_t *) (blob + o_coln))[i] = tx.cnt[i];
+    for (int i = 0; i < ty.ntiles; i++)
+        ((int32_t *) (blob + o_rown))[i] = ty.cnt[i];
     memcpy(blob + o_colorg, tx.org, (size_t) tx.ntiles * 4);
     memcpy(blob + o_roworg, ty.org, (size_t) ty.ntiles * 4);
     float *wc = (float *) (blob + o_weights);
@@ -775,7 +777,7 @@ static bool polar_pp_build(pl_gpu gpu, pl_log log, struct sh_sampler_obj *obj,
         .colbase = (const int32_t *) (d + o_colbase), .rowbase = (const int32_t *) (d + o_rowbase),
         .colloc = (const uint8_t *) (d + o_colloc), .rowloc = (const uint8_t *) (d + o_rowloc),
         .collist = (const uint16_t *) (d + o_collist), .rowlist = (const uint16_t *) (d + o_rowlist),
-        .coln = (const uint8_t *) (d + o_coln), .rown = (const uint8_t *) (d + o_rown),
+        .coln = (const int32_t *) (d + o_coln), .rown = (const int32_t *) (d + o_rown),
         .colorg = (const int32_t *) (d + o_colorg), .roworg = (const int32_t *) (d + o_roworg),
         .weights = (const float *) (d + o_weights), .tapoff = (const int32_t *) (d + o_tapoff),
     };
