@@ -404,11 +404,9 @@ static void launch_ortho_fast(hipStream_t stream, const plh_pass *pass, int epi)
 // -1: not eligible, else the epilogue variant
 static int ortho_fast_variant(plh_pass *pass)
 {
-    static int enabled = -1;    // PL_HIP_ORTHO_FAST=0: always the generic kernel
-    if (enabled < 0) {
-        const char *e = getenv("PL_HIP_ORTHO_FAST");
-        enabled = e ? atoi(e) : 1;
-    }
+    // PL_HIP_ORTHO_FAST=0: always the generic kernel (read per launch: tests switch kernels)
+    const char *e = getenv("PL_HIP_ORTHO_FAST");
+    const int enabled = e ? atoi(e) : 1;
     const plh_sampler_args &s = pass->s;
     if (!enabled || s.address_mode != PLH_ADDRESS_CLAMP || s.use_linear || s.linear ||
         (s.row_size != 4 && s.row_size != 6 && s.row_size != 8) ||

@@ -373,11 +373,9 @@ void k_bilinear_fast(const plh_pass p_)
 // 0: not eligible, else the number of cells per lane
 static int bilinear_fast_iters(plh_pass *pass)
 {
-    static int iters_env = -1;  // PL_HIP_BILIN_ITERS=0 (off) | 1 | 2 | 4
-    if (iters_env < 0) {
-        const char *e = getenv("PL_HIP_BILIN_ITERS");
-        iters_env = e ? atoi(e) : BF_DEFAULT_ITERS;
-    }
+    // PL_HIP_BILIN_ITERS=0 (off) | 1 | 2 | 4; read per launch so that tests can switch kernels
+    const char *e = getenv("PL_HIP_BILIN_ITERS");
+    const int iters_env = e ? atoi(e) : BF_DEFAULT_ITERS;
     if (!iters_env || pass->s.type != PLH_SAMPLE_BILINEAR ||
         pass->s.address_mode != PLH_ADDRESS_CLAMP || pass->num_pre_ops || pass->transpose ||
         (pass->s.src.fmt != PLH_FMT_RGBA16 && pass->s.src.fmt != PLH_FMT_RGBA16F))

@@ -178,12 +178,8 @@ static void plh_pass_choose_cells(struct plh_pass *pass)
     pass->cell_padx = pass->cell_pady = 0;
     // Unorm targets are final frames / output planes (intermediate FBOs are float): nothing on
     // this GPU reads them again, so their stores bypass the caches. PL_HIP_NT_STORE=0 disables.
-    static int nt_env = -1;
-    if (nt_env < 0) {
-        const char *e = getenv("PL_HIP_NT_STORE");
-        nt_env = e ? atoi(e) : 1;
-    }
-    pass->nt_store = nt_env && pass->dst.fmt <= PLH_FMT_RGBA16;
+    const char *nt_env = getenv("PL_HIP_NT_STORE");
+    pass->nt_store = (!nt_env || atoi(nt_env)) && pass->dst.fmt <= PLH_FMT_RGBA16;
     // extra planes (PLANE_FETCH): the same identity-fetch rule as for the main sampler
     for (int i = 0; i < pass->num_ops; i++) {
         struct plh_op *op = &pass->ops[i];

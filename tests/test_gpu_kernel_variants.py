@@ -1,0 +1,114 @@
+"""The specialised kernels (k_bilinear_fast, k_ortho_fast, k_polar_pp + fused PASS A / fused
+epilogue) against the generic ones they replace: same pl_render_image call, kernel selected by
+environment switches that the library reads per launch. Bar: bit-identical frames. (Each generic
+kernel is pinned against the oracle elsewhere: test_gpu_renderer.py, test_gpu_ortho_deband.py.)"""
+import os
+
+import numpy as np
+import pytest
+
+import libplacebo_amd as pl
+import util
+from libplacebo_amd import _capi as capi
+
+pytestmark = pytest.mark.gpu
+
+TEN_BIT = dict(sample_depth=16, color_depth=10, bit_shift=6)
+
+
+def render(gpu, img, dw, dh, params, ten_bit, env, crop=None, src_fmt="rgba16"):
+    old = {k: os.environ.get(k) for k in env}
+    os.environ.update(env)
+    try:
+        sh, sw = img.shape[:2]
+        src = gpu.tex_create(sw, sh, src_fmt, img)
+        dst = gpu.tex_create(dw, dh, "rgba16")
+        image = pl.frame(src, components=3, crop=crop)
+        target = pl.frame(dst, repr_=pl.color_repr("rgb", "full", **TEN_BIT) if ten_bit else None)
+        rr = pl.Renderer(gpu)
+        util.srand(1)
+        assert rr.render(image, target, params), gpu.messages[-4:]
+        assert rr.errors() == 0
+        out = dst.download()
+        rr.destroy(); src.destroy(); dst.destroy()
+        return out
+    finally:
+        for k, v in old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+
+
+def dither():
+    return capi.DitherParams(method=pl.DITHER_BLUE_NOISE, lut_size=6, transfer=0)
+
+
+@pytest.mark.parametrize("scale", [(2, 2), (3, 2), (1.5, 1.25)])
+@pytest.mark.parametrize("ten_bit", [False, True])
+def test_bilinear_fast_equals_generic(gpu, scale, ten_bit):
+    sw, sh = 100, 58
+    img = util.chirp_rgba16(sw, sh)
+    dw, dh = int(sw * scale[0]), int(sh * scale[1])
+    kw = dict(dither_params=dither(), disable_dither_gamma_correction=True) if ten_bit else {}
+    params = pl.render_params("fast", **kw)
+    outs = [render(gpu, img, dw, dh, params, ten_bit, {"PL_HIP_BILIN_ITERS": it})
+            for it in ("0", "1", "2", "4")]
+    for o in outs[1:]:
+        assert np.array_equal(o, outs[0])
+    assert outs[0][..., :3].std() > 1000
+
+
+def test_bilinear_fast_crop_and_flip(gpu):
+    sw, sh = 96, 64
+    img = util.chirp_rgba16(sw, sh)
+    params = pl.render_params("fast")
+    for crop in [(10.5, 7.25, 80.0, 50.5), (90.0, 60.0, 6.0, 4.0)]:     # second one is flipped
+        a = render(gpu, img, 160, 120, params, False, {"PL_HIP_BILIN_ITERS": "0"}, crop=crop)
+        b = render(gpu, img, 160, 120, params, False, {"PL_HIP_BILIN_ITERS": "1"}, crop=crop)
+        assert np.array_equal(a, b)
+
+
+@pytest.mark.parametrize("name", ["lanczos", "mitchell", "catmull_rom", "spline36", "ginseng"])
+@pytest.mark.parametrize("scale", [(2, 2), (1.6, 2.3)])
+def test_ortho_fast_equals_generic(gpu, name, scale):
+    sw, sh = 90, 62
+    img = util.chirp_rgba16(sw, sh)
+    dw, dh = int(sw * scale[0]), int(sh * scale[1])
+    for ar in (0.0, 0.6):
+        params = pl.render_params("fast", upscaler=pl.filter_config(name), dither_params=dither(),
+                                  disable_dither_gamma_correction=True, antiringing_strength=ar)
+        a = render(gpu, img, dw, dh, params, True, {"PL_HIP_ORTHO_FAST": "0"})
+        b = render(gpu, img, dw, dh, params, True, {"PL_HIP_ORTHO_FAST": "1"})
+        assert np.array_equal(a, b), (name, scale, ar, util.diff_stats(a, b))
+    assert a[..., :3].std() > 1000
+
+
+def test_ortho_fast_without_epilogue_and_with_lite_ops(gpu):
+    """16-bit target (no dither: plain store) and a colour-adjusted target (LITE op chain)."""
+    sw, sh = 90, 62
+    img = util.chirp_rgba16(sw, sh)
+    params = pl.render_params("fast", upscaler=pl.filter_config("lanczos"))
+    a = render(gpu, img, 180, 124, params, False, {"PL_HIP_ORTHO_FAST": "0"})
+    b = render(gpu, img, 180, 124, params, False, {"PL_HIP_ORTHO_FAST": "1"})
+    assert np.array_equal(a, b)
+    adj = capi.ColorAdjustment(brightness=0.05, contrast=1.1, saturation=0.9, hue=0.0, gamma=1.0,
+                               temperature=0.0)
+    params = pl.render_params("fast", upscaler=pl.filter_config("lanczos"), color_adjustment=adj)
+    a = render(gpu, img, 180, 124, params, False, {"PL_HIP_ORTHO_FAST": "0"})
+    b = render(gpu, img, 180, 124, params, False, {"PL_HIP_ORTHO_FAST": "1"})
+    assert np.array_equal(a, b)
+
+
+@pytest.mark.parametrize("scale", [(2, 2), (3, 3), (1.5, 1.5)])
+def test_polar_fused_equals_unfused_and_per_pixel(gpu, scale):
+    sw, sh = 96, 64
+    img = util.chirp_rgba16(sw, sh)
+    dw, dh = int(sw * scale[0]), int(sh * scale[1])
+    params = pl.render_params("fast", upscaler=pl.filter_config("ewa_lanczos"),
+                              dither_params=dither(), disable_dither_gamma_correction=True)
+    base = render(gpu, img, dw, dh, params, True, {})
+    for env in ({"PL_HIP_NO_FUSION": "1"}, {"PL_HIP_POLAR_PER_PIXEL": "1"},
+                {"PL_HIP_NT_STORE": "0"}):
+        o = render(gpu, img, dw, dh, params, True, env)
+        assert np.array_equal(o, base), env
