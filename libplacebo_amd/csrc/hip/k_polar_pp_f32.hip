@@ -1,0 +1,8 @@
+// k_polar_pp instantiations for float LDS tiles (k_polar_pp.hiph)
+#include "k_polar_pp.hiph"
+
+int plh_launch_polar_pp_f32(hipStream_t stream, const plh_pass *pass, dim3 grid, dim3 block,
+                             size_t shmem, int n)
+{
+    return launch_pp_mask<float>(stream, pass, grid, block, shmem, n);
+}
