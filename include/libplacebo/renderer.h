@@ -6,7 +6,7 @@
  *
  * Field names, meanings and defaults are the reference's. Not provided (out of the
  * hot-path scope): hooks, custom LUTs, ICC, overlays, film grain,
- * deinterlacing, frame mixing, distortion / cone distortion, blurred borders, rotation.
+ * deinterlacing, distortion / cone distortion, blurred borders, rotation.
  * Images and targets may be packed, semi-planar or planar / subsampled.
  */
 #ifndef LIBPLACEBO_RENDERER_H_
@@ -81,7 +81,7 @@ struct pl_render_params {
     const struct pl_filter_config *plane_upscaler;      // chroma planes; NULL = upscaler
     const struct pl_filter_config *plane_downscaler;    // chroma planes; NULL = downscaler
     float antiringing_strength;
-    const struct pl_filter_config *frame_mixer;         // unsupported
+    const struct pl_filter_config *frame_mixer;         // pl_render_image_mix only
 
     const struct pl_deband_params *deband_params;
     const struct pl_sigmoid_params *sigmoid_params;
@@ -185,7 +185,47 @@ PL_API bool pl_render_image(pl_renderer rr, const struct pl_frame *image,
                             const struct pl_frame *target,
                             const struct pl_render_params *params);
 
-// Drop cached FBOs / LUT state
+/* ---- frame mixing (reference renderer.h :754-854) ---- */
+
+// A set of frames around the vsync being drawn. `timestamps` are relative to that vsync
+// (it is shown at 0.0 and held for `vsync_duration`), in units of one nominal source frame
+// duration, sorted ascending; zero-order-hold semantics. `signatures` identify frames across
+// calls (rendered frames are cached by signature).
+struct pl_frame_mix {
+    int num_frames;
+    const struct pl_frame **frames;
+    const uint64_t *signatures;
+    const float *timestamps;
+    float vsync_duration;
+};
+
+// The radius of frames a mixer needs around the vsync (0 = built-in oversampling: just the
+// current and the next frame)
+static inline float pl_frame_mix_radius(const struct pl_render_params *params)
+{
+    if (!params->frame_mixer || !params->frame_mixer->kernel)
+        return 0.0;
+    return params->frame_mixer->kernel->radius;
+}
+
+// Frame shown at the current vsync by zero-order hold / nearest-neighbour semantics, or NULL
+PL_API const struct pl_frame *pl_frame_mix_current(const struct pl_frame_mix *mix);
+PL_API const struct pl_frame *pl_frame_mix_nearest(const struct pl_frame_mix *mix);
+
+// Generalisation of pl_render_image: every frame with a non-negligible weight under
+// `params->frame_mixer` (a 1-D pl_filter_config over time, or oversampling) is rendered -- or
+// taken from the cache -- at the output size in the target's colour space, the frames are
+// blended in linear light and the result goes through the output stage. Without a frame mixer
+// (or with a single frame) the nearest frame is rendered. An empty mix is not supported here.
+PL_API bool pl_render_image_mix(pl_renderer rr, const struct pl_frame_mix *images,
+                                const struct pl_frame *target,
+                                const struct pl_render_params *params);
+
+// pl_frames_infer for a mix: adjusts `target` and returns the adjusted reference frame
+PL_API void pl_frames_infer_mix(pl_renderer rr, const struct pl_frame_mix *mix,
+                                struct pl_frame *target, struct pl_frame *out_ref);
+
+// Drop cached FBOs / mixing frames / LUT state
 PL_API void pl_renderer_flush_cache(pl_renderer rr);
 
 // HDR metadata measured by the last frame's peak detection, if any

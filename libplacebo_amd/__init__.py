@@ -418,6 +418,18 @@ def recreate_plane(gpu, data, tex=None):
     return out, Texture(gpu, t)
 
 
+def frame_mix(frames, signatures, timestamps, vsync_duration):
+    """pl_frame_mix around parallel python lists (kept alive on the returned struct)."""
+    n = len(frames)
+    ptrs = (C.POINTER(capi.Frame) * max(n, 1))(*[C.pointer(f) for f in frames])
+    sigs = (C.c_uint64 * max(n, 1))(*signatures)
+    ts = (C.c_float * max(n, 1))(*timestamps)
+    m = capi.FrameMix(num_frames=n, frames=ptrs, signatures=sigs, timestamps=ts,
+                      vsync_duration=vsync_duration)
+    m._keep = (ptrs, sigs, ts, list(frames))
+    return m
+
+
 def render_params(preset="fast", **kw):
     """pl_render_{fast,default,high_quality}_params with overrides; pointer fields accept
     ctypes structs (kept alive on the returned object)."""
@@ -445,6 +457,13 @@ class Renderer:
     def render(self, image, target, params=None):
         return lib().pl_render_image(self.rr, C.byref(image), C.byref(target),
                                      C.byref(params) if params is not None else None)
+
+    def render_mix(self, frames, signatures, timestamps, vsync_duration, target, params=None):
+        """pl_render_image_mix over parallel lists of frames / signatures / timestamps."""
+        return lib().pl_render_image_mix(self.rr, C.byref(frame_mix(frames, signatures, timestamps,
+                                                                   vsync_duration)),
+                                         C.byref(target),
+                                         C.byref(params) if params is not None else None)
 
     def errors(self):
         return lib().pl_renderer_get_errors(self.rr).errors

@@ -316,11 +316,17 @@ class Frame(C.Structure):
                 ("rotation", C.c_int), ("user_data", C.c_void_p)]
 
 
+class FrameMix(C.Structure):
+    _fields_ = [("num_frames", C.c_int), ("frames", C.POINTER(C.POINTER(Frame))),
+                ("signatures", C.POINTER(C.c_uint64)), ("timestamps", C.POINTER(C.c_float)),
+                ("vsync_duration", C.c_float)]
+
+
 class RenderParams(C.Structure):
     _fields_ = [("upscaler", C.POINTER(FilterConfig)), ("downscaler", C.POINTER(FilterConfig)),
                 ("plane_upscaler", C.POINTER(FilterConfig)),
                 ("plane_downscaler", C.POINTER(FilterConfig)),
-                ("antiringing_strength", C.c_float), ("frame_mixer", C.c_void_p),
+                ("antiringing_strength", C.c_float), ("frame_mixer", C.POINTER(FilterConfig)),
                 ("deband_params", C.POINTER(DebandParams)),
                 ("sigmoid_params", C.POINTER(SigmoidParams)),
                 ("color_adjustment", C.POINTER(ColorAdjustment)),
@@ -430,6 +436,10 @@ def declare(lib):
     fn("pl_renderer_reset_errors", None, vp, P(RenderErrors))
     fn("pl_render_image", C.c_bool, vp, P(Frame), P(Frame), P(RenderParams))
     fn("pl_frames_infer", None, vp, P(Frame), P(Frame))
+    fn("pl_render_image_mix", C.c_bool, vp, P(FrameMix), P(Frame), P(RenderParams))
+    fn("pl_frames_infer_mix", None, vp, P(FrameMix), P(Frame), P(Frame))
+    fn("pl_frame_mix_current", P(Frame), P(FrameMix))
+    fn("pl_frame_mix_nearest", P(Frame), P(FrameMix))
     fn("pl_frame_set_chroma_location", None, P(Frame), C.c_int)
     fn("pl_plane_data_from_mask", None, P(PlaneData), P(C.c_uint64))
     fn("pl_plane_data_from_comps", None, P(PlaneData), P(C.c_int), P(C.c_int))

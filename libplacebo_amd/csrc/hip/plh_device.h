@@ -176,6 +176,9 @@ enum plh_op_kind {
     //   i2 = fmt | comps << 8 | linear << 12 | address << 13 | on_grid << 15 | map << 16 (4 x 4
     //   bits, 0xf = none); f[0..7] = tex_coord at the 4 corners; f[9], f[10] = |rect| in texels
     PLH_OP_PLANE_FETCH,
+    // frame mixing (pl_render_image_mix, renderer.c:3944-3993): a second colour register
+    PLH_OP_MIX_ADD,         // mix_color += f[0] * color   (mix_color starts at 0)
+    PLH_OP_MIX_END,         // color = mix_color
 };
 
 // flags in plh_op.i1 of LINEARIZE / DELINEARIZE / PEAK_DETECT

@@ -28,6 +28,8 @@
 #include "shaders_priv.h"
 
 #define MAX_FBOS 16
+#define MAX_MIX_FRAMES 16        // renderer.c:3610
+#define MAX_CACHED_FRAMES 32
 
 struct sampler {
     pl_shader_obj upscaler_state;
@@ -50,6 +52,21 @@ struct pl_renderer_t {
     pl_shader_obj tone_map_state;
     pl_shader_obj dither_state;
     int prev_dither;
+
+    // frame mixing cache (pl_render_image_mix, renderer.c:82-110 `struct cached_frame`)
+    struct cached_frame {
+        uint64_t signature;
+        uint64_t params_hash;       // of the params it was rendered with
+        struct pl_color_space color;
+        struct pl_color_repr repr;
+        pl_tex tex;
+        int comps;
+        pl_rect2df crop;
+        bool evict;                 // for garbage collection
+    } frames[MAX_CACHED_FRAMES];
+    int num_frames;
+    pl_tex frame_fbos[MAX_CACHED_FRAMES];   // textures of evicted frames, for reuse
+    int num_frame_fbos;
 };
 
 enum sampler_type {
@@ -114,6 +131,7 @@ static void info_callback(void *priv, const struct pl_dispatch_info *dinfo)
 }
 
 #define RR_ERR(rr, ...)  pl_msg((rr)->log, PL_LOG_ERR, __VA_ARGS__)
+#define PL_WARN_RR(rr, ...) pl_msg((rr)->log, PL_LOG_WARN, __VA_ARGS__)
 #define RR_WARN(rr, ...) pl_msg((rr)->log, PL_LOG_WARN, __VA_ARGS__)
 #define RR_INFO(rr, ...) pl_msg((rr)->log, PL_LOG_INFO, __VA_ARGS__)
 
@@ -158,8 +176,18 @@ static void sampler_destroy(struct sampler *s)
     pl_shader_obj_destroy(&s->downscaler_state);
 }
 
+static void frame_cache_flush(pl_renderer rr)
+{
+    for (int i = 0; i < rr->num_frames; i++)
+        pl_tex_destroy(rr->gpu, &rr->frames[i].tex);
+    for (int i = 0; i < rr->num_frame_fbos; i++)
+        pl_tex_destroy(rr->gpu, &rr->frame_fbos[i]);
+    rr->num_frames = rr->num_frame_fbos = 0;
+}
+
 void pl_renderer_flush_cache(pl_renderer rr)
 {
+    frame_cache_flush(rr);
     for (int i = 0; i < rr->num_fbos; i++)
         pl_tex_destroy(rr->gpu, &rr->fbos[i]);
     rr->num_fbos = 0;
@@ -1592,13 +1620,40 @@ static void pass_uninit(struct pass_state *pass)
 static bool unsupported(pl_renderer rr, const struct pl_render_params *p)
 {
     if (p->cone_params || p->blend_params || p->deinterlace_params || p->distort_params ||
-        p->num_hooks || p->lut || p->frame_mixer)
+        p->num_hooks || p->lut)
     {
         RR_ERR(rr, "pl_render_params requests a stage outside this backend's hot path "
-               "(cone / blend / deinterlace / distort / hooks / LUT / frame mixing)");
+               "(cone / blend / deinterlace / distort / hooks / LUT)");
         return true;
     }
     return false;
+}
+
+// acquire + validate + infer (pass_init :3391-3428)
+static bool pass_init(struct pass_state *pass, bool acquire_image)
+{
+    pl_renderer rr = pass->rr;
+    if (!pass->acquired_target && pass->target.acquire) {
+        if (!pass->target.acquire(rr->gpu, &pass->target))
+            return false;
+        pass->acquired_target = true;
+    }
+    if (acquire_image && pass->image.acquire) {
+        if (!pass->image.acquire(rr->gpu, &pass->image)) {
+            pass_uninit(pass);
+            return false;
+        }
+        pass->acquired_image = true;
+    }
+    if (!validate_frame(rr, &pass->image, "Image", false) ||
+        !validate_frame(rr, &pass->target, "Target", true))
+    {
+        pass_uninit(pass);
+        return false;
+    }
+    find_fbo_format(pass);
+    pass_fix_frames(pass);
+    return true;
 }
 
 bool pl_render_image(pl_renderer rr, const struct pl_frame *pimage, const struct pl_frame *ptarget,
@@ -1619,28 +1674,8 @@ bool pl_render_image(pl_renderer rr, const struct pl_frame *pimage, const struct
         .image = *pimage,
         .target = *ptarget,
     };
-
-    if (pass.target.acquire) {
-        if (!pass.target.acquire(rr->gpu, &pass.target))
-            return false;
-        pass.acquired_target = true;
-    }
-    if (pass.image.acquire) {
-        if (!pass.image.acquire(rr->gpu, &pass.image)) {
-            pass_uninit(&pass);
-            return false;
-        }
-        pass.acquired_image = true;
-    }
-    if (!validate_frame(rr, &pass.image, "Image", false) ||
-        !validate_frame(rr, &pass.target, "Target", true))
-    {
-        pass_uninit(&pass);
+    if (!pass_init(&pass, true))
         return false;
-    }
-
-    find_fbo_format(&pass);
-    pass_fix_frames(&pass);
 
     // no-op (empty crop)
     if (!pl_rect_w(pass.dst_rect) || !pl_rect_h(pass.dst_rect)) {
@@ -1667,6 +1702,413 @@ error:
     RR_ERR(rr, "Failed rendering image!");
     pass_uninit(&pass);
     return false;
+}
+
+/* ---- frame mixing (pl_render_image_mix, renderer.c:3477-3508, 3612-4028) ---------------------- */
+
+const struct pl_frame *pl_frame_mix_current(const struct pl_frame_mix *mix)
+{
+    const struct pl_frame *cur = NULL;
+    for (int i = 0; i < mix->num_frames && mix->timestamps[i] <= 0.0f; i++)
+        cur = mix->frames[i];
+    return cur;
+}
+
+const struct pl_frame *pl_frame_mix_nearest(const struct pl_frame_mix *mix)
+{
+    if (!mix->num_frames)
+        return NULL;
+    // timestamps are sorted: |ts| falls, then rises
+    int best = 0;
+    for (int i = 1; i < mix->num_frames; i++) {
+        if (fabsf(mix->timestamps[i]) < fabsf(mix->timestamps[best]))
+            best = i;
+        else
+            break;
+    }
+    return mix->frames[best];
+}
+
+// Everything in pl_render_params that changes how a cached frame looks (render_params_info
+// :3510-3560 hashes the same set): the struct itself minus callbacks, plus what it points to.
+static uint64_t fnv1a(uint64_t h, const void *data, size_t size)
+{
+    const uint8_t *p = data;
+    for (size_t i = 0; i < size; i++)
+        h = (h ^ p[i]) * 0x100000001b3ull;
+    return h;
+}
+
+static uint64_t params_hash(const struct pl_render_params *params)
+{
+    struct pl_render_params p = *params;
+    p.info_callback = NULL;
+    p.info_priv = NULL;
+    uint64_t h = 0xcbf29ce484222325ull;
+#define HASH_PTR(field)                                         \
+    do {                                                        \
+        if (p.field)                                            \
+            h = fnv1a(h, p.field, sizeof(*p.field));            \
+        p.field = NULL;                                         \
+    } while (0)
+    HASH_PTR(upscaler); HASH_PTR(downscaler); HASH_PTR(plane_upscaler); HASH_PTR(plane_downscaler);
+    HASH_PTR(frame_mixer); HASH_PTR(deband_params); HASH_PTR(sigmoid_params);
+    HASH_PTR(color_adjustment); HASH_PTR(peak_detect_params); HASH_PTR(color_map_params);
+    HASH_PTR(dither_params); HASH_PTR(error_diffusion);
+#undef HASH_PTR
+    return fnv1a(h, &p, sizeof(p));
+}
+
+static bool rect2df_eq(pl_rect2df a, pl_rect2df b)
+{
+    return a.x0 == b.x0 && a.y0 == b.y0 && a.x1 == b.x1 && a.y1 == b.y1;
+}
+
+// `color = texel of frame` for every frame but the first (which the pass' sampler reads)
+static bool mix_fetch(pl_renderer rr, pl_shader sh, pl_tex tex, bool linear)
+{
+    pl_shader psh = pl_dispatch_begin(rr->dp);
+    const struct pl_sample_src src = { .tex = tex };
+    bool ok = linear ? pl_shader_sample_bilinear(psh, &src) : pl_shader_sample_nearest(psh, &src);
+    const struct pl_plane whole = { .components = 4, .component_mapping = { 0, 1, 2, 3 } };
+    ok = ok && merge_plane_fetch(sh, psh, &whole);
+    pl_dispatch_abort(rr->dp, &psh);
+    return ok;
+}
+
+bool pl_render_image_mix(pl_renderer rr, const struct pl_frame_mix *images,
+                         const struct pl_frame *ptarget, const struct pl_render_params *params)
+{
+    params = PL_DEF(params, &pl_render_default_params);
+    if (!images || !images->num_frames) {
+        RR_ERR(rr, "pl_render_image_mix: an empty mix (overlay-only rendering) is not supported");
+        return false;
+    }
+    if (unsupported(rr, params))
+        return false;
+    if (!(images->vsync_duration > 0.0f)) {
+        RR_ERR(rr, "pl_render_image_mix: vsync_duration must be positive");
+        return false;
+    }
+    for (int i = 0; i + 1 < images->num_frames; i++) {
+        if (!(images->timestamps[i] <= images->timestamps[i + 1])) {
+            RR_ERR(rr, "pl_render_image_mix: timestamps must be sorted");
+            return false;
+        }
+    }
+
+    const uint64_t phash = params_hash(params);
+    const struct pl_frame *refimg = pl_frame_mix_nearest(images);
+    struct pass_state pass = {
+        .rr = rr,
+        .params = params,
+        .image = *refimg,
+        .target = *ptarget,
+        .info.stage = PL_RENDER_STAGE_BLEND,
+    };
+
+    if (rr->errors & PL_RENDER_ERR_FRAME_MIXING)
+        goto fallback;
+    if (!pass_init(&pass, false))
+        return false;
+    if (!pass.fbofmt[4])
+        goto fallback;
+
+    const struct pl_frame *target = &pass.target;
+    const int out_w = abs(pl_rect_w(pass.dst_rect)), out_h = abs(pl_rect_h(pass.dst_rect));
+    if (!out_w || !out_h)
+        goto fallback;
+
+    int fidx = 0;
+    struct cached_frame frames[MAX_MIX_FRAMES];
+    float weights[MAX_MIX_FRAMES];
+    float wsum = 0.0f;
+
+    // garbage collection: everything not touched below is evicted
+    for (int i = 0; i < rr->num_frames; i++)
+        rr->frames[i].evict = true;
+
+    // blur the mixer by the vsync ratio (source / display)
+    struct pl_filter_config mixer = {0};
+    if (params->frame_mixer) {
+        mixer = *params->frame_mixer;
+        mixer.blur = PL_DEF(mixer.blur, 1.0f);
+        for (int i = 1; i < images->num_frames; i++) {
+            if (images->timestamps[i] >= 0.0f && images->timestamps[i - 1] < 0.0f) {
+                const float frame_dur = images->timestamps[i] - images->timestamps[i - 1];
+                const float sample_dur = PL_MAX(frame_dur, images->vsync_duration);
+                if (sample_dur > 1.0f && !params->skip_anti_aliasing)
+                    mixer.blur *= sample_dur;
+                break;
+            }
+        }
+    }
+
+    bool single_frame = !params->frame_mixer || images->num_frames == 1;
+retry:
+    for (int i = 0; i < images->num_frames; i++) {
+        const uint64_t sig = images->signatures[i];
+        float rts = images->timestamps[i];
+        const struct pl_frame *img = images->frames[i];
+        if (img->rotation != refimg->rotation)
+            continue; // (only PL_ROTATION_0 passes validation anyway)
+
+        float weight;
+        if (single_frame) {
+            // only the reference image is rendered
+            if (img != refimg)
+                continue;
+            weight = 1.0f;
+        } else if (!mixer.kernel || mixer.kernel == &pl_filter_function_oversample) {
+            // weight = fraction of the vsync interval during which the frame is visible
+            float end = i + 1 < images->num_frames ? images->timestamps[i + 1] : INFINITY;
+            if (rts > images->vsync_duration || end < 0.0f)
+                continue;
+            rts = PL_MAX(rts, 0.0f);
+            end = PL_MIN(end, images->vsync_duration);
+            weight = (end - rts) / images->vsync_duration;
+            if (mixer.kernel && weight < mixer.kernel->params[0])
+                weight = 0.0f; // culled by the oversampling threshold
+        } else {
+            if (fabsf(rts) >= pl_filter_radius_bound(&mixer))
+                continue;
+            weight = pl_filter_sample(&mixer, rts);
+        }
+
+        struct cached_frame *f = NULL;
+        for (int j = 0; j < rr->num_frames; j++) {
+            if (rr->frames[j].signature == sig) {
+                f = &rr->frames[j];
+                f->evict = false;
+                break;
+            }
+        }
+
+        // negligible contributions are skipped -- after the lookup, so that these frames are
+        // not evicted yet; never the reference image (at least one frame must remain)
+        if (fabsf(weight) <= 1e-3f && img != refimg)
+            continue;
+
+        // (the reference also bypasses the cache for "trivial" params; that only saves a copy)
+        const bool skip_cache = single_frame && params->skip_caching_single_frame;
+        if (!f && skip_cache)
+            goto fallback;
+
+        if (!f) {
+            if (rr->num_frames == MAX_CACHED_FRAMES) {
+                PL_WARN_RR(rr, "Frame mixing cache is full, rendering without mixing");
+                goto fallback;
+            }
+            f = &rr->frames[rr->num_frames++];
+            *f = (struct cached_frame) { .signature = sig };
+        }
+
+        bool can_reuse = f->tex;
+        const bool strict_reuse = skip_cache || single_frame || !params->preserve_mixing_cache;
+        if (can_reuse && strict_reuse) {
+            can_reuse = f->tex->params.w == out_w && f->tex->params.h == out_h &&
+                        rect2df_eq(f->crop, img->crop) && f->params_hash == phash &&
+                        pl_color_space_equal(&f->color, &target->color);
+        }
+        if (!can_reuse && skip_cache)
+            goto fallback;
+
+        if (!can_reuse) {
+            // (re-)render this frame, up to where pass_output_target would take over
+            if (!f->tex && rr->num_frame_fbos)
+                f->tex = rr->frame_fbos[--rr->num_frame_fbos];
+            pl_fmt fmt = pass.fbofmt[4];
+            if (!pl_tex_recreate(rr->gpu, &f->tex, pl_tex_params(
+                    .w = out_w, .h = out_h, .format = fmt,
+                    .sampleable = true, .renderable = true, .storable = true,
+                    .blit_dst = !!(fmt->caps & PL_FMT_CAP_BLITTABLE))))
+            {
+                RR_ERR(rr, "Could not create intermediate texture for frame mixing.. disabling!");
+                rr->errors |= PL_RENDER_ERR_FRAME_MIXING;
+                goto fallback;
+            }
+
+            struct pass_state inter = {
+                .rr = rr,
+                .params = params,
+                .image = *img,
+                .target = *ptarget,
+                .info.stage = PL_RENDER_STAGE_FRAME,
+                .acquired_target = pass.acquired_target, // (already acquired by `pass`)
+            };
+            if (!pass_init(&inter, true))
+                goto fail;
+            inter.acquired_target = false; // released by `pass`
+            inter.target = pass.target;
+
+            pl_dispatch_reset_frame(rr->dp);
+            pl_dispatch_callback(rr->dp, &inter, info_callback);
+            bool ok = pass_read_image(&inter) && pass_scale_main(&inter);
+            if (ok) {
+                pass_convert_colors(&inter);
+                ok = inter.img.sh || inter.img.tex;
+            }
+            if (ok) {
+                pl_shader sh = img_sh(&inter, &inter.img);
+                pl_shader_set_alpha(sh, &inter.img.repr, PL_ALPHA_PREMULTIPLIED); // for mixing
+                ok = inter.img.w == out_w && inter.img.h == out_h &&
+                     pl_dispatch_finish(rr->dp, pl_dispatch_params(
+                         .shader = &inter.img.sh, .target = f->tex));
+            }
+            if (ok) {
+                f->params_hash = phash;
+                f->crop = img->crop;
+                f->color = inter.img.color;
+                f->repr = inter.img.repr;
+                f->comps = inter.img.comps;
+            }
+            pass_uninit(&inter);
+            if (!ok)
+                goto fail;
+        }
+
+        if (fidx == MAX_MIX_FRAMES)
+            break;
+        frames[fidx] = *f;
+        weights[fidx] = weight;
+        wsum += weight;
+        fidx++;
+    }
+
+    // evict what this mix did not touch
+    for (int i = 0; i < rr->num_frames; ) {
+        if (!rr->frames[i].evict) {
+            i++;
+            continue;
+        }
+        if (rr->frames[i].tex) {
+            if (rr->num_frame_fbos < MAX_CACHED_FRAMES)
+                rr->frame_fbos[rr->num_frame_fbos++] = rr->frames[i].tex;
+            else
+                pl_tex_destroy(rr->gpu, &rr->frames[i].tex);
+        }
+        rr->frames[i] = rr->frames[--rr->num_frames];
+    }
+
+    // nothing left: zero-order hold
+    if (!fidx) {
+        if (single_frame)
+            goto fallback;
+        single_frame = true;
+        goto retry;
+    }
+
+    // ---- sample and mix --------------------------------------------------------------------
+    pl_dispatch_reset_frame(rr->dp);
+    pl_dispatch_callback(rr->dp, &pass, info_callback);
+    pass.info.count = fidx;
+
+    pl_shader sh = pl_dispatch_begin(rr->dp);
+    // with a single frame there is nothing to mix: no linearize / delinearize round trip
+    const bool mixing = fidx > 1;
+    struct pl_color_space mix_csp = target->color;
+    if (mixing)
+        mix_csp.transfer = PL_COLOR_TRC_LINEAR;
+
+    int comps = 0;
+    bool ok = true;
+    for (int i = 0; i < fidx && ok; i++) {
+        const struct pl_tex_params *tp = &frames[i].tex->params;
+        const bool linear = (tp->w != out_w || tp->h != out_h) &&
+                            (tp->format->caps & PL_FMT_CAP_LINEAR);
+        if (i == 0) {
+            const struct pl_sample_src src = { .tex = frames[i].tex, .new_w = out_w, .new_h = out_h };
+            ok = linear ? pl_shader_sample_bilinear(sh, &src) : pl_shader_sample_nearest(sh, &src);
+        } else {
+            ok = mix_fetch(rr, sh, frames[i].tex, linear);
+        }
+        if (!ok)
+            break;
+
+        // usually just the linearization; handles mixed-colorspace frames when
+        // preserve_mixing_cache spans target changes (differences in HDR metadata are ignored)
+        struct pl_color_repr frame_repr = frames[i].repr;
+        struct pl_color_space frame_csp = frames[i].color;
+        frame_csp.hdr = mix_csp.hdr;
+        if (!pl_color_space_equal(&frame_csp, &mix_csp)) {
+            pl_shader_set_alpha(sh, &frame_repr, PL_ALPHA_INDEPENDENT);
+            pl_shader_color_map_ex(sh, NULL, pl_color_map_args(.src = frame_csp, .dst = mix_csp));
+        }
+        pl_shader_set_alpha(sh, &frame_repr, PL_ALPHA_PREMULTIPLIED);
+
+        if (mixing) {
+            struct plh_op *op = sh_op(sh, PLH_OP_MIX_ADD);
+            if (!op) {
+                ok = false;
+                break;
+            }
+            op->f[0] = weights[i] / wsum;
+            sh_listf(sh, "mix_color += %g * color\n", op->f[0]);
+        }
+        comps = PL_MAX(comps, frames[i].comps);
+    }
+    if (ok && mixing) {
+        ok = !!sh_op(sh, PLH_OP_MIX_END);
+        sh_listf(sh, "color = mix_color\n");
+    }
+    if (!ok || pl_shader_is_failed(sh)) {
+        // (more frames than one pass can hold ops for)
+        PL_WARN_RR(rr, "Frame mixing pass could not be recorded (%d frames), rendering the "
+                   "nearest frame instead", fidx);
+        pl_dispatch_abort(rr->dp, &sh);
+        goto fallback;
+    }
+    sh_describef(sh, "frame mixing (%d frame%s)", fidx, fidx > 1 ? "s" : "");
+
+    pass.img = (struct img) {
+        .sh = sh,
+        .w = out_w,
+        .h = out_h,
+        .comps = comps,
+        .color = target->color,
+        .rect = { 0, 0, out_w, out_h },
+        .repr = {
+            .sys = PL_COLOR_SYSTEM_RGB,
+            .levels = PL_COLOR_LEVELS_FULL,
+            .alpha = comps >= 4 ? PL_ALPHA_PREMULTIPLIED : PL_ALPHA_NONE,
+        },
+    };
+
+    // re-encode to the target transfer (in practice: delinearize)
+    if (!pl_color_space_equal(&mix_csp, &pass.img.color)) {
+        pl_shader_set_alpha(sh, &pass.img.repr, PL_ALPHA_INDEPENDENT);
+        pl_shader_color_map_ex(sh, NULL, pl_color_map_args(.src = mix_csp, .dst = pass.img.color));
+    }
+
+    if (!pass_output_target(&pass))
+        goto fallback;
+
+    pass_uninit(&pass);
+    return true;
+
+fail:
+    RR_ERR(rr, "Could not render image for frame mixing.. disabling!");
+    rr->errors |= PL_RENDER_ERR_FRAME_MIXING;
+    // fall through
+
+fallback:
+    pass_uninit(&pass);
+    return pl_render_image(rr, refimg, ptarget, params);
+}
+
+void pl_frames_infer_mix(pl_renderer rr, const struct pl_frame_mix *mix, struct pl_frame *target,
+                         struct pl_frame *out_ref)
+{
+    const struct pl_frame *refimg = pl_frame_mix_nearest(mix);
+    if (!refimg) {
+        if (out_ref)
+            *out_ref = (struct pl_frame) {0};
+        return;
+    }
+    struct pl_frame ref = *refimg;
+    pl_frames_infer(rr, &ref, target);
+    if (out_ref)
+        *out_ref = ref;
 }
 
 /* Test hook: record `color *= s` the way pass_output_target does (there is no public
