@@ -14,6 +14,7 @@ Workloads (BASELINE.json `configs`):
         pre-ops (same values, PL_HIP_NO_FUSION=1 restores the two-pass structure).
   bilinear_1080p_to_4k               configs[1]: bilinear + sRGB passthrough, one pass.
   lanczos_1080p_to_4k_dither10       the separable (two-pass) Lanczos upscale, same output format
+  default_preset_1080p_to_4k         pl_render_default_params untouched (lanczos, sigmoid, dither)
   hdr10_4k_tonemap                   configs[3]: 4K BT.2020/PQ -> BT.709 SDR, same-frame peak
         detection (histogram) + spline tone mapping + perceptual gamut mapping 3D-LUT.
   ewa_8k_to_4k_deband_tonemap        configs[4], one stream: 8K HDR -> 4K SDR, deband + EWA
@@ -59,6 +60,8 @@ WORKLOADS = {
     "bilinear_1080p_to_4k": (P1080, P4K, px(P1080) * 8 + px(P4K) * 8, None),
     # the separable counterpart of the headline (pl_render_default_params' upscaler): two passes
     "lanczos_1080p_to_4k_dither10": (P1080, P4K, px(P1080) * 8 + px(P4K) * 8, "ortho"),
+    # pl_render_default_params as shipped: lanczos in linear, sigmoidized light + dither
+    "default_preset_1080p_to_4k": (P1080, P4K, px(P1080) * 8 + px(P4K) * 8, "ortho"),
     "hdr10_4k_tonemap": (P4K, P4K, 3 * px(P4K) * 8, "tone map"),
     "ewa_8k_to_4k_deband_tonemap": (P8K, P4K, px(P8K) * 8 + px(P4K) * 8, "polar"),
     # the metric's two halves in one frame: 1080p HDR10 -> EWA 2x upscale -> tone map -> 4K SDR
@@ -109,6 +112,9 @@ class Stream:
             self.params = pl.render_params("fast", upscaler=pl.filter_config("lanczos"),
                                            dither_params=dither,
                                            disable_dither_gamma_correction=True)
+            icsp, tcsp, trepr = sdr, sdr, ten_bit
+        elif workload == "default_preset_1080p_to_4k":
+            self.params = pl.render_params("default")
             icsp, tcsp, trepr = sdr, sdr, ten_bit
         elif workload == "hdr10_4k_tonemap":
             self.params = pl.render_params(

@@ -179,7 +179,8 @@ void k_ortho(const plh_pass p_)
  *   - two horizontally adjacent pixels per lane: one 16-byte store per lane and row
  *   - weights: the two LUT rows bracketing fcoord as 16-byte loads (rows are 16-byte aligned)
  *   - all texel loads of both pixels in flight before the first fma
- *   - EPI 0: no colour ops; 1: fused epilogue (fastepi.hiph) -> rgba16; 2: LITE op interpreter
+ *   - EPI 0: no colour ops; 1: fused epilogue (fastepi.hiph) -> rgba16; 2 / 3: LITE / full op
+ *     interpreter (3 = pl_render_default_params: unsigmoidize + delinearize + dither)
  */
 DEV uint2 of_load(const char *base, int pitch, int x, int y)
 {
@@ -375,6 +376,8 @@ void k_ortho_fast(const plh_pass p_)
     } else {
         if constexpr (EPI == 2)
             apply_ops_n<2, false, true>(outs, p.ops, 0, p.num_ops, fcs);
+        if constexpr (EPI == 3)
+            apply_ops_n<2, false, false>(outs, p.ops, 0, p.num_ops, fcs);
         plh_store_n<2>(p.dst, sx, sy, ok, outs, p.nt_store);
     }
 }
@@ -396,7 +399,8 @@ static void launch_ortho_fast(hipStream_t stream, const plh_pass *pass, int epi)
     } while (0)
     if (epi == 0)      LAUNCH(0);
     else if (epi == 1) LAUNCH(1);
-    else               LAUNCH(2);
+    else if (epi == 2) LAUNCH(2);
+    else               LAUNCH(3);
 #undef LAUNCH
 #undef LAUNCH_N
 }
@@ -418,7 +422,12 @@ static int ortho_fast_variant(plh_pass *pass)
     plh_match_fast_epilogue(pass, true);
     if (pass->epi.enabled)
         return 1;
-    return plh_ops_lite(pass, 0, pass->num_ops) ? 2 : -1;
+    for (int i = 0; i < pass->num_ops; i++) {
+        const int k = pass->ops[i].kind;
+        if (k == PLH_OP_PEAK_DETECT || k == PLH_OP_MIX_ADD)
+            return -1;  // need their own kernels
+    }
+    return plh_ops_lite(pass, 0, pass->num_ops) ? 2 : 3;
 }
 
 int plh_launch_ortho(hipStream_t stream, const plh_pass *pass)

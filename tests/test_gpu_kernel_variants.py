@@ -100,6 +100,18 @@ def test_ortho_fast_without_epilogue_and_with_lite_ops(gpu):
     assert np.array_equal(a, b)
 
 
+def test_ortho_fast_default_preset(gpu):
+    """pl_render_default_params: lanczos in linear + sigmoidized light; the horizontal pass
+    carries unsigmoidize + delinearize + dither (the full op interpreter, EPI 3)."""
+    sw, sh = 90, 62
+    img = util.chirp_rgba16(sw, sh)
+    params = pl.render_params("default")
+    a = render(gpu, img, 180, 124, params, True, {"PL_HIP_ORTHO_FAST": "0"})
+    b = render(gpu, img, 180, 124, params, True, {"PL_HIP_ORTHO_FAST": "1"})
+    assert np.array_equal(a, b)
+    assert a[..., :3].std() > 1000
+
+
 @pytest.mark.parametrize("scale", [(2, 2), (3, 3), (1.5, 1.5)])
 def test_polar_fused_equals_unfused_and_per_pixel(gpu, scale):
     sw, sh = 96, 64
