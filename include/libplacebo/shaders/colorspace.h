@@ -146,10 +146,14 @@ struct pl_color_map_args {
     struct pl_color_space dst;
     bool prelinearized;
     pl_shader_obj *state;   // tone/gamut LUTs + detected peak
-    pl_tex feature_map;     // contrast recovery (not supported yet)
+    pl_tex feature_map;     // contrast recovery: low-resolution r16hf map of
+                            // pl_shader_extract_features output (NULL = none)
 };
 
 #define pl_color_map_args(...) (&(struct pl_color_map_args) { __VA_ARGS__ })
+
+// Replaces the colour by the feature the contrast-recovery stage works on: (I of IPT, 0, 0, 1)
+PL_API void pl_shader_extract_features(pl_shader sh, struct pl_color_space csp);
 
 PL_API void pl_shader_color_map_ex(pl_shader sh, const struct pl_color_map_params *params,
                                    const struct pl_color_map_args *args);

@@ -241,10 +241,15 @@ class Shader:
         pp = peak_detect_params(**kw)
         return lib().pl_shader_detect_peak(self.sh, csp, C.byref(state_obj.slot), C.byref(pp))
 
-    def color_map(self, src, dst, state_obj=None, params=None, prelinearized=False):
+    def extract_features(self, csp):
+        lib().pl_shader_extract_features(self.sh, csp)
+
+    def color_map(self, src, dst, state_obj=None, params=None, prelinearized=False,
+                  feature_map=None):
         params = params or color_map_params()
         args = capi.ColorMapArgs(src=src, dst=dst, prelinearized=prelinearized,
-                                 state=C.pointer(state_obj.slot) if state_obj else None)
+                                 state=C.pointer(state_obj.slot) if state_obj else None,
+                                 feature_map=feature_map.ptr if feature_map else None)
         self._keep.append((params, args))
         lib().pl_shader_color_map_ex(self.sh, C.byref(params), C.byref(args))
 

@@ -462,6 +462,7 @@ def declare(lib):
     fn("pl_reset_detected_peak", None, vp)
     fn("pl_hip_peak_buffer", vp, vp, P(C.c_size_t))
     fn("pl_shader_color_map_ex", None, vp, P(ColorMapParams), P(ColorMapArgs))
+    fn("pl_shader_extract_features", None, vp, ColorSpace)
     fn("pl_find_tone_map_function", vp, C.c_char_p)
     fn("pl_find_gamut_map_function", vp, C.c_char_p)
     fn("pl_color_space_nominal_luma_ex", None, vp)

@@ -158,7 +158,7 @@ void k_ortho(const plh_pass p_)
 
     float4_t outs[1] = { out };
     const frag_t fcs[1] = { { (float) (idx + p.frag_x0) + 0.5f, (float) (idy + p.frag_y0) + 0.5f,
-                              0.0f, 0 } };
+                              0.0f, 0, mx, my } };
     apply_ops_n<1, false, LITE>(outs, p.ops, 0, p.num_ops, fcs);
 
     // guarded store (dispatch.c:1126-1142)
@@ -348,7 +348,8 @@ void k_ortho_fast(const plh_pass p_)
 #pragma unroll
     for (int q = 0; q < 2; q++) {
         const int idx = 2 * cx + q;
-        fcs[q] = { (float) (idx + p.frag_x0) + 0.5f, (float) (idy + p.frag_y0) + 0.5f, 0.0f, 0 };
+        fcs[q] = { (float) (idx + p.frag_x0) + 0.5f, (float) (idy + p.frag_y0) + 0.5f, 0.0f, 0,
+                   p.out_scale[0] * ((float) idx + 0.5f), my };
         sx[q] = p.base_x + p.dir_x * (p.transpose ? idy : idx);
         sy[q] = p.base_y + p.dir_y * (p.transpose ? idx : idy);
         ok[q] = p.out_scale[0] * (float) idx < 1.0f && p.out_scale[1] * (float) idy < 1.0f &&

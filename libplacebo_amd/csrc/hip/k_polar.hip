@@ -180,7 +180,9 @@ void k_polar(const plh_pass p_)
         if (!(MASK & 8u))
             out.w = 1.0f;
 
-        const frag_t fc = { (float) (idx + p.frag_x0) + 0.5f, (float) (idy + p.frag_y0) + 0.5f };
+        const frag_t fc = { (float) (idx + p.frag_x0) + 0.5f, (float) (idy + p.frag_y0) + 0.5f,
+                            0.0f, 0, p.out_scale[0] * ((float) idx + 0.5f),
+                            p.out_scale[1] * ((float) idy + 0.5f) };
         apply_ops(out, p.ops, p.num_pre_ops, p.num_ops, fc);
 
         // guarded store (dispatch.c:1126-1142)

@@ -164,6 +164,9 @@ enum plh_op_kind {
     // colour mapping (colorspace.c:1612-2024), four ops sharing `aux` = i_orig:
     PLH_OP_RGB2IPT,         // f[0..8] = rgb2lms, f[9..13] = 203/10000, m1, c1, c2, c3; f[14] = m2
     PLH_OP_TONE_MAP,        // i0 = mode (0 clip, 1 linear, 2 LUT); f[] see k; ptr = LUT; i1 = size
+                            // contrast recovery (:1880-1921): ptr2 = r16hf feature map,
+                            // i2 = w | h << 16 (0 = off), f[4] = pitch (int bits),
+                            // f[5] = strength, f[6], f[7] = output min / max
     PLH_OP_GAMUT_LUT,       // ptr = rgba16 3-D LUT; i0,i1,i2 = sizes; f[0]=scale f[1]=offset f[2]=0.5/pi
     PLH_OP_IPT2RGB,         // f[0..8] = lms2rgb, f[9..14] = 1/m2, c1, c2, c3, 1/m1, 10000/203
     PLH_OP_PEAK_DETECT,     // see k_peak.hip; only valid in the 16x16 peak kernel
@@ -179,6 +182,9 @@ enum plh_op_kind {
     // frame mixing (pl_render_image_mix, renderer.c:3944-3993): a second colour register
     PLH_OP_MIX_ADD,         // mix_color += f[0] * color   (mix_color starts at 0)
     PLH_OP_MIX_END,         // color = mix_color
+    // pl_shader_extract_features (colorspace.c:1383-1404): color = (I of IPT, 0, 0, 1);
+    // f[0..8] = (203/10000) * rgb2lms, f[9..13] = m1 c1 c2 c3 m2
+    PLH_OP_FEATURES,
 };
 
 // flags in plh_op.i1 of LINEARIZE / DELINEARIZE / PEAK_DETECT

@@ -47,6 +47,7 @@ struct pl_renderer_t {
 
     struct sampler sampler_main;
     struct sampler sampler_src;
+    struct sampler sampler_contrast;             // feature map of the contrast recovery
     struct sampler samplers_aux[PL_MAX_PLANES];  // chroma / alpha plane scalers
     struct sampler samplers_dst[PL_MAX_PLANES];  // planar output
     pl_shader_obj tone_map_state;
@@ -80,7 +81,7 @@ enum sampler_type {
 };
 
 enum sampler_dir { SAMPLER_NOOP, SAMPLER_UP, SAMPLER_DOWN };
-enum sampler_usage { SAMPLER_MAIN, SAMPLER_PLANE };
+enum sampler_usage { SAMPLER_MAIN, SAMPLER_PLANE, SAMPLER_LOWPASS };
 
 struct sampler_info {
     const struct pl_filter_config *config;
@@ -203,6 +204,7 @@ void pl_renderer_destroy(pl_renderer *p_rr)
     pl_renderer_flush_cache(rr);
     sampler_destroy(&rr->sampler_main);
     sampler_destroy(&rr->sampler_src);
+    sampler_destroy(&rr->sampler_contrast);
     for (int i = 0; i < PL_MAX_PLANES; i++) {
         sampler_destroy(&rr->samplers_aux[i]);
         sampler_destroy(&rr->samplers_dst[i]);
@@ -401,8 +403,11 @@ static struct sampler_info sample_src_info(struct pass_state *pass, const struct
     info.dir = PL_MAX(info.dir_sep[0], info.dir_sep[1]);
     switch (info.dir) {
     case SAMPLER_DOWN:
-        info.config = usage == SAMPLER_PLANE && params->plane_downscaler
-                        ? params->plane_downscaler : params->downscaler;
+        if (usage == SAMPLER_LOWPASS)
+            info.config = &pl_filter_bicubic;   // (:630-631)
+        else
+            info.config = usage == SAMPLER_PLANE && params->plane_downscaler
+                            ? params->plane_downscaler : params->downscaler;
         break;
     case SAMPLER_UP:
         info.config = usage == SAMPLER_PLANE && params->plane_upscaler
@@ -490,7 +495,7 @@ static void dispatch_sampler(struct pass_state *pass, pl_shader sh, struct sampl
     struct pl_sample_filter_params fparams = {
         .filter      = *info.config,
         .antiring    = params->antiringing_strength,
-        .no_widening = params->skip_anti_aliasing,
+        .no_widening = params->skip_anti_aliasing && usage != SAMPLER_LOWPASS,
         .lut         = lut,
     };
 
@@ -1271,6 +1276,64 @@ done:
 
 /* ---- pass_convert_colors (:2157-2280) ---------------------------------------------------------- */
 
+// Low-resolution luminance map for the tone mapper's contrast recovery (get_feature_map
+// :2089-2154): I of IPT at full resolution, low-passed (bicubic, mirrored edges) down to
+// 1/contrast_smoothness of the output size.
+static pl_tex get_feature_map(struct pass_state *pass)
+{
+    const struct pl_render_params *params = pass->params;
+    pl_renderer rr = pass->rr;
+    const struct pl_color_map_params *cparams =
+        PL_DEF(params->color_map_params, &pl_color_map_default_params);
+    if (!cparams->contrast_recovery || cparams->contrast_smoothness <= 1)
+        return NULL;
+    if (!pass->fbofmt[4] || !pass->fbofmt[1])
+        return NULL;
+    if (!pl_color_space_is_hdr(&pass->img.color))
+        return NULL;
+    if (rr->errors & (PL_RENDER_ERR_SAMPLING | PL_RENDER_ERR_CONTRAST_RECOVERY))
+        return NULL;
+    if (pass->img.color.hdr.max_luma <= pass->target.color.hdr.max_luma + 1e-6)
+        return NULL; // no adaptation needed
+
+    struct img *img = &pass->img;
+    if (!img_tex(pass, img))
+        return NULL;
+
+    const float ratio = cparams->contrast_smoothness;
+    const int cr_w = ceilf(abs(pl_rect_w(pass->dst_rect)) / ratio);
+    const int cr_h = ceilf(abs(pl_rect_h(pass->dst_rect)) / ratio);
+    pl_tex inter_tex = get_fbo(pass, img->w, img->h, NULL, 1);
+    pl_tex out_tex = get_fbo(pass, cr_w, cr_h, NULL, 1);
+    if (!inter_tex || !out_tex)
+        goto error;
+
+    pl_shader sh = pl_dispatch_begin(rr->dp);
+    pl_shader_sample_direct(sh, pl_sample_src( .tex = img->tex ));
+    pl_shader_extract_features(sh, img->color);
+    if (!pl_dispatch_finish(rr->dp, pl_dispatch_params(.shader = &sh, .target = inter_tex)))
+        goto error;
+
+    const struct pl_sample_src src = {
+        .tex          = inter_tex,
+        .rect         = img->rect,
+        .address_mode = PL_TEX_ADDRESS_MIRROR,
+        .components   = 1,
+        .new_w        = cr_w,
+        .new_h        = cr_h,
+    };
+    sh = pl_dispatch_begin(rr->dp);
+    dispatch_sampler(pass, sh, &rr->sampler_contrast, SAMPLER_LOWPASS, &src);
+    if (!pl_dispatch_finish(rr->dp, pl_dispatch_params(.shader = &sh, .target = out_tex)))
+        goto error;
+    return out_tex;
+
+error:
+    RR_ERR(rr, "Failed extracting luma for contrast recovery, disabling");
+    rr->errors |= PL_RENDER_ERR_CONTRAST_RECOVERY;
+    return NULL;
+}
+
 static void pass_convert_colors(struct pass_state *pass)
 {
     const struct pl_render_params *params = pass->params;
@@ -1303,6 +1366,9 @@ static void pass_convert_colors(struct pass_state *pass)
     // ---- PASS B: a same-frame peak measurement must finish before it is consumed ----
     if (pass->need_peak_fbo && !img_tex(pass, img))
         return;
+
+    // HDR feature map for the contrast recovery, if required (dispatches the image so far)
+    pl_tex feature_map = get_feature_map(pass);
     sh = img_sh(pass, img);
 
     pl_shader_color_map_ex(sh, params->color_map_params, pl_color_map_args(
@@ -1310,6 +1376,7 @@ static void pass_convert_colors(struct pass_state *pass)
         .dst           = target->color,
         .prelinearized = prelinearized,
         .state         = &rr->tone_map_state,
+        .feature_map   = feature_map,
     ));
     img->color = target->color;
 }

@@ -282,6 +282,28 @@ void plh_fill_linearize(struct plh_op *op, const struct pl_color_space *csp)
     }
 }
 
+// pl_shader_extract_features (colorspace.c:1383-1404)
+void pl_shader_extract_features(pl_shader sh, struct pl_color_space csp)
+{
+    if (!sh_require(sh, PL_SHADER_SIG_COLOR, 0, 0))
+        return;
+    sh_describef(sh, "feature extraction");
+    pl_shader_linearize(sh, &csp);
+    struct plh_op *op = sh_op(sh, PLH_OP_FEATURES);
+    if (!op)
+        return;
+    // "vec3 lms = %f * mat3 * color.rgb": scalar * matrix first (left to right), in fp32
+    const pl_matrix3x3 rgb2lms = pl_ipt_rgb2lms(pl_raw_primaries_get(csp.primaries));
+    const float k = plh_fmtf(PL_COLOR_SDR_WHITE / 10000);
+    for (int i = 0; i < 3; i++) {
+        for (int j = 0; j < 3; j++)
+            op->f[3 * i + j] = k * rgb2lms.m[i][j];
+    }
+    op->f[9] = plh_fmtf(PQ_M1); op->f[10] = plh_fmtf(PQ_C1); op->f[11] = plh_fmtf(PQ_C2);
+    op->f[12] = plh_fmtf(PQ_C3); op->f[13] = plh_fmtf(PQ_M2);
+    sh_listf(sh, "extract_features()\n");
+}
+
 void pl_shader_linearize(pl_shader sh, const struct pl_color_space *csp)
 {
     if (!sh_require(sh, PL_SHADER_SIG_COLOR, 0, 0))
@@ -956,6 +978,26 @@ void pl_shader_color_map_ex(pl_shader sh, const struct pl_color_map_params *para
             op->f[0] = 1.0f / lut_range;
             op->f[1] = -tone.input_min / lut_range;
             op->ptr = pl_hip_buf_ptr(obj->tone.lut);
+        }
+        // contrast recovery (:1879-1921): detail = highres - bicubic(feature map)
+        const bool need_recovery = tone.input_max >= tone.output_max;
+        if (need_recovery && params->contrast_recovery && args->feature_map) {
+            pl_tex fm = args->feature_map;
+            struct plh_view v;
+            plh_tex_view(fm, &v);
+            if (v.fmt != PLH_FMT_R16F || v.w > 0xffff || v.h > 0xffff) {
+                SH_FAIL(sh, "Contrast recovery needs an r16hf feature map (got '%s')",
+                        fm->params.format->name);
+                return;
+            }
+            op->ptr2 = v.ptr;
+            op->i2 = v.w | (v.h << 16);
+            memcpy(&op->f[4], &v.pitch, sizeof(float));
+            op->f[5] = params->contrast_recovery;
+            op->f[6] = tone.output_min;
+            op->f[7] = tone.output_max;
+            sh_listf(sh, "contrast_recovery(%g, feature map %dx%d)\n", params->contrast_recovery,
+                     v.w, v.h);
         }
         sh_listf(sh, "tone_map(%s, mode=%d, in=[%g,%g] avg=%g, out=[%g,%g])\n", fun->name,
                  op->i0, tone.input_min, tone.input_max, tone.input_avg, tone.output_min,

@@ -1116,6 +1116,9 @@ struct orc_color_map {
     const uint16_t *gamut_lut;  // rgba16, NULL = none
     int gamut_size[3];
     float gamut_scale, gamut_offset;
+    // contrast recovery (:1879-1921): per-pixel low-frequency luma (orc_feature_luma), NULL = off
+    const float *lowres;
+    float cr_strength, cr_out_min, cr_out_max;
 };
 
 static float o_lut1d(const float *lut, int n, float x)
@@ -1123,6 +1126,88 @@ static float o_lut1d(const float *lut, int n, float x)
     const float fpos = clampf(x, 0.0f, 1.0f) * (float) (n - 1);
     const float fb = floorf(fpos), fc = ceilf(fpos);
     return mixf(lut[(int) fb], lut[(int) fc], fpos - fb);
+}
+
+static float o_tone(const struct orc_color_map *m, float I)
+{
+    switch (m->tone_mode) {
+    case 0: return clampf(I, m->tone_p[0], m->tone_p[1]);                          // :1826
+    case 1:                                                                        // :1836-1842
+        I = m->tone_p[0] * I + m->tone_p[1];
+        I = clampf(I, 0.0f, 1.0f);
+        return m->tone_p[2] * I + m->tone_p[3];
+    default:                                                                       // :1873
+        return o_lut1d(m->tone_lut, m->tone_lut_size, m->tone_p[0] * I + m->tone_p[1]);
+    }
+}
+
+// pl_shader_extract_features after the linearization (colorspace.c:1383-1404): img.r = I of
+// IPT, img.gba = (0, 0, 1). `klms` = (203/10000 as "%f") * rgb2lms, row-major, in fp32.
+ORC_API void orc_extract_features(float *img, size_t npix, const float klms[9])
+{
+    const float m1 = pf(O_PQ_M1), m2 = pf(O_PQ_M2), c1 = pf(O_PQ_C1), c2 = pf(O_PQ_C2),
+                c3 = pf(O_PQ_C3);
+    for (size_t i = 0; i < npix; i++) {
+        float *c = img + i * 4;
+        float lms[3];
+        for (int r = 0; r < 3; r++) {
+            float v = klms[3*r] * c[0] + klms[3*r+1] * c[1] + klms[3*r+2] * c[2];
+            v = powf(fmaxf(v, 0.0f), m1);
+            v = (c1 + c2 * v) / (1.0f + c3 * v);
+            lms[r] = powf(v, m2);
+        }
+        c[0] = 0.4000f * lms[0] + 0.4000f * lms[1] + 0.2000f * lms[2];
+        c[1] = c[2] = 0.0f;
+        c[3] = 1.0f;
+    }
+}
+
+// The low-frequency luma the contrast recovery reads (colorspace.c:1886-1906): bicubic
+// interpolation of the w x h single-channel feature map `fm`, evaluated as four bilinear taps,
+// at the centre of every pixel of an out_w x out_h pass.
+static float fm_linear(const float *fm, int w, int h, float px, float py)
+{
+    const float u = px * (float) w - 0.5f, v = py * (float) h - 0.5f;
+    const float fu = floorf(u), fv = floorf(v);
+    const float ax = u - fu, ay = v - fv;
+    const int x0 = wrap((int) fu, w, ADDR_CLAMP), x1 = wrap((int) fu + 1, w, ADDR_CLAMP);
+    const int y0 = wrap((int) fv, h, ADDR_CLAMP), y1 = wrap((int) fv + 1, h, ADDR_CLAMP);
+    const float t0 = mixf(fm[(size_t) y0 * w + x0], fm[(size_t) y0 * w + x1], ax);
+    const float t1 = mixf(fm[(size_t) y1 * w + x0], fm[(size_t) y1 * w + x1], ax);
+    return mixf(t0, t1, ay);
+}
+
+ORC_API void orc_feature_luma(const float *fm, int w, int h, int out_w, int out_h, float *luma)
+{
+    const float osx = 1.0 / out_w, osy = 1.0 / out_h;
+    const float lsize[2] = { (float) w, (float) h };
+    const float lpt[2] = { 1.0f / (float) w, 1.0f / (float) h };
+    for (int y = 0; y < out_h; y++) {
+        for (int x = 0; x < out_w; x++) {
+            const float pos[2] = { osx * ((float) x + 0.5f), osy * ((float) y + 0.5f) };
+            float g[2], hh[2][2];
+            for (int a = 0; a < 2; a++) {
+                const float t = pos[a] * lsize[a] + 0.5f;
+                const float fr = t - floorf(t);
+                const float fr2 = fr * fr, inv = 1.0f - fr, inv2 = inv * inv;
+                const float w0 = 1.0f / 6.0f * inv2 * inv;
+                const float w1 = 2.0f / 3.0f - 0.5f * fr2 * (2.0f - fr);
+                const float w2 = 2.0f / 3.0f - 0.5f * inv2 * (2.0f - inv);
+                const float w3 = 1.0f / 6.0f * fr2 * fr;
+                const float g0 = w0 + w1, g1 = w2 + w3;
+                g[a] = g0;
+                hh[a][0] = w1 / g0 + inv - 2.0f;
+                hh[a][1] = w3 / g1 + inv;
+            }
+            const float px0 = pos[0] + lpt[0] * hh[0][0], py0 = pos[1] + lpt[1] * hh[1][0];
+            const float px1 = pos[0] + lpt[0] * hh[0][1], py1 = pos[1] + lpt[1] * hh[1][1];
+            const float l00 = fm_linear(fm, w, h, px0, py0), l01 = fm_linear(fm, w, h, px0, py1);
+            const float l0 = mixf(l01, l00, g[1]);
+            const float l10 = fm_linear(fm, w, h, px1, py0), l11 = fm_linear(fm, w, h, px1, py1);
+            const float l1 = mixf(l11, l10, g[1]);
+            luma[(size_t) y * out_w + x] = mixf(l1, l0, g[0]);
+        }
+    }
 }
 
 ORC_API void orc_color_map(float *img, size_t npix, const struct orc_color_map *m)
@@ -1148,15 +1233,15 @@ ORC_API void orc_color_map(float *img, size_t npix, const struct orc_color_map *
         const float i_orig = I;
 
         if (m->tone_mode >= 0) {
-            switch (m->tone_mode) {
-            case 0: I = clampf(I, m->tone_p[0], m->tone_p[1]); break;            // :1826
-            case 1:                                                                // :1836-1842
-                I = m->tone_p[0] * I + m->tone_p[1];
-                I = clampf(I, 0.0f, 1.0f);
-                I = m->tone_p[2] * I + m->tone_p[3];
-                break;
-            default:                                                               // :1873
-                I = o_lut1d(m->tone_lut, m->tone_lut_size, m->tone_p[0] * I + m->tone_p[1]);
+            if (m->lowres) {                                                       // :1908-1916
+                const float highres = clampf(I, 0.0f, 1.0f);
+                const float lowres = clampf(m->lowres[i], 0.0f, 1.0f);
+                const float detail = highres - lowres;
+                const float base = o_tone(m, highres);
+                const float sharp = o_tone(m, lowres) + detail;
+                I = clampf(mixf(base, sharp, m->cr_strength), m->cr_out_min, m->cr_out_max);
+            } else {
+                I = o_tone(m, I);
             }
             const float hx = ((i_orig - 6.0f) * i_orig + 9.0f) * i_orig;         // :1930-1932
             const float hy = ((I - 6.0f) * I + 9.0f) * I;

@@ -120,11 +120,16 @@ def resolve(src, dst, tone=b"spline", gamut=b"perceptual", lut_size=256,
                 delin=(int(dst.transfer), dmin, dmax, luma(dst)), tone=tp, gamut=gp)
 
 
-def apply(img, r):
-    """Full oracle colour-map pipeline on float32 rgba `img` (in place)."""
+def apply(img, r, lowres=None, strength=0.0):
+    """Full oracle colour-map pipeline on float32 rgba `img` (in place). lowres: per-pixel
+    low-frequency luma for the contrast recovery (orc.feature_luma)."""
     orc.linearize(img, *r["lin"])
     if r["need_tone"] or r["need_gamut"]:
-        orc.color_map(img, **r["kw"])
+        kw = dict(r["kw"])
+        if lowres is not None:
+            kw.update(lowres=lowres, cr_strength=strength,
+                      cr_out=(r["tone"].output_min, r["tone"].output_max))
+        orc.color_map(img, **kw)
     else:
         raise NotImplementedError("matrix-only fast path: use orc.op_affine")
     orc.delinearize(img, *r["delin"])

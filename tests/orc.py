@@ -231,11 +231,28 @@ class ColorMap(C.Structure):
     _fields_ = [("rgb2lms", C.c_float * 9), ("lms2rgb", C.c_float * 9), ("tone_mode", C.c_int),
                 ("tone_p", C.c_float * 4), ("tone_lut", C.c_void_p), ("tone_lut_size", C.c_int),
                 ("gamut_lut", C.c_void_p), ("gamut_size", C.c_int * 3),
-                ("gamut_scale", C.c_float), ("gamut_offset", C.c_float)]
+                ("gamut_scale", C.c_float), ("gamut_offset", C.c_float),
+                ("lowres", C.c_void_p), ("cr_strength", C.c_float), ("cr_out_min", C.c_float),
+                ("cr_out_max", C.c_float)]
+
+
+def extract_features(img, klms):
+    """pl_shader_extract_features after the linearization; klms = fp32 (203/10000 * rgb2lms)."""
+    lib().orc_extract_features(_p(img), C.c_size_t(img.size // 4), (C.c_float * 9)(*klms))
+    return img
+
+
+def feature_luma(fm, out_w, out_h):
+    """The contrast recovery's bicubic lookup of the (h x w float32) feature map."""
+    fm = np.ascontiguousarray(fm, np.float32)
+    out = np.empty((out_h, out_w), np.float32)
+    lib().orc_feature_luma(_p(fm), fm.shape[1], fm.shape[0], out_w, out_h, _p(out))
+    return out
 
 
 def color_map(img, rgb2lms, lms2rgb, tone_mode=-1, tone_p=(0, 0, 0, 0), tone_lut=None,
-              gamut_lut=None, gamut_size=(48, 32, 256), gamut_scale=0.0, gamut_offset=0.0):
+              gamut_lut=None, gamut_size=(48, 32, 256), gamut_scale=0.0, gamut_offset=0.0,
+              lowres=None, cr_strength=0.0, cr_out=(0.0, 1.0)):
     cm = ColorMap(tone_mode=tone_mode, gamut_scale=gamut_scale, gamut_offset=gamut_offset)
     cm.rgb2lms = (C.c_float * 9)(*rgb2lms)
     cm.lms2rgb = (C.c_float * 9)(*lms2rgb)
@@ -250,6 +267,12 @@ def color_map(img, rgb2lms, lms2rgb, tone_mode=-1, tone_p=(0, 0, 0, 0), tone_lut
         keep.append(gl)
         cm.gamut_lut = gl.ctypes.data
         cm.gamut_size = (C.c_int * 3)(*gamut_size)
+    if lowres is not None:
+        lr = np.ascontiguousarray(lowres, np.float32)
+        assert lr.size == img.size // 4
+        keep.append(lr)
+        cm.lowres = lr.ctypes.data
+        cm.cr_strength, cm.cr_out_min, cm.cr_out_max = cr_strength, cr_out[0], cr_out[1]
     lib().orc_color_map(_p(img), C.c_size_t(img.size // 4), C.byref(cm))
     return img
 

@@ -1,0 +1,118 @@
+"""Contrast recovery of the tone mapper (first item; reference
+src/shaders/colorspace.c:1383-1404 `pl_shader_extract_features`, :1879-1921, and
+src/renderer.c:2089-2154 `get_feature_map`), which completes pl_render_high_quality_params.
+
+Parity: each stage against the oracle's restatement -- the feature extraction, the bicubic
+(four bilinear taps) lookup of the low-resolution map + detail re-injection inside the colour
+map -- with the colour-map bar of test_gpu_color.py (the chain is ill-conditioned in fp32)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import libplacebo_amd as pl
+import orc
+from libplacebo_amd import _capi as capi
+from test_gpu_color import hdr_test_frame, run_ops
+
+pytestmark = pytest.mark.gpu
+
+
+def klms(primaries):
+    m = pl.lib().pl_ipt_rgb2lms(pl.lib().pl_raw_primaries_get(pl.PRIM[primaries]))
+    k = np.float32(float("%f" % (203.0 / 10000)))
+    return [np.float32(k * np.float32(m.m[i][j])) for i in range(3) for j in range(3)]
+
+
+def test_extract_features_vs_oracle(gpu):
+    import colormap_ref as cr
+    src_img = hdr_test_frame()
+    csp = pl.color_space("bt2020", "pq", max_luma=1000.0)
+    got = run_ops(gpu, src_img, lambda sh: sh.extract_features(csp))
+    r = cr.resolve(cr.make_csp(pl.PRIM["bt2020"], pl.TRC["pq"], max_luma=1000.0),
+                   cr.make_csp(pl.PRIM["bt709"], pl.TRC["bt1886"]))
+    ref = orc.linearize(src_img.copy(), *r["lin"])
+    ref = orc.extract_features(ref, klms("bt2020"))
+    assert np.array_equal(got[..., 1:], ref[..., 1:])       # (0, 0, 1)
+    # I is PQ-coded luminance: round-trips the PQ-coded input up to the matrices
+    d = np.abs(got[..., 0] - ref[..., 0])
+    assert d.max() <= 1e-4 and np.median(d) <= 2e-6, (d.max(), np.median(d))
+    assert 0.05 < got[..., 0].mean() < 0.75
+
+
+@pytest.mark.parametrize("tone", ["spline", "bt2390", "clip"])
+def test_color_map_with_contrast_recovery_vs_oracle(gpu, tone):
+    import colormap_ref as cr
+    src_img = hdr_test_frame()
+    h, w = src_img.shape[:2]
+    # a smooth low-resolution map, values representable in the r16hf texture
+    rng = np.random.default_rng(5)
+    fm = (0.15 + 0.5 * rng.random((12, 16))).astype(np.float16)
+    fm_tex = gpu.tex_create(16, 12, "r16hf", fm)
+    src = pl.color_space("bt2020", "pq", max_luma=1000.0)
+    dst = pl.color_space("bt709", "bt1886")
+    res = {}
+    for strength in (0.0, 0.3):
+        state = pl.ShaderObj()
+        params = pl.color_map_params(tone=tone, gamut="perceptual", contrast_recovery=strength)
+        res[strength] = run_ops(gpu, src_img, lambda sh: sh.color_map(src, dst, state, params,
+                                                                      feature_map=fm_tex))
+        state.destroy()
+    fm_tex.destroy()
+
+    r = cr.resolve(cr.make_csp(pl.PRIM["bt2020"], pl.TRC["pq"], max_luma=1000.0),
+                   cr.make_csp(pl.PRIM["bt709"], pl.TRC["bt1886"]),
+                   tone=tone.encode(), gamut=b"perceptual")
+    if tone == "clip":
+        r["kw"].update(tone_mode=0, tone_p=(r["tone"].input_min, r["tone"].input_max, 0, 0),
+                       tone_lut=None)
+    lowres = orc.feature_luma(fm.astype(np.float32), w, h)
+    ref = cr.apply(src_img.copy(), r, lowres=lowres, strength=0.3)
+    ref0 = cr.apply(src_img.copy(), r)
+
+    for got, want in ((res[0.3], ref), (res[0.0], ref0)):
+        d = np.abs(got - want)[..., :3].ravel() * 65535
+        assert np.quantile(d, 0.5) <= 0.25 and np.quantile(d, 0.9) <= 2.0, np.quantile(d, (.5, .9))
+    # the recovery really changes the picture, the same way in both implementations
+    delta_gpu = (res[0.3] - res[0.0])[..., :3]
+    delta_ref = (ref - ref0)[..., :3]
+    assert np.abs(delta_gpu).max() * 65535 > 500
+    assert np.quantile(np.abs(delta_gpu - delta_ref) * 65535, 0.9) <= 3.0
+
+
+def hdr_frames(gpu, sw, sh, dw, dh):
+    import util
+    f = util.chirp_rgba16(sw, sh).astype(np.float32) * 0.75
+    f[..., 3] = 65535
+    src = gpu.tex_create(sw, sh, "rgba16", f.astype(np.uint16))
+    dst = gpu.tex_create(dw, dh, "rgba16")
+    image = pl.frame(src, components=3, color=pl.color_space("bt2020", "pq", max_luma=1000.0),
+                     repr_=pl.color_repr("rgb", "full"))
+    target = pl.frame(dst, color=pl.color_space("bt709", "bt1886"))
+    return src, dst, image, target
+
+
+def test_high_quality_preset_runs_contrast_recovery(gpu):
+    """pl_render_high_quality_params on HDR -> SDR: feature map passes + recovery in the colour
+    map; switching the strength / smoothness off gives the plain tone mapping."""
+    src, dst, image, target = hdr_frames(gpu, 96, 64, 96, 64)
+    outs = {}
+    for name, kw in (("hq", {}), ("off", dict(contrast_recovery=0.0)),
+                     ("smooth1", dict(contrast_smoothness=1.0))):
+        cm = pl.color_map_params("spline", "perceptual",
+                                 **{**dict(contrast_recovery=0.3, contrast_smoothness=3.5), **kw})
+        params = pl.render_params("high_quality", color_map_params=cm, peak_detect_params=None)
+        rr = pl.Renderer(gpu)
+        assert rr.render(image, target, params), gpu.messages[-4:]
+        assert rr.errors() == 0
+        outs[name] = dst.download()
+        rr.destroy()
+    assert np.array_equal(outs["off"], outs["smooth1"])
+    d = np.abs(outs["hq"].astype(np.int64) - outs["off"].astype(np.int64))[..., :3]
+    assert d.max() > 200 and d.mean() > 5, (int(d.max()), float(d.mean()))
+    # recovery adds local contrast: the high-pass energy of the luma goes up
+    def hp_energy(img):
+        y = img[..., :3].astype(np.float64).mean(axis=2)
+        return np.abs(y[1:-1, 1:-1] * 4 - y[:-2, 1:-1] - y[2:, 1:-1] - y[1:-1, :-2] - y[1:-1, 2:]).mean()
+    assert hp_energy(outs["hq"]) > hp_energy(outs["off"])
+    src.destroy(); dst.destroy()
