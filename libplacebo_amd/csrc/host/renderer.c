@@ -104,6 +104,7 @@ struct img {
     const char *err_msg;
     enum pl_render_error err_enum;
     pl_tex err_tex;
+    pl_tex sh_origin;       // texture that `sh` started from as a plain 1:1 fetch (img_sh)
 };
 
 struct pass_state {
@@ -325,6 +326,23 @@ static pl_tex img_tex(struct pass_state *pass, struct img *img)
         return img->tex;
 
     pl_renderer rr = pass->rr;
+    // img_sh() followed by img_tex() with nothing recorded in between (the reference's
+    // get_feature_map / need_peak_fbo sequences): the texture the shader would copy is the answer
+    if (img->sh && img->sh_origin && !img->fmt) {
+        const struct plh_pass *p = &img->sh->pass;
+        pl_tex o = img->sh_origin;
+        if (img->sh->kind == PLH_SHADER_PASS && !p->num_ops && !p->num_pre_ops &&
+            p->s.scale == 1.0f && !img->sh->detect_peak &&
+            (p->s.type == PLH_SAMPLE_NEAREST || p->s.type == PLH_SAMPLE_BILINEAR) &&
+            o->params.w == img->w && o->params.h == img->h && !pl_shader_is_failed(img->sh))
+        {
+            pl_dispatch_abort(rr->dp, &img->sh);
+            img->sh_origin = NULL;
+            img->tex = o;
+            return o;
+        }
+    }
+    img->sh_origin = NULL;
     pl_tex tex = get_fbo(pass, img->w, img->h, img->fmt, img->comps);
     img->fmt = NULL;
     if (!tex) {
@@ -366,6 +384,7 @@ static pl_shader img_sh(struct pass_state *pass, struct img *img)
         return img->sh;
     img->sh = pl_dispatch_begin(pass->rr->dp);
     pl_shader_sample_direct(img->sh, pl_sample_src( .tex = img->tex ));
+    img->sh_origin = img->tex;
     img->tex = NULL;
     return img->sh;
 }
