@@ -5,7 +5,7 @@
  * pl_frame :528-655, pl_render_image :731).
  *
  * Field names, meanings and defaults are the reference's. Not provided (out of the
- * hot-path scope): hooks, custom LUTs, ICC, overlays, film grain,
+ * hot-path scope): hooks, ICC, overlays, film grain,
  * deinterlacing, distortion / cone distortion, blurred borders, rotation.
  * Images and targets may be packed, semi-planar or planar / subsampled.
  */
@@ -18,6 +18,7 @@
 #include <libplacebo/gpu.h>
 #include <libplacebo/shaders/colorspace.h>
 #include <libplacebo/shaders/dithering.h>
+#include <libplacebo/shaders/lut.h>
 #include <libplacebo/shaders/sampling.h>
 
 PL_API_BEGIN
@@ -74,6 +75,15 @@ struct pl_render_info {
     int count;
 };
 
+// Where in the pipeline a pl_custom_lut acts (reference renderer.h :83-100)
+enum pl_lut_type {
+    PL_LUT_UNKNOWN = 0,
+    PL_LUT_NATIVE,      // on the raw image contents (after fixing the bit depth)
+    PL_LUT_NORMALIZED,  // on normalized (HDR) RGB values
+    PL_LUT_CONVERSION,  // replaces the colour conversion (image LUT: native -> RGB; params LUT:
+                        // image -> target colour space; target LUT: RGB -> native)
+};
+
 struct pl_render_params {
     // Scalers: NULL = built-in bilinear ("free" sampling in the final pass)
     const struct pl_filter_config *upscaler;
@@ -97,8 +107,8 @@ struct pl_render_params {
     const void *distort_params;         // unsupported, must be NULL
     const void * const *hooks;          // unsupported, must be NULL
     int num_hooks;
-    const void *lut;                    // unsupported, must be NULL
-    int lut_type;
+    const struct pl_custom_lut *lut;    // applied between the image's and the target's colour
+    enum pl_lut_type lut_type;          // space, see pl_lut_type
 
     enum pl_clear_mode background;
     enum pl_clear_mode border;
@@ -163,6 +173,11 @@ struct pl_frame {
 
     struct pl_color_repr repr;
     struct pl_color_space color;
+
+    // Optional LUT attached to the frame (images: applied while decoding; targets: while
+    // encoding). lut_type 0 = guess from the LUT's repr_in / repr_out.
+    const struct pl_custom_lut *lut;
+    enum pl_lut_type lut_type;
 
     pl_rect2df crop;          // 0 = whole frame; flipped rects flip the image
     pl_rotation rotation;     // must be PL_ROTATION_0

@@ -241,6 +241,10 @@ class Shader:
         pp = peak_detect_params(**kw)
         return lib().pl_shader_detect_peak(self.sh, csp, C.byref(state_obj.slot), C.byref(pp))
 
+    def custom_lut(self, lut, state_obj):
+        self._keep.append(lut)
+        lib().pl_shader_custom_lut(self.sh, C.byref(lut), C.byref(state_obj.slot))
+
     def extract_features(self, csp):
         lib().pl_shader_extract_features(self.sh, csp)
 
@@ -421,6 +425,36 @@ def recreate_plane(gpu, data, tex=None):
         tex.ptr = t
         return out, tex
     return out, Texture(gpu, t)
+
+
+LUT_UNKNOWN, LUT_NATIVE, LUT_NORMALIZED, LUT_CONVERSION = 0, 1, 2, 3
+
+
+def custom_lut(data, size, shaper_in=None, shaper_out=None, signature=None):
+    """pl_custom_lut around a float32 array of RGB triples (R innermost); size = (n,) or
+    (r, g, b). The array is kept alive on the returned struct."""
+    arr = np.ascontiguousarray(data, np.float32).reshape(-1, 3)
+    size = tuple(size) + (0,) * (3 - len(size))
+    lut = capi.CustomLut(size=(C.c_int * 3)(*size),
+                         data=arr.ctypes.data_as(C.POINTER(C.c_float)),
+                         signature=signature if signature is not None
+                         else hash(arr.tobytes()) & 0xffffffffffffffff)
+    for name, m in (("shaper_in", shaper_in), ("shaper_out", shaper_out)):
+        if m is not None:
+            mm = capi.Matrix3x3()
+            for i in range(3):
+                for j in range(3):
+                    mm.m[i][j] = m[i][j]
+            setattr(lut, name, mm)
+    lut._keep = arr
+    return lut
+
+
+def parse_cube(text, log=None):
+    """pl_lut_parse_cube: returns a pointer (free with lib().pl_lut_free) or None."""
+    raw = text.encode() if isinstance(text, str) else text
+    p = lib().pl_lut_parse_cube(log, raw, len(raw))
+    return p if p else None
 
 
 def frame_mix(frames, signatures, timestamps, vsync_duration):

@@ -309,10 +309,18 @@ class PlaneData(C.Structure):  # utils/upload.h
                 ("priv", C.c_void_p)]
 
 
+class CustomLut(C.Structure):  # shaders/lut.h
+    _fields_ = [("signature", C.c_uint64), ("size", C.c_int * 3), ("data", C.POINTER(C.c_float)),
+                ("shaper_in", Matrix3x3), ("shaper_out", Matrix3x3),
+                ("repr_in", ColorRepr), ("repr_out", ColorRepr),
+                ("color_in", ColorSpace), ("color_out", ColorSpace)]
+
+
 class Frame(C.Structure):
     _fields_ = [("num_planes", C.c_int), ("planes", Plane * 4),
                 ("acquire", C.c_void_p), ("release", C.c_void_p),
-                ("repr", ColorRepr), ("color", ColorSpace), ("crop", Rect2df),
+                ("repr", ColorRepr), ("color", ColorSpace),
+                ("lut", C.POINTER(CustomLut)), ("lut_type", C.c_int), ("crop", Rect2df),
                 ("rotation", C.c_int), ("user_data", C.c_void_p)]
 
 
@@ -336,7 +344,7 @@ class RenderParams(C.Structure):
                 ("error_diffusion", C.POINTER(ErrorDiffusionKernel)),
                 ("cone_params", C.c_void_p), ("blend_params", C.c_void_p),
                 ("deinterlace_params", C.c_void_p), ("distort_params", C.c_void_p),
-                ("hooks", C.c_void_p), ("num_hooks", C.c_int), ("lut", C.c_void_p),
+                ("hooks", C.c_void_p), ("num_hooks", C.c_int), ("lut", C.POINTER(CustomLut)),
                 ("lut_type", C.c_int), ("background", C.c_int), ("border", C.c_int),
                 ("background_color", C.c_float * 3), ("background_transparency", C.c_float),
                 ("tile_colors", (C.c_float * 3) * 2), ("tile_size", C.c_int),
@@ -463,6 +471,9 @@ def declare(lib):
     fn("pl_hip_peak_buffer", vp, vp, P(C.c_size_t))
     fn("pl_shader_color_map_ex", None, vp, P(ColorMapParams), P(ColorMapArgs))
     fn("pl_shader_extract_features", None, vp, ColorSpace)
+    fn("pl_lut_parse_cube", P(CustomLut), vp, C.c_char_p, C.c_size_t)
+    fn("pl_lut_free", None, P(P(CustomLut)))
+    fn("pl_shader_custom_lut", None, vp, P(CustomLut), P(vp))
     fn("pl_find_tone_map_function", vp, C.c_char_p)
     fn("pl_find_gamut_map_function", vp, C.c_char_p)
     fn("pl_color_space_nominal_luma_ex", None, vp)

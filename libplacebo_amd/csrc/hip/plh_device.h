@@ -185,6 +185,9 @@ enum plh_op_kind {
     // pl_shader_extract_features (colorspace.c:1383-1404): color = (I of IPT, 0, 0, 1);
     // f[0..8] = (203/10000) * rgb2lms, f[9..13] = m1 c1 c2 c3 m2
     PLH_OP_FEATURES,
+    // pl_shader_custom_lut (shaders/lut.c:212-280): ptr = rgba32f texels, i0 i1 i2 = sizes
+    // (1D: i1 = i2 = 0 -> per-channel linear lookup; 3D -> tetrahedral interpolation)
+    PLH_OP_CUSTOM_LUT,
 };
 
 // flags in plh_op.i1 of LINEARIZE / DELINEARIZE / PEAK_DETECT

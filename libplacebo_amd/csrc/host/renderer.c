@@ -28,6 +28,7 @@
 #include "shaders_priv.h"
 
 #define MAX_FBOS 16
+enum { LUT_IMAGE, LUT_TARGET, LUT_PARAMS };
 #define MAX_MIX_FRAMES 16        // renderer.c:3610
 #define MAX_CACHED_FRAMES 32
 
@@ -52,6 +53,7 @@ struct pl_renderer_t {
     struct sampler samplers_dst[PL_MAX_PLANES];  // planar output
     pl_shader_obj tone_map_state;
     pl_shader_obj dither_state;
+    pl_shader_obj lut_state[3];         // LUT_IMAGE, LUT_TARGET, LUT_PARAMS
     int prev_dither;
 
     // frame mixing cache (pl_render_image_mix, renderer.c:82-110 `struct cached_frame`)
@@ -212,6 +214,8 @@ void pl_renderer_destroy(pl_renderer *p_rr)
     }
     pl_shader_obj_destroy(&rr->tone_map_state);
     pl_shader_obj_destroy(&rr->dither_state);
+    for (int i = 0; i < 3; i++)
+        pl_shader_obj_destroy(&rr->lut_state[i]);
     pl_dispatch_destroy(&rr->dp);
     free(rr);
     *p_rr = NULL;
@@ -835,6 +839,8 @@ static void hdr_update_peak(struct pass_state *pass)
     const bool uses_ootf = cpars && cpars->tone_mapping_function == &pl_tone_map_st2094_40;
     if (uses_ootf && pass->img.color.hdr.ootf.num_anchors)
         goto cleanup; // HDR10+ OOTF is being used
+    if (params->lut && params->lut_type == PL_LUT_CONVERSION)
+        goto cleanup; // LUT handles tone mapping
 
     if (!pass->fbofmt[4] && !params->peak_detect_params->allow_delayed) {
         RR_WARN(rr, "Disabling peak detection because `pl_peak_detect_params.allow_delayed` "
@@ -961,6 +967,26 @@ static bool merge_plane_fetch(pl_shader sh, const pl_shader psh, const struct pl
     for (int i = 0; i < psh->num_held; i++)
         sh_hold(sh, psh->held[i]);
     return true;
+}
+
+// guess_frame_lut_type (:1447-1468)
+static enum pl_lut_type guess_frame_lut_type(const struct pl_frame *frame, bool reversed)
+{
+    if (!frame->lut)
+        return PL_LUT_UNKNOWN;
+    if (frame->lut_type)
+        return frame->lut_type;
+    enum pl_color_system sys_in = frame->lut->repr_in.sys, sys_out = frame->lut->repr_out.sys;
+    if (reversed) {
+        const enum pl_color_system t = sys_in;
+        sys_in = sys_out;
+        sys_out = t;
+    }
+    if (sys_in == PL_COLOR_SYSTEM_RGB && sys_out == sys_in)
+        return PL_LUT_NORMALIZED;
+    if (sys_in == frame->repr.sys && sys_out == PL_COLOR_SYSTEM_RGB)
+        return PL_LUT_CONVERSION;
+    return PL_LUT_NATIVE; // unknown: the default
 }
 
 static bool pass_read_image(struct pass_state *pass)
@@ -1177,11 +1203,33 @@ static bool pass_read_image(struct pass_state *pass)
     };
     pass->ref_rect = pass->img.rect;
 
-    if (pass->img.repr.sys == PL_COLOR_SYSTEM_XYZ) {
-        pl_shader_linearize(sh, &pass->img.color);
-        pass->img.color.transfer = PL_COLOR_TRC_LINEAR;
+    // frame LUT (:1920-1946): NATIVE / CONVERSION act on the raw (bit-depth-fixed) samples, a
+    // CONVERSION LUT replaces the decoding, NORMALIZED acts on the decoded RGB
+    const enum pl_lut_type lut_type = guess_frame_lut_type(image, false);
+    bool needs_conversion = true;
+    if (lut_type == PL_LUT_NATIVE || lut_type == PL_LUT_CONVERSION) {
+        const float scale = pl_color_repr_normalize(&pass->img.repr);
+        struct plh_op *op = sh_op(sh, PLH_OP_SCALE);
+        if (op) {
+            op->f[0] = op->f[1] = op->f[2] = op->f[3] = scale;
+            sh_listf(sh, "scale(%g)\n", scale);
+        }
+        pl_shader_custom_lut(sh, image->lut, &rr->lut_state[LUT_IMAGE]);
+        if (lut_type == PL_LUT_CONVERSION) {
+            pass->img.repr.sys = PL_COLOR_SYSTEM_RGB;
+            pass->img.repr.levels = PL_COLOR_LEVELS_FULL;
+            needs_conversion = false;
+        }
     }
-    pl_shader_decode_color(sh, &pass->img.repr, params->color_adjustment);
+    if (needs_conversion) {
+        if (pass->img.repr.sys == PL_COLOR_SYSTEM_XYZ) {
+            pl_shader_linearize(sh, &pass->img.color);
+            pass->img.color.transfer = PL_COLOR_TRC_LINEAR;
+        }
+        pl_shader_decode_color(sh, &pass->img.repr, params->color_adjustment);
+    }
+    if (lut_type == PL_LUT_NORMALIZED)
+        pl_shader_custom_lut(sh, image->lut, &rr->lut_state[LUT_IMAGE]);
 
     // pre-multiply alpha before the rest of the pipeline, to avoid bleeding colours from
     // transparent regions into opaque ones
@@ -1314,6 +1362,8 @@ static pl_tex get_feature_map(struct pass_state *pass)
         return NULL;
     if (pass->img.color.hdr.max_luma <= pass->target.color.hdr.max_luma + 1e-6)
         return NULL; // no adaptation needed
+    if (params->lut && params->lut_type == PL_LUT_CONVERSION)
+        return NULL; // LUT handles tone mapping
 
     struct img *img = &pass->img;
     if (!img_tex(pass, img))
@@ -1383,20 +1433,79 @@ static void pass_convert_colors(struct pass_state *pass)
     pl_shader_set_alpha(sh, &img->repr, PL_ALPHA_INDEPENDENT);
 
     // ---- PASS B: a same-frame peak measurement must finish before it is consumed ----
-    if (pass->need_peak_fbo && !img_tex(pass, img))
-        return;
+    // main LUT (:2199-2247): between the image's and the target's colour space
+    bool need_conversion = true;
+    if (params->lut) {
+        struct pl_color_space lut_in = params->lut->color_in;
+        struct pl_color_space lut_out = params->lut->color_out;
+        switch (params->lut_type) {
+        case PL_LUT_UNKNOWN:
+        case PL_LUT_NATIVE:
+            pl_color_space_merge(&lut_in, &image->color);
+            pl_color_space_merge(&lut_out, &image->color);
+            break;
+        case PL_LUT_CONVERSION:
+            pl_color_space_merge(&lut_in, &image->color);
+            need_conversion = false; // the LUT is the conversion
+            break;
+        case PL_LUT_NORMALIZED:
+            if (!prelinearized) {
+                // PL_LUT_NORMALIZED wants linear input data
+                pl_shader_linearize(sh, &img->color);
+                img->color.transfer = PL_COLOR_TRC_LINEAR;
+                prelinearized = true;
+            }
+            pl_color_space_merge(&lut_in, &img->color);
+            pl_color_space_merge(&lut_out, &img->color);
+            break;
+        }
 
-    // HDR feature map for the contrast recovery, if required (dispatches the image so far)
-    pl_tex feature_map = get_feature_map(pass);
-    sh = img_sh(pass, img);
+        pl_shader_color_map_ex(sh, params->color_map_params, pl_color_map_args(
+            .src = image->color, .dst = lut_in, .prelinearized = prelinearized));
+        if (params->lut_type == PL_LUT_NORMALIZED) {
+            struct plh_op *op = sh_op(sh, PLH_OP_SCALE);
+            if (op) {
+                const float k = 1.0f / pl_color_transfer_nominal_peak(lut_in.transfer);
+                op->f[0] = op->f[1] = op->f[2] = k;
+                op->f[3] = 1.0f;
+            }
+        }
+        pl_shader_custom_lut(sh, params->lut, &rr->lut_state[LUT_PARAMS]);
+        if (params->lut_type == PL_LUT_NORMALIZED) {
+            struct plh_op *op = sh_op(sh, PLH_OP_SCALE);
+            if (op) {
+                const float k = pl_color_transfer_nominal_peak(lut_out.transfer);
+                op->f[0] = op->f[1] = op->f[2] = k;
+                op->f[3] = 1.0f;
+            }
+        }
+        if (params->lut_type != PL_LUT_CONVERSION) {
+            pl_shader_color_map_ex(sh, params->color_map_params, pl_color_map_args(
+                .src = lut_out, .dst = img->color));
+        }
+    }
 
-    pl_shader_color_map_ex(sh, params->color_map_params, pl_color_map_args(
-        .src           = image->color,
-        .dst           = target->color,
-        .prelinearized = prelinearized,
-        .state         = &rr->tone_map_state,
-        .feature_map   = feature_map,
-    ));
+    if (need_conversion) {
+        if (pass->need_peak_fbo && !img_tex(pass, img))
+            return;
+
+        // HDR feature map for the contrast recovery, if required (dispatches the image so far)
+        pl_tex feature_map = get_feature_map(pass);
+        sh = img_sh(pass, img);
+
+        pl_shader_color_map_ex(sh, params->color_map_params, pl_color_map_args(
+            .src           = image->color,
+            .dst           = target->color,
+            .prelinearized = prelinearized,
+            .state         = &rr->tone_map_state,
+            .feature_map   = feature_map,
+        ));
+    }
+
+    // target LUT (:2272-2274): NORMALIZED / CONVERSION (RGB -> native) act while encoding
+    const enum pl_lut_type tlut = guess_frame_lut_type(target, true);
+    if (tlut == PL_LUT_NORMALIZED || tlut == PL_LUT_CONVERSION)
+        pl_shader_custom_lut(sh, target->lut, &rr->lut_state[LUT_TARGET]);
     img->color = target->color;
 }
 
@@ -1548,11 +1657,17 @@ static bool pass_output_target(struct pass_state *pass)
         pl_shader_set_alpha(sh, &img->repr, PL_ALPHA_INDEPENDENT);
     }
 
-    pl_shader_encode_color(sh, &repr);
-    if (repr.sys == PL_COLOR_SYSTEM_XYZ) {
-        img->color.transfer = PL_COLOR_TRC_ST428;
-        pl_shader_delinearize(sh, &img->color);
+    // (a CONVERSION LUT on the target already produced native samples, pass_convert_colors)
+    const enum pl_lut_type tlut = guess_frame_lut_type(target, true);
+    if (tlut != PL_LUT_CONVERSION) {
+        pl_shader_encode_color(sh, &repr);
+        if (repr.sys == PL_COLOR_SYSTEM_XYZ) {
+            img->color.transfer = PL_COLOR_TRC_ST428;
+            pl_shader_delinearize(sh, &img->color);
+        }
     }
+    if (tlut == PL_LUT_NATIVE)
+        pl_shader_custom_lut(sh, target->lut, &rr->lut_state[LUT_TARGET]);
 
     const bool flipped_x = dst_rect.x1 < dst_rect.x0, flipped_y = dst_rect.y1 < dst_rect.y0;
 
@@ -1706,10 +1821,10 @@ static void pass_uninit(struct pass_state *pass)
 static bool unsupported(pl_renderer rr, const struct pl_render_params *p)
 {
     if (p->cone_params || p->blend_params || p->deinterlace_params || p->distort_params ||
-        p->num_hooks || p->lut)
+        p->num_hooks)
     {
         RR_ERR(rr, "pl_render_params requests a stage outside this backend's hot path "
-               "(cone / blend / deinterlace / distort / hooks / LUT)");
+               "(cone / blend / deinterlace / distort / hooks)");
         return true;
     }
     return false;

@@ -1128,6 +1128,56 @@ static float o_lut1d(const float *lut, int n, float x)
     return mixf(lut[(int) fb], lut[(int) fc], fpos - fb);
 }
 
+// pl_shader_custom_lut (shaders/lut.c:212-280; 1D linear :731-745, 3D tetrahedral :762-809).
+// `lut`: RGB triples as in pl_custom_lut.data; size[1] = size[2] = 0 for 1D.
+ORC_API void orc_custom_lut(float *img, size_t npix, const float *lut, const int size[3])
+{
+    const int sx = size[0], sy = size[1], sz = size[2];
+    for (size_t i = 0; i < npix; i++) {
+        float *c = img + i * 4;
+        if (!sy) {
+            for (int k = 0; k < 3; k++) {
+                const float fpos = clampf(c[k], 0.0f, 1.0f) * (float) (sx - 1);
+                const float fb = floorf(fpos), fc = ceilf(fpos);
+                c[k] = mixf(lut[3 * (int) fb + k], lut[3 * (int) fc + k], fpos - fb);
+            }
+            continue;
+        }
+        const float pos[3] = { clampf(c[0], 0.0f, 1.0f) * (float) (sx - 1),
+                               clampf(c[1], 0.0f, 1.0f) * (float) (sy - 1),
+                               clampf(c[2], 0.0f, 1.0f) * (float) (sz - 1) };
+        float fpart[3], s[3];
+        int v0[3], v1[3], v2[3], v3[3];
+        for (int k = 0; k < 3; k++) {
+            const float base = floorf(pos[k]);
+            fpart[k] = s[k] = pos[k] - base;
+            v0[k] = v1[k] = (int) base;
+            v3[k] = v2[k] = (int) ceilf(pos[k]);
+        }
+        const int cge[3] = { fpart[0] >= fpart[1], fpart[1] >= fpart[2], fpart[2] >= fpart[0] };
+        // c_xy = cge[0], c_yx = !cge[0], c_yz = cge[1], c_zy = !cge[1], c_zx = cge[2], c_xz = !cge[2]
+        static const int order[6][3] = { {0,1,2}, {0,2,1}, {2,0,1}, {2,1,0}, {1,2,0}, {1,0,2} };
+        for (int t = 0; t < 6; t++) {
+            const int X = order[t][0], Y = order[t][1], Z = order[t][2];
+            // c_AB for A, B in {x, y, z}: A >= B along the cyclic pairs, else the negation
+#define CAB(A, B) ((B) == ((A) + 1) % 3 ? cge[A] : !cge[B])
+            if (CAB(X, Y) && CAB(Y, Z)) {
+                s[0] = fpart[X]; s[1] = fpart[Y]; s[2] = fpart[Z];
+                v1[X] = v3[X];
+                v2[Z] = v0[Z];
+            }
+#undef CAB
+        }
+#define L3(v, k) lut[3 * (((size_t) (v)[2] * sy + (v)[1]) * sx + (v)[0]) + (k)]
+        const float w0 = 1.0f - s[0], w1 = s[0] - s[1], w2 = s[1] - s[2], w3 = s[2];
+        float o[3];
+        for (int k = 0; k < 3; k++)
+            o[k] = w0 * L3(v0, k) + w1 * L3(v1, k) + w2 * L3(v2, k) + w3 * L3(v3, k);
+#undef L3
+        c[0] = o[0]; c[1] = o[1]; c[2] = o[2];
+    }
+}
+
 static float o_tone(const struct orc_color_map *m, float I)
 {
     switch (m->tone_mode) {

@@ -337,3 +337,11 @@ def error_diffusion(img, depth, shift, divisor, pattern):
     pat = ((C.c_int * 5) * 3)(*[(C.c_int * 5)(*row) for row in pattern])
     lib().orc_error_diffusion(_p(img), w, h, depth, shift, divisor, pat, _p(out))
     return out
+
+
+def custom_lut(img, lut, size):
+    """pl_shader_custom_lut: lut = RGB triples (R innermost), size = (n,) or (r, g, b)."""
+    lut = np.ascontiguousarray(lut, np.float32)
+    size = tuple(size) + (0,) * (3 - len(size))
+    lib().orc_custom_lut(_p(img), C.c_size_t(img.size // 4), _p(lut), (C.c_int * 3)(*size))
+    return img
