@@ -14,6 +14,7 @@ Workloads (BASELINE.json `configs`):
         pre-ops (same values, PL_HIP_NO_FUSION=1 restores the two-pass structure).
   bilinear_1080p_to_4k               configs[1]: bilinear + sRGB passthrough, one pass.
   lanczos_1080p_to_4k_dither10       the separable (two-pass) Lanczos upscale, same output format
+  nv12_1080p_to_4k_ewa_dither10      NV12 source planes (pl_upload_plane layout), EWA-Lanczos 2x
   default_preset_1080p_to_4k         pl_render_default_params untouched (lanczos, sigmoid, dither)
   hdr10_4k_tonemap                   configs[3]: 4K BT.2020/PQ -> BT.709 SDR, same-frame peak
         detection (histogram) + spline tone mapping + perceptual gamut mapping 3D-LUT.
@@ -60,6 +61,8 @@ WORKLOADS = {
     "bilinear_1080p_to_4k": (P1080, P4K, px(P1080) * 8 + px(P4K) * 8, None),
     # the separable counterpart of the headline (pl_render_default_params' upscaler): two passes
     "lanczos_1080p_to_4k_dither10": (P1080, P4K, px(P1080) * 8 + px(P4K) * 8, "ortho"),
+    # real video ingest: NV12 (8-bit 4:2:0, BT.709 limited) -> EWA 2x -> RGB, 10-bit dither
+    "nv12_1080p_to_4k_ewa_dither10": (P1080, P4K, px(P1080) * 3 // 2 + px(P4K) * 8, "polar"),
     # pl_render_default_params as shipped: lanczos in linear, sigmoidized light + dither
     "default_preset_1080p_to_4k": (P1080, P4K, px(P1080) * 8 + px(P4K) * 8, "ortho"),
     "hdr10_4k_tonemap": (P4K, P4K, 3 * px(P4K) * 8, "tone map"),
@@ -94,6 +97,16 @@ class Stream:
         self.pool = pool
         self.i = 0
         self.pass_ns = {}
+        self.nv12 = None
+        if workload.startswith("nv12"):
+            # luma from the chirp's green channel, chroma from (b - g, r - g), 8 bit
+            y = (frame[..., 1] >> 8).astype(np.uint8)
+            cb = (128 + ((frame[::2, ::2, 2].astype(np.int32) - frame[::2, ::2, 1]) >> 9)).clip(16, 240)
+            cr = (128 + ((frame[::2, ::2, 0].astype(np.int32) - frame[::2, ::2, 1]) >> 9)).clip(16, 240)
+            uv = np.stack([cb, cr], axis=-1).astype(np.uint8)
+            self.nv12 = [(self.g.tex_create(sw, sh, "r8", np.roll(y, 7 * i, axis=1)[..., None]),
+                          self.g.tex_create(sw // 2, sh // 2, "rg8", np.roll(uv, 3 * i, axis=1)))
+                         for i in range(pool)]
 
         sdr = pl.color_space("bt709", "srgb")
         hdr = pl.color_space("bt2020", "pq", max_luma=1000.0)
@@ -113,6 +126,11 @@ class Stream:
                                            dither_params=dither,
                                            disable_dither_gamma_correction=True)
             icsp, tcsp, trepr = sdr, sdr, ten_bit
+        elif workload == "nv12_1080p_to_4k_ewa_dither10":
+            self.params = pl.render_params("fast", upscaler=pl.filter_config("ewa_lanczos"),
+                                           dither_params=dither,
+                                           disable_dither_gamma_correction=True)
+            icsp, tcsp, trepr = pl.color_space("bt709", "bt1886"), pl.color_space("bt709", "bt1886"), ten_bit
         elif workload == "default_preset_1080p_to_4k":
             self.params = pl.render_params("default")
             icsp, tcsp, trepr = sdr, sdr, ten_bit
@@ -134,6 +152,19 @@ class Stream:
         self._cb = capi.RENDER_INFO_CB(self._info)
         self.params.info_callback = C.cast(self._cb, C.c_void_p)
         self.images = [pl.frame(t, components=3, color=icsp) for t in self.srcs]
+        if self.nv12:
+            self.images = []
+            for ty, tuv in self.nv12:
+                f = capi.Frame(num_planes=2)
+                f.planes[0] = capi.Plane(texture=ty.ptr, components=1)
+                f.planes[1] = capi.Plane(texture=tuv.ptr, components=2)
+                for c in range(4):
+                    f.planes[0].component_mapping[c] = [0, -1, -1, -1][c]
+                    f.planes[1].component_mapping[c] = [1, 2, -1, -1][c]
+                f.repr = pl.color_repr("bt709", "limited", sample_depth=8, color_depth=8)
+                f.color = icsp
+                pl.lib().pl_frame_set_chroma_location(C.byref(f), 1)   # PL_CHROMA_LEFT
+                self.images.append(f)
         self.targets = [pl.frame(t, color=tcsp, repr_=trepr) for t in self.dsts]
 
     def _info(self, _priv, info):
@@ -148,7 +179,7 @@ class Stream:
     def close(self):
         self.g.finish()
         self.rr.destroy()
-        for t in self.srcs + self.dsts:
+        for t in self.srcs + self.dsts + [t for pair in (self.nv12 or []) for t in pair]:
             t.destroy()
         self.g.close()
 

@@ -269,6 +269,10 @@ int plh_launch_polar_pp_f16(hipStream_t stream, const plh_pass *pass, dim3 grid,
                             size_t shmem, int n);
 int plh_launch_polar_pp_f32(hipStream_t stream, const plh_pass *pass, dim3 grid, dim3 block,
                             size_t shmem, int n);
+int plh_launch_polar_pp_f16_c12(hipStream_t stream, const plh_pass *pass, dim3 grid, dim3 block,
+                                size_t shmem, int n);
+int plh_launch_polar_pp_f32_c12(hipStream_t stream, const plh_pass *pass, dim3 grid, dim3 block,
+                                size_t shmem, int n);
 
 int plh_launch_polar_classify(plh_stream stream, const plh_pass *pass, void *out)
 {
@@ -317,7 +321,7 @@ int plh_launch_polar(hipStream_t stream, const plh_pass *pass_in)
     const plh_pass *pass = &local;
     const dim3 block(POLAR_BW, POLAR_BH);
     const uint32_t cm = pass->s.comp_mask & 0xf;
-    if (pass->s.pp && (cm == 0x7 || cm == 0xf)) {
+    if (pass->s.pp && (cm == 0x7 || cm == 0xf || cm == 0x1 || cm == 0x3)) {
         const int n = pass->s.pp_n, cw = pass->s.pp_cells_w, ch = pass->s.pp_cells_h;
         const int cth = POLAR_BH * pass->s.tile_rows;
         const dim3 grid((cw + POLAR_BW - 1) / POLAR_BW, (ch + cth - 1) / cth);
@@ -326,9 +330,12 @@ int plh_launch_polar(hipStream_t stream, const plh_pass *pass_in)
                              (size_t) pass->s.tile_w * pass->s.tile_h * px;
         if (shmem > 160 * 1024)
             return -1000;
+        const bool planes = cm == 0x1 || cm == 0x3;
         if (pass->s.tile_fp32)
-            return plh_launch_polar_pp_f32(stream, pass, grid, block, shmem, n);
-        return plh_launch_polar_pp_f16(stream, pass, grid, block, shmem, n);
+            return planes ? plh_launch_polar_pp_f32_c12(stream, pass, grid, block, shmem, n)
+                          : plh_launch_polar_pp_f32(stream, pass, grid, block, shmem, n);
+        return planes ? plh_launch_polar_pp_f16_c12(stream, pass, grid, block, shmem, n)
+                      : plh_launch_polar_pp_f16(stream, pass, grid, block, shmem, n);
     }
     const int th = POLAR_BH * pass->s.tile_rows;
     const dim3 grid((pass->width + POLAR_BW - 1) / POLAR_BW, (pass->height + th - 1) / th);

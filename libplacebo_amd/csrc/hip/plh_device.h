@@ -70,7 +70,7 @@ enum plh_address_mode {     // gpu.h pl_tex_address_mode
 // (2 canonical phases x fp32 rounding noise for a 2x upscale). The host builds,
 // once per geometry, the exact per-(class pair, tap) weights with the same device
 // arithmetic the per-pixel path uses; the kernel then only does the FMAs.
-#define PLH_PP_LMAX 16      // distinct classes per tile column / row
+#define PLH_PP_LMAX 32      // distinct classes per tile column / row
 struct plh_polar_pp {
     int32_t n;              // output pixels per lane and axis (share one base texel)
     int32_t padx, pady;     // cell c covers outputs [n*c - pad, n*c - pad + n)

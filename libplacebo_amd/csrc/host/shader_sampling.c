@@ -641,8 +641,12 @@ static bool polar_pp_build(pl_gpu gpu, pl_log log, struct sh_sampler_obj *obj,
     // ---- 2. classes ---------------------------------------------------------------------------
     const int ncx = classify_axis(colfc, W, clsx, idx, MAX_CLS);
     const int ncy = classify_axis(rowfc, H, clsy, idy, MAX_CLS);
-    if (ncx < 0 || ncy < 0)
-        goto done; // arbitrary (non-rational) ratio: every column has its own phase
+    if (ncx < 0 || ncy < 0) {
+        // arbitrary (non-rational) ratio: every column has its own phase
+        pl_msg(log, PL_LOG_DEBUG, "polar phase classes: more than %d distinct phases per axis "
+               "(%dx%d outputs)", MAX_CLS, W, H);
+        goto done;
+    }
 
     // ---- 3. outputs per lane: 2x2 when pairs of outputs share their base texel --------------
     int n = 1, padx = 0, pady = 0;
@@ -669,6 +673,8 @@ static bool polar_pp_build(pl_gpu gpu, pl_log log, struct sh_sampler_obj *obj,
     for (;; rows >>= 1) {
         free_axis_tiles(&tx);
         free_axis_tiles(&ty);
+        if (getenv("PL_HIP_PP_TRACE"))
+            pl_msg(log, PL_LOG_DEBUG, "polar phase classes: %dx%d classes, n=%d rows=%d", ncx, ncy, n, rows);
         if (!build_axis_tiles(&tx, idx, colbase, W, n, padx, POLAR_BW, s->bound) ||
             !build_axis_tiles(&ty, idy, rowbase, H, n, pady, POLAR_BH * rows, s->bound))
             goto done;
@@ -810,8 +816,9 @@ void plh_polar_pp_setup(pl_gpu gpu, pl_log log, void *polar_obj, struct plh_pass
     const char *env = getenv("PL_HIP_POLAR_PER_PIXEL");
     if (env && env[0] == '1')
         return;
-    if ((s->comp_mask & 0xf) != 0x7 && (s->comp_mask & 0xf) != 0xf)
-        return; // k_polar_pp is only instantiated for RGB / RGBA
+    const uint32_t cm = s->comp_mask & 0xf;
+    if (cm != 0x7 && cm != 0xf && cm != 0x1 && cm != 0x3)
+        return; // k_polar_pp is instantiated for RGB / RGBA and for 1- / 2-component planes
 
     struct polar_pp_key key = {
         .src_w = s->src.w, .src_h = s->src.h, .width = pass->width, .height = pass->height,
