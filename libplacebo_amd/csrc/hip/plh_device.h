@@ -86,6 +86,8 @@ struct plh_polar_pp {
     const int32_t *colorg, *roworg;     // [tiles] LDS tile origin (texels)
     const float *weights;               // [ncy][ncx][tp]
     const int32_t *tapoff;              // [ntaps] byte offset of the tap in the LDS tile
+    const uint32_t *tilemap;            // [launch id] -> tile x | tile y << 16 (XCD-aware
+                                        // order), NULL = launch order
 };
 
 struct plh_sampler_args {

@@ -730,6 +730,7 @@ static bool polar_pp_build(pl_gpu gpu, pl_log log, struct sh_sampler_obj *obj,
     PLACE(colorg, (size_t) tx.ntiles * 4); PLACE(roworg, (size_t) ty.ntiles * 4);
     PLACE(weights, (size_t) ncx * ncy * tp * 4);
     PLACE(tapoff, (size_t) PL_MAX(ntc, 1) * 4);
+    PLACE(tilemap, (size_t) tx.ntiles * ty.ntiles * 4);
 #undef PLACE
     blob = calloc(1, off);
     if (!blob) {
@@ -768,6 +769,20 @@ static bool polar_pp_build(pl_gpu gpu, pl_log log, struct sh_sampler_obj *obj,
     free(taps_all);
     free(keep);
 
+    // XCD-aware launch order: workgroups go to the 8 XCDs round-robin, each XCD has its own L2;
+    // XCD x gets the x-th contiguous eighth of the tiles so that neighbours share halo texels
+    const uint32_t gx = tx.ntiles, total = (uint32_t) tx.ntiles * ty.ntiles;
+    const bool remap = n == 2 && tx.ntiles <= 0xffff && ty.ntiles <= 0xffff;
+    if (remap) {
+        uint32_t *tm = (uint32_t *) (blob + o_tilemap);
+        const uint32_t q = total / 8, r = total % 8;
+        for (uint32_t lin = 0; lin < total; lin++) {
+            const uint32_t xcd = lin % 8, k = lin / 8;
+            const uint32_t tile = xcd * q + PL_MIN(xcd, r) + k;
+            tm[lin] = (tile % gx) | ((tile / gx) << 16);
+        }
+    }
+
     pl_buf_destroy(gpu, &obj->pp_blob);
     obj->pp_blob = pl_buf_create(gpu, pl_buf_params(.size = off, .storable = true,
                                                     .host_writable = true));
@@ -786,6 +801,7 @@ static bool polar_pp_build(pl_gpu gpu, pl_log log, struct sh_sampler_obj *obj,
         .coln = (const int32_t *) (d + o_coln), .rown = (const int32_t *) (d + o_rown),
         .colorg = (const int32_t *) (d + o_colorg), .roworg = (const int32_t *) (d + o_roworg),
         .weights = (const float *) (d + o_weights), .tapoff = (const int32_t *) (d + o_tapoff),
+        .tilemap = remap ? (const uint32_t *) (d + o_tilemap) : NULL,
     };
     memcpy(blob, pp, sizeof(*pp));
     pl_buf_write(gpu, obj->pp_blob, 0, blob, off);
