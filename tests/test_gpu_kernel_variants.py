@@ -202,3 +202,38 @@ def test_planar_chroma_polar_phase_classes_equal_per_pixel(gpu, fmt):
                     os.environ[k] = v
     assert np.array_equal(outs[0], outs[1])
     assert outs[0][..., :3].std() > 1000
+
+
+def test_one_renderer_across_changing_geometries(gpu):
+    """Cached state (phase-class tables, scaler LUTs, FBO pool, dither matrix) must follow the
+    frame geometry and the params: one long-lived renderer == a fresh renderer per frame."""
+    rng = np.random.default_rng(77)
+    rr = pl.Renderer(gpu)
+    names = ["ewa_lanczos", "lanczos", None, "ewa_lanczos", "mitchell", "ewa_lanczos"]
+    for case in range(12):
+        sw, sh = int(rng.integers(24, 120)), int(rng.integers(16, 80))
+        dw, dh = int(rng.integers(24, 240)), int(rng.integers(16, 160))
+        if case in (3, 4):      # same geometry twice in a row (cache hit), then a new one
+            sw, sh, dw, dh = 64, 40, 128, 80
+        img = util.chirp_rgba16(sw, sh)
+        name = names[case % len(names)]
+        kw = dict(dither_params=dither(), disable_dither_gamma_correction=True)
+        if name:
+            kw.update(upscaler=pl.filter_config(name), downscaler=pl.filter_config(name, 2))
+        params = pl.render_params("fast", **kw)
+        src = gpu.tex_create(sw, sh, "rgba16", img)
+        dst = gpu.tex_create(dw, dh, "rgba16")
+        image = pl.frame(src, components=3)
+        target = pl.frame(dst, repr_=pl.color_repr("rgb", "full", **TEN_BIT))
+        util.srand(1)
+        assert rr.render(image, target, params), gpu.messages[-4:]
+        got = dst.download()
+        fresh = pl.Renderer(gpu)
+        util.srand(1)
+        assert fresh.render(image, target, params)
+        want = dst.download()
+        fresh.destroy()
+        assert np.array_equal(got, want), (case, name, (sw, sh), (dw, dh))
+        src.destroy(); dst.destroy()
+    assert rr.errors() == 0
+    rr.destroy()
