@@ -15,6 +15,7 @@ Workloads (BASELINE.json `configs`):
   bilinear_1080p_to_4k               configs[1]: bilinear + sRGB passthrough, one pass.
   lanczos_1080p_to_4k_dither10       the separable (two-pass) Lanczos upscale, same output format
   nv12_1080p_to_4k_ewa_dither10      NV12 source planes (pl_upload_plane layout), EWA-Lanczos 2x
+  nv12_1080p_to_4k_default_preset    NV12 source, pl_render_default_params untouched
   default_preset_1080p_to_4k         pl_render_default_params untouched (lanczos, sigmoid, dither)
   hdr10_4k_tonemap                   configs[3]: 4K BT.2020/PQ -> BT.709 SDR, same-frame peak
         detection (histogram) + spline tone mapping + perceptual gamut mapping 3D-LUT.
@@ -63,6 +64,7 @@ WORKLOADS = {
     "lanczos_1080p_to_4k_dither10": (P1080, P4K, px(P1080) * 8 + px(P4K) * 8, "ortho"),
     # real video ingest: NV12 (8-bit 4:2:0, BT.709 limited) -> EWA 2x -> RGB, 10-bit dither
     "nv12_1080p_to_4k_ewa_dither10": (P1080, P4K, px(P1080) * 3 // 2 + px(P4K) * 8, "polar"),
+    "nv12_1080p_to_4k_default_preset": (P1080, P4K, px(P1080) * 3 // 2 + px(P4K) * 8, "ortho"),
     # pl_render_default_params as shipped: lanczos in linear, sigmoidized light + dither
     "default_preset_1080p_to_4k": (P1080, P4K, px(P1080) * 8 + px(P4K) * 8, "ortho"),
     "hdr10_4k_tonemap": (P4K, P4K, 3 * px(P4K) * 8, "tone map"),
@@ -130,6 +132,9 @@ class Stream:
             self.params = pl.render_params("fast", upscaler=pl.filter_config("ewa_lanczos"),
                                            dither_params=dither,
                                            disable_dither_gamma_correction=True)
+            icsp, tcsp, trepr = pl.color_space("bt709", "bt1886"), pl.color_space("bt709", "bt1886"), ten_bit
+        elif workload == "nv12_1080p_to_4k_default_preset":
+            self.params = pl.render_params("default")
             icsp, tcsp, trepr = pl.color_space("bt709", "bt1886"), pl.color_space("bt709", "bt1886"), ten_bit
         elif workload == "default_preset_1080p_to_4k":
             self.params = pl.render_params("default")

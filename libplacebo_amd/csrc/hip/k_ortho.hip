@@ -172,8 +172,9 @@ void k_ortho(const plh_pass p_)
 
 /* ------------------------------------------------------------------------ */
 /*
- * k_ortho_fast: the same convolution for the hot configuration -- an 8-byte texel source
- * (rgba16 / rgba16hf: the plane or the first pass' FBO), at most 8 taps, one texel per tap
+ * k_ortho_fast: the same convolution for the hot configurations -- an 8-byte texel source
+ * (rgba16 / rgba16hf: the plane or the first pass' FBO) or a one- / two-component plane of
+ * planar video (r8, rg8, r16, rg16 and their f16 FBOs), 4 / 6 / 8 taps, one texel per tap
  * (no linear trick), on the texel grid across the axis. Same fma order as k_ortho, so both
  * are bit-identical (tests run both: PL_HIP_ORTHO_FAST=0).
  *   - two horizontally adjacent pixels per lane: one 16-byte store per lane and row
@@ -182,29 +183,51 @@ void k_ortho(const plh_pass p_)
  *   - EPI 0: no colour ops; 1: fused epilogue (fastepi.hiph) -> rgba16; 2 / 3: LITE / full op
  *     interpreter (3 = pl_render_default_params: unsigmoidize + delinearize + dither)
  */
+// SRC = the source's plh format: the 8-byte RGBA formats (plane / FBO of packed frames) and the
+// one- / two-component planes of planar video (their passes carry no colour ops: EPI 0 only)
+template <int SRC>
 DEV uint2 of_load(const char *base, int pitch, int x, int y)
 {
-    return *(const uint2 *) (base + (size_t) y * pitch + (size_t) x * 8);
+    const char *row = base + (size_t) y * pitch;
+    if constexpr (SRC == PLH_FMT_RGBA16 || SRC == PLH_FMT_RGBA16F)
+        return *(const uint2 *) (row + (size_t) x * 8);
+    else if constexpr (SRC == PLH_FMT_RG16 || SRC == PLH_FMT_RG16F)
+        return make_uint2(*(const uint32_t *) (row + (size_t) x * 4), 0);
+    else if constexpr (SRC == PLH_FMT_R16 || SRC == PLH_FMT_R16F || SRC == PLH_FMT_RG8)
+        return make_uint2(*(const uint16_t *) (row + (size_t) x * 2), 0);
+    else
+        return make_uint2(*(const uint8_t *) (row + x), 0);
 }
 
-template <bool F16SRC>
+template <int SRC>
 DEV float4_t of_decode(const uint2 v)
 {
-    float4_t c;
-    if (F16SRC) {
+    float4_t c = { 0.0f, 0.0f, 0.0f, 1.0f };    // (plh_fetch's defaults for absent components)
+    if constexpr (SRC == PLH_FMT_RGBA16F) {
         c = { plh_h2f(v.x & 0xffff), plh_h2f(v.x >> 16), plh_h2f(v.y & 0xffff), plh_h2f(v.y >> 16) };
-    } else {
+    } else if constexpr (SRC == PLH_FMT_RGBA16) {
         c = { plh_un16(v.x & 0xffff), plh_un16(v.x >> 16), plh_un16(v.y & 0xffff), plh_un16(v.y >> 16) };
+    } else if constexpr (SRC == PLH_FMT_RG16F) {
+        c.x = plh_h2f(v.x & 0xffff); c.y = plh_h2f(v.x >> 16);
+    } else if constexpr (SRC == PLH_FMT_RG16) {
+        c.x = plh_un16(v.x & 0xffff); c.y = plh_un16(v.x >> 16);
+    } else if constexpr (SRC == PLH_FMT_R16F) {
+        c.x = plh_h2f(v.x & 0xffff);
+    } else if constexpr (SRC == PLH_FMT_R16) {
+        c.x = plh_un16(v.x & 0xffff);
+    } else if constexpr (SRC == PLH_FMT_RG8) {
+        c.x = plh_un8(v.x & 0xff); c.y = plh_un8((v.x >> 8) & 0xff);
+    } else {
+        c.x = plh_un8(v.x & 0xff);
     }
     return c;
 }
-
 
 DEV int of_clamp(int i, int n) { return min(max(i, 0), n - 1); }
 
 // (clamp addressing only: the other modes cost an integer modulo per tap -> generic kernel)
 // NT: number of taps (row_size), 4 / 6 / 8
-template <bool F16SRC, int EPI, int DIR, int NT>
+template <int SRC, int EPI, int DIR, int NT>
 __global__ __launch_bounds__(ORTHO_BW * ORTHO_BH)
 void k_ortho_fast(const plh_pass p_)
 {
@@ -246,15 +269,15 @@ void k_ortho_fast(const plh_pass p_)
 #pragma unroll
     for (int n = 0; n < NT; n++) {
         const int iw = of_clamp(first[0] + n, na);
-        raw[0][n] = DIR ? of_load(sp, spitch, o0[0], iw) : of_load(sp, spitch, iw, o0[0]);
+        raw[0][n] = DIR ? of_load<SRC>(sp, spitch, o0[0], iw) : of_load<SRC>(sp, spitch, iw, o0[0]);
     }
     if (overlap) {
-        extra = of_load(sp, spitch, of_clamp(first[0] + N, na), o0[0]);
+        extra = of_load<SRC>(sp, spitch, of_clamp(first[0] + N, na), o0[0]);
     } else {
 #pragma unroll
         for (int n = 0; n < NT; n++) {
             const int iw = of_clamp(first[1] + n, na);
-            raw[1][n] = DIR ? of_load(sp, spitch, o0[1], iw) : of_load(sp, spitch, iw, o0[1]);
+            raw[1][n] = DIR ? of_load<SRC>(sp, spitch, o0[1], iw) : of_load<SRC>(sp, spitch, iw, o0[1]);
         }
     }
 
@@ -315,7 +338,7 @@ void k_ortho_fast(const plh_pass p_)
         float lo[4] = {1e9f, 1e9f, 1e9f, 1e9f}, hi[4] = {0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll
         for (int n = 0; n < NT; n++) {
-            const float4_t t = of_decode<F16SRC>(raw[q][n]);
+            const float4_t t = of_decode<SRC>(raw[q][n]);
             const float cv[4] = { t.x, t.y, t.z, t.w };
             if (s.use_ar && (n == N / 2 - 1 || n == N / 2)) {
 #pragma unroll
@@ -383,27 +406,42 @@ void k_ortho_fast(const plh_pass p_)
     }
 }
 
-template <bool F16SRC>
+template <int SRC>
 static void launch_ortho_fast(hipStream_t stream, const plh_pass *pass, int epi)
 {
     const dim3 block(ORTHO_BW, ORTHO_BH);
     const dim3 grid(((pass->width + 1) / 2 + ORTHO_BW - 1) / ORTHO_BW,
                     (pass->height + ORTHO_BH - 1) / ORTHO_BH);
 #define LAUNCH_N(E, NT) do { \
-        if (pass->s.dir) hipLaunchKernelGGL((k_ortho_fast<F16SRC, E, 1, NT>), grid, block, 0, stream, *pass); \
-        else             hipLaunchKernelGGL((k_ortho_fast<F16SRC, E, 0, NT>), grid, block, 0, stream, *pass); \
+        if (pass->s.dir) hipLaunchKernelGGL((k_ortho_fast<SRC, E, 1, NT>), grid, block, 0, stream, *pass); \
+        else             hipLaunchKernelGGL((k_ortho_fast<SRC, E, 0, NT>), grid, block, 0, stream, *pass); \
     } while (0)
 #define LAUNCH(E) do { \
         if (pass->s.row_size == 4)      LAUNCH_N(E, 4); \
         else if (pass->s.row_size == 6) LAUNCH_N(E, 6); \
         else                            LAUNCH_N(E, 8); \
     } while (0)
-    if (epi == 0)      LAUNCH(0);
-    else if (epi == 1) LAUNCH(1);
-    else if (epi == 2) LAUNCH(2);
-    else               LAUNCH(3);
+    if constexpr (SRC == PLH_FMT_RGBA16 || SRC == PLH_FMT_RGBA16F) {
+        if (epi == 0)      LAUNCH(0);
+        else if (epi == 1) LAUNCH(1);
+        else if (epi == 2) LAUNCH(2);
+        else               LAUNCH(3);
+    } else {
+        LAUNCH(0);      // plane passes: no colour ops (ortho_fast_variant)
+    }
 #undef LAUNCH
 #undef LAUNCH_N
+}
+
+static bool ortho_fast_packed(int fmt)
+{
+    return fmt == PLH_FMT_RGBA16 || fmt == PLH_FMT_RGBA16F;
+}
+
+static bool ortho_fast_plane(int fmt)
+{
+    return fmt == PLH_FMT_R8 || fmt == PLH_FMT_RG8 || fmt == PLH_FMT_R16 || fmt == PLH_FMT_RG16 ||
+           fmt == PLH_FMT_R16F || fmt == PLH_FMT_RG16F;
 }
 
 // -1: not eligible, else the epilogue variant
@@ -416,10 +454,12 @@ static int ortho_fast_variant(plh_pass *pass)
     if (!enabled || s.address_mode != PLH_ADDRESS_CLAMP || s.use_linear || s.linear ||
         (s.row_size != 4 && s.row_size != 6 && s.row_size != 8) ||
         (s.row_stride & 3) || pass->num_pre_ops ||
-        (s.src.fmt != PLH_FMT_RGBA16 && s.src.fmt != PLH_FMT_RGBA16F))
+        (!ortho_fast_packed(s.src.fmt) && !ortho_fast_plane(s.src.fmt)))
         return -1;
     if (!pass->num_ops)
         return 0;
+    if (!ortho_fast_packed(s.src.fmt))
+        return -1;  // planes with colour ops: generic kernel
     plh_match_fast_epilogue(pass, true);
     if (pass->epi.enabled)
         return 1;
@@ -437,10 +477,16 @@ int plh_launch_ortho(hipStream_t stream, const plh_pass *pass)
         plh_pass local = *pass;
         const int epi = ortho_fast_variant(&local);
         if (epi >= 0) {
-            if (local.s.src.fmt == PLH_FMT_RGBA16F)
-                launch_ortho_fast<true>(stream, &local, epi);
-            else
-                launch_ortho_fast<false>(stream, &local, epi);
+            switch (local.s.src.fmt) {
+            case PLH_FMT_RGBA16F: launch_ortho_fast<PLH_FMT_RGBA16F>(stream, &local, epi); break;
+            case PLH_FMT_RGBA16:  launch_ortho_fast<PLH_FMT_RGBA16>(stream, &local, epi); break;
+            case PLH_FMT_R8:      launch_ortho_fast<PLH_FMT_R8>(stream, &local, epi); break;
+            case PLH_FMT_RG8:     launch_ortho_fast<PLH_FMT_RG8>(stream, &local, epi); break;
+            case PLH_FMT_R16:     launch_ortho_fast<PLH_FMT_R16>(stream, &local, epi); break;
+            case PLH_FMT_RG16:    launch_ortho_fast<PLH_FMT_RG16>(stream, &local, epi); break;
+            case PLH_FMT_R16F:    launch_ortho_fast<PLH_FMT_R16F>(stream, &local, epi); break;
+            default:              launch_ortho_fast<PLH_FMT_RG16F>(stream, &local, epi); break;
+            }
             const hipError_t err = hipGetLastError();
             return err == hipSuccess ? 0 : -(int) err;
         }

@@ -237,3 +237,49 @@ def test_one_renderer_across_changing_geometries(gpu):
         src.destroy(); dst.destroy()
     assert rr.errors() == 0
     rr.destroy()
+
+
+@pytest.mark.parametrize("fmt", ["8", "16"])
+@pytest.mark.parametrize("name", ["lanczos", "mitchell", "spline36"])
+def test_planar_ortho_fast_equals_generic(gpu, fmt, name):
+    """NV12 / P016 with a separable scaler: luma / chroma planes (r8, rg8, r16, rg16 and their
+    f16 FBOs) go through k_ortho_fast's plane instantiations."""
+    rng = np.random.default_rng(6)
+    w, h = 96, 64
+    dt, mx = (np.uint8, 255) if fmt == "8" else (np.uint16, 65535)
+    yy, xx = np.mgrid[0:h, 0:w]
+    y = ((0.5 + 0.4 * np.sin(xx * 0.21) * np.cos(yy * 0.17)) * mx).astype(dt)[..., None]
+    uv = (rng.integers(mx // 4, 3 * mx // 4, (h // 2, w // 2, 2))).astype(dt)
+    outs = []
+    for env in ({"PL_HIP_ORTHO_FAST": "0"}, {}):
+        old = {k: os.environ.get(k) for k in env}
+        os.environ.update(env)
+        try:
+            ty = gpu.tex_create(w, h, "r8" if fmt == "8" else "r16", y)
+            tuv = gpu.tex_create(w // 2, h // 2, "rg8" if fmt == "8" else "rg16", uv)
+            dst = gpu.tex_create(2 * w, 2 * h, "rgba16")
+            f = capi.Frame(num_planes=2)
+            f.planes[0] = capi.Plane(texture=ty.ptr, components=1)
+            f.planes[1] = capi.Plane(texture=tuv.ptr, components=2)
+            for c in range(4):
+                f.planes[0].component_mapping[c] = [0, -1, -1, -1][c]
+                f.planes[1].component_mapping[c] = [1, 2, -1, -1][c]
+            bits = 8 if fmt == "8" else 16
+            f.repr = pl.color_repr("bt709", "limited", sample_depth=bits, color_depth=bits)
+            f.color = pl.color_space("bt709", "bt1886")
+            pl.lib().pl_frame_set_chroma_location(C.byref(f), 1)
+            target = pl.frame(dst, color=pl.color_space("bt709", "bt1886"))
+            params = pl.render_params("fast", upscaler=pl.filter_config(name))
+            rr = pl.Renderer(gpu)
+            assert rr.render(f, target, params), gpu.messages[-4:]
+            assert rr.errors() == 0
+            outs.append(dst.download())
+            rr.destroy(); ty.destroy(); tuv.destroy(); dst.destroy()
+        finally:
+            for k, v in old.items():
+                if v is None:
+                    os.environ.pop(k, None)
+                else:
+                    os.environ[k] = v
+    assert np.array_equal(outs[0], outs[1])
+    assert outs[0][..., :3].std() > 1000
