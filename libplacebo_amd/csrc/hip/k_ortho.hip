@@ -225,8 +225,18 @@ DEV float4_t of_decode(const uint2 v)
 
 DEV int of_clamp(int i, int n) { return min(max(i, 0), n - 1); }
 
-// (clamp addressing only: the other modes cost an integer modulo per tap -> generic kernel)
-// NT: number of taps (row_size), 4 / 6 / 8
+// tap address along the filtered axis: clamp, or GL_MIRRORED_REPEAT for taps that overshoot by
+// less than n (one reflection; the launcher checks n against the tap count)
+DEV int of_tap(int i, int n, bool mirror)
+{
+    if (!mirror)
+        return of_clamp(i, n);
+    return i < 0 ? -1 - i : (i >= n ? 2 * n - 1 - i : i);
+}
+
+// (clamp or single-reflection mirror addressing; repeat costs an integer modulo per tap ->
+// generic kernel)
+// NT: number of taps (row_size), 4 / 6 / 8, or 16 = run-time count in [10, 16]
 template <int SRC, int EPI, int DIR, int NT>
 __global__ __launch_bounds__(ORTHO_BW * ORTHO_BH)
 void k_ortho_fast(const plh_pass p_)
@@ -235,7 +245,8 @@ void k_ortho_fast(const plh_pass p_)
     const plh_sampler_args &s = p.s;
     const int cx = blockIdx.x * ORTHO_BW + threadIdx.x;
     const int idy = blockIdx.y * ORTHO_BH + threadIdx.y;
-    constexpr int N = NT;
+    // NT = 16: any even tap count from 10 to 16 (downscales), N read from the pass
+    const int N = NT == 16 ? s.row_size : NT;
     // source base / pitch pinned in SGPRs: left alone the compiler re-loads them from the
     // kernel arguments in front of every texel load, each time with a full scalar wait
     const char *sp = (const char *) s.src.ptr;
@@ -243,6 +254,7 @@ void k_ortho_fast(const plh_pass p_)
     asm volatile("" : "+s"(sp), "+s"(spitch));
     const int na = DIR ? s.src.h : s.src.w, no = DIR ? s.src.w : s.src.h;
     const float my = p.out_scale[1] * ((float) idy + 0.5f);
+    const bool mirror = s.address_mode == PLH_ADDRESS_MIRROR;
 
     uint2 raw[2][NT];
     float w[2][NT];
@@ -258,7 +270,7 @@ void k_ortho_fast(const plh_pass p_)
         const float fla = __builtin_floorf(ta);
         fcoord[q] = ta - fla;
         first[q] = (int) fla - (N / 2 - 1);
-        o0[q] = of_clamp((int) __builtin_floorf(po * (float) no), no);
+        o0[q] = of_tap((int) __builtin_floorf(po * (float) no), no, mirror);
     }
 
     // texels. Horizontal 2x upscales: the two windows are the same or one texel apart, so
@@ -268,15 +280,15 @@ void k_ortho_fast(const plh_pass p_)
     uint2 extra = make_uint2(0, 0);
 #pragma unroll
     for (int n = 0; n < NT; n++) {
-        const int iw = of_clamp(first[0] + n, na);
+        const int iw = of_tap(first[0] + min(n, N - 1), na, mirror);
         raw[0][n] = DIR ? of_load<SRC>(sp, spitch, o0[0], iw) : of_load<SRC>(sp, spitch, iw, o0[0]);
     }
     if (overlap) {
-        extra = of_load<SRC>(sp, spitch, of_clamp(first[0] + N, na), o0[0]);
+        extra = of_load<SRC>(sp, spitch, of_tap(first[0] + N, na, mirror), o0[0]);
     } else {
 #pragma unroll
         for (int n = 0; n < NT; n++) {
-            const int iw = of_clamp(first[1] + n, na);
+            const int iw = of_tap(first[1] + min(n, N - 1), na, mirror);
             raw[1][n] = DIR ? of_load<SRC>(sp, spitch, o0[1], iw) : of_load<SRC>(sp, spitch, iw, o0[1]);
         }
     }
@@ -306,13 +318,23 @@ void k_ortho_fast(const plh_pass p_)
         const float fr = fpos - fbase;
         const float4 *r0 = (const float4 *) (s.weights + (size_t) (int) fbase * s.row_stride);
         const float4 *r1 = (const float4 *) (s.weights + (size_t) min((int) fbase + 1, 255) * s.row_stride);
-        const float4 a0 = r0[0], b0 = r1[0];
-        float4 a1 = a0, b1 = b0;
-        if (N > 4) {
-            a1 = r0[1]; b1 = r1[1];
+        float ra[NT], rb[NT];
+#pragma unroll
+        for (int j = 0; j < NT / 4 + (NT % 4 != 0); j++) {
+            float4 a = make_float4(0.0f, 0.0f, 0.0f, 0.0f), b = a;
+            if (4 * j < N) {    // (rows are padded to a multiple of four floats)
+                a = r0[j];
+                b = r1[j];
+            }
+            const float av[4] = { a.x, a.y, a.z, a.w }, bv[4] = { b.x, b.y, b.z, b.w };
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                if (4 * j + k < NT) {
+                    ra[4 * j + k] = av[k];
+                    rb[4 * j + k] = bv[k];
+                }
+            }
         }
-        const float ra[8] = { a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w };
-        const float rb[8] = { b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w };
 #pragma unroll
         for (int n = 0; n < NT; n++)
             w[q][n] = plh_mix(ra[n], rb[n], fr);
@@ -338,6 +360,8 @@ void k_ortho_fast(const plh_pass p_)
         float lo[4] = {1e9f, 1e9f, 1e9f, 1e9f}, hi[4] = {0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll
         for (int n = 0; n < NT; n++) {
+            if (NT == 16 && n >= N)
+                continue;
             const float4_t t = of_decode<SRC>(raw[q][n]);
             const float cv[4] = { t.x, t.y, t.z, t.w };
             if (s.use_ar && (n == N / 2 - 1 || n == N / 2)) {
@@ -419,7 +443,8 @@ static void launch_ortho_fast(hipStream_t stream, const plh_pass *pass, int epi)
 #define LAUNCH(E) do { \
         if (pass->s.row_size == 4)      LAUNCH_N(E, 4); \
         else if (pass->s.row_size == 6) LAUNCH_N(E, 6); \
-        else                            LAUNCH_N(E, 8); \
+        else if (pass->s.row_size == 8) LAUNCH_N(E, 8); \
+        else                            LAUNCH_N(E, 16); \
     } while (0)
     if constexpr (SRC == PLH_FMT_RGBA16 || SRC == PLH_FMT_RGBA16F) {
         if (epi == 0)      LAUNCH(0);
@@ -451,8 +476,19 @@ static int ortho_fast_variant(plh_pass *pass)
     const char *e = getenv("PL_HIP_ORTHO_FAST");
     const int enabled = e ? atoi(e) : 1;
     const plh_sampler_args &s = pass->s;
-    if (!enabled || s.address_mode != PLH_ADDRESS_CLAMP || s.use_linear || s.linear ||
-        (s.row_size != 4 && s.row_size != 6 && s.row_size != 8) ||
+    const int n_axis = s.dir ? s.src.h : s.src.w;
+    bool addr_ok = s.address_mode == PLH_ADDRESS_CLAMP;
+    if (s.address_mode == PLH_ADDRESS_MIRROR && n_axis >= 2 * s.row_size) {
+        // one reflection is enough if the rect stays within one texture size of the texture
+        addr_ok = true;
+        for (int c = 0; c < 4; c++) {
+            for (int k = 0; k < 2; k++)
+                addr_ok = addr_ok && s.pos[c][k] > -0.9f && s.pos[c][k] < 1.9f;
+        }
+    }
+    if (!enabled || !addr_ok || s.use_linear || s.linear ||
+        (s.row_size != 4 && s.row_size != 6 && s.row_size != 8 &&
+         !(s.row_size >= 10 && s.row_size <= 16 && !(s.row_size & 1))) ||
         (s.row_stride & 3) || pass->num_pre_ops ||
         (!ortho_fast_packed(s.src.fmt) && !ortho_fast_plane(s.src.fmt)))
         return -1;

@@ -283,3 +283,18 @@ def test_planar_ortho_fast_equals_generic(gpu, fmt, name):
                     os.environ[k] = v
     assert np.array_equal(outs[0], outs[1])
     assert outs[0][..., :3].std() > 1000
+
+
+@pytest.mark.parametrize("name,ratio", [("lanczos", 2.0), ("lanczos", 2.5), ("mitchell", 3.5),
+                                        ("catmull_rom", 4.0), ("hermite", 5.0), ("spline36", 1.7)])
+def test_ortho_fast_downscales_equal_generic(gpu, name, ratio):
+    """Widened (anti-aliased) kernels: 10-16 taps take the run-time tap count variant."""
+    sw, sh = 200, 140
+    img = util.chirp_rgba16(sw, sh)
+    dw, dh = int(sw / ratio), int(sh / ratio)
+    params = pl.render_params("fast", downscaler=pl.filter_config(name, 2),
+                              dither_params=dither(), disable_dither_gamma_correction=True)
+    a = render(gpu, img, dw, dh, params, True, {"PL_HIP_ORTHO_FAST": "0"})
+    b = render(gpu, img, dw, dh, params, True, {"PL_HIP_ORTHO_FAST": "1"})
+    assert np.array_equal(a, b), (name, ratio, util.diff_stats(a, b))
+    assert a[..., :3].std() > 500
