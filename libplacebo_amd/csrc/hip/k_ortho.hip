@@ -237,7 +237,9 @@ DEV int of_tap(int i, int n, bool mirror)
 // (clamp or single-reflection mirror addressing; repeat costs an integer modulo per tap ->
 // generic kernel)
 // NT: number of taps (row_size), 4 / 6 / 8, or 16 = run-time count in [10, 16]
-template <int SRC, int EPI, int DIR, int NT>
+// LIN: "linear trick" LUTs of all-positive filters (fill_ortho_lut, sampling.c:919-936): taps come
+// in pairs {w0 + w1, w1 / (w0 + w1)}, one blended fetch per pair
+template <int SRC, int EPI, int DIR, int NT, bool LIN = false>
 __global__ __launch_bounds__(ORTHO_BW * ORTHO_BH)
 void k_ortho_fast(const plh_pass p_)
 {
@@ -359,10 +361,14 @@ void k_ortho_fast(const plh_pass p_)
         float ca[4] = {0.0f, 0.0f, 0.0f, 0.0f};
         float lo[4] = {1e9f, 1e9f, 1e9f, 1e9f}, hi[4] = {0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll
-        for (int n = 0; n < NT; n++) {
+        for (int n = 0; n < NT; n += LIN ? 2 : 1) {
             if (NT == 16 && n >= N)
                 continue;
-            const float4_t t = of_decode<SRC>(raw[q][n]);
+            float4_t t = of_decode<SRC>(raw[q][n]);
+            if constexpr (LIN) {
+                // off = n + ws[n + 1]: the blend a bilinear fetch between taps n and n + 1 returns
+                t = mix4(t, of_decode<SRC>(raw[q][n + 1 < NT ? n + 1 : n]), w[q][n + 1 < NT ? n + 1 : n]);
+            }
             const float cv[4] = { t.x, t.y, t.z, t.w };
             if (s.use_ar && (n == N / 2 - 1 || n == N / 2)) {
 #pragma unroll
@@ -446,6 +452,14 @@ static void launch_ortho_fast(hipStream_t stream, const plh_pass *pass, int epi)
         else if (pass->s.row_size == 8) LAUNCH_N(E, 8); \
         else                            LAUNCH_N(E, 16); \
     } while (0)
+    if (pass->s.use_linear) {
+        // linear-trick filters (bicubic / gaussian / ... low-pass): no colour ops, any tap count
+        if (pass->s.dir)
+            hipLaunchKernelGGL((k_ortho_fast<SRC, 0, 1, 16, true>), grid, block, 0, stream, *pass);
+        else
+            hipLaunchKernelGGL((k_ortho_fast<SRC, 0, 0, 16, true>), grid, block, 0, stream, *pass);
+        return;
+    }
     if constexpr (SRC == PLH_FMT_RGBA16 || SRC == PLH_FMT_RGBA16F) {
         if (epi == 0)      LAUNCH(0);
         else if (epi == 1) LAUNCH(1);
@@ -486,7 +500,15 @@ static int ortho_fast_variant(plh_pass *pass)
                 addr_ok = addr_ok && s.pos[c][k] > -0.9f && s.pos[c][k] < 1.9f;
         }
     }
-    if (!enabled || !addr_ok || s.use_linear || s.linear ||
+    if (s.use_linear) {
+        // the LIN variant: run-time tap count (even, <= 16), no colour ops
+        if (!enabled || !addr_ok || s.linear || (s.row_size & 1) || s.row_size < 2 ||
+            s.row_size > 16 || (s.row_stride & 3) || pass->num_pre_ops || pass->num_ops ||
+            (!ortho_fast_packed(s.src.fmt) && !ortho_fast_plane(s.src.fmt)))
+            return -1;
+        return 0;
+    }
+    if (!enabled || !addr_ok || s.linear ||
         (s.row_size != 4 && s.row_size != 6 && s.row_size != 8 &&
          !(s.row_size >= 10 && s.row_size <= 16 && !(s.row_size & 1))) ||
         (s.row_stride & 3) || pass->num_pre_ops ||

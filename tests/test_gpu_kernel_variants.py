@@ -286,7 +286,10 @@ def test_planar_ortho_fast_equals_generic(gpu, fmt, name):
 
 
 @pytest.mark.parametrize("name,ratio", [("lanczos", 2.0), ("lanczos", 2.5), ("mitchell", 3.5),
-                                        ("catmull_rom", 4.0), ("hermite", 5.0), ("spline36", 1.7)])
+                                        ("catmull_rom", 4.0), ("hermite", 5.0), ("spline36", 1.7),
+                                        # all-positive kernels: "linear trick" LUTs
+                                        ("bicubic", 3.5), ("bicubic", 1.5), ("gaussian", 2.0),
+                                        ("bilinear", 6.0), ("hermite", 2.2)])
 def test_ortho_fast_downscales_equal_generic(gpu, name, ratio):
     """Widened (anti-aliased) kernels: 10-16 taps take the run-time tap count variant."""
     sw, sh = 200, 140
