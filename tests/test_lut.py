@@ -198,3 +198,52 @@ def test_renderer_lut_slots(gpu):
     got = render(ycc, pl.frame(dst), pl.render_params("fast"))
     assert np.array_equal(got, want)        # no matrix: the LUT output is taken as RGB
     src.destroy(); dst.destroy()
+
+
+@pytest.mark.gpu
+def test_renderer_main_lut_types(gpu):
+    """params->lut as PL_LUT_CONVERSION (replaces the image -> target conversion) and
+    PL_LUT_NORMALIZED (applied to linear light, scaled by the nominal peak)."""
+    import util
+    from test_gpu_color import nominal, luma_coeffs
+    sw, sh_ = 48, 32
+    img = util.chirp_rgba16(sw, sh_)
+    src = gpu.tex_create(sw, sh_, "rgba16", img)
+    dst = gpu.tex_create(sw, sh_, "rgba16")
+    size = (9, 9, 9)
+    grid = np.float32([[r / 8, g / 8, b / 8] for b in range(9) for g in range(9) for r in range(9)])
+    data = (grid ** 1.2).astype(np.float32)
+    lut = pl.custom_lut(data, size)
+    csp = pl.color_space("bt709", "bt1886")
+
+    def render(params):
+        rr = pl.Renderer(gpu)
+        assert rr.render(pl.frame(src, components=3, color=csp), pl.frame(dst, color=csp), params)
+        assert rr.errors() == 0
+        out = dst.download()
+        rr.destroy()
+        return out
+
+    f = orc.tex_decode(img, "rgba16")
+    f[..., 3] = 1.0
+    # CONVERSION: the LUT output is the target signal
+    got = render(pl.render_params("fast", lut=lut, lut_type=pl.LUT_CONVERSION))
+    want = orc.tex_encode(orc.custom_lut(f.copy(), data, size), "rgba16")
+    assert np.array_equal(got, want)
+    # NORMALIZED: linearize -> / peak -> LUT -> * peak -> delinearize (SDR: peak = 1)
+    got = render(pl.render_params("fast", lut=lut, lut_type=pl.LUT_NORMALIZED))
+    c = pl.color_space("bt709", "bt1886")
+    pl.lib().pl_color_space_infer(C.byref(c))
+    mn, mx = nominal(c)
+    luma = luma_coeffs(c.primaries)
+    lin = orc.linearize(f.copy(), int(c.transfer), mn, mx, luma)
+    lin = orc.custom_lut(lin, data, size)
+    want = orc.tex_encode(orc.delinearize(lin, int(c.transfer), mn, mx, luma), "rgba16")
+    d = np.abs(got.astype(np.int64) - want.astype(np.int64))[..., :3]
+    assert d.max() <= 3, int(d.max())
+    # identity LUT in NORMALIZED mode: the frame survives the round trip
+    ident = pl.custom_lut(grid, size)
+    got = render(pl.render_params("fast", lut=ident, lut_type=pl.LUT_NORMALIZED))
+    d = np.abs(got.astype(np.int64) - img.astype(np.int64))[..., :3]
+    assert d.max() <= 3, int(d.max())
+    src.destroy(); dst.destroy()
