@@ -311,7 +311,7 @@ def main():
                 traffic = json.load(f).get(args.workload)
         symbol = ("k_pass_peak" if "peak detection" in name else
                   "k_polar_pp" if name.startswith("polar") else
-                  "k_ortho" if name.startswith("ortho") else
+                  "k_ortho_fast" if name.startswith("ortho") else
                   "k_deband" if name.startswith("deband") else
                   # (bilinear + fused epilogue -> rgba16 has its own kernel, k_pass.hip)
                   "k_bilinear_fast" if args.workload == "bilinear_1080p_to_4k" else "k_pass_generic")
@@ -348,7 +348,8 @@ def main():
             "data": "synthetic",
             "config": {
                 "workload": args.workload,
-                "src": f"{sw}x{sh} rgba16",
+                "src": f"{sw}x{sh} " + ("nv12 (r8 + rg8 planes)" if args.workload.startswith("nv12")
+                                        else "rgba16"),
                 "dst": f"{dw}x{dh} rgba16",
                 "pool": pool,
                 "api": "pl_render_image",
@@ -357,7 +358,7 @@ def main():
             },
             "roofline": roofline,
         }
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:    # (rank 0 at N = 1 only)
             out["cpu_baseline"] = cpu_baseline(args.workload)
         print(json.dumps(out), flush=True)
 
