@@ -195,13 +195,24 @@ def cpu_baseline(workload):
     import orc
     import util
     (sw, sh), (dw, dh), _, _ = WORKLOADS[workload]
-    if workload.startswith("bilinear") or workload.startswith("ewa_lanczos"):
+    ortho = workload.startswith("lanczos") or "default_preset" in workload
+    if workload.startswith("bilinear") or workload.startswith("ewa_lanczos") or \
+            workload.startswith("nv12_1080p_to_4k_ewa") or ortho:
         cw, ch = sw, sh  # one whole frame: ~10 s of scalar CPU work
         src = util.chirp_rgba16(sw, sh)
         tex = orc.tex_decode(src, "rgba16")
         t0 = time.perf_counter()
         if workload.startswith("bilinear"):
             out = orc.sample_simple(tex, orc.S_BILINEAR, cw * 2, ch * 2)
+        elif ortho:
+            # the two passes of the separable Lanczos scaler (the colour stages of the preset
+            # are not part of this sample)
+            rows, n, _, _ = orc.filter_generate_ortho(orc.lanczos())
+            rows = orc.ortho_lut_rows(rows, n, False)
+            img = orc.op_quant_f16(orc.sample_simple(tex, orc.S_BILINEAR, cw, ch))
+            tmp = orc.op_quant_f16(orc.sample_ortho(img, rows, n, 1, cw, ch * 2))
+            out = orc.sample_ortho(tmp, rows, n, 0, cw * 2, ch * 2)
+            orc.dither(out, util.blue_noise(pl), 10)
         else:
             img = orc.op_quant_f16(orc.sample_simple(tex, orc.S_BILINEAR, cw, ch))
             w, r, rz = orc.filter_generate_polar(orc.ewa_lanczos())
