@@ -301,3 +301,26 @@ def test_ortho_fast_downscales_equal_generic(gpu, name, ratio):
     b = render(gpu, img, dw, dh, params, True, {"PL_HIP_ORTHO_FAST": "1"})
     assert np.array_equal(a, b), (name, ratio, util.diff_stats(a, b))
     assert a[..., :3].std() > 500
+
+
+def test_tiny_frames_do_not_break_the_fast_paths(gpu):
+    """1..8 pixel sources and targets through every scaler family: the specialised kernels must
+    either decline or agree with the generic ones (and nothing may fault)."""
+    rng = np.random.default_rng(5)
+    scalers = [None, "lanczos", "bicubic", "ewa_lanczos", "mitchell", "gaussian"]
+    for case in range(30):
+        sw, sh = int(rng.integers(1, 9)), int(rng.integers(1, 9))
+        dw, dh = int(rng.integers(1, 17)), int(rng.integers(1, 17))
+        img = util.chirp_rgba16(max(sw, 2), max(sh, 2))[:sh, :sw].copy()
+        name = scalers[case % len(scalers)]
+        kw = {}
+        if name:
+            kw.update(upscaler=pl.filter_config(name), downscaler=pl.filter_config(name, 2))
+        if case % 2:
+            kw.update(dither_params=dither(), disable_dither_gamma_correction=True)
+        params = pl.render_params("fast", **kw)
+        generic = {"PL_HIP_BILIN_ITERS": "0", "PL_HIP_ORTHO_FAST": "0", "PL_HIP_NO_FUSION": "1",
+                   "PL_HIP_POLAR_PER_PIXEL": "1"}
+        a = render(gpu, img, dw, dh, params, bool(case % 2), generic)
+        b = render(gpu, img, dw, dh, params, bool(case % 2), {})
+        assert np.array_equal(a, b), (case, name, (sw, sh), (dw, dh))
