@@ -30,6 +30,21 @@ typedef struct pl_rect2df {
 #define pl_rect_h(r) ((r).y1 - (r).y0)
 
 PL_API void pl_rect2df_normalize(pl_rect2df *rc);
+
+// Rotation in multiples of 90 degrees clockwise (reference common.h:205-231)
+typedef int pl_rotation;
+enum {
+    PL_ROTATION_0 = 0, PL_ROTATION_90 = 1, PL_ROTATION_180 = 2, PL_ROTATION_270 = 3,
+    PL_ROTATION_360 = 4,    // equivalent to PL_ROTATION_0; values outside [0, 4) are legal
+};
+
+static inline pl_rotation pl_rotation_normalize(pl_rotation rot)
+{
+    return (rot % PL_ROTATION_360 + PL_ROTATION_360) % PL_ROTATION_360;
+}
+
+// Rotates the coordinate system of a rect (PL_ROTATION_90: the x axis becomes the y axis)
+PL_API void pl_rect2df_rotate(pl_rect2df *rc, pl_rotation rot);
 PL_API pl_rect2d pl_rect2df_round(const pl_rect2df *rc);
 
 // Row-major 3x3 matrix: out[i] = sum_j m[i][j] * in[j]

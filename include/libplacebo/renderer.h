@@ -6,7 +6,7 @@
  *
  * Field names, meanings and defaults are the reference's. Not provided (out of the
  * hot-path scope): hooks, ICC, overlays, film grain,
- * deinterlacing, distortion / cone distortion, blurred borders, rotation.
+ * deinterlacing, distortion / cone distortion, blurred borders.
  * Images and targets may be packed, semi-planar or planar / subsampled.
  */
 #ifndef LIBPLACEBO_RENDERER_H_
@@ -159,11 +159,6 @@ struct pl_plane {
     float shift_x, shift_y;   // sample position relative to the reference plane's grid
 };
 
-typedef int pl_rotation;
-enum {
-    PL_ROTATION_0 = 0, PL_ROTATION_90, PL_ROTATION_180, PL_ROTATION_270, PL_ROTATION_360,
-};
-
 struct pl_frame {
     int num_planes;           // 1..4 (packed, semi-planar, planar)
     struct pl_plane planes[PL_MAX_PLANES];
@@ -180,7 +175,7 @@ struct pl_frame {
     enum pl_lut_type lut_type;
 
     pl_rect2df crop;          // 0 = whole frame; flipped rects flip the image
-    pl_rotation rotation;     // must be PL_ROTATION_0
+    pl_rotation rotation;     // clockwise, in multiples of 90 degrees (common.h)
     void *user_data;
 };
 

@@ -122,3 +122,23 @@ void pl_transform3x3_invert(pl_transform3x3 *t)
     for (int i = 0; i < 3; i++)
         t->c[i] = -(t->mat.m[i][0] * c[0] + t->mat.m[i][1] * c[1] + t->mat.m[i][2] * c[2]);
 }
+
+// reference src/common.c:469-500
+void pl_rect2df_rotate(pl_rect2df *rc, pl_rotation rot)
+{
+    rot = pl_rotation_normalize(rot);
+    if (!rot)
+        return;
+    float x0 = rc->x0, y0 = rc->y0, x1 = rc->x1, y1 = rc->y1;
+    if (rot >= PL_ROTATION_180) {
+        // a half turn swaps both pairs of edges
+        rot -= PL_ROTATION_180;
+        float t;
+        t = x0; x0 = x1; x1 = t;
+        t = y0; y0 = y1; y1 = t;
+    }
+    if (rot == PL_ROTATION_90)
+        *rc = (pl_rect2df) { .x0 = y1, .y0 = x0, .x1 = y0, .y1 = x1 };
+    else
+        *rc = (pl_rect2df) { .x0 = x0, .y0 = y0, .x1 = x1, .y1 = y1 };
+}

@@ -15,9 +15,9 @@
  * A pass boundary (FBO) appears exactly where the reference has one; everything between two
  * boundaries runs fused in one HIP launch (sampler + colour ops).
  *
- * Scope: frames with ONE plane (packed RGB(A), or any single-plane representation). Planar /
- * subsampled frames, rotation, hooks, LUTs, ICC, overlays, blending, deinterlacing and frame
- * mixing are outside this round's hot path and rejected with an error.
+ * Scope: packed, semi-planar and planar (subsampled) frames in and out, rotation, custom LUTs,
+ * contrast recovery, frame mixing (pl_render_image_mix). Hooks, ICC, overlays, blending,
+ * deinterlacing and distortion are outside the hot path and rejected with an error.
  */
 #include <math.h>
 #include <stdlib.h>
@@ -121,6 +121,7 @@ struct pass_state {
     bool need_peak_fbo;
     bool acquired_image, acquired_target;
     struct pl_render_info info;
+    pl_rotation rotation;   // logical end-to-end rotation
 };
 
 static void info_callback(void *priv, const struct pl_dispatch_info *dinfo)
@@ -665,7 +666,7 @@ static void fix_refs_and_rects(struct pass_state *pass)
     pl_rect2df *dst = &target->crop, *src = &image->crop;
     pl_tex dst_ref = target->planes[frame_ref(target)].texture,
            src_ref = image->planes[frame_ref(image)].texture;
-    const int dst_w = dst_ref->params.w, dst_h = dst_ref->params.h;
+    int dst_w = dst_ref->params.w, dst_h = dst_ref->params.h;
 
     if ((!dst->x0 && !dst->x1) || (!dst->y0 && !dst->y1)) {
         dst->x1 = dst_w;
@@ -674,6 +675,16 @@ static void fix_refs_and_rects(struct pass_state *pass)
     if ((!src->x0 && !src->x1) || (!src->y0 && !src->y1)) {
         src->x1 = src_ref->params.w;
         src->y1 = src_ref->params.h;
+    }
+
+    // end-to-end rotation (:3113-3117): the image is processed in its own orientation, the
+    // target rect is counter-rotated into it, the output stage transposes / flips the stores
+    pass->rotation = pl_rotation_normalize(image->rotation - target->rotation);
+    pl_rect2df_rotate(dst, -pass->rotation);
+    if (pass->rotation % PL_ROTATION_180 == PL_ROTATION_90) {
+        const int t = dst_w;
+        dst_w = dst_h;
+        dst_h = t;
     }
 
     // is the end-to-end rendering flipped?
@@ -774,10 +785,6 @@ static bool validate_frame(pl_renderer rr, const struct pl_frame *f, const char 
     const struct pl_plane *pl = &f->planes[frame_ref(f)];
     if (pl->shift_x || pl->shift_y) {
         RR_ERR(rr, "%s reference plane must have no shift", what);
-        return false;
-    }
-    if (f->rotation % PL_ROTATION_360 != PL_ROTATION_0) {
-        RR_ERR(rr, "Rotation is not supported by this backend yet");
         return false;
     }
     return true;
@@ -1614,7 +1621,7 @@ static bool pass_output_target(struct pass_state *pass)
     pl_renderer rr = pass->rr;
     struct img *img = &pass->img;
     pl_shader sh = img_sh(pass, img);
-    const pl_rect2d dst_rect = pass->dst_rect;
+    pl_rect2d dst_rect = pass->dst_rect;
     const bool need_clear = pl_frame_is_cropped(target);
 
     enum pl_clear_mode background = params->background;
@@ -1668,6 +1675,16 @@ static bool pass_output_target(struct pass_state *pass)
     }
     if (tlut == PL_LUT_NATIVE)
         pl_shader_custom_lut(sh, target->lut, &rr->lut_state[LUT_TARGET]);
+
+    // rotation by an odd number of quarter turns (:2787-2793): back to the target's
+    // orientation, the stores are transposed
+    if (pass->rotation % PL_ROTATION_180 == PL_ROTATION_90) {
+        int t;
+        t = dst_rect.x0; dst_rect.x0 = dst_rect.y0; dst_rect.y0 = t;
+        t = dst_rect.x1; dst_rect.x1 = dst_rect.y1; dst_rect.y1 = t;
+        t = img->w; img->w = img->h; img->h = t;
+        sh->transpose = true;
+    }
 
     const bool flipped_x = dst_rect.x1 < dst_rect.x0, flipped_y = dst_rect.y1 < dst_rect.y0;
 

@@ -212,9 +212,10 @@ def test_rejects_what_it_does_not_do(gpu, rr):
     f2 = pl.frame(t)
     f2.num_planes = 5
     assert not rr.render(f, f2, pl.render_params("fast"))
-    f3 = pl.frame(t)
-    f3.rotation = 1
-    assert not rr.render(f3, f, pl.render_params("fast"))
+    # stages outside this backend are refused loudly, not skipped (hooks here)
+    params = pl.render_params("fast")
+    params.num_hooks = 1
+    assert not rr.render(f, f, params)
     t.destroy()
 
 
