@@ -189,7 +189,8 @@ PL_API bool pl_frame_is_cropped(const struct pl_frame *frame);
 // Fill in what pl_render_image would infer (crop, bit depths, colour spaces)
 PL_API void pl_frames_infer(pl_renderer rr, struct pl_frame *image, struct pl_frame *target);
 
-// Render `image` to `target`. Returns false on hard failure; soft failures
+// Render `image` to `target` (`image` == NULL: clear the target to the background colour).
+// Returns false on hard failure; soft failures
 // disable the offending stage and are reported by pl_renderer_get_errors.
 PL_API bool pl_render_image(pl_renderer rr, const struct pl_frame *image,
                             const struct pl_frame *target,
@@ -226,7 +227,7 @@ PL_API const struct pl_frame *pl_frame_mix_nearest(const struct pl_frame_mix *mi
 // `params->frame_mixer` (a 1-D pl_filter_config over time, or oversampling) is rendered -- or
 // taken from the cache -- at the output size in the target's colour space, the frames are
 // blended in linear light and the result goes through the output stage. Without a frame mixer
-// (or with a single frame) the nearest frame is rendered. An empty mix is not supported here.
+// (or with a single frame) the nearest frame is rendered. An empty mix clears the target.
 PL_API bool pl_render_image_mix(pl_renderer rr, const struct pl_frame_mix *images,
                                 const struct pl_frame *target,
                                 const struct pl_render_params *params);

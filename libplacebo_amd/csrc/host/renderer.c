@@ -1613,6 +1613,31 @@ error:
     return false;
 }
 
+// clear_target (:2410-2555), PL_CLEAR_COLOR flavour (tiles / blur degrade to it), every plane
+static void clear_target(struct pass_state *pass, float scale)
+{
+    const struct pl_render_params *params = pass->params;
+    const struct pl_frame *target = &pass->target;
+    pl_renderer rr = pass->rr;
+    float bg[3];
+    translate_srgb_color(bg, params->background_color, &target->color);
+    float enc[3] = { bg[0], bg[1], bg[2] };
+    struct pl_color_repr crepr = target->repr;
+    pl_transform3x3 tr = pl_color_repr_decode(&crepr, NULL);
+    pl_transform3x3_invert(&tr);
+    pl_transform3x3_apply(&tr, enc);
+    const float alpha = 1.0 - params->background_transparency;
+    for (int pi = 0; pi < target->num_planes; pi++) {
+        const struct pl_plane *cp = &target->planes[pi];
+        float clear[4];
+        for (int c = 0; c < 4; c++) {
+            const int m = c < cp->components ? cp->component_mapping[c] : -1;
+            clear[c] = m == PL_CHANNEL_A ? alpha : m >= 0 && m < 3 ? enc[m] / scale : 0.0f;
+        }
+        pl_tex_clear(rr->gpu, cp->texture, clear);
+    }
+}
+
 static bool pass_output_target(struct pass_state *pass)
 {
     const struct pl_render_params *params = pass->params;
@@ -1688,26 +1713,8 @@ static bool pass_output_target(struct pass_state *pass)
 
     const bool flipped_x = dst_rect.x1 < dst_rect.x0, flipped_y = dst_rect.y1 < dst_rect.y0;
 
-    if (need_clear && params->border != PL_CLEAR_SKIP) {
-        // clear_target (:2410-2555), PL_CLEAR_COLOR flavour, every plane
-        float bg[3];
-        translate_srgb_color(bg, params->background_color, &target->color);
-        float enc[3] = { bg[0], bg[1], bg[2] };
-        struct pl_color_repr crepr = target->repr;
-        pl_transform3x3 tr = pl_color_repr_decode(&crepr, NULL);
-        pl_transform3x3_invert(&tr);
-        pl_transform3x3_apply(&tr, enc);
-        const float alpha = 1.0 - params->background_transparency;
-        for (int pi = 0; pi < target->num_planes; pi++) {
-            const struct pl_plane *cp = &target->planes[pi];
-            float clear[4];
-            for (int c = 0; c < 4; c++) {
-                const int m = c < cp->components ? cp->component_mapping[c] : -1;
-                clear[c] = m == PL_CHANNEL_A ? alpha : m >= 0 && m < 3 ? enc[m] / scale : 0.0f;
-            }
-            pl_tex_clear(rr->gpu, cp->texture, clear);
-        }
-    }
+    if (need_clear && params->border != PL_CLEAR_SKIP)
+        clear_target(pass, scale);
 
     pl_tex ref_tex = target->planes[frame_ref(target)].texture;
     pl_tex img_fbo = NULL;
@@ -1878,13 +1885,30 @@ bool pl_render_image(pl_renderer rr, const struct pl_frame *pimage, const struct
                      const struct pl_render_params *params)
 {
     params = PL_DEF(params, &pl_render_default_params);
-    if (!pimage || !ptarget) {
-        RR_ERR(rr, "pl_render_image: image and target are required (overlay-only rendering is "
-               "not supported)");
+    if (!ptarget) {
+        RR_ERR(rr, "pl_render_image: a target is required");
         return false;
     }
     if (unsupported(rr, params))
         return false;
+    if (!pimage) {
+        // no image (:3463-3476): the target is cleared (there are no overlays to draw here)
+        struct pass_state pass = { .rr = rr, .params = params, .target = *ptarget };
+        if (pass.target.acquire) {
+            if (!pass.target.acquire(rr->gpu, &pass.target))
+                return false;
+            pass.acquired_target = true;
+        }
+        bool ok = validate_frame(rr, &pass.target, "Target", true);
+        if (ok) {
+            fix_frame(&pass.target);
+            pl_color_space_infer(&pass.target.color);
+            struct pl_color_repr repr = pass.target.repr;
+            clear_target(&pass, pl_color_repr_normalize(&repr));
+        }
+        pass_uninit(&pass);
+        return ok;
+    }
 
     struct pass_state pass = {
         .rr = rr,
@@ -1998,10 +2022,8 @@ bool pl_render_image_mix(pl_renderer rr, const struct pl_frame_mix *images,
                          const struct pl_frame *ptarget, const struct pl_render_params *params)
 {
     params = PL_DEF(params, &pl_render_default_params);
-    if (!images || !images->num_frames) {
-        RR_ERR(rr, "pl_render_image_mix: an empty mix (overlay-only rendering) is not supported");
-        return false;
-    }
+    if (!images || !images->num_frames)
+        return pl_render_image(rr, NULL, ptarget, params);
     if (unsupported(rr, params))
         return false;
     if (!(images->vsync_duration > 0.0f)) {

@@ -198,8 +198,13 @@ def test_rejections_and_fallbacks(gpu, rr):
     assert not ok
     ok, _ = run_mix(gpu, rr, frames[:2], [-0.7, 0.3], params, vsync=0.0)
     assert not ok
-    ok, _ = run_mix(gpu, rr, [], [], params)                            # empty mix
-    assert not ok
+    # an empty mix is pl_render_image without an image: the target is cleared to the background
+    params_bg = pl.render_params("fast", frame_mixer=mixer("linear"))
+    params_bg.background_color = (C.c_float * 3)(1.0, 0.0, 0.5)
+    ok, got = run_mix(gpu, rr, [], [], params_bg)
+    assert ok
+    assert np.all(got[..., 0] == 65535) and np.all(got[..., 1] == 0) and np.all(got[..., 3] == 65535)
+    assert abs(int(got[0, 0, 2]) - 32768) <= 600                        # (sRGB 0.5 in BT.1886)
     # six frames fit one pass ...
     cfg = mixer("lanczos")                                              # radius 3
     params = pl.render_params("fast", frame_mixer=cfg)
