@@ -54,6 +54,7 @@ DEV uint32_t wave_max(uint32_t v)
 // (The 256-lane / 1 px per lane version spent half of its time in barriers and LDS atomics:
 // 4K 127 us -> see DESIGN.md section 7.)
 #define PEAK_WAVES 4
+#define PL_MIN_INT(a, b) ((a) < (b) ? (a) : (b))
 #define PEAK_NPX 4
 
 // op: i0 = transfer (already inferred), i1 = TRC flags, i2 = use_histogram;
@@ -176,6 +177,9 @@ DEV float4_t run_sampler_pk(const plh_sampler_args &s, float px, float py)
     return c;
 }
 
+// LITE: the ops around the measurement only use the cheap cases (plh_ops_lite): the usual
+// "plane -> FBO + measurement" pass then needs < 128 VGPRs (4 waves per SIMD instead of 3)
+template <bool LITE>
 __global__ __launch_bounds__(64 * PEAK_WAVES)
 void k_pass_peak(const plh_pass p_)
 {
@@ -232,10 +236,10 @@ void k_pass_peak(const plh_pass p_)
             break;
         }
     }
-    apply_ops_n<PEAK_NPX>(c, p.ops, 0, pk_op, fcs);
+    apply_ops_n<PEAK_NPX, false, LITE>(c, p.ops, 0, pk_op, fcs);
     if (pk_op < p.num_ops) {
         peak_measure(c, p.ops[pk_op], hists[wave], wg_idx, p.peak_scratch);
-        apply_ops_n<PEAK_NPX>(c, p.ops, pk_op + 1, p.num_ops, fcs);
+        apply_ops_n<PEAK_NPX, false, LITE>(c, p.ops, pk_op + 1, p.num_ops, fcs);
     }
 
     if (!p.dst.ptr)
@@ -277,7 +281,17 @@ int plh_launch_peak(hipStream_t stream, const plh_pass *pass)
     const dim3 grid((tiles + PEAK_WAVES - 1) / PEAK_WAVES);
     if (!pass->peak_buf || !pass->peak_scratch)
         return -1002;
-    hipLaunchKernelGGL(k_pass_peak, grid, block, 0, stream, *pass);
+    int pk_op = pass->num_ops;
+    for (int i = 0; i < pass->num_ops; i++) {
+        if (pass->ops[i].kind == PLH_OP_PEAK_DETECT) {
+            pk_op = i;
+            break;
+        }
+    }
+    if (plh_ops_lite(pass, 0, pk_op) && plh_ops_lite(pass, PL_MIN_INT(pk_op + 1, pass->num_ops), pass->num_ops))
+        hipLaunchKernelGGL(k_pass_peak<true>, grid, block, 0, stream, *pass);
+    else
+        hipLaunchKernelGGL(k_pass_peak<false>, grid, block, 0, stream, *pass);
     hipLaunchKernelGGL(k_peak_fold, dim3((PLH_PEAK_WORDS + 255) / 256), dim3(256), 0, stream,
                        (uint32_t *) pass->peak_buf, (uint32_t *) pass->peak_scratch);
     const hipError_t err = hipGetLastError();
