@@ -242,6 +242,16 @@ def cpu_baseline(workload):
     }
 
 
+def baseline_metric():
+    """BASELINE.json's metric name (the driver matches on it); the workload measured is named in
+    config.workload."""
+    try:
+        with open(os.path.join(ROOT, "BASELINE.json")) as f:
+            return json.load(f)["metric"]
+    except Exception:
+        return "Mpixels/s (and frames/s) for EWA-Lanczos 1080p->4K + HDR tonemap, 1/2/4/8 GPU"
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -344,7 +354,7 @@ def main():
     if rank == 0:
         frames = args.steps * world
         out = {
-            "metric": "Mpixels/s (output) through pl_render_image, per-GPU streams",
+            "metric": baseline_metric(),
             "value": round(frames * dw * dh / elapsed / 1e6, 1),
             "unit": "Mpixels/s",
             "n_gpus": world,
@@ -364,6 +374,7 @@ def main():
                 "dst": f"{dw}x{dh} rgba16",
                 "pool": pool,
                 "api": "pl_render_image",
+                "measured": "output Mpixels/s through pl_render_image, one independent stream per GPU",
                 "render_errors": st.rr.errors(),   # pl_render_error bits: no stage may be disabled
                 "parallelism": f"{world} independent stream(s), one per GPU",
             },
