@@ -343,6 +343,31 @@ PL_API struct pl_raw_primaries pl_primaries_clip(const struct pl_raw_primaries *
 // IPTPQc4 perceptual space used by tone / gamut mapping
 PL_API pl_matrix3x3 pl_ipt_rgb2lms(const struct pl_raw_primaries *prim);
 PL_API pl_matrix3x3 pl_ipt_lms2rgb(const struct pl_raw_primaries *prim);
+// Colour blindness simulation (reference colorspace.h :664-708)
+enum pl_cone {
+    PL_CONE_L = 1 << 0, PL_CONE_M = 1 << 1, PL_CONE_S = 1 << 2,
+    PL_CONE_NONE = 0,
+    PL_CONE_LM  = PL_CONE_L | PL_CONE_M,
+    PL_CONE_MS  = PL_CONE_M | PL_CONE_S,
+    PL_CONE_LS  = PL_CONE_L | PL_CONE_S,
+    PL_CONE_LMS = PL_CONE_L | PL_CONE_M | PL_CONE_S,
+};
+
+struct pl_cone_params {
+    enum pl_cone cones; // cones affected by the vision model
+    float strength;     // 1.0 = unaffected, 0.0 = full blindness (> 1 counteracts)
+};
+
+#define pl_cone_params(...) (&(struct pl_cone_params) { __VA_ARGS__ })
+
+PL_API extern const struct pl_cone_params pl_vision_normal, pl_vision_protanomaly,
+    pl_vision_protanopia, pl_vision_deuteranomaly, pl_vision_deuteranopia, pl_vision_tritanomaly,
+    pl_vision_tritanopia, pl_vision_monochromacy, pl_vision_achromatopsia;
+
+// Matrix applying the cone model to linear RGB of the given primaries
+PL_API pl_matrix3x3 pl_get_cone_matrix(const struct pl_cone_params *params,
+                                       const struct pl_raw_primaries *prim);
+
 PL_API extern const pl_matrix3x3 pl_ipt_lms2ipt;
 PL_API extern const pl_matrix3x3 pl_ipt_ipt2lms;
 

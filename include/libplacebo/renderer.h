@@ -101,7 +101,7 @@ struct pl_render_params {
     const struct pl_dither_params *dither_params;
     const struct pl_error_diffusion_kernel *error_diffusion;
 
-    const void *cone_params;            // unsupported, must be NULL
+    const struct pl_cone_params *cone_params; // colour blindness simulation (NULL = off)
     const void *blend_params;           // unsupported, must be NULL
     const void *deinterlace_params;     // unsupported, must be NULL
     const void *distort_params;         // unsupported, must be NULL

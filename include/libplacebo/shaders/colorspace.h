@@ -153,6 +153,11 @@ struct pl_color_map_args {
 #define pl_color_map_args(...) (&(struct pl_color_map_args) { __VA_ARGS__ })
 
 // Replaces the colour by the feature the contrast-recovery stage works on: (I of IPT, 0, 0, 1)
+// Colour blindness simulation / correction in `csp`: linearize -> cone matrix -> delinearize
+// (reference shaders/colorspace.h, src/shaders/colorspace.c:2040-2064)
+PL_API void pl_shader_cone_distort(pl_shader sh, struct pl_color_space csp,
+                                   const struct pl_cone_params *params);
+
 PL_API void pl_shader_extract_features(pl_shader sh, struct pl_color_space csp);
 
 PL_API void pl_shader_color_map_ex(pl_shader sh, const struct pl_color_map_params *params,

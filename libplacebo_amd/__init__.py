@@ -245,6 +245,9 @@ class Shader:
         self._keep.append(lut)
         lib().pl_shader_custom_lut(self.sh, C.byref(lut), C.byref(state_obj.slot))
 
+    def cone_distort(self, csp, cone_params):
+        lib().pl_shader_cone_distort(self.sh, csp, C.byref(cone_params))
+
     def extract_features(self, csp):
         lib().pl_shader_extract_features(self.sh, csp)
 
@@ -425,6 +428,19 @@ def recreate_plane(gpu, data, tex=None):
         tex.ptr = t
         return out, tex
     return out, Texture(gpu, t)
+
+
+CONE_L, CONE_M, CONE_S = 1, 2, 4
+VISION = ("normal", "protanomaly", "protanopia", "deuteranomaly", "deuteranopia", "tritanomaly",
+          "tritanopia", "monochromacy", "achromatopsia")
+
+
+def cone_params(cones_or_preset, strength=0.0):
+    """pl_cone_params: a preset name from VISION (pl_vision_*) or (cones mask, strength)."""
+    if isinstance(cones_or_preset, str):
+        src = capi.ConeParams.in_dll(lib(), f"pl_vision_{cones_or_preset}")
+        return capi.ConeParams(src.cones, src.strength)
+    return capi.ConeParams(int(cones_or_preset), float(strength))
 
 
 LUT_UNKNOWN, LUT_NATIVE, LUT_NORMALIZED, LUT_CONVERSION = 0, 1, 2, 3

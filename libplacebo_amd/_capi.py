@@ -213,6 +213,10 @@ class CieXy(C.Structure):
     _fields_ = [("x", C.c_float), ("y", C.c_float)]
 
 
+class ConeParams(C.Structure):
+    _fields_ = [("cones", C.c_int), ("strength", C.c_float)]
+
+
 class RawPrimaries(C.Structure):
     _fields_ = [("red", CieXy), ("green", CieXy), ("blue", CieXy), ("white", CieXy)]
 
@@ -342,7 +346,7 @@ class RenderParams(C.Structure):
                 ("color_map_params", C.POINTER(ColorMapParams)),
                 ("dither_params", C.POINTER(DitherParams)),
                 ("error_diffusion", C.POINTER(ErrorDiffusionKernel)),
-                ("cone_params", C.c_void_p), ("blend_params", C.c_void_p),
+                ("cone_params", C.POINTER(ConeParams)), ("blend_params", C.c_void_p),
                 ("deinterlace_params", C.c_void_p), ("distort_params", C.c_void_p),
                 ("hooks", C.c_void_p), ("num_hooks", C.c_int), ("lut", C.POINTER(CustomLut)),
                 ("lut_type", C.c_int), ("background", C.c_int), ("border", C.c_int),
@@ -471,6 +475,8 @@ def declare(lib):
     fn("pl_hip_peak_buffer", vp, vp, P(C.c_size_t))
     fn("pl_shader_color_map_ex", None, vp, P(ColorMapParams), P(ColorMapArgs))
     fn("pl_shader_extract_features", None, vp, ColorSpace)
+    fn("pl_shader_cone_distort", None, vp, ColorSpace, P(ConeParams))
+    fn("pl_get_cone_matrix", Matrix3x3, P(ConeParams), P(RawPrimaries))
     fn("pl_lut_parse_cube", P(CustomLut), vp, C.c_char_p, C.c_size_t)
     fn("pl_lut_free", None, P(P(CustomLut)))
     fn("pl_shader_custom_lut", None, vp, P(CustomLut), P(vp))

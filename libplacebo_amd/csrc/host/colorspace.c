@@ -966,6 +966,84 @@ const pl_matrix3x3 pl_ipt_ipt2lms = {{
     { 1.0,  0.0326151, -0.676887 },
 }};
 
+/* ---- colour blindness simulation (pl_get_cone_matrix, colorspace.c:1397-1540) ------------- */
+
+const struct pl_cone_params pl_vision_normal        = { PL_CONE_NONE, 1.0 };
+const struct pl_cone_params pl_vision_protanomaly   = { PL_CONE_L,    0.5 };
+const struct pl_cone_params pl_vision_protanopia    = { PL_CONE_L,    0.0 };
+const struct pl_cone_params pl_vision_deuteranomaly = { PL_CONE_M,    0.5 };
+const struct pl_cone_params pl_vision_deuteranopia  = { PL_CONE_M,    0.0 };
+const struct pl_cone_params pl_vision_tritanomaly   = { PL_CONE_S,    0.5 };
+const struct pl_cone_params pl_vision_tritanopia    = { PL_CONE_S,    0.0 };
+const struct pl_cone_params pl_vision_monochromacy  = { PL_CONE_LM,   0.0 };
+const struct pl_cone_params pl_vision_achromatopsia = { PL_CONE_LMS,  0.0 };
+
+// Coefficient of cone `j` when cone `i` is rebuilt from cones j and k such that the colours
+// `p` (a primary) and `w` (white) keep their response:  (p_i - p_k w_i / w_k) / (p_j - p_k w_j / w_k)
+static float cone_coeff(const float p[3], const float w[3], int i, int j, int k)
+{
+    return (p[i] - p[k] * w[i] / w[k]) / (p[j] - p[k] * w[j] / w[k]);
+}
+
+pl_matrix3x3 pl_get_cone_matrix(const struct pl_cone_params *params,
+                                const struct pl_raw_primaries *prim)
+{
+    if (params->cones == PL_CONE_NONE)
+        return pl_matrix3x3_identity;
+
+    // LMS <- RGB (CAT16 cone space)
+    pl_matrix3x3 rgb2lms = m_cat16;
+    const pl_matrix3x3 rgb2xyz = pl_get_rgb2xyz_matrix(prim);
+    pl_matrix3x3_mul(&rgb2lms, &rgb2xyz);
+
+    // cone responses to red, blue and white
+    float red[3] = { 1.0, 0.0, 0.0 }, blue[3] = { 0.0, 0.0, 1.0 }, white[3] = { 1.0, 1.0, 1.0 };
+    pl_matrix3x3_apply(&rgb2lms, red);
+    pl_matrix3x3_apply(&rgb2lms, blue);
+    pl_matrix3x3_apply(&rgb2lms, white);
+
+    const float c = params->strength;
+    pl_matrix3x3 distort = pl_matrix3x3_identity;
+    const int cones = params->cones;
+    if (cones == PL_CONE_L || cones == PL_CONE_M || cones == PL_CONE_S) {
+        // one cone is (partly) rebuilt from the other two; neutral and the opposing primary
+        // (blue for L / M, red for S) are preserved
+        const int i = cones == PL_CONE_L ? 0 : cones == PL_CONE_M ? 1 : 2;
+        const int j = i == 0 ? 1 : 0, k = i == 2 ? 1 : 2;
+        const float *p = i == 2 ? red : blue;
+        const float a = cone_coeff(p, white, i, j, k), b = cone_coeff(p, white, i, k, j);
+        distort.m[i][i] = c;
+        distort.m[i][j] = (1.0 - c) * a;
+        distort.m[i][k] = (1.0 - c) * b;
+    } else if (cones == PL_CONE_LMS) {
+        // rods only: roughly a mix of L and M
+        const float w[3] = { 0.3605, 0.6415, -0.002 };
+        for (int i = 0; i < 3; i++) {
+            for (int j = 0; j < 3; j++) {
+                distort.m[i][j] = (1.0 - c) * w[j] * white[i] / white[j];
+                if (i == j)
+                    distort.m[i][j] += c;
+            }
+        }
+    } else {
+        // two cones missing: both follow the remaining one `r`, neutral is preserved
+        const int r = cones == PL_CONE_LM ? 2 : cones == PL_CONE_MS ? 0 : 1;
+        for (int i = 0; i < 3; i++) {
+            if (i == r)
+                continue;
+            distort.m[i][i] = c;
+            distort.m[i][r] = (1.0 - c) * (white[i] / white[r]);
+        }
+    }
+
+    // RGB <- LMS * distort * LMS <- RGB
+    pl_matrix3x3 out = rgb2lms;
+    pl_matrix3x3_invert(&out);
+    pl_matrix3x3_mul(&out, &distort);
+    pl_matrix3x3_mul(&out, &rgb2lms);
+    return out;
+}
+
 pl_matrix3x3 pl_get_color_mapping_matrix(const struct pl_raw_primaries *src,
                                          const struct pl_raw_primaries *dst,
                                          enum pl_rendering_intent intent)

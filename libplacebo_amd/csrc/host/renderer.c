@@ -1439,6 +1439,10 @@ static void pass_convert_colors(struct pass_state *pass)
     // all processing in independent alpha, to avoid nonlinear distortions
     pl_shader_set_alpha(sh, &img->repr, PL_ALPHA_INDEPENDENT);
 
+    // colour blindness simulation (:2194-2196)
+    if (params->cone_params)
+        pl_shader_cone_distort(sh, img->color, params->cone_params);
+
     // ---- PASS B: a same-frame peak measurement must finish before it is consumed ----
     // main LUT (:2199-2247): between the image's and the target's colour space
     bool need_conversion = true;
@@ -1844,11 +1848,11 @@ static void pass_uninit(struct pass_state *pass)
 
 static bool unsupported(pl_renderer rr, const struct pl_render_params *p)
 {
-    if (p->cone_params || p->blend_params || p->deinterlace_params || p->distort_params ||
+    if (p->blend_params || p->deinterlace_params || p->distort_params ||
         p->num_hooks)
     {
         RR_ERR(rr, "pl_render_params requests a stage outside this backend's hot path "
-               "(cone / blend / deinterlace / distort / hooks)");
+               "(blend / deinterlace / distort / hooks)");
         return true;
     }
     return false;
@@ -1996,7 +2000,7 @@ static uint64_t params_hash(const struct pl_render_params *params)
     HASH_PTR(upscaler); HASH_PTR(downscaler); HASH_PTR(plane_upscaler); HASH_PTR(plane_downscaler);
     HASH_PTR(frame_mixer); HASH_PTR(deband_params); HASH_PTR(sigmoid_params);
     HASH_PTR(color_adjustment); HASH_PTR(peak_detect_params); HASH_PTR(color_map_params);
-    HASH_PTR(dither_params); HASH_PTR(error_diffusion);
+    HASH_PTR(dither_params); HASH_PTR(error_diffusion); HASH_PTR(cone_params);
 #undef HASH_PTR
     return fnv1a(h, &p, sizeof(p));
 }

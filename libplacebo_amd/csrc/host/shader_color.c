@@ -282,6 +282,24 @@ void plh_fill_linearize(struct plh_op *op, const struct pl_color_space *csp)
     }
 }
 
+// pl_shader_cone_distort (colorspace.c:2040-2064): three recorded ops, the matrix is one AFFINE
+void pl_shader_cone_distort(pl_shader sh, struct pl_color_space csp,
+                            const struct pl_cone_params *params)
+{
+    if (!sh_require(sh, PL_SHADER_SIG_COLOR, 0, 0))
+        return;
+    if (!params || !params->cones)
+        return;
+
+    pl_color_space_infer(&csp);
+    pl_shader_linearize(sh, &csp);
+    const pl_transform3x3 tr = {
+        .mat = pl_get_cone_matrix(params, pl_raw_primaries_get(csp.primaries)),
+    };
+    op_affine(sh, &tr, "cone distortion");
+    pl_shader_delinearize(sh, &csp);
+}
+
 // pl_shader_extract_features (colorspace.c:1383-1404)
 void pl_shader_extract_features(pl_shader sh, struct pl_color_space csp)
 {

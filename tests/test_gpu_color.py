@@ -354,3 +354,42 @@ def test_detected_peak_feeds_color_map(gpu):
     # brighter, since the measured peak (~600 nits) is far below the mastering peak
     assert dynamic[..., :3].mean() > static[..., :3].mean()
     state.destroy(); t.destroy()
+
+
+@pytest.mark.parametrize("vision", [v for v in pl.VISION if v != "normal"])
+@pytest.mark.parametrize("trc", ["srgb", "pq"])
+def test_cone_distort_vs_oracle(gpu, vision, trc):
+    # pl_shader_cone_distort (shaders/colorspace.c:2040-2064) = linearize -> cone matrix ->
+    # delinearize; the matrix is pinned bit-exact against the reference in test_tier0_ref.py
+    csp = pl.color_space("bt2020" if trc == "pq" else "bt709", trc)
+    pl.lib().pl_color_space_infer(C.byref(csp))
+    mn, mx = nominal(csp)
+    luma = luma_coeffs(csp.primaries)
+    cp = pl.cone_params(vision)
+    m = pl.lib().pl_get_cone_matrix(C.byref(cp), pl.lib().pl_raw_primaries_get(csp.primaries))
+    mat = np.array([[m.m[i][j] for j in range(3)] for i in range(3)], np.float32)
+    rng = np.random.default_rng(11)
+    src = rng.random((32, 32, 4)).astype(np.float32)
+    got = run_ops(gpu, src, lambda sh: sh.cone_distort(csp, cp))
+    ref = orc.linearize(src.copy(), int(csp.transfer), mn, mx, luma)
+    lin = ref[..., :3].astype(np.float64)
+    ref[..., :3] = (lin @ mat.astype(np.float64).T).astype(np.float32)
+    ref = orc.delinearize(ref, int(csp.transfer), mn, mx, luma)
+    assert np.abs(got - src)[..., :3].max() > 0.01   # it did something
+    if trc == "pq":
+        # the PQ OETF has an unbounded slope at black, and the cone matrix cancels to near-black
+        # values: compare in linear light. The PQ EOTF alone is good to the reference's HDR
+        # epsilon (1e-4 of the range, test_transfer_vs_oracle); the matrix rows sum |coeffs| up
+        # to ~2.5 on top of it, hence 3e-4.
+        got, ref = (orc.linearize(x.copy(), int(csp.transfer), mn, mx, luma) for x in (got, ref))
+        assert np.abs(got - ref).max() <= 3e-4 * mx, np.abs(got - ref).max()
+    else:
+        # <= 2 LSB of 16 bit on the encoded signal (the matrix runs in f32 FMAs on the GPU)
+        assert np.abs(got - ref).max() <= 2 / 65535.0, np.abs(got - ref).max()
+
+
+def test_cone_distort_normal_is_noop(gpu):
+    csp = pl.color_space("bt709", "srgb")
+    src = ramp()
+    got = run_ops(gpu, src, lambda sh: sh.cone_distort(csp, pl.cone_params("normal")))
+    assert np.array_equal(got, src)

@@ -444,3 +444,34 @@ def test_planar_output_nv12_from_rgb(gpu, rr):
     assert 16 <= uv.min() and uv.max() <= 240
     for t in (src, ty, tuv):
         t.destroy()
+
+
+@pytest.mark.parametrize("vision", ["deuteranopia", "tritanomaly", "achromatopsia"])
+def test_cone_params_match_manual_composition(gpu, rr, vision):
+    """pl_render_params.cone_params (renderer.c:2194-2196): colour blindness simulation in the
+    image's colour space, after the alpha conversion and before the colour mapping."""
+    w, h = 96, 64
+    img = util.chirp_rgba16(w, h)
+    src = gpu.tex_create(w, h, "rgba16", img)
+    dst = gpu.tex_create(w, h, "rgba16")
+    csp = pl.color_space("bt709", "srgb")
+    image, target = pl.frame(src, components=3, color=csp), pl.frame(dst, color=csp)
+    cp = pl.cone_params(vision)
+    assert rr.render(image, target, pl.render_params("fast", cone_params=cp)), gpu.messages[-4:]
+    assert rr.errors() == 0
+    got = dst.download()
+    assert rr.render(image, target, pl.render_params("fast"))
+    plain = dst.download()
+    assert np.abs(got.astype(np.int64) - plain)[..., :3].max() > 500
+
+    out = gpu.tex_create(w, h, "rgba16")
+    csp_i = pl.color_space("bt709", "srgb")
+    pl.lib().pl_color_space_infer(C.byref(csp_i))
+    s = gpu.begin()
+    assert s.sample("direct", src, components=3)
+    s.cone_distort(csp_i, cp)
+    assert s.finish(out)
+    ref = out.download()
+    assert np.array_equal(got, ref), util.diff_stats(got, ref)
+    for t in (src, dst, out):
+        t.destroy()

@@ -188,3 +188,25 @@ def test_gamut_map_3dlut(libs, name):
             lib.pl_gamut_map_generate(o.ctypes.data_as(C.c_void_p), C.byref(p))
             out.append(o)
         assert bits_equal(out[0], out[1]), (name, pi, po)
+
+
+def test_cone_matrix(libs):
+    # pl_get_cone_matrix (colorspace.c:1408-1540): all presets and a strength sweep over every
+    # cone mask, on every primaries set — the float evaluation order is part of the contract
+    ref, our = libs
+    for lib in (ref, our):
+        lib.pl_get_cone_matrix.restype = capi.Matrix3x3
+    cases = []
+    for name in ("normal", "protanomaly", "protanopia", "deuteranomaly", "deuteranopia",
+                 "tritanomaly", "tritanopia", "monochromacy", "achromatopsia"):
+        a = capi.ConeParams.in_dll(ref, f"pl_vision_{name}")
+        b = capi.ConeParams.in_dll(our, f"pl_vision_{name}")
+        assert (a.cones, a.strength) == (b.cones, b.strength), name
+        cases.append((a.cones, a.strength))
+    cases += [(m, s) for m in range(8) for s in (0.0, 0.25, 0.7, 1.0, 1.5, 2.0)]
+    for p in range(1, 18):
+        for cones, strength in cases:
+            cp = capi.ConeParams(cones, strength)
+            a = ref.pl_get_cone_matrix(C.byref(cp), ref.pl_raw_primaries_get(p))
+            b = our.pl_get_cone_matrix(C.byref(cp), our.pl_raw_primaries_get(p))
+            assert bits_equal(m3(a), m3(b)), (p, cones, strength)
