@@ -150,6 +150,20 @@ PL_API extern const struct pl_render_params pl_render_high_quality_params;
 
 #define PL_MAX_PLANES 4
 
+// Field of an interlaced picture (reference shaders/deinterlacing.h:35-52)
+enum pl_field {
+    PL_FIELD_NONE = 0, // progressive
+    PL_FIELD_EVEN,     // "top" field, even rows
+    PL_FIELD_ODD,      // "bottom" field, odd rows
+    PL_FIELD_TOP = PL_FIELD_EVEN,
+    PL_FIELD_BOTTOM = PL_FIELD_ODD,
+};
+
+static inline enum pl_field pl_field_other(enum pl_field field)
+{
+    return field == PL_FIELD_EVEN ? PL_FIELD_ODD : field == PL_FIELD_ODD ? PL_FIELD_EVEN : field;
+}
+
 struct pl_plane {
     pl_tex texture;
     enum pl_tex_address_mode address_mode;
@@ -177,6 +191,12 @@ struct pl_frame {
     pl_rect2df crop;          // 0 = whole frame; flipped rects flip the image
     pl_rotation rotation;     // clockwise, in multiples of 90 degrees (common.h)
     void *user_data;
+
+    // Interlacing description, filled in by pl_queue (utils/frame_queue.h). This backend has no
+    // deinterlacer (`deinterlace_params` is refused), so the renderer shows such frames woven.
+    enum pl_field field;
+    enum pl_field first_field;
+    const struct pl_frame *prev, *next;
 };
 
 // Set plane shifts from a chroma sample location (applies to subsampled planes)

@@ -485,6 +485,84 @@ def frame_mix(frames, signatures, timestamps, vsync_duration):
     return m
 
 
+QUEUE_OK, QUEUE_EOF, QUEUE_MORE, QUEUE_ERR = 0, 1, 2, -1
+
+
+class Queue:
+    """pl_queue (utils/frame_queue.h): feed it (pl_frame, pts) pairs, ask it for the pl_frame_mix
+    of a vsync. Frames are handed over as ready pl_frame structs ("pass-through" map)."""
+
+    def __init__(self, gpu):
+        self.gpu = gpu
+        self.q = C.c_void_p(lib().pl_queue_create(gpu.gpu))
+        assert self.q
+        self.frames = {}       # frame_data id -> Frame
+        self.unmapped = []     # ids the queue is done with
+        self._next = 1
+        self._map = capi.QUEUE_MAP_FN(self._on_map)
+        self._unmap = capi.QUEUE_UNMAP_FN(self._on_unmap)
+        self._discard = capi.QUEUE_DISCARD_FN(self._on_discard)
+
+    def _on_map(self, gpu, tex, src, out):
+        C.memmove(out, C.byref(self.frames[src.contents.frame_data]), C.sizeof(capi.Frame))
+        return True
+
+    def _on_unmap(self, gpu, frame, src):
+        self.unmapped.append(src.contents.frame_data)
+
+    def _on_discard(self, src):
+        self.unmapped.append(src.contents.frame_data)
+
+    def push(self, frame, pts, duration=0.0, first_field=0, block_ns=None):
+        """pl_queue_push / pl_queue_push_block; frame None = EOF. Returns the frame's id."""
+        if frame is None:
+            lib().pl_queue_push(self.q, None)
+            return None
+        ident, self._next = self._next, self._next + 1
+        self.frames[ident] = frame
+        src = capi.SourceFrame(pts=pts, duration=duration, first_field=first_field,
+                               frame_data=ident, map=self._map, unmap=self._unmap,
+                               discard=self._discard)
+        if block_ns is None:
+            lib().pl_queue_push(self.q, C.byref(src))
+        elif not lib().pl_queue_push_block(self.q, block_ns, C.byref(src)):
+            del self.frames[ident]
+            return None
+        return ident
+
+    def update(self, pts, radius=0.0, vsync_duration=0.0, drift_compensation=1e-3,
+               interpolation_threshold=1e-6, timeout=0):
+        """pl_queue_update -> (status, pl_frame_mix); the mix is valid until the next call."""
+        p = capi.QueueParams(pts=pts, radius=radius, vsync_duration=vsync_duration,
+                             drift_compensation=drift_compensation,
+                             interpolation_threshold=interpolation_threshold, timeout=timeout)
+        mix = capi.FrameMix()
+        return lib().pl_queue_update(self.q, C.byref(mix), C.byref(p)), mix
+
+    def reset(self):
+        lib().pl_queue_reset(self.q)
+
+    def num_frames(self):
+        return lib().pl_queue_num_frames(self.q)
+
+    def estimate_fps(self):
+        return lib().pl_queue_estimate_fps(self.q)
+
+    def estimate_vps(self):
+        return lib().pl_queue_estimate_vps(self.q)
+
+    def destroy(self):
+        lib().pl_queue_destroy(C.byref(self.q))
+
+
+def frame_mix_radius(params):
+    """pl_frame_mix_radius (a static inline of renderer.h): the mixer kernel's radius, 0 for
+    oversampling / no mixer"""
+    if not params.frame_mixer or not params.frame_mixer.contents.kernel:
+        return 0.0
+    return params.frame_mixer.contents.kernel.contents.radius
+
+
 def render_params(preset="fast", **kw):
     """pl_render_{fast,default,high_quality}_params with overrides; pointer fields accept
     ctypes structs (kept alive on the returned object)."""

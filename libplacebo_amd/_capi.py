@@ -325,13 +325,38 @@ class Frame(C.Structure):
                 ("acquire", C.c_void_p), ("release", C.c_void_p),
                 ("repr", ColorRepr), ("color", ColorSpace),
                 ("lut", C.POINTER(CustomLut)), ("lut_type", C.c_int), ("crop", Rect2df),
-                ("rotation", C.c_int), ("user_data", C.c_void_p)]
+                ("rotation", C.c_int), ("user_data", C.c_void_p),
+                ("field", C.c_int), ("first_field", C.c_int),
+                ("prev", C.c_void_p), ("next", C.c_void_p)]
 
 
 class FrameMix(C.Structure):
     _fields_ = [("num_frames", C.c_int), ("frames", C.POINTER(C.POINTER(Frame))),
                 ("signatures", C.POINTER(C.c_uint64)), ("timestamps", C.POINTER(C.c_float)),
                 ("vsync_duration", C.c_float)]
+
+
+class SourceFrame(C.Structure):
+    """struct pl_source_frame (utils/frame_queue.h)"""
+
+
+QUEUE_MAP_FN = C.CFUNCTYPE(C.c_bool, C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(SourceFrame),
+                           C.POINTER(Frame))
+QUEUE_UNMAP_FN = C.CFUNCTYPE(None, C.c_void_p, C.POINTER(Frame), C.POINTER(SourceFrame))
+QUEUE_DISCARD_FN = C.CFUNCTYPE(None, C.POINTER(SourceFrame))
+SourceFrame._fields_ = [("pts", C.c_double), ("duration", C.c_float), ("first_field", C.c_int),
+                        ("frame_data", C.c_void_p), ("map", QUEUE_MAP_FN),
+                        ("unmap", QUEUE_UNMAP_FN), ("discard", QUEUE_DISCARD_FN)]
+
+
+class QueueParams(C.Structure):
+    """struct pl_queue_params (utils/frame_queue.h)"""
+
+
+QUEUE_GET_FN = C.CFUNCTYPE(C.c_int, C.POINTER(SourceFrame), C.POINTER(QueueParams))
+QueueParams._fields_ = [("pts", C.c_double), ("radius", C.c_float), ("vsync_duration", C.c_float),
+                        ("drift_compensation", C.c_float), ("interpolation_threshold", C.c_float),
+                        ("timeout", C.c_uint64), ("get_frame", QUEUE_GET_FN), ("priv", C.c_void_p)]
 
 
 class RenderParams(C.Structure):
@@ -449,6 +474,17 @@ def declare(lib):
     fn("pl_render_image", C.c_bool, vp, P(Frame), P(Frame), P(RenderParams))
     fn("pl_frames_infer", None, vp, P(Frame), P(Frame))
     fn("pl_render_image_mix", C.c_bool, vp, P(FrameMix), P(Frame), P(RenderParams))
+    fn("pl_queue_create", vp, vp)
+    fn("pl_queue_destroy", None, P(vp))
+    fn("pl_queue_reset", None, vp)
+    fn("pl_queue_push", None, vp, P(SourceFrame))
+    fn("pl_queue_push_block", C.c_bool, vp, C.c_uint64, P(SourceFrame))
+    fn("pl_queue_update", C.c_int, vp, P(FrameMix), P(QueueParams))
+    fn("pl_queue_estimate_fps", C.c_float, vp)
+    fn("pl_queue_estimate_vps", C.c_float, vp)
+    fn("pl_queue_num_frames", C.c_int, vp)
+    fn("pl_queue_pts_offset", C.c_double, vp)
+    fn("pl_queue_peek", C.c_bool, vp, C.c_int, P(SourceFrame))
     fn("pl_frames_infer_mix", None, vp, P(FrameMix), P(Frame), P(Frame))
     fn("pl_frame_mix_current", P(Frame), P(FrameMix))
     fn("pl_frame_mix_nearest", P(Frame), P(FrameMix))

@@ -40,6 +40,9 @@ done
 # pure helpers of the plane-upload utility (GPU entry points stubbed by ref_shim.c)
 gcc $CFLAGS -c "$REF/src/utils/upload.c" -o "$OUT/obj/utils_upload.o"
 OBJS="$OBJS $OUT/obj/utils_upload.o"
+# the frame queue is host-only logic (tests/test_frame_queue.py replays traces through it)
+gcc $CFLAGS -c "$REF/src/utils/frame_queue.c" -o "$OUT/obj/utils_frame_queue.o"
+OBJS="$OBJS $OUT/obj/utils_frame_queue.o"
 g++ -std=c++20 -O2 -fPIC -w -DPL_STATIC -I$OUT/gen -I$REF/src/include -I$REF/src \
     -c "$REF/src/convert.cc" -o "$OUT/obj/convert.o"
 # ref_shim.c is OUR glue (exposes a few internals as plain C-ABI for ctypes)

@@ -1,0 +1,385 @@
+"""pl_queue (include/libplacebo/utils/frame_queue.h) against the reference's own
+src/utils/frame_queue.c, compiled as it lies into oracle/_ref/libplref.so: identical random
+push / update / reset traces are replayed through both and every observable is compared —
+status codes, mix signatures, timestamps (bit for bit), which picture each mix entry shows, its
+field / neighbour references, the order of map / unmap / discard callbacks, rate estimates, pts
+offset, queue length and peeked frames. Plus the reference's own scenario (src/tests/gpu_tests.c
+:1500-1586, the queue part of pl_render_tests) with its REQUIREs, and a decoder-thread run.
+
+The queue is host-only logic: these tests need no GPU (a zeroed pl_gpu is enough — the traces'
+`map` callbacks create no textures)."""
+import ctypes as C
+import random
+import struct
+
+import pytest
+
+import orc
+from libplacebo_amd import _capi as capi
+
+pytestmark = pytest.mark.skipif(not orc.have_ref(), reason="oracle/_ref not built")
+
+OK, EOF, MORE, ERR = 0, 1, 2, -1
+
+
+class SourceFrame(C.Structure):
+    pass
+
+
+MAP_FN = C.CFUNCTYPE(C.c_bool, C.c_void_p, C.c_void_p, C.POINTER(SourceFrame), C.c_void_p)
+UNMAP_FN = C.CFUNCTYPE(None, C.c_void_p, C.c_void_p, C.POINTER(SourceFrame))
+DISCARD_FN = C.CFUNCTYPE(None, C.POINTER(SourceFrame))
+SourceFrame._fields_ = [("pts", C.c_double), ("duration", C.c_float), ("first_field", C.c_int),
+                        ("frame_data", C.c_void_p), ("map", MAP_FN), ("unmap", UNMAP_FN),
+                        ("discard", DISCARD_FN)]
+
+
+class QueueParams(C.Structure):
+    pass
+
+
+GET_FN = C.CFUNCTYPE(C.c_int, C.POINTER(SourceFrame), C.POINTER(QueueParams))
+QueueParams._fields_ = [("pts", C.c_double), ("radius", C.c_float), ("vsync_duration", C.c_float),
+                        ("drift_compensation", C.c_float), ("interpolation_threshold", C.c_float),
+                        ("timeout", C.c_uint64), ("get_frame", GET_FN), ("priv", C.c_void_p)]
+
+
+class Mix(C.Structure):
+    _fields_ = [("num_frames", C.c_int), ("frames", C.POINTER(C.c_void_p)),
+                ("signatures", C.POINTER(C.c_uint64)), ("timestamps", C.POINTER(C.c_float)),
+                ("vsync_duration", C.c_float)]
+
+
+def f32bits(x):
+    return struct.unpack("<I", struct.pack("<f", x))[0]
+
+
+class Side:
+    """One implementation of the queue plus a log of everything it did."""
+
+    def __init__(self, lib, layout, gpu):
+        self.lib, self.layout, self.gpu = lib, layout, gpu
+        for name, res in (("pl_queue_create", C.c_void_p), ("pl_queue_update", C.c_int),
+                          ("pl_queue_estimate_fps", C.c_float), ("pl_queue_estimate_vps", C.c_float),
+                          ("pl_queue_num_frames", C.c_int), ("pl_queue_pts_offset", C.c_double),
+                          ("pl_queue_peek", C.c_bool), ("pl_queue_push_block", C.c_bool),
+                          ("pl_queue_push", None), ("pl_queue_reset", None),
+                          ("pl_queue_destroy", None)):
+            getattr(lib, name).restype = res
+        self.events = []
+        self.fail_map = set()
+        self.pending = []       # frames the get_frame callback will hand out
+        self.pull_eof = False
+        self.map_cb = MAP_FN(self._map)
+        self.unmap_cb = UNMAP_FN(self._unmap)
+        self.discard_cb = DISCARD_FN(self._discard)
+        self.get_cb = GET_FN(self._get)
+        self.q = C.c_void_p(lib.pl_queue_create(C.c_void_p(gpu)))
+        assert self.q
+
+    # --- callbacks
+    def _map(self, gpu, tex, src, out_frame):
+        ident = src.contents.frame_data
+        self.events.append(("map", ident))
+        if ident in self.fail_map:
+            return False
+        size, user_data = self.layout[0], self.layout[1]
+        C.memset(out_frame, 0, size)
+        C.c_void_p.from_address(out_frame + user_data).value = ident
+        return True
+
+    def _unmap(self, gpu, frame, src):
+        self.events.append(("unmap", src.contents.frame_data))
+
+    def _discard(self, src):
+        self.events.append(("discard", src.contents.frame_data))
+
+    def _get(self, out, params):
+        if self.pending:
+            out[0] = self.source(*self.pending.pop(0))
+            return OK
+        return EOF if self.pull_eof else MORE
+
+    # --- operations
+    def source(self, ident, pts, duration, field, with_unmap=True, with_discard=True):
+        s = SourceFrame(pts=pts, duration=duration, first_field=field, frame_data=ident,
+                        map=self.map_cb)
+        if with_unmap:
+            s.unmap = self.unmap_cb
+        if with_discard:
+            s.discard = self.discard_cb
+        return s
+
+    def push(self, *a, **kw):
+        s = self.source(*a, **kw)
+        self.lib.pl_queue_push(self.q, C.byref(s))
+
+    def push_eof(self):
+        self.lib.pl_queue_push(self.q, None)
+
+    def user_data(self, frame_ptr):
+        return C.c_void_p.from_address(frame_ptr + self.layout[1]).value if frame_ptr else None
+
+    def update(self, want_mix=True, pull=False, **kw):
+        kw.setdefault("drift_compensation", 1e-3)
+        kw.setdefault("interpolation_threshold", 1e-6)
+        p = QueueParams(**kw)
+        if pull:
+            p.get_frame = self.get_cb
+        mix = Mix()
+        st = self.lib.pl_queue_update(self.q, C.byref(mix) if want_mix else None, C.byref(p))
+        entries = []
+        if want_mix and st != ERR:
+            _, _, o_field, o_first, o_prev, o_next = self.layout
+            for i in range(mix.num_frames):
+                f = mix.frames[i]
+                entries.append((mix.signatures[i], f32bits(mix.timestamps[i]), self.user_data(f),
+                                C.c_int.from_address(f + o_field).value,
+                                C.c_int.from_address(f + o_first).value,
+                                self.user_data(C.c_void_p.from_address(f + o_prev).value),
+                                self.user_data(C.c_void_p.from_address(f + o_next).value)))
+            entries.append(("vsync", f32bits(mix.vsync_duration) if mix.num_frames else 0))
+        return st, entries
+
+    def state(self):
+        lib, q = self.lib, self.q
+        n = lib.pl_queue_num_frames(q)
+        peeks = []
+        for i in range(-1, n + 1):
+            s = SourceFrame()
+            ok = lib.pl_queue_peek(q, i, C.byref(s))
+            peeks.append((ok, s.pts if ok else None, s.frame_data if ok else None,
+                          s.first_field if ok else None))
+        return (n, f32bits(lib.pl_queue_estimate_fps(q)), f32bits(lib.pl_queue_estimate_vps(q)),
+                lib.pl_queue_pts_offset(q), tuple(peeks))
+
+    def reset(self):
+        self.lib.pl_queue_reset(self.q)
+
+    def destroy(self):
+        self.lib.pl_queue_destroy(C.byref(self.q))
+        assert not self.q
+
+
+@pytest.fixture()
+def sides():
+    ref = orc.ref()
+    ref.plref_fake_gpu.restype = C.c_void_p
+    lay = (C.c_int * 6)()
+    ref.plref_frame_layout(lay)
+    our = C.CDLL(capi.LIB_PATH)
+    F = capi.Frame
+    our_layout = (C.sizeof(F), F.user_data.offset, F.field.offset, F.first_field.offset,
+                  F.prev.offset, F.next.offset)
+    fake = C.create_string_buffer(1 << 14)  # a zeroed pl_gpu: the queue only reads `log`
+    a = Side(ref, tuple(lay), ref.plref_fake_gpu())
+    b = Side(our, our_layout, C.addressof(fake))
+    b._keep = fake
+    yield a, b
+    a.destroy(); b.destroy()
+    assert a.events == b.events
+
+
+def both(sides, fn):
+    ra, rb = fn(sides[0]), fn(sides[1])
+    assert ra == rb, (ra, rb)
+    assert sides[0].events == sides[1].events
+    assert sides[0].state() == sides[1].state()
+    return ra
+
+
+def test_struct_layout_matches_the_header():
+    # the ctypes mirror above must be the header's struct pl_source_frame / pl_queue_params
+    assert C.sizeof(SourceFrame) == 48 and SourceFrame.frame_data.offset == 16
+    assert C.sizeof(QueueParams) == 48 and QueueParams.get_frame.offset == 32
+
+
+def test_reference_scenario(sides):
+    """gpu_tests.c:1500-1586: 20 frames at 24 fps for a 60 Hz display; pushed out of order
+    (blocking push with a 1 ns timeout, plain push when refused) with a delayed EOF under a
+    radius-2 mixer; pulled through get_frame with oversampling; then interlaced."""
+    n, frame, vsync = 20, 1.0 / 24.0, 1.0 / 60.0
+    order = [i if i <= 10 else n + 10 - i for i in range(n)]
+
+    def push_anyway(s, i):
+        src = s.source(i + 1, i * frame, frame, 0)
+        if not s.lib.pl_queue_push_block(s.q, C.c_uint64(1), C.byref(src)):
+            s.lib.pl_queue_push(s.q, C.byref(src))
+    for i in order:
+        both(sides, lambda s: push_anyway(s, i))
+
+    pts, sent_eof = 0.0, False
+    while True:
+        st, mix = both(sides, lambda s: s.update(pts=pts, radius=2.0, vsync_duration=vsync))
+        if st == EOF:
+            break
+        if st == MORE:
+            assert pts > 0.0 and not sent_eof            # REQUIRE_CMP(qparams.pts, >, 0.0f)
+            both(sides, lambda s: s.push_eof())
+            sent_eof = True
+            continue
+        assert st == OK
+        pts += vsync
+    assert sent_eof
+
+    both(sides, lambda s: s.reset())
+    for s in sides:
+        s.pending = [(100 + i, i * frame, frame, 0) for i in range(n)]
+        s.pull_eof = True
+    pts = 0.0
+    while True:
+        st, mix = both(sides, lambda s: s.update(pts=pts, pull=True, radius=0.0,
+                                                 vsync_duration=vsync))
+        if st == EOF:
+            break
+        assert st == OK and len(mix) - 1 <= 2            # REQUIRE_CMP(mix.num_frames, <=, 2)
+        pts += vsync
+
+    both(sides, lambda s: s.reset())                     # "large PTS jump": the source is dry
+    assert both(sides, lambda s: s.update(pts=pts, pull=True, vsync_duration=vsync))[0] == EOF
+
+    both(sides, lambda s: s.reset())
+    for i in order:
+        both(sides, lambda s: s.push(200 + i, i * frame, frame, 1))
+    both(sides, lambda s: s.push_eof())
+    pts, fields = 0.0, set()
+    while True:
+        st, mix = both(sides, lambda s: s.update(pts=pts, radius=0.0, vsync_duration=vsync))
+        if st == EOF:
+            break
+        assert st == OK
+        fields |= {e[3] for e in mix[:-1]}
+        pts += vsync
+    assert fields == {1, 2}
+
+
+def test_decoder_thread(sides):
+    """A decoder thread feeding through pl_queue_push_block while the render loop updates with a
+    timeout: no deadlock, nothing lost, nothing mapped twice (this implementation only — thread
+    interleavings are not reproducible across two libraries)."""
+    import threading
+    s = sides[1]
+    n, frame, vsync = 120, 1.0 / 50.0, 1.0 / 60.0
+
+    def decoder():
+        for i in range(n):
+            src = s.source(i + 1, i * frame, frame, 0)
+            while not s.lib.pl_queue_push_block(s.q, C.c_uint64(20_000_000), C.byref(src)):
+                pass
+        s.lib.pl_queue_push(s.q, None)
+    th = threading.Thread(target=decoder)
+    th.start()
+    pts, updates, shown = 0.0, 0, set()
+    while updates < 100000:
+        updates += 1
+        st, mix = s.update(pts=pts, radius=1.0, vsync_duration=vsync, timeout=50_000_000)
+        if st == EOF:
+            break
+        assert st in (OK, MORE)
+        if st == OK:
+            shown |= {e[2] for e in mix[:-1]}
+            pts += vsync
+    th.join(timeout=30)
+    assert not th.is_alive() and st == EOF
+    assert shown == set(range(1, n + 1))
+    maps = [i for k, i in s.events if k == "map"]
+    assert sorted(maps) == list(range(1, n + 1))
+    sides[0].events = list(s.events)    # (the fixture compares both logs; only one side ran)
+    s.lib.pl_queue_reset(s.q)
+    sides[0].events = list(s.events)
+
+
+@pytest.mark.parametrize("seed", range(40))
+def test_random_traces(sides, seed):
+    rng = random.Random(seed)
+    interlaced = seed % 4 == 1          # every frame interlaced
+    mixed = seed % 4 == 2               # some
+    fps = rng.choice([23.976, 24.0, 25.0, 29.97, 50.0, 59.94, 120.0])
+    vps = rng.choice([24.0, 48.0, 59.94, 60.0, 75.0, 144.0, fps, fps * 1.0000001])
+    radius = rng.choice([0.0, 0.0, 1.0, 1.0, 2.0, 3.0])
+    threshold = rng.choice([1e-6, 1e-6, 0.01, 0.1])
+    jitter = rng.choice([0.0, 0.0, 1e-4, 2e-3])
+    pull = seed % 5 == 3
+    give_duration = rng.random() < 0.5
+    ident, next_pts, t = 1, 0.0, 0.0
+    eof_sent = False
+    if rng.random() < 0.2:
+        sides[0].fail_map.add(7); sides[1].fail_map.add(7)
+
+    def new_frame():
+        nonlocal ident, next_pts
+        field = 0
+        if interlaced or (mixed and rng.random() < 0.5):
+            field = rng.choice([1, 2])
+        args = (ident, next_pts, (1 / fps if give_duration else 0.0), field,
+                rng.random() < 0.8, rng.random() < 0.8)
+        ident += 1
+        step = 1 / fps
+        if rng.random() < 0.03:
+            step *= rng.choice([0.0, 3.0, 15.0])     # repeated pts, gap, discontinuity
+        next_pts += step
+        return args
+
+    if seed % 2 and not pull:
+        for _ in range(rng.randrange(5, 40)):       # a decoder running ahead
+            args = new_frame()
+            both(sides, lambda s: s.push(*args))
+
+    for _ in range(rng.randrange(150, 400)):
+        op = rng.random()
+        if op < (0.38 if seed % 3 else 0.5) and not eof_sent:
+            args = new_frame()
+            if pull:
+                for s in sides:
+                    s.pending.append(args)
+            else:
+                both(sides, lambda s: s.push(*args))
+        elif op < 0.41 and not eof_sent and ident > 12:
+            eof_sent = True
+            if pull:
+                for s in sides:
+                    s.pull_eof = True
+            else:
+                both(sides, lambda s: s.push_eof())
+        elif op < 0.43:
+            both(sides, lambda s: s.reset())
+            for s in sides:
+                s.pending.clear(); s.pull_eof = False
+            ident += 100
+            next_pts, t, eof_sent = 0.0, 0.0, False
+        elif op < 0.45:
+            args = new_frame()                      # push after EOF / blocking push, no wait
+            both(sides, lambda s: s.lib.pl_queue_push_block(s.q, C.c_uint64(0),
+                                                            C.byref(s.source(*args))))
+        else:
+            pts = t + rng.uniform(-jitter, jitter) if t else 0.0
+            kw = dict(pts=max(pts, 0.0), radius=radius, interpolation_threshold=threshold,
+                      vsync_duration=(1 / vps if rng.random() < 0.7 else 0.0),
+                      drift_compensation=rng.choice([1e-3, 1e-3, 0.0]))
+            want_mix = rng.random() < 0.93
+            st, _ = both(sides, lambda s: s.update(want_mix=want_mix, pull=pull, **kw))
+            if rng.random() < 0.02:
+                t += 1.5                            # display paused
+            elif rng.random() < 0.02:
+                t = max(0.0, t - 2 / vps)           # stepped back
+            else:
+                t += 1 / vps
+
+
+def test_blocking_push_and_timeouts(sides):
+    # a blocking push refuses (times out) once two not yet mapped frames wait; an update with a
+    # timeout and no frames returns MORE after it
+    for s in sides:
+        for i in range(2):
+            assert s.lib.pl_queue_push_block(s.q, C.c_uint64(1000000), C.byref(s.source(i + 1, i / 25, 0.04, 0)))
+        assert not s.lib.pl_queue_push_block(s.q, C.c_uint64(2000000),
+                                             C.byref(s.source(3, 2 / 25, 0.04, 0)))
+    assert sides[0].state() == sides[1].state()
+    both(sides, lambda s: s.update(pts=0.0, radius=0.0, vsync_duration=1 / 60))
+    # the first two are mapped now: room again
+    for s in sides:
+        assert s.lib.pl_queue_push_block(s.q, C.c_uint64(2000000),
+                                         C.byref(s.source(3, 2 / 25, 0.04, 0)))
+    st, _ = both(sides, lambda s: s.update(pts=1.0, radius=0.0, vsync_duration=1 / 60,
+                                           timeout=3000000))
+    assert st == MORE
