@@ -101,7 +101,7 @@ struct pl_color_map_params {
     const struct pl_gamut_map_function *gamut_mapping;
     struct pl_gamut_map_constants gamut_constants;
     int lut3d_size[3];
-    bool lut3d_tricubic;        // not supported yet (falls back to trilinear)
+    bool lut3d_tricubic;        // cubic B-spline instead of trilinear 3-D LUT lookup
     bool gamut_expansion;
 
     const struct pl_tone_map_function *tone_mapping_function;

@@ -26,6 +26,11 @@ const char *plh_strerror(int err)
 {
     if (err == -1000)
         return "LDS tile does not fit";
+    if (err == -1003)
+        return "frame mixing ops need a plain (nearest / bilinear) sampler";
+    if (err == -1004)
+        return "lut3d_tricubic: the colour map must be a pass of its own (plain sampler, no "
+               "peak detection / mixing in the same shader)";
     return hipGetErrorString((hipError_t) (err < 0 ? -err : err));
 }
 

@@ -78,7 +78,8 @@ DEV lin_fp lin_footprint(const plh_view &v, int mode, float px, float py)
 // SIMPLE: the sampler is none / nearest / bilinear (the hot cases); the closed-form fast
 // samplers are only instantiated in the !SIMPLE variants, whose register budget they set.
 // CH: rows per cell (cells are 2 wide): 2x2 amortises most, 2x1 needs fewer registers
-template <bool LITE, bool SIMPLE, int CH, bool MIX = false>
+// CUBIC: the colour map's lut3d_tricubic lookup (only this kernel carries it)
+template <bool LITE, bool SIMPLE, int CH, bool MIX = false, bool CUBIC = false>
 __global__ __launch_bounds__(PASS_BW * PASS_BH)
 void k_pass_generic(const plh_pass p_)
 {
@@ -181,7 +182,7 @@ void k_pass_generic(const plh_pass p_)
                 p.out_scale[1] * (float) idy < 1.0f && sx[q] >= 0 && sy[q] >= 0 &&
                 sx[q] < p.dst.w && sy[q] < p.dst.h;
     }
-    apply_ops_n<NPX, false, LITE, MIX>(c, p.ops, 0, p.num_ops, fcs);
+    apply_ops_n<NPX, false, LITE, MIX, CUBIC>(c, p.ops, 0, p.num_ops, fcs);
     plh_store_n<NPX>(p.dst, sx, sy, ok, c, p.nt_store);
     }
 }
@@ -427,6 +428,20 @@ extern "C" int plh_launch_pass(plh_stream stream_, const struct plh_pass *pass)
         fprintf(stderr, "\n");
     }
 
+    // lut3d_tricubic lives in one variant of the generic kernel: such a colour map must be its
+    // own pass (the renderer arranges that; a hand-built shader samples from an FBO first)
+    bool cubic = false;
+    for (int i = 0; i < pass->num_ops; i++)
+        cubic |= pass->ops[i].kind == PLH_OP_GAMUT_LUT && pass->ops[i].f[3] != 0.0f;
+    if (cubic) {
+        bool alone = pass->s.type == PLH_SAMPLE_NONE || pass->s.type == PLH_SAMPLE_NEAREST ||
+                     pass->s.type == PLH_SAMPLE_BILINEAR;
+        for (int i = 0; i < pass->num_ops; i++)
+            alone &= pass->ops[i].kind != PLH_OP_PEAK_DETECT && pass->ops[i].kind != PLH_OP_MIX_ADD;
+        if (!alone)
+            return -1004;
+    }
+
     switch (pass->s.type) {
     case PLH_SAMPLE_POLAR:
         return plh_launch_polar(stream, pass);
@@ -474,14 +489,16 @@ extern "C" int plh_launch_pass(plh_stream stream_, const struct plh_pass *pass)
     bool mixing = false;
     for (int i = 0; i < pass->num_ops; i++)
         mixing |= pass->ops[i].kind == PLH_OP_MIX_ADD;
-    if (mixing)
+    if (mixing || cubic)
         ch = 1;
     const int cells_w = (pass->width + pass->cell_padx + 1) / 2;
     const int cells_h = ch == 2 ? (pass->height + pass->cell_pady + 1) / 2 : pass->height;
     const int bh = PASS_BH * PASS_ITERS;
     const dim3 grid((cells_w + PASS_BW - 1) / PASS_BW, (cells_h + bh - 1) / bh);
 #define LAUNCH(L, S, C) hipLaunchKernelGGL((k_pass_generic<L, S, C>), grid, block, 0, stream, *pass)
-    if (mixing) {
+    if (cubic) {
+        hipLaunchKernelGGL((k_pass_generic<false, true, 1, false, true>), grid, block, 0, stream, *pass);
+    } else if (mixing) {
         // frame mixing: the one variant that carries the second colour register
         if (!simple)
             return -1003;

@@ -1416,6 +1416,15 @@ static void pass_convert_colors(struct pass_state *pass)
     const struct pl_frame *image = &pass->image, *target = &pass->target;
     pl_renderer rr = pass->rr;
     struct img *img = &pass->img;
+
+    // lut3d_tricubic exists in one variant of the generic pass kernel only (k_pass.hip): give the
+    // colour conversion a pass of its own instead of fusing it into the pending sampler
+    if (params->color_map_params && params->color_map_params->lut3d_tricubic && img->sh) {
+        if (!img_tex(pass, img)) {
+            RR_ERR(rr, "Failed flushing the image ahead of the tricubic colour map");
+            return;
+        }
+    }
     pl_shader sh = img_sh(pass, img);
 
     bool prelinearized = false;

@@ -1050,8 +1050,10 @@ void pl_shader_color_map_ex(pl_shader sh, const struct pl_color_map_params *para
         op->f[0] = 1.0f / lut_range;
         op->f[1] = -gamut.min_luma / lut_range;
         op->f[2] = plh_fmtf(0.5f / M_PI);
+        op->f[3] = params->lut3d_tricubic ? 1.0f : 0.0f;
         op->ptr = pl_hip_buf_ptr(obj->gamut.lut);
-        sh_listf(sh, "gamut_lut(%s, %dx%dx%d)\n", gamut.function->name, op->i0, op->i1, op->i2);
+        sh_listf(sh, "gamut_lut(%s, %dx%dx%d%s)\n", gamut.function->name, op->i0, op->i1, op->i2,
+                 params->lut3d_tricubic ? ", tricubic" : "");
     }
 
     op = sh_op(sh, PLH_OP_IPT2RGB);

@@ -1119,7 +1119,70 @@ struct orc_color_map {
     // contrast recovery (:1879-1921): per-pixel low-frequency luma (orc_feature_luma), NULL = off
     const float *lowres;
     float cr_strength, cr_out_min, cr_out_max;
+    int gamut_tricubic;         // pl_color_map_params.lut3d_tricubic (shaders/lut.c:718-760)
 };
+
+// linear lookup in the rgba16 3-D LUT at normalised coordinates, clamp to edge (what the
+// reference's linear LUT sampler does, shaders/lut.c:628-650)
+static void o_gamut_trilinear(const struct orc_color_map *m, const float idx[3], float o[3])
+{
+    int i0[3], i1[3];
+    float fr[3];
+    for (int k = 0; k < 3; k++) {
+        const float pos = clampf(idx[k], 0.0f, 1.0f) * (float) (m->gamut_size[k] - 1);
+        const float fl = floorf(pos);
+        i0[k] = (int) fl;
+        i1[k] = i0[k] + 1 < m->gamut_size[k] ? i0[k] + 1 : m->gamut_size[k] - 1;
+        fr[k] = pos - fl;
+    }
+    const int sx = m->gamut_size[0], sy = m->gamut_size[1];
+#define GT(x, y, z, ch) (m->gamut_lut[(((size_t) (z) * sy + (y)) * sx + (x)) * 4 + (ch)] / 65535.0f)
+    for (int ch = 0; ch < 3; ch++) {
+        const float c00 = mixf(GT(i0[0], i0[1], i0[2], ch), GT(i1[0], i0[1], i0[2], ch), fr[0]);
+        const float c10 = mixf(GT(i0[0], i1[1], i0[2], ch), GT(i1[0], i1[1], i0[2], ch), fr[0]);
+        const float c01 = mixf(GT(i0[0], i0[1], i1[2], ch), GT(i1[0], i0[1], i1[2], ch), fr[0]);
+        const float c11 = mixf(GT(i0[0], i1[1], i1[2], ch), GT(i1[0], i1[1], i1[2], ch), fr[0]);
+        o[ch] = mixf(mixf(c00, c10, fr[1]), mixf(c01, c11, fr[1]), fr[2]);
+    }
+#undef GT
+}
+
+// the `lut_tricubic` GLSL function (shaders/lut.c:721-757), statement by statement
+static void o_gamut_tricubic(const struct orc_color_map *m, const float idx[3], float o[3])
+{
+    float g0[3], h0[3], h1[3];
+    for (int k = 0; k < 3; k++) {
+        const float scale = (float) (m->gamut_size[k] - 1), scale_inv = 1.0f / scale;
+        const float pos = idx[k] * scale;
+        const float fpos = pos - floorf(pos);
+        const float base = pos - fpos;
+        const float fpos2 = fpos * fpos, inv = 1.0f - fpos, inv2 = inv * inv;
+        const float w0 = 1.0f / 6.0f * inv2 * inv;
+        const float w1 = 2.0f / 3.0f - 0.5f * fpos2 * (2.0f - fpos);
+        const float w2 = 2.0f / 3.0f - 0.5f * inv2 * (2.0f - inv);
+        const float w3 = 1.0f / 6.0f * fpos2 * fpos;
+        g0[k] = w0 + w1;
+        const float g1 = w2 + w3;
+        h0[k] = scale_inv * ((w1 / g0[k]) - 1.0f + base);
+        h1[k] = scale_inv * ((w3 / g1) + 1.0f + base);
+    }
+    float c000[3], c001[3], c010[3], c011[3], c100[3], c101[3], c110[3], c111[3];
+#define LUT(out, X, Y, Z) do { const float p_[3] = { X[0], Y[1], Z[2] }; o_gamut_trilinear(m, p_, out); } while (0)
+    LUT(c000, h0, h0, h0); LUT(c100, h1, h0, h0);
+    LUT(c010, h0, h1, h0); LUT(c110, h1, h1, h0);
+    LUT(c001, h0, h0, h1); LUT(c101, h1, h0, h1);
+    LUT(c011, h0, h1, h1); LUT(c111, h1, h1, h1);
+#undef LUT
+    for (int ch = 0; ch < 3; ch++) {
+        const float a00 = mixf(c100[ch], c000[ch], g0[0]);
+        const float a10 = mixf(c110[ch], c010[ch], g0[0]);
+        const float a0 = mixf(a10, a00, g0[1]);
+        const float a01 = mixf(c101[ch], c001[ch], g0[0]);
+        const float a11 = mixf(c111[ch], c011[ch], g0[0]);
+        const float a1 = mixf(a11, a01, g0[1]);
+        o[ch] = mixf(a1, a0, g0[2]);
+    }
+}
 
 static float o_lut1d(const float *lut, int n, float x)
 {
@@ -1304,26 +1367,12 @@ ORC_API void orc_color_map(float *img, size_t npix, const struct orc_color_map *
             const float idx[3] = { m->gamut_scale * I + m->gamut_offset,
                                    2.0f * sqrtf(P * P + T * T),
                                    hpi * atan2f(T, P) + 0.5f };
-            int i0[3], i1[3];
-            float fr[3];
-            for (int k = 0; k < 3; k++) {
-                const float pos = clampf(idx[k], 0.0f, 1.0f) * (float) (m->gamut_size[k] - 1);
-                const float fl = floorf(pos);
-                i0[k] = (int) fl;
-                i1[k] = i0[k] + 1 < m->gamut_size[k] ? i0[k] + 1 : m->gamut_size[k] - 1;
-                fr[k] = pos - fl;
-            }
-            const int sx = m->gamut_size[0], sy = m->gamut_size[1];
-#define GT(x, y, z, ch) (m->gamut_lut[(((size_t) (z) * sy + (y)) * sx + (x)) * 4 + (ch)] / 65535.0f)
             float o[3];
-            for (int ch = 0; ch < 3; ch++) {
-                const float c00 = mixf(GT(i0[0], i0[1], i0[2], ch), GT(i1[0], i0[1], i0[2], ch), fr[0]);
-                const float c10 = mixf(GT(i0[0], i1[1], i0[2], ch), GT(i1[0], i1[1], i0[2], ch), fr[0]);
-                const float c01 = mixf(GT(i0[0], i0[1], i1[2], ch), GT(i1[0], i0[1], i1[2], ch), fr[0]);
-                const float c11 = mixf(GT(i0[0], i1[1], i1[2], ch), GT(i1[0], i1[1], i1[2], ch), fr[0]);
-                o[ch] = mixf(mixf(c00, c10, fr[1]), mixf(c01, c11, fr[1]), fr[2]);
+            if (m->gamut_tricubic) {
+                o_gamut_tricubic(m, idx, o);
+            } else {
+                o_gamut_trilinear(m, idx, o);
             }
-#undef GT
             I = o[0];
             P = o[1] - 32768.0f / 65535.0f;
             T = o[2] - 32768.0f / 65535.0f;

@@ -52,6 +52,29 @@ def lerp_lut1d(lut, x):
     return lut[i0] * (1 - f) + lut[i1] * f
 
 
+def cubic_lut3d(lut_u16, size, idx):
+    """shaders/lut.c:721-757 in float64: B-spline weights, eight linear fetches"""
+    g0, h = [], []
+    for k, n in enumerate(size):
+        pos = idx[k] * (n - 1)
+        fpos = pos - np.floor(pos)
+        base = pos - fpos
+        inv = 1.0 - fpos
+        w0, w3 = inv ** 3 / 6.0, fpos ** 3 / 6.0
+        w1 = 2.0 / 3.0 - 0.5 * fpos ** 2 * (2.0 - fpos)
+        w2 = 2.0 / 3.0 - 0.5 * inv ** 2 * (2.0 - inv)
+        g0.append(w0 + w1)
+        h.append(((w1 / (w0 + w1) - 1.0 + base) / (n - 1), (w3 / (w2 + w3) + 1.0 + base) / (n - 1)))
+    out = 0.0
+    for t in range(8):
+        bits = [(t >> k) & 1 for k in range(3)]
+        w = 1.0
+        for k in range(3):
+            w = w * ((1.0 - g0[k]) if bits[k] else g0[k])
+        out = out + w[..., None] * lerp_lut3d(lut_u16, size, [h[k][bits[k]] for k in range(3)])
+    return out
+
+
 def lerp_lut3d(lut_u16, size, idx):
     sx, sy, sz = size
     lut = lut_u16.reshape(sz, sy, sx, 4).astype(np.float64) / 65535.0
@@ -96,7 +119,10 @@ def hdr10_to_sdr(img, r, eps):
     if kw.get("gamut_lut") is not None:
         idx = [kw["gamut_scale"] * I + kw["gamut_offset"], 2.0 * np.hypot(P, T),
                0.159155 * np.arctan2(T, P) + 0.5]
-        o = lerp_lut3d(kw["gamut_lut"], kw["gamut_size"], idx)
+        if kw.get("gamut_tricubic"):
+            o = cubic_lut3d(kw["gamut_lut"], kw["gamut_size"], idx)
+        else:
+            o = lerp_lut3d(kw["gamut_lut"], kw["gamut_size"], idx)
         I, P, T = o[..., 0], o[..., 1] - 32768.0 / 65535.0, o[..., 2] - 32768.0 / 65535.0
     lmspq = np.stack([I, P, T], -1) @ IPT2LMS.T
     lms_out = pq_eotf(lmspq) * K10

@@ -233,7 +233,7 @@ class ColorMap(C.Structure):
                 ("gamut_lut", C.c_void_p), ("gamut_size", C.c_int * 3),
                 ("gamut_scale", C.c_float), ("gamut_offset", C.c_float),
                 ("lowres", C.c_void_p), ("cr_strength", C.c_float), ("cr_out_min", C.c_float),
-                ("cr_out_max", C.c_float)]
+                ("cr_out_max", C.c_float), ("gamut_tricubic", C.c_int)]
 
 
 def extract_features(img, klms):
@@ -252,8 +252,9 @@ def feature_luma(fm, out_w, out_h):
 
 def color_map(img, rgb2lms, lms2rgb, tone_mode=-1, tone_p=(0, 0, 0, 0), tone_lut=None,
               gamut_lut=None, gamut_size=(48, 32, 256), gamut_scale=0.0, gamut_offset=0.0,
-              lowres=None, cr_strength=0.0, cr_out=(0.0, 1.0)):
-    cm = ColorMap(tone_mode=tone_mode, gamut_scale=gamut_scale, gamut_offset=gamut_offset)
+              lowres=None, cr_strength=0.0, cr_out=(0.0, 1.0), gamut_tricubic=False):
+    cm = ColorMap(tone_mode=tone_mode, gamut_scale=gamut_scale, gamut_offset=gamut_offset,
+                  gamut_tricubic=int(gamut_tricubic))
     cm.rgb2lms = (C.c_float * 9)(*rgb2lms)
     cm.lms2rgb = (C.c_float * 9)(*lms2rgb)
     cm.tone_p = (C.c_float * 4)(*tone_p)

@@ -208,17 +208,20 @@ def hdr_test_frame(w=64, h=48, seed=7):
     return img
 
 
-@pytest.mark.parametrize("tone,gamut", [("spline", "perceptual"), ("bt2390", "softclip"),
-                                         ("st2094-40", "relative"), ("hable", "darken"),
-                                         ("mobius", "desaturate"), ("clip", "clip")])
-def test_color_map_hdr10_to_sdr_vs_oracle(gpu, tone, gamut):
+@pytest.mark.parametrize("tone,gamut,tricubic", [
+    ("spline", "perceptual", False), ("bt2390", "softclip", False),
+    ("st2094-40", "relative", False), ("hable", "darken", False),
+    ("mobius", "desaturate", False), ("clip", "clip", False),
+    # pl_color_map_params.lut3d_tricubic (shaders/lut.c:718-760): B-spline LUT lookup
+    ("spline", "perceptual", True), ("bt2390", "softclip", True)])
+def test_color_map_hdr10_to_sdr_vs_oracle(gpu, tone, gamut, tricubic):
     import colormap_ref as cr
     import ref_structs as R
     src_img = hdr_test_frame()
     src = pl.color_space("bt2020", "pq", max_luma=1000.0)
     dst = pl.color_space("bt709", "bt1886")
     state = pl.ShaderObj()
-    params = pl.color_map_params(tone=tone, gamut=gamut)
+    params = pl.color_map_params(tone=tone, gamut=gamut, lut3d_tricubic=tricubic)
     got = run_ops(gpu, src_img, lambda sh: sh.color_map(src, dst, state, params))
     state.destroy()
 
@@ -229,7 +232,12 @@ def test_color_map_hdr10_to_sdr_vs_oracle(gpu, tone, gamut):
         # pl_tone_map_clip without force_lut takes the closed-form path (colorspace.c:1824)
         r["kw"].update(tone_mode=0, tone_p=(r["tone"].input_min, r["tone"].input_max, 0, 0),
                        tone_lut=None)
+    r["kw"]["gamut_tricubic"] = tricubic
     ref = cr.apply(src_img.copy(), r)
+    if tricubic:
+        # the option must change the picture (else this parametrisation proves nothing)
+        r2 = dict(r, kw=dict(r["kw"], gamut_tricubic=False))
+        assert np.abs(cr.apply(src_img.copy(), r2) - ref).max() * 65535 > 4
     # --- tolerance -------------------------------------------------------------------------
     # North star: <= 1 code value at 16 bit. That bar is met on the well-conditioned bulk of
     # samples, but the IPT/PQ round trip is ill-conditioned in fp32 (see tests/colormap_f64.py):

@@ -475,3 +475,42 @@ def test_cone_params_match_manual_composition(gpu, rr, vision):
     assert np.array_equal(got, ref), util.diff_stats(got, ref)
     for t in (src, dst, out):
         t.destroy()
+
+
+def test_tricubic_color_map_gets_its_own_pass(gpu, rr):
+    """pl_color_map_params.lut3d_tricubic: the cubic LUT lookup exists in one variant of the
+    generic pass kernel only, so the renderer un-fuses the colour map from the EWA scaler; a
+    hand-built shader that asks a polar pass to do it is refused, loudly."""
+    from test_gpu_color import hdr_test_frame
+    sw, sh_, dw, dh = 64, 48, 128, 96
+    img16 = (hdr_test_frame(sw, sh_) * 65535 + 0.5).astype(np.uint16)
+    src = gpu.tex_create(sw, sh_, "rgba16", img16)
+    dst = gpu.tex_create(dw, dh, "rgba16")
+    hdr = pl.color_space("bt2020", "pq", max_luma=1000.0)
+    sdr = pl.color_space("bt709", "bt1886")
+    image, target = pl.frame(src, components=3, color=hdr), pl.frame(dst, color=sdr)
+    outs = {}
+    for cubic in (False, True):
+        cmp_ = pl.color_map_params(lut3d_tricubic=cubic)
+        params = pl.render_params("fast", upscaler=pl.filter_config("ewa_lanczos"),
+                                  color_map_params=cmp_, peak_detect_params=None)
+        assert rr.render(image, target, params), gpu.messages[-4:]
+        assert rr.errors() == 0
+        outs[cubic] = orc.tex_decode(dst.download(), "rgba16")
+    d = np.abs(outs[True] - outs[False])[..., :3] * 65535
+    # (a B-spline smooths the LUT: large differences only where the gamut mapping has a crease)
+    assert 2 < d.max() < 8000 and np.median(d) < 40, (d.max(), np.median(d))
+
+    # the same request inside a polar pass
+    lut, state = pl.ShaderObj(), pl.ShaderObj()
+    hdr_i, sdr_i = pl.color_space("bt2020", "pq", max_luma=1000.0), pl.color_space("bt709", "bt1886")
+    pl.lib().pl_color_space_infer_map(C.byref(hdr_i), C.byref(sdr_i))
+    s = gpu.begin()
+    assert s.sample_polar(src, pl.filter_config("ewa_lanczos"), lut, new_w=dw, new_h=dh, components=3)
+    s.color_map(hdr_i, sdr_i, state, pl.color_map_params(lut3d_tricubic=True))
+    n = len(gpu.messages)
+    assert not s.finish(dst)
+    assert any("tricubic" in str(m) for m in gpu.messages[n:]), gpu.messages[n:]
+    for o in (lut, state):
+        o.destroy()
+    src.destroy(); dst.destroy()
