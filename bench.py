@@ -23,6 +23,8 @@ Workloads (BASELINE.json `configs`):
         downscale + tone map.
   ewa_1080p_to_4k_hdr_tonemap        both halves of the metric's name in one frame: 1080p HDR10
         -> peak detect -> EWA-Lanczos 2x -> tone/gamut map -> dither -> 4K SDR.
+  mix_24_to_60_ewa_1080p_to_4k       SURVEY 8f rank 3: a 24 fps stream shown at 60 Hz through pl_queue
+        + pl_render_image_mix (oversampling mixer); a step is one vsync.
 
 The default run (N = 1) also reports the two tone-mapping workloads under "companions" in the same
 JSON line (the metric's name reads "EWA-Lanczos 1080p->4K + HDR tonemap"); `value` is the headline
@@ -75,6 +77,11 @@ WORKLOADS = {
     "ewa_8k_to_4k_deband_tonemap": (P8K, P4K, px(P8K) * 8 + px(P4K) * 8, "polar"),
     # the metric's two halves in one frame: 1080p HDR10 -> EWA 2x upscale -> tone map -> 4K SDR
     "ewa_1080p_to_4k_hdr_tonemap": (P1080, P4K, 2 * px(P1080) * 8 + px(P4K) * 8, "polar"),
+    # 24 fps -> 60 Hz through pl_queue + pl_render_image_mix (oversampling mixer): a step is one
+    # vsync; 0.4 source frames per vsync are scaled into the f16 cache, 40 % of the vsyncs blend
+    # two cached frames, the others show one (bytes: the output pass, 1.4 x f16 in + rgba16 out on
+    # average)
+    "mix_24_to_60_ewa_1080p_to_4k": (P1080, P4K, px(P4K) * 8 * 12 // 5, "frame mixing"),
 }
 
 
@@ -104,6 +111,7 @@ class Stream:
         self.i = 0
         self.pass_ns = {}
         self.nv12 = None
+        self.queue = None
         if workload.startswith("nv12"):
             # luma from the chirp's green channel, chroma from (b - g, r - g), 8 bit
             y = (frame[..., 1] >> 8).astype(np.uint8)
@@ -147,6 +155,16 @@ class Stream:
             self.params = pl.render_params(
                 "default", peak_detect_params=pl.peak_detect_params(percentile=99.995))
             icsp, tcsp, trepr = hdr, bt1886, None
+        elif workload == "mix_24_to_60_ewa_1080p_to_4k":
+            mixer = capi.FilterConfig()
+            C.memmove(C.byref(mixer), C.byref(pl.filter_config("oversample", pl.FILTER_FRAME_MIXING)),
+                      C.sizeof(mixer))
+            self.params = pl.render_params("fast", upscaler=pl.filter_config("ewa_lanczos"),
+                                           dither_params=dither, frame_mixer=mixer,
+                                           disable_dither_gamma_correction=True)
+            icsp, tcsp, trepr = bt1886, bt1886, ten_bit
+            self.queue = pl.Queue(self.g)
+            self.pts, self.fed = 0.0, 0
         elif workload == "ewa_1080p_to_4k_hdr_tonemap":
             self.params = pl.render_params(
                 "default", upscaler=pl.filter_config("ewa_lanczos"), dither_params=dither,
@@ -180,13 +198,35 @@ class Stream:
         d = info.contents.pass_.contents
         self.pass_ns.setdefault(d.description.decode(), []).append(d.last)
 
+    def step_mix(self):
+        """one vsync: keep the queue two source frames ahead, ask it for the mix, render that"""
+        frame, vsync = 1.0 / 24.0, 1.0 / 60.0
+        q = self.queue
+        while self.fed * frame <= self.pts + 2 * frame:
+            q.push(self.images[self.fed % self.pool], self.fed * frame, frame)
+            self.fed += 1
+        st, mix = q.update(self.pts, radius=pl.frame_mix_radius(self.params), vsync_duration=vsync)
+        assert st == pl.QUEUE_OK, st
+        i = self.i % self.pool
+        self.i += 1
+        assert pl.lib().pl_render_image_mix(self.rr.rr, C.byref(mix), C.byref(self.targets[i]),
+                                            C.byref(self.params)), self.g.messages[-3:]
+        self.pts += vsync
+        for ident in q.unmapped:
+            q.frames.pop(ident, None)
+        q.unmapped.clear()
+
     def step(self):
+        if self.queue:
+            return self.step_mix()
         i = self.i % self.pool
         self.i += 1
         assert self.rr.render(self.images[i], self.targets[i], self.params), self.g.messages[-3:]
 
     def close(self):
         self.g.finish()
+        if self.queue:
+            self.queue.destroy()
         self.rr.destroy()
         for t in self.srcs + self.dsts + [t for pair in (self.nv12 or []) for t in pair]:
             t.destroy()
@@ -398,7 +438,7 @@ def main():
                                         else "rgba16"),
                 "dst": f"{dw}x{dh} rgba16",
                 "pool": pool,
-                "api": "pl_render_image",
+                "api": "pl_queue_update + pl_render_image_mix" if args.workload.startswith("mix") else "pl_render_image",
                 "measured": "output Mpixels/s through pl_render_image, one independent stream per GPU",
                 "render_errors": st.rr.errors(),   # pl_render_error bits: no stage may be disabled
                 "parallelism": f"{world} independent stream(s), one per GPU",
