@@ -498,13 +498,29 @@ class Queue:
         assert self.q
         self.frames = {}       # frame_data id -> Frame
         self.unmapped = []     # ids the queue is done with
+        self.uploads = []      # per uploaded plane: did the queue hand in a recycled texture?
         self._next = 1
         self._map = capi.QUEUE_MAP_FN(self._on_map)
         self._unmap = capi.QUEUE_UNMAP_FN(self._on_unmap)
         self._discard = capi.QUEUE_DISCARD_FN(self._on_discard)
 
     def _on_map(self, gpu, tex, src, out):
-        C.memmove(out, C.byref(self.frames[src.contents.frame_data]), C.sizeof(capi.Frame))
+        item = self.frames[src.contents.frame_data]
+        if isinstance(item, capi.Frame):
+            C.memmove(out, C.byref(item), C.sizeof(capi.Frame))
+            return True
+        # host picture: (list of pl_plane_data, repr, color) uploaded into the queue's own
+        # texture slots, which it recycles from frame to frame (what a software decoder does)
+        planes, repr_, color = item
+        f = capi.Frame(num_planes=len(planes), repr=repr_, color=color)
+        slots = C.cast(tex, C.POINTER(C.POINTER(capi.Tex)))
+        for i, data in enumerate(planes):
+            slot = C.cast(C.addressof(slots.contents) + i * C.sizeof(C.c_void_p),
+                          C.POINTER(C.POINTER(capi.Tex)))
+            self.uploads.append(bool(slot.contents))      # True = a recycled texture was handed in
+            if not lib().pl_upload_plane(self.gpu.gpu, C.byref(f.planes[i]), slot, C.byref(data)):
+                return False
+        C.memmove(out, C.byref(f), C.sizeof(capi.Frame))
         return True
 
     def _on_unmap(self, gpu, frame, src):

@@ -133,3 +133,45 @@ def test_oversample_then_interlaced(gpu, rr):
     q.destroy()
     for t in texs + [dst]:
         t.destroy()
+
+
+def test_host_frames_uploaded_in_map_recycle_the_queue_textures(gpu, rr):
+    """frame_queue.h: `map` gets four queue-owned texture slots to (re)create its planes in
+    (pl_upload_plane); the queue invalidates and recycles them when a frame leaves, and destroys
+    them with the queue. The rendered mix must equal the one from pre-uploaded frames."""
+    n = 12
+    imgs, texs, frames = sources(gpu, 4)
+    dst_a, dst_b = gpu.tex_create(W, H, "rgba16"), gpu.tex_create(W, H, "rgba16")
+    csp = pl.color_space("bt709", "bt1886")
+    ta, tb = pl.frame(dst_a, color=csp), pl.frame(dst_b, color=csp)
+    params = pl.render_params("fast", frame_mixer=mixer("oversample"))
+    qa, qb = pl.Queue(gpu), pl.Queue(gpu)
+    def feed(i):
+        if i == n:
+            qa.push(None, 0.0); qb.push(None, 0.0)
+            return
+        qa.push(frames[i % 4], i * FRAME, FRAME)
+        host = ([pl.plane_data(imgs[i % 4], (16, 16, 16, 16))], frames[i % 4].repr, frames[i % 4].color)
+        qb.push(host, i * FRAME, FRAME)
+    pts, compared, fed = 0.0, 0, 0
+    while True:
+        # a decoder two frames ahead of the display (recycled textures are handed out at push time)
+        while fed <= n and fed * FRAME <= pts + 2 * FRAME:
+            feed(fed)
+            fed += 1
+        (sa, ma), (sb, mb) = (q.update(pts, vsync_duration=VSYNC) for q in (qa, qb))
+        assert sa == sb
+        if sa == pl.QUEUE_EOF:
+            break
+        assert sa == pl.QUEUE_OK and ma.num_frames == mb.num_frames
+        assert lib_render(rr, ma, ta, params) and lib_render(rr, mb, tb, params)
+        # (different signatures, so both renders really happen)
+        assert np.array_equal(dst_a.download(), dst_b.download())
+        compared += 1
+        pts += VSYNC
+    assert compared > 20 and rr.errors() == 0
+    # the first frames got fresh textures, later ones the recycled sets
+    assert qb.uploads[:2] == [False, False] and sum(qb.uploads) >= n - 4, qb.uploads
+    qa.destroy(); qb.destroy()
+    for t in texs + [dst_a, dst_b]:
+        t.destroy()
