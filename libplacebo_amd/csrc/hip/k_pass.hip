@@ -371,6 +371,96 @@ void k_bilinear_fast(const plh_pass p_)
     }
 }
 
+/*
+ * k_nearest_fast: nearest-neighbour fetch of an 8-byte RGBA source + the fused epilogue
+ * ([alpha] [dither] [scale] -> rgba16 store). The output pass of a single cached frame
+ * (pl_render_image_mix between two source frames, frame-cache hits) and plain format
+ * conversions are this pass: k_pass_generic's NEAREST case + apply_ops_n, bit-identical, without
+ * the interpreter. A lane owns two adjacent pixels in NF_ROWS rows (one 16-byte store each), all
+ * loads requested before the first use.
+ */
+#define NF_ROWS 2
+
+template <bool F16SRC>
+__global__ __launch_bounds__(BF_BW * BF_BH)
+void k_nearest_fast(const plh_pass p_)
+{
+    const plh_pass &p = plh_kernarg_pass();
+    const plh_sampler_args &s = p.s;
+    const int cx = blockIdx.x * BF_BW + threadIdx.x;
+    const int idx0 = 2 * cx - p.cell_padx;
+    const float sw = (float) s.src.w, sh = (float) s.src.h;
+    const char *sp = (const char *) s.src.ptr;
+    const float *dmat = p.epi.matrix;
+    int spitch = s.src.pitch, srcw = s.src.w, srch = s.src.h;
+    int dmask = p.epi.mask, dsize = p.epi.size, has_dither = p.epi.has_dither;
+    int fx0 = p.frag_x0, fy0 = p.frag_y0;
+    asm volatile("" : "+s"(sp), "+s"(dmat), "+s"(spitch), "+s"(srcw), "+s"(srch), "+s"(dmask),
+                      "+s"(dsize), "+s"(has_dither), "+s"(fx0), "+s"(fy0));
+
+    uint2 raw[NF_ROWS][2];
+    float bias[NF_ROWS][2];
+    int idys[NF_ROWS];
+#pragma unroll
+    for (int r = 0; r < NF_ROWS; r++) {
+        const int idy = (blockIdx.y * NF_ROWS + r) * BF_BH + threadIdx.y;
+        idys[r] = idy;
+        const float my = p.out_scale[1] * ((float) idy + 0.5f);
+#pragma unroll
+        for (int i = 0; i < 2; i++) {
+            const int idx = idx0 + i;
+            const float mx = p.out_scale[0] * ((float) idx + 0.5f);
+            const float px = plh_attr(s.pos, 0, mx, my), py = plh_attr(s.pos, 1, mx, my);
+            // (clamp addressing only; the other modes take the generic kernel)
+            const int ix = min(max((int) __builtin_floorf(px * sw), 0), srcw - 1);
+            const int iy = min(max((int) __builtin_floorf(py * sh), 0), srch - 1);
+            raw[r][i] = bf_load(sp, spitch, ix, iy);
+            bias[r][i] = 0.0f;
+            if (has_dither)
+                bias[r][i] = dmat[((idy + fy0) & dmask) * dsize + ((idx + fx0) & dmask)];
+        }
+    }
+
+#pragma unroll
+    for (int r = 0; r < NF_ROWS; r++) {
+        float4_t o[2];
+        int ox[2], oy[2];
+        bool ok[2];
+#pragma unroll
+        for (int i = 0; i < 2; i++) {
+            const int idx = idx0 + i, idy = idys[r];
+            o[i] = scale4(bf_decode<F16SRC>(raw[r][i]), s.scale);
+            if (p.epi.has_alpha)
+                o[i].w = p.epi.alpha;
+            if (p.epi.has_dither) {
+                const float b = bias[r][i], ds = p.epi.dscale, di = p.epi.dinv;
+                o[i].x = __builtin_floorf(ds * o[i].x + b) * di;
+                o[i].y = __builtin_floorf(ds * o[i].y + b) * di;
+                o[i].z = __builtin_floorf(ds * o[i].z + b) * di;
+                o[i].w = __builtin_floorf(ds * o[i].w + b) * di;
+            }
+            if (p.epi.has_scale)
+                o[i] = scale4(o[i], p.epi.scale);
+            ox[i] = p.base_x + p.dir_x * idx;
+            oy[i] = p.base_y + p.dir_y * idy;
+            ok[i] = idx >= 0 && p.out_scale[0] * (float) idx < 1.0f && ox[i] >= 0 && ox[i] < p.dst.w &&
+                    idy >= 0 && p.out_scale[1] * (float) idy < 1.0f && oy[i] >= 0 && oy[i] < p.dst.h;
+        }
+        plh_store_rgba16_n<2>(p.dst, ox, oy, ok, o, p.nt_store);
+    }
+}
+
+static bool nearest_fast_ok(plh_pass *pass)
+{
+    const char *e = getenv("PL_HIP_BILIN_ITERS");   // (0 = the generic kernel, as for bilinear)
+    if ((e && !atoi(e)) || pass->s.type != PLH_SAMPLE_NEAREST ||
+        pass->s.address_mode != PLH_ADDRESS_CLAMP || pass->num_pre_ops || pass->transpose ||
+        (pass->s.src.fmt != PLH_FMT_RGBA16 && pass->s.src.fmt != PLH_FMT_RGBA16F))
+        return false;
+    plh_match_fast_epilogue(pass, true);
+    return pass->epi.enabled;
+}
+
 // 0: not eligible, else the number of cells per lane
 static int bilinear_fast_iters(plh_pass *pass)
 {
@@ -457,6 +547,22 @@ extern "C" int plh_launch_pass(plh_stream stream_, const struct plh_pass *pass)
     for (int i = 0; i < pass->num_ops; i++) {
         if (pass->ops[i].kind == PLH_OP_PEAK_DETECT)
             return plh_launch_peak(stream, pass);
+    }
+
+    {
+        plh_pass local = *pass;
+        if (nearest_fast_ok(&local)) {
+            const int cells_w = (local.width + local.cell_padx + 1) / 2;
+            const dim3 block(BF_BW, BF_BH);
+            const dim3 grid((cells_w + BF_BW - 1) / BF_BW,
+                            (local.height + BF_BH * NF_ROWS - 1) / (BF_BH * NF_ROWS));
+            if (local.s.src.fmt == PLH_FMT_RGBA16F)
+                hipLaunchKernelGGL(k_nearest_fast<true>, grid, block, 0, stream, local);
+            else
+                hipLaunchKernelGGL(k_nearest_fast<false>, grid, block, 0, stream, local);
+            const hipError_t err = hipGetLastError();
+            return err == hipSuccess ? 0 : -(int) err;
+        }
     }
 
     {

@@ -324,3 +324,24 @@ def test_tiny_frames_do_not_break_the_fast_paths(gpu):
         a = render(gpu, img, dw, dh, params, bool(case % 2), generic)
         b = render(gpu, img, dw, dh, params, bool(case % 2), {})
         assert np.array_equal(a, b), (case, name, (sw, sh), (dw, dh))
+
+
+@pytest.mark.parametrize("ten_bit", [False, True])
+@pytest.mark.parametrize("src_fmt", ["rgba16", "rgba16hf"])
+def test_nearest_fast_equals_generic(gpu, ten_bit, src_fmt):
+    """k_nearest_fast (1:1 and integer-ratio nearest fetch + fused epilogue: the output pass of a
+    single cached frame in pl_render_image_mix, plain conversions) against k_pass_generic"""
+    sw, sh = 101, 57
+    img = util.chirp_rgba16(sw, sh)
+    if src_fmt == "rgba16hf":
+        img = (img.astype(np.float32) / 65535.0).astype(np.float16)
+    kw = dict(dither_params=dither(), disable_dither_gamma_correction=True) if ten_bit else {}
+    nearest = pl.filter_config("nearest")
+    for (dw, dh), crop in [((sw, sh), None), ((2 * sw, 3 * sh), None), ((sw, sh), (sw, 0, 0, sh)),
+                           ((77, 41), (3.0, 2.0, 80.0, 43.0))]:
+        params = pl.render_params("fast", upscaler=nearest, downscaler=nearest, **kw)
+        a = render(gpu, img, dw, dh, params, ten_bit, {"PL_HIP_BILIN_ITERS": "0"}, crop=crop,
+                   src_fmt=src_fmt)
+        b = render(gpu, img, dw, dh, params, ten_bit, {}, crop=crop, src_fmt=src_fmt)
+        assert np.array_equal(a, b), ((dw, dh), crop, util.diff_stats(a, b))
+        assert a[..., :3].std() > 1000
