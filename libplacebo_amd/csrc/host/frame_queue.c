@@ -93,6 +93,14 @@ struct pl_queue_t {
 
 #define Q_MSG(q, lev, ...) pl_msg((q)->log, lev, __VA_ARGS__)
 
+// Allocation failure is fatal, as in the reference's allocator (pl_alloc.c aborts on OOM)
+static void *must(void *ptr)
+{
+    if (!ptr)
+        abort();
+    return ptr;
+}
+
 /* ---- rate estimation ---------------------------------------------------------------------- */
 
 static inline float rel_change(float from, float to)
@@ -168,7 +176,7 @@ static void picture_release(pl_queue q, struct picture **ppic, bool recycle)
     if (recycle && any) {
         if (q->num_spare == q->cap_spare) {
             q->cap_spare = PL_MAX(8, 2 * q->cap_spare);
-            q->spare = realloc(q->spare, q->cap_spare * sizeof(*q->spare));
+            q->spare = must(realloc(q->spare, q->cap_spare * sizeof(*q->spare)));
         }
         memcpy(q->spare[q->num_spare++].tex, pic->tex, sizeof(pic->tex));
     }
@@ -197,7 +205,7 @@ static void line_insert(pl_queue q, int at, struct slot *s)
 {
     if (q->num == q->cap) {
         q->cap = PL_MAX(16, 2 * q->cap);
-        q->line = realloc(q->line, q->cap * sizeof(*q->line));
+        q->line = must(realloc(q->line, q->cap * sizeof(*q->line)));
     }
     memmove(&q->line[at + 1], &q->line[at], (q->num - at) * sizeof(*q->line));
     q->line[at] = s;
@@ -206,7 +214,7 @@ static void line_insert(pl_queue q, int at, struct slot *s)
 
 static struct slot *slot_new(pl_queue q, struct picture *pic, double pts, bool second)
 {
-    struct slot *s = calloc(1, sizeof(*s));
+    struct slot *s = must(calloc(1, sizeof(*s)));
     s->pic = picture_ref(pic);
     s->pts = pts;
     s->second = second;
@@ -357,7 +365,7 @@ static void push_locked(pl_queue q, const struct pl_source_frame *src)
         }
     }
 
-    struct picture *pic = calloc(1, sizeof(*pic));
+    struct picture *pic = must(calloc(1, sizeof(*pic)));
     pic->src = *src;
     struct slot *first = slot_new(q, pic, src->pts, false);
     first->id = q->next_id++;
@@ -598,9 +606,9 @@ static void mix_add(pl_queue q, const struct slot *s, float ts)
 {
     if (q->mix_num == q->mix_cap) {
         q->mix_cap = PL_MAX(16, 2 * q->mix_cap);
-        q->mix_id = realloc(q->mix_id, q->mix_cap * sizeof(*q->mix_id));
-        q->mix_ts = realloc(q->mix_ts, q->mix_cap * sizeof(*q->mix_ts));
-        q->mix_frame = realloc(q->mix_frame, q->mix_cap * sizeof(*q->mix_frame));
+        q->mix_id = must(realloc(q->mix_id, q->mix_cap * sizeof(*q->mix_id)));
+        q->mix_ts = must(realloc(q->mix_ts, q->mix_cap * sizeof(*q->mix_ts)));
+        q->mix_frame = must(realloc(q->mix_frame, q->mix_cap * sizeof(*q->mix_frame)));
     }
     q->mix_id[q->mix_num] = s->id;
     q->mix_ts[q->mix_num] = ts;
