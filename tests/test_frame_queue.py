@@ -347,7 +347,11 @@ def test_random_traces(sides, seed):
                 s.pending.clear(); s.pull_eof = False
             ident += 100
             next_pts, t, eof_sent = 0.0, 0.0, False
-        elif op < 0.45:
+        elif op < 0.47 and not pull:
+            args = new_frame()      # back-pressure: refused (after 1 ns) while too many frames wait
+            both(sides, lambda s: s.lib.pl_queue_push_block(s.q, C.c_uint64(1),
+                                                            C.byref(s.source(*args))))
+        elif op < 0.49:
             args = new_frame()                      # push after EOF / blocking push, no wait
             both(sides, lambda s: s.lib.pl_queue_push_block(s.q, C.c_uint64(0),
                                                             C.byref(s.source(*args))))
