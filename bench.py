@@ -196,7 +196,7 @@ class Stream:
 
     def _info(self, _priv, info):
         d = info.contents.pass_.contents
-        self.pass_ns.setdefault(d.description.decode(), []).append(d.last)
+        self.pass_ns.setdefault(d.shader.contents.description.decode(), []).append(d.last)
 
     def step_mix(self):
         """one vsync: keep the queue two source frames ahead, ask it for the mix, render that"""

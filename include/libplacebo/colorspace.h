@@ -376,6 +376,23 @@ PL_API extern const pl_matrix3x3 pl_ipt_ipt2lms;
 PL_API pl_transform3x3 pl_color_repr_decode(struct pl_color_repr *repr,
                                             const struct pl_color_adjustment *params);
 
+// An ICC profile blob (reference colorspace.h:731-758). `data` == NULL means "no profile";
+// `signature` must identify the contents. This build carries the description through
+// pl_frame but cannot interpret it (no lcms2), see shaders/icc.h.
+struct pl_icc_profile {
+    const void *data;
+    size_t len;
+    uint64_t signature;
+};
+
+#define pl_icc_profile(...) &(struct pl_icc_profile) { __VA_ARGS__ }
+
+// Compares signatures (and sizes), not contents
+PL_API bool pl_icc_profile_equal(const struct pl_icc_profile *p1,
+                                 const struct pl_icc_profile *p2);
+// signature := digest of the profile bytes (0 without a profile)
+PL_API void pl_icc_profile_compute_signature(struct pl_icc_profile *profile);
+
 PL_API_END
 
 #endif // LIBPLACEBO_COLORSPACE_H_

@@ -26,7 +26,7 @@ PL_API void pl_dispatch_reset_frame(pl_dispatch dp);
 PL_API pl_shader pl_dispatch_begin(pl_dispatch dp);
 
 struct pl_dispatch_info {
-    const char *description;    // of the shader that ran
+    pl_shader_info shader;      // of the shader that ran (->description names the pass)
     uint64_t signature;
     uint64_t samples[256];      // nanoseconds
     int num_samples;
@@ -34,6 +34,15 @@ struct pl_dispatch_info {
     uint64_t peak;
     uint64_t average;
 };
+
+// Take over `src` (keeps the shader description alive for as long as `dst` lives)
+static inline void pl_dispatch_info_move(struct pl_dispatch_info *dst,
+                                         const struct pl_dispatch_info *src)
+{
+    pl_shader_info_deref(&dst->shader);
+    *dst = *src;
+    dst->shader = pl_shader_info_ref(src->shader);
+}
 
 // Per-pass timing callback (requires a pl_timer per pass, created internally)
 PL_API void pl_dispatch_callback(pl_dispatch dp, void *priv,

@@ -137,6 +137,7 @@ struct pl_filter_params {
     float cutoff;           // truncate the kernel where |w| <= cutoff
     int max_row_size;       // separable only
     int row_stride_align;   // separable only
+    float filter_scale;     // deprecated since v6.316, ignored (no effect in the reference either)
 };
 
 #define pl_filter_params(...) (&(struct pl_filter_params) { __VA_ARGS__ })
@@ -151,6 +152,7 @@ typedef const struct pl_filter_t {
     int row_size;
     bool insufficient;
     int row_stride;
+    float radius_cutoff;    // deprecated since v6.336: always equal to `radius`
 } *pl_filter;
 
 PL_API pl_filter pl_filter_generate(pl_log log, const struct pl_filter_params *params);

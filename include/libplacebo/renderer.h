@@ -4,9 +4,12 @@
  * (pl_renderer :38-80, pl_render_params :130-380, pl_plane :404-472,
  * pl_frame :528-655, pl_render_image :731).
  *
- * Field names, meanings and defaults are the reference's. Not provided (out of the
- * hot-path scope): hooks, ICC, overlays, film grain,
- * deinterlacing, distortion / cone distortion, blurred borders.
+ * Field names, meanings, defaults AND LAYOUTS are the reference's: `struct pl_frame`,
+ * `struct pl_render_params` etc. built against libplacebo's own headers can be passed in
+ * unchanged (tests/test_abi_layout.py). Members that select features outside the hot-path
+ * scope (hooks, ICC, overlays, film grain, deinterlacing, distortion,
+ * blurred borders) are declared at their reference offsets and refused or ignored at run
+ * time as documented on each member.
  * Images and targets may be packed, semi-planar or planar / subsampled.
  */
 #ifndef LIBPLACEBO_RENDERER_H_
@@ -17,7 +20,10 @@
 #include <libplacebo/filters.h>
 #include <libplacebo/gpu.h>
 #include <libplacebo/shaders/colorspace.h>
+#include <libplacebo/shaders/deinterlacing.h>
 #include <libplacebo/shaders/dithering.h>
+#include <libplacebo/shaders/film_grain.h>
+#include <libplacebo/shaders/icc.h>
 #include <libplacebo/shaders/lut.h>
 #include <libplacebo/shaders/sampling.h>
 
@@ -45,7 +51,7 @@ enum pl_render_error {
 
 struct pl_render_errors {
     enum pl_render_error errors;
-    const struct pl_hook * const *disabled_hooks; // always NULL here
+    const uint64_t *disabled_hooks; // signatures; always NULL here (no hooks)
     int num_disabled_hooks;
 };
 
@@ -102,10 +108,10 @@ struct pl_render_params {
     const struct pl_error_diffusion_kernel *error_diffusion;
 
     const struct pl_cone_params *cone_params; // colour blindness simulation (NULL = off)
-    const void *blend_params;           // unsupported, must be NULL
-    const void *deinterlace_params;     // unsupported, must be NULL
-    const void *distort_params;         // unsupported, must be NULL
-    const void * const *hooks;          // unsupported, must be NULL
+    const struct pl_blend_params *blend_params;             // unsupported, must be NULL
+    const struct pl_deinterlace_params *deinterlace_params; // unsupported, must be NULL
+    const struct pl_distort_params *distort_params;         // unsupported, must be NULL
+    const struct pl_hook * const *hooks;                    // unsupported, must be NULL
     int num_hooks;
     const struct pl_custom_lut *lut;    // applied between the image's and the target's colour
     enum pl_lut_type lut_type;          // space, see pl_lut_type
@@ -133,6 +139,15 @@ struct pl_render_params {
 
     void (*info_callback)(void *priv, const struct pl_render_info *info);
     void *info_priv;
+
+    // Members of older API levels, at the reference's offsets (:350-368)
+    bool allow_delayed_peak_detect;         // since v6.254: peak_detect_params->allow_delayed
+    const struct pl_icc_params *icc_params; // ignored (no ICC)
+    bool ignore_icc_profiles;               // ignored
+    int lut_entries;                        // ignored: scaler LUTs have 256 entries
+    float polar_cutoff;                     // ignored: 1e-3
+    bool skip_target_clearing;              // honoured: = PL_CLEAR_SKIP for background + border
+    bool blend_against_tiles;               // honoured: = PL_CLEAR_TILES for the background
 };
 
 #define PL_RENDER_DEFAULTS                              \
@@ -150,20 +165,6 @@ PL_API extern const struct pl_render_params pl_render_high_quality_params;
 
 #define PL_MAX_PLANES 4
 
-// Field of an interlaced picture (reference shaders/deinterlacing.h:35-52)
-enum pl_field {
-    PL_FIELD_NONE = 0, // progressive
-    PL_FIELD_EVEN,     // "top" field, even rows
-    PL_FIELD_ODD,      // "bottom" field, odd rows
-    PL_FIELD_TOP = PL_FIELD_EVEN,
-    PL_FIELD_BOTTOM = PL_FIELD_ODD,
-};
-
-static inline enum pl_field pl_field_other(enum pl_field field)
-{
-    return field == PL_FIELD_EVEN ? PL_FIELD_ODD : field == PL_FIELD_ODD ? PL_FIELD_EVEN : field;
-}
-
 struct pl_plane {
     pl_tex texture;
     enum pl_tex_address_mode address_mode;
@@ -173,15 +174,57 @@ struct pl_plane {
     float shift_x, shift_y;   // sample position relative to the reference plane's grid
 };
 
+enum pl_overlay_mode {
+    PL_OVERLAY_NORMAL = 0,
+    PL_OVERLAY_MONOCHROME,
+    PL_OVERLAY_MODE_COUNT,
+};
+
+enum pl_overlay_coords {
+    PL_OVERLAY_COORDS_AUTO = 0,
+    PL_OVERLAY_COORDS_SRC_FRAME,
+    PL_OVERLAY_COORDS_SRC_CROP,
+    PL_OVERLAY_COORDS_DST_FRAME,
+    PL_OVERLAY_COORDS_DST_CROP,
+    PL_OVERLAY_COORDS_COUNT,
+};
+
+struct pl_overlay_part {
+    pl_rect2df src;
+    pl_rect2df dst;
+    float color[4];
+};
+
+// On-screen display / subtitle bitmaps. Not drawn by this backend: a frame with overlays is
+// rendered without them and PL_RENDER_ERR_OVERLAY is raised.
+struct pl_overlay {
+    pl_tex tex;
+    enum pl_overlay_mode mode;
+    enum pl_overlay_coords coords;
+    struct pl_color_repr repr;
+    struct pl_color_space color;
+    const struct pl_overlay_part *parts;
+    int num_parts;
+};
+
 struct pl_frame {
     int num_planes;           // 1..4 (packed, semi-planar, planar)
     struct pl_plane planes[PL_MAX_PLANES];
+
+    // Interlacing description, filled in by pl_queue (utils/frame_queue.h). This backend has no
+    // deinterlacer (`deinterlace_params` is refused), so the renderer shows such frames woven.
+    enum pl_field field;
+    enum pl_field first_field;
+    const struct pl_frame *prev, *next;
 
     bool (*acquire)(pl_gpu gpu, struct pl_frame *frame);
     void (*release)(pl_gpu gpu, struct pl_frame *frame);
 
     struct pl_color_repr repr;
     struct pl_color_space color;
+
+    pl_icc_object icc;              // ignored (no lcms2 in this build), warned about once
+    struct pl_icc_profile profile;  // ignored likewise
 
     // Optional LUT attached to the frame (images: applied while decoding; targets: while
     // encoding). lut_type 0 = guess from the LUT's repr_in / repr_out.
@@ -190,13 +233,14 @@ struct pl_frame {
 
     pl_rect2df crop;          // 0 = whole frame; flipped rects flip the image
     pl_rotation rotation;     // clockwise, in multiples of 90 degrees (common.h)
-    void *user_data;
+    float pixel_aspect_ratio; // informational (0 = square); the renderer never reads it
 
-    // Interlacing description, filled in by pl_queue (utils/frame_queue.h). This backend has no
-    // deinterlacer (`deinterlace_params` is refused), so the renderer shows such frames woven.
-    enum pl_field field;
-    enum pl_field first_field;
-    const struct pl_frame *prev, *next;
+    const struct pl_overlay *overlays;      // not drawn, see struct pl_overlay
+    int num_overlays;
+
+    struct pl_film_grain_data film_grain;   // not synthesised, see shaders/film_grain.h
+
+    void *user_data;
 };
 
 // Set plane shifts from a chroma sample location (applies to subsampled planes)

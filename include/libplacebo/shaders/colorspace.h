@@ -89,6 +89,16 @@ PL_API void pl_reset_detected_peak(pl_shader_obj state);
 // Returns the device pointer, or NULL if no measurement is pending.
 PL_API void *pl_hip_peak_buffer(const pl_shader_obj state, size_t *out_size);
 
+// Deprecated since v6.269; only here because pl_color_map_params still carries the members
+enum pl_tone_map_mode {
+    PL_TONE_MAP_AUTO,
+    PL_TONE_MAP_RGB,
+    PL_TONE_MAP_MAX,
+    PL_TONE_MAP_HYBRID,
+    PL_TONE_MAP_LUMA,
+    PL_TONE_MAP_MODE_COUNT,
+};
+
 enum pl_gamut_mode {
     PL_GAMUT_CLIP,
     PL_GAMUT_WARN,
@@ -119,7 +129,13 @@ struct pl_color_map_params {
     float visualize_theta;
     bool show_clipping;         // unsupported (ignored)
 
-    float tone_mapping_param;   // legacy
+    // Members of older API levels, same positions as in the reference (:306-311).
+    enum pl_tone_map_mode tone_mapping_mode;    // ignored (removed in v6.269)
+    float tone_mapping_param;                   // forwarded to pl_tone_map_params.param
+    float tone_mapping_crosstalk;               // ignored (fixed at 0.04)
+    enum pl_rendering_intent intent;            // with gamut_mode: selects a gamut mapping
+    enum pl_gamut_mode gamut_mode;              // function the way the reference does (:1717)
+    float hybrid_mix;                           // ignored
 };
 
 #define PL_COLOR_MAP_DEFAULTS                                   \

@@ -69,6 +69,8 @@ struct pl_sample_filter_params {
     bool no_compute;    // evaluate taps in the reference's gather/fragment order
     bool no_widening;
     pl_shader_obj *lut; // required: persistent LUT / filter state
+    int lut_entries;    // deprecated since v6.335, ignored: LUTs always have 256 entries
+    float cutoff;       // deprecated since v6.335, ignored: 1e-3 for polar kernels
 };
 
 #define pl_sample_filter_params(...) (&(struct pl_sample_filter_params) { __VA_ARGS__ })

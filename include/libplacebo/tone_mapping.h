@@ -24,6 +24,12 @@ struct pl_tone_map_function {
     void (*map)(float *lut, const struct pl_tone_map_params *params);
     void (*map_inverse)(float *lut, const struct pl_tone_map_params *params);
     void *priv;
+    // deprecated since v6.311 (the curves read pl_tone_map_constants instead); kept filled in
+    // with the reference's values for programs that still display them
+    const char *param_desc;
+    float param_min;
+    float param_def;
+    float param_max;
 };
 
 struct pl_tone_map_constants {

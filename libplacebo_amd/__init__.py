@@ -294,7 +294,7 @@ class HipGpu:
 
         self._cb = capi.LOG_CB(_cb)
         lp = capi.LogParams(log_cb=self._cb, log_priv=None, log_level=log_level)
-        self.log = C.c_void_p(L.pl_log_create(365, C.byref(lp)))
+        self.log = C.c_void_p(L.pl_log_create_365(365, C.byref(lp)))
         hp = capi.HipParams(device=device, stream=stream, max_shmem_size=max_shmem_size)
         self.hip = L.pl_hip_create(self.log, C.byref(hp))
         if not self.hip:

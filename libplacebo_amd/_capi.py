@@ -71,24 +71,32 @@ class FilterConfig(C.Structure):
 
 class FilterParams(C.Structure):
     _fields_ = [("config", FilterConfig), ("lut_entries", C.c_int), ("cutoff", C.c_float),
-                ("max_row_size", C.c_int), ("row_stride_align", C.c_int)]
+                ("max_row_size", C.c_int), ("row_stride_align", C.c_int),
+                ("filter_scale", C.c_float)]
 
 
 class Filter(C.Structure):
     _fields_ = [("params", FilterParams), ("radius", C.c_float), ("radius_zero", C.c_float),
                 ("weights", C.POINTER(C.c_float)), ("row_size", C.c_int),
-                ("insufficient", C.c_bool), ("row_stride", C.c_int)]
+                ("insufficient", C.c_bool), ("row_stride", C.c_int),
+                ("radius_cutoff", C.c_float)]
 
 
 # ---- gpu.h / hip.h ----------------------------------------------------------------
+class FmtPlane(C.Structure):
+    _fields_ = [("format", C.c_void_p), ("shift_x", C.c_uint8), ("shift_y", C.c_uint8)]
+
+
 class Fmt(C.Structure):
     _fields_ = [("name", C.c_char_p), ("signature", C.c_uint64), ("type", C.c_int),
                 ("caps", C.c_int), ("num_components", C.c_int),
                 ("component_depth", C.c_int * 4), ("internal_size", C.c_size_t),
+                ("planes", FmtPlane * 4), ("num_planes", C.c_int),
                 ("opaque", C.c_bool), ("emulated", C.c_bool), ("texel_size", C.c_size_t),
                 ("texel_align", C.c_size_t), ("host_bits", C.c_int * 4),
                 ("sample_order", C.c_int * 4), ("gatherable", C.c_bool),
-                ("glsl_type", C.c_char_p), ("glsl_format", C.c_char_p)]
+                ("glsl_type", C.c_char_p), ("glsl_format", C.c_char_p),
+                ("fourcc", C.c_uint32), ("modifiers", C.c_void_p), ("num_modifiers", C.c_int)]
 
 
 class GlslVersion(C.Structure):
@@ -104,12 +112,15 @@ class GpuLimits(C.Structure):
                 ("max_buf_size", C.c_size_t), ("max_ubo_size", C.c_size_t),
                 ("max_ssbo_size", C.c_size_t), ("max_vbo_size", C.c_size_t),
                 ("max_mapped_size", C.c_size_t), ("max_buffer_texels", C.c_uint64),
+                ("host_cached", C.c_bool), ("host_ptr_slow", C.c_bool),
+                ("max_mapped_vram", C.c_size_t), ("align_host_ptr", C.c_size_t),
                 ("max_tex_1d_dim", C.c_uint32), ("max_tex_2d_dim", C.c_uint32),
                 ("max_tex_3d_dim", C.c_uint32), ("blittable_1d_3d", C.c_bool),
                 ("buf_transfer", C.c_bool), ("align_tex_xfer_pitch", C.c_size_t),
                 ("align_tex_xfer_offset", C.c_size_t), ("max_variable_comps", C.c_size_t),
                 ("max_constants", C.c_size_t), ("array_size_constants", C.c_bool),
-                ("max_pushc_size", C.c_size_t), ("max_dispatch", C.c_uint32 * 3),
+                ("max_pushc_size", C.c_size_t), ("align_vertex_stride", C.c_size_t),
+                ("max_dispatch", C.c_uint32 * 3),
                 ("fragment_queues", C.c_uint32), ("compute_queues", C.c_uint32)]
 
 
@@ -118,8 +129,19 @@ class PciAddress(C.Structure):
                 ("function", C.c_uint32)]
 
 
+class HandleCaps(C.Structure):
+    _fields_ = [("tex", C.c_uint64), ("buf", C.c_uint64), ("sync", C.c_uint64)]
+
+
+class SharedMem(C.Structure):
+    _fields_ = [("handle", C.c_void_p), ("size", C.c_size_t), ("offset", C.c_size_t),
+                ("drm_format_mod", C.c_uint64), ("stride_w", C.c_size_t),
+                ("stride_h", C.c_size_t), ("plane", C.c_uint)]
+
+
 class Gpu(C.Structure):
     _fields_ = [("log", C.c_void_p), ("glsl", GlslVersion), ("limits", GpuLimits),
+                ("export_caps", HandleCaps), ("import_caps", HandleCaps),
                 ("uuid", C.c_uint8 * 16), ("formats", C.POINTER(C.POINTER(Fmt))),
                 ("num_formats", C.c_int), ("pci", PciAddress)]
 
@@ -142,26 +164,45 @@ class TexParams(C.Structure):
     _fields_ = [("w", C.c_int), ("h", C.c_int), ("d", C.c_int), ("format", C.POINTER(Fmt)),
                 ("sampleable", C.c_bool), ("renderable", C.c_bool), ("storable", C.c_bool),
                 ("blit_src", C.c_bool), ("blit_dst", C.c_bool), ("host_writable", C.c_bool),
-                ("host_readable", C.c_bool), ("initial_data", C.c_void_p),
+                ("host_readable", C.c_bool), ("export_handle", C.c_int),
+                ("import_handle", C.c_int), ("shared_mem", SharedMem),
+                ("initial_data", C.c_void_p),
                 ("user_data", C.c_void_p), ("debug_tag", C.c_char_p)]
 
 
 class Tex(C.Structure):
-    _fields_ = [("params", TexParams), ("sampler_type", C.c_int)]
+    _fields_ = [("params", TexParams), ("planes", C.c_void_p * 4), ("parent", C.c_void_p),
+                ("shared_mem", SharedMem), ("sampler_type", C.c_int)]
 
 
 class TexTransferParams(C.Structure):
     _fields_ = [("tex", C.POINTER(Tex)), ("rc", Rect3d), ("row_pitch", C.c_size_t),
                 ("depth_pitch", C.c_size_t), ("timer", C.c_void_p), ("callback", C.c_void_p),
                 ("priv", C.c_void_p), ("buf", C.c_void_p), ("buf_offset", C.c_size_t),
-                ("ptr", C.c_void_p)]
+                ("ptr", C.c_void_p), ("no_import", C.c_bool)]
 
 
 # ---- shaders ----------------------------------------------------------------------
+class ShaderParams(C.Structure):
+    _fields_ = [("id", C.c_uint8), ("gpu", C.c_void_p), ("index", C.c_uint8),
+                ("glsl", GlslVersion), ("dynamic_constants", C.c_bool)]
+
+
+class ShaderInfo(C.Structure):
+    _fields_ = [("params", ShaderParams), ("steps", C.POINTER(C.c_char_p)),
+                ("num_steps", C.c_int), ("description", C.c_char_p)]
+
+
 class ShaderRes(C.Structure):
-    _fields_ = [("glsl", C.c_char_p), ("name", C.c_char_p), ("description", C.c_char_p),
+    _fields_ = [("info", C.POINTER(ShaderInfo)), ("glsl", C.c_char_p), ("name", C.c_char_p),
                 ("input", C.c_int), ("output", C.c_int), ("compute_group_size", C.c_int * 2),
-                ("compute_shmem", C.c_size_t), ("num_ops", C.c_int)]
+                ("compute_shmem", C.c_size_t),
+                ("vertex_attribs", C.c_void_p), ("num_vertex_attribs", C.c_int),
+                ("variables", C.c_void_p), ("num_variables", C.c_int),
+                ("descriptors", C.c_void_p), ("num_descriptors", C.c_int),
+                ("constants", C.c_void_p), ("num_constants", C.c_int),
+                ("params", ShaderParams), ("steps", C.POINTER(C.c_char_p)),
+                ("num_steps", C.c_int), ("description", C.c_char_p)]
 
 
 class SampleSrc(C.Structure):
@@ -180,7 +221,8 @@ class DebandParams(C.Structure):
 
 class SampleFilterParams(C.Structure):
     _fields_ = [("filter", FilterConfig), ("antiring", C.c_float), ("no_compute", C.c_bool),
-                ("no_widening", C.c_bool), ("lut", C.POINTER(C.c_void_p))]
+                ("no_widening", C.c_bool), ("lut", C.POINTER(C.c_void_p)),
+                ("lut_entries", C.c_int), ("cutoff", C.c_float)]
 
 
 class DitherParams(C.Structure):
@@ -289,7 +331,9 @@ class ColorMapParams(C.Structure):
                 ("contrast_smoothness", C.c_float), ("force_tone_mapping_lut", C.c_bool),
                 ("visualize_lut", C.c_bool), ("visualize_rect", Rect2df),
                 ("visualize_hue", C.c_float), ("visualize_theta", C.c_float),
-                ("show_clipping", C.c_bool), ("tone_mapping_param", C.c_float)]
+                ("show_clipping", C.c_bool), ("tone_mapping_mode", C.c_int),
+                ("tone_mapping_param", C.c_float), ("tone_mapping_crosstalk", C.c_float),
+                ("intent", C.c_int), ("gamut_mode", C.c_int), ("hybrid_mix", C.c_float)]
 
 
 class ColorMapArgs(C.Structure):
@@ -320,14 +364,49 @@ class CustomLut(C.Structure):  # shaders/lut.h
                 ("color_in", ColorSpace), ("color_out", ColorSpace)]
 
 
+class IccProfile(C.Structure):
+    _fields_ = [("data", C.c_void_p), ("len", C.c_size_t), ("signature", C.c_uint64)]
+
+
+class Av1GrainData(C.Structure):
+    _fields_ = [("num_points_y", C.c_int), ("points_y", (C.c_uint8 * 2) * 14),
+                ("chroma_scaling_from_luma", C.c_bool), ("num_points_uv", C.c_int * 2),
+                ("points_uv", ((C.c_uint8 * 2) * 10) * 2), ("scaling_shift", C.c_int),
+                ("ar_coeff_lag", C.c_int), ("ar_coeffs_y", C.c_int8 * 24),
+                ("ar_coeffs_uv", (C.c_int8 * 25) * 2), ("ar_coeff_shift", C.c_int),
+                ("grain_scale_shift", C.c_int), ("uv_mult", C.c_int8 * 2),
+                ("uv_mult_luma", C.c_int8 * 2), ("uv_offset", C.c_int16 * 2),
+                ("overlap", C.c_bool)]
+
+
+class H274GrainData(C.Structure):
+    _fields_ = [("model_id", C.c_int), ("blending_mode_id", C.c_int),
+                ("log2_scale_factor", C.c_int), ("component_model_present", C.c_bool * 3),
+                ("num_intensity_intervals", C.c_uint16 * 3), ("num_model_values", C.c_uint8 * 3),
+                ("intensity_interval_lower_bound", C.c_void_p * 3),
+                ("intensity_interval_upper_bound", C.c_void_p * 3),
+                ("comp_model_value", C.c_void_p * 3)]
+
+
+class _GrainUnion(C.Union):
+    _fields_ = [("av1", Av1GrainData), ("h274", H274GrainData)]
+
+
+class FilmGrainData(C.Structure):
+    _fields_ = [("type", C.c_int), ("seed", C.c_uint64), ("params", _GrainUnion)]
+
+
 class Frame(C.Structure):
     _fields_ = [("num_planes", C.c_int), ("planes", Plane * 4),
+                ("field", C.c_int), ("first_field", C.c_int),
+                ("prev", C.c_void_p), ("next", C.c_void_p),
                 ("acquire", C.c_void_p), ("release", C.c_void_p),
                 ("repr", ColorRepr), ("color", ColorSpace),
+                ("icc", C.c_void_p), ("profile", IccProfile),
                 ("lut", C.POINTER(CustomLut)), ("lut_type", C.c_int), ("crop", Rect2df),
-                ("rotation", C.c_int), ("user_data", C.c_void_p),
-                ("field", C.c_int), ("first_field", C.c_int),
-                ("prev", C.c_void_p), ("next", C.c_void_p)]
+                ("rotation", C.c_int), ("pixel_aspect_ratio", C.c_float),
+                ("overlays", C.c_void_p), ("num_overlays", C.c_int),
+                ("film_grain", FilmGrainData), ("user_data", C.c_void_p)]
 
 
 class FrameMix(C.Structure):
@@ -384,11 +463,15 @@ class RenderParams(C.Structure):
                 ("force_dither", C.c_bool), ("disable_dither_gamma_correction", C.c_bool),
                 ("disable_fbos", C.c_bool), ("force_low_bit_depth_fbos", C.c_bool),
                 ("dynamic_constants", C.c_bool), ("info_callback", C.c_void_p),
-                ("info_priv", C.c_void_p)]
+                ("info_priv", C.c_void_p),
+                ("allow_delayed_peak_detect", C.c_bool), ("icc_params", C.c_void_p),
+                ("ignore_icc_profiles", C.c_bool), ("lut_entries", C.c_int),
+                ("polar_cutoff", C.c_float), ("skip_target_clearing", C.c_bool),
+                ("blend_against_tiles", C.c_bool)]
 
 
 class DispatchInfo(C.Structure):
-    _fields_ = [("description", C.c_char_p), ("signature", C.c_uint64),
+    _fields_ = [("shader", C.POINTER(ShaderInfo)), ("signature", C.c_uint64),
                 ("samples", C.c_uint64 * 256), ("num_samples", C.c_int), ("last", C.c_uint64),
                 ("peak", C.c_uint64), ("average", C.c_uint64)]
 
@@ -417,7 +500,7 @@ def declare(lib):
         f.argtypes = list(args)
         return f
 
-    fn("pl_log_create", vp, C.c_int, P(LogParams))
+    fn("pl_log_create_365", vp, C.c_int, P(LogParams))
     fn("pl_log_destroy", None, P(vp))
 
     fn("pl_filter_generate", P(Filter), vp, P(FilterParams))
@@ -529,3 +612,42 @@ def declare(lib):
     fn("pl_color_repr_normalize", C.c_float, P(ColorRepr))
     fn("pl_hdr_rescale", C.c_float, C.c_int, C.c_int, C.c_float)
     return lib
+
+
+# C aggregate -> ctypes mirror; tests/test_abi_layout.py checks each against the layout table
+# the C probe prints for include/ (which in turn equals the reference's).
+MIRRORS = {
+    "struct pl_rect2d": Rect2d, "struct pl_rect2df": Rect2df, "struct pl_rect3d": Rect3d,
+    "struct pl_matrix3x3": Matrix3x3, "struct pl_transform3x3": Transform3x3,
+    "struct pl_log_params": LogParams, "struct pl_filter_function": FilterFunction,
+    "struct pl_filter_config": FilterConfig, "struct pl_filter_params": FilterParams,
+    "struct pl_filter_t": Filter, "struct pl_fmt_plane": FmtPlane, "struct pl_fmt_t": Fmt,
+    "struct pl_glsl_version": GlslVersion, "struct pl_gpu_limits": GpuLimits,
+    "struct pl_gpu_pci_address": PciAddress, "struct pl_gpu_handle_caps": HandleCaps,
+    "struct pl_shared_mem": SharedMem, "struct pl_gpu_t": Gpu, "struct pl_hip_t": Hip,
+    "struct pl_hip_params": HipParams, "struct pl_hip_wrap_params": HipWrapParams,
+    "struct pl_tex_params": TexParams, "struct pl_tex_t": Tex,
+    "struct pl_tex_transfer_params": TexTransferParams, "struct pl_shader_params": ShaderParams,
+    "struct pl_shader_info_t": ShaderInfo, "struct pl_shader_res": ShaderRes,
+    "struct pl_sample_src": SampleSrc, "struct pl_deband_params": DebandParams,
+    "struct pl_sample_filter_params": SampleFilterParams, "struct pl_dither_params": DitherParams,
+    "struct pl_error_diffusion_kernel": ErrorDiffusionKernel,
+    "struct pl_error_diffusion_params": ErrorDiffusionParams,
+    "struct pl_dispatch_compute_params": DispatchComputeParams,
+    "struct pl_dispatch_params": DispatchParams, "struct pl_cie_xy": CieXy,
+    "struct pl_cone_params": ConeParams, "struct pl_raw_primaries": RawPrimaries,
+    "struct pl_hdr_bezier": HdrBezier, "struct pl_hdr_metadata": HdrMetadata,
+    "struct pl_color_space": ColorSpace, "struct pl_bit_encoding": BitEncoding,
+    "struct pl_color_repr": ColorRepr, "struct pl_color_adjustment": ColorAdjustment,
+    "struct pl_tone_map_constants": ToneMapConstants,
+    "struct pl_gamut_map_constants": GamutMapConstants, "struct pl_sigmoid_params": SigmoidParams,
+    "struct pl_peak_detect_params": PeakDetectParams, "struct pl_color_map_params": ColorMapParams,
+    "struct pl_color_map_args": ColorMapArgs, "struct pl_plane": Plane,
+    "struct pl_plane_data": PlaneData, "struct pl_custom_lut": CustomLut,
+    "struct pl_icc_profile": IccProfile, "struct pl_av1_grain_data": Av1GrainData,
+    "struct pl_h274_grain_data": H274GrainData, "struct pl_film_grain_data": FilmGrainData,
+    "struct pl_frame": Frame, "struct pl_frame_mix": FrameMix,
+    "struct pl_source_frame": SourceFrame, "struct pl_queue_params": QueueParams,
+    "struct pl_render_params": RenderParams, "struct pl_dispatch_info": DispatchInfo,
+    "struct pl_render_info": RenderInfo, "struct pl_render_errors": RenderErrors,
+}

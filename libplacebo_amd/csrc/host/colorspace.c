@@ -18,6 +18,7 @@
 
 #include "host_common.h"
 #include "colorspace_priv.h"
+#include "cache_priv.h"
 
 #define MAX3(a, b, c) PL_MAX(PL_MAX(a, b), c)
 #define MIXF(a, b, t) ((1 - (t)) * (a) + (t) * (b))
@@ -1288,4 +1289,18 @@ pl_transform3x3 pl_color_repr_decode(struct pl_color_repr *repr,
     repr->sys    = PL_COLOR_SYSTEM_RGB;
     repr->levels = PL_COLOR_LEVELS_FULL;
     return out;
+}
+
+/* ---- ICC profile descriptions (carried through pl_frame, never interpreted here) ---- */
+
+bool pl_icc_profile_equal(const struct pl_icc_profile *a, const struct pl_icc_profile *b)
+{
+    if (a->len != b->len)
+        return false;
+    return !a->len || a->signature == b->signature;    // no profile at all == no profile
+}
+
+void pl_icc_profile_compute_signature(struct pl_icc_profile *profile)
+{
+    profile->signature = profile->len ? plh_mem_hash(profile->data, profile->len) : 0;
 }

@@ -26,7 +26,6 @@ struct pass_timing {
     pl_timer timer;
     struct pl_dispatch_info info;
     int ring;
-    char desc[128];
 };
 
 struct pl_dispatch_t {
@@ -61,8 +60,10 @@ void pl_dispatch_destroy(pl_dispatch *ptr)
         return;
     for (int i = 0; i < dp->num_pool; i++)
         pl_shader_free(&dp->pool[i]);
-    for (int i = 0; i < dp->num_timings; i++)
+    for (int i = 0; i < dp->num_timings; i++) {
         pl_timer_destroy(dp->gpu, &dp->timings[i].timer);
+        pl_shader_info_deref(&dp->timings[i].info.shader);
+    }
     free(dp);
     *ptr = NULL;
 }
@@ -123,8 +124,11 @@ static struct pass_timing *get_timing(pl_dispatch dp, pl_shader sh)
     if (!dp->info_cb)
         return NULL;
     const struct pl_shader_res *res = pl_shader_finalize(sh);
+    if (!res)
+        return NULL;
     // keyed by what the pass does, not by its per-frame values (PRNG seeds, LUT contents)
-    const uint64_t sig = hash_str(res->description) ^ ((uint64_t) res->num_ops << 56) ^
+    const uint64_t sig = hash_str(res->info->description) ^
+                         ((uint64_t) sh->pass.num_ops << 56) ^
                          ((uint64_t) sh->pass.s.type << 48);
     for (int i = 0; i < dp->num_timings; i++) {
         if (dp->timings[i].signature == sig)
@@ -136,17 +140,7 @@ static struct pass_timing *get_timing(pl_dispatch dp, pl_shader sh)
     memset(t, 0, sizeof(*t));
     t->signature = sig;
     t->timer = pl_timer_create(dp->gpu);
-    static const char *const samplers[] = {
-        [PLH_SAMPLE_NONE] = "", [PLH_SAMPLE_NEAREST] = "nearest + ",
-        [PLH_SAMPLE_BILINEAR] = "bilinear + ", [PLH_SAMPLE_BICUBIC] = "bicubic + ",
-        [PLH_SAMPLE_HERMITE] = "hermite + ", [PLH_SAMPLE_GAUSSIAN] = "gaussian + ",
-        [PLH_SAMPLE_OVERSAMPLE] = "oversample + ", [PLH_SAMPLE_POLAR] = "polar + ",
-        [PLH_SAMPLE_ORTHO] = "ortho + ", [PLH_SAMPLE_DEBAND] = "deband + ",
-    };
-    // the shader's description is that of its last stage; prefix the sampler that feeds it
-    snprintf(t->desc, sizeof(t->desc), "%s%s",
-             sh->kind == PLH_SHADER_PASS ? samplers[sh->pass.s.type] : "", res->description);
-    t->info.description = t->desc;
+    t->info.shader = pl_shader_info_ref(res->info);
     t->info.signature = sig;
     return t;
 }
@@ -298,7 +292,7 @@ bool pl_dispatch_finish(pl_dispatch dp, const struct pl_dispatch_params *params)
         plh_timer_end(dp->gpu, timer);
     if (err) {
         pl_msg(dp->log, PL_LOG_ERR, "Failed launching pass '%s': %s",
-               sh->description, plh_strerror(err));
+               sh_description(sh), plh_strerror(err));
         goto done;
     }
     if (!params->timer)
@@ -370,7 +364,7 @@ bool pl_dispatch_compute(pl_dispatch dp, const struct pl_dispatch_compute_params
 
     if (err) {
         pl_msg(dp->log, PL_LOG_ERR, "Failed launching compute shader '%s': %s",
-               sh->description, plh_strerror(err));
+               sh_description(sh), plh_strerror(err));
         goto done;
     }
     if (!params->timer)

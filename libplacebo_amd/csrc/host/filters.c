@@ -503,6 +503,7 @@ pl_filter pl_filter_generate(pl_log log, const struct pl_filter_params *params)
     }
 
     scan_cutoffs(&params->config, params->cutoff, &f->radius, &f->radius_zero);
+    f->radius_cutoff = f->radius;   // legacy alias
 
     const int n = params->lut_entries;
     if (params->config.polar) {

@@ -13,6 +13,7 @@
 #include <libplacebo/hip.h>
 
 #include "gpu_priv.h"
+#include "cache_priv.h"
 
 const struct pl_hip_params pl_hip_default_params = {0};
 
@@ -116,6 +117,52 @@ pl_fmt pl_find_vertex_fmt(pl_gpu gpu, enum pl_fmt_type type, int comps)
     return NULL;
 }
 
+bool pl_fmt_has_modifier(pl_fmt fmt, uint64_t modifier)
+{
+    for (int i = 0; fmt && i < fmt->num_modifiers; i++) {
+        if (fmt->modifiers[i] == modifier)
+            return true;
+    }
+    return false;
+}
+
+pl_fmt pl_find_fourcc(pl_gpu gpu, uint32_t fourcc)
+{
+    for (int n = 0; fourcc && n < gpu->num_formats; n++) {
+        if (gpu->formats[n]->fourcc == fourcc)
+            return gpu->formats[n];
+    }
+    return NULL;    // no DRM interop on this backend: nothing carries a fourcc
+}
+
+size_t pl_var_type_size(enum pl_var_type type)
+{
+    return type == PL_VAR_SINT || type == PL_VAR_UINT || type == PL_VAR_FLOAT ? 4 : 0;
+}
+
+int pl_desc_namespace(pl_gpu gpu, enum pl_desc_type type)
+{
+    (void) gpu;
+    return (int) type;  // bindings are numbered per descriptor type
+}
+
+const struct pl_blend_params pl_alpha_overlay = {
+    .src_rgb = PL_BLEND_SRC_ALPHA,
+    .dst_rgb = PL_BLEND_ONE_MINUS_SRC_ALPHA,
+    .src_alpha = PL_BLEND_ONE,
+    .dst_alpha = PL_BLEND_ONE_MINUS_SRC_ALPHA,
+};
+
+void pl_gpu_set_cache(pl_gpu gpu, pl_cache cache)
+{
+    GPU_PRIV(gpu)->cache = cache;
+}
+
+pl_cache plh_gpu_cache(pl_gpu gpu)
+{
+    return gpu ? GPU_PRIV(gpu)->cache : NULL;
+}
+
 pl_fmt pl_find_named_fmt(pl_gpu gpu, const char *name)
 {
     for (int n = 0; name && n < gpu->num_formats; n++) {
@@ -207,8 +254,14 @@ pl_hip pl_hip_create(pl_log log, const struct pl_hip_params *params)
         .domain = p->info.pci_domain, .bus = p->info.pci_bus, .device = p->info.pci_device,
     };
 
-    for (int i = 0; i < NUM_FMTS; i++)
-        p->fmts[i] = &fmt_table[i].pub;
+    for (int i = 0; i < NUM_FMTS; i++) {
+        p->fmt_store[i] = fmt_table[i];
+        p->fmt_store[i].pub.num_planes = 1;
+        p->fmt_store[i].pub.planes[0].format = &p->fmt_store[i].pub;
+        p->fmt_store[i].pub.signature = plh_mem_hash(fmt_table[i].pub.name,
+                                                     strlen(fmt_table[i].pub.name));
+        p->fmts[i] = &p->fmt_store[i].pub;
+    }
     qsort(p->fmts, NUM_FMTS, sizeof(p->fmts[0]), cmp_fmt);
     gpu->formats = p->fmts;
     gpu->num_formats = NUM_FMTS;
@@ -421,6 +474,80 @@ void pl_tex_clear(pl_gpu gpu, pl_tex dst, const float color[4])
     pl_tex_clear_ex(gpu, dst, c);
 }
 
+// A blit is a pass with a bare nearest / bilinear sampler and no colour stages: the same
+// kernels the renderer uses (the reference emulates blits with a compute shader the same way
+// on backends without a native one, src/gpu/utils.c:852).
+void pl_tex_blit(pl_gpu gpu, const struct pl_tex_blit_params *params)
+{
+    pl_tex src = params->src, dst = params->dst;
+    if (!src || !dst || !src->params.blit_src || !dst->params.blit_dst) {
+        pl_msg(gpu->log, PL_LOG_ERR, "pl_tex_blit: needs a blit_src source and a blit_dst target");
+        return;
+    }
+    if (pl_fmt_is_float(src->params.format) != pl_fmt_is_float(dst->params.format)) {
+        pl_msg(gpu->log, PL_LOG_ERR, "pl_tex_blit: incompatible formats");
+        return;
+    }
+    if (params->sample_mode == PL_TEX_SAMPLE_LINEAR &&
+        !(src->params.format->caps & PL_FMT_CAP_LINEAR)) {
+        pl_msg(gpu->log, PL_LOG_ERR, "pl_tex_blit: source format is not linearly sampleable");
+        return;
+    }
+
+    pl_rect3d sr = params->src_rc, dr = params->dst_rc;
+    if (!sr.x0 && !sr.x1) sr.x1 = src->params.w;
+    if (!sr.y0 && !sr.y1) sr.y1 = PL_MAX(src->params.h, 1);
+    if (!dr.x0 && !dr.x1) dr.x1 = dst->params.w;
+    if (!dr.y0 && !dr.y1) dr.y1 = PL_MAX(dst->params.h, 1);
+    const int w = abs(dr.x1 - dr.x0), h = abs(dr.y1 - dr.y0);
+    if (!w || !h || PL_MIN(dr.x0, dr.x1) < 0 || PL_MIN(dr.y0, dr.y1) < 0 ||
+        PL_MAX(dr.x0, dr.x1) > dst->params.w || PL_MAX(dr.y0, dr.y1) > PL_MAX(dst->params.h, 1)) {
+        pl_msg(gpu->log, PL_LOG_ERR, "pl_tex_blit: target rect outside the texture");
+        return;
+    }
+
+    struct plh_pass *pass = calloc(1, sizeof(*pass));
+    if (!pass)
+        return;
+    struct plh_sampler_args *s = &pass->s;
+    s->type = params->sample_mode == PL_TEX_SAMPLE_LINEAR ? PLH_SAMPLE_BILINEAR : PLH_SAMPLE_NEAREST;
+    plh_tex_view(src, &s->src);
+    const float sx = 1.0f / s->src.w, sy = 1.0f / s->src.h;
+    const float x0 = sx * sr.x0, x1 = sx * sr.x1, y0 = sy * sr.y0, y1 = sy * sr.y1;
+    s->pos[0][0] = x0; s->pos[0][1] = y0;
+    s->pos[1][0] = x1; s->pos[1][1] = y0;
+    s->pos[2][0] = x0; s->pos[2][1] = y1;
+    s->pos[3][0] = x1; s->pos[3][1] = y1;
+    s->pt[0] = sx;
+    s->pt[1] = sy;
+    s->scale = 1.0f;
+    s->comp_mask = 0xf;
+    s->linear = s->type == PLH_SAMPLE_BILINEAR;
+    s->rect_w = abs(sr.x1 - sr.x0);
+    s->rect_h = abs(sr.y1 - sr.y0);
+    s->rect_on_grid = 1;
+
+    plh_tex_view(dst, &pass->dst);
+    pass->width = w;
+    pass->height = h;
+    pass->out_scale[0] = 1.0 / w;
+    pass->out_scale[1] = 1.0 / h;
+    pass->base_x = dr.x0 - (dr.x0 > dr.x1);
+    pass->base_y = dr.y0 - (dr.y0 > dr.y1);
+    pass->dir_x = dr.x0 > dr.x1 ? -1 : 1;
+    pass->dir_y = dr.y0 > dr.y1 ? -1 : 1;
+    // a 1:1 copy returns the texels themselves (what a texture unit does on the grid)
+    if (s->type == PLH_SAMPLE_BILINEAR && s->rect_w == w && s->rect_h == h)
+        s->type = PLH_SAMPLE_NEAREST;
+
+    const int err = plh_launch_pass(GPU_PRIV(gpu)->stream, pass);
+    free(pass);
+    if (err) {
+        pl_msg(gpu->log, PL_LOG_ERR, "pl_tex_blit: %s", plh_strerror(err));
+        GPU_PRIV(gpu)->failed = true;
+    }
+}
+
 static bool tex_transfer(pl_gpu gpu, const struct pl_tex_transfer_params *params, bool upload)
 {
     struct gpu_priv *g = GPU_PRIV(gpu);
@@ -585,6 +712,13 @@ void pl_buf_copy(pl_gpu gpu, pl_buf dst, size_t dst_offset, pl_buf src, size_t s
 {
     plh_copy2d_d2d(GPU_PRIV(gpu)->stream, (uint8_t *) BUF_PRIV(dst)->ptr + dst_offset, size,
                    (uint8_t *) BUF_PRIV(src)->ptr + src_offset, size, size, 1);
+}
+
+bool pl_buf_export(pl_gpu gpu, pl_buf buf)
+{
+    (void) buf;
+    pl_msg(gpu->log, PL_LOG_ERR, "pl_buf_export: buffers of this backend have no exportable handle");
+    return false;
 }
 
 bool pl_buf_poll(pl_gpu gpu, pl_buf buf, uint64_t timeout)

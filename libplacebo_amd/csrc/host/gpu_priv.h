@@ -25,6 +25,8 @@ struct gpu_priv {
     plh_stream stream;
     bool own_stream;
     bool failed;
+    pl_cache cache;     // pl_gpu_set_cache (borrowed)
+    struct fmt_priv fmt_store[16];
     pl_fmt fmts[16];
 };
 
@@ -57,6 +59,7 @@ void plh_tex_view(pl_tex tex, struct plh_view *out);
 void plh_timer_begin(pl_gpu gpu, pl_timer t);
 void plh_timer_end(pl_gpu gpu, pl_timer t);
 
+pl_cache plh_gpu_cache(pl_gpu gpu);
 static inline plh_stream plh_gpu_stream(pl_gpu gpu) { return GPU_PRIV(gpu)->stream; }
 static inline int plh_gpu_device(pl_gpu gpu) { return GPU_PRIV(gpu)->device; }
 

@@ -918,7 +918,7 @@ bool plh_shader_sample_polar_fused(pl_shader sh, const pl_shader pre,
     for (int i = 0; i < pre->num_held; i++)
         sh_hold(sh, pre->held[i]);
     sh_listf(sh, "fused_pre_ops(%d ops of '%s' run per source texel, f16 tile)\n", n,
-             pre->description);
+             sh_description(pre));
     return true;
 }
 

@@ -11,8 +11,74 @@
 
 #include "shaders_priv.h"
 
+/* ---- pl_shader_info: the description of a finished shader, shareable beyond its life ---- */
+
+struct info_obj {
+    struct pl_shader_info_t pub;
+    int refcount;
+    char *text;     // the steps, NUL-separated, followed by the joined description
+};
+
+static pl_shader_info info_create(pl_shader sh)
+{
+    struct info_obj *obj = calloc(1, sizeof(*obj));
+    if (!obj)
+        return NULL;
+    const int n = PL_MAX(sh->num_steps, 1);
+    size_t len = 0;
+    for (int i = 0; i < sh->num_steps; i++)
+        len += strlen(sh->steps[i]) + 1;
+    // steps + joined description ("a + b + c") + fallback
+    obj->text = calloc(1, 2 * len + 3 * n + 32);
+    obj->pub.steps = calloc(n, sizeof(char *));
+    if (!obj->text || !obj->pub.steps) {
+        free(obj->text);
+        free((void *) obj->pub.steps);
+        free(obj);
+        return NULL;
+    }
+    char *w = obj->text;
+    for (int i = 0; i < sh->num_steps; i++) {
+        obj->pub.steps[i] = w;
+        w = stpcpy(w, sh->steps[i]) + 1;
+    }
+    obj->pub.num_steps = sh->num_steps;
+    obj->pub.description = w;
+    if (!sh->num_steps)
+        w = stpcpy(w, "(unknown shader)");
+    for (int i = 0; i < sh->num_steps; i++) {
+        if (i)
+            w = stpcpy(w, " + ");
+        w = stpcpy(w, sh->steps[i]);
+    }
+    obj->pub.params = sh->params;
+    obj->refcount = 1;
+    return &obj->pub;
+}
+
+pl_shader_info pl_shader_info_ref(pl_shader_info info)
+{
+    if (info)
+        __atomic_add_fetch(&((struct info_obj *) info)->refcount, 1, __ATOMIC_RELAXED);
+    return info;
+}
+
+void pl_shader_info_deref(pl_shader_info *pinfo)
+{
+    struct info_obj *obj = pinfo ? (struct info_obj *) *pinfo : NULL;
+    if (!obj)
+        return;
+    *pinfo = NULL;
+    if (__atomic_sub_fetch(&obj->refcount, 1, __ATOMIC_ACQ_REL) > 0)
+        return;
+    free((void *) obj->pub.steps);
+    free(obj->text);
+    free(obj);
+}
+
 static void sh_release(pl_shader sh)
 {
+    pl_shader_info_deref(&sh->info);
     for (int i = 0; i < sh->num_held; i++)
         pl_shader_obj_destroy(&sh->held[i]);
     sh->num_held = 0;
@@ -118,12 +184,21 @@ bool sh_try_compute(pl_shader sh, int bw, int bh, bool flex, size_t mem)
     return true;
 }
 
+// Names the stage being recorded: one entry of pl_shader_info.steps (sh_describef in the
+// reference appends to the same list, src/shaders.c:140-150)
 void sh_describef(pl_shader sh, const char *fmt, ...)
 {
+    if (sh->num_steps == (int) PL_ARRAY_SIZE(sh->steps))
+        return;
     va_list ap;
     va_start(ap, fmt);
-    vsnprintf(sh->description, sizeof(sh->description), fmt, ap);
+    vsnprintf(sh->steps[sh->num_steps++], sizeof(sh->steps[0]), fmt, ap);
     va_end(ap);
+}
+
+const char *sh_description(pl_shader sh)
+{
+    return sh->num_steps ? sh->steps[sh->num_steps - 1] : "(unknown shader)";
 }
 
 void sh_listf(pl_shader sh, const char *fmt, ...)
@@ -166,15 +241,25 @@ const struct pl_shader_res *pl_shader_finalize(pl_shader sh)
         return NULL;
     if (!sh->mutable_)
         return &sh->res;
+    if (!sh->info)
+        sh->info = info_create(sh);
+    if (!sh->info) {
+        sh->failed = true;
+        return NULL;
+    }
     sh->res = (struct pl_shader_res) {
+        .info = sh->info,
         .glsl = sh->listing ? sh->listing : "",
         .name = "main",
-        .description = sh->description[0] ? sh->description : "(unknown shader)",
         .input = sh->input,
         .output = sh->output,
         .compute_group_size = { sh->group_size[0], sh->group_size[1] },
         .compute_shmem = sh->shmem,
-        .num_ops = sh->pass.num_ops,
+        // mirrors of `info` for programs written against older API levels
+        .params = sh->info->params,
+        .steps = sh->info->steps,
+        .num_steps = sh->info->num_steps,
+        .description = sh->info->description,
     };
     sh->mutable_ = false;
     return &sh->res;

@@ -54,7 +54,9 @@ struct pl_shader_t {
     // peak detection request (K10), resolved by dispatch
     bool detect_peak;
 
-    char description[256];
+    char steps[12][96];         // one name per recorded stage (sh_describef)
+    int num_steps;
+    pl_shader_info info;        // built by pl_shader_finalize
     char *listing;
     size_t listing_len, listing_cap;
     struct pl_shader_res res;
@@ -96,6 +98,7 @@ static inline struct pl_glsl_version sh_glsl(const pl_shader sh)
 bool sh_require(pl_shader sh, enum pl_shader_sig insig, int w, int h);
 bool sh_try_compute(pl_shader sh, int bw, int bh, bool flex, size_t mem);
 void sh_describef(pl_shader sh, const char *fmt, ...) __attribute__((format(printf, 2, 3)));
+const char *sh_description(pl_shader sh);    // name of the last recorded stage
 void sh_listf(pl_shader sh, const char *fmt, ...) __attribute__((format(printf, 2, 3)));
 
 // append a colour op; returns NULL (and fails the shader) if the chain is full

@@ -572,22 +572,35 @@ static void map_linear(float *lut, const struct pl_tone_map_params *p)
 
 /* ------------------------------------------------------------------------ */
 
-#define CURVE(sym, nm, desc, scal, fwd, inv) \
+// The trailing four values are the legacy single-parameter description (deprecated since
+// v6.311; the curves themselves read pl_tone_map_constants). Kept for programs that list them.
+#define CURVE(sym, nm, desc, scal, fwd, inv, ...) \
     const struct pl_tone_map_function sym = { .name = nm, .description = desc, \
-        .scaling = scal, .map = fwd, .map_inverse = inv }
+        .scaling = scal, .map = fwd, .map_inverse = inv, __VA_ARGS__ }
+#define LEGACY(what, lo, def, hi) \
+    .param_desc = what, .param_min = lo, .param_def = def, .param_max = hi
 
 CURVE(pl_tone_map_clip,      "clip",      "No tone mapping (clip)",        PL_HDR_NORM, map_identity, map_identity);
-CURVE(pl_tone_map_st2094_40, "st2094-40", "SMPTE ST 2094-40 Annex B",      PL_HDR_NITS, map_st2094_40, NULL);
-CURVE(pl_tone_map_st2094_10, "st2094-10", "SMPTE ST 2094-10 Annex B.2",    PL_HDR_NITS, map_st2094_10, NULL);
-CURVE(pl_tone_map_bt2390,    "bt2390",    "ITU-R BT.2390 EETF",            PL_HDR_PQ,   map_bt2390, NULL);
+CURVE(pl_tone_map_st2094_40, "st2094-40", "SMPTE ST 2094-40 Annex B",      PL_HDR_NITS, map_st2094_40, NULL,
+      LEGACY("Knee point target", 0.00f, 0.70f, 1.00f));
+CURVE(pl_tone_map_st2094_10, "st2094-10", "SMPTE ST 2094-10 Annex B.2",    PL_HDR_NITS, map_st2094_10, NULL,
+      LEGACY("Knee point target", 0.00f, 0.70f, 1.00f));
+CURVE(pl_tone_map_bt2390,    "bt2390",    "ITU-R BT.2390 EETF",            PL_HDR_PQ,   map_bt2390, NULL,
+      LEGACY("Knee offset", 0.50, 1.00, 2.00));
 CURVE(pl_tone_map_bt2446a,   "bt2446a",   "ITU-R BT.2446 Method A",        PL_HDR_NITS, map_bt2446a, map_bt2446a_inv);
-CURVE(pl_tone_map_spline,    "spline",    "Single-pivot polynomial spline", PL_HDR_PQ,  map_spline, map_spline);
-CURVE(pl_tone_map_reinhard,  "reinhard",  "Reinhard",                      PL_HDR_NORM, map_reinhard, NULL);
-CURVE(pl_tone_map_mobius,    "mobius",    "Mobius",                        PL_HDR_NORM, map_mobius, NULL);
+CURVE(pl_tone_map_spline,    "spline",    "Single-pivot polynomial spline", PL_HDR_PQ,  map_spline, map_spline,
+      LEGACY("Contrast", 0.00f, 0.50f, 1.50f));
+CURVE(pl_tone_map_reinhard,  "reinhard",  "Reinhard",                      PL_HDR_NORM, map_reinhard, NULL,
+      LEGACY("Contrast", 0.001, 0.50, 0.99));
+CURVE(pl_tone_map_mobius,    "mobius",    "Mobius",                        PL_HDR_NORM, map_mobius, NULL,
+      LEGACY("Knee point", 0.00, 0.30, 0.99));
 CURVE(pl_tone_map_hable,     "hable",     "Filmic tone-mapping (Hable)",   PL_HDR_NORM, map_hable, NULL);
-CURVE(pl_tone_map_gamma,     "gamma",     "Gamma function with knee",      PL_HDR_NORM, map_gamma, NULL);
-CURVE(pl_tone_map_linear,    "linear",    "Perceptually linear stretch",   PL_HDR_PQ,   map_linear, map_linear);
-CURVE(pl_tone_map_linear_light, "linearlight", "Linear light stretch",     PL_HDR_NORM, map_linear, map_linear);
+CURVE(pl_tone_map_gamma,     "gamma",     "Gamma function with knee",      PL_HDR_NORM, map_gamma, NULL,
+      LEGACY("Knee point", 0.001, 0.30, 1.00));
+CURVE(pl_tone_map_linear,    "linear",    "Perceptually linear stretch",   PL_HDR_PQ,   map_linear, map_linear,
+      LEGACY("Exposure", 0.001, 1.00, 10.0));
+CURVE(pl_tone_map_linear_light, "linearlight", "Linear light stretch",     PL_HDR_NORM, map_linear, map_linear,
+      LEGACY("Exposure", 0.001, 1.00, 10.0));
 
 const struct pl_tone_map_function * const pl_tone_map_functions[] = {
     &pl_tone_map_clip,
