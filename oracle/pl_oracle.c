@@ -30,6 +30,7 @@
  * Compiled with -ffp-contract=off so nothing else fuses.
  */
 #include <math.h>
+#include <stdio.h>
 #include <stdint.h>
 #include <stdlib.h>
 #include <string.h>
@@ -159,6 +160,10 @@ struct orc_src {
     int w, h;
     float rect[4];      // x0 y0 x1 y1 in texels (sh_bind `rect`)
     int address_mode;
+    // Optional: `tex` holds only the texels [rx, rx+rw) x [ry, ry+rh) of the w x h texture
+    // (rw == 0: all of it). Lets a full-size pass be checked on output windows without
+    // materialising the whole intermediate image; touching a texel outside aborts.
+    int rx, ry, rw, rh;
 };
 
 static int wrap(int i, int n, int mode)
@@ -177,9 +182,32 @@ static int wrap(int i, int n, int mode)
 
 static const float *texel(const struct orc_src *s, int x, int y)
 {
-    return s->tex + ((size_t) wrap(y, s->h, s->address_mode) * s->w +
-                     wrap(x, s->w, s->address_mode)) * 4;
+    const int tx = wrap(x, s->w, s->address_mode), ty = wrap(y, s->h, s->address_mode);
+    if (!s->rw)
+        return s->tex + ((size_t) ty * s->w + tx) * 4;
+    if (tx < s->rx || ty < s->ry || tx >= s->rx + s->rw || ty >= s->ry + s->rh) {
+        fprintf(stderr, "oracle: texel (%d, %d) outside the provided region [%d,%d)x[%d,%d)\n",
+                tx, ty, s->rx, s->rx + s->rw, s->ry, s->ry + s->rh);
+        abort();
+    }
+    return s->tex + ((size_t) (ty - s->ry) * s->rw + (tx - s->rx)) * 4;
 }
+
+// Output window for the samplers below: with a window set, only the output pixels
+// [x0, x0+w) x [y0, y0+h) of the out_w x out_h pass are evaluated (same arithmetic: the
+// interpolated attribute still refers to the full pass) and `out` is w x h.
+static struct { int x0, y0, w, h; } g_win;
+ORC_API void orc_set_window(int x0, int y0, int w, int h)
+{
+    g_win.x0 = x0; g_win.y0 = y0; g_win.w = w; g_win.h = h;
+}
+#define WIN_SETUP(out_w, out_h)                                                     \
+    const int wx0 = g_win.w ? g_win.x0 : 0, wy0 = g_win.w ? g_win.y0 : 0;           \
+    const int wx1 = g_win.w ? g_win.x0 + g_win.w : (out_w);                         \
+    const int wy1 = g_win.w ? g_win.y0 + g_win.h : (out_h);                         \
+    const int wstride = wx1 - wx0
+#define WIN_OUT(out, x, y) ((out) + ((size_t) ((y) - wy0) * wstride + ((x) - wx0)) * 4)
+
 
 // tex_coord corners: rect / tex_size (sh_bind, src/shaders.c:541-561)
 static void corners(const struct orc_src *s, float p[4][2], float pt[2])
@@ -266,11 +294,13 @@ ORC_API void orc_sample_simple(const struct orc_src *s, int type, float scale,
         s->rect[0] == truncf(s->rect[0]) && s->rect[1] == truncf(s->rect[1]))
         type = S_NEAREST;
 
-    for (int y = 0; y < out_h; y++) {
-        for (int x = 0; x < out_w; x++) {
+    WIN_SETUP(out_w, out_h);
+    #pragma omp parallel for schedule(dynamic, 4)
+    for (int y = wy0; y < wy1; y++) {
+        for (int x = wx0; x < wx1; x++) {
             const float fx = osx * ((float) x + 0.5f), fy = osy * ((float) y + 0.5f);
             float pos[2] = { attr(p, 0, fx, fy), attr(p, 1, fx, fy) };
-            float *o = out + ((size_t) y * out_w + x) * 4;
+            float *o = WIN_OUT(out, x, y);
             float c[4];
             switch (type) {
             case S_NEAREST: // sampling.c:290-302
@@ -424,8 +454,10 @@ ORC_API void orc_sample_polar(const struct orc_src *s, const float *lut, float r
                                    antiring > 0 };
     const int bound = ceil(radius);
 
-    for (int oy = 0; oy < out_h; oy++) {
-        for (int ox = 0; ox < out_w; ox++) {
+    WIN_SETUP(out_w, out_h);
+    #pragma omp parallel for schedule(dynamic, 4)
+    for (int oy = wy0; oy < wy1; oy++) {
+        for (int ox = wx0; ox < wx1; ox++) {
             const float fx = osx * ((float) ox + 0.5f), fy = osy * ((float) oy + 0.5f);
             const float px = attr(p, 0, fx, fy), py = attr(p, 1, fx, fy);
             // fcoord = fract(pos*size - 0.5); base = texel floor(pos*size - 0.5) (:639-640)
@@ -479,7 +511,7 @@ ORC_API void orc_sample_polar(const struct orc_src *s, const float *lut, float r
             }
 
             // color = scale / wsum * color; AR; alpha (:896-908)
-            float *o = out + ((size_t) oy * out_w + ox) * 4;
+            float *o = WIN_OUT(out, ox, oy);
             const float norm = scale / a.wsum;
             for (int k = 0; k < 4; k++) {
                 float v = norm * a.color[k];
@@ -504,6 +536,7 @@ ORC_API void orc_sample_polar(const struct orc_src *s, const float *lut, float r
 
 ORC_API void orc_op_scale(float *img, size_t npix, const float s[4])
 {
+    #pragma omp parallel for schedule(static) if (npix > 16384)
     for (size_t i = 0; i < npix; i++) {
         for (int c = 0; c < 4; c++)
             img[i * 4 + c] *= s[c];
@@ -512,6 +545,7 @@ ORC_API void orc_op_scale(float *img, size_t npix, const float s[4])
 
 ORC_API void orc_op_quant_f16(float *img, size_t npix)
 {
+    #pragma omp parallel for schedule(static) if (npix > 16384)
     for (size_t i = 0; i < npix * 4; i++)
         img[i] = orc_round_f16(img[i]);
 }
@@ -519,6 +553,7 @@ ORC_API void orc_op_quant_f16(float *img, size_t npix)
 ORC_API void orc_op_affine(float *img, size_t npix, const float m[9], const float c[3])
 {
     // color.rgb = M * color.rgb + c (shaders/colorspace.c:308,569), row-wise
+    #pragma omp parallel for schedule(static) if (npix > 16384)
     for (size_t i = 0; i < npix; i++) {
         float *p = img + i * 4;
         const float r = p[0], g = p[1], b = p[2];
@@ -543,9 +578,12 @@ ORC_API void orc_dither(float *img, int w, int h, const float *matrix, int size,
         // column-major mat2 {{cos r, -sin r}, {sin r * m, cos r * m}} (:185-196)
         rot[0] = cos(r); rot[1] = -sin(r); rot[2] = sin(r) * m; rot[3] = cos(r) * m;
     }
+    // with an output window set (orc_set_window), `img` is that window of the pass
+    const int fx0 = g_win.w ? g_win.x0 : 0, fy0 = g_win.w ? g_win.y0 : 0;
+    #pragma omp parallel for schedule(static)
     for (int y = 0; y < h; y++) {
         for (int x = 0; x < w; x++) {
-            const float fcx = (float) x + 0.5f, fcy = (float) y + 0.5f;
+            const float fcx = (float) (x + fx0) + 0.5f, fcy = (float) (y + fy0) + 0.5f;
             float px = fractf(fcx / (float) size), py = fractf(fcy / (float) size); // :183
             if (temporal) {
                 const float qx = (rot[0] * px + rot[2] * py) + 1.0f;
@@ -812,6 +850,7 @@ ORC_API void orc_linearize(float *img, size_t npix, int trc, float csp_min, floa
 {
     if (trc == T_LINEAR)
         return;
+    #pragma omp parallel for schedule(static) if (npix > 16384)
     for (size_t i = 0; i < npix; i++) {
         float *c = img + i * 4;
         if (trc != T_SCRGB) {
@@ -912,6 +951,7 @@ ORC_API void orc_delinearize(float *img, size_t npix, int trc, float csp_min, fl
 {
     if (trc == T_LINEAR)
         return;
+    #pragma omp parallel for schedule(static) if (npix > 16384)
     for (size_t i = 0; i < npix; i++) {
         float *c = img + i * 4;
         if (black_scaled(trc) && trc != T_HLG && (csp_max != 1 || csp_min != 0)) {   // :740-747
@@ -1006,6 +1046,7 @@ ORC_API void orc_sigmoid(float *img, size_t npix, float center, float slope, int
     const float offset = 1.0 / (1 + expf(slope * center));
     const float scale = 1.0 / (1 + expf(slope * (center - 1))) - offset;
     const float inv_slope = 1.0 / slope, inv_scale = 1.0 / scale, off_scale = offset / scale;
+    #pragma omp parallel for schedule(static) if (npix > 16384)
     for (size_t i = 0; i < npix; i++) {
         float *c = img + i * 4;
         for (int k = 0; k < 3; k++) {
@@ -1019,6 +1060,7 @@ ORC_API void orc_sigmoid(float *img, size_t npix, float center, float slope, int
 // pl_shader_set_alpha pieces, colorspace.c:34-47
 ORC_API void orc_alpha(float *img, size_t npix, int mode)
 {
+    #pragma omp parallel for schedule(static) if (npix > 16384)
     for (size_t i = 0; i < npix; i++) {
         float *c = img + i * 4;
         if (mode == 0) {        // premultiply
@@ -1055,6 +1097,8 @@ ORC_API void orc_detect_peak(const float *img, int pw, int ph, int trc, float cs
     memset(out, 0, sizeof(*out));
     const int nwx = pw / 16, nwy = ph / 16;
     const float cutoff = fmaxf(black_cutoff, 0.0f) * 1e-2f;
+    // workgroups are independent; their integer results are accumulated (order-free)
+    #pragma omp parallel for schedule(dynamic, 1)
     for (int wy = 0; wy < nwy; wy++) {
         for (int wx = 0; wx < nwx; wx++) {
             const uint32_t wg_idx = wy * nwx + wx, slice = wg_idx % O_SLICES;
@@ -1086,6 +1130,8 @@ ORC_API void orc_detect_peak(const float *img, int pw, int ph, int trc, float cs
                         wg_black++;
                 }
             }
+            #pragma omp critical(orc_peak)
+            {
             if (use_hist) {                                                  // :1329-1337
                 if (cutoff)
                     wg_hist[0] -= wg_black;
@@ -1099,6 +1145,7 @@ ORC_API void orc_detect_peak(const float *img, int pw, int ph, int trc, float cs
                 out->frame_sum_pq[slice] += wg_sum / num;
                 if (wg_max > out->frame_max_pq[slice])
                     out->frame_max_pq[slice] = wg_max;
+            }
             }
         }
     }
@@ -1196,6 +1243,7 @@ static float o_lut1d(const float *lut, int n, float x)
 ORC_API void orc_custom_lut(float *img, size_t npix, const float *lut, const int size[3])
 {
     const int sx = size[0], sy = size[1], sz = size[2];
+    #pragma omp parallel for schedule(static) if (npix > 16384)
     for (size_t i = 0; i < npix; i++) {
         float *c = img + i * 4;
         if (!sy) {
@@ -1260,6 +1308,7 @@ ORC_API void orc_extract_features(float *img, size_t npix, const float klms[9])
 {
     const float m1 = pf(O_PQ_M1), m2 = pf(O_PQ_M2), c1 = pf(O_PQ_C1), c2 = pf(O_PQ_C2),
                 c3 = pf(O_PQ_C3);
+    #pragma omp parallel for schedule(static) if (npix > 16384)
     for (size_t i = 0; i < npix; i++) {
         float *c = img + i * 4;
         float lms[3];
@@ -1329,6 +1378,7 @@ ORC_API void orc_color_map(float *img, size_t npix, const struct orc_color_map *
                 c1 = pf(O_PQ_C1), c2 = pf(O_PQ_C2), c3 = pf(O_PQ_C3),
                 im1 = 1.0f / pf(O_PQ_M1), im2 = 1.0f / pf(O_PQ_M2), k10 = pf(10000 / 203.0f),
                 hpi = pf(0.5f / M_PI);
+    #pragma omp parallel for schedule(static) if (npix > 16384)
     for (size_t i = 0; i < npix; i++) {
         float *c = img + i * 4;
         // lms = rgb2lms * rgb; lmspq = PQ(k * lms); ipt = lms2ipt * lmspq         :1792-1799
@@ -1412,8 +1462,10 @@ ORC_API void orc_sample_ortho(const struct orc_src *s, const float *rows, int ro
     const int across_linear = r0v != truncf(r0v);
     const int na = dir ? s->h : s->w, no = dir ? s->w : s->h;
 
-    for (int y = 0; y < out_h; y++) {
-        for (int x = 0; x < out_w; x++) {
+    WIN_SETUP(out_w, out_h);
+    #pragma omp parallel for schedule(dynamic, 4)
+    for (int y = wy0; y < wy1; y++) {
+        for (int x = wx0; x < wx1; x++) {
             const float fx = osx * ((float) x + 0.5f), fy = osy * ((float) y + 0.5f);
             const float px = attr(p, 0, fx, fy), py = attr(p, 1, fx, fy);
             const float pa = dir ? py : px, po = dir ? px : py;
@@ -1469,7 +1521,7 @@ ORC_API void orc_sample_ortho(const struct orc_src *s, const float *rows, int ro
                 for (int k = 0; k < 4; k++)
                     ca[k] = fmaf(w, c[k], ca[k]);                             // :1082
             }
-            float *o = out + ((size_t) y * out_w + x) * 4;
+            float *o = WIN_OUT(out, x, y);
             const float def[4] = {0, 0, 0, 1};
             for (int k = 0; k < 4; k++) {
                 if (use_ar)
@@ -1506,8 +1558,10 @@ ORC_API void orc_deband(const struct orc_src *s, int iterations, float threshold
     mask &= 7u;                                                               // :201
     const float thr = threshold / (1000 * scale);                             // :225
     const float two_pi = pf(M_PI * 2);                                        // "%f"
-    for (int y = 0; y < out_h; y++) {
-        for (int x = 0; x < out_w; x++) {
+    WIN_SETUP(out_w, out_h);
+    #pragma omp parallel for schedule(dynamic, 4)
+    for (int y = wy0; y < wy1; y++) {
+        for (int x = wx0; x < wx1; x++) {
             const float fx = osx * ((float) x + 0.5f), fy = osy * ((float) y + 0.5f);
             const float px = attr(p, 0, fx, fy), py = attr(p, 1, fx, fy);
             float color[4], res[3];
@@ -1550,7 +1604,7 @@ ORC_API void orc_deband(const struct orc_src *s, int iterations, float threshold
                     k++;
                 }
             }
-            float *o = out + ((size_t) y * out_w + x) * 4;
+            float *o = WIN_OUT(out, x, y);
             for (int c = 0; c < 3; c++)
                 o[c] = ((mask & (1u << c)) ? res[c] : color[c]) * scale;      // :270-271
             o[3] = color[3] * scale;

@@ -120,10 +120,12 @@ def resolve(src, dst, tone=b"spline", gamut=b"perceptual", lut_size=256,
                 delin=(int(dst.transfer), dmin, dmax, luma(dst)), tone=tp, gamut=gp)
 
 
-def apply(img, r, lowres=None, strength=0.0):
+def apply(img, r, lowres=None, strength=0.0, prelinearized=False):
     """Full oracle colour-map pipeline on float32 rgba `img` (in place). lowres: per-pixel
-    low-frequency luma for the contrast recovery (orc.feature_luma)."""
-    orc.linearize(img, *r["lin"])
+    low-frequency luma for the contrast recovery (orc.feature_luma). prelinearized: `img` is
+    already in linear light (pl_color_map_args.prelinearized)."""
+    if not prelinearized:
+        orc.linearize(img, *r["lin"])
     if r["need_tone"] or r["need_gamut"]:
         kw = dict(r["kw"])
         if lowres is not None:

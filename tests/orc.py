@@ -20,7 +20,41 @@ _f32p = C.POINTER(C.c_float)
 
 class Src(C.Structure):
     _fields_ = [("tex", _f32p), ("w", C.c_int), ("h", C.c_int),
-                ("rect", C.c_float * 4), ("address_mode", C.c_int)]
+                ("rect", C.c_float * 4), ("address_mode", C.c_int),
+                ("rx", C.c_int), ("ry", C.c_int), ("rw", C.c_int), ("rh", C.c_int)]
+
+
+class Region:
+    """Texels [x0, x0+w) x [y0, y0+h) of a (full_w x full_h) texture: lets the oracle evaluate
+    output windows of a full-size pass without the whole intermediate image."""
+
+    def __init__(self, data, x0, y0, full_w, full_h):
+        self.data = np.ascontiguousarray(data, np.float32)
+        self.x0, self.y0, self.full_w, self.full_h = x0, y0, full_w, full_h
+
+
+class window:
+    """with orc.window(x0, y0, w, h): samplers evaluate only that window of their pass (and
+    return w x h); dither takes its fragment coordinates from it."""
+
+    def __init__(self, x0, y0, w, h):
+        self.win = (x0, y0, w, h)
+
+    def __enter__(self):
+        lib().orc_set_window(*self.win)
+        _WIN.append(self.win)
+        return self
+
+    def __exit__(self, *exc):
+        _WIN.pop()
+        lib().orc_set_window(*(_WIN[-1] if _WIN else (0, 0, 0, 0)))
+
+
+_WIN = []
+
+
+def _out_shape(out_w, out_h):
+    return (_WIN[-1][3], _WIN[-1][2], 4) if _WIN else (out_h, out_w, 4)
 
 
 class OrcFilter(C.Structure):
@@ -83,9 +117,16 @@ def tex_encode(img, fmt):
 
 
 def _src(img, rect, address_mode):
-    img = np.ascontiguousarray(img, np.float32)
-    h, w = img.shape[:2]
-    s = Src(tex=img.ctypes.data_as(_f32p), w=w, h=h, address_mode=address_mode)
+    if isinstance(img, Region):
+        d = img.data
+        s = Src(tex=d.ctypes.data_as(_f32p), w=img.full_w, h=img.full_h,
+                address_mode=address_mode, rx=img.x0, ry=img.y0, rw=d.shape[1], rh=d.shape[0])
+        w, h = img.full_w, img.full_h
+        img = d
+    else:
+        img = np.ascontiguousarray(img, np.float32)
+        h, w = img.shape[:2]
+        s = Src(tex=img.ctypes.data_as(_f32p), w=w, h=h, address_mode=address_mode)
     rect = rect if rect is not None else (0, 0, w, h)
     s.rect = (C.c_float * 4)(*rect)
     return s, img
@@ -94,7 +135,7 @@ def _src(img, rect, address_mode):
 def sample_simple(img, kind, out_w, out_h, rect=None, scale=1.0, address_mode=0,
                   threshold=0.0):
     s, keep = _src(img, rect, address_mode)
-    out = np.empty((out_h, out_w, 4), np.float32)
+    out = np.empty(_out_shape(out_w, out_h), np.float32)
     rw = abs(s.rect[2] - s.rect[0]); rh = abs(s.rect[3] - s.rect[1])
     lib().orc_sample_simple(C.byref(s), kind, C.c_float(scale), C.c_float(out_w / rw),
                             C.c_float(out_h / rh), C.c_float(threshold), out_w, out_h, _p(out))
@@ -106,7 +147,7 @@ def sample_polar(img, lut, radius, radius_zero, out_w, out_h, rect=None, scale=1
     s, keep = _src(img, rect, address_mode)
     lut = np.ascontiguousarray(lut, np.float32)
     assert lut.size == 256
-    out = np.empty((out_h, out_w, 4), np.float32)
+    out = np.empty(_out_shape(out_w, out_h), np.float32)
     lib().orc_sample_polar(C.byref(s), _p(lut), C.c_float(radius), C.c_float(radius_zero),
                            C.c_float(antiring), int(gather_order), C.c_float(scale),
                            C.c_uint(mask), out_w, out_h, _p(out))
@@ -314,7 +355,7 @@ def sample_ortho(img, rows, row_size, direction, out_w, out_h, rect=None, scale=
                  use_linear=False, use_ar=False, antiring=0.0, mask=0xF, address_mode=0):
     s, keep = _src(img, rect, address_mode)
     rows = np.ascontiguousarray(rows, np.float32)
-    out = np.empty((out_h, out_w, 4), np.float32)
+    out = np.empty(_out_shape(out_w, out_h), np.float32)
     lib().orc_sample_ortho(C.byref(s), _p(rows), row_size, rows.shape[1], direction,
                            int(use_linear), int(use_ar), C.c_float(antiring), C.c_float(scale),
                            C.c_uint(mask), out_w, out_h, _p(out))
@@ -324,7 +365,7 @@ def sample_ortho(img, rows, row_size, direction, out_w, out_h, rect=None, scale=
 def deband(img, out_w, out_h, iterations=1, threshold=3.0, radius=16.0, grain=4.0,
            grain_neutral=(0, 0, 0), scale=1.0, mask=0x7, frame_index=0, rect=None, address_mode=0):
     s, keep = _src(img, rect, address_mode)
-    out = np.empty((out_h, out_w, 4), np.float32)
+    out = np.empty(_out_shape(out_w, out_h), np.float32)
     lib().orc_deband(C.byref(s), iterations, C.c_float(threshold), C.c_float(radius),
                      C.c_float(grain), (C.c_float * 3)(*grain_neutral), C.c_float(scale),
                      C.c_uint(mask), C.c_uint(frame_index), out_w, out_h, _p(out))

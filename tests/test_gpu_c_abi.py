@@ -1,0 +1,60 @@
+"""The drop-in boundary exercised from C.
+
+tests/c/render_frame.c is compiled twice (tests/c/Makefile, run by __graft_entry__.build()):
+against include/ and against the REFERENCE's own headers (only <libplacebo/hip.h> comes from
+this repository), both linked against libplacebo_hip.so. Both must render the same frame,
+and that frame must equal the oracle's, bit for bit. The second binary is the proof that
+structs laid out by libplacebo's declarations are what this library reads."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+import orc
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BUILD = os.path.join(ROOT, "tests", "c", "build")
+
+
+def run(binary, out, sw, sh):
+    r = subprocess.run([os.path.join(BUILD, binary), out, str(sw), str(sh)],
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    return r.stdout
+
+
+def test_c_program_renders_through_the_c_abi(gpu, tmp_path):
+    sw, sh = 96, 64
+    ours = os.path.join(BUILD, "render_frame_ours")
+    assert os.path.exists(ours), "tests/c/build/render_frame_ours missing: run build()"
+    log = run("render_frame_ours", str(tmp_path / "ours.raw"), sw, sh)
+    got = np.fromfile(tmp_path / "ours.raw", np.uint16).reshape(2 * sh, 2 * sw, 4)
+
+    # the same frame through the oracle (pattern = the C program's, bench.c:32-51)
+    yc, xc = (sh - 1) / 2.0, (sw - 1) / 2.0
+    y, x = np.mgrid[0:sh, 0:sw].astype(np.float64)
+    r2 = (x - xc) ** 2 + (y - yc) ** 2
+    phi = 1.6180339887498948
+    fr = 0.1 * np.pi * 0.5 / np.sqrt(xc * xc + yc * yc)
+    img = np.empty((sh, sw, 4), np.uint16)
+    for k, f in enumerate((fr, fr / phi, fr / phi / phi)):
+        img[..., k] = np.rint(65535.0 * (0.5 * np.sin(f * r2) + 0.5))
+    img[..., 3] = 65535
+    a = orc.tex_decode(img, "rgba16")
+    a[..., 3] = 1.0
+    a = orc.op_quant_f16(a)
+    w, r, rz = orc.filter_generate_polar(orc.ewa_lanczos())
+    ref = orc.tex_encode(orc.sample_polar(a, w, r, rz, 2 * sw, 2 * sh, mask=0x7), "rgba16")
+    assert np.array_equal(got, ref), (log, int(np.abs(got.astype(int) - ref.astype(int)).max()))
+
+    # and the binary built against libplacebo's own headers
+    if not os.path.exists(os.path.join(BUILD, "render_frame_ref")):
+        pytest.skip("render_frame_ref was not built (reference headers absent at build time)")
+    log2 = run("render_frame_ref", str(tmp_path / "ref.raw"), sw, sh)
+    got2 = np.fromfile(tmp_path / "ref.raw", np.uint16).reshape(2 * sh, 2 * sw, 4)
+    assert np.array_equal(got2, got), (log, log2)
+    # both report the reference's struct sizes
+    assert "sizeof(pl_frame)=736" in log and "sizeof(pl_frame)=736" in log2, (log, log2)
