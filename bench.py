@@ -5,37 +5,41 @@ Contract (see the task statement): `python bench.py --gpus N --steps K --warmup 
 JSON line on rank 0. A "step" is one frame through `pl_render_image` on synthetic input that is
 already resident in HBM.
 
-Workloads (BASELINE.json `configs`):
-  ewa_lanczos_1080p_to_4k_dither10   configs[2], the default: the configuration the north-star
-        target (">= 70 % of HBM roofline on EWA-Lanczos 1080p->4K") and the metric are quoted on.
-        1920x1080 RGBA16 -> 3840x2160, EWA-Lanczos (Jinc) polar upscale + blue-noise dither to
-        10 bit in an RGBA16 target. One launch per frame: the reference's PASS A (plane ->
-        rgba16hf FBO, renderer.c:2064) is folded into the polar kernel as per-source-texel
-        pre-ops (same values, PL_HIP_NO_FUSION=1 restores the two-pass structure).
-  bilinear_1080p_to_4k               configs[1]: bilinear + sRGB passthrough, one pass.
-  lanczos_1080p_to_4k_dither10       the separable (two-pass) Lanczos upscale, same output format
-  nv12_1080p_to_4k_ewa_dither10      NV12 source planes (pl_upload_plane layout), EWA-Lanczos 2x
-  nv12_1080p_to_4k_default_preset    NV12 source, pl_render_default_params untouched
-  default_preset_1080p_to_4k         pl_render_default_params untouched (lanczos, sigmoid, dither)
-  hdr10_4k_tonemap                   configs[3]: 4K BT.2020/PQ -> BT.709 SDR, same-frame peak
-        detection (histogram) + spline tone mapping + perceptual gamut mapping 3D-LUT.
-  ewa_8k_to_4k_deband_tonemap        configs[4], one stream: 8K HDR -> 4K SDR, deband + EWA
-        downscale + tone map.
-  ewa_1080p_to_4k_hdr_tonemap        both halves of the metric's name in one frame: 1080p HDR10
-        -> peak detect -> EWA-Lanczos 2x -> tone/gamut map -> dither -> 4K SDR.
-  mix_24_to_60_ewa_1080p_to_4k       SURVEY 8f rank 3: a 24 fps stream shown at 60 Hz through pl_queue
-        + pl_render_image_mix (oversampling mixer); a step is one vsync.
+`value` answers BASELINE.json's metric, "EWA-Lanczos 1080p->4K + HDR tonemap": the default
+workload `ewa_1080p_to_4k_hdr_tonemap` is one 1920x1080 BT.2020 PQ (HDR10) RGBA16 frame ->
+same-frame peak detection (histogram) -> EWA-Lanczos (Jinc) 2x polar upscale -> tone mapping
+(spline) + gamut mapping (perceptual 3D-LUT) -> BT.709 BT.1886 -> blue-noise dither to 10 bit
+-> 3840x2160 RGBA16. Nothing is skipped or cached between frames.
 
-The default run (N = 1) also reports the two tone-mapping workloads under "companions" in the same
-JSON line (the metric's name reads "EWA-Lanczos 1080p->4K + HDR tonemap"); `value` is the headline
-workload alone.
+The same line carries, per BASELINE.json config, one measured block under "rooflines"
+(frame time, dominant kernel, algorithmic GB/s, fraction of the 8 TB/s HBM peak AND of the
+157.3 TFLOP/s FP32 vector peak):
+  bilinear_1080p_to_4k               configs[1]
+  ewa_lanczos_1080p_to_4k_dither10   configs[2] (the launch the north star's ">= 70 % of HBM
+                                     roofline" target is quoted on)
+  hdr10_4k_tonemap                   configs[3]
+  ewa_8k_to_4k_deband_tonemap        configs[4], one stream (use --scene-peak-allreduce with
+                                     --gpus N for the cross-GPU scene peak)
+Other workloads (--workload): lanczos_1080p_to_4k_dither10, nv12_*, default_preset_1080p_to_4k,
+mix_24_to_60_ewa_1080p_to_4k.
+
+roofline.traffic is MEASURED in the run: bench.py re-launches itself under
+`rocprofv3 --pmc FETCH_SIZE` and `--pmc WRITE_SIZE` (separate passes, gfx950 correction
+FETCH_SIZE x 2, MI355X_MICROARCH.md "HBM") for a few frames and reads the dominant kernel's
+counters; null if rocprofv3 is unavailable.
+
+cpu_baseline is the REFERENCE's own CPU code (filters.c / tone_mapping.c / gamut_mapping.c /
+colorspace.c / dither.c compiled into oracle/_ref/libplref.so, driven by oracle/cpu_baseline.c)
+timed on this box's host cores, 1 thread and all threads, CPU model stated.
 
 Frames rotate over a pool of source/target textures larger than the 256 MiB Infinity Cache so
 that every frame's compulsory traffic really crosses HBM.
 
 Multi-GPU (--gpus N>1, launched by torch.distributed.run): streams are independent, one per
 GPU, no data-path collective -> weak scaling; value = frames of all ranks /
-max-over-ranks time.
+max-over-ranks time. With --scene-peak-allreduce the ranks render frames of ONE scene: after
+every frame's measurement pass the 816-word peak buffer is all-reduced over RCCL (SUM, MAX for
+frame_max_pq) before the tone mapper consumes it (BASELINE configs[4]).
 """
 import argparse
 import ctypes as C
@@ -216,6 +220,18 @@ class Stream:
             q.frames.pop(ident, None)
         q.unmapped.clear()
 
+    def enable_scene_peak_allreduce(self, dist):
+        """BASELINE configs[4]: the ranks render frames of one scene -- every measurement is
+        all-reduced over RCCL (the library's own C entry, on the render stream) before the tone
+        mapper consumes it."""
+        from libplacebo_amd.dist import RcclPeakExchange, rccl_unique_id
+        rank = dist.get_rank() if dist is not None else 0
+        world = dist.get_world_size() if dist is not None else 1
+        box = [rccl_unique_id() if rank == 0 else None]
+        if dist is not None:
+            dist.broadcast_object_list(box, src=0)
+        self.exchange = RcclPeakExchange(self.g, rank, world, box[0])
+
     def step(self):
         if self.queue:
             return self.step_mix()
@@ -225,6 +241,8 @@ class Stream:
 
     def close(self):
         self.g.finish()
+        if getattr(self, "exchange", None):
+            self.exchange.close()
         if self.queue:
             self.queue.destroy()
         self.rr.destroy()
@@ -233,81 +251,247 @@ class Stream:
         self.g.close()
 
 
-def cpu_baseline(workload):
-    """The CPU oracle (a scalar port of the reference's algorithm) timed on the host, single
-    thread, on a bounded sample of the same workload."""
-    import orc
-    import util
-    (sw, sh), (dw, dh), _, _ = WORKLOADS[workload]
-    ortho = workload.startswith("lanczos") or "default_preset" in workload
-    if workload.startswith("bilinear") or workload.startswith("ewa_lanczos") or \
-            workload.startswith("nv12_1080p_to_4k_ewa") or ortho:
-        cw, ch = sw, sh  # one whole frame: ~10 s of scalar CPU work
-        src = util.chirp_rgba16(sw, sh)
-        tex = orc.tex_decode(src, "rgba16")
-        t0 = time.perf_counter()
-        if workload.startswith("bilinear"):
-            out = orc.sample_simple(tex, orc.S_BILINEAR, cw * 2, ch * 2)
-        elif ortho:
-            # the two passes of the separable Lanczos scaler (the colour stages of the preset
-            # are not part of this sample)
-            rows, n, _, _ = orc.filter_generate_ortho(orc.lanczos())
-            rows = orc.ortho_lut_rows(rows, n, False)
-            img = orc.op_quant_f16(orc.sample_simple(tex, orc.S_BILINEAR, cw, ch))
-            tmp = orc.op_quant_f16(orc.sample_ortho(img, rows, n, 1, cw, ch * 2))
-            out = orc.sample_ortho(tmp, rows, n, 0, cw * 2, ch * 2)
-            orc.dither(out, util.blue_noise(pl), 10)
-        else:
-            img = orc.op_quant_f16(orc.sample_simple(tex, orc.S_BILINEAR, cw, ch))
-            w, r, rz = orc.filter_generate_polar(orc.ewa_lanczos())
-            out = orc.sample_polar(img, w, r, rz, cw * 2, ch * 2, mask=0x7)
-            orc.dither(out, util.blue_noise(pl), 10)
-        orc.tex_encode(out, "rgba16")
-        dt = time.perf_counter() - t0
-        npx, sample = cw * 2 * ch * 2, f"1 frame {cw}x{ch}->{cw * 2}x{ch * 2}"
+FP32_PEAK_TFLOPS = 157.3    # vector FP32, MI355X_MICROARCH.md
+
+# FP32 operations per output pixel of the arithmetic the reference's shaders specify (SURVEY.md
+# 8d counts the taps the same way): polar tap = length (5) + compare (1) + LUT lerp (4) + 3
+# channels x FMA (6) + weight sum (1) = 17 flop, 32 taps survive the radius test at 2x, 120 at
+# 0.5x; colour map = 6 pow(vec3) + 3 3x3 matrices + LUT lerps ~ 300 flop (pow = exp2 + log2 + mul
+# counted as 3).
+FLOPS_PER_PX = {
+    "bilinear_1080p_to_4k": 4 * 3 * 4,
+    "ewa_lanczos_1080p_to_4k_dither10": 32 * 17 + 12,
+    "ewa_1080p_to_4k_hdr_tonemap": 32 * 17 + 300 + 12,
+    "hdr10_4k_tonemap": 300,
+    "ewa_8k_to_4k_deband_tonemap": 120 * 17,
+}
+
+BASELINE_CONFIGS = {
+    "bilinear_1080p_to_4k": "configs[1]",
+    "ewa_lanczos_1080p_to_4k_dither10": "configs[2]",
+    "hdr10_4k_tonemap": "configs[3]",
+    "ewa_8k_to_4k_deband_tonemap": "configs[4] (one stream)",
+}
+
+
+def kernel_symbol(workload, name):
+    """rocprofv3 kernel name prefix of the pass described by `name`"""
+    if "peak detection" in name and "scaling" not in name and "map" not in name:
+        return "k_pass_peak"
+    if "polar" in name:
+        return "k_polar_pp"
+    if "ortho" in name:
+        return "k_ortho_fast"
+    if "debanding" in name:
+        return "k_deband"
+    if workload == "bilinear_1080p_to_4k":
+        return "k_bilinear_fast"
+    if "tone map" in name or "gamut map" in name:
+        return "k_colormap"
+    return "k_pass_generic"
+
+
+def measure_passes(st, frames=48):
+    """per-pass GPU time: HIP events recorded around every launch on the stream the launches go
+    to (pl_timer), reported through pl_render_params.info_callback"""
+    st.pass_ns.clear()
+    for _ in range(frames):
+        st.step()
+    st.g.finish()
+    st.step()           # drains the last timers
+    st.g.finish()
+    return {k: float(np.mean(v)) for k, v in st.pass_ns.items() if v}
+
+
+def roofline_block(workload, passes):
+    (sw, sh), (dw, dh), alg_bytes, dominant = WORKLOADS[workload]
+    if dominant:
+        name = max((k for k in passes if dominant in k), key=lambda k: passes[k],
+                   default=max(passes, key=passes.get))
     else:
-        # colour-mapping workloads: a 1920x1080 crop through linearize -> IPT/PQ -> tone LUT
-        # -> gamut 3D-LUT -> delinearize (the per-pixel part of the pass structure)
-        import colormap_ref as cr
-        cw, ch = 1920, 1080
-        img = (synthetic_frame(workload, cw, ch).astype(np.float32) / 65535.0)
-        r = cr.resolve(cr.make_csp(pl.PRIM["bt2020"], pl.TRC["pq"], max_luma=1000.0),
-                       cr.make_csp(pl.PRIM["bt709"], pl.TRC["bt1886"]))
-        t0 = time.perf_counter()
-        cr.apply(img, r)
-        dt = time.perf_counter() - t0
-        npx, sample = cw * ch, f"{cw}x{ch} crop, colour-mapping stage only"
-    return {
-        "value": round(npx / dt / 1e6, 4),
-        "unit": "Mpixels/s",
-        "cores": 1,
-        "kind": "port",
-        "sample": f"{sample} of the same workload, oracle/pl_oracle.c (scalar C, -O2), {dt:.1f} s",
+        name = max(passes, key=passes.get)
+    kern_s = passes[name] * 1e-9
+    frame_s = sum(passes.values()) * 1e-9
+    achieved = alg_bytes / kern_s / 1e9
+    flops = FLOPS_PER_PX.get(workload)
+    block = {
+        "bound": "hbm",
+        "kernel": f"{kernel_symbol(workload, name)} ({name})",
+        "achieved": round(achieved, 1),
+        "peak": HBM_PEAK_GBS,
+        "unit": "GB/s",
+        "frac": round(achieved / HBM_PEAK_GBS, 4),
+        "traffic": None,
+        "kernel_us": round(kern_s * 1e6, 2),
+        "algorithmic_bytes": alg_bytes,
+        "passes_us": {k: round(v / 1e3, 2) for k, v in passes.items()},
+        "frame_gpu_us": round(frame_s * 1e6, 2),
+        "frame_frac": round(alg_bytes / frame_s / 1e9 / HBM_PEAK_GBS, 4),
     }
+    if flops:
+        tf = flops * dw * dh / frame_s / 1e12
+        block["fp32_tflops"] = round(tf, 2)
+        block["fp32_frac"] = round(tf / FP32_PEAK_TFLOPS, 4)
+        block["fp32_flop_per_px"] = flops
+    return block
 
 
-def companion(device, workload, steps=80, warmup=10):
-    """value / ms_per_step of another workload, timed like the main one (single stream)."""
-    (sw, sh), (dw, dh), _, _ = WORKLOADS[workload]
-    per_frame = (sw * sh + dw * dh) * 8
-    st = Stream(device, workload, max(4, -(-800_000_000 // per_frame)))
+def measure_traffic(workload, symbol, timeout=240):
+    """HBM bytes per launch of the kernel whose name starts with `symbol`: two separate
+    rocprofv3 --pmc passes over a short run of this script (FETCH_SIZE, WRITE_SIZE; KiB), gfx950
+    correction FETCH_SIZE x 2 (MI355X_MICROARCH.md "HBM"). None if rocprofv3 is unavailable."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+    rocprof = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(rocprof):
+        return None
+    out = {}
+    for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+        with tempfile.TemporaryDirectory(dir="/tmp") as td:
+            env = dict(os.environ, TMPDIR="/tmp", PL_BENCH_CHILD="1")
+            cmd = [rocprof, "--pmc", counter, "--kernel-trace", "--output-format", "csv", "-d", td,
+                   "--", sys.executable, os.path.abspath(__file__), "--workload", workload,
+                   "--steps", "6", "--warmup", "2", "--bare"]
+            try:
+                r = subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, text=True,
+                                   timeout=timeout)
+            except Exception:
+                return None
+            if r.returncode != 0:
+                return None
+            vals = []
+            for fn in glob.glob(os.path.join(td, "**", "*counter_collection.csv"), recursive=True):
+                for row in csv.DictReader(open(fn)):
+                    if row["Kernel_Name"].startswith(symbol) and row["Counter_Name"] == counter:
+                        vals.append(float(row["Counter_Value"]))
+            if not vals:
+                return None
+            # a kernel symbol can cover several launches per frame (e.g. two colour passes):
+            # keep the launches of the largest variant
+            top = max(vals)
+            vals = [v for v in vals if v > 0.5 * top]
+            out[counter] = sum(vals) / len(vals) * 1024.0
+    return {"bytes": int(2 * out["FETCH_SIZE"] + out["WRITE_SIZE"]),
+            "fetch_bytes": int(2 * out["FETCH_SIZE"]), "write_bytes": int(out["WRITE_SIZE"]),
+            "method": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, FETCH x2 (gfx950)"}
+
+
+def cpu_model():
+    try:
+        for ln in open("/proc/cpuinfo"):
+            if ln.startswith("model name"):
+                return ln.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def cpu_baseline(budget_s=25.0):
+    """The REFERENCE's own CPU code (oracle/_ref/libplref.so = filters.c, tone_mapping.c,
+    gamut_mapping.c, colorspace.c, dither.c compiled as they lie; per-pixel driver
+    oracle/cpu_baseline.c) on this box's host cores: BASELINE configs[0] (pl_filter_sample direct
+    and 256-entry LUT EWA, 256^2 -> 512^2), and a bounded sample of the metric's workload
+    (EWA-Lanczos 2x + blue-noise dither, HDR tone map), 1 thread and all threads."""
+    import orc
+    if not orc.have_ref():
+        return None
+    L = orc.ref()
+    L.plcb_ewa_r32f.restype = C.c_double
+    nthreads = os.cpu_count() or 1
+    rng = np.random.default_rng(1)
+
+    def vp(a):
+        return a.ctypes.data_as(C.c_void_p)
+
+    t_start = time.perf_counter()
+    out = {"unit": "Mpixels/s", "kind": "reference", "cores": nthreads, "cpu": cpu_model(),
+           "code": "oracle/_ref/libplref.so: the reference's filters.c / tone_mapping.c / "
+                   "gamut_mapping.c / colorspace.c / dither.c (gcc -O2 -fno-math-errno "
+                   "-fno-signed-zeros -fno-trapping-math), per-pixel loops oracle/cpu_baseline.c"}
+    # configs[0]
+    src = rng.random((256, 256), dtype=np.float32)
+    dst = np.empty((512, 512), np.float32)
+    cfg0 = {}
+    for label, direct in (("pl_filter_sample_direct", 1), ("lut256_lerp", 0)):
+        for th in (1, nthreads):
+            L.plcb_ewa_r32f(vp(src), 256, 256, vp(dst), 512, 512, direct, th)   # warm the team
+            t0 = time.perf_counter()
+            taps = L.plcb_ewa_r32f(vp(src), 256, 256, vp(dst), 512, 512, direct, th)
+            dt = time.perf_counter() - t0
+            cfg0[f"{label}_{th}t"] = round(512 * 512 / dt / 1e6, 3)
+        cfg0["taps_per_px"] = round(taps, 1)
+    out["configs0_ewa_256_to_512"] = cfg0
+
+    # the metric's workload, bounded: a 960x540 HDR crop -> 1920x1080
+    sw, sh, dw, dh = 960, 540, 1920, 1080
+    img = (synthetic_frame("ewa_1080p_to_4k_hdr_tonemap", sw, sh).astype(np.float32) / 65535.0)
+    up = np.empty((dh, dw, 4), np.float32)
+    lut_s = C.c_double()
+    res = {}
+    for th in (nthreads, 1):
+        if th == 1 and time.perf_counter() - t_start > budget_s:
+            break
+        t0 = time.perf_counter()
+        L.plcb_ewa_rgb_dither(vp(img), sw, sh, vp(up), dw, dh, 10, th)
+        t1 = time.perf_counter()
+        tm = up.copy()
+        t2 = time.perf_counter()
+        L.plcb_tone_map(vp(tm), C.c_size_t(dw * dh), C.c_float(1000.0), th, C.byref(lut_s))
+        t3 = time.perf_counter()
+        ewa_s, map_s = t1 - t0, (t3 - t2) - lut_s.value
+        res[th] = (dw * dh / (ewa_s + map_s) / 1e6, dw * dh / ewa_s / 1e6, dw * dh / map_s / 1e6)
+    out["value"] = round(res[nthreads][0], 3)
+    out["ewa_dither_only"] = round(res[nthreads][1], 3)
+    out["tone_map_only"] = round(res[nthreads][2], 3)
+    if 1 in res:
+        out["single_thread"] = {"value": round(res[1][0], 3), "ewa_dither_only": round(res[1][1], 3),
+                                "tone_map_only": round(res[1][2], 3)}
+    out["lut_generation_s"] = round(lut_s.value, 4)
+    out["sample"] = (f"{sw}x{sh} -> {dw}x{dh} crop of the metric's workload: LUT EWA-Lanczos on 3 "
+                     f"channels + blue-noise dither, then the per-pixel HDR10 -> BT.709 tone/gamut "
+                     f"map; value = output Mpx/s of both stages with {nthreads} threads")
+    return out
+
+
+def run_timed(st, steps, warmup, sync=None, barrier=None):
     for _ in range(warmup):
         st.step()
     st.g.finish()
+    if sync:
+        sync()
+    if barrier:
+        barrier()
     t0 = time.perf_counter()
     for _ in range(steps):
         st.step()
     st.g.finish()
-    dt = time.perf_counter() - t0
-    errors = st.rr.errors()
+    if sync:
+        sync()
+    elapsed = time.perf_counter() - t0
+    if barrier:
+        barrier()
+    return elapsed
+
+
+def config_block(device, workload, steps=60, warmup=8):
+    """One BASELINE config measured like the headline (single stream): frame rate + roofline."""
+    (sw, sh), (dw, dh), _, _ = WORKLOADS[workload]
+    per_frame = (sw * sh + dw * dh) * 8
+    st = Stream(device, workload, max(4, -(-800_000_000 // per_frame)))
+    dt = run_timed(st, steps, warmup)
+    block = roofline_block(workload, measure_passes(st, 24))
+    block.update(config=BASELINE_CONFIGS.get(workload), value=round(steps * dw * dh / dt / 1e6, 1),
+                 unit="Mpixels/s", ms_per_step=round(dt / steps * 1e3, 4), steps=steps,
+                 render_errors=st.rr.errors())
     st.close()
-    return {"value": round(steps * dw * dh / dt / 1e6, 1), "unit": "Mpixels/s",
-            "ms_per_step": round(dt / steps * 1e3, 4), "steps": steps, "render_errors": errors}
+    return block
 
 
 def baseline_metric():
-    """BASELINE.json's metric name (the driver matches on it); the workload measured is named in
-    config.workload."""
+    """BASELINE.json's metric name (the driver matches on it)."""
     try:
         with open(os.path.join(ROOT, "BASELINE.json")) as f:
             return json.load(f)["metric"]
@@ -318,17 +502,24 @@ def baseline_metric():
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)
-    ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--workload", default="ewa_lanczos_1080p_to_4k_dither10",
-                    choices=sorted(WORKLOADS))
+    ap.add_argument("--steps", type=int, default=300)
+    ap.add_argument("--warmup", type=int, default=30)
+    ap.add_argument("--workload", default="ewa_1080p_to_4k_hdr_tonemap", choices=sorted(WORKLOADS))
     ap.add_argument("--pool", type=int, default=0,
                     help="rotating source/target textures per stream (0 = enough to exceed "
                          "the 256 MiB Infinity Cache)")
+    ap.add_argument("--scene-peak-allreduce", action="store_true",
+                    help="ranks render frames of one scene: all-reduce the peak-detection buffer "
+                         "over RCCL every frame (BASELINE configs[4])")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-companions", action="store_true",
-                    help="skip the tone-mapping workloads reported next to the default one")
+                    help="skip the per-config 'rooflines' blocks")
+    ap.add_argument("--no-traffic", action="store_true", help="skip the rocprofv3 --pmc passes")
+    ap.add_argument("--bare", action="store_true",
+                    help="timed loop only (what the --pmc child processes run)")
     args = ap.parse_args()
+    if args.bare:
+        args.no_cpu_baseline = args.no_companions = args.no_traffic = True
 
     import torch
 
@@ -351,72 +542,18 @@ def main():
     per_frame = (sw * sh + dw * dh) * 8
     pool = args.pool or max(4, -(-800_000_000 // per_frame))
     st = Stream(local_rank, args.workload, pool)
+    if args.scene_peak_allreduce:
+        st.enable_scene_peak_allreduce(dist)
 
-    for _ in range(args.warmup):
-        st.step()
-    st.g.finish()
-    torch.cuda.synchronize()
-    barrier()
-
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        st.step()
-    st.g.finish()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    barrier()
-
+    elapsed = run_timed(st, args.steps, args.warmup, sync=torch.cuda.synchronize, barrier=barrier)
     if dist is not None:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
-    # ---- per-pass GPU time: HIP events recorded around every launch on the stream the
-    # launches go to (pl_timer), reported through pl_render_params.info_callback ------------
-    roofline = None
+    out = None
     if rank == 0:
-        st.pass_ns.clear()
-        for _ in range(48):
-            st.step()
-        st.g.finish()
-        st.step()           # drains the last timers
-        st.g.finish()
-        passes = {k: float(np.mean(v)) for k, v in st.pass_ns.items() if v}
-        if dominant:
-            name = max((k for k in passes if dominant in k), key=lambda k: passes[k],
-                       default=max(passes, key=passes.get))
-        else:
-            name = max(passes, key=passes.get)
-        kern_s = passes[name] * 1e-9
-        frame_s = sum(passes.values()) * 1e-9
-        achieved = alg_bytes / kern_s / 1e9
-        traffic = None
-        prof = os.path.join(ROOT, "profiles", "hbm_traffic.json")
-        if os.path.exists(prof):
-            with open(prof) as f:
-                traffic = json.load(f).get(args.workload)
-        symbol = ("k_pass_peak" if "peak detection" in name else
-                  "k_polar_pp" if name.startswith("polar") else
-                  "k_ortho_fast" if name.startswith("ortho") else
-                  "k_deband" if name.startswith("deband") else
-                  # (bilinear + fused epilogue -> rgba16 has its own kernel, k_pass.hip)
-                  "k_bilinear_fast" if args.workload == "bilinear_1080p_to_4k" else "k_pass_generic")
-        roofline = {
-            "bound": "hbm",
-            "kernel": f"{symbol} ({name})",   # HIP kernel (rocprofv3 name) + pass description
-            "achieved": round(achieved, 1),
-            "peak": HBM_PEAK_GBS,
-            "unit": "GB/s",
-            "frac": round(achieved / HBM_PEAK_GBS, 4),
-            "traffic": traffic,
-            "kernel_us": round(kern_s * 1e6, 2),
-            "algorithmic_bytes": alg_bytes,
-            "passes_us": {k: round(v / 1e3, 2) for k, v in passes.items()},
-            "frame_gpu_us": round(frame_s * 1e6, 2),
-            "frame_frac": round(alg_bytes / frame_s / 1e9 / HBM_PEAK_GBS, 4),
-        }
-
-    if rank == 0:
+        roofline = None if args.bare else roofline_block(args.workload, measure_passes(st))
         frames = args.steps * world
         out = {
             "metric": baseline_metric(),
@@ -441,20 +578,29 @@ def main():
                 "api": "pl_queue_update + pl_render_image_mix" if args.workload.startswith("mix") else "pl_render_image",
                 "measured": "output Mpixels/s through pl_render_image, one independent stream per GPU",
                 "render_errors": st.rr.errors(),   # pl_render_error bits: no stage may be disabled
-                "parallelism": f"{world} independent stream(s), one per GPU",
+                "peak_exchanges": (st.exchange.stats() if getattr(st, "exchange", None) else None),
+                "parallelism": f"{world} independent stream(s), one per GPU" +
+                               (", scene peak all-reduced over RCCL every frame"
+                                if args.scene_peak_allreduce else ""),
             },
             "roofline": roofline,
         }
-        if not args.no_cpu_baseline and world == 1:    # (rank 0 at N = 1 only)
-            out["cpu_baseline"] = cpu_baseline(args.workload)
-
     st.close()
+
+    if rank == 0 and world == 1 and not args.bare:
+        if not args.no_traffic and roofline:
+            t = measure_traffic(args.workload, roofline["kernel"].split(" ")[0])
+            if t:
+                roofline["traffic"] = t["bytes"]
+                roofline["traffic_detail"] = t
+        if not args.no_companions:
+            out["rooflines"] = {w: config_block(local_rank, w) for w in BASELINE_CONFIGS
+                                if w != args.workload}
+        if not args.no_cpu_baseline:
+            cb = cpu_baseline()
+            if cb:
+                out["cpu_baseline"] = cb
     if rank == 0:
-        # The metric's name also carries "+ HDR tonemap": the same run reports the tone-mapping
-        # workloads next to the headline (shorter timed loops; not part of `value`).
-        if world == 1 and not args.no_companions and args.workload == "ewa_lanczos_1080p_to_4k_dither10":
-            out["companions"] = {w: companion(local_rank, w)
-                                 for w in ("ewa_1080p_to_4k_hdr_tonemap", "hdr10_4k_tonemap")}
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.destroy_process_group()

@@ -61,6 +61,34 @@ PL_API void *pl_hip_tex_ptr(pl_tex tex, size_t *out_row_pitch);
 // Device pointer of a buffer created by this backend.
 PL_API void *pl_hip_buf_ptr(pl_buf buf);
 
+/* ---- multi-GPU: one scene rendered by several GPUs --------------------------
+ * Streams are independent; the only state worth sharing is the HDR peak measurement when the
+ * ranks render tiles or frames of ONE scene and must tone-map with one common peak. The
+ * measurement is 816 x uint32 (the reference's `peak_buf_data`, shaders/colorspace.c:936-942):
+ * every word is a SUM across ranks, except words [36, 48) (frame_max_pq), which are a MAX.
+ * All integer, hence order-independent: every rank derives bit-identical tone curves.
+ */
+
+// Called on the host right before a finished measurement is read back, with the device
+// buffer and the stream it was produced on. The callback must leave the reduced words in
+// place, ordered on `stream` (or synchronise itself).
+typedef void (*pl_hip_peak_exchange_fn)(void *priv, void *words, size_t size, void *stream);
+
+// Install (fn != NULL) or remove the exchange for every measurement made on `gpu`.
+PL_API void pl_hip_set_peak_exchange(pl_gpu gpu, pl_hip_peak_exchange_fn fn, void *priv);
+
+// Ready-made exchange over RCCL (xGMI inside a node). `nccl_comm` is an initialised
+// ncclComm_t whose local device is the one `gpu` runs on; librccl.so is resolved at run time
+// (dlopen), the library has no link-time dependency on it. Typical use:
+//     pl_hip_rccl x = pl_hip_rccl_create(gpu, comm);
+//     pl_hip_set_peak_exchange(gpu, pl_hip_rccl_peak_exchange, x);
+typedef struct pl_hip_rccl_t *pl_hip_rccl;
+PL_API pl_hip_rccl pl_hip_rccl_create(pl_gpu gpu, void *nccl_comm);
+PL_API void pl_hip_rccl_destroy(pl_hip_rccl *x);
+PL_API void pl_hip_rccl_peak_exchange(void *priv, void *words, size_t size, void *stream);
+// number of exchanges performed / nonzero RCCL status seen so far
+PL_API int pl_hip_rccl_stats(pl_hip_rccl x, int *out_errors);
+
 PL_API_END
 
 #endif // LIBPLACEBO_HIP_H_

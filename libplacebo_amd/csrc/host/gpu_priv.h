@@ -26,6 +26,8 @@ struct gpu_priv {
     bool own_stream;
     bool failed;
     pl_cache cache;     // pl_gpu_set_cache (borrowed)
+    pl_hip_peak_exchange_fn peak_exchange;  // pl_hip_set_peak_exchange
+    void *peak_exchange_priv;
     struct fmt_priv fmt_store[16];
     pl_fmt fmts[16];
 };
@@ -60,6 +62,8 @@ void plh_timer_begin(pl_gpu gpu, pl_timer t);
 void plh_timer_end(pl_gpu gpu, pl_timer t);
 
 pl_cache plh_gpu_cache(pl_gpu gpu);
+// runs the installed cross-GPU exchange (if any) on a finished peak measurement
+void plh_gpu_peak_exchange(pl_gpu gpu, void *words, size_t size);
 static inline plh_stream plh_gpu_stream(pl_gpu gpu) { return GPU_PRIV(gpu)->stream; }
 static inline int plh_gpu_device(pl_gpu gpu) { return GPU_PRIV(gpu)->device; }
 

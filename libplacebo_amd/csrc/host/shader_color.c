@@ -579,6 +579,9 @@ static void update_peak_buf(pl_gpu gpu, struct sh_color_map_obj *obj, bool force
     if (!force && params->allow_delayed && pl_buf_poll(gpu, obj->peak.buf, 0))
         return;
 
+    // ranks rendering one scene fold their measurements together first (hip.h)
+    plh_gpu_peak_exchange(gpu, pl_hip_buf_ptr(obj->peak.buf), sizeof(struct peak_buf_data));
+
     struct peak_buf_data data = {0};
     const bool ok = pl_buf_read(gpu, obj->peak.buf, 0, &data, sizeof(data));
     if (ok && data.frame_wg_count[0] > 0) {

@@ -45,3 +45,77 @@ def allreduce_renderer_peak(renderer, dist):
     allreduce_peak_buffer(buf, dist)
     torch.cuda.synchronize()
     return True
+
+
+# ---- the C-level exchange (include/libplacebo/hip.h) over a communicator of our own ----------
+import ctypes as _C
+import glob as _glob
+import os as _os
+
+
+def _load_rccl():
+    """librccl: the copy torch ships if torch is importable (one RCCL per process), else ROCm's"""
+    cands = []
+    try:
+        import torch
+        cands += _glob.glob(_os.path.join(_os.path.dirname(torch.__file__), "lib", "librccl.so*"))
+    except Exception:
+        pass
+    cands += ["librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so"]
+    for c in cands:
+        try:
+            return _C.CDLL(c, mode=_os.RTLD_GLOBAL)
+        except OSError:
+            continue
+    raise OSError("librccl.so not found")
+
+
+class _UniqueId(_C.Structure):
+    _fields_ = [("internal", _C.c_char * 128)]
+
+
+def rccl_unique_id():
+    """ncclGetUniqueId -> bytes (rank 0 creates it, every rank must receive the same one)"""
+    uid = _UniqueId()
+    rc = _load_rccl().ncclGetUniqueId(_C.byref(uid))
+    assert rc == 0, f"ncclGetUniqueId: {rc}"
+    return bytes(uid)
+
+
+class RcclPeakExchange:
+    """ncclCommInitRank + pl_hip_rccl_create + pl_hip_set_peak_exchange on one HipGpu: from then
+    on every HDR peak measurement made on that GPU is all-reduced across the communicator
+    before it is consumed (same-frame or delayed)."""
+
+    def __init__(self, gpu, rank, world, unique_id, device=None):
+        from . import lib
+        self.gpu, self.L, self.rccl = gpu, lib(), _load_rccl()
+        if device is not None:
+            hip = _C.CDLL("libamdhip64.so")
+            assert hip.hipSetDevice(int(device)) == 0
+        uid = _UniqueId.from_buffer_copy(unique_id)
+        self.comm = _C.c_void_p()
+        self.rccl.ncclCommInitRank.argtypes = [_C.POINTER(_C.c_void_p), _C.c_int, _UniqueId, _C.c_int]
+        rc = self.rccl.ncclCommInitRank(_C.byref(self.comm), int(world), uid, int(rank))
+        assert rc == 0, f"ncclCommInitRank: {rc}"
+        self.L.pl_hip_rccl_create.restype = _C.c_void_p
+        self.L.pl_hip_rccl_create.argtypes = [_C.c_void_p, _C.c_void_p]
+        self.x = _C.c_void_p(self.L.pl_hip_rccl_create(gpu.gpu, self.comm))
+        assert self.x, gpu.messages[-3:]
+        fn = _C.cast(self.L.pl_hip_rccl_peak_exchange, _C.c_void_p)
+        self.L.pl_hip_set_peak_exchange.argtypes = [_C.c_void_p, _C.c_void_p, _C.c_void_p]
+        self.L.pl_hip_set_peak_exchange(gpu.gpu, fn, self.x)
+
+    def stats(self):
+        err = _C.c_int()
+        self.L.pl_hip_rccl_stats.argtypes = [_C.c_void_p, _C.POINTER(_C.c_int)]
+        n = self.L.pl_hip_rccl_stats(self.x, _C.byref(err))
+        return n, err.value
+
+    def close(self):
+        self.L.pl_hip_set_peak_exchange(self.gpu.gpu, None, None)
+        self.gpu.finish()
+        self.L.pl_hip_rccl_destroy.argtypes = [_C.POINTER(_C.c_void_p)]
+        self.L.pl_hip_rccl_destroy(_C.byref(self.x))
+        self.rccl.ncclCommDestroy.argtypes = [_C.c_void_p]
+        self.rccl.ncclCommDestroy(self.comm)

@@ -47,5 +47,8 @@ g++ -std=c++20 -O2 -fPIC -w -DPL_STATIC -I$OUT/gen -I$REF/src/include -I$REF/src
     -c "$REF/src/convert.cc" -o "$OUT/obj/convert.o"
 # ref_shim.c is OUR glue (exposes a few internals as plain C-ABI for ctypes)
 gcc $CFLAGS -c "$HERE/ref_shim.c" -o "$OUT/obj/ref_shim.o"
-g++ -shared -Wl,--no-undefined -Wl,-Bsymbolic -o "$OUT/libplref.so" $OBJS "$OUT/obj/convert.o" "$OUT/obj/ref_shim.o" -lm -lpthread
+# cpu_baseline.c is OUR per-pixel driver around the reference's CPU functions (bench.py's
+# cpu_baseline leg, kind "reference"); built with the reference's own flags + OpenMP
+gcc $CFLAGS -fopenmp -c "$HERE/cpu_baseline.c" -o "$OUT/obj/cpu_baseline.o"
+g++ -shared -fopenmp -Wl,--no-undefined -Wl,-Bsymbolic -o "$OUT/libplref.so" $OBJS "$OUT/obj/convert.o" "$OUT/obj/ref_shim.o" "$OUT/obj/cpu_baseline.o" -lm -lpthread
 echo "built $OUT/libplref.so"

@@ -1,0 +1,89 @@
+"""The one cross-GPU exchange of the path on real device buffers (VERDICT r01
+item 9): the peak measurement is handed to the installed exchange right before the host
+consumes it. (a) the library's RCCL entry over a world-size-1 communicator (all that one GPU can
+host): same picture, exchanges counted, no RCCL error; (b) a host callback that plays "a second
+rank measured the identical tile": SUM words double, MAX words stay -- averages, percentiles and
+therefore the picture must not move."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import libplacebo_amd as pl
+from libplacebo_amd import _capi as capi
+
+pytestmark = pytest.mark.gpu
+
+
+def render_hdr(gpu, img):
+    h, w = img.shape[:2]
+    rr = pl.Renderer(gpu)
+    src = gpu.tex_create(w, h, "rgba16", img)
+    dst = gpu.tex_create(w, h, "rgba16")
+    ok = rr.render(pl.frame(src, components=3, color=pl.color_space("bt2020", "pq")),
+                   pl.frame(dst, color=pl.color_space("bt709", "bt1886")),
+                   pl.render_params("default", dither_params=None))
+    assert ok and rr.errors() == 0, gpu.messages[-4:]
+    out = dst.download()
+    meta = capi.HdrMetadata()
+    assert pl.lib().pl_renderer_get_hdr_metadata(rr.rr, C.byref(meta))
+    src.destroy(); dst.destroy(); rr.destroy()
+    return out, (meta.max_pq_y, meta.avg_pq_y)
+
+
+def frame(w=192, h=128):
+    from test_gpu_fullsize import hdr_frame16
+    return hdr_frame16(w, h)
+
+
+def test_rccl_exchange_world_size_one(gpu):
+    from libplacebo_amd.dist import RcclPeakExchange, rccl_unique_id
+    img = frame()
+    ref, meta_ref = render_hdr(gpu, img)
+    try:
+        ex = RcclPeakExchange(gpu, 0, 1, rccl_unique_id())
+    except OSError as e:
+        pytest.skip(f"no RCCL: {e}")
+    try:
+        got, meta = render_hdr(gpu, img)
+        n, errors = ex.stats()
+    finally:
+        ex.close()
+    assert n >= 1 and errors == 0, (n, errors, gpu.messages[-3:])
+    assert meta == meta_ref
+    assert np.array_equal(got, ref)
+    # and with the exchange removed again nothing is called
+    again, _ = render_hdr(gpu, img)
+    assert np.array_equal(again, ref)
+
+
+def test_exchange_hook_sees_the_buffer_before_it_is_consumed(gpu):
+    hip = C.CDLL("libamdhip64.so")
+    calls = []
+
+    @C.CFUNCTYPE(None, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p)
+    def second_identical_rank(priv, words, size, stream):
+        assert size == 816 * 4
+        assert hip.hipStreamSynchronize(C.c_void_p(stream)) == 0
+        buf = np.zeros(816, np.uint32)
+        assert hip.hipMemcpy(buf.ctypes.data_as(C.c_void_p), C.c_void_p(words), size, 2) == 0
+        calls.append(buf.copy())
+        mx = buf[36:48].copy()
+        buf *= 2                # SUM with an identical rank
+        buf[36:48] = mx         # MAX with an identical rank
+        assert hip.hipMemcpy(C.c_void_p(words), buf.ctypes.data_as(C.c_void_p), size, 1) == 0
+
+    img = frame()
+    ref, meta_ref = render_hdr(gpu, img)
+    L = pl.lib()
+    L.pl_hip_set_peak_exchange.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+    L.pl_hip_set_peak_exchange(gpu.gpu, C.cast(second_identical_rank, C.c_void_p), None)
+    try:
+        got, meta = render_hdr(gpu, img)
+    finally:
+        L.pl_hip_set_peak_exchange(gpu.gpu, None, None)
+    assert len(calls) == 1
+    m = calls[0]
+    assert m[0:12].sum() == (192 // 16) * (128 // 16)      # a finished measurement
+    assert meta == meta_ref, (meta, meta_ref)
+    assert np.array_equal(got, ref)
