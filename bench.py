@@ -358,16 +358,22 @@ def measure_traffic(workload, symbol, timeout=240):
             try:
                 r = subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, text=True,
                                    timeout=timeout)
-            except Exception:
+            except Exception as e:
+                print(f"bench: traffic probe failed to run: {e}", file=sys.stderr)
                 return None
             if r.returncode != 0:
+                print(f"bench: traffic probe ({counter}) exited {r.returncode}:\n"
+                      f"{(r.stdout + r.stderr)[-1500:]}", file=sys.stderr)
                 return None
             vals = []
             for fn in glob.glob(os.path.join(td, "**", "*counter_collection.csv"), recursive=True):
                 for row in csv.DictReader(open(fn)):
-                    if row["Kernel_Name"].startswith(symbol) and row["Counter_Name"] == counter:
+                    if symbol in row["Kernel_Name"] and row["Counter_Name"] == counter:
                         vals.append(float(row["Counter_Value"]))
             if not vals:
+                print(f"bench: traffic probe ({counter}): no launches of {symbol}* in "
+                      f"{glob.glob(os.path.join(td, '**', '*.csv'), recursive=True)}",
+                      file=sys.stderr)
                 return None
             # a kernel symbol can cover several launches per frame (e.g. two colour passes):
             # keep the launches of the largest variant
@@ -483,8 +489,9 @@ def config_block(device, workload, steps=60, warmup=8):
     st = Stream(device, workload, max(4, -(-800_000_000 // per_frame)))
     dt = run_timed(st, steps, warmup)
     block = roofline_block(workload, measure_passes(st, 24))
-    block.update(config=BASELINE_CONFIGS.get(workload), value=round(steps * dw * dh / dt / 1e6, 1),
-                 unit="Mpixels/s", ms_per_step=round(dt / steps * 1e3, 4), steps=steps,
+    block.update(config=BASELINE_CONFIGS.get(workload),
+                 mpixels_per_s=round(steps * dw * dh / dt / 1e6, 1),
+                 ms_per_step=round(dt / steps * 1e3, 4), steps=steps,
                  render_errors=st.rr.errors())
     st.close()
     return block

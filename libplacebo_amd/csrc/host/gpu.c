@@ -172,6 +172,18 @@ pl_fmt pl_find_named_fmt(pl_gpu gpu, const char *name)
     return NULL;
 }
 
+/* Test hook (tests/test_render_plan.py): a format description without a device, so that the
+ * renderer's planner can be exercised on CPU-only hosts. */
+PL_API pl_fmt plh_test_format(const char *name);
+pl_fmt plh_test_format(const char *name)
+{
+    for (int i = 0; i < NUM_FMTS; i++) {
+        if (!strcmp(fmt_table[i].pub.name, name))
+            return &fmt_table[i].pub;
+    }
+    return NULL;
+}
+
 /* ------------------------------------------------------------------------ */
 /* backend object                                                            */
 

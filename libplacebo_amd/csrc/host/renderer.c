@@ -1,146 +1,36 @@
 /*
- * libplacebo-hip — pl_renderer: the pl_render_image hot path.
+ * libplacebo-hip — pl_renderer: executor of the pl_render_image hot path.
  *
- * Host-side pass graph of the reference's src/renderer.c, restated for the op-recording
- * shaders of this backend. Same stages, same order, same decisions:
+ * render_plan.c decides, this file does: it turns the planner's decisions into recorded
+ * shaders (pl_shader_* calls, i.e. op lists for the HIP kernels) and dispatches them. A frame
+ * moves through four stages, the same ones the reference's src/renderer.c has, with a pass
+ * boundary (round trip through an rgba16hf image) exactly where the reference has one, because
+ * that rounding is part of the numerics:
  *
- *   pass_fix_frames     crop rounding, bit-depth / colour-space inference   renderer.c:3068-3293
- *   pass_read_image     [deband] -> sample plane -> decode -> premultiply  :1553-1960
- *   pass_scale_main     sampler choice, [peak detect], linearize/sigmoidize,
- *                       PASS A into an FBO, main scaler, unsigmoidize       :597-682, :1964-2087
- *   pass_convert_colors [PASS B for same-frame peak], colour mapping        :2157-2280
- *   pass_output_target  background, encode, dither / error diffusion,
- *                       1/scale, swizzle, final pass into the target        :2586-2960
+ *   read     planes -> one image on the reference plane's grid: [deband], sample, merge,
+ *            decode, premultiply                                    (reference :1553-1960)
+ *   scale    [peak], linearize / sigmoidize, main scaler            (:1964-2087)
+ *   colours  alpha mode, LUTs, tone + gamut mapping                 (:2157-2280)
+ *   output   background, encode, dither / error diffusion, 1/scale, swizzle, store per plane
+ *                                                                   (:2586-2960)
  *
- * A pass boundary (FBO) appears exactly where the reference has one; everything between two
- * boundaries runs fused in one HIP launch (sampler + colour ops).
+ * Everything between two boundaries is ONE kernel launch. Where the main scaler is a polar
+ * filter and what precedes it is a plain fetch plus colour ops, even that boundary is folded
+ * into the polar kernel (the ops run on the source texels while they are staged, with the
+ * rgba16hf rounding the intermediate image would have applied): same values, one pass less.
  *
- * Scope: packed, semi-planar and planar (subsampled) frames in and out, rotation, custom LUTs,
- * contrast recovery, frame mixing (pl_render_image_mix). Hooks, ICC, overlays, blending,
- * deinterlacing and distortion are outside the hot path and rejected with an error.
+ * Outside the scope of this backend: hooks, blending onto the target,
+ * deinterlacing, distortion (refused); ICC profiles, overlays, film grain (ignored with an
+ * error bit / warning).
  */
 #include <math.h>
 #include <stdlib.h>
 #include <string.h>
 
-#include <libplacebo/renderer.h>
-
-#include "shaders_priv.h"
-
-#define MAX_FBOS 16
-enum { LUT_IMAGE, LUT_TARGET, LUT_PARAMS };
-#define MAX_MIX_FRAMES 16        // renderer.c:3610
-#define MAX_CACHED_FRAMES 32
-
-struct sampler {
-    pl_shader_obj upscaler_state;
-    pl_shader_obj downscaler_state;
-};
-
-struct pl_renderer_t {
-    pl_gpu gpu;
-    pl_dispatch dp;
-    pl_log log;
-    enum pl_render_error errors;
-
-    pl_tex fbos[MAX_FBOS];
-    int num_fbos;
-
-    struct sampler sampler_main;
-    struct sampler sampler_src;
-    struct sampler sampler_contrast;             // feature map of the contrast recovery
-    struct sampler samplers_aux[PL_MAX_PLANES];  // chroma / alpha plane scalers
-    struct sampler samplers_dst[PL_MAX_PLANES];  // planar output
-    pl_shader_obj tone_map_state;
-    pl_shader_obj dither_state;
-    pl_shader_obj lut_state[3];         // LUT_IMAGE, LUT_TARGET, LUT_PARAMS
-    int prev_dither;
-
-    // frame mixing cache (pl_render_image_mix, renderer.c:82-110 `struct cached_frame`)
-    struct cached_frame {
-        uint64_t signature;
-        uint64_t params_hash;       // of the params it was rendered with
-        struct pl_color_space color;
-        struct pl_color_repr repr;
-        pl_tex tex;
-        int comps;
-        pl_rect2df crop;
-        bool evict;                 // for garbage collection
-    } frames[MAX_CACHED_FRAMES];
-    int num_frames;
-    pl_tex frame_fbos[MAX_CACHED_FRAMES];   // textures of evicted frames, for reuse
-    int num_frame_fbos;
-};
-
-enum sampler_type {
-    SAMPLER_DIRECT,     // pick based on texture caps
-    SAMPLER_NEAREST,
-    SAMPLER_BICUBIC,
-    SAMPLER_HERMITE,
-    SAMPLER_GAUSSIAN,
-    SAMPLER_COMPLEX,    // polar / separable filters
-    SAMPLER_OVERSAMPLE,
-};
-
-enum sampler_dir { SAMPLER_NOOP, SAMPLER_UP, SAMPLER_DOWN };
-enum sampler_usage { SAMPLER_MAIN, SAMPLER_PLANE, SAMPLER_LOWPASS };
-
-struct sampler_info {
-    const struct pl_filter_config *config;
-    enum sampler_usage usage;
-    enum sampler_type type;
-    enum sampler_dir dir;
-    enum sampler_dir dir_sep[2];
-};
-
-// An image in flight: either a recorded-but-not-yet-dispatched shader or a texture
-struct img {
-    pl_shader sh;
-    pl_tex tex;
-    int w, h;
-    pl_rect2df rect;
-    struct pl_color_repr repr;
-    struct pl_color_space color;
-    int comps;
-    pl_fmt fmt;             // FBO format override
-    const char *err_msg;
-    enum pl_render_error err_enum;
-    pl_tex err_tex;
-    pl_tex sh_origin;       // texture that `sh` started from as a plain 1:1 fetch (img_sh)
-};
-
-struct pass_state {
-    pl_renderer rr;
-    const struct pl_render_params *params;
-    struct pl_frame image, target;
-    pl_rect2d dst_rect;
-    pl_rect2df ref_rect;
-    struct img img;
-    pl_fmt fbofmt[5];
-    bool fbos_used[MAX_FBOS];
-    bool need_peak_fbo;
-    bool acquired_image, acquired_target;
-    struct pl_render_info info;
-    pl_rotation rotation;   // logical end-to-end rotation
-};
-
-static void info_callback(void *priv, const struct pl_dispatch_info *dinfo)
-{
-    struct pass_state *pass = priv;
-    const struct pl_render_params *params = pass->params;
-    if (!params->info_callback)
-        return;
-    pass->info.pass = dinfo;
-    params->info_callback(params->info_priv, &pass->info);
-    pass->info.index++;
-}
-
-#define RR_ERR(rr, ...)  pl_msg((rr)->log, PL_LOG_ERR, __VA_ARGS__)
-#define PL_WARN_RR(rr, ...) pl_msg((rr)->log, PL_LOG_WARN, __VA_ARGS__)
-#define RR_WARN(rr, ...) pl_msg((rr)->log, PL_LOG_WARN, __VA_ARGS__)
-#define RR_INFO(rr, ...) pl_msg((rr)->log, PL_LOG_INFO, __VA_ARGS__)
+#include "renderer_priv.h"
 
 const struct pl_render_params pl_render_fast_params = { PL_RENDER_DEFAULTS };
+
 const struct pl_render_params pl_render_default_params = {
     PL_RENDER_DEFAULTS
     .upscaler           = &pl_filter_lanczos,
@@ -149,6 +39,7 @@ const struct pl_render_params pl_render_default_params = {
     .dither_params      = &pl_dither_default_params,
     .peak_detect_params = &pl_peak_detect_default_params,
 };
+
 const struct pl_render_params pl_render_high_quality_params = {
     PL_RENDER_DEFAULTS
     .upscaler           = &pl_filter_ewa_lanczossharp,
@@ -160,9 +51,11 @@ const struct pl_render_params pl_render_high_quality_params = {
     .deband_params      = &pl_deband_default_params,
 };
 
+/* ---- object ---------------------------------------------------------------------------- */
+
 pl_renderer pl_renderer_create(pl_log log, pl_gpu gpu)
 {
-    pl_renderer rr = calloc(1, sizeof(*rr));
+    struct pl_renderer_t *rr = calloc(1, sizeof(*rr));
     if (!rr)
         return NULL;
     rr->gpu = gpu;
@@ -175,51 +68,45 @@ pl_renderer pl_renderer_create(pl_log log, pl_gpu gpu)
     return rr;
 }
 
-static void sampler_destroy(struct sampler *s)
+static void slot_release(struct scaler_slot *slot)
 {
-    pl_shader_obj_destroy(&s->upscaler_state);
-    pl_shader_obj_destroy(&s->downscaler_state);
-}
-
-static void frame_cache_flush(pl_renderer rr)
-{
-    for (int i = 0; i < rr->num_frames; i++)
-        pl_tex_destroy(rr->gpu, &rr->frames[i].tex);
-    for (int i = 0; i < rr->num_frame_fbos; i++)
-        pl_tex_destroy(rr->gpu, &rr->frame_fbos[i]);
-    rr->num_frames = rr->num_frame_fbos = 0;
+    pl_shader_obj_destroy(&slot->up);
+    pl_shader_obj_destroy(&slot->down);
 }
 
 void pl_renderer_flush_cache(pl_renderer rr)
 {
-    frame_cache_flush(rr);
+    for (int i = 0; i < rr->num_cached; i++)
+        pl_tex_destroy(rr->gpu, &rr->cache[i].tex);
+    for (int i = 0; i < rr->num_spare; i++)
+        pl_tex_destroy(rr->gpu, &rr->spare[i]);
     for (int i = 0; i < rr->num_fbos; i++)
         pl_tex_destroy(rr->gpu, &rr->fbos[i]);
-    rr->num_fbos = 0;
+    rr->num_cached = rr->num_spare = rr->num_fbos = 0;
     pl_reset_detected_peak(rr->tone_map_state);
 }
 
-void pl_renderer_destroy(pl_renderer *p_rr)
+void pl_renderer_destroy(pl_renderer *ptr)
 {
-    pl_renderer rr = *p_rr;
+    pl_renderer rr = ptr ? *ptr : NULL;
     if (!rr)
         return;
-    pl_gpu_finish(rr->gpu);
+    pl_gpu_finish(rr->gpu);     // nothing recorded may still reference our objects
     pl_renderer_flush_cache(rr);
-    sampler_destroy(&rr->sampler_main);
-    sampler_destroy(&rr->sampler_src);
-    sampler_destroy(&rr->sampler_contrast);
+    slot_release(&rr->scale_main);
+    slot_release(&rr->scale_ref);
+    slot_release(&rr->scale_contrast);
     for (int i = 0; i < PL_MAX_PLANES; i++) {
-        sampler_destroy(&rr->samplers_aux[i]);
-        sampler_destroy(&rr->samplers_dst[i]);
+        slot_release(&rr->scale_plane[i]);
+        slot_release(&rr->scale_out[i]);
     }
+    for (int i = 0; i < RR_LUT_COUNT; i++)
+        pl_shader_obj_destroy(&rr->lut_state[i]);
     pl_shader_obj_destroy(&rr->tone_map_state);
     pl_shader_obj_destroy(&rr->dither_state);
-    for (int i = 0; i < 3; i++)
-        pl_shader_obj_destroy(&rr->lut_state[i]);
     pl_dispatch_destroy(&rr->dp);
     free(rr);
-    *p_rr = NULL;
+    *ptr = NULL;
 }
 
 struct pl_render_errors pl_renderer_get_errors(pl_renderer rr)
@@ -229,11 +116,7 @@ struct pl_render_errors pl_renderer_get_errors(pl_renderer rr)
 
 void pl_renderer_reset_errors(pl_renderer rr, const struct pl_render_errors *errors)
 {
-    if (!errors) {
-        rr->errors = PL_RENDER_ERR_NONE;
-        return;
-    }
-    rr->errors &= ~errors->errors;
+    rr->errors = errors ? rr->errors & ~errors->errors : PL_RENDER_ERR_NONE;
 }
 
 bool pl_renderer_get_hdr_metadata(pl_renderer rr, struct pl_hdr_metadata *metadata)
@@ -246,1299 +129,961 @@ pl_shader_obj pl_hip_renderer_tone_map_state(pl_renderer rr)
     return rr->tone_map_state;
 }
 
-/* ---- FBOs (find_fbo_format :383-434, get_fbo :448-503) ----------------------------------- */
-
-static void find_fbo_format(struct pass_state *pass)
+static void raise(pl_renderer rr, enum pl_render_error bit, enum pl_log_level lev, const char *msg)
 {
-    const struct pl_render_params *params = pass->params;
-    pl_renderer rr = pass->rr;
-    if (params->disable_fbos || (rr->errors & PL_RENDER_ERR_FBO) || pass->fbofmt[4])
+    RR_LOG(rr, lev, "%s", msg);
+    rr->errors |= bit;
+}
+
+/* ---- intermediate images ------------------------------------------------------------------ */
+
+// Preference order for the intermediate format (reference :383-434): 16-bit float first, then
+// 16-bit integer, then 8 bit; linearly sampleable before merely sampleable.
+static void choose_fbo_formats(struct frame_job *job)
+{
+    pl_renderer rr = job->rr;
+    struct rp_caps *caps = &job->caps;
+    if (job->params->disable_fbos || (rr->errors & PL_RENDER_ERR_FBO) || caps->fbo[4])
         return;
 
-    static const struct { enum pl_fmt_type type; int depth; enum pl_fmt_caps caps; } configs[] = {
-        {PL_FMT_FLOAT, 16, PL_FMT_CAP_LINEAR},
-        {PL_FMT_FLOAT, 16, PL_FMT_CAP_SAMPLEABLE},
-        {PL_FMT_UNORM, 16, PL_FMT_CAP_LINEAR},
-        {PL_FMT_SNORM, 16, PL_FMT_CAP_LINEAR},
-        {PL_FMT_UNORM, 16, PL_FMT_CAP_SAMPLEABLE},
-        {PL_FMT_SNORM, 16, PL_FMT_CAP_SAMPLEABLE},
-        {PL_FMT_UNORM, 8, PL_FMT_CAP_LINEAR},
-        {PL_FMT_UNORM, 8, PL_FMT_CAP_SAMPLEABLE},
+    static const struct candidate {
+        enum pl_fmt_type type;
+        int depth;
+        bool linear;
+    } order[] = {
+        { PL_FMT_FLOAT, 16, true }, { PL_FMT_FLOAT, 16, false },
+        { PL_FMT_UNORM, 16, true }, { PL_FMT_SNORM, 16, true },
+        { PL_FMT_UNORM, 16, false }, { PL_FMT_SNORM, 16, false },
+        { PL_FMT_UNORM, 8, true }, { PL_FMT_UNORM, 8, false },
     };
 
-    for (size_t i = 0; i < sizeof(configs) / sizeof(configs[0]); i++) {
-        if (params->force_low_bit_depth_fbos && configs[i].depth > 8)
+    for (size_t i = 0; i < PL_ARRAY_SIZE(order); i++) {
+        const struct candidate *c = &order[i];
+        if (c->depth > 8 && job->params->force_low_bit_depth_fbos)
             continue;
-        pl_fmt fmt = pl_find_fmt(rr->gpu, configs[i].type, 4, configs[i].depth, 0,
-                                 PL_FMT_CAP_RENDERABLE | configs[i].caps);
-        if (!fmt)
+        const enum pl_fmt_caps need = PL_FMT_CAP_RENDERABLE |
+            (c->linear ? PL_FMT_CAP_LINEAR : PL_FMT_CAP_SAMPLEABLE);
+        pl_fmt four = pl_find_fmt(rr->gpu, c->type, 4, c->depth, 0, need);
+        if (!four)
             continue;
-        pass->fbofmt[4] = fmt;
-        for (int c = 3; c >= 1; c--) {
-            pass->fbofmt[c] = pl_find_fmt(rr->gpu, configs[i].type, c, configs[i].depth, 0,
-                                          fmt->caps);
-            pass->fbofmt[c] = PL_DEF(pass->fbofmt[c], pass->fbofmt[c + 1]);
+        caps->fbo[4] = four;
+        // narrower variants with the same capabilities, else the next wider one
+        for (int n = 3; n >= 1; n--) {
+            pl_fmt f = pl_find_fmt(rr->gpu, c->type, n, c->depth, 0, four->caps);
+            caps->fbo[n] = f ? f : caps->fbo[n + 1];
         }
         return;
     }
-
-    RR_WARN(rr, "Found no renderable FBO format! Most features disabled");
-    rr->errors |= PL_RENDER_ERR_FBO;
+    raise(rr, PL_RENDER_ERR_FBO, PL_LOG_WARN,
+          "Found no renderable FBO format! Most features disabled");
 }
 
-static pl_tex get_fbo(struct pass_state *pass, int w, int h, pl_fmt fmt, int comps)
+// An unused pooled image that fits (w, h, fmt) best, recreated to fit exactly
+static pl_tex borrow_fbo(struct frame_job *job, int w, int h, pl_fmt fmt, int comps)
 {
-    pl_renderer rr = pass->rr;
-    comps = PL_DEF(comps, 4);
-    fmt = PL_DEF(fmt, pass->fbofmt[comps]);
+    pl_renderer rr = job->rr;
+    if (!fmt)
+        fmt = job->caps.fbo[comps ? comps : 4];
     if (!fmt)
         return NULL;
 
-    const struct pl_tex_params params = {
-        .w = w, .h = h, .format = fmt,
-        .sampleable = true, .renderable = true,
-        .storable = fmt->caps & PL_FMT_CAP_STORABLE,
-    };
-
-    // best fit among the unused FBOs: |dw| + |dh| + 1000 * (format mismatch)
-    int best_idx = -1, best_diff = 0;
+    int pick = -1, pick_cost = 0;
     for (int i = 0; i < rr->num_fbos; i++) {
-        if (pass->fbos_used[i])
+        if (job->fbo_busy[i])
             continue;
-        const int diff = abs(rr->fbos[i]->params.w - w) + abs(rr->fbos[i]->params.h - h) +
-                         (rr->fbos[i]->params.format != fmt ? 1000 : 0);
-        if (best_idx < 0 || diff < best_diff) {
-            best_idx = i;
-            best_diff = diff;
+        const struct pl_tex_params *have = &rr->fbos[i]->params;
+        const int cost = abs(have->w - w) + abs(have->h - h) + (have->format == fmt ? 0 : 1000);
+        if (pick < 0 || cost < pick_cost) {
+            pick = i;
+            pick_cost = cost;
         }
     }
-    if (best_idx < 0) {
-        if (rr->num_fbos == MAX_FBOS)
+    if (pick < 0) {
+        if (rr->num_fbos == RR_MAX_FBOS)
             return NULL;
-        best_idx = rr->num_fbos++;
-        rr->fbos[best_idx] = NULL;
+        pick = rr->num_fbos++;
+        rr->fbos[pick] = NULL;
     }
-    if (!pl_tex_recreate(rr->gpu, &rr->fbos[best_idx], &params))
+
+    const struct pl_tex_params want = {
+        .w = w, .h = h, .format = fmt,
+        .sampleable = true, .renderable = true,
+        .storable = !!(fmt->caps & PL_FMT_CAP_STORABLE),
+    };
+    if (!pl_tex_recreate(rr->gpu, &rr->fbos[pick], &want))
         return NULL;
-    pass->fbos_used[best_idx] = true;
-    return rr->fbos[best_idx];
+    job->fbo_busy[pick] = true;
+    return rr->fbos[pick];
 }
 
-// Forcibly convert an img to `tex`, dispatching where necessary (:505-547)
-static pl_tex img_tex(struct pass_state *pass, struct img *img)
+// true if `rec` would do nothing but copy `copy_of`: then that texture is the answer
+static bool is_pure_copy(const struct work_image *img)
 {
+    const pl_shader sh = img->rec;
+    pl_tex o = img->copy_of;
+    if (!sh || !o || img->store_as || sh->kind != PLH_SHADER_PASS || pl_shader_is_failed(sh))
+        return false;
+    const struct plh_pass *p = &sh->pass;
+    const bool plain_fetch = p->s.type == PLH_SAMPLE_NEAREST || p->s.type == PLH_SAMPLE_BILINEAR;
+    return plain_fetch && !p->num_ops && !p->num_pre_ops && p->s.scale == 1.0f &&
+           !sh->detect_peak && o->params.w == img->w && o->params.h == img->h;
+}
+
+// Make the image resident (reference _img_tex :505-547)
+pl_tex plh_work_texture(struct frame_job *job, struct work_image *img)
+{
+    pl_renderer rr = job->rr;
     if (img->tex)
         return img->tex;
 
-    pl_renderer rr = pass->rr;
-    // img_sh() followed by img_tex() with nothing recorded in between (the reference's
-    // get_feature_map / need_peak_fbo sequences): the texture the shader would copy is the answer
-    if (img->sh && img->sh_origin && !img->fmt) {
-        const struct plh_pass *p = &img->sh->pass;
-        pl_tex o = img->sh_origin;
-        if (img->sh->kind == PLH_SHADER_PASS && !p->num_ops && !p->num_pre_ops &&
-            p->s.scale == 1.0f && !img->sh->detect_peak &&
-            (p->s.type == PLH_SAMPLE_NEAREST || p->s.type == PLH_SAMPLE_BILINEAR) &&
-            o->params.w == img->w && o->params.h == img->h && !pl_shader_is_failed(img->sh))
-        {
-            pl_dispatch_abort(rr->dp, &img->sh);
-            img->sh_origin = NULL;
-            img->tex = o;
-            return o;
-        }
+    if (is_pure_copy(img)) {
+        pl_dispatch_abort(rr->dp, &img->rec);
+        img->tex = img->copy_of;
+        img->copy_of = NULL;
+        return img->tex;
     }
-    img->sh_origin = NULL;
-    pl_tex tex = get_fbo(pass, img->w, img->h, img->fmt, img->comps);
-    img->fmt = NULL;
-    if (!tex) {
-        RR_ERR(rr, "Failed creating FBO texture! Disabling advanced rendering..");
-        memset(pass->fbofmt, 0, sizeof(pass->fbofmt));
-        pl_dispatch_abort(rr->dp, &img->sh);
-        rr->errors |= PL_RENDER_ERR_FBO;
-        return img->err_tex;
+    img->copy_of = NULL;
+
+    pl_tex fbo = borrow_fbo(job, img->w, img->h, img->store_as, img->comps);
+    img->store_as = NULL;
+    if (!fbo) {
+        // without intermediates only the simplest pipeline remains
+        raise(rr, PL_RENDER_ERR_FBO, PL_LOG_ERR,
+              "Failed creating FBO texture! Disabling advanced rendering..");
+        memset(job->caps.fbo, 0, sizeof(job->caps.fbo));
+        pl_dispatch_abort(rr->dp, &img->rec);
+        return img->fail_tex;
     }
 
     const bool ok = pl_dispatch_finish(rr->dp, pl_dispatch_params(
-        .shader = &img->sh,
-        .target = tex,
+        .shader = &img->rec,
+        .target = fbo,
     ));
-
-    const char *err_msg = img->err_msg;
-    const enum pl_render_error err_enum = img->err_enum;
-    pl_tex err_tex = img->err_tex;
-    img->err_msg = NULL;
-    img->err_enum = PL_RENDER_ERR_NONE;
-    img->err_tex = NULL;
+    const char *msg = img->fail_msg ? img->fail_msg : "Failed dispatching intermediate pass!";
+    const enum pl_render_error bit = img->fail_bit;
+    pl_tex fallback = img->fail_tex;
+    img->fail_msg = NULL;
+    img->fail_bit = PL_RENDER_ERR_NONE;
+    img->fail_tex = NULL;
 
     if (!ok) {
-        RR_ERR(rr, "%s", PL_DEF(err_msg, "Failed dispatching intermediate pass!"));
-        rr->errors |= err_enum;
-        img->sh = pl_dispatch_begin(rr->dp);
-        img->tex = err_tex;
-        return img->tex;
+        raise(rr, bit, PL_LOG_ERR, msg);
+        img->tex = fallback;
+        return fallback;
     }
-
-    img->tex = tex;
-    return img->tex;
+    img->tex = fbo;
+    return fbo;
 }
 
-// Forcibly convert an img to `sh`, sampling where necessary (:552-567)
-static pl_shader img_sh(struct pass_state *pass, struct img *img)
+// Make the image recordable (reference img_sh :552-567)
+pl_shader plh_work_shader(struct frame_job *job, struct work_image *img)
 {
-    if (img->sh)
-        return img->sh;
-    img->sh = pl_dispatch_begin(pass->rr->dp);
-    pl_shader_sample_direct(img->sh, pl_sample_src( .tex = img->tex ));
-    img->sh_origin = img->tex;
-    img->tex = NULL;
-    return img->sh;
+    if (!img->rec) {
+        img->rec = pl_dispatch_begin(job->rr->dp);
+        pl_shader_sample_direct(img->rec, pl_sample_src( .tex = img->tex ));
+        img->copy_of = img->tex;
+        img->tex = NULL;
+    }
+    return img->rec;
 }
 
-/* ---- samplers (sample_src_info :597-682, dispatch_sampler :684-789) ------------------------ */
-
-static struct sampler_info sample_src_info(struct pass_state *pass, const struct pl_sample_src *src,
-                                           enum sampler_usage usage)
+struct plh_op *plh_append_scale(pl_shader sh, float k, bool with_alpha)
 {
-    const struct pl_render_params *params = pass->params;
-    struct sampler_info info = { .usage = usage };
-    pl_renderer rr = pass->rr;
-
-    const float rx = src->new_w / fabsf(pl_rect_w(src->rect));
-    if (rx < 1.0 - 1e-6) {
-        info.dir_sep[0] = SAMPLER_DOWN;
-    } else if (rx > 1.0 + 1e-6) {
-        info.dir_sep[0] = SAMPLER_UP;
-    }
-    const float ry = src->new_h / fabsf(pl_rect_h(src->rect));
-    if (ry < 1.0 - 1e-6) {
-        info.dir_sep[1] = SAMPLER_DOWN;
-    } else if (ry > 1.0 + 1e-6) {
-        info.dir_sep[1] = SAMPLER_UP;
-    }
-
-    if (params->correct_subpixel_offsets) {
-        if (!info.dir_sep[0] && fabsf(src->rect.x0) > 1e-6f)
-            info.dir_sep[0] = SAMPLER_UP;
-        if (!info.dir_sep[1] && fabsf(src->rect.y0) > 1e-6f)
-            info.dir_sep[1] = SAMPLER_UP;
-    }
-
-    // downscaling overrides upscaling when choosing scalers
-    info.dir = PL_MAX(info.dir_sep[0], info.dir_sep[1]);
-    switch (info.dir) {
-    case SAMPLER_DOWN:
-        if (usage == SAMPLER_LOWPASS)
-            info.config = &pl_filter_bicubic;   // (:630-631)
-        else
-            info.config = usage == SAMPLER_PLANE && params->plane_downscaler
-                            ? params->plane_downscaler : params->downscaler;
-        break;
-    case SAMPLER_UP:
-        info.config = usage == SAMPLER_PLANE && params->plane_upscaler
-                        ? params->plane_upscaler : params->upscaler;
-        break;
-    case SAMPLER_NOOP:
-        info.type = SAMPLER_NEAREST;
-        return info;
-    }
-
-    if ((rr->errors & PL_RENDER_ERR_SAMPLING) || !info.config) {
-        info.type = SAMPLER_DIRECT;
-    } else if (info.config->kernel == &pl_filter_function_oversample) {
-        info.type = SAMPLER_OVERSAMPLE;
-    } else {
-        info.type = SAMPLER_COMPLEX;
-
-        // faster replacements for the scalers a texture unit provides
-        pl_fmt texfmt = src->tex ? src->tex->params.format : pass->fbofmt[4];
-        const bool can_linear = texfmt->caps & PL_FMT_CAP_LINEAR;
-        const bool can_fast = info.dir == SAMPLER_UP || params->skip_anti_aliasing;
-        if (can_fast && !params->disable_builtin_scalers) {
-            if (can_linear && pl_filter_config_eq(info.config, &pl_filter_bicubic))
-                info.type = SAMPLER_BICUBIC;
-            if (can_linear && pl_filter_config_eq(info.config, &pl_filter_hermite))
-                info.type = SAMPLER_HERMITE;
-            if (can_linear && pl_filter_config_eq(info.config, &pl_filter_gaussian))
-                info.type = SAMPLER_GAUSSIAN;
-            if (can_linear && pl_filter_config_eq(info.config, &pl_filter_bilinear))
-                info.type = SAMPLER_DIRECT;
-            if (pl_filter_config_eq(info.config, &pl_filter_nearest))
-                info.type = can_linear ? SAMPLER_NEAREST : SAMPLER_DIRECT;
-        }
-    }
-
-    // no advanced scaling without FBOs
-    if (!pass->fbofmt[4] && info.type == SAMPLER_COMPLEX)
-        info.type = SAMPLER_DIRECT;
-    return info;
+    struct plh_op *op = sh_op(sh, PLH_OP_SCALE);
+    if (!op)
+        return NULL;
+    op->f[0] = op->f[1] = op->f[2] = k;
+    op->f[3] = with_alpha ? k : 1.0f;
+    sh_listf(sh, "scale(%g%s)\n", k, with_alpha ? "" : ", rgb only");
+    return op;
 }
 
-static void dispatch_sampler(struct pass_state *pass, pl_shader sh, struct sampler *sampler,
-                             enum sampler_usage usage, const struct pl_sample_src *src)
+/* ---- scalers -------------------------------------------------------------------------------- */
+
+// Separable filter along both axes: vertical pass into an intermediate, then horizontal
+static bool run_two_pass(struct frame_job *job, pl_shader sh, const struct pl_sample_src *req,
+                         const struct pl_sample_filter_params *fp)
 {
-    const struct pl_render_params *params = pass->params;
-    pl_renderer rr = pass->rr;
-    if (!sampler)
-        goto fallback;
+    pl_renderer rr = job->rr;
+    struct pl_sample_src vert = *req, horiz = *req;
+    vert.new_w = req->tex->params.w;
+    vert.rect.x0 = 0;
+    vert.rect.x1 = vert.new_w;
+    horiz.rect.y0 = 0;
+    horiz.rect.y1 = vert.new_h;
 
-    const struct sampler_info info = sample_src_info(pass, src, usage);
-    pl_shader_obj *lut = NULL;
-    switch (info.dir) {
-    case SAMPLER_NOOP:
-        goto fallback;
-    case SAMPLER_DOWN:
-        lut = &sampler->downscaler_state;
-        break;
-    case SAMPLER_UP:
-        lut = &sampler->upscaler_state;
-        break;
+    pl_shader first = pl_dispatch_begin(rr->dp);
+    if (!pl_shader_sample_ortho2(first, &vert, fp)) {
+        pl_dispatch_abort(rr->dp, &first);
+        return false;
     }
-
-    switch (info.type) {
-    case SAMPLER_DIRECT:
-        goto fallback;
-    case SAMPLER_NEAREST:
-        pl_shader_sample_nearest(sh, src);
-        return;
-    case SAMPLER_OVERSAMPLE:
-        pl_shader_sample_oversample(sh, src, info.config->kernel->params[0]);
-        return;
-    case SAMPLER_BICUBIC:
-        pl_shader_sample_bicubic(sh, src);
-        return;
-    case SAMPLER_HERMITE:
-        pl_shader_sample_hermite(sh, src);
-        return;
-    case SAMPLER_GAUSSIAN:
-        pl_shader_sample_gaussian(sh, src);
-        return;
-    case SAMPLER_COMPLEX:
-        break;
-    }
-
-    struct pl_sample_filter_params fparams = {
-        .filter      = *info.config,
-        .antiring    = params->antiringing_strength,
-        .no_widening = params->skip_anti_aliasing && usage != SAMPLER_LOWPASS,
-        .lut         = lut,
+    struct work_image mid = {
+        .rec = first, .w = vert.new_w, .h = vert.new_h, .comps = req->components,
     };
-
-    bool ok;
-    if (info.config->polar) {
-        ok = pl_shader_sample_polar(sh, src, &fparams);
-    } else if (info.dir_sep[0] && info.dir_sep[1]) {
-        // both directions: vertical pass into an FBO, then the horizontal pass (:745-772)
-        struct pl_sample_src src1 = *src, src2 = *src;
-        src1.new_w = src->tex->params.w;
-        src1.rect.x0 = 0;
-        src1.rect.x1 = src1.new_w;
-        src2.rect.y0 = 0;
-        src2.rect.y1 = src1.new_h;
-
-        pl_shader tsh = pl_dispatch_begin(rr->dp);
-        ok = pl_shader_sample_ortho2(tsh, &src1, &fparams);
-        if (!ok) {
-            pl_dispatch_abort(rr->dp, &tsh);
-            goto done;
-        }
-        struct img img = {
-            .sh = tsh, .w = src1.new_w, .h = src1.new_h, .comps = src->components,
-        };
-        src2.tex = img_tex(pass, &img);
-        src2.scale = 1.0;
-        ok = src2.tex && pl_shader_sample_ortho2(sh, &src2, &fparams);
-    } else {
-        ok = pl_shader_sample_ortho2(sh, src, &fparams);
-    }
-
-done:
-    if (!ok) {
-        RR_ERR(rr, "Failed dispatching scaler.. disabling");
-        rr->errors |= PL_RENDER_ERR_SAMPLING;
-        goto fallback;
-    }
-    return;
-
-fallback:
-    pl_shader_sample_direct(sh, src);
+    horiz.tex = plh_work_texture(job, &mid);
+    horiz.scale = 1.0;
+    return horiz.tex && pl_shader_sample_ortho2(sh, &horiz, fp);
 }
 
-// PASS A fusion (not in the reference, which always renders `pre` into an FBO before a complex
-// scaler, renderer.c:2064): if the main scaler is a polar one and `pre` - everything recorded
-// so far - is a plain fetch of the whole plane followed by colour ops, the polar kernel runs
-// those ops on the source texels while it stages them, with the FBO's rgba16hf rounding, and
-// the intermediate pass (one full-frame write + read) disappears. Same values, one pass less.
-static bool try_fused_polar(struct pass_state *pass, pl_shader sh, const struct pl_sample_src *src,
-                            pl_shader pre, int fbo_w, int fbo_h)
+// Record the sampling of `req` into `sh` with whatever rp_pick_scaler chooses for it
+static void run_scaler(struct frame_job *job, pl_shader sh, struct scaler_slot *slot,
+                       enum rp_usage usage, const struct pl_sample_src *req)
 {
-    const struct pl_render_params *params = pass->params;
-    pl_renderer rr = pass->rr;
-    const char *env = getenv("PL_HIP_NO_FUSION");
-    if (!pre || (env && env[0] == '1'))
-        return false;
-    pl_fmt fbofmt = pass->fbofmt[pass->img.comps];
-    if (!fbofmt || fbofmt->type != PL_FMT_FLOAT || fbofmt->component_depth[0] != 16)
-        return false; // the fused tile rounds to f16: only valid if the FBO would too
+    pl_renderer rr = job->rr;
+    const struct pl_render_params *params = job->params;
+    struct rp_scaler sc = { .kind = RP_SCALER_BUILTIN };
+    if (slot)
+        sc = rp_pick_scaler(&job->caps, params, usage, req, req->tex ? req->tex->params.format : NULL);
+    if (sc.dir == RP_DIR_NONE)
+        sc.kind = RP_SCALER_BUILTIN;    // 1:1: a plain fetch
 
-    // sample_src_info wants a texture for its format checks: the FBO that would be used
-    struct pl_sample_src probe = *src;
-    const struct pl_tex_params tp = { .w = fbo_w, .h = fbo_h, .format = fbofmt };
-    const struct pl_tex_t fake = { .params = tp };
-    probe.tex = &fake;
-    const struct sampler_info info = sample_src_info(pass, &probe, SAMPLER_MAIN);
-    if (info.type != SAMPLER_COMPLEX || !info.config->polar || info.dir == SAMPLER_NOOP)
+    switch (sc.kind) {
+    case RP_SCALER_NEAREST:
+        pl_shader_sample_nearest(sh, req);
+        return;
+    case RP_SCALER_BICUBIC:
+        pl_shader_sample_bicubic(sh, req);
+        return;
+    case RP_SCALER_HERMITE:
+        pl_shader_sample_hermite(sh, req);
+        return;
+    case RP_SCALER_GAUSSIAN:
+        pl_shader_sample_gaussian(sh, req);
+        return;
+    case RP_SCALER_OVERSAMPLE:
+        pl_shader_sample_oversample(sh, req, sc.filter->kernel->params[0]);
+        return;
+    case RP_SCALER_BUILTIN:
+        pl_shader_sample_direct(sh, req);
+        return;
+    case RP_SCALER_FILTER:
+        break;
+    }
+
+    const struct pl_sample_filter_params fp = {
+        .filter      = *sc.filter,
+        .antiring    = params->antiringing_strength,
+        .no_widening = params->skip_anti_aliasing && usage != RP_USE_LOWPASS,
+        .lut         = sc.dir == RP_DIR_UP ? &slot->up : &slot->down,
+    };
+    bool ok;
+    if (sc.filter->polar)
+        ok = pl_shader_sample_polar(sh, req, &fp);
+    else if (sc.axis[0] && sc.axis[1])
+        ok = run_two_pass(job, sh, req, &fp);
+    else
+        ok = pl_shader_sample_ortho2(sh, req, &fp);
+
+    if (!ok) {
+        raise(rr, PL_RENDER_ERR_SAMPLING, PL_LOG_ERR, "Failed dispatching scaler.. disabling");
+        pl_shader_sample_direct(sh, req);
+    }
+}
+
+// Fold the pending image (`pre`: a plain whole-plane fetch + colour ops) into a polar main
+// scaler instead of writing it to an intermediate first. Only valid where the intermediate
+// would be rgba16hf, because the fused tile rounds to f16.
+static bool try_fused_polar(struct frame_job *job, pl_shader sh, const struct pl_sample_src *req,
+                            pl_shader pre, int w, int h)
+{
+    const struct pl_render_params *params = job->params;
+    const char *off = getenv("PL_HIP_NO_FUSION");
+    if (!pre || (off && off[0] == '1'))
         return false;
-    if (PL_DEF(info.config->antiring, params->antiringing_strength) > 0)
+    pl_fmt fmt = job->caps.fbo[job->img.comps];
+    if (!fmt || fmt->type != PL_FMT_FLOAT || fmt->component_depth[0] != 16)
         return false;
 
-    struct pl_sample_filter_params fparams = {
-        .filter      = *info.config,
+    // the scaler choice looks at the source format: describe the intermediate that is skipped
+    const struct pl_tex_t stand_in = { .params = { .w = w, .h = h, .format = fmt } };
+    struct pl_sample_src probe = *req;
+    probe.tex = &stand_in;
+    const struct rp_scaler sc = rp_pick_scaler(&job->caps, params, RP_USE_MAIN, &probe, fmt);
+    if (sc.kind != RP_SCALER_FILTER || !sc.filter->polar || sc.dir == RP_DIR_NONE)
+        return false;
+    const float ar = sc.filter->antiring ? sc.filter->antiring : params->antiringing_strength;
+    if (ar > 0)
+        return false;   // the anti-ringing variant has no fused form
+
+    const struct pl_sample_filter_params fp = {
+        .filter      = *sc.filter,
         .antiring    = params->antiringing_strength,
         .no_widening = params->skip_anti_aliasing,
-        .lut         = info.dir == SAMPLER_UP ? &rr->sampler_main.upscaler_state
-                                              : &rr->sampler_main.downscaler_state,
+        .lut         = sc.dir == RP_DIR_UP ? &job->rr->scale_main.up : &job->rr->scale_main.down,
     };
-    return plh_shader_sample_polar_fused(sh, pre, &probe, &fparams);
+    return plh_shader_sample_polar_fused(sh, pre, &probe, &fp);
 }
 
-/* ---- planes (detect_plane_type :287-335, frame_ref :3048-3066) -------------------------------- */
+/* ---- job set-up --------------------------------------------------------------------------------- */
 
-enum plane_type { PLANE_INVALID = 0, PLANE_ALPHA, PLANE_CHROMA, PLANE_LUMA, PLANE_RGB, PLANE_XYZ };
-
-static enum plane_type detect_plane_type(const struct pl_plane *plane,
-                                         const struct pl_color_repr *repr)
+static void forward_pass_info(void *priv, const struct pl_dispatch_info *dinfo)
 {
-    if (pl_color_system_is_ycbcr_like(repr->sys)) {
-        int t = PLANE_INVALID;
-        for (int c = 0; c < plane->components; c++) {
-            switch (plane->component_mapping[c]) {
-            case PL_CHANNEL_Y: t = PL_MAX(t, PLANE_LUMA); continue;
-            case PL_CHANNEL_A: t = PL_MAX(t, PLANE_ALPHA); continue;
-            case PL_CHANNEL_CB:
-            case PL_CHANNEL_CR: t = PL_MAX(t, PLANE_CHROMA); continue;
-            default: continue;
-            }
-        }
-        return t;
-    }
-    if (plane->components == 1 && plane->component_mapping[0] == PL_CHANNEL_A)
-        return PLANE_ALPHA;
-    return repr->sys == PL_COLOR_SYSTEM_XYZ ? PLANE_XYZ : PLANE_RGB;
+    struct frame_job *job = priv;
+    if (!job->params->info_callback)
+        return;
+    job->info.pass = dinfo;
+    job->params->info_callback(job->params->info_priv, &job->info);
+    job->info.index++;
 }
 
-static int frame_ref(const struct pl_frame *frame)
+void plh_job_watch_passes(struct frame_job *job)
 {
-    for (int i = 0; i < frame->num_planes; i++) {
-        switch (detect_plane_type(&frame->planes[i], &frame->repr)) {
-        case PLANE_RGB: case PLANE_LUMA: case PLANE_XYZ:
-            return i;
-        default:
-            continue;
-        }
-    }
-    return 0;
+    pl_dispatch_reset_frame(job->rr->dp);
+    pl_dispatch_callback(job->rr->dp, job, forward_pass_info);
 }
 
-/* ---- frame fix-ups (:3068-3293) -------------------------------------------------------------- */
-
-static void default_rect(pl_rect2df *rc, const pl_rect2df *backup)
+bool plh_params_supported(pl_renderer rr, const struct pl_render_params *p)
 {
-    if (!rc->x0 && !rc->y0 && !rc->x1 && !rc->y1)
-        *rc = *backup;
+    const char *what = p->blend_params ? "blend_params" :
+                       p->deinterlace_params ? "deinterlace_params" :
+                       p->distort_params ? "distort_params" :
+                       p->num_hooks ? "hooks" : NULL;
+    if (!what)
+        return true;
+    RR_LOG(rr, PL_LOG_ERR, "pl_render_params.%s requests a stage this backend does not have "
+           "(outside the pl_render_image hot path, SURVEY.md 8)", what);
+    return false;
 }
 
-bool pl_frame_is_cropped(const struct pl_frame *frame)
+// things a frame may carry that are not rendered here: say so once, keep going
+static void note_ignored_members(pl_renderer rr, const struct pl_frame *f)
 {
-    if (!frame->num_planes || !frame->planes[frame_ref(frame)].texture)
-        return false;
-    pl_tex ref = frame->planes[frame_ref(frame)].texture;
-    pl_rect2df crop = frame->crop;
-    default_rect(&crop, &(pl_rect2df) { 0, 0, ref->params.w, ref->params.h });
-    pl_rect2df_normalize(&crop);
-    const int x0 = roundf(crop.x0), y0 = roundf(crop.y0),
-              x1 = roundf(crop.x1), y1 = roundf(crop.y1);
-    return x0 > 0 || y0 > 0 || x1 < ref->params.w || y1 < ref->params.h;
-}
-
-static void fix_refs_and_rects(struct pass_state *pass)
-{
-    struct pl_frame *target = &pass->target, *image = &pass->image;
-    pl_rect2df *dst = &target->crop, *src = &image->crop;
-    pl_tex dst_ref = target->planes[frame_ref(target)].texture,
-           src_ref = image->planes[frame_ref(image)].texture;
-    int dst_w = dst_ref->params.w, dst_h = dst_ref->params.h;
-
-    if ((!dst->x0 && !dst->x1) || (!dst->y0 && !dst->y1)) {
-        dst->x1 = dst_w;
-        dst->y1 = dst_h;
+    if ((f->icc || f->profile.data) && !rr->warned_icc) {
+        rr->warned_icc = true;
+        RR_LOG(rr, PL_LOG_WARN, "ICC profiles are not interpreted by this build (no lcms2): "
+               "rendering from the frame's pl_color_space");
     }
-    if ((!src->x0 && !src->x1) || (!src->y0 && !src->y1)) {
-        src->x1 = src_ref->params.w;
-        src->y1 = src_ref->params.h;
+    if (f->num_overlays && !rr->warned_overlay) {
+        rr->warned_overlay = true;
+        raise(rr, PL_RENDER_ERR_OVERLAY, PL_LOG_WARN, "Overlays are not drawn by this backend");
     }
-
-    // end-to-end rotation (:3113-3117): the image is processed in its own orientation, the
-    // target rect is counter-rotated into it, the output stage transposes / flips the stores
-    pass->rotation = pl_rotation_normalize(image->rotation - target->rotation);
-    pl_rect2df_rotate(dst, -pass->rotation);
-    if (pass->rotation % PL_ROTATION_180 == PL_ROTATION_90) {
-        const int t = dst_w;
-        dst_w = dst_h;
-        dst_h = t;
-    }
-
-    // is the end-to-end rendering flipped?
-    const bool flipped_x = (src->x0 > src->x1) != (dst->x0 > dst->x1),
-               flipped_y = (src->y0 > src->y1) != (dst->y0 > dst->y1);
-    pl_rect2df_normalize(src);
-    pl_rect2df_normalize(dst);
-
-    // round the output rect and clip it to the framebuffer
-    const float rx0 = roundf(PL_CLAMP(dst->x0, 0.0, dst_w)),
-                ry0 = roundf(PL_CLAMP(dst->y0, 0.0, dst_h)),
-                rx1 = roundf(PL_CLAMP(dst->x1, 0.0, dst_w)),
-                ry1 = roundf(PL_CLAMP(dst->y1, 0.0, dst_h));
-
-    // adjust the src rect for the rounded crop
-    const float scale_x = pl_rect_w(*src) / pl_rect_w(*dst),
-                scale_y = pl_rect_h(*src) / pl_rect_h(*dst),
-                base_x = src->x0, base_y = src->y0;
-    src->x0 = base_x + (rx0 - dst->x0) * scale_x;
-    src->x1 = base_x + (rx1 - dst->x0) * scale_x;
-    src->y0 = base_y + (ry0 - dst->y0) * scale_y;
-    src->y1 = base_y + (ry1 - dst->y0) * scale_y;
-
-    // flips always go to the dst rect (keeps compute samplers usable)
-    *dst = (pl_rect2df) {
-        .x0 = flipped_x ? rx1 : rx0,
-        .y0 = flipped_y ? ry1 : ry0,
-        .x1 = flipped_x ? rx0 : rx1,
-        .y1 = flipped_y ? ry0 : ry1,
-    };
-    pass->ref_rect = *src;
-    pass->dst_rect = (pl_rect2d) { dst->x0, dst->y0, dst->x1, dst->y1 };
-}
-
-static void fix_frame(struct pl_frame *frame)
-{
-    pl_tex tex = frame->planes[frame_ref(frame)].texture;
-    if (frame->repr.sys == PL_COLOR_SYSTEM_XYZ) {
-        // XYZ is implicitly converted to linear DCI-P3 in pl_color_repr_decode
-        frame->color.primaries = PL_COLOR_PRIM_DCI_P3;
-        frame->color.transfer = PL_COLOR_TRC_ST428;
-    }
-    if (tex && !frame->color.primaries)
-        frame->color.primaries = pl_color_primaries_guess(tex->params.w, tex->params.h);
-
-    bool has_alpha = false;
-    for (int p = 0; p < frame->num_planes; p++) {
-        for (int c = 0; c < frame->planes[p].components; c++)
-            has_alpha |= frame->planes[p].component_mapping[c] == PL_CHANNEL_A;
-    }
-    if (!has_alpha)
-        frame->repr.alpha = PL_ALPHA_NONE;
-
-    // UNORM textures tell us the sampled bit depth
-    struct pl_bit_encoding *bits = &frame->repr.bits;
-    if (!bits->sample_depth && tex && tex->params.format->type == PL_FMT_UNORM) {
-        bits->sample_depth = tex->params.format->component_depth[0];
-        bits->color_depth = PL_DEF(bits->color_depth, bits->sample_depth);
-        bits->color_depth = PL_MIN(bits->color_depth, bits->sample_depth);
-        bits->bit_shift += bits->sample_depth - bits->color_depth;
+    if (f->film_grain.type != PL_FILM_GRAIN_NONE && !rr->warned_grain) {
+        rr->warned_grain = true;
+        raise(rr, PL_RENDER_ERR_FILM_GRAIN, PL_LOG_WARN,
+              "Film grain synthesis is not part of this backend");
     }
 }
 
-static void pass_fix_frames(struct pass_state *pass)
+void plh_job_end(struct frame_job *job)
 {
-    struct pl_frame *image = &pass->image, *target = &pass->target;
-    fix_refs_and_rects(pass);
-    fix_frame(image);
-    pl_color_space_infer_map(&image->color, &target->color);
-    fix_frame(target); // only after infer_map
-    if (image->repr.alpha == PL_ALPHA_UNKNOWN)
-        image->repr.alpha = PL_ALPHA_INDEPENDENT;
-    if (target->repr.alpha == PL_ALPHA_UNKNOWN)
-        target->repr.alpha = PL_ALPHA_PREMULTIPLIED;
+    pl_renderer rr = job->rr;
+    pl_dispatch_abort(rr->dp, &job->img.rec);
+    pl_dispatch_callback(rr->dp, NULL, NULL);
+    if (job->image_acquired && job->image.release)
+        job->image.release(rr->gpu, &job->image);
+    if (job->target_acquired && !job->target_borrowed && job->target.release)
+        job->target.release(rr->gpu, &job->target);
+    job->image_acquired = job->target_acquired = false;
 }
 
-static bool validate_frame(pl_renderer rr, const struct pl_frame *f, const char *what, bool dst)
+// acquire both frames, validate, fit the rects, complete the descriptions (:3317-3428)
+bool plh_job_begin(struct frame_job *job, bool acquire_image)
 {
-    if (f->num_planes < 1 || f->num_planes > PL_MAX_PLANES) {
-        RR_ERR(rr, "%s frame has an invalid number of planes: %d", what, f->num_planes);
-        return false;
+    pl_renderer rr = job->rr;
+    if (!job->target_acquired && !job->target_borrowed && job->target.acquire) {
+        if (!job->target.acquire(rr->gpu, &job->target))
+            return false;
+        job->target_acquired = true;
     }
-    for (int i = 0; i < f->num_planes; i++) {
-        const struct pl_plane *pi = &f->planes[i];
-        if (!pi->texture || pi->components < 1 || pi->components > 4) {
-            RR_ERR(rr, "%s plane %d: missing texture or invalid number of components", what, i);
+    if (acquire_image && job->image.acquire) {
+        if (!job->image.acquire(rr->gpu, &job->image)) {
+            plh_job_end(job);
             return false;
         }
-        if (!dst && !pi->texture->params.sampleable) {
-            RR_ERR(rr, "Image textures must be sampleable");
-            return false;
-        }
-        if (dst && !pi->texture->params.storable) {
-            RR_ERR(rr, "Target textures must be storable (every pass is a compute pass)");
-            return false;
-        }
+        job->image_acquired = true;
     }
-    const struct pl_plane *pl = &f->planes[frame_ref(f)];
-    if (pl->shift_x || pl->shift_y) {
-        RR_ERR(rr, "%s reference plane must have no shift", what);
+
+    const char *bad = rp_frame_problem(&job->image, false);
+    if (bad) {
+        RR_LOG(rr, PL_LOG_ERR, "Image frame: %s", bad);
+    } else if ((bad = rp_frame_problem(&job->target, true))) {
+        RR_LOG(rr, PL_LOG_ERR, "Target frame: %s", bad);
+    }
+    if (bad) {
+        plh_job_end(job);
         return false;
     }
+    note_ignored_members(rr, &job->image);
+    note_ignored_members(rr, &job->target);
+
+    job->caps.max_shmem = rr->gpu->glsl.max_shmem_size;
+    job->caps.sampling_broken = rr->errors & PL_RENDER_ERR_SAMPLING;
+    job->caps.peak_broken = rr->errors & PL_RENDER_ERR_PEAK_DETECT;
+    job->caps.deband_broken = rr->errors & PL_RENDER_ERR_DEBANDING;
+    job->caps.contrast_broken = rr->errors & PL_RENDER_ERR_CONTRAST_RECOVERY;
+    job->caps.errdiff_broken = rr->errors & PL_RENDER_ERR_ERROR_DIFFUSION;
+    choose_fbo_formats(job);
+
+    pl_tex iref = job->image.planes[rp_reference_plane(&job->image)].texture,
+           tref = job->target.planes[rp_reference_plane(&job->target)].texture;
+    job->geo = rp_fit_rects(job->image.crop, iref->params.w, iref->params.h, job->image.rotation,
+                            job->target.crop, tref->params.w, tref->params.h,
+                            job->target.rotation);
+    job->image.crop = job->geo.src;
+    job->target.crop = job->geo.dstf;
+    rp_complete_frames(&job->image, &job->target);
     return true;
-}
-
-void pl_frame_set_chroma_location(struct pl_frame *frame, enum pl_chroma_location chroma_loc)
-{
-    pl_tex ref = frame->planes[frame_ref(frame)].texture;
-    for (int i = 0; i < frame->num_planes; i++) {
-        struct pl_plane *plane = &frame->planes[i];
-        pl_tex tex = plane->texture;
-        const bool apply = ref && tex
-            ? tex->params.w < ref->params.w || tex->params.h < ref->params.h
-            : detect_plane_type(plane, &frame->repr) == PLANE_CHROMA;
-        if (apply)
-            pl_chroma_location_offset(chroma_loc, &plane->shift_x, &plane->shift_y);
-    }
 }
 
 void pl_frames_infer(pl_renderer rr, struct pl_frame *image, struct pl_frame *target)
 {
-    struct pass_state pass = { .rr = rr, .image = *image, .target = *target };
-    if (!validate_frame(rr, image, "Image", false) || !validate_frame(rr, target, "Target", true))
+    if (rp_frame_problem(image, false) || rp_frame_problem(target, true))
         return;
-    pass_fix_frames(&pass);
-    *image = pass.image;
-    *target = pass.target;
+    pl_tex iref = image->planes[rp_reference_plane(image)].texture,
+           tref = target->planes[rp_reference_plane(target)].texture;
+    const struct rp_geometry geo = rp_fit_rects(image->crop, iref->params.w, iref->params.h,
+                                                image->rotation, target->crop, tref->params.w,
+                                                tref->params.h, target->rotation);
+    image->crop = geo.src;
+    target->crop = geo.dstf;
+    rp_complete_frames(image, target);
+    (void) rr;
 }
 
-/* ---- peak detection (hdr_update_peak :1183-1250) --------------------------------------------- */
-
-static void hdr_update_peak(struct pass_state *pass)
+void pl_frame_set_chroma_location(struct pl_frame *frame, enum pl_chroma_location loc)
 {
-    const struct pl_render_params *params = pass->params;
-    pl_renderer rr = pass->rr;
-    if (!params->peak_detect_params || !pl_color_space_is_hdr(&pass->image.color))
-        goto cleanup;
-    if (rr->errors & PL_RENDER_ERR_PEAK_DETECT)
-        goto cleanup;
-    if (pass->fbofmt[4] && !(pass->fbofmt[4]->caps & PL_FMT_CAP_STORABLE))
-        goto cleanup;
-
-    float max_peak = pl_color_transfer_nominal_peak(pass->image.color.transfer) *
-                     PL_COLOR_SDR_WHITE;
-    if (pass->image.color.transfer == PL_COLOR_TRC_HLG)
-        max_peak = pass->img.color.hdr.max_luma;
-    if (max_peak <= pass->target.color.hdr.max_luma + 1e-6)
-        goto cleanup; // no adaptation needed
-    if (pass->img.color.hdr.avg_pq_y)
-        goto cleanup; // dynamic metadata already present
-
-    enum pl_hdr_metadata_type metadata = PL_HDR_METADATA_ANY;
-    if (params->color_map_params)
-        metadata = params->color_map_params->metadata;
-    if (metadata && metadata != PL_HDR_METADATA_CIE_Y)
-        goto cleanup; // measurement would be unused
-
-    const struct pl_color_map_params *cpars = params->color_map_params;
-    const bool uses_ootf = cpars && cpars->tone_mapping_function == &pl_tone_map_st2094_40;
-    if (uses_ootf && pass->img.color.hdr.ootf.num_anchors)
-        goto cleanup; // HDR10+ OOTF is being used
-    if (params->lut && params->lut_type == PL_LUT_CONVERSION)
-        goto cleanup; // LUT handles tone mapping
-
-    if (!pass->fbofmt[4] && !params->peak_detect_params->allow_delayed) {
-        RR_WARN(rr, "Disabling peak detection because `pl_peak_detect_params.allow_delayed` "
-                "is false, but lack of FBOs forces the result to be delayed.");
-        rr->errors |= PL_RENDER_ERR_PEAK_DETECT;
-        goto cleanup;
-    }
-
-    // The polar / separable / deband kernels own their workgroup shape, so a measurement cannot
-    // ride on them (the reference merges it into the scaler's compute shader): materialise the
-    // image and measure it with a target-less pass that only reads it. Same 16x16 tiling of the
-    // same image; the values it sees went through the FBO's f16 rounding.
-    struct img *img = &pass->img;
-    if (img->sh && pass->fbofmt[4] &&
-        (img->sh->pass.s.type == PLH_SAMPLE_POLAR || img->sh->pass.s.type == PLH_SAMPLE_ORTHO ||
-         img->sh->pass.s.type == PLH_SAMPLE_DEBAND))
-    {
-        pl_tex tex = img_tex(pass, img);
-        if (!tex)
-            goto cleanup;
-        pl_shader msh = pl_dispatch_begin(rr->dp);
-        bool mok = pl_shader_sample_direct(msh, pl_sample_src( .tex = tex )) &&
-                   pl_shader_detect_peak(msh, img->color, &rr->tone_map_state,
-                                         params->peak_detect_params);
-        if (mok) {
-            mok = pl_dispatch_compute(rr->dp, pl_dispatch_compute_params(
-                .shader = &msh, .width = tex->params.w, .height = tex->params.h,
-            ));
+    pl_tex ref = frame->planes[rp_reference_plane(frame)].texture;
+    for (int i = 0; i < frame->num_planes; i++) {
+        struct pl_plane *plane = &frame->planes[i];
+        // a plane smaller than the reference is subsampled; without textures, go by content
+        bool subsampled;
+        if (ref && plane->texture) {
+            subsampled = plane->texture->params.w < ref->params.w ||
+                         plane->texture->params.h < ref->params.h;
         } else {
-            pl_dispatch_abort(rr->dp, &msh);
+            subsampled = rp_plane_role(plane, &frame->repr) == RP_PLANE_CHROMA;
         }
-        if (!mok) {
-            RR_WARN(rr, "Failed measuring the HDR peak.. disabling");
-            rr->errors |= PL_RENDER_ERR_PEAK_DETECT;
-            goto cleanup;
-        }
-        pass->need_peak_fbo = false; // already complete (stream order)
-        return;
+        if (subsampled)
+            pl_chroma_location_offset(loc, &plane->shift_x, &plane->shift_y);
     }
-
-    const bool ok = pl_shader_detect_peak(img_sh(pass, &pass->img), pass->img.color,
-                                          &rr->tone_map_state, params->peak_detect_params);
-    if (!ok) {
-        RR_WARN(rr, "Failed creating HDR peak detection shader.. disabling");
-        rr->errors |= PL_RENDER_ERR_PEAK_DETECT;
-        goto cleanup;
-    }
-    pass->need_peak_fbo = !params->peak_detect_params->allow_delayed;
-    return;
-
-cleanup:
-    pl_reset_detected_peak(rr->tone_map_state);
 }
 
-/* ---- pass_read_image (:1553-1960) ------------------------------------------------------------ */
-
-static bool plane_deband(struct pass_state *pass, struct img *img, const float neutral[3])
+bool pl_frame_is_cropped(const struct pl_frame *frame)
 {
-    const struct pl_render_params *params = pass->params;
-    pl_renderer rr = pass->rr;
-    if ((rr->errors & PL_RENDER_ERR_DEBANDING) || !params->deband_params || !pass->fbofmt[4])
+    if (!frame->num_planes)
         return false;
+    pl_tex ref = frame->planes[rp_reference_plane(frame)].texture;
+    if (!ref)
+        return false;
+    pl_rect2df crop = frame->crop;
+    if (!crop.x0 && !crop.y0 && !crop.x1 && !crop.y1)
+        return false;   // unset = the whole plane
+    pl_rect2df_normalize(&crop);
+    const pl_rect2d r = pl_rect2df_round(&crop);
+    return r.x0 > 0 || r.y0 > 0 || r.x1 < ref->params.w || r.y1 < ref->params.h;
+}
 
-    struct pl_color_repr repr = img->repr;
-    struct pl_sample_src src = {
-        .tex = img_tex(pass, img),
-        .components = img->comps,
+/* ---- stage 1: read -------------------------------------------------------------------------- */
+
+// Replace a plane's texture by its debanded version (recorded, not yet run). :1318-1350
+static void deband_plane(struct frame_job *job, struct work_image *pimg, const float neutral[3])
+{
+    pl_renderer rr = job->rr;
+    const struct pl_render_params *params = job->params;
+    if (!params->deband_params || job->caps.deband_broken || !job->caps.fbo[4])
+        return;
+
+    pl_tex source = plh_work_texture(job, pimg);
+    struct pl_color_repr repr = pimg->repr;
+    const struct pl_sample_src src = {
+        .tex = source,
+        .components = pimg->comps,
         .scale = pl_color_repr_normalize(&repr),
     };
 
-    // keep the grain intensity independent of the source's nominal peak (:1337-1342)
-    struct pl_deband_params dparams = *params->deband_params;
-    dparams.grain /= pass->image.color.hdr.max_luma / PL_COLOR_SDR_WHITE;
-    memcpy(dparams.grain_neutral, neutral, sizeof(dparams.grain_neutral));
+    struct pl_deband_params dp = *params->deband_params;
+    // grain strength is specified for SDR white: keep it there for brighter sources
+    dp.grain /= job->image.color.hdr.max_luma / PL_COLOR_SDR_WHITE;
+    memcpy(dp.grain_neutral, neutral, sizeof(dp.grain_neutral));
 
-    img->tex = NULL;
-    img->sh = pl_dispatch_begin(rr->dp);
-    pl_shader_deband(img->sh, &src, &dparams);
-    img->err_msg = "Failed applying debanding... disabling!";
-    img->err_enum = PL_RENDER_ERR_DEBANDING;
-    img->err_tex = src.tex;
-    img->repr = repr;
-    return true;
+    pimg->tex = NULL;
+    pimg->rec = pl_dispatch_begin(rr->dp);
+    pl_shader_deband(pimg->rec, &src, &dp);
+    pimg->repr = repr;
+    pimg->fail_msg = "Failed applying debanding... disabling!";
+    pimg->fail_bit = PL_RENDER_ERR_DEBANDING;
+    pimg->fail_tex = source;
 }
 
-struct plane_state {
-    enum plane_type type;
-    struct pl_plane plane;
-    struct img img;
-    float plane_w, plane_h; // logical plane dimensions
-};
-
-// color = scale * texel of another shader's plain fetch, merged into `sh` (the reference's
-// sh_subpass). Returns false if `psh` is more than a plain fetch.
-static bool merge_plane_fetch(pl_shader sh, const pl_shader psh, const struct pl_plane *plane)
+// `fetch` must be a bare nearest / bilinear fetch: its texture is read from inside `sh`
+bool plh_append_plane_fetch(pl_shader sh, const pl_shader fetch, const struct pl_plane *plane)
 {
-    const struct plh_sampler_args *ps = &psh->pass.s;
-    if (psh->pass.num_ops || psh->kind != PLH_SHADER_PASS ||
-        (ps->type != PLH_SAMPLE_NEAREST && ps->type != PLH_SAMPLE_BILINEAR))
+    const struct plh_sampler_args *s = &fetch->pass.s;
+    const bool bilinear = s->type == PLH_SAMPLE_BILINEAR;
+    if (fetch->kind != PLH_SHADER_PASS || fetch->pass.num_ops ||
+        (s->type != PLH_SAMPLE_NEAREST && !bilinear))
         return false;
-    if (ps->src.w > 0xffff || ps->src.h > 0xffff)
-        return false;
+    if (s->src.w > 0xffff || s->src.h > 0xffff)
+        return false;   // sizes are packed into 16 bits each
+
     struct plh_op *op = sh_op(sh, PLH_OP_PLANE_FETCH);
     if (!op)
         return false;
-    memcpy(op->f, ps->pos, sizeof(ps->pos));
-    op->f[8] = ps->scale;
-    op->f[9] = ps->rect_w;
-    op->f[10] = ps->rect_h;
-    op->ptr = ps->src.ptr;
-    op->i0 = ps->src.w | (ps->src.h << 16);
-    op->i1 = ps->src.pitch;
-    uint32_t map = 0;
+
+    uint32_t dest = 0;      // 4 bits per fetched component: where it goes (0xf = nowhere)
     for (int c = 0; c < 4; c++) {
-        const int m = c < plane->components ? plane->component_mapping[c] : -1;
-        map |= (uint32_t) (m < 0 ? 0xf : m) << (4 * c);
+        const int to = c < plane->components ? plane->component_mapping[c] : -1;
+        dest |= (uint32_t) (to < 0 ? 0xf : to) << (4 * c);
     }
-    op->i2 = ps->src.fmt | (plane->components << 8) |
-             ((ps->type == PLH_SAMPLE_BILINEAR) << 12) | (ps->address_mode << 13) |
-             ((ps->type == PLH_SAMPLE_BILINEAR && ps->rect_on_grid) << 15) | (map << 16);
-    sh_listf(sh, "plane_fetch(tex=%dx%d, %s, scale=%g, comps=%d, map=0x%04x)\n", ps->src.w,
-             ps->src.h, ps->type == PLH_SAMPLE_BILINEAR ? "bilinear" : "nearest", ps->scale,
-             plane->components, map);
-    for (int i = 0; i < psh->num_held; i++)
-        sh_hold(sh, psh->held[i]);
+    memcpy(op->f, s->pos, sizeof(s->pos));
+    op->f[8] = s->scale;
+    op->f[9] = s->rect_w;
+    op->f[10] = s->rect_h;
+    op->ptr = s->src.ptr;
+    op->i0 = s->src.w | (s->src.h << 16);
+    op->i1 = s->src.pitch;
+    op->i2 = s->src.fmt | (plane->components << 8) | (bilinear << 12) | (s->address_mode << 13) |
+             ((bilinear && s->rect_on_grid) << 15) | (dest << 16);
+    sh_listf(sh, "plane_fetch(tex=%dx%d, %s, scale=%g, comps=%d, map=0x%04x)\n", s->src.w,
+             s->src.h, bilinear ? "bilinear" : "nearest", s->scale, plane->components, dest);
+    for (int i = 0; i < fetch->num_held; i++)
+        sh_hold(sh, fetch->held[i]);
     return true;
 }
 
-// guess_frame_lut_type (:1447-1468)
-static enum pl_lut_type guess_frame_lut_type(const struct pl_frame *frame, bool reversed)
+// color = (neutral luma, neutral chroma x 2, 1), then the sampled components go where the
+// plane's mapping says. Not needed for a plain RGBA plane.
+static bool append_plane_map(pl_shader sh, const struct pl_plane *plane, bool only_plane,
+                             float neutral_luma, float neutral_chroma)
 {
-    if (!frame->lut)
-        return PL_LUT_UNKNOWN;
-    if (frame->lut_type)
-        return frame->lut_type;
-    enum pl_color_system sys_in = frame->lut->repr_in.sys, sys_out = frame->lut->repr_out.sys;
-    if (reversed) {
-        const enum pl_color_system t = sys_in;
-        sys_in = sys_out;
-        sys_out = t;
+    bool identity = true;
+    uint32_t dest = 0;
+    for (int c = 0; c < 4; c++) {
+        const int to = c < plane->components ? plane->component_mapping[c] : -1;
+        dest |= (uint32_t) (to < 0 ? 0xff : to) << (8 * c);
+        if (c < plane->components && to != c)
+            identity = false;
     }
-    if (sys_in == PL_COLOR_SYSTEM_RGB && sys_out == sys_in)
-        return PL_LUT_NORMALIZED;
-    if (sys_in == frame->repr.sys && sys_out == PL_COLOR_SYSTEM_RGB)
-        return PL_LUT_CONVERSION;
-    return PL_LUT_NATIVE; // unknown: the default
+    if (identity && plane->components == 4 && only_plane)
+        return true;
+
+    struct plh_op *op = sh_op(sh, PLH_OP_PLANE_MAP);
+    if (!op)
+        return false;
+    op->f[0] = neutral_luma;
+    op->f[1] = op->f[2] = neutral_chroma;
+    op->f[3] = 1.0f;
+    op->i0 = dest;
+    op->i1 = plane->components;
+    op->i2 = identity;      // the sampled components stay where they are
+    sh_listf(sh, "plane_map(comps=%d, map=0x%08x, neutral=%g/%g)\n", plane->components,
+             (unsigned) dest, neutral_luma, neutral_chroma);
+    return true;
 }
 
-static bool pass_read_image(struct pass_state *pass)
+bool plh_stage_read(struct frame_job *job)
 {
-    const struct pl_render_params *params = pass->params;
-    struct pl_frame *image = &pass->image;
-    pl_renderer rr = pass->rr;
-    const int src_ref = frame_ref(image);
+    pl_renderer rr = job->rr;
+    const struct pl_render_params *params = job->params;
+    const struct pl_frame *image = &job->image;
 
-    struct plane_state planes[PL_MAX_PLANES];
-    struct plane_state *ref = &planes[src_ref];
+    struct rp_image_layout lay;
+    rp_layout_image(image, &lay);
+
+    // every plane: texture -> [deband] -> sampled onto the reference grid
+    struct work_image pimg[PL_MAX_PLANES];
+    float gain[PL_MAX_PLANES];
     for (int i = 0; i < image->num_planes; i++) {
-        planes[i] = (struct plane_state) {
-            .type = detect_plane_type(&image->planes[i], &image->repr),
-            .plane = image->planes[i],
-            .img = {
-                .w = image->planes[i].texture->params.w,
-                .h = image->planes[i].texture->params.h,
-                .tex = image->planes[i].texture,
-                .repr = image->repr,
-                .color = image->color,
-                .comps = image->planes[i].components,
-            },
-        };
-        // an overridden alpha mode drops the alpha channel / plane
-        if (image->repr.alpha == PL_ALPHA_NONE) {
-            if (planes[i].type == PLANE_ALPHA) {
-                planes[i].type = PLANE_INVALID;
-                continue;
-            }
-            for (int j = 0; j < planes[i].plane.components; j++) {
-                if (planes[i].plane.component_mapping[j] == PL_CHANNEL_A)
-                    planes[i].plane.component_mapping[j] = PL_CHANNEL_NONE;
-            }
-        }
-    }
-    pl_tex ref_tex = ref->plane.texture;
-
-    const int bits = image->repr.bits.sample_depth;
-    const float out_scale = bits ? (1llu << bits) / ((1llu << bits) - 1.0f) : 1.0f;
-    float neutral_luma = 0.0, neutral_chroma = 0.5f * out_scale;
-    if (pl_color_levels_guess(&image->repr) == PL_COLOR_LEVELS_LIMITED)
-        neutral_luma = 16 / 256.0f * out_scale;
-    if (!pl_color_system_is_ycbcr_like(image->repr.sys))
-        neutral_chroma = neutral_luma;
-
-    // sampling rect of every plane (:1724-1790)
-    for (int i = 0; i < image->num_planes; i++) {
-        struct plane_state *st = &planes[i];
-        if (!st->type)
+        const struct rp_plane_layout *pl = &lay.planes[i];
+        if (!pl->role)
             continue;
-        const float rx = (float) st->plane.texture->params.w / ref_tex->params.w,
-                    ry = (float) st->plane.texture->params.h / ref_tex->params.h;
-        // integer subsampling ratios only (fractionally subsampled planes are rounded up)
-        const float rrx = rx >= 1 ? roundf(rx) : 1.0 / roundf(1.0 / rx),
-                    rry = ry >= 1 ? roundf(ry) : 1.0 / roundf(1.0 / ry);
-        const float sx = st->plane.shift_x, sy = st->plane.shift_y;
-        st->img.rect = (pl_rect2df) {
-            .x0 = (image->crop.x0 - sx) * rrx,
-            .y0 = (image->crop.y0 - sy) * rry,
-            .x1 = (image->crop.x1 - sx) * rrx,
-            .y1 = (image->crop.y1 - sy) * rry,
+        pl_tex tex = image->planes[i].texture;
+        pimg[i] = (struct work_image) {
+            .tex = tex, .w = tex->params.w, .h = tex->params.h,
+            .repr = image->repr, .color = image->color,
+            .comps = image->planes[i].components,
+            .rect = pl->rect,
         };
-        st->plane_w = ref_tex->params.w * rrx;
-        st->plane_h = ref_tex->params.h * rry;
+        deband_plane(job, &pimg[i], pl->neutral);
 
-        float neutral[3] = {0.0};
-        for (int c = 0, idx = 0; c < st->plane.components; c++) {
-            switch (st->plane.component_mapping[c]) {
-            case PL_CHANNEL_Y: neutral[idx++] = neutral_luma; break;
-            case PL_CHANNEL_U: // fall through
-            case PL_CHANNEL_V: neutral[idx++] = neutral_chroma; break;
-            }
-        }
-        plane_deband(pass, &st->img, neutral);
-    }
-
-    // Drop subpixel offsets from the ref rect and re-add them as part of `pass->img.rect`,
-    // always rounding towards 0; drop anamorphic subpixel mismatches (:1810-1828)
-    const pl_rect2df ref_rc = ref->img.rect;
-    pl_rect2d ref_rounded;
-    ref_rounded.x0 = truncf(ref_rc.x0);
-    ref_rounded.y0 = truncf(ref_rc.y0);
-    ref_rounded.x1 = ref_rounded.x0 + roundf(pl_rect_w(ref_rc));
-    ref_rounded.y1 = ref_rounded.y0 + roundf(pl_rect_h(ref_rc));
-    const float off_x = ref_rc.x0 - ref_rounded.x0, off_y = ref_rc.y0 - ref_rounded.y0,
-                stretch_x = pl_rect_w(ref_rounded) / pl_rect_w(ref_rc),
-                stretch_y = pl_rect_h(ref_rounded) / pl_rect_h(ref_rc);
-
-    // every plane becomes a shader producing it on the (rounded) reference grid (:1830-1872)
-    float plane_scale[PL_MAX_PLANES];
-    for (int i = 0; i < image->num_planes; i++) {
-        struct plane_state *st = &planes[i];
-        const struct pl_plane *plane = &st->plane;
-        if (!st->type)
-            continue;
-
-        const float scale_x = pl_rect_w(st->img.rect) / pl_rect_w(ref_rc),
-                    scale_y = pl_rect_h(st->img.rect) / pl_rect_h(ref_rc),
-                    base_x = st->img.rect.x0 - scale_x * off_x,
-                    base_y = st->img.rect.y0 - scale_y * off_y;
-        struct pl_sample_src src = {
-            .components = plane->components,
-            .address_mode = plane->address_mode,
-            .scale      = pl_color_repr_normalize(&st->img.repr),
-            .new_w      = pl_rect_w(ref_rounded),
-            .new_h      = pl_rect_h(ref_rounded),
-            .rect = {
-                base_x, base_y,
-                base_x + stretch_x * pl_rect_w(st->img.rect),
-                base_y + stretch_y * pl_rect_h(st->img.rect),
-            },
-        };
-        if (plane->flipped) {
-            src.rect.y0 = st->plane_h - src.rect.y0;
-            src.rect.y1 = st->plane_h - src.rect.y1;
-        }
-
-        const bool unscaled = src.rect.x0 == 0 && src.rect.y0 == 0 &&
-                              src.rect.x1 == src.new_w && src.rect.y1 == src.new_h;
-        if (st->img.sh && st->img.w == src.new_w && st->img.h == src.new_h && unscaled) {
-            // image rects are already equal, no indirect scaling needed
-        } else {
-            src.tex = img_tex(pass, &st->img);
-            if (!src.tex)
+        struct pl_sample_src req = rp_plane_request(&lay, i);
+        req.scale = pl_color_repr_normalize(&pimg[i].repr);
+        const bool as_is = pimg[i].rec && pimg[i].w == req.new_w && pimg[i].h == req.new_h &&
+                           rp_plane_request_is_identity(&req);
+        if (!as_is) {
+            req.tex = plh_work_texture(job, &pimg[i]);
+            if (!req.tex)
                 return false;
-            st->img.tex = NULL;
-            st->img.sh = pl_dispatch_begin(rr->dp);
-            dispatch_sampler(pass, st->img.sh, i == src_ref ? &rr->sampler_src : &rr->samplers_aux[i],
-                             SAMPLER_PLANE, &src);
-            st->img.err_enum |= PL_RENDER_ERR_SAMPLING;
-            st->img.rect.x0 = st->img.rect.y0 = 0.0f;
-            st->img.w = st->img.rect.x1 = src.new_w;
-            st->img.h = st->img.rect.y1 = src.new_h;
-            src.scale = 1.0;
+            pimg[i].tex = NULL;
+            pimg[i].rec = pl_dispatch_begin(rr->dp);
+            run_scaler(job, pimg[i].rec, i == lay.ref ? &rr->scale_ref : &rr->scale_plane[i],
+                       RP_USE_PLANE, &req);
+            pimg[i].fail_bit |= PL_RENDER_ERR_SAMPLING;
+            pimg[i].w = req.new_w;
+            pimg[i].h = req.new_h;
+            pimg[i].rect = (pl_rect2df) { 0, 0, req.new_w, req.new_h };
+            req.scale = 1.0;    // applied by the sampler
         }
-        plane_scale[i] = src.scale;
+        gain[i] = req.scale;
     }
 
-    // "pass_read_image": color = (neutral_luma, neutral_chroma x2, 1); per plane
-    // tmp = scale * plane(); color[mapping[c]] = tmp[c]                            (:1790-1890)
-    // The reference plane's shader is the pass itself; the other planes are fetched into it.
-    pl_shader sh = img_sh(pass, &ref->img);
-    ref->img.sh = NULL;
-    if (plane_scale[src_ref] != 1.0f) {
-        struct plh_op *op = sh_op(sh, PLH_OP_SCALE);
-        if (!op)
-            return false;
-        op->f[0] = op->f[1] = op->f[2] = op->f[3] = plane_scale[src_ref];
-        sh_listf(sh, "scale(%g)\n", plane_scale[src_ref]);
-    }
-    const struct pl_plane *rplane = &ref->plane;
-    bool trivial = rplane->components == 4 && image->num_planes == 1;
-    for (int c = 0; c < rplane->components; c++)
-        trivial &= rplane->component_mapping[c] == c;
-    if (!trivial) {
-        struct plh_op *op = sh_op(sh, PLH_OP_PLANE_MAP);
-        if (!op)
-            return false;
-        op->f[0] = neutral_luma;
-        op->f[1] = op->f[2] = neutral_chroma;
-        op->f[3] = 1.0f;
-        op->i1 = rplane->components;
-        op->i0 = 0;
-        op->i2 = 1; // identity prefix?
-        for (int c = 0; c < 4; c++) {
-            const int m = c < rplane->components ? rplane->component_mapping[c] : -1;
-            op->i0 |= (m < 0 ? 0xff : m) << (8 * c);
-            if (c < rplane->components && m != c)
-                op->i2 = 0;
-        }
-        sh_listf(sh, "plane_map(comps=%d, map=0x%08x, neutral=%g/%g)\n", rplane->components,
-                 (unsigned) op->i0, neutral_luma, neutral_chroma);
-    }
+    // the reference plane's recording becomes the pass; the others are fetched into it
+    struct work_image *ref = &pimg[lay.ref];
+    pl_shader sh = plh_work_shader(job, ref);
+    ref->rec = NULL;
+    if (gain[lay.ref] != 1.0f && !plh_append_scale(sh, gain[lay.ref], true))
+        return false;
+    if (!append_plane_map(sh, &lay.planes[lay.ref].plane, image->num_planes == 1,
+                          lay.neutral_luma, lay.neutral_chroma))
+        return false;
 
     for (int i = 0; i < image->num_planes; i++) {
-        struct plane_state *st = &planes[i];
-        if (!st->type || i == src_ref)
+        if (i == lay.ref || !lay.planes[i].role)
             continue;
-        pl_shader psh = img_sh(pass, &st->img);
-        if (plane_scale[i] != 1.0f || !merge_plane_fetch(sh, psh, &st->plane)) {
-            // not a plain fetch (debanded / scaled by a complex filter): render it, fetch 1:1
-            st->img.sh = psh;
-            if (plane_scale[i] != 1.0f) {
-                struct plh_op *op = sh_op(psh, PLH_OP_SCALE);
-                if (op)
-                    op->f[0] = op->f[1] = op->f[2] = op->f[3] = plane_scale[i];
+        const struct pl_plane *plane = &lay.planes[i].plane;
+        pl_shader psh = plh_work_shader(job, &pimg[i]);
+        if (gain[i] != 1.0f || !plh_append_plane_fetch(sh, psh, plane)) {
+            // more than a fetch (debanded, or scaled by a real filter): run it, fetch the result
+            if (gain[i] != 1.0f)
+                plh_append_scale(psh, gain[i], true);
+            pimg[i].comps = plane->components;
+            bool merged = plh_work_texture(job, &pimg[i]) != NULL;
+            if (merged) {
+                psh = plh_work_shader(job, &pimg[i]);
+                merged = plh_append_plane_fetch(sh, psh, plane);
             }
-            st->img.comps = st->plane.components;
-            if (!img_tex(pass, &st->img)) {
-                pl_dispatch_abort(rr->dp, &sh);
-                return false;
-            }
-            psh = img_sh(pass, &st->img);
-            if (!merge_plane_fetch(sh, psh, &st->plane)) {
-                pl_dispatch_abort(rr->dp, &psh);
+            if (!merged) {
+                pl_dispatch_abort(rr->dp, &pimg[i].rec);
                 pl_dispatch_abort(rr->dp, &sh);
                 return false;
             }
         }
-        pl_dispatch_abort(rr->dp, &psh);
-        st->img.sh = NULL;
+        pl_dispatch_abort(rr->dp, &pimg[i].rec);
     }
 
-    pass->img = (struct img) {
-        .sh     = sh,
-        .w      = pl_rect_w(ref_rounded),
-        .h      = pl_rect_h(ref_rounded),
-        .repr   = ref->img.repr,
-        .color  = image->color,
-        .comps  = ref->img.repr.alpha == PL_ALPHA_NONE ? 3 : 4,
-        .rect   = { off_x, off_y, off_x + pl_rect_w(ref_rc), off_y + pl_rect_h(ref_rc) },
-        .err_msg = ref->img.err_msg, .err_enum = ref->img.err_enum, .err_tex = ref->img.err_tex,
+    job->img = (struct work_image) {
+        .rec   = sh,
+        .w     = pl_rect_w(lay.grid),
+        .h     = pl_rect_h(lay.grid),
+        .repr  = ref->repr,
+        .color = image->color,
+        .comps = ref->repr.alpha == PL_ALPHA_NONE ? 3 : 4,
+        .rect  = {
+            lay.off_x, lay.off_y,
+            lay.off_x + pl_rect_w(lay.planes[lay.ref].rect),
+            lay.off_y + pl_rect_h(lay.planes[lay.ref].rect),
+        },
+        .fail_msg = ref->fail_msg, .fail_bit = ref->fail_bit, .fail_tex = ref->fail_tex,
     };
-    pass->ref_rect = pass->img.rect;
+    struct work_image *img = &job->img;
 
-    // frame LUT (:1920-1946): NATIVE / CONVERSION act on the raw (bit-depth-fixed) samples, a
-    // CONVERSION LUT replaces the decoding, NORMALIZED acts on the decoded RGB
-    const enum pl_lut_type lut_type = guess_frame_lut_type(image, false);
-    bool needs_conversion = true;
-    if (lut_type == PL_LUT_NATIVE || lut_type == PL_LUT_CONVERSION) {
-        const float scale = pl_color_repr_normalize(&pass->img.repr);
-        struct plh_op *op = sh_op(sh, PLH_OP_SCALE);
-        if (op) {
-            op->f[0] = op->f[1] = op->f[2] = op->f[3] = scale;
-            sh_listf(sh, "scale(%g)\n", scale);
-        }
-        pl_shader_custom_lut(sh, image->lut, &rr->lut_state[LUT_IMAGE]);
-        if (lut_type == PL_LUT_CONVERSION) {
-            pass->img.repr.sys = PL_COLOR_SYSTEM_RGB;
-            pass->img.repr.levels = PL_COLOR_LEVELS_FULL;
-            needs_conversion = false;
-        }
+    // Frame LUT (:1920-1946). NATIVE and CONVERSION see the raw samples (bit depth fixed up),
+    // CONVERSION also does the decoding; NORMALIZED sees decoded RGB.
+    const enum pl_lut_type lut = rp_frame_lut_type(image, false);
+    const bool raw_lut = lut == PL_LUT_NATIVE || lut == PL_LUT_CONVERSION;
+    if (raw_lut) {
+        plh_append_scale(sh, pl_color_repr_normalize(&img->repr), true);
+        pl_shader_custom_lut(sh, image->lut, &rr->lut_state[RR_LUT_IMAGE]);
     }
-    if (needs_conversion) {
-        if (pass->img.repr.sys == PL_COLOR_SYSTEM_XYZ) {
-            pl_shader_linearize(sh, &pass->img.color);
-            pass->img.color.transfer = PL_COLOR_TRC_LINEAR;
+    if (lut == PL_LUT_CONVERSION) {
+        img->repr.sys = PL_COLOR_SYSTEM_RGB;
+        img->repr.levels = PL_COLOR_LEVELS_FULL;
+    } else {
+        if (img->repr.sys == PL_COLOR_SYSTEM_XYZ) {
+            // the XYZ matrix applies to linear light
+            pl_shader_linearize(sh, &img->color);
+            img->color.transfer = PL_COLOR_TRC_LINEAR;
         }
-        pl_shader_decode_color(sh, &pass->img.repr, params->color_adjustment);
+        pl_shader_decode_color(sh, &img->repr, params->color_adjustment);
     }
-    if (lut_type == PL_LUT_NORMALIZED)
-        pl_shader_custom_lut(sh, image->lut, &rr->lut_state[LUT_IMAGE]);
+    if (lut == PL_LUT_NORMALIZED)
+        pl_shader_custom_lut(sh, image->lut, &rr->lut_state[RR_LUT_IMAGE]);
 
-    // pre-multiply alpha before the rest of the pipeline, to avoid bleeding colours from
-    // transparent regions into opaque ones
-    pl_shader_set_alpha(sh, &pass->img.repr, PL_ALPHA_PREMULTIPLIED);
+    // transparent regions must not bleed into opaque ones while filtering
+    pl_shader_set_alpha(sh, &img->repr, PL_ALPHA_PREMULTIPLIED);
     return !pl_shader_is_failed(sh);
 }
 
-/* ---- pass_scale_main (:1964-2087) ------------------------------------------------------------- */
+/* ---- HDR peak measurement ------------------------------------------------------------------- */
 
-static bool pass_scale_main(struct pass_state *pass)
+static bool owns_workgroup_shape(const pl_shader sh)
 {
-    const struct pl_render_params *params = pass->params;
-    pl_renderer rr = pass->rr;
-    pl_fmt fbofmt = pass->fbofmt[pass->img.comps];
-    if (!fbofmt)
-        return true; // no FBOs: skip the main scaler
+    const int t = sh->pass.s.type;
+    return t == PLH_SAMPLE_POLAR || t == PLH_SAMPLE_ORTHO || t == PLH_SAMPLE_DEBAND;
+}
 
-    const pl_rect2df new_rect = {
-        .x1 = abs(pl_rect_w(pass->dst_rect)),
-        .y1 = abs(pl_rect_h(pass->dst_rect)),
-    };
+static void measure_peak(struct frame_job *job)
+{
+    pl_renderer rr = job->rr;
+    const struct pl_render_params *params = job->params;
+    struct work_image *img = &job->img;
 
-    struct img *img = &pass->img;
-    struct pl_sample_src src = {
+    const char *why_not = rp_peak_skip_reason(&job->caps, params, &job->image.color, &img->color,
+                                              &job->target.color);
+    if (!why_not && !job->caps.fbo[4] && !params->peak_detect_params->allow_delayed) {
+        raise(rr, PL_RENDER_ERR_PEAK_DETECT, PL_LOG_WARN, "Disabling peak detection because "
+              "`pl_peak_detect_params.allow_delayed` is false, but lack of FBOs forces the "
+              "result to be delayed.");
+        why_not = "no intermediates";
+    }
+    if (why_not) {
+        pl_reset_detected_peak(rr->tone_map_state);
+        return;
+    }
+
+    if (img->rec && job->caps.fbo[4] && owns_workgroup_shape(img->rec)) {
+        // The scaler / deband kernels have their own workgroup shape, the measurement needs the
+        // reference's 16x16 tiling: make the image resident and measure it with a pass that
+        // only reads (the reference merges the two into one compute shader; same image, same
+        // tiling, the values having gone through the intermediate's f16 rounding).
+        pl_tex tex = plh_work_texture(job, img);
+        bool ok = tex != NULL;
+        if (ok) {
+            pl_shader probe = pl_dispatch_begin(rr->dp);
+            ok = pl_shader_sample_direct(probe, pl_sample_src( .tex = tex )) &&
+                 pl_shader_detect_peak(probe, img->color, &rr->tone_map_state,
+                                       params->peak_detect_params);
+            if (ok) {
+                ok = pl_dispatch_compute(rr->dp, pl_dispatch_compute_params(
+                    .shader = &probe, .width = tex->params.w, .height = tex->params.h,
+                ));
+            } else {
+                pl_dispatch_abort(rr->dp, &probe);
+            }
+        }
+        if (!ok) {
+            raise(rr, PL_RENDER_ERR_PEAK_DETECT, PL_LOG_WARN,
+                  "Failed measuring the HDR peak.. disabling");
+            pl_reset_detected_peak(rr->tone_map_state);
+        }
+        job->peak_pending = false;  // already complete in stream order
+        return;
+    }
+
+    if (!pl_shader_detect_peak(plh_work_shader(job, img), img->color, &rr->tone_map_state,
+                               params->peak_detect_params)) {
+        raise(rr, PL_RENDER_ERR_PEAK_DETECT, PL_LOG_WARN,
+              "Failed creating HDR peak detection shader.. disabling");
+        pl_reset_detected_peak(rr->tone_map_state);
+        return;
+    }
+    // the pass carrying the measurement has to run before this frame's tone mapping
+    job->peak_pending = !params->peak_detect_params->allow_delayed;
+}
+
+/* ---- stage 2: scale ------------------------------------------------------------------------- */
+
+bool plh_stage_scale(struct frame_job *job)
+{
+    pl_renderer rr = job->rr;
+    const struct pl_render_params *params = job->params;
+    struct work_image *img = &job->img;
+    if (!job->caps.fbo[img->comps])
+        return true;    // no intermediates: the output pass samples the source directly
+
+    struct pl_sample_src req = {
         .components = img->comps,
-        .new_w      = pl_rect_w(new_rect),
-        .new_h      = pl_rect_h(new_rect),
+        .new_w      = abs(pl_rect_w(job->geo.dst)),
+        .new_h      = abs(pl_rect_h(job->geo.dst)),
         .rect       = img->rect,
     };
+    // a recording with a fixed output size (deband, ...) cannot be resampled in place
+    int fw, fh;
+    const bool fixed = img->rec && pl_shader_output_size(img->rec, &fw, &fh) &&
+                       (fw != req.new_w || fh != req.new_h);
+    const struct rp_scale_stage st = rp_plan_scale(&job->caps, params, &req, NULL, &img->color,
+                                                   img->comps, fixed);
+    const pl_rect2df full = { .x1 = st.out_w, .y1 = st.out_h };
 
-    const struct pl_frame *image = &pass->image;
-    bool need_fbo = false;
+    if (st.peak_before)
+        measure_peak(job);
 
-    // force FBO indirection if this shader is non-resizable
-    int out_w, out_h;
-    if (img->sh && pl_shader_output_size(img->sh, &out_w, &out_h))
-        need_fbo |= out_w != src.new_w || out_h != src.new_h;
-
-    const struct sampler_info info = sample_src_info(pass, &src, SAMPLER_MAIN);
-    bool use_sigmoid = info.dir == SAMPLER_UP && params->sigmoid_params;
-    bool use_linear  = info.dir == SAMPLER_DOWN;
-
-    // opportunistically measure the peak here if that saves a pass
-    if (info.dir == SAMPLER_UP)
-        hdr_update_peak(pass);
-
-    if (info.dir == SAMPLER_NOOP && !need_fbo)
-        goto done; // no-op
-
-    if (info.type == SAMPLER_DIRECT && !need_fbo) {
-        // "free" sampling: the final pass samples the source at the output size
-        img->w = src.new_w;
-        img->h = src.new_h;
-        img->rect = new_rect;
-        goto done;
-    }
-
-    // hard-disable sigmoidization and linearization when required
-    if (params->disable_linear_scaling || fbofmt->component_depth[0] < 16)
-        use_sigmoid = use_linear = false;
-
-    // sigmoidization clips to [0,1]: not for HDR; linear HDR needs a float FBO
-    if (pl_color_space_is_hdr(&img->color)) {
-        use_sigmoid = false;
-        if (fbofmt->type != PL_FMT_FLOAT)
-            use_linear = false;
-    }
-
-    if (!(use_linear || use_sigmoid) && img->color.transfer == PL_COLOR_TRC_LINEAR) {
-        img->color.transfer = image->color.transfer;
-        if (image->color.transfer == PL_COLOR_TRC_LINEAR)
-            img->color.transfer = PL_COLOR_TRC_GAMMA22; // arbitrary fallback
-        pl_shader_delinearize(img_sh(pass, img), &img->color);
-    }
-
-    if (use_linear || use_sigmoid) {
-        pl_shader_linearize(img_sh(pass, img), &img->color);
-        img->color.transfer = PL_COLOR_TRC_LINEAR;
-    }
-    if (use_sigmoid)
-        pl_shader_sigmoidize(img_sh(pass, img), params->sigmoid_params);
-
-    // ---- PASS A: everything recorded so far lands in an FBO (or is fused, see above) ----
-    pl_shader sh = pl_dispatch_begin(rr->dp);
-    if (img->sh && try_fused_polar(pass, sh, &src, img->sh, img->w, img->h)) {
-        pl_dispatch_abort(rr->dp, &img->sh);
-    } else {
-        src.tex = img_tex(pass, img);
-        if (!src.tex) {
-            pl_dispatch_abort(rr->dp, &sh);
-            return false;
+    if (st.defer) {
+        img->w = st.out_w;
+        img->h = st.out_h;
+        img->rect = full;
+    } else if (!st.skip) {
+        if (st.restore_transfer) {
+            // decoding left linear light (XYZ), but scaling is to happen non-linearly
+            img->color.transfer = job->image.color.transfer;
+            if (img->color.transfer == PL_COLOR_TRC_LINEAR)
+                img->color.transfer = PL_COLOR_TRC_GAMMA22;     // arbitrary, as the reference
+            pl_shader_delinearize(plh_work_shader(job, img), &img->color);
         }
-        dispatch_sampler(pass, sh, &rr->sampler_main, SAMPLER_MAIN, &src);
+        if (st.linear || st.sigmoid) {
+            pl_shader_linearize(plh_work_shader(job, img), &img->color);
+            img->color.transfer = PL_COLOR_TRC_LINEAR;
+        }
+        if (st.sigmoid)
+            pl_shader_sigmoidize(plh_work_shader(job, img), params->sigmoid_params);
+
+        // pass boundary: what is recorded so far either fuses into the polar kernel or lands
+        // in an intermediate image the scaler reads
+        pl_shader sh = pl_dispatch_begin(rr->dp);
+        if (img->rec && try_fused_polar(job, sh, &req, img->rec, img->w, img->h)) {
+            pl_dispatch_abort(rr->dp, &img->rec);
+        } else {
+            req.tex = plh_work_texture(job, img);
+            if (!req.tex) {
+                pl_dispatch_abort(rr->dp, &sh);
+                return false;
+            }
+            run_scaler(job, sh, &rr->scale_main, RP_USE_MAIN, &req);
+        }
+        job->peak_pending = false;  // whatever rode on the previous pass has run
+        img->tex = NULL;
+        img->copy_of = NULL;
+        img->rec = sh;
+        img->w = st.out_w;
+        img->h = st.out_h;
+        img->rect = full;
+        if (st.sigmoid)
+            pl_shader_unsigmoidize(sh, params->sigmoid_params);
     }
-    pass->need_peak_fbo = false;
 
-    img->tex  = NULL;
-    img->sh   = sh;
-    img->w    = src.new_w;
-    img->h    = src.new_h;
-    img->rect = new_rect;
-
-    if (use_sigmoid)
-        pl_shader_unsigmoidize(img_sh(pass, img), params->sigmoid_params);
-
-done:
-    if (info.dir != SAMPLER_UP)
-        hdr_update_peak(pass);
+    if (!st.peak_before)
+        measure_peak(job);
     return true;
 }
 
-/* ---- pass_convert_colors (:2157-2280) ---------------------------------------------------------- */
+/* ---- stage 3: colours ----------------------------------------------------------------------- */
 
-// Low-resolution luminance map for the tone mapper's contrast recovery (get_feature_map
-// :2089-2154): I of IPT at full resolution, low-passed (bicubic, mirrored edges) down to
-// 1/contrast_smoothness of the output size.
-static pl_tex get_feature_map(struct pass_state *pass)
+// Low-resolution luminance of the image for the tone mapper's contrast recovery: I of IPT at
+// full size, then low-passed (bicubic, mirrored edges) to 1/smoothness of the output size.
+static pl_tex make_feature_map(struct frame_job *job)
 {
-    const struct pl_render_params *params = pass->params;
-    pl_renderer rr = pass->rr;
-    const struct pl_color_map_params *cparams =
-        PL_DEF(params->color_map_params, &pl_color_map_default_params);
-    if (!cparams->contrast_recovery || cparams->contrast_smoothness <= 1)
+    pl_renderer rr = job->rr;
+    struct work_image *img = &job->img;
+    int mw, mh;
+    if (!rp_wants_feature_map(&job->caps, job->params, &img->color, &job->target.color,
+                              abs(pl_rect_w(job->geo.dst)), abs(pl_rect_h(job->geo.dst)),
+                              &mw, &mh))
         return NULL;
-    if (!pass->fbofmt[4] || !pass->fbofmt[1])
-        return NULL;
-    if (!pl_color_space_is_hdr(&pass->img.color))
-        return NULL;
-    if (rr->errors & (PL_RENDER_ERR_SAMPLING | PL_RENDER_ERR_CONTRAST_RECOVERY))
-        return NULL;
-    if (pass->img.color.hdr.max_luma <= pass->target.color.hdr.max_luma + 1e-6)
-        return NULL; // no adaptation needed
-    if (params->lut && params->lut_type == PL_LUT_CONVERSION)
-        return NULL; // LUT handles tone mapping
-
-    struct img *img = &pass->img;
-    if (!img_tex(pass, img))
+    if (!plh_work_texture(job, img))
         return NULL;
 
-    const float ratio = cparams->contrast_smoothness;
-    const int cr_w = ceilf(abs(pl_rect_w(pass->dst_rect)) / ratio);
-    const int cr_h = ceilf(abs(pl_rect_h(pass->dst_rect)) / ratio);
-    pl_tex inter_tex = get_fbo(pass, img->w, img->h, NULL, 1);
-    pl_tex out_tex = get_fbo(pass, cr_w, cr_h, NULL, 1);
-    if (!inter_tex || !out_tex)
-        goto error;
-
-    pl_shader sh = pl_dispatch_begin(rr->dp);
-    pl_shader_sample_direct(sh, pl_sample_src( .tex = img->tex ));
-    pl_shader_extract_features(sh, img->color);
-    if (!pl_dispatch_finish(rr->dp, pl_dispatch_params(.shader = &sh, .target = inter_tex)))
-        goto error;
-
-    const struct pl_sample_src src = {
-        .tex          = inter_tex,
-        .rect         = img->rect,
-        .address_mode = PL_TEX_ADDRESS_MIRROR,
-        .components   = 1,
-        .new_w        = cr_w,
-        .new_h        = cr_h,
-    };
-    sh = pl_dispatch_begin(rr->dp);
-    dispatch_sampler(pass, sh, &rr->sampler_contrast, SAMPLER_LOWPASS, &src);
-    if (!pl_dispatch_finish(rr->dp, pl_dispatch_params(.shader = &sh, .target = out_tex)))
-        goto error;
-    return out_tex;
-
-error:
-    RR_ERR(rr, "Failed extracting luma for contrast recovery, disabling");
-    rr->errors |= PL_RENDER_ERR_CONTRAST_RECOVERY;
-    return NULL;
+    pl_tex full = borrow_fbo(job, img->w, img->h, NULL, 1);
+    pl_tex small = borrow_fbo(job, mw, mh, NULL, 1);
+    bool ok = full && small;
+    if (ok) {
+        pl_shader sh = pl_dispatch_begin(rr->dp);
+        pl_shader_sample_direct(sh, pl_sample_src( .tex = img->tex ));
+        pl_shader_extract_features(sh, img->color);
+        ok = pl_dispatch_finish(rr->dp, pl_dispatch_params( .shader = &sh, .target = full ));
+    }
+    if (ok) {
+        const struct pl_sample_src req = {
+            .tex = full, .rect = img->rect, .address_mode = PL_TEX_ADDRESS_MIRROR,
+            .components = 1, .new_w = mw, .new_h = mh,
+        };
+        pl_shader sh = pl_dispatch_begin(rr->dp);
+        run_scaler(job, sh, &rr->scale_contrast, RP_USE_LOWPASS, &req);
+        ok = pl_dispatch_finish(rr->dp, pl_dispatch_params( .shader = &sh, .target = small ));
+    }
+    if (!ok) {
+        raise(rr, PL_RENDER_ERR_CONTRAST_RECOVERY, PL_LOG_ERR,
+              "Failed extracting luma for contrast recovery, disabling");
+        return NULL;
+    }
+    return small;
 }
 
-static void pass_convert_colors(struct pass_state *pass)
+// pl_render_params.lut between the image's and the target's colour space (:2199-2247).
+// Returns false if the LUT replaces the regular conversion.
+static bool apply_params_lut(struct frame_job *job, pl_shader sh, bool *prelinearized)
 {
-    const struct pl_render_params *params = pass->params;
-    const struct pl_frame *image = &pass->image, *target = &pass->target;
-    pl_renderer rr = pass->rr;
-    struct img *img = &pass->img;
+    pl_renderer rr = job->rr;
+    const struct pl_render_params *params = job->params;
+    struct work_image *img = &job->img;
+    const struct pl_custom_lut *lut = params->lut;
+    struct pl_color_space in = lut->color_in, out = lut->color_out;
+    const bool normalized = params->lut_type == PL_LUT_NORMALIZED;
+    const bool conversion = params->lut_type == PL_LUT_CONVERSION;
 
-    // lut3d_tricubic exists in one variant of the generic pass kernel only (k_pass.hip): give the
-    // colour conversion a pass of its own instead of fusing it into the pending sampler
-    if (params->color_map_params && params->color_map_params->lut3d_tricubic && img->sh) {
-        if (!img_tex(pass, img)) {
-            RR_ERR(rr, "Failed flushing the image ahead of the tricubic colour map");
-            return;
-        }
+    if (normalized && !*prelinearized) {
+        pl_shader_linearize(sh, &img->color);   // this placement wants linear input
+        img->color.transfer = PL_COLOR_TRC_LINEAR;
+        *prelinearized = true;
     }
-    pl_shader sh = img_sh(pass, img);
+    // whatever the LUT leaves unspecified is taken from the image (as it is at this point)
+    const struct pl_color_space *fill = normalized ? &img->color : &job->image.color;
+    pl_color_space_merge(&in, fill);
+    if (!conversion)
+        pl_color_space_merge(&out, fill);
+
+    pl_shader_color_map_ex(sh, params->color_map_params, pl_color_map_args(
+        .src = job->image.color, .dst = in, .prelinearized = *prelinearized));
+    if (normalized)
+        plh_append_scale(sh, 1.0f / pl_color_transfer_nominal_peak(in.transfer), false);
+    pl_shader_custom_lut(sh, lut, &rr->lut_state[RR_LUT_PARAMS]);
+    if (normalized)
+        plh_append_scale(sh, pl_color_transfer_nominal_peak(out.transfer), false);
+    if (conversion)
+        return false;
+    pl_shader_color_map_ex(sh, params->color_map_params, pl_color_map_args(
+        .src = out, .dst = img->color));
+    return true;
+}
+
+void plh_stage_colors(struct frame_job *job)
+{
+    pl_renderer rr = job->rr;
+    const struct pl_render_params *params = job->params;
+    const struct pl_frame *image = &job->image, *target = &job->target;
+    struct work_image *img = &job->img;
+
+    // the tricubic 3D-LUT lookup exists in one variant of the generic pass kernel only: keep
+    // the colour conversion out of a pending scaler pass
+    const struct pl_color_map_params *cm = params->color_map_params;
+    if (cm && cm->lut3d_tricubic && img->rec && !plh_work_texture(job, img)) {
+        RR_LOG(rr, PL_LOG_ERR, "Failed flushing the image ahead of the tricubic colour map");
+        return;
+    }
+    pl_shader sh = plh_work_shader(job, img);
 
     bool prelinearized = false;
     if (img->color.transfer == PL_COLOR_TRC_LINEAR) {
         if (img->repr.alpha == PL_ALPHA_PREMULTIPLIED) {
-            // prelinearization happened with premultiplied alpha, colour mapping wants
-            // independent alpha: go back to the non-linear representation *before* the alpha
-            // mode conversion, to avoid distortion
+            // scaled in linear light *with premultiplied alpha*; the mapping wants independent
+            // alpha: return to the encoded signal first, so that the alpha division happens
+            // where it was multiplied in
             img->color.transfer = image->color.transfer;
             pl_shader_delinearize(sh, &img->color);
         } else {
             prelinearized = true;
         }
-    } else if (img->color.transfer != image->color.transfer) {
-        if (image->color.transfer == PL_COLOR_TRC_LINEAR) {
-            pl_shader_linearize(sh, &img->color);
-            img->color.transfer = PL_COLOR_TRC_LINEAR;
-        }
+    } else if (image->color.transfer == PL_COLOR_TRC_LINEAR) {
+        pl_shader_linearize(sh, &img->color);
+        img->color.transfer = PL_COLOR_TRC_LINEAR;
     }
-
-    // all processing in independent alpha, to avoid nonlinear distortions
     pl_shader_set_alpha(sh, &img->repr, PL_ALPHA_INDEPENDENT);
 
-    // colour blindness simulation (:2194-2196)
     if (params->cone_params)
         pl_shader_cone_distort(sh, img->color, params->cone_params);
 
-    // ---- PASS B: a same-frame peak measurement must finish before it is consumed ----
-    // main LUT (:2199-2247): between the image's and the target's colour space
-    bool need_conversion = true;
-    if (params->lut) {
-        struct pl_color_space lut_in = params->lut->color_in;
-        struct pl_color_space lut_out = params->lut->color_out;
-        switch (params->lut_type) {
-        case PL_LUT_UNKNOWN:
-        case PL_LUT_NATIVE:
-            pl_color_space_merge(&lut_in, &image->color);
-            pl_color_space_merge(&lut_out, &image->color);
-            break;
-        case PL_LUT_CONVERSION:
-            pl_color_space_merge(&lut_in, &image->color);
-            need_conversion = false; // the LUT is the conversion
-            break;
-        case PL_LUT_NORMALIZED:
-            if (!prelinearized) {
-                // PL_LUT_NORMALIZED wants linear input data
-                pl_shader_linearize(sh, &img->color);
-                img->color.transfer = PL_COLOR_TRC_LINEAR;
-                prelinearized = true;
-            }
-            pl_color_space_merge(&lut_in, &img->color);
-            pl_color_space_merge(&lut_out, &img->color);
-            break;
-        }
-
-        pl_shader_color_map_ex(sh, params->color_map_params, pl_color_map_args(
-            .src = image->color, .dst = lut_in, .prelinearized = prelinearized));
-        if (params->lut_type == PL_LUT_NORMALIZED) {
-            struct plh_op *op = sh_op(sh, PLH_OP_SCALE);
-            if (op) {
-                const float k = 1.0f / pl_color_transfer_nominal_peak(lut_in.transfer);
-                op->f[0] = op->f[1] = op->f[2] = k;
-                op->f[3] = 1.0f;
-            }
-        }
-        pl_shader_custom_lut(sh, params->lut, &rr->lut_state[LUT_PARAMS]);
-        if (params->lut_type == PL_LUT_NORMALIZED) {
-            struct plh_op *op = sh_op(sh, PLH_OP_SCALE);
-            if (op) {
-                const float k = pl_color_transfer_nominal_peak(lut_out.transfer);
-                op->f[0] = op->f[1] = op->f[2] = k;
-                op->f[3] = 1.0f;
-            }
-        }
-        if (params->lut_type != PL_LUT_CONVERSION) {
-            pl_shader_color_map_ex(sh, params->color_map_params, pl_color_map_args(
-                .src = lut_out, .dst = img->color));
-        }
-    }
-
-    if (need_conversion) {
-        if (pass->need_peak_fbo && !img_tex(pass, img))
+    const bool convert = !params->lut || apply_params_lut(job, sh, &prelinearized);
+    if (convert) {
+        // a measurement made by this frame has to be on the device before it is read
+        if (job->peak_pending && !plh_work_texture(job, img))
             return;
-
-        // HDR feature map for the contrast recovery, if required (dispatches the image so far)
-        pl_tex feature_map = get_feature_map(pass);
-        sh = img_sh(pass, img);
-
+        pl_tex features = make_feature_map(job);
+        sh = plh_work_shader(job, img);
         pl_shader_color_map_ex(sh, params->color_map_params, pl_color_map_args(
             .src           = image->color,
             .dst           = target->color,
             .prelinearized = prelinearized,
             .state         = &rr->tone_map_state,
-            .feature_map   = feature_map,
+            .feature_map   = features,
         ));
     }
 
-    // target LUT (:2272-2274): NORMALIZED / CONVERSION (RGB -> native) act while encoding
-    const enum pl_lut_type tlut = guess_frame_lut_type(target, true);
-    if (tlut == PL_LUT_NORMALIZED || tlut == PL_LUT_CONVERSION)
-        pl_shader_custom_lut(sh, target->lut, &rr->lut_state[LUT_TARGET]);
+    // a target LUT working on RGB acts here; a NATIVE one after the encoding
+    const enum pl_lut_type tl = rp_frame_lut_type(target, true);
+    if (tl == PL_LUT_NORMALIZED || tl == PL_LUT_CONVERSION)
+        pl_shader_custom_lut(sh, target->lut, &rr->lut_state[RR_LUT_TARGET]);
     img->color = target->color;
 }
 
-/* ---- pass_output_target (:2586-2960) ------------------------------------------------------------ */
+/* ---- stage 4: output ------------------------------------------------------------------------ */
 
-// sRGB background colour -> target colour space (translate_srgb_color :2557-2584)
-static void translate_srgb_color(float out[3], const float in[3], const struct pl_color_space *csp)
+// the sRGB background colour in the target's colour space (:2557-2584)
+static void background_in(const struct pl_color_space *csp, const float srgb[3], float out[3])
 {
-    memcpy(out, in, 3 * sizeof(float));
+    memcpy(out, srgb, 3 * sizeof(float));
     if (csp->primaries == PL_COLOR_PRIM_BT_709 && csp->transfer == PL_COLOR_TRC_SRGB)
         return;
-    struct pl_color_space srgb = pl_color_space_srgb;
-    pl_color_linearize(&srgb, out);
+    const struct pl_color_space from = pl_color_space_srgb;
+    pl_color_linearize(&from, out);
     if (csp->primaries != PL_COLOR_PRIM_BT_709) {
         const pl_matrix3x3 m = pl_get_color_mapping_matrix(
             pl_raw_primaries_get(PL_COLOR_PRIM_BT_709), pl_raw_primaries_get(csp->primaries),
@@ -1548,829 +1093,317 @@ static void translate_srgb_color(float out[3], const float in[3], const struct p
     pl_color_delinearize(csp, out);
 }
 
-static void record_swizzle(pl_shader sh, int comps, const int mapping[4])
+// fill every plane of the target with the (encoded) background colour
+static void clear_planes(struct frame_job *job, float scale)
 {
-    // swizzle_color (:791-808): color = (0,0,0,1); color[c] = orig[mapping[c]]
-    bool trivial = comps == 4;
-    for (int c = 0; c < comps; c++)
-        trivial &= mapping[c] == c;
-    if (trivial)
+    const struct pl_render_params *params = job->params;
+    const struct pl_frame *target = &job->target;
+    float rgb[3];
+    background_in(&target->color, params->background_color, rgb);
+    struct pl_color_repr repr = target->repr;
+    pl_transform3x3 enc = pl_color_repr_decode(&repr, NULL);
+    pl_transform3x3_invert(&enc);
+    pl_transform3x3_apply(&enc, rgb);
+
+    for (int i = 0; i < target->num_planes; i++) {
+        const struct pl_plane *pl = &target->planes[i];
+        float texel[4] = {0};
+        for (int c = 0; c < pl->components; c++) {
+            const int ch = pl->component_mapping[c];
+            if (ch == PL_CHANNEL_A)
+                texel[c] = 1.0 - params->background_transparency;
+            else if (ch >= 0 && ch < 3)
+                texel[c] = rgb[ch] / scale;
+        }
+        pl_tex_clear(job->rr->gpu, pl->texture, texel);
+    }
+}
+
+// color = (0, 0, 0, 1) with color[c] = previous[mapping[c]] (reference swizzle_color :791-808)
+static void append_swizzle(pl_shader sh, int comps, const int mapping[4])
+{
+    bool identity = comps == 4;
+    uint32_t from = 0;
+    for (int c = 0; c < 4; c++) {
+        const int m = c < comps ? mapping[c] : -1;
+        from |= (uint32_t) (m < 0 ? 0xff : m) << (8 * c);
+        identity &= c >= comps || m == c;
+    }
+    if (identity)
         return;
     struct plh_op *op = sh_op(sh, PLH_OP_SWIZZLE);
     if (!op)
         return;
+    op->i0 = from;
     op->i1 = comps;
-    op->i0 = 0;
-    for (int c = 0; c < 4; c++) {
-        const int m = c < comps ? mapping[c] : -1;
-        op->i0 |= (m < 0 ? 0xff : m) << (8 * c);
-    }
-    sh_listf(sh, "swizzle(comps=%d, map=0x%08x)\n", comps, (unsigned) op->i0);
+    sh_listf(sh, "swizzle(comps=%d, map=0x%08x)\n", comps, (unsigned) from);
 }
 
-// Returns true if error diffusion was performed (pass_error_diffusion :2282-2344)
-static bool pass_error_diffusion(struct pass_state *pass, pl_shader *sh, int new_depth,
-                                 int comps, int out_w, int out_h)
+// Run `*sh` into an intermediate, diffuse the quantisation error over it (one workgroup, the
+// whole image's error ring in LDS), and continue from the result (:2282-2344)
+static bool run_error_diffusion(struct frame_job *job, pl_shader *sh, int depth, int comps,
+                                int w, int h)
 {
-    const struct pl_render_params *params = pass->params;
-    pl_renderer rr = pass->rr;
-    if (!params->error_diffusion || (rr->errors & PL_RENDER_ERR_ERROR_DIFFUSION))
-        return false;
-
-    const size_t shmem_req = pl_error_diffusion_shmem_req(params->error_diffusion, out_h);
-    if (shmem_req > rr->gpu->glsl.max_shmem_size)
-        return false;
-
-    pl_fmt fmt = pass->fbofmt[comps];
+    pl_renderer rr = job->rr;
+    pl_fmt fmt = job->caps.fbo[comps];
     if (!fmt || !(fmt->caps & PL_FMT_CAP_STORABLE)) {
-        RR_ERR(rr, "Error diffusion requires storable FBOs.. disabling!");
-        goto error;
+        raise(rr, PL_RENDER_ERR_ERROR_DIFFUSION, PL_LOG_ERR,
+              "Error diffusion requires storable FBOs.. disabling!");
+        return false;
     }
-
-    struct pl_error_diffusion_params edpars = {
-        .new_depth = new_depth,
-        .kernel = params->error_diffusion,
+    struct pl_error_diffusion_params ed = {
+        .input_tex  = borrow_fbo(job, w, h, fmt, comps),
+        .output_tex = borrow_fbo(job, w, h, fmt, comps),
+        .new_depth  = depth,
+        .kernel     = job->params->error_diffusion,
     };
-    edpars.input_tex = get_fbo(pass, out_w, out_h, fmt, comps);
-    edpars.output_tex = get_fbo(pass, out_w, out_h, fmt, comps);
-    if (!edpars.input_tex || !edpars.output_tex)
-        goto error;
-
-    pl_shader dsh = pl_dispatch_begin(rr->dp);
-    if (!pl_shader_error_diffusion(dsh, &edpars)) {
-        pl_dispatch_abort(rr->dp, &dsh);
-        goto error;
+    pl_shader diffuse = ed.input_tex && ed.output_tex ? pl_dispatch_begin(rr->dp) : NULL;
+    if (diffuse && !pl_shader_error_diffusion(diffuse, &ed))
+        pl_dispatch_abort(rr->dp, &diffuse);
+    if (!diffuse) {
+        rr->errors |= PL_RENDER_ERR_ERROR_DIFFUSION;
+        return false;
     }
 
-    bool ok = pl_dispatch_finish(rr->dp, pl_dispatch_params(
-        .shader = sh,
-        .target = edpars.input_tex,
-    ));
+    bool ok = pl_dispatch_finish(rr->dp, pl_dispatch_params( .shader = sh, .target = ed.input_tex ));
     if (ok) {
         ok = pl_dispatch_compute(rr->dp, pl_dispatch_compute_params(
-            .shader = &dsh,
-            .dispatch_size = {1, 1, 1},
+            .shader = &diffuse, .dispatch_size = {1, 1, 1},
         ));
     } else {
-        pl_dispatch_abort(rr->dp, &dsh);
+        pl_dispatch_abort(rr->dp, &diffuse);
     }
-
     *sh = pl_dispatch_begin(rr->dp);
-    pl_shader_sample_direct(*sh, pl_sample_src(
-        .tex = ok ? edpars.output_tex : edpars.input_tex,
-    ));
+    pl_shader_sample_direct(*sh, pl_sample_src( .tex = ok ? ed.output_tex : ed.input_tex ));
     return ok;
-
-error:
-    rr->errors |= PL_RENDER_ERR_ERROR_DIFFUSION;
-    return false;
 }
 
-// clear_target (:2410-2555), PL_CLEAR_COLOR flavour (tiles / blur degrade to it), every plane
-static void clear_target(struct pass_state *pass, float scale)
+bool plh_stage_output(struct frame_job *job)
 {
-    const struct pl_render_params *params = pass->params;
-    const struct pl_frame *target = &pass->target;
-    pl_renderer rr = pass->rr;
-    float bg[3];
-    translate_srgb_color(bg, params->background_color, &target->color);
-    float enc[3] = { bg[0], bg[1], bg[2] };
-    struct pl_color_repr crepr = target->repr;
-    pl_transform3x3 tr = pl_color_repr_decode(&crepr, NULL);
-    pl_transform3x3_invert(&tr);
-    pl_transform3x3_apply(&tr, enc);
-    const float alpha = 1.0 - params->background_transparency;
-    for (int pi = 0; pi < target->num_planes; pi++) {
-        const struct pl_plane *cp = &target->planes[pi];
-        float clear[4];
-        for (int c = 0; c < 4; c++) {
-            const int m = c < cp->components ? cp->component_mapping[c] : -1;
-            clear[c] = m == PL_CHANNEL_A ? alpha : m >= 0 && m < 3 ? enc[m] / scale : 0.0f;
-        }
-        pl_tex_clear(rr->gpu, cp->texture, clear);
-    }
-}
+    pl_renderer rr = job->rr;
+    const struct pl_render_params *params = job->params;
+    const struct pl_frame *target = &job->target;
+    struct work_image *img = &job->img;
+    pl_shader sh = plh_work_shader(job, img);
 
-static bool pass_output_target(struct pass_state *pass)
-{
-    const struct pl_render_params *params = pass->params;
-    const struct pl_frame *target = &pass->target;
-    const struct pl_plane *plane = &target->planes[frame_ref(target)];
-    pl_renderer rr = pass->rr;
-    struct img *img = &pass->img;
-    pl_shader sh = img_sh(pass, img);
-    pl_rect2d dst_rect = pass->dst_rect;
-    const bool need_clear = pl_frame_is_cropped(target);
+    struct rp_output_stage out;
+    rp_plan_output(params, target, &job->geo, img->comps, img->repr.alpha, &out);
 
-    enum pl_clear_mode background = params->background;
-    if (background == PL_CLEAR_TILES || background == PL_CLEAR_BLUR)
-        background = PL_CLEAR_COLOR; // (unsupported modes degrade to a plain colour)
-
-    // avoid an unnecessary round trip through premultiplied alpha
-    const bool has_alpha = target->repr.alpha != PL_ALPHA_NONE;
-    if (params->background_transparency >= 1.0 && has_alpha)
-        background = PL_CLEAR_SKIP;
-
-    const bool need_blend = background != PL_CLEAR_SKIP || !has_alpha;
-    if (img->comps == 4 && need_blend) {
+    if (out.premultiply)
         pl_shader_set_alpha(sh, &img->repr, PL_ALPHA_PREMULTIPLIED);
-        if (background == PL_CLEAR_COLOR) {
-            float bg[3];
-            translate_srgb_color(bg, params->background_color, &target->color);
-            struct plh_op *op = sh_op(sh, PLH_OP_BLEND_BG);
-            if (!op)
-                return false;
-            op->f[0] = bg[0]; op->f[1] = bg[1]; op->f[2] = bg[2];
-            op->f[3] = 1.0 - params->background_transparency;
-            sh_listf(sh, "blend_background(%g %g %g %g)\n", bg[0], bg[1], bg[2], op->f[3]);
-            if (!params->background_transparency || !has_alpha) {
-                img->repr.alpha = PL_ALPHA_NONE;
-                img->comps = 3;
-            }
-        }
+    if (out.blend) {
+        struct plh_op *op = sh_op(sh, PLH_OP_BLEND_BG);
+        if (!op)
+            return false;
+        background_in(&target->color, params->background_color, op->f);
+        op->f[3] = 1.0 - params->background_transparency;
+        sh_listf(sh, "blend_background(%g %g %g %g)\n", op->f[0], op->f[1], op->f[2], op->f[3]);
     }
-
-    // the colour scale is applied separately, after encoding, so that an intermediate FBO
-    // (error diffusion) has the right precision
-    struct pl_color_repr repr = target->repr;
-    const float scale = pl_color_repr_normalize(&repr);
-
-    // don't double-apply an alpha mode that is already in effect
-    if (img->repr.alpha == repr.alpha || img->comps < 4) {
-        repr.alpha = PL_ALPHA_NONE;
-    } else {
+    if (out.drop_alpha) {
+        img->repr.alpha = PL_ALPHA_NONE;
+        img->comps = 3;
+    }
+    if (out.unpremultiply)
         pl_shader_set_alpha(sh, &img->repr, PL_ALPHA_INDEPENDENT);
-    }
 
-    // (a CONVERSION LUT on the target already produced native samples, pass_convert_colors)
-    const enum pl_lut_type tlut = guess_frame_lut_type(target, true);
-    if (tlut != PL_LUT_CONVERSION) {
-        pl_shader_encode_color(sh, &repr);
-        if (repr.sys == PL_COLOR_SYSTEM_XYZ) {
+    // The integer scale of the encoding is applied last, separately, so that an intermediate
+    // (error diffusion) still holds normalised values
+    if (out.encode) {
+        pl_shader_encode_color(sh, &out.repr);
+        if (out.delinearize_xyz) {
             img->color.transfer = PL_COLOR_TRC_ST428;
             pl_shader_delinearize(sh, &img->color);
         }
     }
-    if (tlut == PL_LUT_NATIVE)
-        pl_shader_custom_lut(sh, target->lut, &rr->lut_state[LUT_TARGET]);
+    if (out.target_lut == PL_LUT_NATIVE)
+        pl_shader_custom_lut(sh, target->lut, &rr->lut_state[RR_LUT_TARGET]);
 
-    // rotation by an odd number of quarter turns (:2787-2793): back to the target's
-    // orientation, the stores are transposed
-    if (pass->rotation % PL_ROTATION_180 == PL_ROTATION_90) {
-        int t;
-        t = dst_rect.x0; dst_rect.x0 = dst_rect.y0; dst_rect.y0 = t;
-        t = dst_rect.x1; dst_rect.x1 = dst_rect.y1; dst_rect.y1 = t;
-        t = img->w; img->w = img->h; img->h = t;
+    if (out.transposed) {
+        const int t = img->w;
+        img->w = img->h;
+        img->h = t;
         sh->transpose = true;
     }
+    if (out.clear_border)
+        clear_planes(job, out.scale);
 
-    const bool flipped_x = dst_rect.x1 < dst_rect.x0, flipped_y = dst_rect.y1 < dst_rect.y0;
-
-    if (need_clear && params->border != PL_CLEAR_SKIP)
-        clear_target(pass, scale);
-
-    pl_tex ref_tex = target->planes[frame_ref(target)].texture;
-    pl_tex img_fbo = NULL;
-    if (target->num_planes > 1) {
-        // planar output: every plane samples the finished image from an intermediate FBO
-        img->sh = sh;
-        img_fbo = img_tex(pass, img);
+    // a planar target samples the finished image once per plane
+    pl_tex finished = NULL;
+    if (out.num_planes > 1) {
+        img->rec = sh;
+        finished = plh_work_texture(job, img);
         sh = NULL;
-        if (!img_fbo) {
-            RR_ERR(rr, "Output requires multiple planes, but FBOs are unavailable.");
+        if (!finished) {
+            RR_LOG(rr, PL_LOG_ERR, "Output requires multiple planes, but FBOs are unavailable.");
             return false;
         }
     } else {
-        img->sh = NULL;
+        img->rec = NULL;
     }
 
     bool ok = true;
-    for (int pi = 0; pi < target->num_planes && ok; pi++) {
-        plane = &target->planes[pi];
-        const float prx = (float) plane->texture->params.w / ref_tex->params.w,
-                    pry = (float) plane->texture->params.h / ref_tex->params.h;
-        // integer subsampling ratios only (fractional sizes are rounded up: over-render)
-        const float rrx = prx >= 1 ? roundf(prx) : 1.0 / roundf(1.0 / prx),
-                    rry = pry >= 1 ? roundf(pry) : 1.0 / roundf(1.0 / pry);
-        const float psx = plane->shift_x, psy = plane->shift_y;
+    for (int i = 0; i < out.num_planes && ok; i++) {
+        const struct pl_plane *plane = &target->planes[i];
+        const struct rp_output_plane *op = &out.planes[i];
+        const int pw = pl_rect_w(op->covered), ph = pl_rect_h(op->covered);
 
-        pl_rect2df plane_rectf = {
-            .x0 = (dst_rect.x0 - psx) * rrx,
-            .y0 = (dst_rect.y0 - psy) * rry,
-            .x1 = (dst_rect.x1 - psx) * rrx,
-            .y1 = (dst_rect.y1 - psy) * rry,
-        };
-        pl_rect2df_normalize(&plane_rectf);
-        const int rx0 = floorf(plane_rectf.x0), ry0 = floorf(plane_rectf.y0),
-                  rx1 =  ceilf(plane_rectf.x1), ry1 =  ceilf(plane_rectf.y1);
-
-        if (target->num_planes > 1) {
-            uint8_t mask = 0;
-            for (int c = 0; c < plane->components; c++) {
-                if (plane->component_mapping[c] >= 0)
-                    mask |= 1 << plane->component_mapping[c];
-            }
-            struct pl_sample_src src = {
-                .tex        = img_fbo,
-                .new_w      = rx1 - rx0,
-                .new_h      = ry1 - ry0,
-                .rect = {
-                    .x0 = (rx0 - plane_rectf.x0) / rrx,
-                    .x1 = (rx1 - plane_rectf.x0) / rrx,
-                    .y0 = (ry0 - plane_rectf.y0) / rry,
-                    .y1 = (ry1 - plane_rectf.y0) / rry,
-                },
-                .component_mask = mask,
-            };
+        if (finished) {
+            struct pl_sample_src req = op->request;
+            req.tex = finished;
             sh = pl_dispatch_begin(rr->dp);
-            dispatch_sampler(pass, sh, &rr->samplers_dst[pi], SAMPLER_PLANE, &src);
+            run_scaler(job, sh, &rr->scale_out[i], RP_USE_PLANE, &req);
         }
 
-        // > 16-bit outputs are not dithered by default (:2884-2900)
-        const int depth = target->repr.bits.color_depth;
-        int applied_dither = 0;
-        if (depth && (depth < 16 || params->force_dither)) {
-            if (pass_error_diffusion(pass, &sh, depth, plane->components, rx1 - rx0, ry1 - ry0)) {
-                applied_dither = depth;
-            } else if (params->dither_params) {
-                struct pl_dither_params dparams = *params->dither_params;
-                if (!params->disable_dither_gamma_correction)
-                    dparams.transfer = target->color.transfer;
-                pl_shader_dither(sh, depth, &rr->dither_state, &dparams);
-                applied_dither = depth;
+        int dithered = 0;
+        switch (rp_pick_dither(&job->caps, params, out.dither_depth, ph)) {
+        case RP_DITHER_ERROR_DIFFUSION:
+            if (run_error_diffusion(job, &sh, out.dither_depth, plane->components, pw, ph)) {
+                dithered = out.dither_depth;
+                break;
             }
+            if (!params->dither_params)
+                break;
+            __attribute__((fallthrough));   // ordered dither instead
+        case RP_DITHER_ORDERED: {
+            struct pl_dither_params dp = *params->dither_params;
+            if (!params->disable_dither_gamma_correction)
+                dp.transfer = target->color.transfer;
+            pl_shader_dither(sh, out.dither_depth, &rr->dither_state, &dp);
+            dithered = out.dither_depth;
+            break;
         }
-        if (applied_dither != rr->prev_dither) {
-            if (applied_dither) {
-                RR_INFO(rr, "Dithering to %d bit depth", applied_dither);
-            } else {
-                RR_INFO(rr, "Dithering disabled");
-            }
-            rr->prev_dither = applied_dither;
+        case RP_DITHER_NONE:
+            break;
+        }
+        if (dithered != rr->last_dither_depth) {
+            if (dithered)
+                RR_LOG(rr, PL_LOG_INFO, "Dithering to %d bit depth", dithered);
+            else
+                RR_LOG(rr, PL_LOG_INFO, "Dithering disabled");
+            rr->last_dither_depth = dithered;
         }
 
-        // color *= 1 / scale                                                          (:2911)
-        struct plh_op *op = sh_op(sh, PLH_OP_SCALE);
-        if (!op) {
+        if (!plh_append_scale(sh, 1.0f / out.scale, true)) {
             pl_dispatch_abort(rr->dp, &sh);
             return false;
         }
-        op->f[0] = op->f[1] = op->f[2] = op->f[3] = 1.0f / scale;
-        sh_listf(sh, "scale(1/%g)\n", scale);
-
-        record_swizzle(sh, plane->components, plane->component_mapping);
-
-        pl_rect2d plane_rect = {
-            .x0 = flipped_x ? rx1 : rx0,
-            .x1 = flipped_x ? rx0 : rx1,
-            .y0 = flipped_y ? ry1 : ry0,
-            .y1 = flipped_y ? ry0 : ry1,
-        };
-        if (plane->flipped) {
-            const int plane_h = rry * ref_tex->params.h;
-            plane_rect.y0 = plane_h - plane_rect.y0;
-            plane_rect.y1 = plane_h - plane_rect.y1;
-        }
-
+        append_swizzle(sh, plane->components, plane->component_mapping);
         ok = pl_dispatch_finish(rr->dp, pl_dispatch_params(
             .shader = &sh,
             .target = plane->texture,
-            .rect = plane_rect,
+            .rect   = op->store,
         ));
     }
-    *img = (struct img) {0};
+    *img = (struct work_image) {0};
     return ok;
 }
 
-/* ---- entry point (:3433-3480) --------------------------------------------------------------------- */
+/* ---- pl_render_image ------------------------------------------------------------------------ */
 
-static void pass_uninit(struct pass_state *pass)
+// clear the target: what remains of a render without an image (there are no overlays here)
+static bool render_nothing(pl_renderer rr, const struct pl_frame *ptarget,
+                           const struct pl_render_params *params)
 {
-    pl_renderer rr = pass->rr;
-    pl_dispatch_abort(rr->dp, &pass->img.sh);
-    pl_dispatch_callback(rr->dp, NULL, NULL);
-    if (pass->acquired_image && pass->image.release)
-        pass->image.release(rr->gpu, &pass->image);
-    if (pass->acquired_target && pass->target.release)
-        pass->target.release(rr->gpu, &pass->target);
-}
-
-static bool unsupported(pl_renderer rr, const struct pl_render_params *p)
-{
-    if (p->blend_params || p->deinterlace_params || p->distort_params ||
-        p->num_hooks)
-    {
-        RR_ERR(rr, "pl_render_params requests a stage outside this backend's hot path "
-               "(blend / deinterlace / distort / hooks)");
-        return true;
-    }
-    return false;
-}
-
-// acquire + validate + infer (pass_init :3391-3428)
-static bool pass_init(struct pass_state *pass, bool acquire_image)
-{
-    pl_renderer rr = pass->rr;
-    if (!pass->acquired_target && pass->target.acquire) {
-        if (!pass->target.acquire(rr->gpu, &pass->target))
+    struct frame_job job = { .rr = rr, .params = params, .target = *ptarget };
+    if (job.target.acquire) {
+        if (!job.target.acquire(rr->gpu, &job.target))
             return false;
-        pass->acquired_target = true;
+        job.target_acquired = true;
     }
-    if (acquire_image && pass->image.acquire) {
-        if (!pass->image.acquire(rr->gpu, &pass->image)) {
-            pass_uninit(pass);
-            return false;
-        }
-        pass->acquired_image = true;
+    const char *bad = rp_frame_problem(&job.target, true);
+    if (bad) {
+        RR_LOG(rr, PL_LOG_ERR, "Target frame: %s", bad);
+    } else {
+        rp_complete_frame(&job.target);
+        pl_color_space_infer(&job.target.color);
+        struct pl_color_repr repr = job.target.repr;
+        clear_planes(&job, pl_color_repr_normalize(&repr));
     }
-    if (!validate_frame(rr, &pass->image, "Image", false) ||
-        !validate_frame(rr, &pass->target, "Target", true))
-    {
-        pass_uninit(pass);
-        return false;
-    }
-    find_fbo_format(pass);
-    pass_fix_frames(pass);
-    return true;
+    plh_job_end(&job);
+    return !bad;
 }
 
 bool pl_render_image(pl_renderer rr, const struct pl_frame *pimage, const struct pl_frame *ptarget,
                      const struct pl_render_params *params)
 {
-    params = PL_DEF(params, &pl_render_default_params);
+    params = params ? params : &pl_render_default_params;
     if (!ptarget) {
-        RR_ERR(rr, "pl_render_image: a target is required");
+        RR_LOG(rr, PL_LOG_ERR, "pl_render_image: a target is required");
         return false;
     }
-    if (unsupported(rr, params))
+    if (!plh_params_supported(rr, params))
         return false;
-    if (!pimage) {
-        // no image (:3463-3476): the target is cleared (there are no overlays to draw here)
-        struct pass_state pass = { .rr = rr, .params = params, .target = *ptarget };
-        if (pass.target.acquire) {
-            if (!pass.target.acquire(rr->gpu, &pass.target))
-                return false;
-            pass.acquired_target = true;
-        }
-        bool ok = validate_frame(rr, &pass.target, "Target", true);
-        if (ok) {
-            fix_frame(&pass.target);
-            pl_color_space_infer(&pass.target.color);
-            struct pl_color_repr repr = pass.target.repr;
-            clear_target(&pass, pl_color_repr_normalize(&repr));
-        }
-        pass_uninit(&pass);
-        return ok;
+    if (!pimage)
+        return render_nothing(rr, ptarget, params);
+
+    // pre-v6.254 spelling of pl_peak_detect_params.allow_delayed
+    struct pl_render_params local;
+    struct pl_peak_detect_params peak;
+    if (params->allow_delayed_peak_detect && params->peak_detect_params &&
+        !params->peak_detect_params->allow_delayed)
+    {
+        local = *params;
+        peak = *params->peak_detect_params;
+        peak.allow_delayed = true;
+        local.peak_detect_params = &peak;
+        params = &local;
     }
 
-    struct pass_state pass = {
-        .rr = rr,
-        .params = params,
-        .image = *pimage,
-        .target = *ptarget,
+    struct frame_job job = {
+        .rr = rr, .params = params, .image = *pimage, .target = *ptarget,
     };
-    if (!pass_init(&pass, true))
+    if (!plh_job_begin(&job, true))
         return false;
-
-    // no-op (empty crop)
-    if (!pl_rect_w(pass.dst_rect) || !pl_rect_h(pass.dst_rect)) {
-        pass_uninit(&pass);
-        return true;
+    if (!pl_rect_w(job.geo.dst) || !pl_rect_h(job.geo.dst)) {
+        plh_job_end(&job);
+        return true;    // nothing visible
     }
 
-    pl_dispatch_reset_frame(rr->dp);
-    pl_dispatch_callback(rr->dp, &pass, info_callback);
-    if (!pass_read_image(&pass))
-        goto error;
-    if (!pass_scale_main(&pass))
-        goto error;
-    pass_convert_colors(&pass);
-    if (!pass.img.sh && !pass.img.tex)
-        goto error;
-    if (!pass_output_target(&pass))
-        goto error;
-
-    pass_uninit(&pass);
-    return true;
-
-error:
-    RR_ERR(rr, "Failed rendering image!");
-    pass_uninit(&pass);
-    return false;
-}
-
-/* ---- frame mixing (pl_render_image_mix, renderer.c:3477-3508, 3612-4028) ---------------------- */
-
-const struct pl_frame *pl_frame_mix_current(const struct pl_frame_mix *mix)
-{
-    const struct pl_frame *cur = NULL;
-    for (int i = 0; i < mix->num_frames && mix->timestamps[i] <= 0.0f; i++)
-        cur = mix->frames[i];
-    return cur;
-}
-
-const struct pl_frame *pl_frame_mix_nearest(const struct pl_frame_mix *mix)
-{
-    if (!mix->num_frames)
-        return NULL;
-    // timestamps are sorted: |ts| falls, then rises
-    int best = 0;
-    for (int i = 1; i < mix->num_frames; i++) {
-        if (fabsf(mix->timestamps[i]) < fabsf(mix->timestamps[best]))
-            best = i;
-        else
-            break;
+    plh_job_watch_passes(&job);
+    bool ok = plh_stage_read(&job) && plh_stage_scale(&job);
+    if (ok) {
+        plh_stage_colors(&job);
+        ok = (job.img.rec || job.img.tex) && plh_stage_output(&job);
     }
-    return mix->frames[best];
-}
-
-// Everything in pl_render_params that changes how a cached frame looks (render_params_info
-// :3510-3560 hashes the same set): the struct itself minus callbacks, plus what it points to.
-static uint64_t fnv1a(uint64_t h, const void *data, size_t size)
-{
-    const uint8_t *p = data;
-    for (size_t i = 0; i < size; i++)
-        h = (h ^ p[i]) * 0x100000001b3ull;
-    return h;
-}
-
-static uint64_t params_hash(const struct pl_render_params *params)
-{
-    struct pl_render_params p = *params;
-    p.info_callback = NULL;
-    p.info_priv = NULL;
-    uint64_t h = 0xcbf29ce484222325ull;
-#define HASH_PTR(field)                                         \
-    do {                                                        \
-        if (p.field)                                            \
-            h = fnv1a(h, p.field, sizeof(*p.field));            \
-        p.field = NULL;                                         \
-    } while (0)
-    HASH_PTR(upscaler); HASH_PTR(downscaler); HASH_PTR(plane_upscaler); HASH_PTR(plane_downscaler);
-    HASH_PTR(frame_mixer); HASH_PTR(deband_params); HASH_PTR(sigmoid_params);
-    HASH_PTR(color_adjustment); HASH_PTR(peak_detect_params); HASH_PTR(color_map_params);
-    HASH_PTR(dither_params); HASH_PTR(error_diffusion); HASH_PTR(cone_params);
-#undef HASH_PTR
-    return fnv1a(h, &p, sizeof(p));
-}
-
-static bool rect2df_eq(pl_rect2df a, pl_rect2df b)
-{
-    return a.x0 == b.x0 && a.y0 == b.y0 && a.x1 == b.x1 && a.y1 == b.y1;
-}
-
-// `color = texel of frame` for every frame but the first (which the pass' sampler reads)
-static bool mix_fetch(pl_renderer rr, pl_shader sh, pl_tex tex, bool linear)
-{
-    pl_shader psh = pl_dispatch_begin(rr->dp);
-    const struct pl_sample_src src = { .tex = tex };
-    bool ok = linear ? pl_shader_sample_bilinear(psh, &src) : pl_shader_sample_nearest(psh, &src);
-    const struct pl_plane whole = { .components = 4, .component_mapping = { 0, 1, 2, 3 } };
-    ok = ok && merge_plane_fetch(sh, psh, &whole);
-    pl_dispatch_abort(rr->dp, &psh);
+    if (!ok)
+        RR_LOG(rr, PL_LOG_ERR, "Failed rendering image!");
+    plh_job_end(&job);
     return ok;
 }
 
-bool pl_render_image_mix(pl_renderer rr, const struct pl_frame_mix *images,
-                         const struct pl_frame *ptarget, const struct pl_render_params *params)
-{
-    params = PL_DEF(params, &pl_render_default_params);
-    if (!images || !images->num_frames)
-        return pl_render_image(rr, NULL, ptarget, params);
-    if (unsupported(rr, params))
-        return false;
-    if (!(images->vsync_duration > 0.0f)) {
-        RR_ERR(rr, "pl_render_image_mix: vsync_duration must be positive");
-        return false;
-    }
-    for (int i = 0; i + 1 < images->num_frames; i++) {
-        if (!(images->timestamps[i] <= images->timestamps[i + 1])) {
-            RR_ERR(rr, "pl_render_image_mix: timestamps must be sorted");
-            return false;
-        }
-    }
-
-    const uint64_t phash = params_hash(params);
-    const struct pl_frame *refimg = pl_frame_mix_nearest(images);
-    struct pass_state pass = {
-        .rr = rr,
-        .params = params,
-        .image = *refimg,
-        .target = *ptarget,
-        .info.stage = PL_RENDER_STAGE_BLEND,
-    };
-
-    if (rr->errors & PL_RENDER_ERR_FRAME_MIXING)
-        goto fallback;
-    if (!pass_init(&pass, false))
-        return false;
-    if (!pass.fbofmt[4])
-        goto fallback;
-
-    const struct pl_frame *target = &pass.target;
-    const int out_w = abs(pl_rect_w(pass.dst_rect)), out_h = abs(pl_rect_h(pass.dst_rect));
-    if (!out_w || !out_h)
-        goto fallback;
-
-    int fidx = 0;
-    struct cached_frame frames[MAX_MIX_FRAMES];
-    float weights[MAX_MIX_FRAMES];
-    float wsum = 0.0f;
-
-    // garbage collection: everything not touched below is evicted
-    for (int i = 0; i < rr->num_frames; i++)
-        rr->frames[i].evict = true;
-
-    // blur the mixer by the vsync ratio (source / display)
-    struct pl_filter_config mixer = {0};
-    if (params->frame_mixer) {
-        mixer = *params->frame_mixer;
-        mixer.blur = PL_DEF(mixer.blur, 1.0f);
-        for (int i = 1; i < images->num_frames; i++) {
-            if (images->timestamps[i] >= 0.0f && images->timestamps[i - 1] < 0.0f) {
-                const float frame_dur = images->timestamps[i] - images->timestamps[i - 1];
-                const float sample_dur = PL_MAX(frame_dur, images->vsync_duration);
-                if (sample_dur > 1.0f && !params->skip_anti_aliasing)
-                    mixer.blur *= sample_dur;
-                break;
-            }
-        }
-    }
-
-    bool single_frame = !params->frame_mixer || images->num_frames == 1;
-retry:
-    for (int i = 0; i < images->num_frames; i++) {
-        const uint64_t sig = images->signatures[i];
-        float rts = images->timestamps[i];
-        const struct pl_frame *img = images->frames[i];
-        if (img->rotation != refimg->rotation)
-            continue; // (only PL_ROTATION_0 passes validation anyway)
-
-        float weight;
-        if (single_frame) {
-            // only the reference image is rendered
-            if (img != refimg)
-                continue;
-            weight = 1.0f;
-        } else if (!mixer.kernel || mixer.kernel == &pl_filter_function_oversample) {
-            // weight = fraction of the vsync interval during which the frame is visible
-            float end = i + 1 < images->num_frames ? images->timestamps[i + 1] : INFINITY;
-            if (rts > images->vsync_duration || end < 0.0f)
-                continue;
-            rts = PL_MAX(rts, 0.0f);
-            end = PL_MIN(end, images->vsync_duration);
-            weight = (end - rts) / images->vsync_duration;
-            if (mixer.kernel && weight < mixer.kernel->params[0])
-                weight = 0.0f; // culled by the oversampling threshold
-        } else {
-            if (fabsf(rts) >= pl_filter_radius_bound(&mixer))
-                continue;
-            weight = pl_filter_sample(&mixer, rts);
-        }
-
-        struct cached_frame *f = NULL;
-        for (int j = 0; j < rr->num_frames; j++) {
-            if (rr->frames[j].signature == sig) {
-                f = &rr->frames[j];
-                f->evict = false;
-                break;
-            }
-        }
-
-        // negligible contributions are skipped -- after the lookup, so that these frames are
-        // not evicted yet; never the reference image (at least one frame must remain)
-        if (fabsf(weight) <= 1e-3f && img != refimg)
-            continue;
-
-        // (the reference also bypasses the cache for "trivial" params; that only saves a copy)
-        const bool skip_cache = single_frame && params->skip_caching_single_frame;
-        if (!f && skip_cache)
-            goto fallback;
-
-        if (!f) {
-            if (rr->num_frames == MAX_CACHED_FRAMES) {
-                PL_WARN_RR(rr, "Frame mixing cache is full, rendering without mixing");
-                goto fallback;
-            }
-            f = &rr->frames[rr->num_frames++];
-            *f = (struct cached_frame) { .signature = sig };
-        }
-
-        bool can_reuse = f->tex;
-        const bool strict_reuse = skip_cache || single_frame || !params->preserve_mixing_cache;
-        if (can_reuse && strict_reuse) {
-            can_reuse = f->tex->params.w == out_w && f->tex->params.h == out_h &&
-                        rect2df_eq(f->crop, img->crop) && f->params_hash == phash &&
-                        pl_color_space_equal(&f->color, &target->color);
-        }
-        if (!can_reuse && skip_cache)
-            goto fallback;
-
-        if (!can_reuse) {
-            // (re-)render this frame, up to where pass_output_target would take over
-            if (!f->tex && rr->num_frame_fbos)
-                f->tex = rr->frame_fbos[--rr->num_frame_fbos];
-            pl_fmt fmt = pass.fbofmt[4];
-            if (!pl_tex_recreate(rr->gpu, &f->tex, pl_tex_params(
-                    .w = out_w, .h = out_h, .format = fmt,
-                    .sampleable = true, .renderable = true, .storable = true,
-                    .blit_dst = !!(fmt->caps & PL_FMT_CAP_BLITTABLE))))
-            {
-                RR_ERR(rr, "Could not create intermediate texture for frame mixing.. disabling!");
-                rr->errors |= PL_RENDER_ERR_FRAME_MIXING;
-                goto fallback;
-            }
-
-            struct pass_state inter = {
-                .rr = rr,
-                .params = params,
-                .image = *img,
-                .target = *ptarget,
-                .info.stage = PL_RENDER_STAGE_FRAME,
-                .acquired_target = pass.acquired_target, // (already acquired by `pass`)
-            };
-            if (!pass_init(&inter, true))
-                goto fail;
-            inter.acquired_target = false; // released by `pass`
-            inter.target = pass.target;
-
-            pl_dispatch_reset_frame(rr->dp);
-            pl_dispatch_callback(rr->dp, &inter, info_callback);
-            bool ok = pass_read_image(&inter) && pass_scale_main(&inter);
-            if (ok) {
-                pass_convert_colors(&inter);
-                ok = inter.img.sh || inter.img.tex;
-            }
-            if (ok) {
-                pl_shader sh = img_sh(&inter, &inter.img);
-                pl_shader_set_alpha(sh, &inter.img.repr, PL_ALPHA_PREMULTIPLIED); // for mixing
-                ok = inter.img.w == out_w && inter.img.h == out_h &&
-                     pl_dispatch_finish(rr->dp, pl_dispatch_params(
-                         .shader = &inter.img.sh, .target = f->tex));
-            }
-            if (ok) {
-                f->params_hash = phash;
-                f->crop = img->crop;
-                f->color = inter.img.color;
-                f->repr = inter.img.repr;
-                f->comps = inter.img.comps;
-            }
-            pass_uninit(&inter);
-            if (!ok)
-                goto fail;
-        }
-
-        if (fidx == MAX_MIX_FRAMES)
-            break;
-        frames[fidx] = *f;
-        weights[fidx] = weight;
-        wsum += weight;
-        fidx++;
-    }
-
-    // evict what this mix did not touch
-    for (int i = 0; i < rr->num_frames; ) {
-        if (!rr->frames[i].evict) {
-            i++;
-            continue;
-        }
-        if (rr->frames[i].tex) {
-            if (rr->num_frame_fbos < MAX_CACHED_FRAMES)
-                rr->frame_fbos[rr->num_frame_fbos++] = rr->frames[i].tex;
-            else
-                pl_tex_destroy(rr->gpu, &rr->frames[i].tex);
-        }
-        rr->frames[i] = rr->frames[--rr->num_frames];
-    }
-
-    // nothing left: zero-order hold
-    if (!fidx) {
-        if (single_frame)
-            goto fallback;
-        single_frame = true;
-        goto retry;
-    }
-
-    // ---- sample and mix --------------------------------------------------------------------
-    pl_dispatch_reset_frame(rr->dp);
-    pl_dispatch_callback(rr->dp, &pass, info_callback);
-    pass.info.count = fidx;
-
-    pl_shader sh = pl_dispatch_begin(rr->dp);
-    // with a single frame there is nothing to mix: no linearize / delinearize round trip
-    const bool mixing = fidx > 1;
-    struct pl_color_space mix_csp = target->color;
-    if (mixing)
-        mix_csp.transfer = PL_COLOR_TRC_LINEAR;
-
-    int comps = 0;
-    bool ok = true;
-    for (int i = 0; i < fidx && ok; i++) {
-        const struct pl_tex_params *tp = &frames[i].tex->params;
-        const bool linear = (tp->w != out_w || tp->h != out_h) &&
-                            (tp->format->caps & PL_FMT_CAP_LINEAR);
-        if (i == 0) {
-            const struct pl_sample_src src = { .tex = frames[i].tex, .new_w = out_w, .new_h = out_h };
-            ok = linear ? pl_shader_sample_bilinear(sh, &src) : pl_shader_sample_nearest(sh, &src);
-        } else {
-            ok = mix_fetch(rr, sh, frames[i].tex, linear);
-        }
-        if (!ok)
-            break;
-
-        // usually just the linearization; handles mixed-colorspace frames when
-        // preserve_mixing_cache spans target changes (differences in HDR metadata are ignored)
-        struct pl_color_repr frame_repr = frames[i].repr;
-        struct pl_color_space frame_csp = frames[i].color;
-        frame_csp.hdr = mix_csp.hdr;
-        if (!pl_color_space_equal(&frame_csp, &mix_csp)) {
-            pl_shader_set_alpha(sh, &frame_repr, PL_ALPHA_INDEPENDENT);
-            pl_shader_color_map_ex(sh, NULL, pl_color_map_args(.src = frame_csp, .dst = mix_csp));
-        }
-        pl_shader_set_alpha(sh, &frame_repr, PL_ALPHA_PREMULTIPLIED);
-
-        if (mixing) {
-            struct plh_op *op = sh_op(sh, PLH_OP_MIX_ADD);
-            if (!op) {
-                ok = false;
-                break;
-            }
-            op->f[0] = weights[i] / wsum;
-            sh_listf(sh, "mix_color += %g * color\n", op->f[0]);
-        }
-        comps = PL_MAX(comps, frames[i].comps);
-    }
-    if (ok && mixing) {
-        ok = !!sh_op(sh, PLH_OP_MIX_END);
-        sh_listf(sh, "color = mix_color\n");
-    }
-    if (!ok || pl_shader_is_failed(sh)) {
-        // (more frames than one pass can hold ops for)
-        PL_WARN_RR(rr, "Frame mixing pass could not be recorded (%d frames), rendering the "
-                   "nearest frame instead", fidx);
-        pl_dispatch_abort(rr->dp, &sh);
-        goto fallback;
-    }
-    sh_describef(sh, "frame mixing (%d frame%s)", fidx, fidx > 1 ? "s" : "");
-
-    pass.img = (struct img) {
-        .sh = sh,
-        .w = out_w,
-        .h = out_h,
-        .comps = comps,
-        .color = target->color,
-        .rect = { 0, 0, out_w, out_h },
-        .repr = {
-            .sys = PL_COLOR_SYSTEM_RGB,
-            .levels = PL_COLOR_LEVELS_FULL,
-            .alpha = comps >= 4 ? PL_ALPHA_PREMULTIPLIED : PL_ALPHA_NONE,
-        },
-    };
-
-    // re-encode to the target transfer (in practice: delinearize)
-    if (!pl_color_space_equal(&mix_csp, &pass.img.color)) {
-        pl_shader_set_alpha(sh, &pass.img.repr, PL_ALPHA_INDEPENDENT);
-        pl_shader_color_map_ex(sh, NULL, pl_color_map_args(.src = mix_csp, .dst = pass.img.color));
-    }
-
-    if (!pass_output_target(&pass))
-        goto fallback;
-
-    pass_uninit(&pass);
-    return true;
-
-fail:
-    RR_ERR(rr, "Could not render image for frame mixing.. disabling!");
-    rr->errors |= PL_RENDER_ERR_FRAME_MIXING;
-    // fall through
-
-fallback:
-    pass_uninit(&pass);
-    return pl_render_image(rr, refimg, ptarget, params);
-}
-
-void pl_frames_infer_mix(pl_renderer rr, const struct pl_frame_mix *mix, struct pl_frame *target,
-                         struct pl_frame *out_ref)
-{
-    const struct pl_frame *refimg = pl_frame_mix_nearest(mix);
-    if (!refimg) {
-        if (out_ref)
-            *out_ref = (struct pl_frame) {0};
-        return;
-    }
-    struct pl_frame ref = *refimg;
-    pl_frames_infer(rr, &ref, target);
-    if (out_ref)
-        *out_ref = ref;
-}
-
-/* Test hook: record `color *= s` the way pass_output_target does (there is no public
- * pl_shader_* entry point for it); used by tests/test_gpu_renderer.py to rebuild the
- * renderer's passes by hand. */
+/* Test hooks (tests/): record `color *= s` the way the output stage does -- there is no public
+ * pl_shader_* entry point for it -- and print the plan of a frame without a GPU. */
 PL_API void plh_test_op_scale(pl_shader sh, float s);
 void plh_test_op_scale(pl_shader sh, float s)
 {
     struct plh_op *op = sh_op(sh, PLH_OP_SCALE);
     if (op)
         op->f[0] = op->f[1] = op->f[2] = op->f[3] = s;
+}
+
+// Plan a frame from descriptions alone (the textures only need valid `params`) and print the
+// decisions. `fbos`: whether intermediate images (rgba16hf) are available.
+PL_API pl_fmt plh_test_format(const char *name);
+PL_API size_t plh_test_plan(const struct pl_frame *image, const struct pl_frame *target,
+                            const struct pl_render_params *params, bool fbos,
+                            size_t max_shmem, char *out, size_t out_size);
+size_t plh_test_plan(const struct pl_frame *image, const struct pl_frame *target,
+                     const struct pl_render_params *params, bool fbos, size_t max_shmem,
+                     char *out, size_t out_size)
+{
+    struct rp_caps caps = { .max_shmem = max_shmem };
+    if (fbos) {
+        caps.fbo[4] = caps.fbo[3] = plh_test_format("rgba16hf");
+        caps.fbo[2] = plh_test_format("rg16hf");
+        caps.fbo[1] = plh_test_format("r16hf");
+    }
+    struct rp_summary sum;
+    rp_summarise(&caps, image, target, params ? params : &pl_render_default_params, &sum);
+    const size_t len = strlen(sum.text);
+    if (out && out_size) {
+        const size_t n = len < out_size - 1 ? len : out_size - 1;
+        memcpy(out, sum.text, n);
+        out[n] = '\0';
+    }
+    return len;
 }

@@ -1,0 +1,110 @@
+/*
+ * libplacebo-hip — internals shared by the two halves of the renderer's executor:
+ * renderer.c (one frame) and render_mix.c (pl_render_image_mix).
+ */
+#ifndef PLH_RENDERER_PRIV_H_
+#define PLH_RENDERER_PRIV_H_
+
+#include <libplacebo/renderer.h>
+
+#include "render_plan.h"
+#include "shaders_priv.h"
+
+#define RR_MAX_FBOS 16
+#define RR_MAX_MIX_FRAMES 16        // frames one mix may blend (reference renderer.c:3610)
+#define RR_MAX_CACHED_FRAMES 32
+
+// persistent filter state of one scaler slot, per direction
+struct scaler_slot {
+    pl_shader_obj up, down;
+};
+
+enum { RR_LUT_IMAGE, RR_LUT_TARGET, RR_LUT_PARAMS, RR_LUT_COUNT };
+
+// a frame rendered for mixing, kept across vsyncs
+struct mix_entry {
+    uint64_t signature;
+    uint64_t params_digest;     // of the render params it was produced with
+    struct pl_color_space color;
+    struct pl_color_repr repr;
+    pl_rect2df crop;
+    pl_tex tex;
+    int comps;
+    bool stale;                 // not referenced by the mix being built
+};
+
+struct pl_renderer_t {
+    pl_gpu gpu;
+    pl_dispatch dp;
+    pl_log log;
+    enum pl_render_error errors;
+
+    pl_tex fbos[RR_MAX_FBOS];
+    int num_fbos;
+
+    struct scaler_slot scale_main, scale_ref, scale_contrast;
+    struct scaler_slot scale_plane[PL_MAX_PLANES];   // chroma / alpha planes of the image
+    struct scaler_slot scale_out[PL_MAX_PLANES];     // planes of a planar target
+    pl_shader_obj tone_map_state;
+    pl_shader_obj dither_state;
+    pl_shader_obj lut_state[RR_LUT_COUNT];
+    int last_dither_depth;
+    bool warned_icc, warned_overlay, warned_grain;
+
+    struct mix_entry cache[RR_MAX_CACHED_FRAMES];
+    int num_cached;
+    pl_tex spare[RR_MAX_CACHED_FRAMES];     // textures of evicted entries, for reuse
+    int num_spare;
+};
+
+// The image as it travels through a frame: either recorded-but-not-run (`rec`) or resident
+// in a texture (`tex`), never both.
+struct work_image {
+    pl_shader rec;
+    pl_tex tex;
+    pl_tex copy_of;             // `rec` is so far nothing but a 1:1 fetch of this texture
+    int w, h;
+    pl_rect2df rect;
+    struct pl_color_repr repr;
+    struct pl_color_space color;
+    int comps;
+    pl_fmt store_as;            // format override for the next flush
+    // if the next flush fails: message, error bit to raise, texture to continue with
+    const char *fail_msg;
+    enum pl_render_error fail_bit;
+    pl_tex fail_tex;
+};
+
+// everything one pl_render_image call needs
+struct frame_job {
+    pl_renderer rr;
+    const struct pl_render_params *params;
+    struct pl_frame image, target;
+    struct rp_caps caps;
+    struct rp_geometry geo;
+    struct work_image img;
+    bool fbo_busy[RR_MAX_FBOS];
+    bool peak_pending;          // a same-frame measurement rides on `img.rec`
+    bool image_acquired, target_acquired;
+    bool target_borrowed;       // the target belongs to an enclosing job: neither acquire nor release
+    struct pl_render_info info;
+};
+
+#define RR_LOG(rr, lev, ...) pl_msg((rr)->log, lev, __VA_ARGS__)
+
+// renderer.c
+bool plh_job_begin(struct frame_job *job, bool acquire_image);
+void plh_job_end(struct frame_job *job);
+bool plh_params_supported(pl_renderer rr, const struct pl_render_params *params);
+void plh_job_watch_passes(struct frame_job *job);    // route pass timings to info_callback
+bool plh_stage_read(struct frame_job *job);
+bool plh_stage_scale(struct frame_job *job);
+void plh_stage_colors(struct frame_job *job);
+bool plh_stage_output(struct frame_job *job);
+pl_shader plh_work_shader(struct frame_job *job, struct work_image *img);
+pl_tex plh_work_texture(struct frame_job *job, struct work_image *img);
+// append a plain 1:1 fetch of another texture to `sh` as a colour op
+bool plh_append_plane_fetch(pl_shader sh, const pl_shader fetch, const struct pl_plane *plane);
+struct plh_op *plh_append_scale(pl_shader sh, float k, bool with_alpha);
+
+#endif // PLH_RENDERER_PRIV_H_

@@ -282,7 +282,8 @@ def test_color_map_sdr_to_hdr_matrix_fast_path(gpu):
 
 
 def _read_device(ptr, nbytes):
-    hip = C.CDLL("libamdhip64.so")
+    import util
+    hip = util.hip_runtime()
     hip.hipDeviceSynchronize()
     out = np.zeros(nbytes // 4, np.uint32)
     rc = hip.hipMemcpy(out.ctypes.data_as(C.c_void_p), C.c_void_p(ptr), C.c_size_t(nbytes), 2)

@@ -58,13 +58,15 @@ def test_rccl_exchange_world_size_one(gpu):
 
 
 def test_exchange_hook_sees_the_buffer_before_it_is_consumed(gpu):
-    hip = C.CDLL("libamdhip64.so")
+    import util
+    hip = util.hip_runtime()
     calls = []
 
     @C.CFUNCTYPE(None, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p)
     def second_identical_rank(priv, words, size, stream):
         assert size == 816 * 4
-        assert hip.hipStreamSynchronize(C.c_void_p(stream)) == 0
+        rc = hip.hipStreamSynchronize(C.c_void_p(stream))
+        assert rc == 0, (rc, hip._paths)
         buf = np.zeros(816, np.uint32)
         assert hip.hipMemcpy(buf.ctypes.data_as(C.c_void_p), C.c_void_p(words), size, 2) == 0
         calls.append(buf.copy())

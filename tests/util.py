@@ -41,3 +41,22 @@ def blue_noise(pl, size=64, seed=1):
 def diff_stats(a, b):
     d = np.abs(a.astype(np.int64) - b.astype(np.int64))
     return int(d.max()), int((d > 0).sum())
+
+
+def hip_runtime():
+    """ctypes handle of the HIP runtime instance libplacebo_hip.so itself is bound to (found in
+    /proc/self/maps; dlopen of an already mapped path returns that very instance). Loading
+    "libamdhip64.so" by name can pick up another copy (torch bundles one), whose streams and
+    allocations are not interchangeable with ours."""
+    import libplacebo_amd as pl
+    pl.lib()
+    paths = []
+    for ln in open("/proc/self/maps"):
+        if "libamdhip64" in ln:
+            path = ln.split()[-1]
+            if path not in paths:
+                paths.append(path)
+    assert paths, "no HIP runtime mapped"
+    lib = C.CDLL(paths[0])
+    lib._paths = paths
+    return lib
