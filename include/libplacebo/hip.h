@@ -78,12 +78,16 @@ typedef void (*pl_hip_peak_exchange_fn)(void *priv, void *words, size_t size, vo
 PL_API void pl_hip_set_peak_exchange(pl_gpu gpu, pl_hip_peak_exchange_fn fn, void *priv);
 
 // Ready-made exchange over RCCL (xGMI inside a node). `nccl_comm` is an initialised
-// ncclComm_t whose local device is the one `gpu` runs on; librccl.so is resolved at run time
-// (dlopen), the library has no link-time dependency on it. Typical use:
-//     pl_hip_rccl x = pl_hip_rccl_create(gpu, comm);
+// ncclComm_t whose local device is the one `gpu` runs on. `nccl_all_reduce` is the address of
+// ncclAllReduce in the RCCL instance that created the communicator (a communicator is only
+// valid inside the instance that made it, and that instance must sit on the same HIP runtime as
+// this library: ROCm's librccl, not a copy bundled with another framework); NULL = resolve
+// "ncclAllReduce" at run time (process scope, then dlopen of librccl.so). The library has no
+// link-time dependency on RCCL. Typical use:
+//     pl_hip_rccl x = pl_hip_rccl_create(gpu, comm, (void *) ncclAllReduce);
 //     pl_hip_set_peak_exchange(gpu, pl_hip_rccl_peak_exchange, x);
 typedef struct pl_hip_rccl_t *pl_hip_rccl;
-PL_API pl_hip_rccl pl_hip_rccl_create(pl_gpu gpu, void *nccl_comm);
+PL_API pl_hip_rccl pl_hip_rccl_create(pl_gpu gpu, void *nccl_comm, void *nccl_all_reduce);
 PL_API void pl_hip_rccl_destroy(pl_hip_rccl *x);
 PL_API void pl_hip_rccl_peak_exchange(void *priv, void *words, size_t size, void *stream);
 // number of exchanges performed / nonzero RCCL status seen so far

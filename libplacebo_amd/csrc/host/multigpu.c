@@ -42,7 +42,7 @@ void plh_gpu_peak_exchange(pl_gpu gpu, void *words, size_t size)
         p->peak_exchange(p->peak_exchange_priv, words, size, p->stream);
 }
 
-pl_hip_rccl pl_hip_rccl_create(pl_gpu gpu, void *nccl_comm)
+pl_hip_rccl pl_hip_rccl_create(pl_gpu gpu, void *nccl_comm, void *nccl_all_reduce)
 {
     if (!nccl_comm) {
         pl_msg(gpu->log, PL_LOG_ERR, "pl_hip_rccl_create: NULL communicator");
@@ -53,9 +53,10 @@ pl_hip_rccl pl_hip_rccl_create(pl_gpu gpu, void *nccl_comm)
         return NULL;
     x->gpu = gpu;
     x->comm = nccl_comm;
-    // prefer the copy the process already has (torch ships its own)
     static const char *const names[] = { "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so" };
-    x->all_reduce = (allreduce_fn) dlsym(RTLD_DEFAULT, "ncclAllReduce");
+    x->all_reduce = (allreduce_fn) nccl_all_reduce;
+    if (!x->all_reduce)
+        x->all_reduce = (allreduce_fn) dlsym(RTLD_DEFAULT, "ncclAllReduce");
     for (size_t i = 0; !x->all_reduce && i < PL_ARRAY_SIZE(names); i++) {
         x->dl = dlopen(names[i], RTLD_NOW | RTLD_GLOBAL);
         if (x->dl)

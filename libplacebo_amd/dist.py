@@ -54,14 +54,11 @@ import os as _os
 
 
 def _load_rccl():
-    """librccl: the copy torch ships if torch is importable (one RCCL per process), else ROCm's"""
-    cands = []
-    try:
-        import torch
-        cands += _glob.glob(_os.path.join(_os.path.dirname(torch.__file__), "lib", "librccl.so*"))
-    except Exception:
-        pass
-    cands += ["librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so"]
+    """The RCCL that belongs to the HIP runtime libplacebo_hip.so is linked against (ROCm's).
+    NOT the copy torch bundles: that one is bound to torch's own bundled HIP runtime, whose
+    streams are not interchangeable with ours; a communicator must be created and used by one
+    and the same RCCL instance."""
+    cands = ["/opt/rocm/lib/librccl.so", "/opt/rocm/lib/librccl.so.1", "librccl.so.1", "librccl.so"]
     for c in cands:
         try:
             return _C.CDLL(c, mode=_os.RTLD_GLOBAL)
@@ -99,8 +96,10 @@ class RcclPeakExchange:
         rc = self.rccl.ncclCommInitRank(_C.byref(self.comm), int(world), uid, int(rank))
         assert rc == 0, f"ncclCommInitRank: {rc}"
         self.L.pl_hip_rccl_create.restype = _C.c_void_p
-        self.L.pl_hip_rccl_create.argtypes = [_C.c_void_p, _C.c_void_p]
-        self.x = _C.c_void_p(self.L.pl_hip_rccl_create(gpu.gpu, self.comm))
+        self.L.pl_hip_rccl_create.argtypes = [_C.c_void_p, _C.c_void_p, _C.c_void_p]
+        # the all-reduce entry of the very RCCL instance that owns the communicator
+        fn_ar = _C.cast(self.rccl.ncclAllReduce, _C.c_void_p)
+        self.x = _C.c_void_p(self.L.pl_hip_rccl_create(gpu.gpu, self.comm, fn_ar))
         assert self.x, gpu.messages[-3:]
         fn = _C.cast(self.L.pl_hip_rccl_peak_exchange, _C.c_void_p)
         self.L.pl_hip_set_peak_exchange.argtypes = [_C.c_void_p, _C.c_void_p, _C.c_void_p]

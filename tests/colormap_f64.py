@@ -94,14 +94,19 @@ def lerp_lut3d(lut_u16, size, idx):
     return out
 
 
-def hdr10_to_sdr(img, r, eps):
+def hdr10_to_sdr(img, r, eps, prelinearized=False, lowres=None, strength=0.0, cr_out=(0.0, 1.0)):
     """PQ/HDR10 -> BT.1886 colour map in float64.
 
     `r` = colormap_ref.resolve(...). Returns (out, allow): the float64 result and the per-sample
     first-order bound on |fp32 result - out| given that the PQ-decoded LMS values (the inputs of
-    the last matrix) carry a relative error <= eps."""
+    the last matrix) carry a relative error <= eps. prelinearized: `img` already is linear light
+    (1.0 = 203 cd/m^2). lowres / strength / cr_out: contrast recovery (colorspace.c:1880-1921),
+    `lowres` = the low-pass luma per pixel."""
     kw = r["kw"]
-    rgb = pq_eotf(img[..., :3].astype(np.float64)) * K10          # linearize (PQ)
+    if prelinearized:
+        rgb = img[..., :3].astype(np.float64)
+    else:
+        rgb = pq_eotf(img[..., :3].astype(np.float64)) * K10          # linearize (PQ)
     lms = rgb @ np.array(kw["rgb2lms"], np.float64).reshape(3, 3).T
     ipt = pq_oetf(K203 * lms) @ LMS2IPT.T
     I, P, T = ipt[..., 0], ipt[..., 1], ipt[..., 2]
@@ -112,7 +117,14 @@ def hdr10_to_sdr(img, r, eps):
         if mode == 0:
             I = np.clip(I, tp[0], tp[1])
         elif mode == 2:
-            I = lerp_lut1d(kw["tone_lut"], tp[0] * I + tp[1])
+            curve = lambda v: lerp_lut1d(kw["tone_lut"], tp[0] * v + tp[1])  # noqa: E731
+            if lowres is not None:
+                hi = np.clip(I, 0.0, 1.0)
+                lo = np.clip(np.asarray(lowres, np.float64).reshape(I.shape), 0.0, 1.0)
+                base, sharp = curve(hi), curve(lo) + (hi - lo)
+                I = np.clip(base * (1 - strength) + sharp * strength, cr_out[0], cr_out[1])
+            else:
+                I = curve(I)
         hull = lambda v: ((v - 6.0) * v + 9.0) * v   # noqa: E731
         k = np.minimum(i_orig / I, hull(I) / hull(i_orig))
         P, T = P * k, T * k

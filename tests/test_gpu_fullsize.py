@@ -165,22 +165,15 @@ def resolve_with_peak(meta, tone=b"spline", gamut=b"perceptual"):
 
 
 def colormap_tolerance(got16, ref16, truth=None, sel=None):
-    """Parity statement for the colour-mapped stages, in 16-bit code values.
-
-    vs the oracle (float libm): median <= 0.25, 90 % <= 2.
-    vs float64 (where given): at every quantile the GPU may be at most 1 LSB further from the
-    float64 evaluation than the float-libm oracle is (VERDICT r01 weak #3)."""
-    d = np.abs(got16[..., :3].astype(np.int64) - ref16[..., :3].astype(np.int64)).ravel()
-    q50, q90 = np.quantile(d, (0.5, 0.9))
-    assert q50 <= 0.25 and q90 <= 2.0, (q50, q90, int(d.max()))
-    if truth is not None:
-        g = got16[..., :3].reshape(-1, 3)[sel].astype(np.float64)
-        o = ref16[..., :3].reshape(-1, 3)[sel].astype(np.float64)
-        t = np.clip(truth[..., :3].reshape(-1, 3), 0, 1) * 65535.0
-        eg, eo = np.abs(g - t).ravel(), np.abs(o - t).ravel()
-        for q in (0.5, 0.9, 0.99, 0.999, 1.0):
-            assert np.quantile(eg, q) <= np.quantile(eo, q) + 1.0, \
-                (q, float(np.quantile(eg, q)), float(np.quantile(eo, q)))
+    """util.assert_colormap_parity on rgba16 images; `truth` (float, [0, 1]) covers the flat pixel
+    indices `sel`."""
+    if truth is None:
+        util.assert_colormap_parity(got16, ref16, None, scale=1.0)
+        return
+    g = got16[..., :3].reshape(-1, 3)[sel]
+    o = ref16[..., :3].reshape(-1, 3)[sel]
+    util.assert_colormap_parity(g, o, truth.reshape(-1, truth.shape[-1])[:, :3], scale=1.0)
+    util.assert_colormap_parity(got16, ref16, None, scale=1.0)
 
 
 @pytest.mark.parametrize("size", [(128, 80), P4K])
@@ -344,13 +337,14 @@ def test_cfg5_8k_to_4k_deband_ewa_tone_map(gpu, size):
     avg = refbuf[24:36].sum() / (refbuf[12:24].sum() * 16383.0)
     assert abs(meta.avg_pq_y - avg) <= 3e-4, (meta.avg_pq_y, avg)
     # D: colour map on linear light, BT.1886, store
+    import colormap_f64 as c64
     r_ = resolve_with_peak(meta)
+    sel = np.arange(0, dw * dh, 13)
+    truth, _ = c64.hdr10_to_sdr(b.reshape(-1, 1, 4)[sel], r_, 0.0, prelinearized=True)
     ref = cr.apply(b, r_, prelinearized=True)
     ref16 = orc.tex_encode(ref, "rgba16")
-    colormap_tolerance(got, ref16)
-    # the handful of debanding decisions that differ (native sin/cos at texel boundaries, see
-    # test_gpu_ortho_deband.py) are diluted by the 150-tap kernel: nothing may stand out
-    d = np.abs(got[..., :3].astype(np.int64) - ref16[..., :3].astype(np.int64))
-    assert np.quantile(d, 0.999) <= 64, float(np.quantile(d, 0.999))
+    # (against float64 the comparison is exact only up to the few debanding decisions that
+    # differ, which is why the oracle-side statement below has its own bound)
+    colormap_tolerance(got, ref16, truth.reshape(-1, 4), sel)
     assert np.all(got[..., 3] == 65535)
     src.destroy(); dst.destroy(); rr.destroy()
