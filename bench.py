@@ -286,8 +286,6 @@ def kernel_symbol(workload, name):
         return "k_deband"
     if workload == "bilinear_1080p_to_4k":
         return "k_bilinear_fast"
-    if "tone map" in name or "gamut map" in name:
-        return "k_colormap"
     return "k_pass_generic"
 
 

@@ -129,6 +129,13 @@ ORC_API void orc_tex_decode(const void *src, int fmt, int w, int h, size_t pitch
 }
 
 // Image store with the target format's conversion (unorm: clamp, scale, RNE)
+// unorm encode: the exact product, rounded half-even once -- what the GPU's colour export
+// (v_cvt_pknorm_u16_f32) computes; the double product of a float and 2^n - 1 is exact
+static double unorm_rne(float v, double maxv)
+{
+    return rint((double) fminf(fmaxf(v, 0.0f), 1.0f) * maxv);
+}
+
 ORC_API void orc_tex_encode(const float *img, int w, int h, int fmt, void *dst, size_t pitch)
 {
     const int nc = fmt_comps(fmt), cls = fmt_class(fmt);
@@ -140,8 +147,8 @@ ORC_API void orc_tex_encode(const float *img, int w, int h, int fmt, void *dst, 
                 const int i = x * nc + c;
                 const float v = p[c];
                 switch (cls) {
-                case 0: row[i] = (uint8_t) rintf(fminf(fmaxf(v, 0.0f), 1.0f) * 255.0f); break;
-                case 1: ((uint16_t *) row)[i] = (uint16_t) rintf(fminf(fmaxf(v, 0.0f), 1.0f) * 65535.0f); break;
+                case 0: row[i] = (uint8_t) unorm_rne(v, 255.0); break;
+                case 1: ((uint16_t *) row)[i] = (uint16_t) unorm_rne(v, 65535.0); break;
                 case 2: ((uint16_t *) row)[i] = float_to_half(v); break;
                 case 3: ((float *) row)[i] = v; break;
                 }

@@ -164,7 +164,7 @@ def resolve_with_peak(meta, tone=b"spline", gamut=b"perceptual"):
     return cr.resolve(src, dst, tone=tone, gamut=gamut)
 
 
-def colormap_tolerance(got16, ref16, truth=None, sel=None):
+def colormap_tolerance(got16, ref16, truth=None, sel=None, **kw):
     """util.assert_colormap_parity on rgba16 images; `truth` (float, [0, 1]) covers the flat pixel
     indices `sel`."""
     if truth is None:
@@ -172,7 +172,7 @@ def colormap_tolerance(got16, ref16, truth=None, sel=None):
         return
     g = got16[..., :3].reshape(-1, 3)[sel]
     o = ref16[..., :3].reshape(-1, 3)[sel]
-    util.assert_colormap_parity(g, o, truth.reshape(-1, truth.shape[-1])[:, :3], scale=1.0)
+    util.assert_colormap_parity(g, o, truth.reshape(-1, truth.shape[-1])[:, :3], scale=1.0, **kw)
     util.assert_colormap_parity(got16, ref16, None, scale=1.0)
 
 
@@ -343,8 +343,116 @@ def test_cfg5_8k_to_4k_deband_ewa_tone_map(gpu, size):
     truth, _ = c64.hdr10_to_sdr(b.reshape(-1, 1, 4)[sel], r_, 0.0, prelinearized=True)
     ref = cr.apply(b, r_, prelinearized=True)
     ref16 = orc.tex_encode(ref, "rgba16")
-    # (against float64 the comparison is exact only up to the few debanding decisions that
-    # differ, which is why the oracle-side statement below has its own bound)
-    colormap_tolerance(got, ref16, truth.reshape(-1, 4), sel)
+    # `truth` is float64 on the ORACLE's intermediate image. The renderer's own differs from it
+    # in a few f16 codes of the 8K FBO (a PQ EOTF ulp that crosses an f16 rounding boundary,
+    # ~1e-4 of the texels); where that texel is a 3900-nit highlight on a black surround, one
+    # f16 ulp of it is thousands of output codes on the negative lobes around it. Those ~1e-5 of
+    # the pixels make the maximum meaningless end to end: the quantiles up to 99.9 % are stated
+    # here, the maximum stage by stage in test_cfg5_stage_by_stage (each stage fed the oracle's
+    # output of the previous one).
+    colormap_tolerance(got, ref16, truth.reshape(-1, 4), sel, quantiles=(0.5, 0.9, 0.99, 0.999))
+    far = np.abs(got[..., :3].astype(np.int64) - ref16[..., :3]).max(axis=2) > 300
+    assert far.mean() <= 2e-5, far.sum()
     assert np.all(got[..., 3] == 65535)
     src.destroy(); dst.destroy(); rr.destroy()
+
+
+@pytest.mark.parametrize("size", [((256, 144), (128, 72)), (P8K, P4K)])
+def test_cfg5_stage_by_stage(gpu, size):
+    """configs[4] with every stage run on its own through the shader API and fed the ORACLE's
+    output of the previous stage, so that each comparison is about that stage alone:
+    A deband + PQ linearize -> f16 (identical codes but for EOTF-ulp rounding flips and the
+    debanding decisions that follow a sin/cos ulp); B widened EWA in linear light (bit-exact);
+    C colour map + BT.1886 (never further from float64 than the oracle, maximum included)."""
+    import types
+    import colormap_ref as cr
+    import colormap_f64 as c64
+    from test_gpu_color import luma_coeffs, nominal
+    (sw, sh), (dw, dh) = size
+    img = hdr_frame16(sw, sh)
+    hdr = pl.color_space("bt2020", "pq")
+    sdr = pl.color_space("bt709", "bt1886")
+    hdr_i, sdr_i = inferred(hdr, sdr)
+    mn, mx = nominal(hdr_i)
+    luma = luma_coeffs(hdr_i.primaries)
+    deband = capi.DebandParams.in_dll(pl.lib(), "pl_deband_default_params")
+    grain = float(np.float32(deband.grain / (hdr_i.hdr.max_luma / 203.0)))
+
+    # -- A
+    src = gpu.tex_create(sw, sh, "rgba16", img)
+    ta = gpu.tex_create(sw, sh, "rgba16hf")
+    s = gpu.begin()
+    assert s.deband(src, iterations=deband.iterations, threshold=deband.threshold,
+                    radius=deband.radius, grain=grain, components=3), gpu.messages[-3:]
+    s.linearize(hdr_i)
+    seed = int(s.listing().split("seed=")[1].split(")")[0])
+    assert s.finish(ta), gpu.messages[-3:]
+    got_a = ta.download()[..., :3]
+    src.destroy()
+    a = orc.deband(orc.tex_decode(img, "rgba16"), sw, sh, iterations=deband.iterations,
+                   threshold=deband.threshold, radius=deband.radius, grain=grain, frame_index=seed)
+    a[..., 3] = 1.0
+    # float64 EOTF of the oracle's debanded image, rounded to f16 once
+    t16 = (c64.pq_eotf(a[..., :3].astype(np.float64)) * c64.K10).astype(np.float16)
+    orc.linearize(a, pl.TRC["pq"], mn, mx, luma)
+    orc.op_quant_f16(a)
+    ref_a = a[..., :3].astype(np.float16)
+    u16 = lambda x: x.view(np.uint16)
+    ulps = np.abs(u16(got_a).astype(np.int32) - u16(ref_a))
+    # an EOTF error that straddles an f16 rounding boundary flips the stored code by one. The
+    # oracle's float-libm EOTF does that on ~1.5 % of the texels, the kernel's (pqmath.hiph) on
+    # fewer: it must match the float64 codes at least as often as the oracle does
+    miss_gpu, miss_orc = (u16(got_a) != u16(t16)).mean(), (u16(ref_a) != u16(t16)).mean()
+    assert miss_gpu <= miss_orc + 1e-4, (miss_gpu, miss_orc)
+    assert (ulps == 0).mean() >= 1.0 - (miss_gpu + miss_orc) - 1e-4, (ulps == 0).mean()
+    assert (ulps <= 1).mean() >= 0.9999, (ulps <= 1).mean()
+    # the rest: a debanding decision that went the other way (a sin/cos ulp moved a sample point
+    # across a texel edge) -- bounded by what debanding may change at all (threshold + grain in
+    # PQ code space: < 10 % of the linear value + a floor)
+    far = ulps > 1
+    if far.any():
+        g, r = got_a[far].astype(np.float64), ref_a[far].astype(np.float64)
+        assert np.all(np.abs(g - r) <= 0.1 * np.maximum(np.abs(g), np.abs(r)) + 1e-4), \
+            np.abs(g - r).max()
+    print("cfg5 stage A: f16 codes != float64: GPU %.5f oracle %.5f; GPU != oracle %.5f, > 1 ulp %.2e"
+          % (miss_gpu, miss_orc, (ulps != 0).mean(), far.mean()))
+    del t16
+    del got_a, ref_a, ulps, far
+
+    # -- B: the oracle's A, uploaded
+    ta.upload(a.astype(np.float16))
+    tb = gpu.tex_create(dw, dh, "rgba16hf")
+    lut = pl.ShaderObj()
+    s = gpu.begin()
+    assert s.sample_polar(ta, pl.filter_config("ewa_lanczos", 2), lut, new_w=dw, new_h=dh,
+                          components=3), gpu.messages[-3:]
+    assert s.finish(tb), gpu.messages[-3:]
+    got_b = tb.download()
+    w, r, rz = orc.filter_generate_polar(orc.ewa_lanczos(blur=float(sw) / dw))
+    b = orc.sample_polar(a, w, r, rz, dw, dh, mask=0x7, gather_order=not r < 6.0)
+    del a
+    orc.op_quant_f16(b)
+    assert np.array_equal(got_b[..., :3].view(np.uint16), b[..., :3].astype(np.float16).view(np.uint16)), \
+        util.diff_stats(got_b[..., :3].astype(np.float32), b[..., :3])
+    ta.destroy(); lut.destroy()
+
+    # -- C: the oracle's B, uploaded; a fixed scene measurement in the source metadata
+    b[..., 3] = 1.0
+    tb.upload(b.astype(np.float16))
+    meta = types.SimpleNamespace(max_pq_y=0.70, avg_pq_y=0.35)
+    src_csp = capi.ColorSpace()
+    C.memmove(C.byref(src_csp), C.byref(hdr_i), C.sizeof(src_csp))
+    src_csp.hdr.max_pq_y, src_csp.hdr.avg_pq_y = meta.max_pq_y, meta.avg_pq_y
+    dst = gpu.tex_create(dw, dh, "rgba16")
+    state = pl.ShaderObj()
+    s = gpu.begin()
+    assert s.sample("direct", tb)
+    s.color_map(src_csp, sdr_i, state, prelinearized=True)
+    assert s.finish(dst), gpu.messages[-3:]
+    got = dst.download()
+    r_ = resolve_with_peak(meta)
+    sel = np.arange(0, dw * dh, 7)
+    truth, _ = c64.hdr10_to_sdr(b.reshape(-1, 1, 4)[sel], r_, 0.0, prelinearized=True)
+    ref16 = orc.tex_encode(cr.apply(b, r_, prelinearized=True), "rgba16")
+    colormap_tolerance(got, ref16, truth.reshape(-1, 4), sel)
+    tb.destroy(); dst.destroy(); state.destroy()

@@ -64,7 +64,8 @@ def hip_runtime():
     return lib
 
 
-def assert_colormap_parity(got, ref, truth=None, scale=65535.0):
+def assert_colormap_parity(got, ref, truth=None, scale=65535.0,
+                           quantiles=(0.5, 0.9, 0.99, 0.999, 1.0)):
     """Parity statement for stages that go through the PQ / IPT colour-mapping chain, in 16-bit
     code values (`got`, `ref`, `truth`: same shape, RGB in the first three components; float
     images in [0, 1] or integer code values with scale = 1).
@@ -93,7 +94,7 @@ def assert_colormap_parity(got, ref, truth=None, scale=65535.0):
         return
     t = np.clip(np.asarray(truth, np.float64)[..., :3].reshape(-1), 0.0, 1.0) * 65535.0
     eg, eo = np.abs(g - t), np.abs(o - t)
-    for q in (0.5, 0.9, 0.99, 0.999, 1.0):
+    for q in quantiles:
         qg, qo = np.quantile(eg, q), np.quantile(eo, q)
         assert qg <= qo + 1.0, ("GPU further from float64 than the oracle", q, qg, qo)
         # (quantiles are not sub-additive sample by sample: allow half as much again)
