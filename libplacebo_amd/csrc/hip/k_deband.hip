@@ -27,21 +27,6 @@
 #define DEBAND_BW 64
 #define DEBAND_BH 4
 
-struct prng3 { uint32_t x, y, z; };
-
-DEV void pcg3d(prng3 &s, float out[3])
-{
-    s.x = 1664525u * s.x + 1013904223u;
-    s.y = 1664525u * s.y + 1013904223u;
-    s.z = 1664525u * s.z + 1013904223u;
-    s.x += s.y * s.z; s.y += s.z * s.x; s.z += s.x * s.y;
-    s.x ^= s.x >> 16; s.y ^= s.y >> 16; s.z ^= s.z >> 16;
-    s.x += s.y * s.z; s.y += s.z * s.x; s.z += s.x * s.y;
-    // vec3(s) * 1.0/float(0xFFFFFFFFu): float(0xFFFFFFFF) rounds to 2^32
-    const float k = 1.0f / 4294967296.0f;
-    out[0] = (float) s.x * k; out[1] = (float) s.y * k; out[2] = (float) s.z * k;
-}
-
 template <bool LITE>
 __global__ __launch_bounds__(DEBAND_BW * DEBAND_BH)
 void k_deband(const plh_pass p_)

@@ -107,24 +107,22 @@ void pl_shader_dither(pl_shader sh, int new_depth, pl_shader_obj *dither_state,
         }
     }
 
-    if (method == PL_DITHER_WHITE_NOISE) {
-        SH_FAIL(sh, "PL_DITHER_WHITE_NOISE is not supported by the HIP backend yet");
-        return;
-    }
-
+    const bool white = method == PL_DITHER_WHITE_NOISE;
     const int size = obj ? lut_size : 16;
     struct plh_op *op = sh_op(sh, PLH_OP_DITHER);
     if (!op)
         return;
-    op->i0 = size;
-    op->i1 = obj ? 0 : 1;   // 0 = LUT, 1 = ordered-fixed bit tricks
-    op->i2 = params->temporal;
+    // i1: 0 = LUT, 1 = ordered-fixed bit tricks, 2 = white noise (i0 = PRNG seed: the frame
+    // index if temporal, else 0 -- sh_prng, shaders.c:985-990)
+    op->i0 = white ? (params->temporal ? (int32_t) sh->params.index : 0) : size;
+    op->i1 = white ? 2 : obj ? 0 : 1;
+    op->i2 = !white && params->temporal;
     op->f[0] = (float) ((1LLU << new_depth) - 1);
     op->f[1] = approx_gamma(params->transfer);
     op->f[2] = 1.0f / (float) size;     // GLSL constant expression `1.0/size`
     op->f[3] = new_depth;
     op->f[8] = 1.0f / op->f[0];         // GLSL constant expression `1.0 / scale`
-    if (params->temporal) {
+    if (op->i2) {
         const int phase = sh->params.index % 8;
         const float r = phase * (M_PI / 2);
         const float m = phase < 4 ? 1 : -1;
@@ -138,8 +136,9 @@ void pl_shader_dither(pl_shader sh, int new_depth, pl_shader_obj *dither_state,
         op->ptr = pl_hip_buf_ptr(obj->lut);
         sh_hold(sh, *dither_state);
     }
-    sh_listf(sh, "dither(depth=%d, method=%d, size=%d, gamma=%g, temporal=%d)\n",
-             new_depth, (int) method, size, op->f[1], (int) params->temporal);
+    sh_listf(sh, "dither(depth=%d, method=%d, size=%d, gamma=%g, temporal=%d, index=%d)\n",
+             new_depth, (int) method, white ? 0 : size, op->f[1], (int) params->temporal,
+             (int) sh->params.index);
 }
 
 // Right-most column (after the (y, x) -> (y, x + y*shift) skew) that the

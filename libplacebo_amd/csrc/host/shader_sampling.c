@@ -422,7 +422,12 @@ static bool sample_polar(pl_shader sh, const struct pl_sample_src *src,
     // (+2: one texel of rounding slack per side, see k_polar.hip)
     const int padding = 2 * bound - 1;
     const float margin = 1e-5;
-    const bool fp32_tile = !force_f16_tile && src->tex->params.format->component_depth[0] > 16;
+    // the LDS tile holds f16 texels only where that is lossless: an rgba16hf source, or the fused
+    // PASS A whose result the reference rounds to an rgba16hf FBO anyway. unorm8/16 and fp32
+    // sources are staged as fp32 (k/255 and k/65535 are not f16 numbers)
+    const pl_fmt sfmt = src->tex->params.format;
+    const bool f16_src = sfmt->type == PL_FMT_FLOAT && sfmt->component_depth[0] == 16;
+    const bool fp32_tile = !force_f16_tile && !f16_src;
     const size_t texel = fp32_tile ? 16 : 8;
     const size_t max_lds = 160 * 1024 / 2; // keep two workgroups per CU resident
     int rows = 4, tile_w, tile_h;

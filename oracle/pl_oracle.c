@@ -573,6 +573,19 @@ ORC_API void orc_op_affine(float *img, size_t npix, const float m[9], const floa
 // pl_shader_dither (src/shaders/dithering.c:109-274); gl_FragCoord = id + 0.5
 // (rect-relative in compute passes, dispatch.c:1040). method: 0 = LUT (blue
 // noise / bayer: integer index path), 1 = PL_DITHER_ORDERED_FIXED.
+static void o_pcg3d(uint32_t s[3], float out[3])
+{
+    for (int k = 0; k < 3; k++)
+        s[k] = 1664525u * s[k] + 1013904223u;
+    s[0] += s[1] * s[2]; s[1] += s[2] * s[0]; s[2] += s[0] * s[1];
+    for (int k = 0; k < 3; k++)
+        s[k] ^= s[k] >> 16;
+    s[0] += s[1] * s[2]; s[1] += s[2] * s[0]; s[2] += s[0] * s[1];
+    const float k32 = 1.0f / (float) 0xFFFFFFFFu;    // float(0xFFFFFFFF) == 2^32
+    for (int k = 0; k < 3; k++)
+        out[k] = (float) s[k] * k32;
+}
+
 ORC_API void orc_dither(float *img, int w, int h, const float *matrix, int size, int method,
                         int depth, float gamma, int temporal, int frame_index)
 {
@@ -592,13 +605,18 @@ ORC_API void orc_dither(float *img, int w, int h, const float *matrix, int size,
         for (int x = 0; x < w; x++) {
             const float fcx = (float) (x + fx0) + 0.5f, fcy = (float) (y + fy0) + 0.5f;
             float px = fractf(fcx / (float) size), py = fractf(fcy / (float) size); // :183
-            if (temporal) {
+            if (temporal && method != 2) {
                 const float qx = (rot[0] * px + rot[2] * py) + 1.0f;
                 const float qy = (rot[1] * px + rot[3] * py) + 1.0f;
                 px = fractf(qx); py = fractf(qy);                             // :199
             }
             float bias;
-            if (method == 0) {
+            if (method == 2) {                                                 // :204-207
+                uint32_t st[3] = { (uint32_t) fcx, (uint32_t) fcy, temporal ? (uint32_t) frame_index : 0u };
+                float rnd[3];
+                o_pcg3d(st, rnd);
+                bias = rnd[0];
+            } else if (method == 0) {
                 bias = matrix[(int) (py * (float) size) * size + (int) (px * (float) size)]; // :230
             } else {
                 uint32_t ux = (uint32_t) (px * 16.0f) % 16u, uy = (uint32_t) (py * 16.0f) % 16u;
@@ -1542,18 +1560,6 @@ ORC_API void orc_sample_ortho(const struct orc_src *s, const float *rows, int ro
 /* ======================================================================== */
 /* K6: debanding (src/shaders/sampling.c:183-275), PRNG src/shaders.c:965-998  */
 
-static void o_pcg3d(uint32_t s[3], float out[3])
-{
-    for (int k = 0; k < 3; k++)
-        s[k] = 1664525u * s[k] + 1013904223u;
-    s[0] += s[1] * s[2]; s[1] += s[2] * s[0]; s[2] += s[0] * s[1];
-    for (int k = 0; k < 3; k++)
-        s[k] ^= s[k] >> 16;
-    s[0] += s[1] * s[2]; s[1] += s[2] * s[0]; s[2] += s[0] * s[1];
-    const float k32 = 1.0f / (float) 0xFFFFFFFFu;    // float(0xFFFFFFFF) == 2^32
-    for (int k = 0; k < 3; k++)
-        out[k] = (float) s[k] * k32;
-}
 
 ORC_API void orc_deband(const struct orc_src *s, int iterations, float threshold, float radius,
                         float grain, const float grain_neutral[3], float scale, unsigned mask,
