@@ -508,3 +508,21 @@ pl_cache_obj pl_cache_get_file(void *path, uint64_t key)
     }
     return obj;
 }
+
+bool plh_cache_memoize(pl_cache cache, uint64_t signature, void *data, size_t size,
+                       void (*fill)(void *data, void *priv), void *priv)
+{
+    pl_cache_obj obj = { .key = PLH_CACHE_KEY_SH_LUT ^ signature };
+    if (cache && signature && pl_cache_get(cache, &obj) && obj.size == size) {
+        memcpy(data, obj.data, size);
+        pl_cache_set(cache, &obj);      // pl_cache_get took it out: hand it back
+        return true;
+    }
+    pl_cache_obj_free(&obj);
+    fill(data, priv);
+    if (cache && signature) {
+        obj = (pl_cache_obj) { .key = PLH_CACHE_KEY_SH_LUT ^ signature, .data = data, .size = size };
+        pl_cache_set(cache, &obj);      // free == NULL: the cache keeps its own copy
+    }
+    return false;
+}

@@ -22,6 +22,7 @@
 #include <libplacebo/shaders/colorspace.h>
 
 #include "shaders_priv.h"
+#include "cache_priv.h"
 #include "colorspace_priv.h"
 
 #define MIXF(a, b, x) ((x) * (b) + (1 - (x)) * (a))
@@ -792,28 +793,55 @@ static void mat_to_f(float *f, const pl_matrix3x3 *m)
 
 // 48x32x256 IPT LUT -> rgba16 unorm with a +32767 chroma bias (fill_gamut_lut,
 // colorspace.c:1589-1610)
-static pl_buf make_gamut_lut(pl_gpu gpu, const struct pl_gamut_map_params *gamut)
+static void fill_gamut_lut(void *data, void *priv)
 {
+    const struct pl_gamut_map_params *gamut = priv;
     const size_t n = (size_t) gamut->lut_size_I * gamut->lut_size_C * gamut->lut_size_h;
     float *tmp = malloc(n * 3 * sizeof(float));
-    uint16_t *packed = malloc(n * 4 * sizeof(uint16_t));
-    pl_buf buf = NULL;
-    if (tmp && packed) {
-        pl_gamut_map_generate(tmp, gamut);
-        const float *in = tmp;
-        uint16_t *out = packed;
-        for (size_t i = 0; i < n; i++) {
-            out[0] = roundf(in[0] * UINT16_MAX);
-            out[1] = roundf(in[1] * UINT16_MAX + (UINT16_MAX >> 1));
-            out[2] = roundf(in[2] * UINT16_MAX + (UINT16_MAX >> 1));
-            out[3] = 0;
-            in += 3;
-            out += 4;
-        }
-        buf = pl_buf_create(gpu, pl_buf_params(.size = n * 4 * sizeof(uint16_t),
-                                               .storable = true, .initial_data = packed));
+    if (!tmp)
+        abort();
+    pl_gamut_map_generate(tmp, gamut);
+    const float *in = tmp;
+    uint16_t *out = data;
+    for (size_t i = 0; i < n; i++) {
+        out[0] = roundf(in[0] * UINT16_MAX);
+        out[1] = roundf(in[1] * UINT16_MAX + (UINT16_MAX >> 1));
+        out[2] = roundf(in[2] * UINT16_MAX + (UINT16_MAX >> 1));
+        out[3] = 0;
+        in += 3;
+        out += 4;
     }
     free(tmp);
+}
+
+// everything the table depends on except its size, which the cache protocol checks
+// (gamut_map_signature, colorspace.c:991-1001)
+static uint64_t gamut_lut_signature(const struct pl_gamut_map_params *par)
+{
+    uint64_t sig = PLH_CACHE_KEY_GAMUT_LUT;
+    plh_hash_merge(&sig, plh_mem_hash(par->function->name, strlen(par->function->name)));
+    plh_hash_merge(&sig, plh_mem_hash(&par->input_gamut, sizeof(par->input_gamut)));
+    plh_hash_merge(&sig, plh_mem_hash(&par->output_gamut, sizeof(par->output_gamut)));
+    plh_hash_merge(&sig, plh_mem_hash(&par->min_luma, sizeof(par->min_luma)));
+    plh_hash_merge(&sig, plh_mem_hash(&par->max_luma, sizeof(par->max_luma)));
+    plh_hash_merge(&sig, plh_mem_hash(&par->constants, sizeof(par->constants)));
+    return sig;
+}
+
+static pl_buf make_gamut_lut(pl_shader sh, const struct pl_gamut_map_params *gamut)
+{
+    pl_gpu gpu = SH_GPU(sh);
+    const size_t n = (size_t) gamut->lut_size_I * gamut->lut_size_C * gamut->lut_size_h;
+    const size_t size = n * 4 * sizeof(uint16_t);
+    uint16_t *packed = malloc(size);
+    if (!packed)
+        return NULL;
+    const bool hit = plh_cache_memoize(plh_gpu_cache(gpu), gamut_lut_signature(gamut), packed,
+                                       size, fill_gamut_lut, (void *) gamut);
+    pl_msg(sh->log, PL_LOG_DEBUG, hit ? "Re-using cached gamut LUT (%s)" : "Generated gamut LUT (%s)",
+           gamut->function->name);
+    pl_buf buf = pl_buf_create(gpu, pl_buf_params(.size = size, .storable = true,
+                                                  .initial_data = packed));
     free(packed);
     return buf;
 }
@@ -1034,7 +1062,7 @@ void pl_shader_color_map_ex(pl_shader sh, const struct pl_color_map_params *para
         if (!obj->gamut.valid || !obj->gamut.lut ||
             !pl_gamut_map_params_equal(&gamut, &obj->gamut.params)) {
             pl_buf_destroy(gpu, &obj->gamut.lut);
-            obj->gamut.lut = make_gamut_lut(gpu, &gamut);
+            obj->gamut.lut = make_gamut_lut(sh, &gamut);
             obj->gamut.params = gamut;
             obj->gamut.valid = !!obj->gamut.lut;
         }

@@ -10,6 +10,7 @@
 #include <libplacebo/shaders/dithering.h>
 
 #include "shaders_priv.h"
+#include "cache_priv.h"
 
 const struct pl_dither_params pl_dither_default_params = { PL_DITHER_DEFAULTS };
 
@@ -24,6 +25,11 @@ static void sh_dither_uninit(pl_gpu gpu, void *ptr)
     struct sh_dither_obj *obj = ptr;
     pl_buf_destroy(gpu, &obj->lut);
     memset(obj, 0, sizeof(*obj));
+}
+
+static void fill_blue_noise(void *data, void *priv)
+{
+    pl_generate_blue_noise(data, *(const int *) priv);
 }
 
 // Representative gamma of a transfer curve (approx_gamma, dithering.c:77-107)
@@ -91,7 +97,13 @@ void pl_shader_dither(pl_shader sh, int new_depth, pl_shader_obj *dither_state,
             if (method == PL_DITHER_ORDERED_LUT) {
                 pl_generate_bayer_matrix(mat, lut_size);
             } else {
-                pl_generate_blue_noise(mat, lut_size);
+                // void-and-cluster is O(size^4): memoised (dithering.c:149,158-159)
+                int size_arg = lut_size;
+                const bool hit = plh_cache_memoize(plh_gpu_cache(SH_GPU(sh)),
+                        (PLH_CACHE_KEY_DITHER ^ (uint64_t) method) * (uint64_t) lut_size, mat,
+                        sizeof(float) * lut_size * lut_size, fill_blue_noise, &size_arg);
+                pl_msg(sh->log, PL_LOG_DEBUG, hit ? "Re-using cached dither matrix (%dx%d)"
+                       : "Generated dither matrix (%dx%d)", lut_size, lut_size);
             }
             pl_buf_destroy(SH_GPU(sh), &obj->lut);
             obj->lut = pl_buf_create(SH_GPU(sh), pl_buf_params(
