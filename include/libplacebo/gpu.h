@@ -477,22 +477,22 @@ enum pl_pass_type {
 
 struct pl_pass_params {
     enum pl_pass_type type;
-    struct pl_var *variables;           // must be empty
+    struct pl_var *variables;
     int num_variables;
-    struct pl_desc *descriptors;        // in the order of the op list's binding table
+    struct pl_desc *descriptors;
     int num_descriptors;
-    struct pl_constant *constants;      // must be empty
+    struct pl_constant *constants;
     int num_constants;
     void *constant_data;
-    size_t push_constants_size;         // must be 0
-    const char *glsl_shader;            // "#pl_hip ..." serialised op list, NOT GLSL
-    enum pl_prim_type vertex_type;      // raster members below: ignored / must be empty
+    size_t push_constants_size;
+    const char *glsl_shader;
+    enum pl_prim_type vertex_type;
     struct pl_vertex_attrib *vertex_attribs;
     int num_vertex_attribs;
     size_t vertex_stride;
     const char *vertex_shader;
     pl_fmt target_format;               // raster: format of the targets this pass will write
-    const struct pl_blend_params *blend_params; // must be NULL (blending is an op)
+    const struct pl_blend_params *blend_params;
     bool load_target;
     const uint8_t *cached_program;      // deprecated since v6.322, ignored
     size_t cached_program_len;
@@ -505,10 +505,14 @@ typedef const struct pl_pass_t {
     struct pl_pass_params params;       // deep copy
 } *pl_pass;
 
-// Parses and validates the op list and picks the kernel; no run-time compilation happens,
-// so this is cheap (microseconds). NULL + log message on malformed input.
-//TODO_PASS PL_API pl_pass pl_pass_create(pl_gpu gpu, const struct pl_pass_params *params);
-//TODO_PASS PL_API void pl_pass_destroy(pl_gpu gpu, pl_pass *pass);
+// DEVIATION (INTEGRATION.md "pl_pass"): a pl_pass of the reference is a compiled GLSL program
+// (src/gpu.c:794-888). This backend has no GLSL front-end -- passes are op lists recorded
+// through pl_shader and launched by pl_dispatch_finish / pl_dispatch_compute as precompiled
+// HIP kernels -- so there is nothing pl_pass_create could compile. The entry points exist so
+// that programs written against the reference link unchanged; pl_pass_create logs an error
+// naming the replacement and returns NULL, pl_pass_run reports an error and does nothing.
+PL_API pl_pass pl_pass_create(pl_gpu gpu, const struct pl_pass_params *params);
+PL_API void pl_pass_destroy(pl_gpu gpu, pl_pass *pass);
 
 struct pl_desc_binding {
     const void *object;                 // pl_tex or pl_buf, by descriptor type
@@ -549,7 +553,7 @@ struct pl_pass_run_params {
 
 #define pl_pass_run_params(...) (&(struct pl_pass_run_params) { __VA_ARGS__ })
 
-//TODO_PASS PL_API void pl_pass_run(pl_gpu gpu, const struct pl_pass_run_params *params);
+PL_API void pl_pass_run(pl_gpu gpu, const struct pl_pass_run_params *params);
 
 // Flush queued work to the device / wait for all of it.
 PL_API void pl_gpu_flush(pl_gpu gpu);

@@ -585,11 +585,41 @@ static bool tex_transfer(pl_gpu gpu, const struct pl_tex_transfer_params *params
         return false;
     }
 
+    const char *what = upload ? "upload" : "download";
     const size_t tsz = tex->params.format->texel_size;
     const size_t row_bytes = (size_t) (rc.x1 - rc.x0) * tsz;
     const size_t rows = rc.y1 - rc.y0;
     const size_t host_pitch = PL_DEF(params->row_pitch, row_bytes);
     uint8_t *dev = (uint8_t *) t->ptr + (size_t) rc.y0 * t->pitch + (size_t) rc.x0 * tsz;
+
+    // what the reference's front-end rejects before a backend sees it (src/gpu.c:440-497)
+    if (tex->params.d || rc.z0 || (rc.z1 && rc.z1 != 1)) {
+        pl_msg(gpu->log, PL_LOG_ERR, "pl_tex_%s: 3D textures are not supported", what);
+        return false;
+    }
+    if (host_pitch < row_bytes || host_pitch % PL_DEF(tex->params.format->texel_align, 1)) {
+        pl_msg(gpu->log, PL_LOG_ERR, "pl_tex_%s: row_pitch %zu is below the row size %zu or not "
+               "a multiple of the texel alignment", what, host_pitch, row_bytes);
+        return false;
+    }
+    if (!params->buf == !params->ptr) {
+        pl_msg(gpu->log, PL_LOG_ERR, "pl_tex_%s: exactly one of `buf` and `ptr` must be set", what);
+        return false;
+    }
+    if (params->buf) {
+        pl_buf buf = params->buf;
+        const size_t span = (rows - 1) * host_pitch + row_bytes;   // pl_tex_transfer_size
+        if (params->buf_offset + span < params->buf_offset ||
+            params->buf_offset + span > buf->params.size) {
+            pl_msg(gpu->log, PL_LOG_ERR, "pl_tex_%s: %zu bytes at offset %zu exceed the buffer "
+                   "(%zu bytes)", what, span, params->buf_offset, buf->params.size);
+            return false;
+        }
+        if (!gpu->limits.buf_transfer) {
+            pl_msg(gpu->log, PL_LOG_ERR, "pl_tex_%s: buffer transfers unsupported", what);
+            return false;
+        }
+    }
 
     if (params->timer)
         plh_timer_begin(gpu, params->timer);
@@ -649,8 +679,14 @@ bool pl_tex_poll(pl_gpu gpu, pl_tex tex, uint64_t timeout)
 pl_buf pl_buf_create(pl_gpu gpu, const struct pl_buf_params *params)
 {
     struct gpu_priv *g = GPU_PRIV(gpu);
-    if (!params->size) {
-        pl_msg(gpu->log, PL_LOG_ERR, "pl_buf_create: size must be > 0");
+    if (!params->size || params->size > gpu->limits.max_buf_size) {
+        pl_msg(gpu->log, PL_LOG_ERR, "pl_buf_create: size %zu outside (0, %zu]", params->size,
+               gpu->limits.max_buf_size);
+        return NULL;
+    }
+    if (params->import_handle || params->export_handle) {
+        pl_msg(gpu->log, PL_LOG_ERR, "pl_buf_create: this backend neither imports nor exports "
+               "buffer handles (wrap device memory with pl_hip_wrap instead)");
         return NULL;
     }
     struct buf_priv *b = calloc(1, sizeof(*b));
@@ -696,34 +732,99 @@ void *pl_hip_buf_ptr(pl_buf buf)
     return BUF_PRIV(buf)->ptr;
 }
 
-void pl_buf_write(pl_gpu gpu, pl_buf buf, size_t buf_offset, const void *data, size_t size)
+// Backend half: no validation, used by the library's own tables (which are created without
+// host access flags, as device-only storage).
+void plh_buf_write(pl_gpu gpu, pl_buf buf, size_t buf_offset, const void *data, size_t size)
 {
     struct gpu_priv *g = GPU_PRIV(gpu);
-    if (buf_offset + size > buf->params.size) {
-        pl_msg(gpu->log, PL_LOG_ERR, "pl_buf_write: out of range");
-        return;
-    }
     plh_copy2d_h2d(g->stream, (uint8_t *) BUF_PRIV(buf)->ptr + buf_offset, size, data, size, size, 1);
     plh_stream_sync(g->stream);
 }
 
-bool pl_buf_read(pl_gpu gpu, pl_buf buf, size_t buf_offset, void *dest, size_t size)
+bool plh_buf_read(pl_gpu gpu, pl_buf buf, size_t buf_offset, void *dest, size_t size)
 {
     struct gpu_priv *g = GPU_PRIV(gpu);
-    if (buf_offset + size > buf->params.size) {
-        pl_msg(gpu->log, PL_LOG_ERR, "pl_buf_read: out of range");
-        return false;
-    }
     int err = plh_copy2d_d2h(g->stream, dest, size, (uint8_t *) BUF_PRIV(buf)->ptr + buf_offset,
                              size, size, 1);
     err = err ? err : plh_stream_sync(g->stream);
     return !err;
 }
 
+// Front-end half: the API contract (reference src/gpu.c:662-716). A violation is reported
+// and the call does nothing -- never an out-of-bounds device access.
+static bool buf_range_ok(pl_gpu gpu, const char *fn, pl_buf buf, size_t offset, size_t size)
+{
+    if (offset + size < offset || offset + size > buf->params.size) {
+        pl_msg(gpu->log, PL_LOG_ERR, "%s: %zu bytes at offset %zu exceed the buffer (%zu bytes)%s%s",
+               fn, size, offset, buf->params.size, buf->params.debug_tag ? " for buffer: " : "",
+               buf->params.debug_tag ? buf->params.debug_tag : "");
+        return false;
+    }
+    return true;
+}
+
+void pl_buf_write(pl_gpu gpu, pl_buf buf, size_t buf_offset, const void *data, size_t size)
+{
+    if (!buf->params.host_writable) {
+        pl_msg(gpu->log, PL_LOG_ERR, "pl_buf_write: buffer was not created host_writable");
+        return;
+    }
+    if (buf_offset % 4) {
+        pl_msg(gpu->log, PL_LOG_ERR, "pl_buf_write: offset %zu is not a multiple of 4", buf_offset);
+        return;
+    }
+    if (buf_range_ok(gpu, "pl_buf_write", buf, buf_offset, size))
+        plh_buf_write(gpu, buf, buf_offset, data, size);
+}
+
+bool pl_buf_read(pl_gpu gpu, pl_buf buf, size_t buf_offset, void *dest, size_t size)
+{
+    if (!buf->params.host_readable) {
+        pl_msg(gpu->log, PL_LOG_ERR, "pl_buf_read: buffer was not created host_readable");
+        return false;
+    }
+    return buf_range_ok(gpu, "pl_buf_read", buf, buf_offset, size) &&
+           plh_buf_read(gpu, buf, buf_offset, dest, size);
+}
+
 void pl_buf_copy(pl_gpu gpu, pl_buf dst, size_t dst_offset, pl_buf src, size_t src_offset, size_t size)
 {
+    if (src == dst) {
+        pl_msg(gpu->log, PL_LOG_ERR, "pl_buf_copy: source and destination are the same buffer");
+        return;
+    }
+    if (!buf_range_ok(gpu, "pl_buf_copy (src)", src, src_offset, size) ||
+        !buf_range_ok(gpu, "pl_buf_copy (dst)", dst, dst_offset, size))
+        return;
     plh_copy2d_d2d(GPU_PRIV(gpu)->stream, (uint8_t *) BUF_PRIV(dst)->ptr + dst_offset, size,
                    (uint8_t *) BUF_PRIV(src)->ptr + src_offset, size, size, 1);
+}
+
+/* ------------------------------------------------------------------------ */
+/* pl_pass: present for linking, not a way to run anything (gpu.h) */
+
+pl_pass pl_pass_create(pl_gpu gpu, const struct pl_pass_params *params)
+{
+    (void) params;
+    pl_msg(gpu->log, PL_LOG_ERR, "pl_pass_create: this backend runs precompiled HIP kernels and "
+           "has no GLSL compiler; record the pass with pl_shader_* and run it with "
+           "pl_dispatch_finish / pl_dispatch_compute");
+    return NULL;
+}
+
+void pl_pass_destroy(pl_gpu gpu, pl_pass *pass)
+{
+    (void) gpu;
+    if (pass)
+        *pass = NULL;
+}
+
+void pl_pass_run(pl_gpu gpu, const struct pl_pass_run_params *params)
+{
+    (void) params;
+    pl_msg(gpu->log, PL_LOG_ERR, "pl_pass_run: no pl_pass can exist on this backend "
+           "(pl_pass_create always fails)");
+    GPU_PRIV(gpu)->failed = true;
 }
 
 bool pl_buf_export(pl_gpu gpu, pl_buf buf)

@@ -62,6 +62,9 @@ void plh_timer_begin(pl_gpu gpu, pl_timer t);
 void plh_timer_end(pl_gpu gpu, pl_timer t);
 
 pl_cache plh_gpu_cache(pl_gpu gpu);
+// unvalidated buffer IO for the library's own device-only tables (gpu.c)
+void plh_buf_write(pl_gpu gpu, pl_buf buf, size_t buf_offset, const void *data, size_t size);
+bool plh_buf_read(pl_gpu gpu, pl_buf buf, size_t buf_offset, void *dest, size_t size);
 // runs the installed cross-GPU exchange (if any) on a finished peak measurement
 void plh_gpu_peak_exchange(pl_gpu gpu, void *words, size_t size);
 static inline plh_stream plh_gpu_stream(pl_gpu gpu) { return GPU_PRIV(gpu)->stream; }

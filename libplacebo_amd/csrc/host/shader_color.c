@@ -584,7 +584,7 @@ static void update_peak_buf(pl_gpu gpu, struct sh_color_map_obj *obj, bool force
     plh_gpu_peak_exchange(gpu, pl_hip_buf_ptr(obj->peak.buf), sizeof(struct peak_buf_data));
 
     struct peak_buf_data data = {0};
-    const bool ok = pl_buf_read(gpu, obj->peak.buf, 0, &data, sizeof(data));
+    const bool ok = plh_buf_read(gpu, obj->peak.buf, 0, &data, sizeof(data));
     if (ok && data.frame_wg_count[0] > 0) {
         pl_buf_destroy(gpu, &obj->peak.buf);
     } else {
@@ -718,7 +718,7 @@ bool pl_shader_detect_peak(pl_shader sh, struct pl_color_space csp, pl_shader_ob
         if (!obj->peak.consts)
             return false;
     }
-    pl_buf_write(gpu, obj->peak.consts, 0, consts, sizeof(consts));
+    plh_buf_write(gpu, obj->peak.consts, 0, consts, sizeof(consts));
     op->ptr2 = pl_hip_buf_ptr(obj->peak.consts);
     if (!obj->peak.scratch) {
         const size_t size = (size_t) PLH_PEAK_COPIES * sizeof(struct peak_buf_data);
@@ -1011,7 +1011,7 @@ void pl_shader_color_map_ex(pl_shader sh, const struct pl_color_map_params *para
                         .size = tone.lut_size * sizeof(float), .storable = true,
                         .initial_data = lut));
                 } else {
-                    pl_buf_write(gpu, obj->tone.lut, 0, lut, tone.lut_size * sizeof(float));
+                    plh_buf_write(gpu, obj->tone.lut, 0, lut, tone.lut_size * sizeof(float));
                 }
                 free(lut);
                 obj->tone.lut_size = tone.lut_size;

@@ -637,7 +637,7 @@ static bool polar_pp_build(pl_gpu gpu, pl_log log, struct sh_sampler_obj *obj,
     if (!tmp || !host || !clsx || !clsy || !idx || !idy)
         goto done;
     if (plh_launch_polar_classify(stream, pass, pl_hip_buf_ptr(tmp)) ||
-        !pl_buf_read(gpu, tmp, 0, host, cls_bytes))
+        !plh_buf_read(gpu, tmp, 0, host, cls_bytes))
         goto done;
     const float *colfc = host, *rowfc = host + 2 * W;
     const int32_t *colbase = (const int32_t *) (host + W);
@@ -698,16 +698,16 @@ static bool polar_pp_build(pl_gpu gpu, pl_log log, struct sh_sampler_obj *obj,
     wall = malloc(wall_bytes);
     if (!wbuf || !wall)
         goto done;
-    pl_buf_write(gpu, wbuf, wall_bytes, clsx, ncx * 4);
-    pl_buf_write(gpu, wbuf, wall_bytes + ncx * 4, clsy, ncy * 4);
+    plh_buf_write(gpu, wbuf, wall_bytes, clsx, ncx * 4);
+    plh_buf_write(gpu, wbuf, wall_bytes + ncx * 4, clsy, ncy * 4);
     const float *dcls = (const float *) ((const char *) pl_hip_buf_ptr(wbuf) + wall_bytes);
     if (plh_launch_polar_weights(stream, pass, dcls, ncx, dcls + ncx, ncy, pl_hip_buf_ptr(wbuf)) ||
-        !pl_buf_read(gpu, wbuf, 0, wall, wall_bytes))
+        !plh_buf_read(gpu, wbuf, 0, wall, wall_bytes))
         goto done;
 
     uint32_t *taps_all = malloc(PL_MAX(ntaps, 1) * sizeof(uint32_t));
     int *keep = malloc(PL_MAX(ntaps, 1) * sizeof(int));
-    if (!taps_all || !keep || !pl_buf_read(gpu, obj->taps, 0, taps_all, ntaps * sizeof(uint32_t))) {
+    if (!taps_all || !keep || !plh_buf_read(gpu, obj->taps, 0, taps_all, ntaps * sizeof(uint32_t))) {
         free(taps_all);
         free(keep);
         goto done;
@@ -809,7 +809,7 @@ static bool polar_pp_build(pl_gpu gpu, pl_log log, struct sh_sampler_obj *obj,
         .tilemap = remap ? (const uint32_t *) (d + o_tilemap) : NULL,
     };
     memcpy(blob, pp, sizeof(*pp));
-    pl_buf_write(gpu, obj->pp_blob, 0, blob, off);
+    plh_buf_write(gpu, obj->pp_blob, 0, blob, off);
 
     obj->pp_tile_w = tx.extent;
     obj->pp_tile_h = ty.extent;

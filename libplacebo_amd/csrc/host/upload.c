@@ -211,7 +211,8 @@ bool pl_upload_plane(pl_gpu gpu, struct pl_plane *out_plane, pl_tex *tex,
 
     // non-native byte order: swap every sample into a staging copy
     const size_t word = fmt->texel_size / fmt->num_components;
-    const size_t bytes = pitch * (size_t) (data->height - 1) + (size_t) data->width * fmt->texel_size;
+    const int rows = PL_MAX(data->height, 1);       // 1D planes have height 0
+    const size_t bytes = pitch * (size_t) (rows - 1) + (size_t) data->width * fmt->texel_size;
     uint8_t *tmp = malloc(bytes);
     if (!tmp)
         return false;
@@ -221,7 +222,7 @@ bool pl_upload_plane(pl_gpu gpu, struct pl_plane *out_plane, pl_tex *tex,
         free(tmp);
         return false;
     }
-    for (int y = 0; y < data->height; y++) {
+    for (int y = 0; y < rows; y++) {
         uint8_t *row = tmp + pitch * (size_t) y;
         for (size_t i = 0; i + word <= (size_t) data->width * fmt->texel_size; i += word) {
             for (size_t k = 0; k < word / 2; k++) {

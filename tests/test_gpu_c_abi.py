@@ -58,3 +58,17 @@ def test_c_program_renders_through_the_c_abi(gpu, tmp_path):
     assert np.array_equal(got2, got), (log, log2)
     # both report the reference's struct sizes
     assert "sizeof(pl_frame)=736" in log and "sizeof(pl_frame)=736" in log2, (log, log2)
+
+
+@pytest.mark.parametrize("binary", ["gpu_contract", "gpu_contract_ref"])
+def test_gpu_api_contract_from_c(gpu, binary):
+    """tests/c/gpu_contract.c: buffer / texture round trips and every API misuse the reference's
+    validation front-end rejects (bounds, flags, alignment, overflow) -- compiled against this
+    repository's headers and against the reference's"""
+    exe = os.path.join(BUILD, binary)
+    if not os.path.exists(exe):
+        if binary.endswith("_ref"):
+            pytest.skip("built only where the reference's headers exist")
+        pytest.fail(f"tests/c/build/{binary} missing: run build()")
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0 and r.stdout.strip().endswith("ok"), r.stdout + r.stderr
