@@ -33,6 +33,7 @@ int plh_dev_open(int device, struct plh_dev_info *info);
 int plh_stream_create(int device, plh_stream *out);
 void plh_stream_destroy(plh_stream s);
 int plh_stream_sync(plh_stream s);
+int plh_stream_idle(plh_stream s);   // 1 idle, 0 busy, < 0 error
 
 void *plh_malloc(int device, size_t size);
 void plh_free(void *ptr);
@@ -59,6 +60,9 @@ int plh_event_elapsed_ns(plh_event a, plh_event b, uint64_t *ns);
 
 // fills the whole texture with a constant colour (pl_tex_clear_ex)
 int plh_launch_clear(plh_stream s, const struct plh_view *dst, const float color[4]);
+// k_noise.hip: plane[y * stride + x] = pcg3d(x + x0, y + y0, seed).x for x < w, y < h
+int plh_launch_white_noise(plh_stream s, float *plane, int stride, int w, int h, int x0, int y0,
+                           uint32_t seed);
 
 #ifdef __cplusplus
 }

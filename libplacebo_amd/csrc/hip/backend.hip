@@ -77,6 +77,17 @@ int plh_stream_sync(plh_stream s)
     return 0;
 }
 
+// 1 = everything submitted so far has completed, 0 = still running
+int plh_stream_idle(plh_stream s)
+{
+    const hipError_t r = hipStreamQuery((hipStream_t) s);
+    if (r == hipSuccess)
+        return 1;
+    if (r == hipErrorNotReady)
+        return 0;
+    return -(int) r;
+}
+
 void *plh_malloc(int device, size_t size)
 {
     void *p = NULL;

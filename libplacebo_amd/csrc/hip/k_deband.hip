@@ -22,6 +22,7 @@
  * HBM traffic stays one read + one write of the plane.
  */
 #include "colorops.hiph"
+#include "prng.hiph"
 #include "samplers.hiph"
 
 #define DEBAND_BW 64

@@ -41,6 +41,7 @@ struct pl_dispatch_t {
     void *info_priv;
     struct pass_timing timings[64];
     int num_timings;
+    pl_buf noise;               // white-noise dither plane of the pass being launched
 };
 
 pl_dispatch pl_dispatch_create(pl_log log, pl_gpu gpu)
@@ -60,6 +61,7 @@ void pl_dispatch_destroy(pl_dispatch *ptr)
         return;
     for (int i = 0; i < dp->num_pool; i++)
         pl_shader_free(&dp->pool[i]);
+    pl_buf_destroy(dp->gpu, &dp->noise);
     for (int i = 0; i < dp->num_timings; i++) {
         pl_timer_destroy(dp->gpu, &dp->timings[i].timer);
         pl_shader_info_deref(&dp->timings[i].info.shader);
@@ -210,6 +212,39 @@ static void plh_pass_choose_cells(struct plh_pass *pass)
     }
 }
 
+// PL_DITHER_WHITE_NOISE is recorded as (i1 = 2, i0 = seed). The kernels only know dither
+// matrices: now that the size of the pass is known, evaluate the PRNG for its fragment
+// coordinates into the corner of a power-of-two square and turn the op into a plain LUT
+// dither over it (k_noise.hip says why).
+static bool realize_white_noise(pl_dispatch dp, struct plh_pass *pass)
+{
+    for (int i = 0; i < pass->num_ops; i++) {
+        struct plh_op *op = &pass->ops[i];
+        if (op->kind != PLH_OP_DITHER || op->i1 != 2)
+            continue;
+        int side = 16;
+        while (side < pass->width || side < pass->height)
+            side <<= 1;
+        const size_t size = (size_t) side * side * sizeof(float);
+        if (!dp->noise || dp->noise->params.size < size) {
+            pl_buf_destroy(dp->gpu, &dp->noise);
+            dp->noise = pl_buf_create(dp->gpu, pl_buf_params(.size = size, .storable = true));
+            if (!dp->noise)
+                return false;
+        }
+        if (plh_launch_white_noise(plh_gpu_stream(dp->gpu), pl_hip_buf_ptr(dp->noise), side,
+                                   pass->width, pass->height, pass->frag_x0, pass->frag_y0,
+                                   (uint32_t) op->i0))
+            return false;
+        op->i0 = side;
+        op->i1 = 0;     // LUT
+        op->i2 = 0;     // not rotated
+        op->f[2] = 1.0f / side;
+        op->ptr = pl_hip_buf_ptr(dp->noise);
+    }
+    return true;
+}
+
 bool pl_dispatch_finish(pl_dispatch dp, const struct pl_dispatch_params *params)
 {
     pl_shader sh = *params->shader;
@@ -282,6 +317,10 @@ bool pl_dispatch_finish(pl_dispatch dp, const struct pl_dispatch_params *params)
     if (pass->s.type == PLH_SAMPLE_POLAR && sh->polar_obj)
         plh_polar_pp_setup(dp->gpu, dp->log, sh->polar_obj, pass);
     plh_pass_choose_cells(pass);
+    if (!realize_white_noise(dp, pass)) {
+        pl_msg(dp->log, PL_LOG_ERR, "Failed preparing the white-noise dither plane");
+        goto done;
+    }
 
     struct pass_timing *timing = get_timing(dp, sh);
     pl_timer timer = params->timer ? params->timer : timing ? timing->timer : NULL;
@@ -290,6 +329,8 @@ bool pl_dispatch_finish(pl_dispatch dp, const struct pl_dispatch_params *params)
     const int err = plh_launch_pass(plh_gpu_stream(dp->gpu), pass);
     if (timer)
         plh_timer_end(dp->gpu, timer);
+    if (!err && sh->detect_peak)
+        plh_peak_pass_launched(dp->gpu, sh->peak_state);
     if (err) {
         pl_msg(dp->log, PL_LOG_ERR, "Failed launching pass '%s': %s",
                sh_description(sh), plh_strerror(err));
@@ -355,11 +396,15 @@ bool pl_dispatch_compute(pl_dispatch dp, const struct pl_dispatch_compute_params
         pass->transpose = 0;
         pass->frag_x0 = pass->frag_y0 = 0;
         plh_pass_choose_cells(pass);
+        if (!realize_white_noise(dp, pass))
+            goto done;
         if (timer)
             plh_timer_begin(dp->gpu, timer);
         err = plh_launch_pass(plh_gpu_stream(dp->gpu), pass);
         if (timer)
             plh_timer_end(dp->gpu, timer);
+        if (!err && sh->detect_peak)
+            plh_peak_pass_launched(dp->gpu, sh->peak_state);
     }
 
     if (err) {

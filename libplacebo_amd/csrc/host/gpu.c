@@ -664,13 +664,21 @@ bool pl_tex_download(pl_gpu gpu, const struct pl_tex_transfer_params *params)
     return tex_transfer(gpu, params, false);
 }
 
+// One in-order stream: an object is in use at most for as long as the stream has unfinished
+// work. With a timeout the call waits (any non-zero timeout: a frame is milliseconds).
+static bool stream_busy(pl_gpu gpu, uint64_t timeout)
+{
+    if (timeout) {
+        pl_gpu_finish(gpu);
+        return false;
+    }
+    return plh_stream_idle(GPU_PRIV(gpu)->stream) == 0;
+}
+
 bool pl_tex_poll(pl_gpu gpu, pl_tex tex, uint64_t timeout)
 {
     (void) tex;
-    // single in-order stream: a texture is busy iff the stream is
-    if (timeout)
-        pl_gpu_finish(gpu);
-    return false;
+    return stream_busy(gpu, timeout);
 }
 
 /* ------------------------------------------------------------------------ */
@@ -837,9 +845,7 @@ bool pl_buf_export(pl_gpu gpu, pl_buf buf)
 bool pl_buf_poll(pl_gpu gpu, pl_buf buf, uint64_t timeout)
 {
     (void) buf;
-    if (timeout)
-        pl_gpu_finish(gpu);
-    return false;
+    return stream_busy(gpu, timeout);
 }
 
 /* ------------------------------------------------------------------------ */

@@ -486,12 +486,21 @@ struct sh_color_map_obj {
         bool valid;
     } gamut;
 
+    // Scene brightness measurement. The device side lives for as long as the object does:
+    // one result buffer (rewritten whole by every measuring pass), its pinned host mirror,
+    // the constant block and the kernel's scratch copies -- a frame costs no allocation and
+    // exactly one wait (the read of its result), none when the result may lag a frame.
     struct {
         struct pl_peak_detect_params params;
-        pl_buf buf;         // pending measurement
-        pl_buf consts;      // per-pass constant block of the detect stage
-        pl_buf scratch;     // PLH_PEAK_COPIES zeroed copies of the buffer (k_peak.hip)
-        float avg_pq, max_pq;
+        pl_buf buf;             // 816 words, written by k_peak_fold
+        struct peak_buf_data *mirror;   // pinned
+        plh_event written;      // recorded by the dispatch behind the measuring pass
+        bool awaiting;          // a measuring pass was recorded and its result not yet taken
+        bool launched;          // ... and that pass has been dispatched (`written` is live)
+        pl_buf consts;          // constant block of the detect stage
+        float consts_now[16];   // what `consts` holds
+        pl_buf scratch;         // PLH_PEAK_COPIES zeroed copies of the buffer (k_peak.hip)
+        float avg_pq, max_pq;   // the filtered state
     } peak;
 };
 
@@ -503,6 +512,8 @@ static void sh_color_map_uninit(pl_gpu gpu, void *ptr)
     pl_buf_destroy(gpu, &obj->peak.buf);
     pl_buf_destroy(gpu, &obj->peak.consts);
     pl_buf_destroy(gpu, &obj->peak.scratch);
+    plh_event_destroy(obj->peak.written);
+    plh_host_free(obj->peak.mirror);
     memset(obj, 0, sizeof(*obj));
 }
 
@@ -525,125 +536,149 @@ static inline float smoothstepf(float edge0, float edge1, float x)
     return x * x * (3.0f - 2.0f * x);
 }
 
-// Frame peak from the max / the percentile of the 64-bin histogram
-static float measure_peak(const struct peak_buf_data *data, float percentile)
+// ---- host side of the measurement: fetch -> totals -> one sample -> temporal filter ----------
+// (what the reference does in update_peak_buf / measure_peak, src/shaders/colorspace.c:
+// 1003-1150; the arithmetic of every step is the reference's, float for float)
+
+// The kernel spreads its atomics over SLICES partial results; everything below works on sums.
+struct peak_totals {
+    uint64_t groups, lit_groups;    // workgroups that ran / that saw a non-black pixel
+    uint64_t sum_pq;                // sum over lit groups of their mean PQ code
+    unsigned max_pq;
+    uint64_t hist[HIST_BINS], hist_n;
+};
+
+static void peak_totals_of(const struct peak_buf_data *raw, struct peak_totals *t)
 {
-    unsigned frame_max_pq = data->frame_max_pq[0];
-    for (int k = 1; k < SLICES; k++)
-        frame_max_pq = PL_MAX(frame_max_pq, data->frame_max_pq[k]);
-    const float frame_max = (float) frame_max_pq / PQ_MAX;
-    if (percentile <= 0 || percentile >= 100)
-        return frame_max;
-
-    unsigned total_pixels = 0;
+    memset(t, 0, sizeof(*t));
     for (int k = 0; k < SLICES; k++) {
-        for (int i = 0; i < HIST_BINS; i++)
-            total_pixels += data->frame_hist[k][i];
+        t->groups     += raw->frame_wg_count[k];
+        t->lit_groups += raw->frame_wg_active[k];
+        t->sum_pq     += raw->frame_sum_pq[k];
+        t->max_pq      = PL_MAX(t->max_pq, raw->frame_max_pq[k]);
+        for (int b = 0; b < HIST_BINS; b++)
+            t->hist[b] += raw->frame_hist[k][b];
     }
-    if (!total_pixels)
-        return frame_max;
-
-    const unsigned target_pixel = ceilf(percentile / 100.0f * total_pixels);
-    if (target_pixel >= total_pixels)
-        return frame_max;
-
-    unsigned sum = 0;
-    for (int i = 0; i < HIST_BINS; i++) {
-        unsigned next = sum;
-        for (int k = 0; k < SLICES; k++)
-            next += data->frame_hist[k][i];
-        if (next < target_pixel) {
-            sum = next;
-            continue;
-        }
-
-        // interpolate inside the bin that contains the target pixel
-        const unsigned count_low  = sum;
-        const unsigned count_high = next + 1;
-        const float pq_low = (float) HIST_PQ(i) / PQ_MAX;
-        float pq_high      = (float) HIST_PQ(i + 1) / PQ_MAX;
-        if (count_high > total_pixels)
-            pq_high = frame_max; // last occupied bin
-        const float ratio = (float) (target_pixel - count_low) / (count_high - count_low);
-        return MIXF(pq_low, pq_high, ratio);
-    }
-
-    return frame_max; // unreachable
+    for (int b = 0; b < HIST_BINS; b++)
+        t->hist_n += t->hist[b];
 }
 
-// Read the pending measurement (if any) and fold it into the smoothed state
-static void update_peak_buf(pl_gpu gpu, struct sh_color_map_obj *obj, bool force)
+// PQ level below which `percentile` percent of the histogrammed pixels lie; the frame maximum
+// where the histogram cannot tell (none collected, 0 / 100 %, or the rank is the last pixel).
+static float peak_percentile(const struct peak_totals *t, float percentile)
+{
+    const float top = (float) t->max_pq / PQ_MAX;
+    if (percentile <= 0 || percentile >= 100 || !t->hist_n)
+        return top;
+    const uint64_t rank = ceilf(percentile / 100.0f * t->hist_n);
+    if (rank >= t->hist_n)
+        return top;
+
+    uint64_t below = 0;     // pixels in the bins before `b`
+    int b = 0;
+    while (b < HIST_BINS - 1 && below + t->hist[b] < rank)
+        below += t->hist[b++];
+    // pixels assumed evenly spread inside the bin, between the last pixel of the bin before
+    // and the first pixel of the bin after; the topmost occupied bin ends at the maximum
+    const uint64_t above = below + t->hist[b] + 1;
+    const float lo = (float) HIST_PQ(b) / PQ_MAX;
+    const float hi = above > t->hist_n ? top : (float) HIST_PQ(b + 1) / PQ_MAX;
+    const float where = (float) (rank - below) / (above - below);
+    return MIXF(lo, hi, where);
+}
+
+struct peak_sample { float avg_pq, max_pq, lit; };
+
+static struct peak_sample peak_sample_of(const struct peak_totals *t, float percentile)
+{
+    if (!t->lit_groups)    // solid black frame
+        return (struct peak_sample) { PL_COLOR_HDR_BLACK, PL_COLOR_HDR_BLACK, 0.0f };
+    return (struct peak_sample) {
+        .avg_pq = (float) t->sum_pq / (t->lit_groups * PQ_MAX),
+        .max_pq = peak_percentile(t, percentile),
+        .lit    = (float) t->lit_groups / t->groups,
+    };
+}
+
+// first-order low-pass with a scene-change bypass, on avg and max alike
+static void peak_filter(float *avg_pq, float *max_pq, struct peak_sample in,
+                        const struct pl_peak_detect_params *params)
+{
+    if (!*avg_pq) {
+        *avg_pq = in.avg_pq;    // first sample: adopt
+        *max_pq = in.max_pq;
+    } else {
+        // a change below one PQ code is measurement jitter
+        const float lsb = 1.0f / PQ_MAX;
+        if (fabsf(in.avg_pq - *avg_pq) < lsb)
+            in.avg_pq = *avg_pq;
+        if (fabsf(in.max_pq - *max_pq) < lsb)
+            in.max_pq = *max_pq;
+    }
+
+    const float gain = params->smoothing_period ? 1.0f - expf(-1.0f / params->smoothing_period)
+                                                : 1.0f;
+    *avg_pq += gain * (in.avg_pq - *avg_pq);
+    *max_pq += gain * (in.max_pq - *max_pq);
+
+    if (params->scene_threshold_low > 0 && params->scene_threshold_high > 0) {
+        // thresholds are in units of 1 % PQ; the jump is weighted by how much of the frame is lit
+        const float unit = 1e-2f;
+        const float jump = in.lit * fabsf(in.avg_pq - *avg_pq);
+        const float snap = smoothstepf(params->scene_threshold_low * unit,
+                                       params->scene_threshold_high * unit, jump);
+        *avg_pq = MIXF(*avg_pq, in.avg_pq, snap);
+        *max_pq = MIXF(*max_pq, in.max_pq, snap);
+    }
+}
+
+// Take the outstanding measurement, if there is one and it may be taken now.
+// `must`: the caller is about to reuse the buffer -- wait for the pass rather than give up.
+static void peak_collect(pl_gpu gpu, struct sh_color_map_obj *obj, bool must)
 {
     const struct pl_peak_detect_params *params = &obj->peak.params;
-    if (!obj->peak.buf)
+    if (!obj->peak.awaiting)
         return;
-    if (!force && params->allow_delayed && pl_buf_poll(gpu, obj->peak.buf, 0))
-        return;
-
-    // ranks rendering one scene fold their measurements together first (hip.h)
-    plh_gpu_peak_exchange(gpu, pl_hip_buf_ptr(obj->peak.buf), sizeof(struct peak_buf_data));
-
-    struct peak_buf_data data = {0};
-    const bool ok = plh_buf_read(gpu, obj->peak.buf, 0, &data, sizeof(data));
-    if (ok && data.frame_wg_count[0] > 0) {
-        pl_buf_destroy(gpu, &obj->peak.buf);
-    } else {
-        if (!ok) {
-            pl_msg(gpu->log, PL_LOG_ERR, "Failed reading peak detection buffer!");
+    if (!obj->peak.launched) {
+        // recorded, never dispatched: either abandoned (`must`), or the caller asks for the
+        // result from inside the very shader that measures
+        if (must) {
+            obj->peak.awaiting = false;
         } else if (!params->allow_delayed) {
             pl_msg(gpu->log, PL_LOG_WARN, "Peak detection usage error: attempted detecting "
                    "peak and using detected peak in the same shader program, but "
                    "`params->allow_delayed` is false! Ignoring, but expect incorrect output.");
         }
-        if (force || !ok)
-            pl_buf_destroy(gpu, &obj->peak.buf);
+        return;
+    }
+    if (!must && params->allow_delayed && plh_event_query(obj->peak.written) == 0)
+        return;     // still rendering: this frame goes with the previous result
+
+    // ranks rendering one scene fold their measurements together first (hip.h)
+    plh_gpu_peak_exchange(gpu, pl_hip_buf_ptr(obj->peak.buf), sizeof(struct peak_buf_data));
+    obj->peak.awaiting = obj->peak.launched = false;
+    plh_stream stream = plh_gpu_stream(gpu);
+    if (plh_copy2d_d2h(stream, obj->peak.mirror, sizeof(*obj->peak.mirror),
+                       pl_hip_buf_ptr(obj->peak.buf), sizeof(*obj->peak.mirror),
+                       sizeof(*obj->peak.mirror), 1) || plh_stream_sync(stream)) {
+        pl_msg(gpu->log, PL_LOG_ERR, "Failed reading peak detection buffer!");
         return;
     }
 
-    uint64_t frame_sum_pq = 0u, frame_wg_count = 0u, frame_wg_active = 0u;
-    for (int k = 0; k < SLICES; k++) {
-        frame_sum_pq    += data.frame_sum_pq[k];
-        frame_wg_count  += data.frame_wg_count[k];
-        frame_wg_active += data.frame_wg_active[k];
-    }
+    struct peak_totals totals;
+    peak_totals_of(obj->peak.mirror, &totals);
+    if (!totals.groups)
+        return;     // an empty launch measured nothing
+    peak_filter(&obj->peak.avg_pq, &obj->peak.max_pq,
+                peak_sample_of(&totals, params->percentile), params);
+}
 
-    float avg_pq, max_pq;
-    if (frame_wg_active) {
-        avg_pq = (float) frame_sum_pq / (frame_wg_active * PQ_MAX);
-        max_pq = measure_peak(&data, params->percentile);
-    } else {
-        avg_pq = max_pq = PL_COLOR_HDR_BLACK; // solid black frame
-    }
-
-    if (!obj->peak.avg_pq) {
-        obj->peak.avg_pq = avg_pq;
-        obj->peak.max_pq = max_pq;
-    } else {
-        // ignore sub-LSB jitter
-        static const float epsilon = 1.0f / PQ_MAX;
-        if (fabsf(avg_pq - obj->peak.avg_pq) < epsilon)
-            avg_pq = obj->peak.avg_pq;
-        if (fabsf(max_pq - obj->peak.max_pq) < epsilon)
-            max_pq = obj->peak.max_pq;
-    }
-
-    // IIR low-pass
-    const float coeff = params->smoothing_period ? 1.0f - expf(-1.0f / params->smoothing_period)
-                                                 : 1.0f;
-    obj->peak.avg_pq += coeff * (avg_pq - obj->peak.avg_pq);
-    obj->peak.max_pq += coeff * (max_pq - obj->peak.max_pq);
-
-    // scene change: snap towards the new measurement
-    if (params->scene_threshold_low > 0 && params->scene_threshold_high > 0) {
-        const float log10_pq = 1e-2f;
-        const float thresh_low = params->scene_threshold_low * log10_pq;
-        const float thresh_high = params->scene_threshold_high * log10_pq;
-        const float bias = (float) frame_wg_active / frame_wg_count;
-        const float delta = bias * fabsf(avg_pq - obj->peak.avg_pq);
-        const float mix_coeff = smoothstepf(thresh_low, thresh_high, delta);
-        obj->peak.avg_pq = MIXF(obj->peak.avg_pq, avg_pq, mix_coeff);
-        obj->peak.max_pq = MIXF(obj->peak.max_pq, max_pq, mix_coeff);
-    }
+// dispatch.c, behind the launch of a pass that carries a measurement
+void plh_peak_pass_launched(pl_gpu gpu, pl_shader_obj state)
+{
+    struct sh_color_map_obj *obj = state->priv;
+    if (!plh_event_record(obj->peak.written, plh_gpu_stream(gpu)))
+        obj->peak.launched = true;
 }
 
 bool pl_shader_detect_peak(pl_shader sh, struct pl_color_space csp, pl_shader_obj *state,
@@ -679,20 +714,23 @@ bool pl_shader_detect_peak(pl_shader sh, struct pl_color_space csp, pl_shader_ob
         return false;
 
     if (peak_params_eq(&obj->peak.params, params)) {
-        update_peak_buf(gpu, obj, true); // consume the previous frame first
+        peak_collect(gpu, obj, true);   // the previous frame's result, before its buffer is reused
     } else {
         pl_reset_detected_peak(*state);
     }
 
-    static const struct peak_buf_data zero = {0};
-    obj->peak.buf = pl_buf_create(gpu, pl_buf_params(
-        .size = sizeof(struct peak_buf_data), .host_readable = true, .storable = true,
-        .initial_data = &zero));
     if (!obj->peak.buf) {
-        SH_FAIL(sh, "Failed creating peak detection SSBO!");
-        return false;
+        obj->peak.buf = pl_buf_create(gpu, pl_buf_params(
+            .size = sizeof(struct peak_buf_data), .host_readable = true, .storable = true));
+        obj->peak.mirror = plh_host_alloc(sizeof(struct peak_buf_data));
+        if (!obj->peak.buf || !obj->peak.mirror || plh_event_create(&obj->peak.written)) {
+            SH_FAIL(sh, "Failed creating peak detection SSBO!");
+            return false;
+        }
     }
     obj->peak.params = *params;
+    obj->peak.awaiting = true;
+    obj->peak.launched = false;
 
     struct plh_op *op = sh_op(sh, PLH_OP_PEAK_DETECT);
     if (!op)
@@ -718,7 +756,10 @@ bool pl_shader_detect_peak(pl_shader sh, struct pl_color_space csp, pl_shader_ob
         if (!obj->peak.consts)
             return false;
     }
-    plh_buf_write(gpu, obj->peak.consts, 0, consts, sizeof(consts));
+    if (memcmp(consts, obj->peak.consts_now, sizeof(consts))) {
+        plh_buf_write(gpu, obj->peak.consts, 0, consts, sizeof(consts));
+        memcpy(obj->peak.consts_now, consts, sizeof(consts));
+    }
     op->ptr2 = pl_hip_buf_ptr(obj->peak.consts);
     if (!obj->peak.scratch) {
         const size_t size = (size_t) PLH_PEAK_COPIES * sizeof(struct peak_buf_data);
@@ -732,6 +773,7 @@ bool pl_shader_detect_peak(pl_shader sh, struct pl_color_space csp, pl_shader_ob
     sh->pass.peak_buf = pl_hip_buf_ptr(obj->peak.buf);
     sh->pass.peak_scratch = pl_hip_buf_ptr(obj->peak.scratch);
     sh->detect_peak = true;
+    sh->peak_state = *state;    // (held below: outlives the shader's dispatch)
     sh_hold(sh, *state);
 
     sh_describef(sh, "peak detection");
@@ -746,7 +788,7 @@ bool pl_get_detected_hdr_metadata(const pl_shader_obj state, struct pl_hdr_metad
         return false;
 
     struct sh_color_map_obj *obj = state->priv;
-    update_peak_buf(state->gpu, obj, false);
+    peak_collect(state->gpu, obj, false);
     if (!obj->peak.avg_pq)
         return false;
 
@@ -761,11 +803,10 @@ void pl_reset_detected_peak(pl_shader_obj state)
         return;
 
     struct sh_color_map_obj *obj = state->priv;
-    pl_buf consts = obj->peak.consts, scratch = obj->peak.scratch;
-    pl_buf_destroy(state->gpu, &obj->peak.buf);
-    memset(&obj->peak, 0, sizeof(obj->peak));
-    obj->peak.consts = consts;
-    obj->peak.scratch = scratch;
+    // the filter state and the request go, the device objects stay
+    memset(&obj->peak.params, 0, sizeof(obj->peak.params));
+    obj->peak.awaiting = obj->peak.launched = false;
+    obj->peak.avg_pq = obj->peak.max_pq = 0.0f;
 }
 
 void *pl_hip_peak_buffer(const pl_shader_obj state, size_t *out_size)
@@ -773,7 +814,7 @@ void *pl_hip_peak_buffer(const pl_shader_obj state, size_t *out_size)
     if (!state || state->type != PL_SHADER_OBJ_COLOR_MAP)
         return NULL;
     struct sh_color_map_obj *obj = state->priv;
-    if (!obj->peak.buf)
+    if (!obj->peak.buf || !obj->peak.awaiting)
         return NULL;
     if (out_size)
         *out_size = sizeof(struct peak_buf_data);

@@ -51,8 +51,10 @@ struct pl_shader_t {
     // persistent objects whose device memory the recorded pass points at
     pl_shader_obj held[16];
     int num_held;
-    // peak detection request (K10), resolved by dispatch
+    // the pass carries a brightness measurement for `peak_state` (shader_color.c); the
+    // dispatch reports its launch through plh_peak_pass_launched
     bool detect_peak;
+    pl_shader_obj peak_state;
 
     char steps[12][96];         // one name per recorded stage (sh_describef)
     int num_steps;
@@ -82,6 +84,8 @@ bool plh_shader_sample_polar_fused(pl_shader sh, const pl_shader pre,
 
 // called by the dispatch once the target geometry of a POLAR pass is known
 void plh_polar_pp_setup(pl_gpu gpu, pl_log log, void *polar_obj, struct plh_pass *pass);
+
+void plh_peak_pass_launched(pl_gpu gpu, pl_shader_obj state);
 
 #define SH_GPU(sh) ((sh)->params.gpu)
 

@@ -391,3 +391,71 @@ def test_cone_distort_normal_is_noop(gpu):
     src = ramp()
     got = run_ops(gpu, src, lambda sh: sh.cone_distort(csp, pl.cone_params("normal")))
     assert np.array_equal(got, src)
+
+
+def test_peak_result_timing_and_state_lifecycle(gpu):
+    """pl_peak_detect_params.allow_delayed and the life cycle of the measurement
+    (src/shaders/colorspace.c:1041-1150):
+      * asking for the result inside the shader that measures: a usage error unless
+        allow_delayed (then: silently the previous result);
+      * a recorded-but-never-dispatched measurement is abandoned by the next one;
+      * consecutive frames are low-passed (smoothing_period), a scene cut snaps;
+      * pl_reset_detected_peak forgets the result, the next frame starts over."""
+    w, h = 64, 48
+    dim = hdr_test_frame(w, h) * np.float32(0.5)
+    bright = np.clip(hdr_test_frame(w, h) * np.float32(1.15), 0, 1)
+    for im in (dim, bright):
+        im[..., 3] = 1
+    csp = pl.color_space("bt2020", "pq")
+    t_dim, t_bright = gpu.tex_create(w, h, "rgba32f", dim), gpu.tex_create(w, h, "rgba32f", bright)
+    state = pl.ShaderObj()
+    hdr = capi.HdrMetadata()
+    get = lambda: bool(pl.lib().pl_get_detected_hdr_metadata(state.slot, C.byref(hdr)))
+
+    def measure(tex, dispatch=True, **kw):
+        sh = gpu.begin()
+        assert sh.sample("nearest", tex)
+        assert sh.detect_peak(csp, state, **kw)
+        return sh if not dispatch else sh.compute(w, h)
+
+    # inside the measuring shader, without allow_delayed: warning, no result
+    n_warn = sum("usage error" in m for _, m in gpu.messages)
+    sh = measure(t_dim, dispatch=False, smoothing_period=0.0)
+    assert not get()
+    assert sum("usage error" in m for _, m in gpu.messages) == n_warn + 1
+    assert sh.compute(w, h)
+    assert get()
+    first = (hdr.max_pq_y, hdr.avg_pq_y)
+    assert 0.3 < first[0] < 0.5 and 0.0 < first[1] < first[0]
+
+    # same, with allow_delayed: no warning, the previous result stays in force
+    sh = measure(t_bright, dispatch=False, smoothing_period=0.0, allow_delayed=True)
+    assert get() and (hdr.max_pq_y, hdr.avg_pq_y) == first
+    assert sum("usage error" in m for _, m in gpu.messages) == n_warn + 1
+    sh.abort()
+    # ... and the abandoned measurement does not poison the next one
+    assert measure(t_bright, smoothing_period=0.0, allow_delayed=True)
+    gpu.finish()
+    assert get() and hdr.max_pq_y > first[0] + 0.2
+    bright_peak = hdr.max_pq_y
+
+    # low-pass: period 20 moves 1 - exp(-1/20) of the way per frame (below the scene-cut
+    # thresholds when they are disabled)
+    assert measure(t_dim, smoothing_period=0.0, scene_threshold_low=0.0, scene_threshold_high=0.0)
+    assert get()
+    lo = hdr.max_pq_y
+    assert abs(lo - first[0]) < 1e-6
+    kw = dict(smoothing_period=20.0, scene_threshold_low=0.0, scene_threshold_high=0.0)
+    pl.lib().pl_reset_detected_peak(state.slot)
+    assert not get()
+    assert measure(t_dim, **kw) and get() and abs(hdr.max_pq_y - lo) < 1e-6     # first sample: adopted
+    assert measure(t_bright, **kw) and get()
+    step = 1.0 - np.exp(-1.0 / 20.0)
+    assert abs(hdr.max_pq_y - (lo + step * (bright_peak - lo))) < 1e-5
+    # with the default thresholds the same jump is a scene cut: snaps (almost) all the way
+    pl.lib().pl_reset_detected_peak(state.slot)
+    kw = dict(smoothing_period=20.0)
+    assert measure(t_dim, **kw) and get()
+    assert measure(t_bright, **kw) and get()
+    assert abs(hdr.max_pq_y - bright_peak) < 1e-3
+    state.destroy(); t_dim.destroy(); t_bright.destroy()

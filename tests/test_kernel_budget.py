@@ -1,0 +1,63 @@
+"""Register budgets of the tuned kernels, from the compiler's own resource report
+(libplacebo_amd/csrc/Makefile keeps it next to every object as build/hip_*.usage).
+
+These kernels are latency-bound on occupancy: the polar kernel runs 240 us at 3 waves per SIMD
+with the colour interpreter and 313 us at 2, and it sits 5 VGPRs below that cliff. A three-line
+case added to a shared header (dither_bias) once moved it over without any test noticing --
+this is the test that notices. No kernel may spill."""
+import glob
+import os
+import re
+import subprocess
+
+import pytest
+
+BUILD = os.path.join(os.path.dirname(__file__), "..", "libplacebo_amd", "csrc", "build")
+
+
+@pytest.fixture(scope="module")
+def usage(built):
+    recs = {}
+    files = glob.glob(os.path.join(BUILD, "hip_*.usage"))
+    assert files, "no build/hip_*.usage files: run build()"
+    for f in files:
+        found = re.findall(r"Function Name: (\S+)\nVGPRs: (\d+)\nScratchSize \[bytes/lane\]: (\d+)\n"
+                           r"Occupancy \[waves/SIMD\]: (\d+)", open(f).read())
+        names = subprocess.run(["c++filt"] + [n for n, *_ in found], capture_output=True,
+                               text=True).stdout.split("\n")
+        for (_, vgpr, scratch, occ), name in zip(found, names):
+            recs[name.replace("void ", "").replace("(plh_pass)", "")] = (int(vgpr), int(scratch), int(occ))
+    return recs
+
+
+def test_no_kernel_spills(usage):
+    spilling = {k: v for k, v in usage.items() if v[1]}
+    assert not spilling, spilling
+
+
+# (pattern, minimum waves per SIMD)
+BUDGET = [
+    # LITE polar variants on the f16 tile (scaler + dither: BASELINE configs[2]): 4 waves
+    (r"k_polar_pp<__half, (7|15)u, [12], true, (true|false)>", 4),
+    (r"k_polar_pp<__half, (1|3)u, [12], true, (true|false)>", 4),
+    # with the full colour interpreter (the metric's EWA + tone-map launch): 3 waves
+    (r"k_polar_pp<__half, \d+u, [12], false, false>", 3),
+    (r"k_polar_pp<float, \d+u, 1, false, false>", 3),
+    (r"k_bilinear_fast<(true|false), 4>", 4),
+    (r"k_nearest_fast<(true|false)>", 8),
+    (r"k_pass_generic<.*>", 4),
+    (r"k_pass_peak<true>", 4),
+    (r"k_pass_peak<false>", 3),
+    (r"k_deband<true>", 8),
+    (r"k_deband<false>", 5),
+    (r"k_ortho_fast<\d, 0, [01], (4|6), false>", 7),
+    (r"k_polar<.*>", 5),
+]
+
+
+@pytest.mark.parametrize("pattern,min_occ", BUDGET)
+def test_occupancy_budget(usage, pattern, min_occ):
+    hit = {k: v for k, v in usage.items() if re.fullmatch(pattern, k)}
+    assert hit, f"no kernel matches {pattern}: {sorted(usage)[:5]}..."
+    low = {k: v for k, v in hit.items() if v[2] < min_occ}
+    assert not low, f"below {min_occ} waves/SIMD (vgpr, scratch, occupancy): {low}"
