@@ -20,6 +20,12 @@
  * Launch shape: 64x4 lanes, one pixel per lane. 4*iterations + 1 data-dependent
  * 8..16-byte gathers per pixel within `radius` texels of it: served by L2/MALL,
  * HBM traffic stays one read + one write of the plane.
+ *
+ * The kernel is VALU-bound, not gather-bound (8K plane + PQ linearize: 408 VALU instructions
+ * per pixel, VALU busy 86 % of the 487 us; profiles/r02_*). Tried and dropped: a 64x16 block
+ * staging its texels + a 17-texel halo in LDS (38 KiB) and gathering from there, four pixels
+ * per lane sharing one walk through the op interpreter -- 652 us: the window bookkeeping costs
+ * more VALU than the gathers cost anything, and occupancy drops from 5 to 4 waves.
  */
 #include "colorops.hiph"
 #include "prng.hiph"
