@@ -122,27 +122,26 @@ enum pl_color_levels pl_color_levels_guess(const struct pl_color_repr *repr)
 float pl_color_repr_normalize(struct pl_color_repr *repr)
 {
     struct pl_bit_encoding *bits = &repr->bits;
-    float scale = 1.0;
+    // depth of the stored samples / of the colour values in them; either stands in for the
+    // other when unset, 8 bits when both are
+    int stored = bits->sample_depth ? bits->sample_depth : bits->color_depth;
+    int coded  = bits->color_depth ? bits->color_depth : bits->sample_depth;
+    if (!stored)
+        stored = coded = 8;
+    const bool limited = pl_color_levels_guess(repr) == PL_COLOR_LEVELS_LIMITED;
 
-    // undo a representational left shift
-    if (bits->bit_shift) {
-        scale /= (1LL << bits->bit_shift);
-        bits->bit_shift = 0;
-    }
-
-    int tex_bits = PL_DEF(bits->sample_depth, bits->color_depth);
-    int col_bits = PL_DEF(bits->color_depth, bits->sample_depth);
-    if (!tex_bits)
-        tex_bits = col_bits = 8;
-
-    if (pl_color_levels_guess(repr) == PL_COLOR_LEVELS_LIMITED) {
-        // limited range is padded with zero bits: pure shift
-        scale *= (float) (1LL << tex_bits) / (1LL << col_bits);
+    // a representational left shift is undone by a power of two (exact in float) ...
+    float scale = ldexpf(1.0f, -bits->bit_shift);
+    if (limited) {
+        // ... so is limited range, which pads with zero bits
+        scale = ldexpf(scale, stored - coded);
     } else {
-        // full range spans the whole code range at either depth
-        scale *= ((1LL << tex_bits) - 1.) / ((1LL << col_bits) - 1.);
+        // full range spans all codes at either depth: (2^stored - 1) / (2^coded - 1), in double
+        const double top_stored = (double) ((1LL << stored) - 1), top_coded = (double) ((1LL << coded) - 1);
+        scale = (float) (scale * (top_stored / top_coded));
     }
 
+    bits->bit_shift = 0;
     bits->color_depth = bits->sample_depth;
     return scale;
 }
@@ -193,12 +192,18 @@ const char *pl_color_primaries_name(enum pl_color_primaries prim)
 
 enum pl_color_primaries pl_color_primaries_guess(int width, int height)
 {
-    if (width >= 1280 || height > 576)
-        return PL_COLOR_PRIM_BT_709;
-    if (height == 576)
-        return PL_COLOR_PRIM_BT_601_625;
-    if (height == 480 || height == 486)
-        return PL_COLOR_PRIM_BT_601_525;
+    // standard-definition rasters, by their line count; anything else (and anything at least
+    // 1280 wide or taller than PAL) is assumed to be BT.709
+    static const struct { int lines; enum pl_color_primaries prim; } sd[] = {
+        { 576, PL_COLOR_PRIM_BT_601_625 },
+        { 480, PL_COLOR_PRIM_BT_601_525 },
+        { 486, PL_COLOR_PRIM_BT_601_525 },
+    };
+    const bool hd = width >= 1280 || height > 576;
+    for (size_t i = 0; !hd && i < PL_ARRAY_SIZE(sd); i++) {
+        if (height == sd[i].lines)
+            return sd[i].prim;
+    }
     return PL_COLOR_PRIM_BT_709;
 }
 
@@ -584,67 +589,82 @@ static void luma_from_maxrgb(const struct pl_color_space *csp, enum pl_hdr_scali
     *out_avg = pl_hdr_rescale(PL_HDR_NITS, scaling, coef * csp->hdr.scene_avg);
 }
 
+// The nominal range of a colour space is assembled from up to three kinds of metadata, in
+// increasing order of authority, then sanitised and completed from the transfer function.
+struct luma_range { float min, max, avg; };
+
+static bool md_selected(enum pl_hdr_metadata_type asked, enum pl_hdr_metadata_type kind)
+{
+    return asked == PL_HDR_METADATA_ANY || asked == kind;
+}
+
+static void range_from_metadata(const struct pl_nominal_luma_params *params, struct luma_range *r)
+{
+    const struct pl_hdr_metadata *hdr = &params->color->hdr;
+    const enum pl_hdr_scaling to = params->scaling;
+    if (params->metadata == PL_HDR_METADATA_NONE)
+        return;
+
+    // static mastering display metadata (any selection includes it); MaxCLL stands in for
+    // a missing peak
+    r->min = pl_hdr_rescale(PL_HDR_NITS, to, hdr->min_luma);
+    r->max = pl_hdr_rescale(PL_HDR_NITS, to, hdr->max_luma);
+    if (!r->max && hdr->max_cll)
+        r->max = pl_hdr_rescale(PL_HDR_NITS, to, hdr->max_cll);
+
+    if (md_selected(params->metadata, PL_HDR_METADATA_HDR10PLUS) &&
+        pl_hdr_metadata_contains(hdr, PL_HDR_METADATA_HDR10PLUS))
+        luma_from_maxrgb(params->color, to, &r->max, &r->avg);
+
+    if (md_selected(params->metadata, PL_HDR_METADATA_CIE_Y) &&
+        pl_hdr_metadata_contains(hdr, PL_HDR_METADATA_CIE_Y)) {
+        r->max = pl_hdr_rescale(PL_HDR_PQ, to, hdr->max_pq_y);
+        r->avg = pl_hdr_rescale(PL_HDR_PQ, to, hdr->avg_pq_y);
+    }
+}
+
 void pl_color_space_nominal_luma_ex(const struct pl_nominal_luma_params *params)
 {
     if (!params || (!params->out_min && !params->out_max && !params->out_avg))
         return;
 
-    const struct pl_color_space *csp = params->color;
-    const enum pl_hdr_scaling scaling = params->scaling;
-    const enum pl_hdr_metadata_type md = params->metadata;
-    float min_luma = 0, max_luma = 0, avg_luma = 0;
+    const enum pl_color_transfer trc = params->color->transfer;
+    const enum pl_hdr_scaling to = params->scaling;
+    struct luma_range r = {0};
+    range_from_metadata(params, &r);
 
-    if (md != PL_HDR_METADATA_NONE) {
-        // static HDR10 mastering metadata, MaxCLL as a fallback for the peak
-        min_luma = pl_hdr_rescale(PL_HDR_NITS, scaling, csp->hdr.min_luma);
-        max_luma = pl_hdr_rescale(PL_HDR_NITS, scaling, csp->hdr.max_luma);
-        if (!max_luma && csp->hdr.max_cll)
-            max_luma = pl_hdr_rescale(PL_HDR_NITS, scaling, csp->hdr.max_cll);
+    // whatever was tagged must lie inside what PQ can express, and be a range
+    const float floor_ = pl_hdr_rescale(PL_HDR_NITS, to, PL_COLOR_HDR_BLACK);
+    const float ceil_  = pl_hdr_rescale(PL_HDR_PQ, to, 1.0f);
+    if (r.max)
+        r.max = PL_CLAMP(r.max, floor_, ceil_);
+    if (r.min)
+        r.min = PL_CLAMP(r.min, floor_, ceil_);
+    const bool inverted = r.max && r.min >= r.max;
+    if (inverted || r.min >= ceil_)
+        r.min = r.max = 0;
+
+    // the rest follows from the transfer function
+    if (!r.max) {
+        r.max = trc == PL_COLOR_TRC_HLG
+              ? pl_hdr_rescale(PL_HDR_NITS, to, PL_COLOR_HLG_PEAK)
+              : pl_hdr_rescale(PL_HDR_NORM, to, pl_color_transfer_nominal_peak(trc));
     }
-
-    if ((md == PL_HDR_METADATA_ANY || md == PL_HDR_METADATA_HDR10PLUS) &&
-        pl_hdr_metadata_contains(&csp->hdr, PL_HDR_METADATA_HDR10PLUS))
-        luma_from_maxrgb(csp, scaling, &max_luma, &avg_luma);
-
-    if ((md == PL_HDR_METADATA_ANY || md == PL_HDR_METADATA_CIE_Y) &&
-        pl_hdr_metadata_contains(&csp->hdr, PL_HDR_METADATA_CIE_Y)) {
-        max_luma = pl_hdr_rescale(PL_HDR_PQ, scaling, csp->hdr.max_pq_y);
-        avg_luma = pl_hdr_rescale(PL_HDR_PQ, scaling, csp->hdr.avg_pq_y);
-    }
-
-    // sanitise
-    const float hdr_min = pl_hdr_rescale(PL_HDR_NITS, scaling, PL_COLOR_HDR_BLACK);
-    const float hdr_max = pl_hdr_rescale(PL_HDR_PQ,   scaling, 1.0f);
-    max_luma = max_luma ? PL_CLAMP(max_luma, hdr_min, hdr_max) : 0;
-    min_luma = min_luma ? PL_CLAMP(min_luma, hdr_min, hdr_max) : 0;
-    if ((max_luma && min_luma >= max_luma) || min_luma >= hdr_max)
-        min_luma = max_luma = 0;
-
-    // defaults derived from the transfer function alone
-    if (!max_luma) {
-        if (csp->transfer == PL_COLOR_TRC_HLG) {
-            max_luma = pl_hdr_rescale(PL_HDR_NITS, scaling, PL_COLOR_HLG_PEAK);
+    if (!r.min) {
+        if (pl_color_transfer_is_hdr(trc)) {
+            r.min = floor_;
         } else {
-            const float peak = pl_color_transfer_nominal_peak(csp->transfer);
-            max_luma = pl_hdr_rescale(PL_HDR_NORM, scaling, peak);
+            // SDR: the nominal contrast below the peak
+            const float peak_nits = pl_hdr_rescale(to, PL_HDR_NITS, r.max);
+            r.min = pl_hdr_rescale(PL_HDR_NITS, to, peak_nits / PL_COLOR_SDR_CONTRAST);
         }
     }
+    if (r.avg)
+        r.avg = PL_CLAMP(r.avg, r.min, r.max);
 
-    if (!min_luma) {
-        if (pl_color_transfer_is_hdr(csp->transfer)) {
-            min_luma = hdr_min;
-        } else {
-            const float peak = pl_hdr_rescale(scaling, PL_HDR_NITS, max_luma);
-            min_luma = pl_hdr_rescale(PL_HDR_NITS, scaling, peak / PL_COLOR_SDR_CONTRAST);
-        }
-    }
-
-    if (avg_luma)
-        avg_luma = PL_CLAMP(avg_luma, min_luma, max_luma);
-
-    if (params->out_min) *params->out_min = min_luma;
-    if (params->out_max) *params->out_max = max_luma;
-    if (params->out_avg) *params->out_avg = avg_luma;
+    if (params->out_min) *params->out_min = r.min;
+    if (params->out_max) *params->out_max = r.max;
+    if (params->out_avg) *params->out_avg = r.avg;
 }
 
 void pl_color_space_infer(struct pl_color_space *space)
@@ -664,38 +684,40 @@ void pl_color_space_infer(struct pl_color_space *space)
         space->hdr.prim = *pl_raw_primaries_get(space->primaries);
 }
 
+// Transfer function of a display space left untagged, given the space it is paired with:
+// close-to-2.2 curves are adopted as they are (no needless small adaptation), HDR and log
+// curves pair with BT.1886 (which models an SDR display's contrast), everything else with a
+// pure power curve (no black crush).
+static enum pl_color_transfer companion_transfer(enum pl_color_transfer ref)
+{
+    static const enum pl_color_transfer pairs[][2] = {
+        { PL_COLOR_TRC_BT_1886,   PL_COLOR_TRC_BT_1886 },
+        { PL_COLOR_TRC_SRGB,      PL_COLOR_TRC_SRGB },
+        { PL_COLOR_TRC_GAMMA22,   PL_COLOR_TRC_GAMMA22 },
+        { PL_COLOR_TRC_PQ,        PL_COLOR_TRC_BT_1886 },
+        { PL_COLOR_TRC_HLG,       PL_COLOR_TRC_BT_1886 },
+        { PL_COLOR_TRC_V_LOG,     PL_COLOR_TRC_BT_1886 },
+        { PL_COLOR_TRC_S_LOG1,    PL_COLOR_TRC_BT_1886 },
+        { PL_COLOR_TRC_S_LOG2,    PL_COLOR_TRC_BT_1886 },
+        { PL_COLOR_TRC_PRO_PHOTO, PL_COLOR_TRC_SRGB },
+    };
+    for (size_t i = 0; i < PL_ARRAY_SIZE(pairs); i++) {
+        if (pairs[i][0] == ref)
+            return pairs[i][1];
+    }
+    return PL_COLOR_TRC_GAMMA22;
+}
+
 static void infer_both_ref(struct pl_color_space *space, struct pl_color_space *ref)
 {
     pl_color_space_infer(ref);
-
     if (!space->primaries) {
-        space->primaries = pl_color_primaries_is_wide_gamut(ref->primaries)
-                         ? PL_COLOR_PRIM_BT_709 : ref->primaries;
+        // a wide-gamut partner does not make an untagged space wide-gamut
+        const bool wide = pl_color_primaries_is_wide_gamut(ref->primaries);
+        space->primaries = wide ? PL_COLOR_PRIM_BT_709 : ref->primaries;
     }
-
-    if (!space->transfer) {
-        switch (ref->transfer) {
-        case PL_COLOR_TRC_BT_1886:
-        case PL_COLOR_TRC_SRGB:
-        case PL_COLOR_TRC_GAMMA22:
-            space->transfer = ref->transfer; // avoid needless small adaptations
-            break;
-        case PL_COLOR_TRC_PQ:
-        case PL_COLOR_TRC_HLG:
-        case PL_COLOR_TRC_V_LOG:
-        case PL_COLOR_TRC_S_LOG1:
-        case PL_COLOR_TRC_S_LOG2:
-            space->transfer = PL_COLOR_TRC_BT_1886; // models SDR contrast
-            break;
-        case PL_COLOR_TRC_PRO_PHOTO:
-            space->transfer = PL_COLOR_TRC_SRGB;
-            break;
-        default:
-            space->transfer = PL_COLOR_TRC_GAMMA22; // pure power: no black crush
-            break;
-        }
-    }
-
+    if (!space->transfer)
+        space->transfer = companion_transfer(ref->transfer);
     pl_color_space_infer(space);
 }
 

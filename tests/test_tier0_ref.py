@@ -210,3 +210,66 @@ def test_cone_matrix(libs):
             a = ref.pl_get_cone_matrix(C.byref(cp), ref.pl_raw_primaries_get(p))
             b = our.pl_get_cone_matrix(C.byref(cp), our.pl_raw_primaries_get(p))
             assert bits_equal(m3(a), m3(b)), (p, cones, strength)
+
+
+class NominalLuma(C.Structure):
+    _fields_ = [("color", C.POINTER(Csp)), ("metadata", C.c_int), ("scaling", C.c_int),
+                ("out_min", C.POINTER(C.c_float)), ("out_max", C.POINTER(C.c_float)),
+                ("out_avg", C.POINTER(C.c_float))]
+
+
+def test_colorspace_decision_functions_match_reference_code(libs):
+    """pl_color_primaries_guess, pl_color_repr_normalize, pl_color_space_nominal_luma_ex and the
+    inference pair (src/colorspace.c:70-120, 400-445, 955-1100) are pure decision logic, written
+    here in their own structure: exhaustive / randomised agreement with the reference build"""
+    ref, our = libs
+    for w in (320, 640, 720, 1024, 1279, 1280, 1920, 3840):
+        for h in (240, 480, 486, 487, 576, 577, 720, 1080):
+            assert ref.pl_color_primaries_guess(w, h) == our.pl_color_primaries_guess(w, h)
+
+    for lib in (ref, our):
+        lib.pl_color_repr_normalize.restype = C.c_float
+    for sys_ in range(0, 11):
+        for levels in (0, 1, 2):
+            for sample in (0, 8, 10, 12, 16):
+                for color in (0, 8, 10, 12, 16):
+                    for shift in (0, 2, 4, 6):
+                        ra = Repr(sys=sys_, levels=levels, bits=Bits(sample, color, shift))
+                        rb = Repr(sys=sys_, levels=levels, bits=Bits(sample, color, shift))
+                        a, b = ref.pl_color_repr_normalize(C.byref(ra)), our.pl_color_repr_normalize(C.byref(rb))
+                        assert bits_equal([a], [b]) and bytes(ra) == bytes(rb), (sys_, levels, sample, color, shift)
+
+    rng = np.random.default_rng(5)
+    for it in range(3000):
+        cs = Csp(primaries=int(rng.integers(0, 16)), transfer=int(rng.integers(0, 18)))
+        pick = lambda vals: float(vals[int(rng.integers(0, len(vals)))])
+        cs.hdr.min_luma = pick((0, 0, 1e-7, 0.005, 0.2, 50, 20000))
+        cs.hdr.max_luma = pick((0, 0, 0.1, 100, 203, 1000, 4000, 20000))
+        cs.hdr.max_cll = pick((0, 0, 800, 12000))
+        cs.hdr.scene_avg = pick((0, 0, 40, 200))
+        for k in range(3):
+            cs.hdr.scene_max[k] = pick((0, 300, 900, 5000)) if cs.hdr.scene_avg else 0.0
+        cs.hdr.max_pq_y = pick((0, 0, 0.3, 0.75, 1.2))
+        cs.hdr.avg_pq_y = pick((0, 0.1, 0.4)) if cs.hdr.max_pq_y else 0.0
+        for metadata in range(5):
+            for scaling in range(4):
+                outs = []
+                for lib in (ref, our):
+                    mn, mx, av = C.c_float(-1), C.c_float(-1), C.c_float(-1)
+                    p = NominalLuma(C.pointer(cs), metadata, scaling, C.pointer(mn), C.pointer(mx),
+                                    C.pointer(av) if it % 3 else None)
+                    lib.pl_color_space_nominal_luma_ex(C.byref(p))
+                    outs.append([mn.value, mx.value, av.value])
+                assert bits_equal(*outs), (it, metadata, scaling, outs)
+        # inference: alone, against a reference space, as a mapping pair
+        other = Csp(primaries=int(rng.integers(0, 16)), transfer=int(rng.integers(0, 18)))
+        other.hdr.max_luma = pick((0, 0, 100, 1000))
+        res = []
+        for lib in (ref, our):
+            a, b, c, d = (Csp.from_buffer_copy(x) for x in (cs, other, cs, other))
+            lib.pl_color_space_infer(C.byref(a))
+            e = Csp(primaries=0, transfer=0)
+            lib.pl_color_space_infer_ref(C.byref(e), C.byref(b))
+            lib.pl_color_space_infer_map(C.byref(c), C.byref(d))
+            res.append(bytes(a) + bytes(e) + bytes(c) + bytes(d))
+        assert res[0] == res[1], it
