@@ -495,6 +495,49 @@ def config_block(device, workload, steps=60, warmup=8):
     return block
 
 
+def concurrent_block(device, workload, nstreams, steps=120, warmup=12):
+    """`nstreams` independent streams on ONE GPU, each a pl_hip backend (its own HIP stream) and
+    a pl_renderer driven by its own host thread: the launch gaps and host waits of one stream
+    (44 us of a 311 us frame) are filled by the others'. Aggregate output rate."""
+    import threading
+    (sw, sh), (dw, dh), _, _ = WORKLOADS[workload]
+    per_frame = (sw * sh + dw * dh) * 8
+    streams = [Stream(device, workload, max(4, -(-400_000_000 // per_frame))) for _ in range(nstreams)]
+    gate = threading.Barrier(nstreams + 1)
+    errors = []
+
+    def drive(st):
+        try:
+            for _ in range(warmup):
+                st.step()
+            st.g.finish()
+            gate.wait()
+            for _ in range(steps):
+                st.step()
+            st.g.finish()
+            gate.wait()
+        except Exception as e:      # noqa: BLE001
+            errors.append(repr(e))
+            gate.abort()
+
+    threads = [threading.Thread(target=drive, args=(st,)) for st in streams]
+    for t in threads:
+        t.start()
+    gate.wait()
+    t0 = time.perf_counter()
+    gate.wait()
+    dt = time.perf_counter() - t0
+    for t in threads:
+        t.join()
+    block = {"streams": nstreams, "frames": nstreams * steps,
+             "mpixels_per_s": round(nstreams * steps * dw * dh / dt / 1e6, 1),
+             "ms_per_frame_aggregate": round(dt / (nstreams * steps) * 1e3, 4),
+             "render_errors": [st.rr.errors() for st in streams], "errors": errors}
+    for st in streams:
+        st.close()
+    return block
+
+
 def baseline_metric():
     """BASELINE.json's metric name (the driver matches on it)."""
     try:
@@ -520,11 +563,13 @@ def main():
     ap.add_argument("--no-companions", action="store_true",
                     help="skip the per-config 'rooflines' blocks")
     ap.add_argument("--no-traffic", action="store_true", help="skip the rocprofv3 --pmc passes")
+    ap.add_argument("--no-concurrent", action="store_true",
+                    help="skip the several-streams-on-one-GPU companion measurement")
     ap.add_argument("--bare", action="store_true",
                     help="timed loop only (what the --pmc child processes run)")
     args = ap.parse_args()
     if args.bare:
-        args.no_cpu_baseline = args.no_companions = args.no_traffic = True
+        args.no_cpu_baseline = args.no_companions = args.no_traffic = args.no_concurrent = True
 
     import torch
 
@@ -601,6 +646,10 @@ def main():
         if not args.no_companions:
             out["rooflines"] = {w: config_block(local_rank, w) for w in BASELINE_CONFIGS
                                 if w != args.workload}
+        if not args.no_concurrent:
+            # companion only: `value` stays the single-stream figure
+            out["concurrent_streams_one_gpu"] = [concurrent_block(local_rank, args.workload, n)
+                                                 for n in (2, 4)]
         if not args.no_cpu_baseline:
             cb = cpu_baseline()
             if cb:

@@ -10,6 +10,7 @@ import numpy as np
 import pytest
 
 import libplacebo_amd as pl
+import util
 from libplacebo_amd import _capi as capi
 
 pytestmark = pytest.mark.gpu
@@ -89,3 +90,50 @@ def test_exchange_hook_sees_the_buffer_before_it_is_consumed(gpu):
     assert m[0:12].sum() == (192 // 16) * (128 // 16)      # a finished measurement
     assert meta == meta_ref, (meta, meta_ref)
     assert np.array_equal(got, ref)
+
+
+def test_concurrent_streams_on_one_gpu():
+    """Several pl_hip backends on the same device are independent (own HIP stream, own dispatch,
+    no shared mutable state): driven from separate host threads their frames overlap on the GPU
+    (bench.py: concurrent_streams_one_gpu) and every stream still renders exactly what it renders
+    alone."""
+    import threading
+    w, h = 320, 180
+    imgs = [util.random_rgba16(w, h, seed=20 + i) for i in range(3)]
+    hdr, sdr = pl.color_space("bt2020", "pq"), pl.color_space("bt709", "bt1886")
+
+    def render(g, img, frames):
+        rr = pl.Renderer(g)
+        src = g.tex_create(w, h, "rgba16", img)
+        dst = g.tex_create(2 * w, 2 * h, "rgba16")
+        params = pl.render_params("default", upscaler=pl.filter_config("ewa_lanczos"),
+                                  dither_params=None)
+        out = None
+        for _ in range(frames):
+            assert rr.render(pl.frame(src, components=3, color=hdr), pl.frame(dst, color=sdr), params)
+            out = dst.download()
+        assert rr.errors() == 0
+        rr.destroy(); src.destroy(); dst.destroy()
+        return out
+
+    with pl.HipGpu(0) as g:
+        alone = [render(g, img, 3) for img in imgs]
+    gpus = [pl.HipGpu(0) for _ in imgs]
+    together, failures = [None] * len(imgs), []
+
+    def work(i):
+        try:
+            together[i] = render(gpus[i], imgs[i], 3)
+        except Exception as e:      # noqa: BLE001
+            failures.append((i, repr(e)))
+
+    threads = [threading.Thread(target=work, args=(i,)) for i in range(len(imgs))]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    for g in gpus:
+        g.close()
+    assert not failures, failures
+    for a, b in zip(alone, together):
+        assert np.array_equal(a, b)
