@@ -38,6 +38,7 @@ int plh_stream_idle(plh_stream s);   // 1 idle, 0 busy, < 0 error
 void *plh_malloc(int device, size_t size);
 void plh_free(void *ptr);
 void *plh_host_alloc(size_t size); // pinned
+void *plh_host_alloc_coherent(size_t size); // pinned, fine-grained, device-mapped
 void plh_host_free(void *ptr);
 
 int plh_copy2d_h2d(plh_stream s, void *dst, size_t dpitch, const void *src, size_t spitch,

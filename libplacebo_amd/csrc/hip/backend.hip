@@ -112,6 +112,16 @@ void *plh_host_alloc(size_t size)
     return p;
 }
 
+// fine-grained (host-coherent) pinned memory, mapped for the device: a kernel's system-scope
+// stores become visible to a polling host thread while the stream keeps running
+void *plh_host_alloc_coherent(size_t size)
+{
+    void *p = NULL;
+    if (hipHostMalloc(&p, size, hipHostMallocCoherent | hipHostMallocMapped) != hipSuccess)
+        return NULL;
+    return p;
+}
+
 void plh_host_free(void *ptr)
 {
     if (ptr)

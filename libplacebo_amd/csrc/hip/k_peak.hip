@@ -256,19 +256,37 @@ void k_pass_peak(const plh_pass p_)
     plh_store_n<PEAK_NPX>(p.dst, sx, sy, ok, c, p.nt_store);
 }
 
-__global__ void k_peak_fold(uint32_t *dst, uint32_t *scratch)
+// One block: the end of the measurement is a single point in the program, after which the
+// result is published to the host mailbox (if any) with system-scope ordering.
+__global__ __launch_bounds__(1024)
+void k_peak_fold(uint32_t *dst, uint32_t *scratch, uint32_t *mailbox, uint32_t ticket)
 {
-    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= PLH_PEAK_WORDS)
-        return;
-    const bool is_max = t >= 3 * PEAK_SLICES && t < 4 * PEAK_SLICES;   // frame_max_pq
-    uint32_t acc = 0;
-    for (int c = 0; c < PLH_PEAK_COPIES; c++) {
-        const uint32_t v = scratch[c * PLH_PEAK_WORDS + t];
-        acc = is_max ? max(acc, v) : acc + v;
-        scratch[c * PLH_PEAK_WORDS + t] = 0u;
+    const uint32_t t = threadIdx.x;
+    if (t < PLH_PEAK_WORDS) {
+        const bool is_max = t >= 3 * PEAK_SLICES && t < 4 * PEAK_SLICES;   // frame_max_pq
+        uint32_t acc = 0;
+        // sixteen copies per round trip (one block has to cover all 64: latency, not bandwidth)
+        for (int c0 = 0; c0 < PLH_PEAK_COPIES; c0 += 16) {
+            uint32_t v[16];
+#pragma unroll
+            for (int c = 0; c < 16; c++)
+                v[c] = scratch[(c0 + c) * PLH_PEAK_WORDS + t];
+#pragma unroll
+            for (int c = 0; c < 16; c++) {
+                acc = is_max ? max(acc, v[c]) : acc + v[c];
+                scratch[(c0 + c) * PLH_PEAK_WORDS + t] = 0u;
+            }
+        }
+        dst[t] = acc;       // the whole buffer is rewritten: the host never has to clear it
+        if (mailbox)
+            __hip_atomic_store(&mailbox[t], acc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }
-    dst[t] = acc;       // the whole buffer is rewritten: the host never has to clear it
+    if (!mailbox)
+        return;
+    __threadfence_system();
+    __syncthreads();
+    if (t == 0)
+        __hip_atomic_store(&mailbox[PLH_PEAK_WORDS], ticket, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
 int plh_launch_peak(hipStream_t stream, const plh_pass *pass)
@@ -289,8 +307,10 @@ int plh_launch_peak(hipStream_t stream, const plh_pass *pass)
         hipLaunchKernelGGL(k_pass_peak<true>, grid, block, 0, stream, *pass);
     else
         hipLaunchKernelGGL(k_pass_peak<false>, grid, block, 0, stream, *pass);
-    hipLaunchKernelGGL(k_peak_fold, dim3((PLH_PEAK_WORDS + 255) / 256), dim3(256), 0, stream,
-                       (uint32_t *) pass->peak_buf, (uint32_t *) pass->peak_scratch);
+    static_assert(PLH_PEAK_WORDS <= 1024 && PLH_PEAK_COPIES % 16 == 0, "k_peak_fold is one block");
+    hipLaunchKernelGGL(k_peak_fold, dim3(1), dim3(1024), 0, stream, (uint32_t *) pass->peak_buf,
+                       (uint32_t *) pass->peak_scratch, (uint32_t *) pass->peak_mailbox,
+                       pass->peak_ticket);
     const hipError_t err = hipGetLastError();
     return err == hipSuccess ? 0 : -(int) err;
 }

@@ -251,6 +251,11 @@ struct plh_pass {
     // scratch area of PLH_PEAK_COPIES such buffers that spreads the per-workgroup atomics
     void *peak_buf;
     void *peak_scratch;
+    // optional host mailbox (pinned, device-visible): the fold kernel also writes the 816 words
+    // there and then publishes `peak_ticket` in word 816 -- the host polls that word instead of
+    // waiting on the stream and copying the buffer back
+    void *peak_mailbox;
+    uint32_t peak_ticket;
 };
 
 /* ---- error diffusion (k_errdiff.hip) ------------------------------------------ */

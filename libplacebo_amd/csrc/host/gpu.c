@@ -298,6 +298,10 @@ void pl_hip_destroy(pl_hip *hip)
         return;
     struct gpu_priv *p = GPU_PRIV((*hip)->gpu);
     plh_stream_sync(p->stream);
+    for (int i = 0; i < PLH_STAGE_SLOTS; i++) {
+        plh_event_destroy(p->stage[i].done);
+        plh_host_free(p->stage[i].host);
+    }
     if (p->own_stream)
         plh_stream_destroy(p->stream);
     free(p);
@@ -745,7 +749,31 @@ void *pl_hip_buf_ptr(pl_buf buf)
 void plh_buf_write(pl_gpu gpu, pl_buf buf, size_t buf_offset, const void *data, size_t size)
 {
     struct gpu_priv *g = GPU_PRIV(gpu);
-    plh_copy2d_h2d(g->stream, (uint8_t *) BUF_PRIV(buf)->ptr + buf_offset, size, data, size, size, 1);
+    uint8_t *dst = (uint8_t *) BUF_PRIV(buf)->ptr + buf_offset;
+    if (size <= PLH_STAGE_BYTES) {
+        // through a pinned slot: `data` is the caller's again as soon as it is copied there,
+        // the device copy is ordered on the stream like everything else
+        const int i = g->stage_next;
+        if (!g->stage[i].host) {
+            g->stage[i].host = plh_host_alloc(PLH_STAGE_BYTES);
+            if (g->stage[i].host && plh_event_create(&g->stage[i].done)) {
+                plh_host_free(g->stage[i].host);
+                g->stage[i].host = NULL;
+            }
+        }
+        if (g->stage[i].host) {
+            if (g->stage[i].in_flight)
+                plh_event_sync(g->stage[i].done);   // eight uploads ago: long finished
+            memcpy(g->stage[i].host, data, size);
+            if (!plh_copy2d_h2d(g->stream, dst, size, g->stage[i].host, size, size, 1) &&
+                !plh_event_record(g->stage[i].done, g->stream)) {
+                g->stage[i].in_flight = true;
+                g->stage_next = (i + 1) % PLH_STAGE_SLOTS;
+                return;
+            }
+        }
+    }
+    plh_copy2d_h2d(g->stream, dst, size, data, size, size, 1);
     plh_stream_sync(g->stream);
 }
 

@@ -17,6 +17,9 @@ struct fmt_priv {
     int plh;            // enum plh_fmt
 };
 
+#define PLH_STAGE_SLOTS 8
+#define PLH_STAGE_BYTES (64 * 1024)
+
 struct gpu_priv {
     struct pl_gpu_t gpu;
     struct pl_hip_t hip;
@@ -30,6 +33,14 @@ struct gpu_priv {
     void *peak_exchange_priv;
     struct fmt_priv fmt_store[16];
     pl_fmt fmts[16];
+    // pinned staging slots for small host -> device uploads (per-frame tables: tone curve,
+    // constant blocks): the copy is queued and the call returns, no stream wait
+    struct {
+        void *host;
+        plh_event done;
+        bool in_flight;
+    } stage[PLH_STAGE_SLOTS];
+    int stage_next;
 };
 
 struct tex_priv {
@@ -67,6 +78,8 @@ void plh_buf_write(pl_gpu gpu, pl_buf buf, size_t buf_offset, const void *data, 
 bool plh_buf_read(pl_gpu gpu, pl_buf buf, size_t buf_offset, void *dest, size_t size);
 // runs the installed cross-GPU exchange (if any) on a finished peak measurement
 void plh_gpu_peak_exchange(pl_gpu gpu, void *words, size_t size);
+static inline bool plh_gpu_has_peak_exchange(pl_gpu gpu);
+static inline bool plh_gpu_has_peak_exchange(pl_gpu gpu) { return !!((struct gpu_priv *) gpu)->peak_exchange; }
 static inline plh_stream plh_gpu_stream(pl_gpu gpu) { return GPU_PRIV(gpu)->stream; }
 static inline int plh_gpu_device(pl_gpu gpu) { return GPU_PRIV(gpu)->device; }
 

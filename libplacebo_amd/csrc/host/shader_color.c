@@ -455,6 +455,7 @@ void pl_shader_unsigmoidize(pl_shader sh, const struct pl_sigmoid_params *params
 /* peak detection                                                            */
 
 enum {
+    PEAK_WORDS = 816,   // sizeof(struct peak_buf_data) / 4
     SLICES    = 12,
     PQ_BITS   = 14,
     PQ_MAX    = (1 << PQ_BITS) - 1,
@@ -493,7 +494,8 @@ struct sh_color_map_obj {
     struct {
         struct pl_peak_detect_params params;
         pl_buf buf;             // 816 words, written by k_peak_fold
-        struct peak_buf_data *mirror;   // pinned
+        struct peak_buf_data *mirror;   // pinned, device-visible: the kernel's mailbox, + 1 word
+        uint32_t ticket;        // the value the pass in flight publishes behind its result
         plh_event written;      // recorded by the dispatch behind the measuring pass
         bool awaiting;          // a measuring pass was recorded and its result not yet taken
         bool launched;          // ... and that pass has been dispatched (`written` is live)
@@ -654,13 +656,29 @@ static void peak_collect(pl_gpu gpu, struct sh_color_map_obj *obj, bool must)
     if (!must && params->allow_delayed && plh_event_query(obj->peak.written) == 0)
         return;     // still rendering: this frame goes with the previous result
 
-    // ranks rendering one scene fold their measurements together first (hip.h)
-    plh_gpu_peak_exchange(gpu, pl_hip_buf_ptr(obj->peak.buf), sizeof(struct peak_buf_data));
     obj->peak.awaiting = obj->peak.launched = false;
     plh_stream stream = plh_gpu_stream(gpu);
-    if (plh_copy2d_d2h(stream, obj->peak.mirror, sizeof(*obj->peak.mirror),
-                       pl_hip_buf_ptr(obj->peak.buf), sizeof(*obj->peak.mirror),
-                       sizeof(*obj->peak.mirror), 1) || plh_stream_sync(stream)) {
+    bool have = false;
+    if (!plh_gpu_has_peak_exchange(gpu)) {
+        // the fold kernel wrote the result into the pinned mirror and then its ticket: poll
+        // that word (a few microseconds after the kernel retires, against ~20 for a stream
+        // wait plus a copy). Bounded: a lost kernel must not hang the caller.
+        volatile const uint32_t *seen = (volatile const uint32_t *) obj->peak.mirror + PEAK_WORDS;
+        for (long spin = 0; spin < 200000000L && !have; spin++) {
+            have = __atomic_load_n(seen, __ATOMIC_ACQUIRE) == obj->peak.ticket;
+            if (!have && (spin & 1023) == 1023 && plh_event_query(obj->peak.written) != 0)
+                break;      // the stream is past the pass (or failed): look once more below
+        }
+        if (!have)
+            have = __atomic_load_n(seen, __ATOMIC_ACQUIRE) == obj->peak.ticket;
+    } else {
+        // ranks rendering one scene fold their measurements together first (hip.h); the
+        // exchange works on the device buffer, which is then copied back
+        plh_gpu_peak_exchange(gpu, pl_hip_buf_ptr(obj->peak.buf), sizeof(struct peak_buf_data));
+    }
+    if (!have && (plh_copy2d_d2h(stream, obj->peak.mirror, sizeof(*obj->peak.mirror),
+                                 pl_hip_buf_ptr(obj->peak.buf), sizeof(*obj->peak.mirror),
+                                 sizeof(*obj->peak.mirror), 1) || plh_stream_sync(stream))) {
         pl_msg(gpu->log, PL_LOG_ERR, "Failed reading peak detection buffer!");
         return;
     }
@@ -722,7 +740,9 @@ bool pl_shader_detect_peak(pl_shader sh, struct pl_color_space csp, pl_shader_ob
     if (!obj->peak.buf) {
         obj->peak.buf = pl_buf_create(gpu, pl_buf_params(
             .size = sizeof(struct peak_buf_data), .host_readable = true, .storable = true));
-        obj->peak.mirror = plh_host_alloc(sizeof(struct peak_buf_data));
+        obj->peak.mirror = plh_host_alloc_coherent(sizeof(struct peak_buf_data) + sizeof(uint32_t));
+        if (obj->peak.mirror)
+            memset(obj->peak.mirror, 0, sizeof(struct peak_buf_data) + sizeof(uint32_t));
         if (!obj->peak.buf || !obj->peak.mirror || plh_event_create(&obj->peak.written)) {
             SH_FAIL(sh, "Failed creating peak detection SSBO!");
             return false;
@@ -772,6 +792,9 @@ bool pl_shader_detect_peak(pl_shader sh, struct pl_color_space csp, pl_shader_ob
     }
     sh->pass.peak_buf = pl_hip_buf_ptr(obj->peak.buf);
     sh->pass.peak_scratch = pl_hip_buf_ptr(obj->peak.scratch);
+    obj->peak.ticket = obj->peak.ticket + 1 ? obj->peak.ticket + 1 : 1;    // never 0
+    sh->pass.peak_mailbox = obj->peak.mirror;
+    sh->pass.peak_ticket = obj->peak.ticket;
     sh->detect_peak = true;
     sh->peak_state = *state;    // (held below: outlives the shader's dispatch)
     sh_hold(sh, *state);
