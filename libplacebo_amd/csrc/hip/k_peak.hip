@@ -256,37 +256,63 @@ void k_pass_peak(const plh_pass p_)
     plh_store_n<PEAK_NPX>(p.dst, sx, sy, ok, c, p.nt_store);
 }
 
-// One block: the end of the measurement is a single point in the program, after which the
-// result is published to the host mailbox (if any) with system-scope ordering.
-__global__ __launch_bounds__(1024)
+// Sum (maximum for frame_max_pq) of the PLH_PEAK_COPIES partial buffers. 13 blocks of 64 words x
+// 4 copy groups: every lane has 16 independent loads in flight, one memory round trip for the
+// whole fold (a single block takes 12 us: one CU cannot pull 200 KiB any faster). The block
+// that finishes last copies the 816 words into the host mailbox (if any) and publishes the
+// ticket behind them with system-scope ordering; `scratch[COPIES * WORDS]` counts the blocks.
+#define FOLD_WORDS 64
+#define FOLD_GROUPS 4
+__global__ __launch_bounds__(FOLD_WORDS * FOLD_GROUPS)
 void k_peak_fold(uint32_t *dst, uint32_t *scratch, uint32_t *mailbox, uint32_t ticket)
 {
-    const uint32_t t = threadIdx.x;
+    __shared__ uint32_t part[FOLD_GROUPS][FOLD_WORDS];
+    __shared__ bool last;
+    const uint32_t lane = threadIdx.x & (FOLD_WORDS - 1), g = threadIdx.x / FOLD_WORDS;
+    const uint32_t t = blockIdx.x * FOLD_WORDS + lane;
+    const bool is_max = t >= 3 * PEAK_SLICES && t < 4 * PEAK_SLICES;   // frame_max_pq
+    constexpr int PER = PLH_PEAK_COPIES / FOLD_GROUPS;
+    uint32_t acc = 0;
     if (t < PLH_PEAK_WORDS) {
-        const bool is_max = t >= 3 * PEAK_SLICES && t < 4 * PEAK_SLICES;   // frame_max_pq
-        uint32_t acc = 0;
-        // sixteen copies per round trip (one block has to cover all 64: latency, not bandwidth)
-        for (int c0 = 0; c0 < PLH_PEAK_COPIES; c0 += 16) {
-            uint32_t v[16];
+        uint32_t v[PER];
 #pragma unroll
-            for (int c = 0; c < 16; c++)
-                v[c] = scratch[(c0 + c) * PLH_PEAK_WORDS + t];
+        for (int c = 0; c < PER; c++)
+            v[c] = scratch[(g * PER + c) * PLH_PEAK_WORDS + t];
 #pragma unroll
-            for (int c = 0; c < 16; c++) {
-                acc = is_max ? max(acc, v[c]) : acc + v[c];
-                scratch[(c0 + c) * PLH_PEAK_WORDS + t] = 0u;
-            }
+        for (int c = 0; c < PER; c++) {
+            acc = is_max ? max(acc, v[c]) : acc + v[c];
+            scratch[(g * PER + c) * PLH_PEAK_WORDS + t] = 0u;
         }
+    }
+    part[g][lane] = acc;
+    __syncthreads();
+    if (g == 0 && t < PLH_PEAK_WORDS) {
+#pragma unroll
+        for (int k = 1; k < FOLD_GROUPS; k++)
+            acc = is_max ? max(acc, part[k][lane]) : acc + part[k][lane];
         dst[t] = acc;       // the whole buffer is rewritten: the host never has to clear it
-        if (mailbox)
-            __hip_atomic_store(&mailbox[t], acc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }
     if (!mailbox)
         return;
+    __threadfence();
+    __syncthreads();
+    uint32_t *counter = scratch + PLH_PEAK_COPIES * PLH_PEAK_WORDS;
+    if (threadIdx.x == 0)
+        last = atomicAdd(counter, 1u) == gridDim.x - 1;
+    __syncthreads();
+    if (!last)
+        return;
+    __threadfence();
+    for (uint32_t i = threadIdx.x; i < PLH_PEAK_WORDS; i += blockDim.x) {
+        const uint32_t v = __hip_atomic_load(&dst[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(&mailbox[i], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
     __threadfence_system();
     __syncthreads();
-    if (t == 0)
+    if (threadIdx.x == 0) {
+        *counter = 0u;
         __hip_atomic_store(&mailbox[PLH_PEAK_WORDS], ticket, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
 }
 
 int plh_launch_peak(hipStream_t stream, const plh_pass *pass)
@@ -307,8 +333,9 @@ int plh_launch_peak(hipStream_t stream, const plh_pass *pass)
         hipLaunchKernelGGL(k_pass_peak<true>, grid, block, 0, stream, *pass);
     else
         hipLaunchKernelGGL(k_pass_peak<false>, grid, block, 0, stream, *pass);
-    static_assert(PLH_PEAK_WORDS <= 1024 && PLH_PEAK_COPIES % 16 == 0, "k_peak_fold is one block");
-    hipLaunchKernelGGL(k_peak_fold, dim3(1), dim3(1024), 0, stream, (uint32_t *) pass->peak_buf,
+    static_assert(PLH_PEAK_COPIES % FOLD_GROUPS == 0, "copy groups");
+    hipLaunchKernelGGL(k_peak_fold, dim3((PLH_PEAK_WORDS + FOLD_WORDS - 1) / FOLD_WORDS),
+                       dim3(FOLD_WORDS * FOLD_GROUPS), 0, stream, (uint32_t *) pass->peak_buf,
                        (uint32_t *) pass->peak_scratch, (uint32_t *) pass->peak_mailbox,
                        pass->peak_ticket);
     const hipError_t err = hipGetLastError();

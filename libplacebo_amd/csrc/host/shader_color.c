@@ -782,7 +782,8 @@ bool pl_shader_detect_peak(pl_shader sh, struct pl_color_space csp, pl_shader_ob
     }
     op->ptr2 = pl_hip_buf_ptr(obj->peak.consts);
     if (!obj->peak.scratch) {
-        const size_t size = (size_t) PLH_PEAK_COPIES * sizeof(struct peak_buf_data);
+        // (+ the block counter of k_peak_fold behind the copies)
+        const size_t size = (size_t) PLH_PEAK_COPIES * sizeof(struct peak_buf_data) + 64;
         void *zeros = calloc(1, size);
         obj->peak.scratch = zeros ? pl_buf_create(gpu, pl_buf_params(
             .size = size, .storable = true, .initial_data = zeros)) : NULL;
