@@ -229,7 +229,9 @@ struct bf_cell {
     bool shared;
 };
 
-template <bool F16SRC, int ITERS>
+// RGB: the epilogue overwrites alpha (p.epi.has_alpha: video without an alpha plane), so the
+// fourth channel is neither decoded nor blended.
+template <bool F16SRC, int ITERS, bool RGB>
 __global__ __launch_bounds__(BF_BW * BF_BH)
 void k_bilinear_fast(const plh_pass p_)
 {
@@ -303,16 +305,49 @@ void k_bilinear_fast(const plh_pass p_)
 
     // stage B: decode, blend, epilogue, store
     auto stage_b = [&](const bf_cell &c) {
-        float4_t t[4];
+        constexpr int NCH = RGB ? 3 : 4;
+        float t[4][NCH];
 #pragma unroll
-        for (int k = 0; k < 4; k++)
-            t[k] = bf_decode<F16SRC>(c.raw[k]);
-        float4_t o[4];
+        for (int k = 0; k < 4; k++) {
+            const uint32_t w[4] = { c.raw[k].x & 0xffff, c.raw[k].x >> 16, c.raw[k].y & 0xffff,
+                                    c.raw[k].y >> 16 };
 #pragma unroll
-        for (int q = 0; q < 4; q++) {
-            o[q] = scale4(mix4(mix4(t[0], t[1], c.ax[q]), mix4(t[2], t[3], c.ax[q]), c.ay[q]),
-                          s.scale);
+            for (int ch = 0; ch < NCH; ch++)
+                t[k][ch] = F16SRC ? plh_h2f(w[ch]) : plh_un16(w[ch]);
         }
+        float4_t o[4];
+        // The blend factors are per column (ax) and per row (ay) up to the rounding of the
+        // attribute interpolation; when they are -- bit for bit, checked here -- the two
+        // horizontal blends of a column serve both of its pixels: 8 mixes per channel, not 12.
+        const bool separable = c.ax[0] == c.ax[2] && c.ax[1] == c.ax[3] &&
+                               c.ay[0] == c.ay[1] && c.ay[2] == c.ay[3];
+        float ov[4][4];
+        if (separable) {
+#pragma unroll
+            for (int ch = 0; ch < NCH; ch++) {
+                float top[2], bot[2];
+#pragma unroll
+                for (int i = 0; i < 2; i++) {
+                    top[i] = plh_mix(t[0][ch], t[1][ch], c.ax[i]);
+                    bot[i] = plh_mix(t[2][ch], t[3][ch], c.ax[i]);
+                }
+#pragma unroll
+                for (int q = 0; q < 4; q++)
+                    ov[q][ch] = s.scale * plh_mix(top[q & 1], bot[q & 1], c.ay[q]);
+            }
+        } else {
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+#pragma unroll
+                for (int ch = 0; ch < NCH; ch++) {
+                    ov[q][ch] = s.scale * plh_mix(plh_mix(t[0][ch], t[1][ch], c.ax[q]),
+                                                  plh_mix(t[2][ch], t[3][ch], c.ax[q]), c.ay[q]);
+                }
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < 4; q++)
+            o[q] = { ov[q][0], ov[q][1], ov[q][2], RGB ? 0.0f : ov[q][NCH - 1] };
         if (!c.shared) {
             // pixels of this cell straddle a texel boundary (not a 2x upscale on the cell
             // phase): every pixel fetches its own footprint
@@ -485,12 +520,19 @@ static void launch_bilinear_fast(hipStream_t stream, const plh_pass *pass, int i
     const dim3 block(BF_BW, BF_BH);
     const int bh = BF_BH * iters;
     const dim3 grid((cells_w + BF_BW - 1) / BF_BW, (cells_h + bh - 1) / bh);
+#define BF_LAUNCH(IT) do { \
+        if (pass->epi.has_alpha) \
+            hipLaunchKernelGGL((k_bilinear_fast<F16SRC, IT, true>), grid, block, 0, stream, *pass); \
+        else \
+            hipLaunchKernelGGL((k_bilinear_fast<F16SRC, IT, false>), grid, block, 0, stream, *pass); \
+    } while (0)
     if (iters == 4)
-        hipLaunchKernelGGL((k_bilinear_fast<F16SRC, 4>), grid, block, 0, stream, *pass);
+        BF_LAUNCH(4);
     else if (iters == 2)
-        hipLaunchKernelGGL((k_bilinear_fast<F16SRC, 2>), grid, block, 0, stream, *pass);
+        BF_LAUNCH(2);
     else
-        hipLaunchKernelGGL((k_bilinear_fast<F16SRC, 1>), grid, block, 0, stream, *pass);
+        BF_LAUNCH(1);
+#undef BF_LAUNCH
 }
 
 /* ------------------------------------------------------------------------ */

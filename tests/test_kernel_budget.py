@@ -43,7 +43,7 @@ BUDGET = [
     # with the full colour interpreter (the metric's EWA + tone-map launch): 3 waves
     (r"k_polar_pp<__half, \d+u, [12], false, false>", 3),
     (r"k_polar_pp<float, \d+u, 1, false, false>", 3),
-    (r"k_bilinear_fast<(true|false), 4>", 4),
+    (r"k_bilinear_fast<(true|false), 4, (true|false)>", 4),
     (r"k_nearest_fast<(true|false)>", 8),
     (r"k_pass_generic<.*>", 4),
     (r"k_pass_peak<true>", 4),
