@@ -506,7 +506,7 @@ typedef const struct pl_pass_t {
 } *pl_pass;
 
 // DEVIATION (INTEGRATION.md "pl_pass"): a pl_pass of the reference is a compiled GLSL program
-// (src/gpu.c:794-888). This backend has no GLSL front-end -- passes are op lists recorded
+// (src/gpu.c:1025-1290). This backend has no GLSL front-end -- passes are op lists recorded
 // through pl_shader and launched by pl_dispatch_finish / pl_dispatch_compute as precompiled
 // HIP kernels -- so there is nothing pl_pass_create could compile. The entry points exist so
 // that programs written against the reference link unchanged; pl_pass_create logs an error
