@@ -383,6 +383,45 @@ def measure_traffic(workload, symbol, timeout=240):
             "method": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, FETCH x2 (gfx950)"}
 
 
+def measure_trace(workload, symbol, timeout=240):
+    """Average duration of the kernel `symbol` in a rocprofv3 kernel trace of a short run of this
+    script (the same figure profiles/*_kernel_stats.csv holds). An event pair bracketing ONE launch
+    also times ~3-4 us of launch latency, which shows on 20 us kernels; the trace does not."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+    rocprof = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(rocprof):
+        return None
+    with tempfile.TemporaryDirectory(dir="/tmp") as td:
+        env = dict(os.environ, TMPDIR="/tmp", PL_BENCH_CHILD="1")
+        cmd = [rocprof, "--kernel-trace", "--stats", "--output-format", "csv", "-d", td, "--",
+               sys.executable, os.path.abspath(__file__), "--workload", workload, "--steps", "40",
+               "--warmup", "8", "--bare"]
+        try:
+            r = subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, text=True,
+                               timeout=timeout)
+        except Exception as e:      # noqa: BLE001
+            print(f"bench: trace probe failed to run: {e}", file=sys.stderr)
+            return None
+        if r.returncode != 0:
+            print(f"bench: trace probe exited {r.returncode}:\n{(r.stdout + r.stderr)[-1500:]}",
+                  file=sys.stderr)
+            return None
+        best = None
+        for fn in glob.glob(os.path.join(td, "**", "*kernel_stats.csv"), recursive=True):
+            for row in csv.DictReader(open(fn)):
+                if symbol in row["Name"]:
+                    cand = (float(row["TotalDurationNs"]), float(row["AverageNs"]), int(row["Calls"]),
+                            row["Name"])
+                    best = max(best, cand) if best else cand
+        if not best:
+            return None
+        return {"kernel_us": round(best[1] / 1e3, 2), "calls": best[2], "name": best[3]}
+
+
 def cpu_model():
     try:
         for ln in open("/proc/cpuinfo"):
@@ -480,7 +519,7 @@ def run_timed(st, steps, warmup, sync=None, barrier=None):
     return elapsed
 
 
-def config_block(device, workload, steps=60, warmup=8):
+def config_block(device, workload, steps=60, warmup=8, trace=False):
     """One BASELINE config measured like the headline (single stream): frame rate + roofline."""
     (sw, sh), (dw, dh), _, _ = WORKLOADS[workload]
     per_frame = (sw * sh + dw * dh) * 8
@@ -492,6 +531,11 @@ def config_block(device, workload, steps=60, warmup=8):
                  ms_per_step=round(dt / steps * 1e3, 4), steps=steps,
                  render_errors=st.rr.errors())
     st.close()
+    if trace:
+        tr = measure_trace(workload, block["kernel"].split(" ")[0])
+        if tr:
+            block["trace"] = dict(tr, achieved=round(block["algorithmic_bytes"] / tr["kernel_us"] / 1e3, 1))
+            block["trace"]["frac"] = round(block["trace"]["achieved"] / block["peak"], 4)
     return block
 
 
@@ -643,9 +687,15 @@ def main():
             if t:
                 roofline["traffic"] = t["bytes"]
                 roofline["traffic_detail"] = t
+            tr = measure_trace(args.workload, roofline["kernel"].split(" ")[0])
+            if tr:
+                # the same kernel in a rocprofv3 kernel trace (what profiles/ holds)
+                roofline["trace"] = dict(tr, achieved=round(roofline["algorithmic_bytes"] /
+                                                            tr["kernel_us"] / 1e3, 1))
+                roofline["trace"]["frac"] = round(roofline["trace"]["achieved"] / roofline["peak"], 4)
         if not args.no_companions:
-            out["rooflines"] = {w: config_block(local_rank, w) for w in BASELINE_CONFIGS
-                                if w != args.workload}
+            out["rooflines"] = {w: config_block(local_rank, w, trace=not args.no_traffic)
+                                for w in BASELINE_CONFIGS if w != args.workload}
         if not args.no_concurrent:
             # companion only: `value` stays the single-stream figure
             out["concurrent_streams_one_gpu"] = [concurrent_block(local_rank, args.workload, n)

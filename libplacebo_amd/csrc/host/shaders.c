@@ -318,11 +318,17 @@ void *sh_require_obj(pl_shader sh, pl_shader_obj *ptr, enum pl_shader_obj_type t
 
 void sh_hold(pl_shader sh, pl_shader_obj obj)
 {
-    if (!obj || sh->num_held >= (int) PL_ARRAY_SIZE(sh->held))
+    if (!obj)
         return;
     for (int i = 0; i < sh->num_held; i++) {
         if (sh->held[i] == obj)
             return;
+    }
+    if (sh->num_held >= (int) PL_ARRAY_SIZE(sh->held)) {
+        // the recorded pass points into this object's device memory: without the reference it
+        // could be freed under the pass, so the shader is refused rather than run unprotected
+        SH_FAIL(sh, "Too many state objects in one shader (%d)", sh->num_held);
+        return;
     }
     obj->refcount++;
     sh->held[sh->num_held++] = obj;
