@@ -505,12 +505,15 @@ typedef const struct pl_pass_t {
     struct pl_pass_params params;       // deep copy
 } *pl_pass;
 
-// DEVIATION (INTEGRATION.md "pl_pass"): a pl_pass of the reference is a compiled GLSL program
-// (src/gpu.c:1025-1290). This backend has no GLSL front-end -- passes are op lists recorded
-// through pl_shader and launched by pl_dispatch_finish / pl_dispatch_compute as precompiled
-// HIP kernels -- so there is nothing pl_pass_create could compile. The entry points exist so
-// that programs written against the reference link unchanged; pl_pass_create logs an error
-// naming the replacement and returns NULL, pl_pass_run reports an error and does nothing.
+// A pl_pass of the reference is a compiled GLSL program (src/gpu.c:1025-1290). This backend has
+// no GLSL front-end: what it turns into a pass is a recorded pl_shader. pl_shader_finalize()
+// ends pl_shader_res.glsl with a line "#pl_hip_pass <ticket>" naming the recorded sampler +
+// colour ops; pl_pass_create() with that text as `glsl_shader` (while the shader is alive)
+// copies them into a pass that can be run any number of times, on any target of
+// `target_format` (PL_PASS_RASTER: `target` + `viewport` / `scissors`) or into the storage image
+// bound as its only descriptor (PL_PASS_COMPUTE). Variables, constants, push constants, vertex
+// data and blending do not exist here (the ops carry their values) and must be unset. Any
+// other text -- GLSL -- is refused with a message. DEVIATION: see INTEGRATION.md section 2.
 PL_API pl_pass pl_pass_create(pl_gpu gpu, const struct pl_pass_params *params);
 PL_API void pl_pass_destroy(pl_gpu gpu, pl_pass *pass);
 

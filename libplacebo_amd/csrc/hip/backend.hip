@@ -28,6 +28,8 @@ const char *plh_strerror(int err)
         return "LDS tile does not fit";
     if (err == -1003)
         return "frame mixing ops need a plain (nearest / bilinear) sampler";
+    if (err == -1005)
+        return "could not prepare the white-noise dither plane";
     if (err == -1004)
         return "lut3d_tricubic: the colour map must be a pass of its own (plain sampler, no "
                "peak detection / mixing in the same shader)";

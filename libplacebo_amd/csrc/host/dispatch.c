@@ -216,7 +216,7 @@ static void plh_pass_choose_cells(struct plh_pass *pass)
 // matrices: now that the size of the pass is known, evaluate the PRNG for its fragment
 // coordinates into the corner of a power-of-two square and turn the op into a plain LUT
 // dither over it (k_noise.hip says why).
-static bool realize_white_noise(pl_dispatch dp, struct plh_pass *pass)
+static bool realize_white_noise(pl_gpu gpu, pl_buf *noise, struct plh_pass *pass)
 {
     for (int i = 0; i < pass->num_ops; i++) {
         struct plh_op *op = &pass->ops[i];
@@ -226,13 +226,13 @@ static bool realize_white_noise(pl_dispatch dp, struct plh_pass *pass)
         while (side < pass->width || side < pass->height)
             side <<= 1;
         const size_t size = (size_t) side * side * sizeof(float);
-        if (!dp->noise || dp->noise->params.size < size) {
-            pl_buf_destroy(dp->gpu, &dp->noise);
-            dp->noise = pl_buf_create(dp->gpu, pl_buf_params(.size = size, .storable = true));
-            if (!dp->noise)
+        if (!*noise || (*noise)->params.size < size) {
+            pl_buf_destroy(gpu, noise);
+            *noise = pl_buf_create(gpu, pl_buf_params(.size = size, .storable = true));
+            if (!*noise)
                 return false;
         }
-        if (plh_launch_white_noise(plh_gpu_stream(dp->gpu), pl_hip_buf_ptr(dp->noise), side,
+        if (plh_launch_white_noise(plh_gpu_stream(gpu), pl_hip_buf_ptr(*noise), side,
                                    pass->width, pass->height, pass->frag_x0, pass->frag_y0,
                                    (uint32_t) op->i0))
             return false;
@@ -240,9 +240,43 @@ static bool realize_white_noise(pl_dispatch dp, struct plh_pass *pass)
         op->i1 = 0;     // LUT
         op->i2 = 0;     // not rotated
         op->f[2] = 1.0f / side;
-        op->ptr = pl_hip_buf_ptr(dp->noise);
+        op->ptr = pl_hip_buf_ptr(*noise);
     }
     return true;
+}
+
+// The target half of a pass and its launch: shared by pl_dispatch_finish and pl_pass_run (gpu.c).
+int plh_pass_execute(pl_gpu gpu, pl_log log, const struct plh_pass_exec *x, pl_tex target,
+                     pl_rect2d rc, pl_timer timer, pl_buf *noise)
+{
+    struct plh_pass *pass = x->pass;
+    const int tw = abs(pl_rect_w(rc)), th = abs(pl_rect_h(rc));
+    plh_tex_view(target, &pass->dst);
+    pass->width = x->transpose ? th : tw;
+    pass->height = x->transpose ? tw : th;
+    pass->out_scale[0] = 1.0 / pass->width;
+    pass->out_scale[1] = 1.0 / pass->height;
+    pass->base_x = rc.x0 - (rc.x0 > rc.x1);
+    pass->base_y = rc.y0 - (rc.y0 > rc.y1);
+    pass->dir_x = rc.x0 > rc.x1 ? -1 : 1;
+    pass->dir_y = rc.y0 > rc.y1 ? -1 : 1;
+    pass->transpose = x->transpose;
+    pass->frag_x0 = pass->frag_y0 = 0; // compute passes: rect-relative gl_FragCoord
+
+    if (pass->s.type == PLH_SAMPLE_POLAR && x->polar_obj)
+        plh_polar_pp_setup(gpu, log, x->polar_obj, pass);
+    plh_pass_choose_cells(pass);
+    if (!realize_white_noise(gpu, noise, pass)) {
+        return -1005;
+    }
+    if (timer)
+        plh_timer_begin(gpu, timer);
+    const int err = plh_launch_pass(plh_gpu_stream(gpu), pass);
+    if (timer)
+        plh_timer_end(gpu, timer);
+    if (!err && x->detect_peak)
+        plh_peak_pass_launched(gpu, x->peak_state);
+    return err;
 }
 
 bool pl_dispatch_finish(pl_dispatch dp, const struct pl_dispatch_params *params)
@@ -296,41 +330,13 @@ bool pl_dispatch_finish(pl_dispatch dp, const struct pl_dispatch_params *params)
         goto done;
     }
 
-    struct plh_pass *pass = &sh->pass;
-    plh_tex_view(target, &pass->dst);
-    int width = tw, height = th;
-    if (sh->transpose) {
-        width = th;
-        height = tw;
-    }
-    pass->width = width;
-    pass->height = height;
-    pass->out_scale[0] = 1.0 / width;
-    pass->out_scale[1] = 1.0 / height;
-    pass->base_x = rc.x0 - (rc.x0 > rc.x1);
-    pass->base_y = rc.y0 - (rc.y0 > rc.y1);
-    pass->dir_x = rc.x0 > rc.x1 ? -1 : 1;
-    pass->dir_y = rc.y0 > rc.y1 ? -1 : 1;
-    pass->transpose = sh->transpose;
-    pass->frag_x0 = pass->frag_y0 = 0; // compute passes: rect-relative gl_FragCoord
-
-    if (pass->s.type == PLH_SAMPLE_POLAR && sh->polar_obj)
-        plh_polar_pp_setup(dp->gpu, dp->log, sh->polar_obj, pass);
-    plh_pass_choose_cells(pass);
-    if (!realize_white_noise(dp, pass)) {
-        pl_msg(dp->log, PL_LOG_ERR, "Failed preparing the white-noise dither plane");
-        goto done;
-    }
-
     struct pass_timing *timing = get_timing(dp, sh);
     pl_timer timer = params->timer ? params->timer : timing ? timing->timer : NULL;
-    if (timer)
-        plh_timer_begin(dp->gpu, timer);
-    const int err = plh_launch_pass(plh_gpu_stream(dp->gpu), pass);
-    if (timer)
-        plh_timer_end(dp->gpu, timer);
-    if (!err && sh->detect_peak)
-        plh_peak_pass_launched(dp->gpu, sh->peak_state);
+    const struct plh_pass_exec x = {
+        .pass = &sh->pass, .transpose = sh->transpose, .polar_obj = sh->polar_obj,
+        .detect_peak = sh->detect_peak, .peak_state = sh->peak_state,
+    };
+    const int err = plh_pass_execute(dp->gpu, dp->log, &x, target, rc, timer, &dp->noise);
     if (err) {
         pl_msg(dp->log, PL_LOG_ERR, "Failed launching pass '%s': %s",
                sh_description(sh), plh_strerror(err));
@@ -396,7 +402,7 @@ bool pl_dispatch_compute(pl_dispatch dp, const struct pl_dispatch_compute_params
         pass->transpose = 0;
         pass->frag_x0 = pass->frag_y0 = 0;
         plh_pass_choose_cells(pass);
-        if (!realize_white_noise(dp, pass))
+        if (!realize_white_noise(dp->gpu, &dp->noise, pass))
             goto done;
         if (timer)
             plh_timer_begin(dp->gpu, timer);

@@ -13,6 +13,7 @@
 #include <libplacebo/hip.h>
 
 #include "gpu_priv.h"
+#include "shaders_priv.h"
 #include "cache_priv.h"
 
 const struct pl_hip_params pl_hip_default_params = {0};
@@ -837,30 +838,218 @@ void pl_buf_copy(pl_gpu gpu, pl_buf dst, size_t dst_offset, pl_buf src, size_t s
 }
 
 /* ------------------------------------------------------------------------ */
-/* pl_pass: present for linking, not a way to run anything (gpu.h) */
+/* pl_pass: a recorded op list behind the reference's pass interface          */
+//
+// The reference's pl_pass is a compiled GLSL program (src/gpu.c:1025-1290). This backend compiles
+// nothing at run time; what it can turn into a pass is what pl_shader recorded. pl_shader_finalize
+// therefore ends pl_shader_res.glsl with a line "#pl_hip_pass <ticket>" that resolves -- for as
+// long as that shader is alive, i.e. for as long as the pl_shader_res is valid at all -- to the
+// recorded sampler + colour ops. pl_pass_create copies them (and takes references on the
+// shader's state objects: LUTs, filter tables, peak buffers), so the pass outlives the shader and
+// can be run any number of times; textures the shader sampled are bound by address and must
+// outlive the pass, like any descriptor in the reference. Text without such a line (GLSL) is
+// refused with a message naming the alternative.
+
+struct pass_priv {
+    struct pl_pass_t pub;
+    struct plh_pass pass;
+    bool transpose, detect_peak;
+    void *polar_obj;
+    pl_shader_obj peak_state;
+    int out_w, out_h;
+    pl_shader_obj held[16];
+    int num_held;
+    pl_buf noise;
+    char *text;
+    struct pl_desc *descs;
+};
 
 pl_pass pl_pass_create(pl_gpu gpu, const struct pl_pass_params *params)
 {
-    (void) params;
-    pl_msg(gpu->log, PL_LOG_ERR, "pl_pass_create: this backend runs precompiled HIP kernels and "
-           "has no GLSL compiler; record the pass with pl_shader_* and run it with "
-           "pl_dispatch_finish / pl_dispatch_compute");
-    return NULL;
+    if (!params->glsl_shader) {
+        pl_msg(gpu->log, PL_LOG_ERR, "pl_pass_create: `glsl_shader` is NULL");
+        return NULL;
+    }
+    pl_shader sh = plh_shader_from_glsl(params->glsl_shader);
+    if (!sh) {
+        pl_msg(gpu->log, PL_LOG_ERR, "pl_pass_create: this backend runs precompiled HIP kernels and "
+               "has no GLSL compiler. A pass can be created from the text pl_shader_finalize() "
+               "returns for a shader recorded on this pl_gpu (while that shader is alive); "
+               "otherwise record with pl_shader_* and run with pl_dispatch_finish / _compute.");
+        return NULL;
+    }
+    if (SH_GPU(sh) != gpu || sh->failed || sh->kind != PLH_SHADER_PASS ||
+        sh->input != PL_SHADER_SIG_NONE || sh->output != PL_SHADER_SIG_COLOR) {
+        pl_msg(gpu->log, PL_LOG_ERR, "pl_pass_create: the shader behind this text belongs to "
+               "another pl_gpu, failed, or does not produce a colour from no input");
+        return NULL;
+    }
+    if (params->type != PL_PASS_RASTER && params->type != PL_PASS_COMPUTE) {
+        pl_msg(gpu->log, PL_LOG_ERR, "pl_pass_create: invalid pass type");
+        return NULL;
+    }
+    if (params->num_variables || params->num_constants || params->push_constants_size ||
+        params->blend_params) {
+        pl_msg(gpu->log, PL_LOG_ERR, "pl_pass_create: variables, constants, push constants and "
+               "blending do not exist on this backend (the recorded ops carry their values)");
+        return NULL;
+    }
+    if (params->type == PL_PASS_RASTER && (!params->target_format ||
+        !(params->target_format->caps & PL_FMT_CAP_STORABLE))) {
+        pl_msg(gpu->log, PL_LOG_ERR, "pl_pass_create: raster passes need a storable `target_format` "
+               "(every pass is a compute launch here)");
+        return NULL;
+    }
+    if (params->type == PL_PASS_COMPUTE &&
+        (params->num_descriptors > 1 ||
+         (params->num_descriptors == 1 && params->descriptors[0].type != PL_DESC_STORAGE_IMG))) {
+        pl_msg(gpu->log, PL_LOG_ERR, "pl_pass_create: a compute pass takes at most one descriptor, "
+               "the storage image it writes");
+        return NULL;
+    }
+
+    struct pass_priv *p = calloc(1, sizeof(*p));
+    if (!p)
+        return NULL;
+    p->pub.params = *params;
+    p->text = strdup(params->glsl_shader);
+    p->pub.params.glsl_shader = p->text;
+    p->pub.params.vertex_shader = NULL;
+    p->pub.params.vertex_attribs = NULL;
+    p->pub.params.num_vertex_attribs = 0;
+    p->pub.params.variables = NULL;
+    p->pub.params.constants = NULL;
+    p->pub.params.constant_data = NULL;
+    p->pub.params.descriptors = NULL;
+    if (params->num_descriptors) {
+        p->descs = calloc(params->num_descriptors, sizeof(*p->descs));
+        if (p->descs) {
+            memcpy(p->descs, params->descriptors, params->num_descriptors * sizeof(*p->descs));
+            for (int i = 0; i < params->num_descriptors; i++)
+                p->descs[i].name = NULL;
+        }
+        p->pub.params.descriptors = p->descs;
+    }
+    if (!p->text || (params->num_descriptors && !p->descs)) {
+        free(p->text);
+        free(p->descs);
+        free(p);
+        return NULL;
+    }
+    p->pass = sh->pass;
+    p->transpose = sh->transpose;
+    p->detect_peak = sh->detect_peak;
+    p->peak_state = sh->peak_state;
+    p->polar_obj = sh->polar_obj;
+    p->out_w = sh->output_w;
+    p->out_h = sh->output_h;
+    for (int i = 0; i < sh->num_held; i++) {
+        p->held[p->num_held++] = sh->held[i];
+        sh->held[i]->refcount++;
+    }
+    return &p->pub;
 }
 
 void pl_pass_destroy(pl_gpu gpu, pl_pass *pass)
 {
-    (void) gpu;
-    if (pass)
-        *pass = NULL;
+    if (!pass || !*pass)
+        return;
+    struct pass_priv *p = (struct pass_priv *) *pass;
+    pl_gpu_finish(gpu);     // launches of this pass may still read its objects
+    for (int i = 0; i < p->num_held; i++)
+        pl_shader_obj_destroy(&p->held[i]);
+    pl_buf_destroy(gpu, &p->noise);
+    free(p->text);
+    free(p->descs);
+    free(p);
+    *pass = NULL;
 }
 
 void pl_pass_run(pl_gpu gpu, const struct pl_pass_run_params *params)
 {
-    (void) params;
-    pl_msg(gpu->log, PL_LOG_ERR, "pl_pass_run: no pl_pass can exist on this backend "
-           "(pl_pass_create always fails)");
-    GPU_PRIV(gpu)->failed = true;
+    struct gpu_priv *g = GPU_PRIV(gpu);
+    struct pass_priv *p = (struct pass_priv *) params->pass;
+    if (!p) {
+        pl_msg(gpu->log, PL_LOG_ERR, "pl_pass_run: no pass");
+        goto error;
+    }
+    if (params->num_var_updates || params->push_constants || params->vertex_buf ||
+        params->index_data || params->index_buf) {
+        pl_msg(gpu->log, PL_LOG_ERR, "pl_pass_run: variables, push constants and vertex / index "
+               "buffers do not exist on this backend");
+        goto error;
+    }
+
+    pl_tex target = NULL;
+    pl_rect2d rc = {0};
+    if (p->pub.params.type == PL_PASS_RASTER) {
+        target = params->target;
+        if (!target || target->params.format != p->pub.params.target_format) {
+            pl_msg(gpu->log, PL_LOG_ERR, "pl_pass_run: `target` missing or not of the pass' "
+                   "target_format");
+            goto error;
+        }
+        rc = pl_rect_w(params->scissors) && pl_rect_h(params->scissors) ? params->scissors
+                                                                       : params->viewport;
+    } else if (p->pub.params.num_descriptors) {
+        if (!params->desc_bindings || !params->desc_bindings[0].object) {
+            pl_msg(gpu->log, PL_LOG_ERR, "pl_pass_run: the storage image is not bound");
+            goto error;
+        }
+        target = (pl_tex) params->desc_bindings[0].object;
+    }
+
+    struct plh_pass local = p->pass;    // the stored op list stays as it was recorded
+    const struct plh_pass_exec x = {
+        .pass = &local, .transpose = p->transpose, .polar_obj = p->polar_obj,
+        .detect_peak = p->detect_peak, .peak_state = p->peak_state,
+    };
+    int err;
+    if (target) {
+        if (pl_tex_params_dimension(target->params) != 2 || !target->params.storable) {
+            pl_msg(gpu->log, PL_LOG_ERR, "pl_pass_run: the target must be a storable 2D texture");
+            goto error;
+        }
+        if (!pl_rect_w(rc)) { rc.x0 = 0; rc.x1 = target->params.w; }
+        if (!pl_rect_h(rc)) { rc.y0 = 0; rc.y1 = target->params.h; }
+        const int tw = abs(pl_rect_w(rc)), th = abs(pl_rect_h(rc));
+        const int need_w = p->transpose ? p->out_h : p->out_w, need_h = p->transpose ? p->out_w : p->out_h;
+        if (need_w && need_h && (need_w != tw || need_h != th)) {
+            pl_msg(gpu->log, PL_LOG_ERR, "pl_pass_run: the pass was recorded for a %dx%d output, "
+                   "the target rect is %dx%d", need_w, need_h, tw, th);
+            goto error;
+        }
+        err = plh_pass_execute(gpu, gpu->log, &x, target, rc, params->timer, &p->noise);
+    } else {
+        // a pass without an image output (a measurement): it covers its recorded output size
+        if (!p->out_w || !p->out_h) {
+            pl_msg(gpu->log, PL_LOG_ERR, "pl_pass_run: a compute pass without a storage image "
+                   "needs a shader with a defined output size");
+            goto error;
+        }
+        memset(&local.dst, 0, sizeof(local.dst));
+        local.width = p->out_w;
+        local.height = p->out_h;
+        local.out_scale[0] = 1.0 / p->out_w;
+        local.out_scale[1] = 1.0 / p->out_h;
+        local.base_x = local.base_y = 0;
+        local.dir_x = local.dir_y = 1;
+        local.transpose = 0;
+        local.frag_x0 = local.frag_y0 = 0;
+        if (params->timer)
+            plh_timer_begin(gpu, params->timer);
+        err = plh_launch_pass(g->stream, &local);
+        if (params->timer)
+            plh_timer_end(gpu, params->timer);
+        if (!err && p->detect_peak)
+            plh_peak_pass_launched(gpu, p->peak_state);
+    }
+    if (err) {
+        pl_msg(gpu->log, PL_LOG_ERR, "pl_pass_run: %s", plh_strerror(err));
+        g->failed = true;
+    }
+error:  // (API misuse: reported above, nothing was launched)
+    return;
 }
 
 bool pl_buf_export(pl_gpu gpu, pl_buf buf)

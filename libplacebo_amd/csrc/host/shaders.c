@@ -76,8 +76,60 @@ void pl_shader_info_deref(pl_shader_info *pinfo)
     free(obj);
 }
 
+/* ---- finalized shaders that can be turned into a pl_pass ------------------------------------ */
+// A small process-wide table: ticket -> live shader. Entries are added by pl_shader_finalize and
+// removed when the shader is reset or freed, so a stale "#pl_hip_pass" line resolves to nothing.
+#include <pthread.h>
+
+static pthread_mutex_t ticket_lock = PTHREAD_MUTEX_INITIALIZER;
+static struct { uint64_t ticket; pl_shader sh; } ticket_tab[128];
+static uint64_t ticket_next = 0x1000;
+
+static void ticket_issue(pl_shader sh)
+{
+    pthread_mutex_lock(&ticket_lock);
+    for (size_t i = 0; i < PL_ARRAY_SIZE(ticket_tab); i++) {
+        if (!ticket_tab[i].sh) {
+            ticket_tab[i].sh = sh;
+            ticket_tab[i].ticket = sh->ticket = ++ticket_next;
+            break;
+        }
+    }
+    pthread_mutex_unlock(&ticket_lock);
+}
+
+static void ticket_revoke(pl_shader sh)
+{
+    if (!sh->ticket)
+        return;
+    pthread_mutex_lock(&ticket_lock);
+    for (size_t i = 0; i < PL_ARRAY_SIZE(ticket_tab); i++) {
+        if (ticket_tab[i].sh == sh)
+            ticket_tab[i].sh = NULL;
+    }
+    pthread_mutex_unlock(&ticket_lock);
+    sh->ticket = 0;
+}
+
+pl_shader plh_shader_from_glsl(const char *glsl)
+{
+    const char *tag = glsl ? strstr(glsl, "#pl_hip_pass ") : NULL;
+    if (!tag)
+        return NULL;
+    const uint64_t ticket = strtoull(tag + strlen("#pl_hip_pass "), NULL, 16);
+    pl_shader sh = NULL;
+    pthread_mutex_lock(&ticket_lock);
+    for (size_t i = 0; ticket && i < PL_ARRAY_SIZE(ticket_tab); i++) {
+        if (ticket_tab[i].sh && ticket_tab[i].ticket == ticket)
+            sh = ticket_tab[i].sh;
+    }
+    pthread_mutex_unlock(&ticket_lock);
+    return sh;
+}
+
 static void sh_release(pl_shader sh)
 {
+    ticket_revoke(sh);
     pl_shader_info_deref(&sh->info);
     for (int i = 0; i < sh->num_held; i++)
         pl_shader_obj_destroy(&sh->held[i]);
@@ -246,6 +298,13 @@ const struct pl_shader_res *pl_shader_finalize(pl_shader sh)
     if (!sh->info) {
         sh->failed = true;
         return NULL;
+    }
+    // the op list, "serialised" for pl_pass_create: a ticket that resolves to it for as long as
+    // this shader is alive and unchanged (the life time of pl_shader_res itself)
+    if (SH_GPU(sh) && sh->kind == PLH_SHADER_PASS) {
+        ticket_issue(sh);
+        if (sh->ticket)
+            sh_listf(sh, "#pl_hip_pass %016llx\n", (unsigned long long) sh->ticket);
     }
     sh->res = (struct pl_shader_res) {
         .info = sh->info,

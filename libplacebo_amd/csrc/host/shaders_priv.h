@@ -63,6 +63,10 @@ struct pl_shader_t {
     size_t listing_len, listing_cap;
     struct pl_shader_res res;
 
+    // pl_shader_finalize publishes the recorded pass under this ticket (the last line of
+    // pl_shader_res.glsl): what pl_pass_create resolves back to the op list (gpu.c)
+    uint64_t ticket;
+
     struct plh_errdiff_args *errdiff;
     // polar sampler state, for the launch-time phase-class setup (shader_sampling.c)
     void *polar_obj;
@@ -86,6 +90,23 @@ bool plh_shader_sample_polar_fused(pl_shader sh, const pl_shader pre,
 void plh_polar_pp_setup(pl_gpu gpu, pl_log log, void *polar_obj, struct plh_pass *pass);
 
 void plh_peak_pass_launched(pl_gpu gpu, pl_shader_obj state);
+
+// the finalized, still-alive shader behind a "#pl_hip_pass <ticket>" line; NULL if there is none
+pl_shader plh_shader_from_glsl(const char *glsl);
+
+// What a launch needs beyond the op list, and the launch itself: shared by pl_dispatch_finish
+// and pl_pass_run. `noise` is the caller's white-noise plane (dispatch.c: realize_white_noise).
+struct plh_pass_exec {
+    struct plh_pass *pass;      // modified: target half, polar tables, cell phases
+    bool transpose;
+    void *polar_obj;
+    bool detect_peak;
+    pl_shader_obj peak_state;
+    int out_w, out_h;           // the shader's own output size requirement, 0 = none
+};
+// returns 0, a negative plh error code, or PLH_EXEC_BAD_* (message already logged)
+int plh_pass_execute(pl_gpu gpu, pl_log log, const struct plh_pass_exec *x, pl_tex target,
+                     pl_rect2d rc, pl_timer timer, pl_buf *noise);
 
 #define SH_GPU(sh) ((sh)->params.gpu)
 

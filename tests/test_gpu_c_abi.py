@@ -60,10 +60,13 @@ def test_c_program_renders_through_the_c_abi(gpu, tmp_path):
     assert "sizeof(pl_frame)=736" in log and "sizeof(pl_frame)=736" in log2, (log, log2)
 
 
-@pytest.mark.parametrize("binary", ["gpu_contract", "gpu_contract_ref"])
+@pytest.mark.parametrize("binary", ["gpu_contract", "gpu_contract_ref", "pass_roundtrip",
+                                    "pass_roundtrip_ref"])
 def test_gpu_api_contract_from_c(gpu, binary):
     """tests/c/gpu_contract.c: buffer / texture round trips and every API misuse the reference's
-    validation front-end rejects (bounds, flags, alignment, overflow) -- compiled against this
+    validation front-end rejects (bounds, flags, alignment, overflow); tests/c/pass_roundtrip.c:
+    pl_pass_create / pl_pass_run on a recorded shader (raster and compute flavour, reuse, the
+    shader freed first) byte-identical to pl_dispatch_finish -- each compiled against this
     repository's headers and against the reference's"""
     exe = os.path.join(BUILD, binary)
     if not os.path.exists(exe):
