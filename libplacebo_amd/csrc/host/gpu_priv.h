@@ -17,11 +17,53 @@ struct fmt_priv {
     int plh;            // enum plh_fmt
 };
 
+// The backend half of a pl_gpu, after the reference's `struct pl_gpu_fns` (src/gpu.h:36-77). The
+// public pl_tex_* / pl_buf_* / pl_pass_* / pl_timer_* entry points (gpu.c) check the API contract
+// the way src/gpu.c does, complete the parameters (inferred rects, pitches) and call through
+// this table; a backend function may assume what the front-end established. gpu_hip.c is the one
+// implementation.
+struct pl_shader_t;
+struct plh_gpu_fns {
+    void (*destroy)(pl_gpu gpu);
+    pl_tex (*tex_create)(pl_gpu gpu, const struct pl_tex_params *params);
+    void (*tex_destroy)(pl_gpu gpu, pl_tex tex);
+    void (*tex_invalidate)(pl_gpu gpu, pl_tex tex);
+    void (*tex_clear_ex)(pl_gpu gpu, pl_tex dst, const union pl_clear_color color);
+    // rects complete, inside the textures, formats compatible
+    void (*tex_blit)(pl_gpu gpu, const struct pl_tex_blit_params *params);
+    // rc / row_pitch complete and checked, exactly one of ptr / buf, buffer range checked
+    bool (*tex_upload)(pl_gpu gpu, const struct pl_tex_transfer_params *params);
+    bool (*tex_download)(pl_gpu gpu, const struct pl_tex_transfer_params *params);
+    bool (*tex_poll)(pl_gpu gpu, pl_tex tex, uint64_t timeout);
+    pl_buf (*buf_create)(pl_gpu gpu, const struct pl_buf_params *params);
+    void (*buf_destroy)(pl_gpu gpu, pl_buf buf);
+    void (*buf_write)(pl_gpu gpu, pl_buf buf, size_t offset, const void *data, size_t size);
+    bool (*buf_read)(pl_gpu gpu, pl_buf buf, size_t offset, void *dest, size_t size);
+    void (*buf_copy)(pl_gpu gpu, pl_buf dst, size_t dst_offset, pl_buf src, size_t src_offset,
+                     size_t size);
+    bool (*buf_export)(pl_gpu gpu, pl_buf buf);
+    bool (*buf_poll)(pl_gpu gpu, pl_buf buf, uint64_t timeout);
+    // `recorded`: the live shader params->glsl_shader names (resolved by the front-end)
+    pl_pass (*pass_create)(pl_gpu gpu, const struct pl_pass_params *params,
+                           struct pl_shader_t *recorded);
+    void (*pass_destroy)(pl_gpu gpu, pl_pass pass);
+    // target / rc: the image the pass writes and the rect inside it (NULL: a pass without one)
+    void (*pass_run)(pl_gpu gpu, const struct pl_pass_run_params *params, pl_tex target,
+                     pl_rect2d rc);
+    pl_timer (*timer_create)(pl_gpu gpu);
+    void (*timer_destroy)(pl_gpu gpu, pl_timer timer);
+    uint64_t (*timer_query)(pl_gpu gpu, pl_timer timer);
+    void (*gpu_flush)(pl_gpu gpu);
+    void (*gpu_finish)(pl_gpu gpu);
+    bool (*gpu_is_failed)(pl_gpu gpu);
+};
+
 #define PLH_STAGE_SLOTS 8
 #define PLH_STAGE_BYTES (64 * 1024)
 
 struct gpu_priv {
     struct pl_gpu_t gpu;
+    const struct plh_gpu_fns *fns;
     struct pl_hip_t hip;
     struct plh_dev_info info;
     int device;
@@ -67,6 +109,7 @@ struct pl_timer_t {
 #define TEX_PRIV(t)  ((struct tex_priv *) (t))
 #define BUF_PRIV(b)  ((struct buf_priv *) (b))
 #define FMT_PRIV(f)  ((const struct fmt_priv *) (f))
+#define GPU_FNS(g)   (GPU_PRIV(g)->fns)
 
 void plh_tex_view(pl_tex tex, struct plh_view *out);
 void plh_timer_begin(pl_gpu gpu, pl_timer t);
