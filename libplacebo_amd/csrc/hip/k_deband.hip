@@ -123,8 +123,148 @@ void k_deband(const plh_pass p_)
     plh_store_n<1>(p.dst, sx, sy, ok, outs);
 }
 
+/*
+ * k_deband_fast: the renderer's debanding pass as one small kernel -- a whole rgba16 plane at
+ * native resolution (output pixel (x, y) sits on texel (x, y)), clamp addressing, RGB mask,
+ * ops = [identity PLANE_MAP] [LINEARIZE], rgba16hf target. Same arithmetic as k_deband statement
+ * for statement (the PRNG, the tap positions from the interpolated attribute, the order of the
+ * four additions, op_linearize itself), bit-identical output (tests/test_gpu_ortho_deband.py
+ * renders with both); what goes is what the general kernel pays for being general: the op
+ * interpreter, format and address-mode switches, 64-bit address arithmetic, the alpha channel of
+ * the four taps, half of the store instructions. Two horizontally adjacent pixels per lane: one
+ * 16-byte load for the two centre texels, one 16-byte store.
+ */
+#define DBF_BW 64
+#define DBF_BH 4
+
+__global__ __launch_bounds__(DBF_BW * DBF_BH)
+void k_deband_fast(const plh_pass p_)
+{
+    const plh_pass &p = plh_kernarg_pass();
+    const plh_sampler_args &s = p.s;
+    const int idx0 = 2 * (blockIdx.x * DBF_BW + threadIdx.x);
+    const int idy = blockIdx.y * DBF_BH + threadIdx.y;
+    if (idx0 >= p.width || idy >= p.height)
+        return;
+    const char *sp = (const char *) s.src.ptr;
+    const uint32_t spitch = s.src.pitch;
+    const int srcw = s.src.w, srch = s.src.h;
+    const float sw = (float) srcw, sh = (float) srch;
+    const bool has_map = p.num_ops == 2;    // [identity PLANE_MAP] LINEARIZE, or LINEARIZE alone
+    const plh_op &o_map = p.ops[0], &o_lin = p.ops[p.num_ops - 1];
+    const float my = p.out_scale[1] * ((float) idy + 0.5f);
+
+    // the two centre texels (idx0 is even and rows are 256-byte aligned: 16-byte aligned)
+    const bool two = idx0 + 1 < p.width;
+    uint4 centre;
+    if (two) {
+        centre = *(const uint4 *) (sp + (uint32_t) idy * spitch + (uint32_t) idx0 * 8u);
+    } else {
+        const uint2 c0 = *(const uint2 *) (sp + (uint32_t) idy * spitch + (uint32_t) idx0 * 8u);
+        centre = make_uint4(c0.x, c0.y, c0.x, c0.y);
+    }
+
+    uint32_t packed[2][2];
+#pragma unroll
+    for (int q = 0; q < 2; q++) {
+        const int idx = idx0 + q;
+        const float mx = p.out_scale[0] * ((float) idx + 0.5f);
+        const float px = plh_attr(s.pos, 0, mx, my), py = plh_attr(s.pos, 1, mx, my);
+        const uint32_t cx = q ? centre.z : centre.x, cy = q ? centre.w : centre.y;
+        float4_t color = { plh_un16(cx & 0xffffu), plh_un16(cx >> 16), plh_un16(cy & 0xffffu),
+                           plh_un16(cy >> 16) };
+        float res[3] = { color.x, color.y, color.z };
+
+        prng3 st = { (uint32_t) ((float) (idx + p.frag_x0) + 0.5f),
+                     (uint32_t) ((float) (idy + p.frag_y0) + 0.5f), s.prng_seed };
+        float rnd[3];
+        for (int i = 1; i <= s.iterations; i++) {
+            pcg3d(st, rnd);
+            float dx = rnd[0] * ((float) i * s.db_radius);
+            const float rev = (rnd[1] * 6.283185f) * 0.15915494309189532f;
+            const float dy = dx * __builtin_amdgcn_sinf(rev);
+            dx = dx * __builtin_amdgcn_cosf(rev);
+            const float ox[4] = { dx, -dx, -dx, dx }, oy[4] = { dy, dy, -dy, -dy };
+            uint2 raw[4];
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const float qx = px + s.pt[0] * ox[k], qy = py + s.pt[1] * oy[k];
+                const int tx = min(max((int) __builtin_floorf(qx * sw), 0), srcw - 1);
+                const int ty = min(max((int) __builtin_floorf(qy * sh), 0), srch - 1);
+                raw[k] = *(const uint2 *) (sp + (uint32_t) ty * spitch + (uint32_t) tx * 8u);
+            }
+            float avg[3] = {0.0f, 0.0f, 0.0f};
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                avg[0] += plh_un16(raw[k].x & 0xffffu);
+                avg[1] += plh_un16(raw[k].x >> 16);
+                avg[2] += plh_un16(raw[k].y & 0xffffu);
+            }
+            const float bound = s.db_threshold / (float) i;
+#pragma unroll
+            for (int c = 0; c < 3; c++) {
+                const float a = avg[c] * 0.25f;
+                const float diff = __builtin_fabsf(res[c] - a);
+                res[c] = diff > bound ? res[c] : a;
+            }
+        }
+        if (s.db_grain > 0.0f) {
+            pcg3d(st, rnd);
+#pragma unroll
+            for (int c = 0; c < 3; c++) {
+                const float strength = fminf(__builtin_fabsf(res[c] - s.db_neutral[c]), s.db_grain);
+                res[c] += strength * (rnd[c] - 0.5f);
+            }
+        }
+        color.x = res[0] * s.scale; color.y = res[1] * s.scale; color.z = res[2] * s.scale;
+        color.w *= s.scale;
+        // identity PLANE_MAP of the first i1 components: the others take their neutral values
+        if (has_map) {
+            if (o_map.i1 < 4) color.w = o_map.f[3];
+            if (o_map.i1 < 3) color.z = o_map.f[2];
+            if (o_map.i1 < 2) color.y = o_map.f[1];
+        }
+        op_linearize(color, o_lin);
+        packed[q][0] = (uint32_t) plh_f2h(color.x) | ((uint32_t) plh_f2h(color.y) << 16);
+        packed[q][1] = (uint32_t) plh_f2h(color.z) | ((uint32_t) plh_f2h(color.w) << 16);
+    }
+
+    char *dp = (char *) p.dst.ptr + (size_t) idy * p.dst.pitch + (size_t) idx0 * 8;
+    if (two)
+        *(uint4 *) dp = make_uint4(packed[0][0], packed[0][1], packed[1][0], packed[1][1]);
+    else
+        *(uint2 *) dp = make_uint2(packed[0][0], packed[0][1]);
+}
+
+// the shape k_deband_fast is written for
+static bool deband_fast_applies(const plh_pass *pass)
+{
+    const plh_sampler_args &s = pass->s;
+    const char *env = getenv("PL_HIP_DEBAND_FAST");
+    if (env && env[0] == '0')
+        return false;
+    const bool native = pass->width == s.src.w && pass->height == s.src.h &&
+        s.pos[0][0] == 0.0f && s.pos[0][1] == 0.0f && s.pos[3][0] == 1.0f && s.pos[3][1] == 1.0f &&
+        s.pos[1][0] == 1.0f && s.pos[1][1] == 0.0f && s.pos[2][0] == 0.0f && s.pos[2][1] == 1.0f;
+    return native && s.src.fmt == PLH_FMT_RGBA16 && pass->dst.fmt == PLH_FMT_RGBA16F &&
+           s.address_mode == PLH_ADDRESS_CLAMP && (s.comp_mask & 7u) == 7u && !pass->transpose &&
+           pass->base_x == 0 && pass->base_y == 0 && pass->dir_x == 1 && pass->dir_y == 1 &&
+           pass->dst.w >= pass->width && pass->dst.h >= pass->height &&
+           (size_t) s.src.pitch * s.src.h < (1ull << 32) &&
+           !pass->num_pre_ops &&
+           ((pass->num_ops == 1 && pass->ops[0].kind == PLH_OP_LINEARIZE) ||
+            (pass->num_ops == 2 && pass->ops[0].kind == PLH_OP_PLANE_MAP && pass->ops[0].i2 &&
+             pass->ops[0].i1 >= 1 && pass->ops[1].kind == PLH_OP_LINEARIZE));
+}
+
 int plh_launch_deband(hipStream_t stream, const plh_pass *pass)
 {
+    if (deband_fast_applies(pass)) {
+        const dim3 grid((pass->width + 2 * DBF_BW - 1) / (2 * DBF_BW), (pass->height + DBF_BH - 1) / DBF_BH);
+        hipLaunchKernelGGL(k_deband_fast, grid, dim3(DBF_BW, DBF_BH), 0, stream, *pass);
+        const hipError_t err = hipGetLastError();
+        return err == hipSuccess ? 0 : -(int) err;
+    }
     const dim3 block(DEBAND_BW, DEBAND_BH);
     const dim3 grid((pass->width + DEBAND_BW - 1) / DEBAND_BW,
                     (pass->height + DEBAND_BH - 1) / DEBAND_BH);

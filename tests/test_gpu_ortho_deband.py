@@ -192,3 +192,29 @@ def test_deband_prng_is_temporal(gpu):
         outs.append(d.download())
     assert not np.array_equal(outs[0], outs[1])
     t.destroy(); d.destroy()
+
+
+@pytest.mark.parametrize("kw", [dict(), dict(iterations=3, radius=20.0), dict(iterations=0),
+                                dict(grain=0.0, threshold=8.0)])
+@pytest.mark.parametrize("size", [(201, 75), (128, 64)])
+@pytest.mark.parametrize("trc", ["pq", "bt1886"])
+def test_deband_fast_kernel_is_bit_identical(gpu, kw, size, trc, monkeypatch):
+    """k_deband_fast (native-resolution rgba16 plane, [PLANE_MAP] LINEARIZE, rgba16hf target --
+    the renderer's debanding pass) against the general kernel (PL_HIP_DEBAND_FAST=0): the same
+    arithmetic, so the same f16 codes; odd widths exercise the single-pixel tail"""
+    w, h = size
+    img = util.random_rgba16(w, h, seed=17)
+    t = gpu.tex_create(w, h, "rgba16", img)
+    csp = pl.color_space("bt2020" if trc == "pq" else "bt709", trc)
+    outs = []
+    for fast in ("1", "0"):
+        monkeypatch.setenv("PL_HIP_DEBAND_FAST", fast)
+        d = gpu.tex_create(w, h, "rgba16hf")
+        sh = gpu.begin()
+        assert sh.deband(t, components=3, **kw), gpu.messages[-3:]
+        sh.linearize(csp)
+        assert sh.finish(d), gpu.messages[-3:]
+        outs.append(d.download().view(np.uint16))
+        d.destroy()
+    assert np.array_equal(outs[0], outs[1]), util.diff_stats(outs[0], outs[1])
+    t.destroy()
