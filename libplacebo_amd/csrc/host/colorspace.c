@@ -26,30 +26,28 @@
 /* ------------------------------------------------------------------------ */
 /* colour systems / representation                                           */
 
+// Small classifications of the enums are written as membership in a bit set.
+#define MEMBER(e) (UINT64_C(1) << (e))
+static inline bool among(int value, uint64_t set)
+{
+    return value >= 0 && value < 64 && ((set >> value) & 1);
+}
+
 bool pl_color_system_is_ycbcr_like(enum pl_color_system sys)
 {
-    switch (sys) {
-    case PL_COLOR_SYSTEM_UNKNOWN:
-    case PL_COLOR_SYSTEM_RGB:
-    case PL_COLOR_SYSTEM_XYZ:
-        return false;
-    default:
-        return sys > PL_COLOR_SYSTEM_UNKNOWN && sys < PL_COLOR_SYSTEM_COUNT;
-    }
+    // every known system except the tristimulus ones carries one luma-like and two
+    // difference-like channels
+    const bool known = sys > PL_COLOR_SYSTEM_UNKNOWN && sys < PL_COLOR_SYSTEM_COUNT;
+    return known && !among(sys, MEMBER(PL_COLOR_SYSTEM_RGB) | MEMBER(PL_COLOR_SYSTEM_XYZ));
 }
 
 bool pl_color_system_is_linear(enum pl_color_system sys)
 {
-    switch (sys) {
-    case PL_COLOR_SYSTEM_BT_2020_C:
-    case PL_COLOR_SYSTEM_BT_2100_PQ:
-    case PL_COLOR_SYSTEM_BT_2100_HLG:
-    case PL_COLOR_SYSTEM_DOLBYVISION:
-    case PL_COLOR_SYSTEM_XYZ:
-        return false;
-    default:
-        return true;
-    }
+    // systems whose decoding is more than a matrix: constant luminance, ICtCp, Dolby Vision
+    // reshaping, XYZ's own gamma
+    return !among(sys, MEMBER(PL_COLOR_SYSTEM_BT_2020_C) | MEMBER(PL_COLOR_SYSTEM_BT_2100_PQ) |
+                       MEMBER(PL_COLOR_SYSTEM_BT_2100_HLG) | MEMBER(PL_COLOR_SYSTEM_DOLBYVISION) |
+                       MEMBER(PL_COLOR_SYSTEM_XYZ));
 }
 
 static const char *const system_names[PL_COLOR_SYSTEM_COUNT] = {
@@ -111,12 +109,12 @@ void pl_color_repr_merge(struct pl_color_repr *orig, const struct pl_color_repr 
 
 enum pl_color_levels pl_color_levels_guess(const struct pl_color_repr *repr)
 {
-    if (repr->sys == PL_COLOR_SYSTEM_DOLBYVISION)
-        return PL_COLOR_LEVELS_FULL;
-    if (repr->levels)
+    // an explicit tag wins, except that Dolby Vision is full range by definition
+    const bool full_by_nature = repr->sys == PL_COLOR_SYSTEM_DOLBYVISION ||
+                                !pl_color_system_is_ycbcr_like(repr->sys);
+    if (repr->levels && repr->sys != PL_COLOR_SYSTEM_DOLBYVISION)
         return repr->levels;
-    return pl_color_system_is_ycbcr_like(repr->sys) ? PL_COLOR_LEVELS_LIMITED
-                                                    : PL_COLOR_LEVELS_FULL;
+    return full_by_nature ? PL_COLOR_LEVELS_FULL : PL_COLOR_LEVELS_LIMITED;
 }
 
 float pl_color_repr_normalize(struct pl_color_repr *repr)
@@ -151,17 +149,10 @@ float pl_color_repr_normalize(struct pl_color_repr *repr)
 
 bool pl_color_primaries_is_wide_gamut(enum pl_color_primaries prim)
 {
-    switch (prim) {
-    case PL_COLOR_PRIM_UNKNOWN:
-    case PL_COLOR_PRIM_BT_601_525:
-    case PL_COLOR_PRIM_BT_601_625:
-    case PL_COLOR_PRIM_BT_709:
-    case PL_COLOR_PRIM_BT_470M:
-    case PL_COLOR_PRIM_EBU_3213:
-        return false;
-    default:
-        return true;
-    }
+    // the standard-gamut containers (and "unknown", which is inferred as one of them)
+    return !among(prim, MEMBER(PL_COLOR_PRIM_UNKNOWN) | MEMBER(PL_COLOR_PRIM_BT_601_525) |
+                        MEMBER(PL_COLOR_PRIM_BT_601_625) | MEMBER(PL_COLOR_PRIM_BT_709) |
+                        MEMBER(PL_COLOR_PRIM_BT_470M) | MEMBER(PL_COLOR_PRIM_EBU_3213));
 }
 
 static const char *const primaries_names[PL_COLOR_PRIM_COUNT] = {
@@ -365,17 +356,10 @@ bool pl_color_space_is_hdr(const struct pl_color_space *csp)
 
 bool pl_color_space_is_black_scaled(const struct pl_color_space *csp)
 {
-    switch (csp->transfer) {
-    case PL_COLOR_TRC_BT_1886:
-    case PL_COLOR_TRC_PQ:
-    case PL_COLOR_TRC_SCRGB:
-    case PL_COLOR_TRC_V_LOG:
-    case PL_COLOR_TRC_S_LOG1:
-    case PL_COLOR_TRC_S_LOG2:
-        return false;
-    default:
-        return true;
-    }
+    // curves with an absolute black point of their own are not rescaled to the display's
+    return !among(csp->transfer, MEMBER(PL_COLOR_TRC_BT_1886) | MEMBER(PL_COLOR_TRC_PQ) |
+                                 MEMBER(PL_COLOR_TRC_SCRGB) | MEMBER(PL_COLOR_TRC_V_LOG) |
+                                 MEMBER(PL_COLOR_TRC_S_LOG1) | MEMBER(PL_COLOR_TRC_S_LOG2));
 }
 
 /* ------------------------------------------------------------------------ */

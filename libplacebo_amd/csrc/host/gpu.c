@@ -32,26 +32,35 @@ bool pl_fmt_is_float(pl_fmt fmt)
            fmt->type == PL_FMT_FLOAT;
 }
 
+// does `fmt` satisfy a pl_find_fmt query?
+static bool fmt_answers(pl_fmt fmt, enum pl_fmt_type type, int comps, int min_depth, int host_bits,
+                        enum pl_fmt_caps caps)
+{
+    if (fmt->type != type || fmt->num_components != comps || (fmt->caps & caps) != caps)
+        return false;
+    for (int i = 0; i < comps; i++) {
+        if (fmt->component_depth[i] < min_depth)
+            return false;
+    }
+    if (!host_bits)
+        return true;
+    // a host representation was asked for: plain, in order, exactly host_bits per component
+    if (fmt->opaque || !pl_fmt_is_ordered(fmt) || fmt->texel_size * 8 != (size_t) host_bits * comps)
+        return false;
+    for (int i = 0; i < comps; i++) {
+        if (fmt->host_bits[i] != host_bits)
+            return false;
+    }
+    return true;
+}
+
 pl_fmt pl_find_fmt(pl_gpu gpu, enum pl_fmt_type type, int num_components,
                    int min_depth, int host_bits, enum pl_fmt_caps caps)
 {
+    // (formats are sorted best first)
     for (int n = 0; n < gpu->num_formats; n++) {
-        pl_fmt fmt = gpu->formats[n];
-        if (fmt->type != type || fmt->num_components != num_components)
-            continue;
-        if ((fmt->caps & caps) != caps)
-            continue;
-        if (host_bits && (fmt->opaque || !pl_fmt_is_ordered(fmt) ||
-                          fmt->texel_size * 8 != (size_t) host_bits * num_components))
-            continue;
-
-        bool ok = true;
-        for (int i = 0; i < fmt->num_components; i++) {
-            ok &= fmt->component_depth[i] >= min_depth;
-            ok &= !host_bits || fmt->host_bits[i] == host_bits;
-        }
-        if (ok)
-            return fmt;
+        if (fmt_answers(gpu->formats[n], type, num_components, min_depth, host_bits, caps))
+            return gpu->formats[n];
     }
     return NULL;
 }

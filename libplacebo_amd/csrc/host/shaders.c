@@ -188,38 +188,44 @@ bool pl_shader_output_size(const pl_shader sh, int *w, int *h)
     return true;
 }
 
+// Every recording entry point starts here: may the shader take another stage that consumes
+// `insig` and (optionally) fixes the output size to w x h? On success the shader produces a colour.
 bool sh_require(pl_shader sh, enum pl_shader_sig insig, int w, int h)
 {
-    if (sh->failed) {
-        SH_FAIL(sh, "Attempting to modify a failed shader!");
+    static const char *const sig_name[] = { "PL_SHADER_SIG_NONE", "PL_SHADER_SIG_COLOR",
+                                            "PL_SHADER_SIG_SAMPLER" };
+    const char *why = NULL;
+    if (sh->failed)
+        why = "Attempting to modify a failed shader!";
+    else if (!sh->mutable_)
+        why = "Attempted to modify an immutable shader!";
+    if (why) {
+        SH_FAIL(sh, "%s", why);
         return false;
     }
-    if (!sh->mutable_) {
-        SH_FAIL(sh, "Attempted to modify an immutable shader!");
-        return false;
-    }
-    if ((w && sh->output_w && sh->output_w != w) ||
-        (h && sh->output_h && sh->output_h != h)) {
+
+    const bool w_clash = w && sh->output_w && sh->output_w != w;
+    const bool h_clash = h && sh->output_h && sh->output_h != h;
+    if (w_clash || h_clash) {
         SH_FAIL(sh, "Illegal sequence of shader operations: Incompatible output "
                 "size requirements %dx%d and %dx%d", sh->output_w, sh->output_h, w, h);
         return false;
     }
 
-    static const char *names[] = { "PL_SHADER_SIG_NONE", "PL_SHADER_SIG_COLOR",
-                                   "PL_SHADER_SIG_SAMPLER" };
-    if (!sh->output && insig) {
-        // nothing produced a colour yet: it becomes an explicit input
+    // an empty shader adopts the stage's input as its own; otherwise the signatures must chain
+    if (sh->output == PL_SHADER_SIG_NONE && insig != PL_SHADER_SIG_NONE) {
         sh->input = insig;
     } else if (sh->output != insig) {
         SH_FAIL(sh, "Illegal sequence of shader operations! Current output signature "
-                "is '%s', but called operation expects '%s'!",
-                names[sh->output], names[insig]);
+                "is '%s', but called operation expects '%s'!", sig_name[sh->output], sig_name[insig]);
         return false;
     }
 
     sh->output = PL_SHADER_SIG_COLOR;
-    sh->output_w = PL_DEF(sh->output_w, w);
-    sh->output_h = PL_DEF(sh->output_h, h);
+    if (!sh->output_w)
+        sh->output_w = w;
+    if (!sh->output_h)
+        sh->output_h = h;
     return true;
 }
 
