@@ -229,12 +229,11 @@ def test_colorspace_decision_functions_match_reference_code(libs):
 
     for lib in (ref, our):
         for fn in ("pl_color_system_is_ycbcr_like", "pl_color_system_is_linear",
-                   "pl_color_primaries_is_wide_gamut", "pl_color_space_is_black_scaled",
-                   "pl_color_transfer_is_hdr"):
+                   "pl_color_primaries_is_wide_gamut", "pl_color_space_is_black_scaled"):
             getattr(lib, fn).restype = C.c_bool
     for v in range(-1, 24):
         for fn in ("pl_color_system_is_ycbcr_like", "pl_color_system_is_linear",
-                   "pl_color_primaries_is_wide_gamut", "pl_color_transfer_is_hdr"):
+                   "pl_color_primaries_is_wide_gamut"):
             assert getattr(ref, fn)(v) == getattr(our, fn)(v), (fn, v)
         cs = Csp(primaries=1, transfer=max(v, 0))
         assert ref.pl_color_space_is_black_scaled(C.byref(cs)) == our.pl_color_space_is_black_scaled(C.byref(cs))
