@@ -180,8 +180,11 @@ class Stream:
                 peak_detect_params=pl.peak_detect_params(percentile=99.995))
             icsp, tcsp, trepr = hdr, bt1886, ten_bit
 
+        # per-pass timings travel through pl_render_params.info_callback -- a Python callback per
+        # pass and frame. It is installed for the per-pass measurement only (measure_passes),
+        # not inside the timed region: an application does not time every pass either.
         self._cb = capi.RENDER_INFO_CB(self._info)
-        self.params.info_callback = C.cast(self._cb, C.c_void_p)
+        self.params.info_callback = None
         self.images = [pl.frame(t, components=3, color=icsp) for t in self.srcs]
         if self.nv12:
             self.images = []
@@ -292,6 +295,7 @@ def kernel_symbol(workload, name):
 def measure_passes(st, frames=48):
     """per-pass GPU time: HIP events recorded around every launch on the stream the launches go
     to (pl_timer), reported through pl_render_params.info_callback"""
+    st.params.info_callback = C.cast(st._cb, C.c_void_p)
     st.pass_ns.clear()
     for _ in range(frames):
         st.step()
@@ -647,7 +651,9 @@ def main():
 
     out = None
     if rank == 0:
-        roofline = None if args.bare else roofline_block(args.workload, measure_passes(st))
+        # the same K steps again, this time with a HIP event pair around every launch
+        roofline = None if args.bare else roofline_block(args.workload,
+                                                         measure_passes(st, args.steps))
         frames = args.steps * world
         out = {
             "metric": baseline_metric(),
