@@ -713,6 +713,7 @@ def main():
     if rank == 0:
         print(json.dumps(out), flush=True)
     if dist is not None:
+        dist.barrier()      # rank 0 measured per-pass times after the timed region: leave together
         dist.destroy_process_group()
 
 
