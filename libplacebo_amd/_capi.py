@@ -9,7 +9,8 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # PL_HIP_LIB: load another build of the library (A/B kernel experiments, tools/ab.sh)
-LIB_PATH = os.environ.get("PL_HIP_LIB") or os.path.join(_HERE, "libplacebo_hip.so")
+_DEFAULT_LIB_PATH = os.path.join(_HERE, "libplacebo_hip.so")
+LIB_PATH = os.environ.get("PL_HIP_LIB") or _DEFAULT_LIB_PATH
 
 
 class BuildError(RuntimeError):
@@ -21,7 +22,28 @@ def load():
         raise BuildError(
             f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
             "(or `make -C libplacebo_amd/csrc`). There is no Python/CPU fallback.")
+    _warn_if_stale()
     return C.CDLL(LIB_PATH)  # RTLD_LOCAL: never interpose on the checker libraries
+
+
+def _warn_if_stale():
+    """A library older than its sources measures (and tests) the previous kernels: say so."""
+    import glob
+    import sys
+    if LIB_PATH != _DEFAULT_LIB_PATH:
+        return
+    here = os.path.dirname(os.path.abspath(__file__))
+    srcs = [f for pat in ("csrc/host/*.[ch]", "csrc/hip/*.hip", "csrc/hip/*.hiph", "csrc/hip/*.h")
+            for f in glob.glob(os.path.join(here, pat))]
+    try:
+        built = os.path.getmtime(LIB_PATH)
+        newer = [os.path.basename(f) for f in srcs if os.path.getmtime(f) > built + 1.0]
+    except OSError:
+        return
+    if newer:
+        print(f"libplacebo_amd: WARNING: {os.path.basename(LIB_PATH)} is older than "
+              f"{', '.join(sorted(newer)[:4])}{' ...' if len(newer) > 4 else ''}: rebuild "
+              "(make -C libplacebo_amd/csrc) before measuring", file=sys.stderr)
 
 
 # ---- common.h ---------------------------------------------------------------
