@@ -102,8 +102,13 @@ def synthetic_frame(workload, w, h):
 class Stream:
     """One independent video stream on one GPU: a pl_hip backend + a pl_renderer."""
 
+    # pl_hip_params.async_measure (include/libplacebo/hip.h): the measuring pass of frame N+1 on a
+    # second HIP stream beside the scaler of frame N. Same frames bit for bit
+    # (tests/test_gpu_async_measure.py); --async-measure 0 turns it off for an A/B.
+    async_measure = True
+
     def __init__(self, device, workload, pool):
-        self.g = pl.HipGpu(device)
+        self.g = pl.HipGpu(device, async_measure=Stream.async_measure)
         self.rr = pl.Renderer(self.g)
         self.workload = workload
         (sw, sh), (dw, dh), _, _ = WORKLOADS[workload]
@@ -294,11 +299,15 @@ def kernel_symbol(workload, name):
 
 def measure_passes(st, frames=48):
     """per-pass GPU time: HIP events recorded around every launch on the stream the launches go
-    to (pl_timer), reported through pl_render_params.info_callback"""
+    to (pl_timer), reported through pl_render_params.info_callback. With async_measure the frames
+    are kept apart here (pl_gpu_finish after each): a kernel's duration is its own, not that of two
+    kernels of neighbouring frames sharing the CUs -- the overlap shows in `value`, not here."""
     st.params.info_callback = C.cast(st._cb, C.c_void_p)
     st.pass_ns.clear()
     for _ in range(frames):
         st.step()
+        if Stream.async_measure:
+            st.g.finish()
     st.g.finish()
     st.step()           # drains the last timers
     st.g.finish()
@@ -356,7 +365,7 @@ def measure_traffic(workload, symbol, timeout=240):
             env = dict(os.environ, TMPDIR="/tmp", PL_BENCH_CHILD="1")
             cmd = [rocprof, "--pmc", counter, "--kernel-trace", "--output-format", "csv", "-d", td,
                    "--", sys.executable, os.path.abspath(__file__), "--workload", workload,
-                   "--steps", "6", "--warmup", "2", "--bare"]
+                   "--steps", "6", "--warmup", "2", "--bare", "--async-measure", "0"]
             try:
                 r = subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, text=True,
                                    timeout=timeout)
@@ -403,7 +412,7 @@ def measure_trace(workload, symbol, timeout=240):
         env = dict(os.environ, TMPDIR="/tmp", PL_BENCH_CHILD="1")
         cmd = [rocprof, "--kernel-trace", "--stats", "--output-format", "csv", "-d", td, "--",
                sys.executable, os.path.abspath(__file__), "--workload", workload, "--steps", "40",
-               "--warmup", "8", "--bare"]
+               "--warmup", "8", "--bare", "--async-measure", "0"]    # (kernels one at a time)
         try:
             r = subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, text=True,
                                timeout=timeout)
@@ -514,10 +523,15 @@ def run_timed(st, steps, warmup, sync=None, barrier=None):
     t0 = time.perf_counter()
     for _ in range(steps):
         st.step()
+    t1 = time.perf_counter()
     st.g.finish()
+    t2 = time.perf_counter()
     if sync:
         sync()
     elapsed = time.perf_counter() - t0
+    if os.environ.get("PL_BENCH_DEBUG"):
+        print(f"bench: steps {1e3 * (t1 - t0):.2f} ms, finish {1e3 * (t2 - t1):.2f} ms, "
+              f"device sync {1e3 * (elapsed - (t2 - t0)):.2f} ms", file=sys.stderr)
     if barrier:
         barrier()
     return elapsed
@@ -607,6 +621,8 @@ def main():
     ap.add_argument("--scene-peak-allreduce", action="store_true",
                     help="ranks render frames of one scene: all-reduce the peak-detection buffer "
                          "over RCCL every frame (BASELINE configs[4])")
+    ap.add_argument("--async-measure", type=int, default=1, choices=[0, 1],
+                    help="pl_hip_params.async_measure for every stream (default 1)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-companions", action="store_true",
                     help="skip the per-config 'rooflines' blocks")
@@ -616,6 +632,7 @@ def main():
     ap.add_argument("--bare", action="store_true",
                     help="timed loop only (what the --pmc child processes run)")
     args = ap.parse_args()
+    Stream.async_measure = bool(args.async_measure)
     if args.bare:
         args.no_cpu_baseline = args.no_companions = args.no_traffic = args.no_concurrent = True
 
@@ -631,6 +648,11 @@ def main():
         torch.cuda.set_device(local_rank)
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    # torch's device state is created now, not by the first torch.cuda.synchronize() of the timed
+    # region's bracket: its lazy initialisation leaves work behind that a later device-wide
+    # synchronize waits for (seen as a constant ~40 ms on top of any number of frames)
+    torch.cuda.set_device(local_rank)
+    torch.cuda.synchronize()
 
     def barrier():
         if dist is not None:
@@ -675,6 +697,7 @@ def main():
                                         else "rgba16"),
                 "dst": f"{dw}x{dh} rgba16",
                 "pool": pool,
+                "pl_hip_params": {"async_measure": bool(args.async_measure)},
                 "api": "pl_queue_update + pl_render_image_mix" if args.workload.startswith("mix") else "pl_render_image",
                 "measured": "output Mpixels/s through pl_render_image, one independent stream per GPU",
                 "render_errors": st.rr.errors(),   # pl_render_error bits: no stage may be disabled

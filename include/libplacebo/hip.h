@@ -30,6 +30,13 @@ struct pl_hip_params {
     // uses it to decide e.g. whether error diffusion fits in LDS
     // (renderer.c:2290); CDNA4 allows up to 163840.
     size_t max_shmem_size;
+    // Run the HDR measurement pass of a frame (pl_shader_detect_peak: source plane -> FBO +
+    // brightness statistics) on a second HIP stream, so that it overlaps the previous frame's
+    // scaling / colour-mapping pass, which is still running when the next pl_render_image call
+    // arrives. The counterpart of pl_vulkan_params.async_compute (vulkan.h). Results are
+    // identical; the renderer keeps two FBOs for that pass. Ignored (one stream) when `stream`
+    // is given or a peak exchange is installed. Off by default.
+    bool async_measure;
 };
 
 #define pl_hip_params(...) (&(struct pl_hip_params) { __VA_ARGS__ })

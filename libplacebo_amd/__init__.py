@@ -125,6 +125,13 @@ class Texture:
         if not lib().pl_tex_upload(self.gpu.gpu, C.byref(xp)):
             raise RuntimeError("pl_tex_upload failed")
 
+    def blit_from(self, src):
+        """whole-texture 1:1 copy of `src` into this texture, queued on the stream (no host sync)"""
+        bp = capi.TexBlitParams(src=src.ptr, dst=self.ptr,
+                                src_rc=capi.Rect3d(0, 0, 0, src.w, src.h, 1),
+                                dst_rc=capi.Rect3d(0, 0, 0, self.w, self.h, 1))
+        lib().pl_tex_blit(self.gpu.gpu, C.byref(bp))
+
     def download(self):
         dt, nc = _FMT_DTYPES[self.fmt_name]
         out = np.empty((self.h, self.w, nc), dtype=dt)
@@ -285,7 +292,7 @@ class Shader:
 class HipGpu:
     """pl_hip backend + a pl_dispatch, as a context manager."""
 
-    def __init__(self, device=0, stream=None, log_level=3, max_shmem_size=0):
+    def __init__(self, device=0, stream=None, log_level=3, max_shmem_size=0, async_measure=False):
         L = lib()
         self._msgs = []
 
@@ -295,7 +302,8 @@ class HipGpu:
         self._cb = capi.LOG_CB(_cb)
         lp = capi.LogParams(log_cb=self._cb, log_priv=None, log_level=log_level)
         self.log = C.c_void_p(L.pl_log_create_365(365, C.byref(lp)))
-        hp = capi.HipParams(device=device, stream=stream, max_shmem_size=max_shmem_size)
+        hp = capi.HipParams(device=device, stream=stream, max_shmem_size=max_shmem_size,
+                            async_measure=async_measure)
         self.hip = L.pl_hip_create(self.log, C.byref(hp))
         if not self.hip:
             raise RuntimeError("pl_hip_create failed: " + "; ".join(m for _, m in self._msgs))

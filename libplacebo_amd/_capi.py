@@ -174,7 +174,8 @@ class Hip(C.Structure):
 
 
 class HipParams(C.Structure):
-    _fields_ = [("device", C.c_int), ("stream", C.c_void_p), ("max_shmem_size", C.c_size_t)]
+    _fields_ = [("device", C.c_int), ("stream", C.c_void_p), ("max_shmem_size", C.c_size_t),
+                ("async_measure", C.c_bool)]
 
 
 class HipWrapParams(C.Structure):
@@ -202,6 +203,11 @@ class TexTransferParams(C.Structure):
                 ("depth_pitch", C.c_size_t), ("timer", C.c_void_p), ("callback", C.c_void_p),
                 ("priv", C.c_void_p), ("buf", C.c_void_p), ("buf_offset", C.c_size_t),
                 ("ptr", C.c_void_p), ("no_import", C.c_bool)]
+
+
+class TexBlitParams(C.Structure):
+    _fields_ = [("src", C.POINTER(Tex)), ("dst", C.POINTER(Tex)), ("src_rc", Rect3d),
+                ("dst_rc", Rect3d), ("sample_mode", C.c_int)]
 
 
 # ---- shaders ----------------------------------------------------------------------
@@ -543,6 +549,7 @@ def declare(lib):
     fn("pl_tex_create", P(Tex), P(Gpu), P(TexParams))
     fn("pl_tex_destroy", None, P(Gpu), P(P(Tex)))
     fn("pl_tex_upload", C.c_bool, P(Gpu), P(TexTransferParams))
+    fn("pl_tex_blit", None, P(Gpu), P(TexBlitParams))
     fn("pl_tex_download", C.c_bool, P(Gpu), P(TexTransferParams))
     fn("pl_tex_clear", None, P(Gpu), P(Tex), P(C.c_float))
     fn("pl_gpu_finish", None, P(Gpu))

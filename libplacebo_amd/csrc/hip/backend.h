@@ -53,6 +53,7 @@ typedef void *plh_event;
 int plh_event_create(plh_event *out);
 void plh_event_destroy(plh_event e);
 int plh_event_record(plh_event e, plh_stream s);
+int plh_stream_wait_event(plh_stream s, plh_event e);
 // 1 = ready, 0 = not yet, <0 error
 int plh_event_query(plh_event e);
 int plh_event_sync(plh_event e);

@@ -180,6 +180,13 @@ int plh_event_record(plh_event e, plh_stream s)
     return 0;
 }
 
+// everything submitted to `s` after this call runs after `e` has completed
+int plh_stream_wait_event(plh_stream s, plh_event e)
+{
+    CHK(hipStreamWaitEvent((hipStream_t) s, (hipEvent_t) e, 0));
+    return 0;
+}
+
 int plh_event_query(plh_event e)
 {
     const hipError_t r = hipEventQuery((hipEvent_t) e);

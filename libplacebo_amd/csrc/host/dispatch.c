@@ -269,13 +269,18 @@ int plh_pass_execute(pl_gpu gpu, pl_log log, const struct plh_pass_exec *x, pl_t
     if (!realize_white_noise(gpu, noise, pass)) {
         return -1005;
     }
+    // which stream (gpu_hip.c "two streams"); every call here is a no-op in one-stream mode
+    const int on = x->on_aux && plh_gpu_async(gpu) && !plh_gpu_has_peak_exchange(gpu);
+    if (on)
+        plh_gpu_order_after(gpu, 1, x->aux_after);
+    const uint64_t seq = plh_tex_order(gpu, on, x->src_tex, target);
     if (timer)
-        plh_timer_begin(gpu, timer);
-    const int err = plh_launch_pass(plh_gpu_stream(gpu), pass);
+        plh_timer_begin(gpu, timer, on);
+    const int err = plh_launch_pass(plh_gpu_stream_n(gpu, on), pass);
     if (timer)
-        plh_timer_end(gpu, timer);
+        plh_timer_end(gpu, timer, on);
     if (!err && x->detect_peak)
-        plh_peak_pass_launched(gpu, x->peak_state);
+        plh_peak_pass_launched(gpu, x->peak_state, on, seq);
     return err;
 }
 
@@ -335,6 +340,7 @@ bool pl_dispatch_finish(pl_dispatch dp, const struct pl_dispatch_params *params)
     const struct plh_pass_exec x = {
         .pass = &sh->pass, .transpose = sh->transpose, .polar_obj = sh->polar_obj,
         .detect_peak = sh->detect_peak, .peak_state = sh->peak_state,
+        .src_tex = sh->src_tex, .on_aux = sh->on_aux, .aux_after = sh->aux_after,
     };
     const int err = plh_pass_execute(dp->gpu, dp->log, &x, target, rc, timer, &dp->noise);
     if (err) {
@@ -378,10 +384,10 @@ bool pl_dispatch_compute(pl_dispatch dp, const struct pl_dispatch_compute_params
 
     if (sh->kind == PLH_SHADER_ERROR_DIFFUSION) {
         if (timer)
-            plh_timer_begin(dp->gpu, timer);
+            plh_timer_begin(dp->gpu, timer, 0);
         err = plh_launch_errdiff(plh_gpu_stream(dp->gpu), sh->errdiff);
         if (timer)
-            plh_timer_end(dp->gpu, timer);
+            plh_timer_end(dp->gpu, timer, 0);
     } else {
         // targetless pass (e.g. sample + peak detection): the rendering area
         // must be given, results leave through side buffers only
@@ -405,12 +411,12 @@ bool pl_dispatch_compute(pl_dispatch dp, const struct pl_dispatch_compute_params
         if (!realize_white_noise(dp->gpu, &dp->noise, pass))
             goto done;
         if (timer)
-            plh_timer_begin(dp->gpu, timer);
+            plh_timer_begin(dp->gpu, timer, 0);
         err = plh_launch_pass(plh_gpu_stream(dp->gpu), pass);
         if (timer)
-            plh_timer_end(dp->gpu, timer);
+            plh_timer_end(dp->gpu, timer, 0);
         if (!err && sh->detect_peak)
-            plh_peak_pass_launched(dp->gpu, sh->peak_state);
+            plh_peak_pass_launched(dp->gpu, sh->peak_state, 0, 0);
     }
 
     if (err) {

@@ -126,6 +126,7 @@ pl_hip pl_hip_create(pl_log log, const struct pl_hip_params *params)
     }
 
     p->fns = &hip_fns;
+    p->async_measure = params->async_measure && !params->stream;   // (own streams only)
     struct pl_gpu_t *gpu = &p->gpu;
     gpu->log = log;
     gpu->glsl = (struct pl_glsl_version) {
@@ -193,7 +194,11 @@ pl_hip pl_hip_create(pl_log log, const struct pl_hip_params *params)
 static void hip_destroy(pl_gpu gpu)
 {
     struct gpu_priv *p = GPU_PRIV(gpu);
-    plh_stream_sync(p->stream);
+    plh_gpu_sync_all(gpu);
+    if (p->aux)
+        plh_stream_destroy(p->aux);
+    for (int i = 0; i < PLH_FENCES; i++)
+        plh_event_destroy(p->fence[i].ev);
     for (int i = 0; i < PLH_STAGE_SLOTS; i++) {
         plh_event_destroy(p->stage[i].done);
         plh_host_free(p->stage[i].host);
@@ -222,14 +227,164 @@ static void hip_gpu_flush(pl_gpu gpu)
     (void) gpu; // HIP submits eagerly
 }
 
+static int sync_main(struct gpu_priv *p);
+
 static void hip_gpu_finish(pl_gpu gpu)
 {
     struct gpu_priv *p = GPU_PRIV(gpu);
-    const int err = plh_stream_sync(p->stream);
+    int err = sync_main(p);
+    if (!err && p->aux && !(err = plh_stream_sync(p->aux)))
+        p->done[1] = p->seq[1];
     if (err) {
         pl_msg(gpu->log, PL_LOG_ERR, "pl_gpu_finish: %s", plh_strerror(err));
         p->failed = true;
     }
+}
+
+/* ------------------------------------------------------------------------ */
+/* two streams: who has to wait for whom                                      */
+//
+// With pl_hip_params.async_measure the measuring pass of a frame runs on a second stream while
+// the main stream is still busy with the previous frame. Ordering between the two is kept with
+// as few stream events as possible -- every event recorded behind a kernel costs the queue a few
+// microseconds, which is what the second stream is there to save. Each stream counts the
+// launches that touch a texture (`seq`); a texture remembers the count of its last write and of
+// its last read per stream; the host remembers how far each stream is known to have got (`done`:
+// a stream sync, a measurement whose result has been seen on the host) and how far each stream
+// is already ordered behind the other (`after`). Only when a launch depends on a count that is
+// neither known done nor already waited for is an event recorded (on the other stream, at its
+// current end -- later than needed, never earlier) and waited on.
+
+bool plh_gpu_async(pl_gpu gpu)
+{
+    return GPU_PRIV(gpu)->async_measure;
+}
+
+plh_stream plh_gpu_stream_n(pl_gpu gpu, int on)
+{
+    struct gpu_priv *p = GPU_PRIV(gpu);
+    if (!on || !p->async_measure)
+        return p->stream;
+    if (!p->aux && plh_stream_create(p->device, &p->aux)) {
+        pl_msg(gpu->log, PL_LOG_WARN, "pl_hip: no second stream: async_measure disabled");
+        p->async_measure = false;
+        return p->stream;
+    }
+    if (!p->aux_announced) {
+        pl_msg(gpu->log, PL_LOG_INFO, "pl_hip: measurement passes run on a second stream (async_measure)");
+        p->aux_announced = true;
+    }
+    return p->aux;
+}
+
+// mark the current end of stream `on` with an event
+static struct plh_fence *fence_here(pl_gpu gpu, int on)
+{
+    struct gpu_priv *p = GPU_PRIV(gpu);
+    // (an event may be re-recorded while a wait on its earlier recording is still queued: the
+    // wait keeps the recording it was issued against)
+    struct plh_fence *f = &p->fence[p->fence_next++ % PLH_FENCES];
+    f->live = false;
+    if (!f->ev && plh_event_create(&f->ev))
+        return NULL;
+    if (plh_event_record(f->ev, plh_gpu_stream_n(gpu, on)))
+        return NULL;
+    f->on = on;
+    f->seq = p->seq[on];
+    f->live = true;
+    return f;
+}
+
+// stream `on` continues only once the other stream has got to its launch number `s`
+static void order_after(pl_gpu gpu, int on, uint64_t s)
+{
+    struct gpu_priv *p = GPU_PRIV(gpu);
+    const int other = !on;
+    if (!s || s <= p->done[other] || s <= p->after[on])
+        return;
+    struct plh_fence *f = NULL;
+    for (int i = 0; i < PLH_FENCES; i++) {
+        struct plh_fence *c = &p->fence[i];
+        if (c->live && c->on == other && c->seq >= s && (!f || c->seq < f->seq))
+            f = c;
+    }
+    if (f && plh_event_query(f->ev) == 1) {
+        p->done[other] = PL_MAX(p->done[other], f->seq);
+        return;
+    }
+    if (!f && !(f = fence_here(gpu, other))) {
+        plh_stream_sync(plh_gpu_stream_n(gpu, other));  // no event to be had: the blunt way
+        p->done[other] = p->seq[other];
+        return;
+    }
+    plh_stream_wait_event(plh_gpu_stream_n(gpu, on), f->ev);
+    p->after[on] = PL_MAX(p->after[on], f->seq);
+}
+
+uint64_t plh_tex_order(pl_gpu gpu, int on, pl_tex reads, pl_tex writes)
+{
+    struct gpu_priv *p = GPU_PRIV(gpu);
+    if (!p->async_measure)
+        return 0;
+    struct tex_priv *r = reads ? TEX_PRIV(reads) : NULL, *w = writes ? TEX_PRIV(writes) : NULL;
+    if (r && r->write_on != on)
+        order_after(gpu, on, r->write_seq);
+    if (w) {
+        if (w->write_on != on)
+            order_after(gpu, on, w->write_seq);
+        order_after(gpu, on, w->read_seq[!on]);
+    }
+    const uint64_t s = ++p->seq[on];
+    if (r)
+        r->read_seq[on] = s;
+    if (w) {
+        w->write_seq = s;
+        w->write_on = on;
+    }
+    return s;
+}
+
+void plh_tex_read_so_far(pl_gpu gpu, pl_tex tex, int on)
+{
+    struct gpu_priv *p = GPU_PRIV(gpu);
+    if (!p->async_measure || !tex)
+        return;
+    TEX_PRIV(tex)->read_seq[on] = p->seq[on];
+    fence_here(gpu, on);
+}
+
+uint64_t plh_gpu_stamp(pl_gpu gpu, int on)
+{
+    struct gpu_priv *p = GPU_PRIV(gpu);
+    return p->async_measure ? ++p->seq[on] : 0;
+}
+
+void plh_gpu_order_after(pl_gpu gpu, int on, uint64_t other_seq)
+{
+    if (GPU_PRIV(gpu)->async_measure)
+        order_after(gpu, on, other_seq);
+}
+
+void plh_gpu_reached(pl_gpu gpu, int on, uint64_t seq)
+{
+    struct gpu_priv *p = GPU_PRIV(gpu);
+    p->done[on] = PL_MAX(p->done[on], seq);
+}
+
+static int sync_main(struct gpu_priv *p)
+{
+    const int err = plh_stream_sync(p->stream);
+    if (!err)
+        p->done[0] = p->seq[0];
+    return err;
+}
+
+void plh_gpu_sync_all(pl_gpu gpu)
+{
+    struct gpu_priv *p = GPU_PRIV(gpu);
+    sync_main(p);
+    if (p->aux && !plh_stream_sync(p->aux))
+        p->done[1] = p->seq[1];
 }
 
 static bool hip_gpu_is_failed(pl_gpu gpu)
@@ -267,7 +422,7 @@ static pl_tex hip_tex_create(pl_gpu gpu, const struct pl_tex_params *params)
         const int err = plh_copy2d_h2d(g->stream, t->ptr, t->pitch, params->initial_data,
                                        row_bytes, row_bytes, rows);
         // initial_data may be freed by the caller right away
-        if (err || plh_stream_sync(g->stream)) {
+        if (err || sync_main(g)) {
             pl_msg(gpu->log, PL_LOG_ERR, "pl_tex_create: initial upload failed");
             plh_free(t->ptr);
             free(t);
@@ -304,7 +459,7 @@ static void hip_tex_destroy(pl_gpu gpu, pl_tex tex)
     struct tex_priv *t = TEX_PRIV(tex);
     if (t->owned) {
         // the allocation may still be referenced by queued work
-        plh_stream_sync(GPU_PRIV(gpu)->stream);
+        plh_gpu_sync_all(gpu);
         plh_free(t->ptr);
     }
     free(t);
@@ -336,6 +491,7 @@ static void hip_tex_clear_ex(pl_gpu gpu, pl_tex dst, const union pl_clear_color 
 {
     struct plh_view v;
     plh_tex_view(dst, &v);
+    plh_tex_order(gpu, 0, NULL, dst);
     const int err = plh_launch_clear(GPU_PRIV(gpu)->stream, &v, color.f);
     if (err)
         pl_msg(gpu->log, PL_LOG_ERR, "pl_tex_clear: %s", plh_strerror(err));
@@ -383,6 +539,7 @@ static void hip_tex_blit(pl_gpu gpu, const struct pl_tex_blit_params *params)
     if (s->type == PLH_SAMPLE_BILINEAR && s->rect_w == w && s->rect_h == h)
         s->type = PLH_SAMPLE_NEAREST;
 
+    plh_tex_order(gpu, 0, src, dst);
     const int err = plh_launch_pass(GPU_PRIV(gpu)->stream, pass);
     free(pass);
     if (err) {
@@ -404,8 +561,9 @@ static bool hip_tex_transfer(pl_gpu gpu, const struct pl_tex_transfer_params *pa
     const size_t host_pitch = params->row_pitch;
     uint8_t *dev = (uint8_t *) t->ptr + (size_t) rc.y0 * t->pitch + (size_t) rc.x0 * tsz;
 
+    plh_tex_order(gpu, 0, upload ? NULL : tex, upload ? tex : NULL);
     if (params->timer)
-        plh_timer_begin(gpu, params->timer);
+        plh_timer_begin(gpu, params->timer, 0);
 
     int err;
     if (params->buf) {
@@ -418,11 +576,11 @@ static bool hip_tex_transfer(pl_gpu gpu, const struct pl_tex_transfer_params *pa
         // pageable host memory: the reference's contract is that `ptr` may be
         // reused / is filled when the call returns (gpu.h, no callback given)
         if (!err && !params->callback)
-            err = plh_stream_sync(g->stream);
+            err = sync_main(g);
     }
 
     if (params->timer)
-        plh_timer_end(gpu, params->timer);
+        plh_timer_end(gpu, params->timer, 0);
 
     if (err) {
         pl_msg(gpu->log, PL_LOG_ERR, "pl_tex_%s: %s", upload ? "upload" : "download",
@@ -431,7 +589,7 @@ static bool hip_tex_transfer(pl_gpu gpu, const struct pl_tex_transfer_params *pa
         return false;
     }
     if (params->callback) {
-        plh_stream_sync(g->stream);
+        sync_main(g);
         params->callback(params->priv);
     }
     return true;
@@ -453,7 +611,8 @@ static bool stream_busy(pl_gpu gpu, uint64_t timeout)
         pl_gpu_finish(gpu);
         return false;
     }
-    return plh_stream_idle(GPU_PRIV(gpu)->stream) == 0;
+    const struct gpu_priv *p = GPU_PRIV(gpu);
+    return plh_stream_idle(p->stream) == 0 || (p->aux && plh_stream_idle(p->aux) == 0);
 }
 
 static bool hip_tex_poll(pl_gpu gpu, pl_tex tex, uint64_t timeout)
@@ -482,14 +641,14 @@ static pl_buf hip_buf_create(pl_gpu gpu, const struct pl_buf_params *params)
     if (params->initial_data) {
         plh_copy2d_h2d(g->stream, b->ptr, params->size, params->initial_data, params->size,
                        params->size, 1);
-        plh_stream_sync(g->stream);
+        sync_main(g);
     }
     return &b->buf;
 }
 
 static void hip_buf_destroy(pl_gpu gpu, pl_buf buf)
 {
-    plh_stream_sync(GPU_PRIV(gpu)->stream);
+    plh_gpu_sync_all(gpu);
     plh_free(BUF_PRIV(buf)->ptr);
     free(BUF_PRIV(buf));
 }
@@ -528,7 +687,7 @@ void plh_buf_write(pl_gpu gpu, pl_buf buf, size_t buf_offset, const void *data, 
         }
     }
     plh_copy2d_h2d(g->stream, dst, size, data, size, size, 1);
-    plh_stream_sync(g->stream);
+    sync_main(g);
 }
 
 bool plh_buf_read(pl_gpu gpu, pl_buf buf, size_t buf_offset, void *dest, size_t size)
@@ -536,7 +695,7 @@ bool plh_buf_read(pl_gpu gpu, pl_buf buf, size_t buf_offset, void *dest, size_t 
     struct gpu_priv *g = GPU_PRIV(gpu);
     int err = plh_copy2d_d2h(g->stream, dest, size, (uint8_t *) BUF_PRIV(buf)->ptr + buf_offset,
                              size, size, 1);
-    err = err ? err : plh_stream_sync(g->stream);
+    err = err ? err : sync_main(g);
     return !err;
 }
 
@@ -671,12 +830,12 @@ static void hip_pass_run(pl_gpu gpu, const struct pl_pass_run_params *params, pl
         local.transpose = 0;
         local.frag_x0 = local.frag_y0 = 0;
         if (params->timer)
-            plh_timer_begin(gpu, params->timer);
+            plh_timer_begin(gpu, params->timer, 0);
         err = plh_launch_pass(g->stream, &local);
         if (params->timer)
-            plh_timer_end(gpu, params->timer);
+            plh_timer_end(gpu, params->timer, 0);
         if (!err && p->detect_peak)
-            plh_peak_pass_launched(gpu, p->peak_state);
+            plh_peak_pass_launched(gpu, p->peak_state, 0, 0);
     }
     if (err) {
         pl_msg(gpu->log, PL_LOG_ERR, "pl_pass_run: %s", plh_strerror(err));
@@ -711,16 +870,16 @@ static pl_timer hip_timer_create(pl_gpu gpu)
     return t;
 }
 
-void plh_timer_begin(pl_gpu gpu, pl_timer t)
+void plh_timer_begin(pl_gpu gpu, pl_timer t, int on)
 {
     if (t->head - t->tail >= PLH_TIMER_RING)
         t->tail++; // drop the oldest sample
-    plh_event_record(t->start[t->head % PLH_TIMER_RING], GPU_PRIV(gpu)->stream);
+    plh_event_record(t->start[t->head % PLH_TIMER_RING], plh_gpu_stream_n(gpu, on));
 }
 
-void plh_timer_end(pl_gpu gpu, pl_timer t)
+void plh_timer_end(pl_gpu gpu, pl_timer t, int on)
 {
-    plh_event_record(t->stop[t->head % PLH_TIMER_RING], GPU_PRIV(gpu)->stream);
+    plh_event_record(t->stop[t->head % PLH_TIMER_RING], plh_gpu_stream_n(gpu, on));
     t->head++;
 }
 

@@ -61,6 +61,8 @@ struct plh_gpu_fns {
 #define PLH_STAGE_SLOTS 8
 #define PLH_STAGE_BYTES (64 * 1024)
 
+#define PLH_FENCES 16
+
 struct gpu_priv {
     struct pl_gpu_t gpu;
     const struct plh_gpu_fns *fns;
@@ -69,6 +71,16 @@ struct gpu_priv {
     int device;
     plh_stream stream;
     bool own_stream;
+    // pl_hip_params.async_measure: a second stream for the per-frame measurement pass
+    // (index 1 in the functions below; index 0 is `stream`). Created on first use.
+    bool async_measure;
+    plh_stream aux;
+    bool aux_announced;
+    // (gpu_hip.c "two streams") launches counted per stream, how far each is known to have got,
+    // how far each is already ordered behind the other, and the events recorded so far
+    uint64_t seq[2], done[2], after[2];
+    struct plh_fence { plh_event ev; int on; uint64_t seq; bool live; } fence[PLH_FENCES];
+    unsigned fence_next;
     bool failed;
     pl_cache cache;     // pl_gpu_set_cache (borrowed)
     pl_hip_peak_exchange_fn peak_exchange;  // pl_hip_set_peak_exchange
@@ -92,6 +104,10 @@ struct tex_priv {
     size_t pitch;
     int plh_fmt;
     bool owned;
+    // cross-stream ordering (async_measure only; all zero otherwise): launch numbers of the last
+    // write (on stream `write_on`) and of the last read per stream
+    uint64_t write_seq, read_seq[2];
+    int write_on;
 };
 
 struct buf_priv {
@@ -112,8 +128,8 @@ struct pl_timer_t {
 #define GPU_FNS(g)   (GPU_PRIV(g)->fns)
 
 void plh_tex_view(pl_tex tex, struct plh_view *out);
-void plh_timer_begin(pl_gpu gpu, pl_timer t);
-void plh_timer_end(pl_gpu gpu, pl_timer t);
+void plh_timer_begin(pl_gpu gpu, pl_timer t, int on);    // `on`: stream index, see below
+void plh_timer_end(pl_gpu gpu, pl_timer t, int on);
 
 pl_cache plh_gpu_cache(pl_gpu gpu);
 // unvalidated buffer IO for the library's own device-only tables (gpu.c)
@@ -124,6 +140,25 @@ void plh_gpu_peak_exchange(pl_gpu gpu, void *words, size_t size);
 static inline bool plh_gpu_has_peak_exchange(pl_gpu gpu);
 static inline bool plh_gpu_has_peak_exchange(pl_gpu gpu) { return !!((struct gpu_priv *) gpu)->peak_exchange; }
 static inline plh_stream plh_gpu_stream(pl_gpu gpu) { return GPU_PRIV(gpu)->stream; }
+
+// ---- two-stream ordering (gpu_hip.c). `on`: 0 = the main stream, 1 = the measurement stream.
+// Everything here does nothing (and plh_gpu_stream_n returns the main stream) unless
+// pl_hip_params.async_measure is set.
+bool plh_gpu_async(pl_gpu gpu);
+plh_stream plh_gpu_stream_n(pl_gpu gpu, int on);
+// Before a launch on stream `on` that reads `reads` and writes `writes` (either may be NULL):
+// makes the stream wait for whatever the other stream still has to do with them, and notes the
+// launch on both textures. Returns the launch's number on its stream.
+uint64_t plh_tex_order(pl_gpu gpu, int on, pl_tex reads, pl_tex writes);
+// `tex` has been read by launches on `on` that plh_tex_order did not see, all of them queued by now
+void plh_tex_read_so_far(pl_gpu gpu, pl_tex tex, int on);
+// a number for something just queued on `on` that is no texture (a table upload)...
+uint64_t plh_gpu_stamp(pl_gpu gpu, int on);
+// ... which stream `on` (the other one) has to wait for
+void plh_gpu_order_after(pl_gpu gpu, int on, uint64_t other_seq);
+// the host has seen the result of launch `seq` of stream `on`
+void plh_gpu_reached(pl_gpu gpu, int on, uint64_t seq);
+void plh_gpu_sync_all(pl_gpu gpu);
 static inline int plh_gpu_device(pl_gpu gpu) { return GPU_PRIV(gpu)->device; }
 
 #endif // PLH_GPU_PRIV_H_

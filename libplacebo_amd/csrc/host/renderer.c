@@ -82,6 +82,8 @@ void pl_renderer_flush_cache(pl_renderer rr)
         pl_tex_destroy(rr->gpu, &rr->spare[i]);
     for (int i = 0; i < rr->num_fbos; i++)
         pl_tex_destroy(rr->gpu, &rr->fbos[i]);
+    for (int i = 0; i < RR_MEASURE_FBOS; i++)
+        pl_tex_destroy(rr->gpu, &rr->measure_fbo[i]);
     rr->num_cached = rr->num_spare = rr->num_fbos = 0;
     pl_reset_detected_peak(rr->tone_map_state);
 }
@@ -216,6 +218,26 @@ static pl_tex borrow_fbo(struct frame_job *job, int w, int h, pl_fmt fmt, int co
     return rr->fbos[pick];
 }
 
+// The intermediate of a pass that goes on the measurement stream (see renderer_priv.h)
+static pl_tex borrow_measure_fbo(struct frame_job *job, int w, int h, pl_fmt fmt, int comps)
+{
+    pl_renderer rr = job->rr;
+    if (!fmt)
+        fmt = job->caps.fbo[comps ? comps : 4];
+    if (!fmt || !(fmt->caps & PL_FMT_CAP_STORABLE) || job->measure_fbo)
+        return NULL;
+    pl_tex *slot = &rr->measure_fbo[rr->measure_flip % RR_MEASURE_FBOS];
+    const struct pl_tex_params want = {
+        .w = w, .h = h, .format = fmt,
+        .sampleable = true, .renderable = true, .storable = true,
+    };
+    if (!pl_tex_recreate(rr->gpu, slot, &want))
+        return NULL;
+    rr->measure_flip++;
+    job->measure_fbo = *slot;
+    return *slot;
+}
+
 // true if `rec` would do nothing but copy `copy_of`: then that texture is the answer
 static bool is_pure_copy(const struct work_image *img)
 {
@@ -244,7 +266,13 @@ pl_tex plh_work_texture(struct frame_job *job, struct work_image *img)
     }
     img->copy_of = NULL;
 
-    pl_tex fbo = borrow_fbo(job, img->w, img->h, img->store_as, img->comps);
+    pl_tex fbo = NULL;
+    if (plh_gpu_async(rr->gpu) && plh_shader_aux_eligible(img->rec)) {
+        fbo = borrow_measure_fbo(job, img->w, img->h, img->store_as, img->comps);
+        img->rec->on_aux = !!fbo;
+    }
+    if (!fbo)
+        fbo = borrow_fbo(job, img->w, img->h, img->store_as, img->comps);
     img->store_as = NULL;
     if (!fbo) {
         // without intermediates only the simplest pipeline remains
@@ -469,6 +497,12 @@ void plh_job_end(struct frame_job *job)
     pl_renderer rr = job->rr;
     pl_dispatch_abort(rr->dp, &job->img.rec);
     pl_dispatch_callback(rr->dp, NULL, NULL);
+    if (job->measure_fbo) {
+        // every reader of this frame's measured intermediate is queued by now: the measuring
+        // pass that reuses the texture two frames on waits for this point
+        plh_tex_read_so_far(rr->gpu, job->measure_fbo, 0);
+        job->measure_fbo = NULL;
+    }
     if (job->image_acquired && job->image.release)
         job->image.release(rr->gpu, &job->image);
     if (job->target_acquired && !job->target_borrowed && job->target.release)

@@ -11,6 +11,7 @@
 #include "shaders_priv.h"
 
 #define RR_MAX_FBOS 16
+#define RR_MEASURE_FBOS 3
 #define RR_MAX_MIX_FRAMES 16        // frames one mix may blend (reference renderer.c:3610)
 #define RR_MAX_CACHED_FRAMES 32
 
@@ -41,6 +42,12 @@ struct pl_renderer_t {
 
     pl_tex fbos[RR_MAX_FBOS];
     int num_fbos;
+    // pl_hip_params.async_measure: the measuring pass of a frame runs on its own stream, beside
+    // the previous frame's later passes -- which still read the previous frame's intermediate, so
+    // that pass cycles through textures of its own instead of drawing from `fbos` (three: the
+    // host runs a frame ahead of the main stream, so the texture of two frames ago may still be read)
+    pl_tex measure_fbo[RR_MEASURE_FBOS];
+    unsigned measure_flip;
 
     struct scaler_slot scale_main, scale_ref, scale_contrast;
     struct scaler_slot scale_plane[PL_MAX_PLANES];   // chroma / alpha planes of the image
@@ -85,6 +92,7 @@ struct frame_job {
     struct work_image img;
     bool fbo_busy[RR_MAX_FBOS];
     bool peak_pending;          // a same-frame measurement rides on `img.rec`
+    pl_tex measure_fbo;         // the member of rr->measure_fbo this frame wrote, if any
     bool image_acquired, target_acquired;
     bool target_borrowed;       // the target belongs to an enclosing job: neither acquire nor release
     struct pl_render_info info;

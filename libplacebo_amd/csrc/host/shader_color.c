@@ -499,6 +499,9 @@ struct sh_color_map_obj {
         plh_event written;      // recorded by the dispatch behind the measuring pass
         bool awaiting;          // a measuring pass was recorded and its result not yet taken
         bool launched;          // ... and that pass has been dispatched (`written` is live)
+        int on;                 // ... on this stream (gpu_priv.h: 0 main, 1 measurement)
+        uint64_t seq;           // ... as that stream's launch number `seq`
+        uint64_t tables_seq;    // main-stream stamp of the last upload into consts / scratch
         pl_buf consts;          // constant block of the detect stage
         float consts_now[16];   // what `consts` holds
         pl_buf scratch;         // PLH_PEAK_COPIES zeroed copies of the buffer (k_peak.hip)
@@ -657,7 +660,7 @@ static void peak_collect(pl_gpu gpu, struct sh_color_map_obj *obj, bool must)
         return;     // still rendering: this frame goes with the previous result
 
     obj->peak.awaiting = obj->peak.launched = false;
-    plh_stream stream = plh_gpu_stream(gpu);
+    plh_stream stream = plh_gpu_stream_n(gpu, obj->peak.on);
     bool have = false;
     if (!plh_gpu_has_peak_exchange(gpu)) {
         // the fold kernel wrote the result into the pinned mirror and then its ticket: poll
@@ -683,6 +686,7 @@ static void peak_collect(pl_gpu gpu, struct sh_color_map_obj *obj, bool must)
         return;
     }
 
+    plh_gpu_reached(gpu, obj->peak.on, obj->peak.seq);
     struct peak_totals totals;
     peak_totals_of(obj->peak.mirror, &totals);
     if (!totals.groups)
@@ -692,10 +696,12 @@ static void peak_collect(pl_gpu gpu, struct sh_color_map_obj *obj, bool must)
 }
 
 // dispatch.c, behind the launch of a pass that carries a measurement
-void plh_peak_pass_launched(pl_gpu gpu, pl_shader_obj state)
+void plh_peak_pass_launched(pl_gpu gpu, pl_shader_obj state, int on, uint64_t seq)
 {
     struct sh_color_map_obj *obj = state->priv;
-    if (!plh_event_record(obj->peak.written, plh_gpu_stream(gpu)))
+    obj->peak.on = on;
+    obj->peak.seq = seq;
+    if (!plh_event_record(obj->peak.written, plh_gpu_stream_n(gpu, on)))
         obj->peak.launched = true;
 }
 
@@ -779,6 +785,7 @@ bool pl_shader_detect_peak(pl_shader sh, struct pl_color_space csp, pl_shader_ob
     if (memcmp(consts, obj->peak.consts_now, sizeof(consts))) {
         plh_buf_write(gpu, obj->peak.consts, 0, consts, sizeof(consts));
         memcpy(obj->peak.consts_now, consts, sizeof(consts));
+        obj->peak.tables_seq = plh_gpu_stamp(gpu, 0);
     }
     op->ptr2 = pl_hip_buf_ptr(obj->peak.consts);
     if (!obj->peak.scratch) {
@@ -790,7 +797,9 @@ bool pl_shader_detect_peak(pl_shader sh, struct pl_color_space csp, pl_shader_ob
         free(zeros);
         if (!obj->peak.scratch)
             return false;
+        obj->peak.tables_seq = plh_gpu_stamp(gpu, 0);
     }
+    sh->aux_after = obj->peak.tables_seq;
     sh->pass.peak_buf = pl_hip_buf_ptr(obj->peak.buf);
     sh->pass.peak_scratch = pl_hip_buf_ptr(obj->peak.scratch);
     obj->peak.ticket = obj->peak.ticket + 1 ? obj->peak.ticket + 1 : 1;    // never 0

@@ -441,3 +441,18 @@ float plh_fmtf(double v)
     snprintf(buf, sizeof(buf), "%f", v);
     return strtof(buf, NULL);
 }
+
+bool plh_shader_aux_eligible(const pl_shader sh)
+{
+    if (!sh || sh->failed || sh->kind != PLH_SHADER_PASS || !sh->detect_peak || !sh->src_tex)
+        return false;
+    const struct plh_pass *p = &sh->pass;
+    if (p->s.type != PLH_SAMPLE_NEAREST && p->s.type != PLH_SAMPLE_BILINEAR)
+        return false;
+    for (int i = 0; i < p->num_ops; i++) {
+        const struct plh_op *op = &p->ops[i];
+        if (op->kind != PLH_OP_PEAK_DETECT && (op->ptr || op->ptr2))
+            return false;   // tables, other planes, feature maps: not tracked across streams
+    }
+    return true;
+}

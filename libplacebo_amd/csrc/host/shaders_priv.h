@@ -73,7 +73,14 @@ struct pl_shader_t {
     // texture and rect bound by the sampling stage (sh_bind), for pass fusion
     pl_tex src_tex;
     pl_rect2df src_rect;
+    // run on the measurement stream (set by the renderer on a pass plh_shader_aux_eligible accepts)
+    bool on_aux;
+    uint64_t aux_after;
 };
+
+// true if the only device memory the recorded pass reads is `src_tex` and the measurement's own
+// buffers: what the two-stream ordering of gpu_hip.c covers
+bool plh_shader_aux_eligible(const pl_shader sh);
 
 struct pl_sample_src;
 struct pl_sample_filter_params;
@@ -89,7 +96,7 @@ bool plh_shader_sample_polar_fused(pl_shader sh, const pl_shader pre,
 // called by the dispatch once the target geometry of a POLAR pass is known
 void plh_polar_pp_setup(pl_gpu gpu, pl_log log, void *polar_obj, struct plh_pass *pass);
 
-void plh_peak_pass_launched(pl_gpu gpu, pl_shader_obj state);
+void plh_peak_pass_launched(pl_gpu gpu, pl_shader_obj state, int on, uint64_t seq);
 
 // the finalized, still-alive shader behind a "#pl_hip_pass <ticket>" line; NULL if there is none
 pl_shader plh_shader_from_glsl(const char *glsl);
@@ -103,6 +110,11 @@ struct plh_pass_exec {
     bool detect_peak;
     pl_shader_obj peak_state;
     int out_w, out_h;           // the shader's own output size requirement, 0 = none
+    // two-stream mode (pl_hip_params.async_measure): the texture the sampler reads, and whether
+    // the caller wants this pass on the measurement stream (renderer.c: plh_work_texture)
+    pl_tex src_tex;
+    bool on_aux;
+    uint64_t aux_after;         // main-stream stamp of the last upload into the measurement's tables
 };
 // returns 0, a negative plh error code, or PLH_EXEC_BAD_* (message already logged)
 int plh_pass_execute(pl_gpu gpu, pl_log log, const struct plh_pass_exec *x, pl_tex target,
