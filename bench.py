@@ -104,11 +104,15 @@ class Stream:
 
     # pl_hip_params.async_measure (include/libplacebo/hip.h): the measuring pass of frame N+1 on a
     # second HIP stream beside the scaler of frame N. Same frames bit for bit
-    # (tests/test_gpu_async_measure.py); --async-measure 0 turns it off for an A/B.
-    async_measure = True
+    # (tests/test_gpu_async_measure.py). Off in the headline run -- one stream, every kernel with
+    # the GPU to itself, which is what the roofline block and profiles/ describe; the JSON line
+    # carries the same workload with the option on as a companion ("async_measure").
+    async_measure = False
 
-    def __init__(self, device, workload, pool):
-        self.g = pl.HipGpu(device, async_measure=Stream.async_measure)
+    def __init__(self, device, workload, pool, async_measure=None):
+        on = Stream.async_measure if async_measure is None else async_measure
+        self.async_on = bool(on)
+        self.g = pl.HipGpu(device, async_measure=self.async_on)
         self.rr = pl.Renderer(self.g)
         self.workload = workload
         (sw, sh), (dw, dh), _, _ = WORKLOADS[workload]
@@ -306,7 +310,7 @@ def measure_passes(st, frames=48):
     st.pass_ns.clear()
     for _ in range(frames):
         st.step()
-        if Stream.async_measure:
+        if st.async_on:
             st.g.finish()
     st.g.finish()
     st.step()           # drains the last timers
@@ -365,7 +369,7 @@ def measure_traffic(workload, symbol, timeout=240):
             env = dict(os.environ, TMPDIR="/tmp", PL_BENCH_CHILD="1")
             cmd = [rocprof, "--pmc", counter, "--kernel-trace", "--output-format", "csv", "-d", td,
                    "--", sys.executable, os.path.abspath(__file__), "--workload", workload,
-                   "--steps", "6", "--warmup", "2", "--bare", "--async-measure", "0"]
+                   "--steps", "6", "--warmup", "2", "--bare"]
             try:
                 r = subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, text=True,
                                    timeout=timeout)
@@ -412,7 +416,7 @@ def measure_trace(workload, symbol, timeout=240):
         env = dict(os.environ, TMPDIR="/tmp", PL_BENCH_CHILD="1")
         cmd = [rocprof, "--kernel-trace", "--stats", "--output-format", "csv", "-d", td, "--",
                sys.executable, os.path.abspath(__file__), "--workload", workload, "--steps", "40",
-               "--warmup", "8", "--bare", "--async-measure", "0"]    # (kernels one at a time)
+               "--warmup", "8", "--bare"]
         try:
             r = subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, text=True,
                                timeout=timeout)
@@ -549,6 +553,8 @@ def config_block(device, workload, steps=60, warmup=8, trace=False):
                  ms_per_step=round(dt / steps * 1e3, 4), steps=steps,
                  render_errors=st.rr.errors())
     st.close()
+    if workload in ASYNC_WORKLOADS:
+        block["async_measure"] = async_measure_block(device, workload, steps, warmup)
     if trace:
         tr = measure_trace(workload, block["kernel"].split(" ")[0])
         if tr:
@@ -600,6 +606,24 @@ def concurrent_block(device, workload, nstreams, steps=120, warmup=12):
     return block
 
 
+# workloads with a measuring pass the option can move (the others render the same either way)
+ASYNC_WORKLOADS = ("ewa_1080p_to_4k_hdr_tonemap", "hdr10_4k_tonemap")
+
+
+def async_measure_block(device, workload, steps, warmup):
+    """The same single stream with pl_hip_params.async_measure: frame rate only (the kernels are
+    the same; what changes is that two of them share the GPU for part of every frame)."""
+    (sw, sh), (dw, dh), _, _ = WORKLOADS[workload]
+    per_frame = (sw * sh + dw * dh) * 8
+    st = Stream(device, workload, max(4, -(-800_000_000 // per_frame)), async_measure=True)
+    dt = run_timed(st, steps, warmup)
+    block = {"pl_hip_params": {"async_measure": True}, "steps": steps,
+             "mpixels_per_s": round(steps * dw * dh / dt / 1e6, 1),
+             "ms_per_step": round(dt / steps * 1e3, 4), "render_errors": st.rr.errors()}
+    st.close()
+    return block
+
+
 def baseline_metric():
     """BASELINE.json's metric name (the driver matches on it)."""
     try:
@@ -621,8 +645,9 @@ def main():
     ap.add_argument("--scene-peak-allreduce", action="store_true",
                     help="ranks render frames of one scene: all-reduce the peak-detection buffer "
                          "over RCCL every frame (BASELINE configs[4])")
-    ap.add_argument("--async-measure", type=int, default=1, choices=[0, 1],
-                    help="pl_hip_params.async_measure for every stream (default 1)")
+    ap.add_argument("--async-measure", type=int, default=0, choices=[0, 1],
+                    help="pl_hip_params.async_measure for every stream (default 0; the default run "
+                         "reports the option's effect in its \"async_measure\" block)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-companions", action="store_true",
                     help="skip the per-config 'rooflines' blocks")
@@ -725,6 +750,8 @@ def main():
         if not args.no_companions:
             out["rooflines"] = {w: config_block(local_rank, w, trace=not args.no_traffic)
                                 for w in BASELINE_CONFIGS if w != args.workload}
+        if not args.no_concurrent and not args.async_measure and args.workload in ASYNC_WORKLOADS:
+            out["async_measure"] = async_measure_block(local_rank, args.workload, args.steps, args.warmup)
         if not args.no_concurrent:
             # companion only: `value` stays the single-stream figure
             out["concurrent_streams_one_gpu"] = [concurrent_block(local_rank, args.workload, n)
