@@ -185,18 +185,24 @@ void k_ortho(const plh_pass p_)
  */
 // SRC = the source's plh format: the 8-byte RGBA formats (plane / FBO of packed frames) and the
 // one- / two-component planes of planar video (their passes carry no colour ops: EPI 0 only)
+// (`base` comes through the asm that pins it in SGPRs, after which it is a generic pointer to
+// the compiler and every access a flat_ instruction: it is a device allocation, say so)
+#define OF_GLOBAL __attribute__((address_space(1)))
+
 template <int SRC>
 DEV uint2 of_load(const char *base, int pitch, int x, int y)
 {
-    const char *row = base + (size_t) y * pitch;
-    if constexpr (SRC == PLH_FMT_RGBA16 || SRC == PLH_FMT_RGBA16F)
-        return *(const uint2 *) (row + (size_t) x * 8);
-    else if constexpr (SRC == PLH_FMT_RG16 || SRC == PLH_FMT_RG16F)
-        return make_uint2(*(const uint32_t *) (row + (size_t) x * 4), 0);
-    else if constexpr (SRC == PLH_FMT_R16 || SRC == PLH_FMT_R16F || SRC == PLH_FMT_RG8)
-        return make_uint2(*(const uint16_t *) (row + (size_t) x * 2), 0);
-    else
-        return make_uint2(*(const uint8_t *) (row + x), 0);
+    const OF_GLOBAL char *row = (const OF_GLOBAL char *) (uintptr_t) base + (size_t) y * pitch;
+    if constexpr (SRC == PLH_FMT_RGBA16 || SRC == PLH_FMT_RGBA16F) {
+        const plh_u32x2 v = *(const OF_GLOBAL plh_u32x2 *) (row + (size_t) x * 8);
+        return make_uint2(v.x, v.y);
+    } else if constexpr (SRC == PLH_FMT_RG16 || SRC == PLH_FMT_RG16F) {
+        return make_uint2(*(const OF_GLOBAL uint32_t *) (row + (size_t) x * 4), 0);
+    } else if constexpr (SRC == PLH_FMT_R16 || SRC == PLH_FMT_R16F || SRC == PLH_FMT_RG8) {
+        return make_uint2(*(const OF_GLOBAL uint16_t *) (row + (size_t) x * 2), 0);
+    } else {
+        return make_uint2(*(const OF_GLOBAL uint8_t *) (row + x), 0);
+    }
 }
 
 template <int SRC>

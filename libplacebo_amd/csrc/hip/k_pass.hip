@@ -204,9 +204,21 @@ void k_pass_generic(const plh_pass p_)
 #define BF_BW 64
 #define BF_BH 4
 
+// The kernels below pin their uniforms in SGPRs with an empty asm; a pointer that went through
+// one is a generic pointer to the compiler afterwards, and every access through it a flat_
+// instruction (which also ties up the LDS counter). These are device allocations: say so.
+#define BF_GLOBAL __attribute__((address_space(1)))
+
 DEV uint2 bf_load(const char *base, int pitch, int x, int y)
 {
-    return *(const uint2 *) (base + (size_t) y * pitch + (size_t) x * 8);
+    const BF_GLOBAL char *g = (const BF_GLOBAL char *) (uintptr_t) base;
+    const plh_u32x2 v = *(const BF_GLOBAL plh_u32x2 *) (g + (size_t) y * pitch + (size_t) x * 8);
+    return make_uint2(v.x, v.y);
+}
+
+DEV float bf_bias(const float *matrix, int i)
+{
+    return ((const BF_GLOBAL float *) (uintptr_t) matrix)[i];
 }
 
 template <bool F16SRC>
@@ -290,7 +302,7 @@ void k_bilinear_fast(const plh_pass p_)
             if (has_dither) {
                 const int ix = (idx0 + i + fx0) & dmask;
                 const int iy = (c.idy0 + j + fy0) & dmask;
-                c.bias[q] = dmat[iy * dsize + ix];
+                c.bias[q] = bf_bias(dmat, iy * dsize + ix);
             }
         }
         c.shared = shared;
@@ -452,7 +464,7 @@ void k_nearest_fast(const plh_pass p_)
             raw[r][i] = bf_load(sp, spitch, ix, iy);
             bias[r][i] = 0.0f;
             if (has_dither)
-                bias[r][i] = dmat[((idy + fy0) & dmask) * dsize + ((idx + fx0) & dmask)];
+                bias[r][i] = bf_bias(dmat, ((idy + fy0) & dmask) * dsize + ((idx + fx0) & dmask));
         }
     }
 
