@@ -35,7 +35,8 @@ struct pl_hip_params {
     // scaling / colour-mapping pass, which is still running when the next pl_render_image call
     // arrives. The counterpart of pl_vulkan_params.async_compute (vulkan.h). Results are
     // identical; the renderer keeps two FBOs for that pass. Ignored (one stream) when `stream`
-    // is given or a peak exchange is installed. Off by default.
+    // is given or a peak exchange is installed. Off by default; the environment variable
+    // PL_HIP_ASYNC_MEASURE=0|1 overrides it.
     bool async_measure;
 };
 

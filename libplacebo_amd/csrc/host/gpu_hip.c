@@ -127,6 +127,11 @@ pl_hip pl_hip_create(pl_log log, const struct pl_hip_params *params)
 
     p->fns = &hip_fns;
     p->async_measure = params->async_measure && !params->stream;   // (own streams only)
+    // PL_HIP_ASYNC_MEASURE=0|1 overrides the parameter: lets a whole test suite or an unmodified
+    // application run with the option on
+    const char *async_env = getenv("PL_HIP_ASYNC_MEASURE");
+    if (async_env)
+        p->async_measure = atoi(async_env) && !params->stream;
     struct pl_gpu_t *gpu = &p->gpu;
     gpu->log = log;
     gpu->glsl = (struct pl_glsl_version) {
