@@ -565,8 +565,8 @@ def config_block(device, workload, steps=60, warmup=8, trace=False):
 
 def concurrent_block(device, workload, nstreams, steps=120, warmup=12):
     """`nstreams` independent streams on ONE GPU, each a pl_hip backend (its own HIP stream) and
-    a pl_renderer driven by its own host thread: the launch gaps and host waits of one stream
-    (44 us of a 311 us frame) are filled by the others'. Aggregate output rate."""
+    a pl_renderer driven by its own host thread: the host round trip of one stream's same-frame
+    measurement (a few us of every frame) is filled by the others'. Aggregate output rate."""
     import threading
     (sw, sh), (dw, dh), _, _ = WORKLOADS[workload]
     per_frame = (sw * sh + dw * dh) * 8
