@@ -4,6 +4,7 @@
 // with and without an event recorded after every launch. Time per launch = kernel + gap.
 // Build: hipcc --offload-arch=gfx950 -O2 -o launch_gap.bin launch_gap.hip
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <cstdio>
 #include <cstring>
 
@@ -32,8 +33,10 @@ __global__ __launch_bounds__(256) void k_expand(const A a)
 static u32x2 *g_src[POOL];
 static u32x4 *g_dst[POOL];
 
+// mode 0: plain launches; 1: hipEventRecord behind each; 2: the event attached to the launch itself
+// (hipExtLaunchKernelGGL's stop event: the dispatch packet's own completion signal)
 template <typename A>
-static double run(hipStream_t s, int reps, bool events)
+static double run(hipStream_t s, int reps, int mode)
 {
     hipEvent_t a, b, e[8];
     (void) hipEventCreate(&a); (void) hipEventCreate(&b);
@@ -47,8 +50,11 @@ static double run(hipStream_t s, int reps, bool events)
         }
         args.dst = g_dst[i % POOL];
         args.src = g_src[i % POOL];
-        hipLaunchKernelGGL(k_expand<A>, dim3(30, 270), dim3(256), 0, s, args);
-        if (events)
+        if (mode == 2)
+            hipExtLaunchKernelGGL(k_expand<A>, dim3(30, 270), dim3(256), 0, s, nullptr, e[i % 8], 0, args);
+        else
+            hipLaunchKernelGGL(k_expand<A>, dim3(30, 270), dim3(256), 0, s, args);
+        if (mode == 1)
             (void) hipEventRecord(e[i % 8], s);
     }
     (void) hipEventRecord(b, s);
@@ -68,11 +74,12 @@ int main()
     hipStream_t nb;
     (void) hipStreamCreateWithFlags(&nb, hipStreamNonBlocking);
     for (int rep = 0; rep < 2; rep++) {
-        printf("null stream,   24 B args            %7.2f us per launch\n", run<small_args>(0, 200, false));
-        printf("null stream,   2560 B args          %7.2f us per launch\n", run<big_args>(0, 200, false));
-        printf("own stream,    24 B args            %7.2f us per launch\n", run<small_args>(nb, 200, false));
-        printf("own stream,    2560 B args          %7.2f us per launch\n", run<big_args>(nb, 200, false));
-        printf("own stream,    2560 B args + event  %7.2f us per launch\n", run<big_args>(nb, 200, true));
+        printf("null stream,   24 B args            %7.2f us per launch\n", run<small_args>(0, 200, 0));
+        printf("null stream,   2560 B args          %7.2f us per launch\n", run<big_args>(0, 200, 0));
+        printf("own stream,    24 B args            %7.2f us per launch\n", run<small_args>(nb, 200, 0));
+        printf("own stream,    2560 B args          %7.2f us per launch\n", run<big_args>(nb, 200, 0));
+        printf("own stream,    2560 B args + event  %7.2f us per launch\n", run<big_args>(nb, 200, 1));
+        printf("own stream,    2560 B args, stop event on the launch %7.2f us per launch\n", run<big_args>(nb, 200, 2));
     }
     return 0;
 }
