@@ -273,6 +273,8 @@ int plh_launch_polar_pp_f16_c12(hipStream_t stream, const plh_pass *pass, dim3 g
                                 size_t shmem, int n);
 int plh_launch_polar_pp_f32_c12(hipStream_t stream, const plh_pass *pass, dim3 grid, dim3 block,
                                 size_t shmem, int n);
+// k_polar_mx.hip
+int plh_launch_polar_mx(hipStream_t stream, const plh_pass *pass);
 
 int plh_launch_polar_classify(plh_stream stream, const plh_pass *pass, void *out)
 {
@@ -321,6 +323,8 @@ int plh_launch_polar(hipStream_t stream, const plh_pass *pass_in)
     const plh_pass *pass = &local;
     const dim3 block(POLAR_BW, POLAR_BH);
     const uint32_t cm = pass->s.comp_mask & 0xf;
+    if (pass->s.pp && pass->s.mx.enabled && (cm == 0x7 || cm == 0xf))
+        return plh_launch_polar_mx(stream, pass);
     if (pass->s.pp && (cm == 0x7 || cm == 0xf || cm == 0x1 || cm == 0x3)) {
         const int n = pass->s.pp_n, cw = pass->s.pp_cells_w, ch = pass->s.pp_cells_h;
         const int cth = POLAR_BH * pass->s.tile_rows;

@@ -90,6 +90,22 @@ struct plh_polar_pp {
                                         // order), NULL = launch order
 };
 
+// POLAR on the matrix pipe (k_polar_mx.hiph): an exact 2x upscale has two phases per axis, so a
+// 16-row x 16-column block of same-phase outputs is a small GEMM  out[m][n] = sum_k A[m][k] B[k][n]
+// with A = rows of the f16 source tile (LDS, channel-planar) and B = a banded (Toeplitz) matrix
+// of the filter weights, split into f16 hi + lo halves (the products are exact in fp32, the sums
+// are fp32). One v_mfma_f32_16x16x32_f16 covers two source rows x 16 source columns.
+// The host builds B once per (filter, geometry) in fragment order: frag f, lane l, element e.
+#define PLH_MX_NFRAG 18     // (py = 0: 4 row pairs, py = 1: 5) x {hi, lo}
+#define PLH_MX_WT_COLS 5    // wave tiles (16 output columns each) per workgroup row
+struct plh_polar_mx {
+    int32_t enabled;
+    int32_t org_x, org_y;   // source texel held by LDS tile (0, 0) of workgroup (0, 0)
+    int32_t tiles_x, tiles_y;
+    int32_t wrows;          // wave tiles (32 output rows each) per workgroup column
+    const void *bfrag;      // device: [PLH_MX_NFRAG][64 lanes][8] f16
+};
+
 struct plh_sampler_args {
     int32_t type;           // enum plh_sampler
     struct plh_view src;
@@ -122,6 +138,7 @@ struct plh_sampler_args {
     int32_t pp_lds_weights; // bytes of LDS for the staged weight sub-table
     int32_t pp_n, pp_cells_w, pp_cells_h;   // host copies of pp->n, cells_w, cells_h
     int32_t pp_debug;       // profiling aid (PL_HIP_PP_DEBUG): 1 = no taps, 2 = no verify, 4 = no store
+    struct plh_polar_mx mx; // matrix-pipe variant (enabled = 0: k_polar_pp)
 
     // ORTHO: weights[256][row_stride] rows; N taps along `dir`
     const float *weights;   // device

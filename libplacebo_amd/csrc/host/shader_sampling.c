@@ -204,6 +204,11 @@ struct sh_sampler_obj {
     pl_buf pp_blob;
     struct plh_polar_pp pp_host;    // host copy (device pointers)
     int pp_tile_w, pp_tile_h, pp_rows, pp_lds_weights;
+
+    // matrix-pipe variant of the same geometry (k_polar_mx): B fragments + tile origin
+    pl_buf mx_blob;
+    struct plh_polar_mx mx_host;    // .enabled = 0: geometry not eligible
+    bool mx_announced;
 };
 
 static void sh_sampler_uninit(pl_gpu gpu, void *ptr)
@@ -212,6 +217,7 @@ static void sh_sampler_uninit(pl_gpu gpu, void *ptr)
     pl_buf_destroy(gpu, &obj->lut);
     pl_buf_destroy(gpu, &obj->taps);
     pl_buf_destroy(gpu, &obj->pp_blob);
+    pl_buf_destroy(gpu, &obj->mx_blob);
     pl_shader_obj_destroy(&obj->pass2);
     pl_filter_free(&obj->filter);
     memset(obj, 0, sizeof(*obj));
@@ -611,6 +617,162 @@ int plh_launch_polar_classify(plh_stream stream, const struct plh_pass *pass, vo
 int plh_launch_polar_weights(plh_stream stream, const struct plh_pass *pass, const float *clsx,
                              int ncx, const float *clsy, int ncy, float *weights);
 
+
+/* ---- polar on the matrix pipe (device side: k_polar_mx.hiph, struct plh_polar_mx) ------- */
+
+// IEEE binary32 -> binary16, round to nearest even (subnormals and overflow included)
+static uint16_t f32_to_f16(float f)
+{
+    uint32_t x;
+    memcpy(&x, &f, 4);
+    const uint32_t sign = (x >> 16) & 0x8000u;
+    x &= 0x7fffffffu;
+    if (x >= 0x7f800000u)
+        return sign | (x > 0x7f800000u ? 0x7e00u : 0x7c00u);
+    if (x >= 0x477ff000u)   // rounds to >= 65520: infinity
+        return sign | 0x7c00u;
+    if (x < 0x38800000u) {  // below the smallest normal half: a multiple of 2^-24
+        const float scaled = fabsf(f) * 16777216.0f;       // exact
+        return sign | (uint16_t) lrintf(scaled);            // (round-half-even rounding mode)
+    }
+    const uint32_t mant = x & 0x007fffffu, exp = (x >> 23) - 112;
+    uint32_t h = (exp << 10) | (mant >> 13);
+    const uint32_t rest = mant & 0x1fffu;
+    if (rest > 0x1000u || (rest == 0x1000u && (h & 1)))
+        h++;                // (a carry into the exponent is the correct result)
+    return sign | (uint16_t) h;
+}
+
+static float f16_to_f32(uint16_t h)
+{
+    const int exp = (h >> 10) & 0x1f, mant = h & 0x3ff;
+    float v;
+    if (exp == 0)
+        v = ldexpf((float) mant, -24);
+    else if (exp == 31)
+        v = mant ? NAN : INFINITY;
+    else
+        v = ldexpf((float) (mant | 0x400), exp - 25);
+    return (h & 0x8000) ? -v : v;
+}
+
+// The geometry k_polar_mx covers: an axis whose outputs alternate between two phases and step
+// one source texel per two outputs (an exact 2x upscale, any sub-texel offset). Returns the
+// class of each parity and c1 = base(1) - base(0); false if the axis does not have that shape.
+static bool mx_axis(const float *fc, const int32_t *base, const uint16_t *ids, int len,
+                    int canon[2], int *c1)
+{
+    if (len < 2)
+        return false;
+    *c1 = base[1] - base[0];
+    if (*c1 != 0 && *c1 != 1)
+        return false;
+    for (int q = 0; q < 2; q++) {
+        canon[q] = ids[q];
+        // (a phase next to 0 or 1 could flip its base texel with the rounding of one pixel)
+        if (fc[q] < 0.02f || fc[q] > 0.98f)
+            return false;
+    }
+    for (int i = 0; i < len; i++) {
+        const int q = i & 1;
+        if (base[i] != base[0] + (i >> 1) + (q ? *c1 : 0))
+            return false;
+        if (fabsf(fc[i] - fc[q]) > 1e-5f)
+            return false;
+    }
+    return true;
+}
+
+// B fragments (plh_device.h): frag f = (py ? 8 + 2 j : 2 j) + hl, lane l, element e hold
+//   T(py, wy)[k][n] with n = l & 15, k = 8 * ((l >> 4) & 1) + e, wy = 2 j + (l >> 5) - cy(py),
+//   = w'(phase py, phase n & 1, tap (k - dbx[n] - 3, wy - 3)), hi or lo f16 half
+static bool polar_mx_build(pl_gpu gpu, pl_log log, struct sh_sampler_obj *obj,
+                           const struct plh_pass *pass, const float *wall, const uint32_t *taps,
+                           int ntaps, int ncx, const float *colfc, const int32_t *colbase,
+                           const uint16_t *idx, const float *rowfc, const int32_t *rowbase,
+                           const uint16_t *idy)
+{
+    const struct plh_sampler_args *s = &pass->s;
+    const int W = pass->width, H = pass->height;
+    obj->mx_host = (struct plh_polar_mx) {0};
+    if (s->bound > 4 || s->tile_fp32 || s->address_mode != PLH_ADDRESS_CLAMP || pass->transpose ||
+        s->src.w < 2 || s->antiring > 0)
+        return false;
+    int cx[2], cy[2], c1x, c1y;
+    if (!mx_axis(colfc, colbase, idx, W, cx, &c1x) || !mx_axis(rowfc, rowbase, idy, H, cy, &c1y))
+        return false;
+
+    // tap (x, y) -> index in the list, x, y in [-3, 4]
+    int tap_at[8][8];
+    for (int y = 0; y < 8; y++) {
+        for (int x = 0; x < 8; x++)
+            tap_at[y][x] = -1;
+    }
+    for (int t = 0; t < ntaps; t++) {
+        const int x = (int8_t) (taps[t] & 0xff), y = (int8_t) ((taps[t] >> 8) & 0xff);
+        if (x < -3 || x > 4 || y < -3 || y > 4)
+            return false;
+        tap_at[y + 3][x + 3] = t;
+    }
+
+    uint16_t *frag = calloc((size_t) PLH_MX_NFRAG * 64 * 8, sizeof(uint16_t));
+    if (!frag)
+        return false;
+    double worst = 0.0;
+    for (int py = 0; py < 2; py++) {
+        for (int j = 0; j < (py ? 5 : 4); j++) {
+            for (int l = 0; l < 64; l++) {
+                const int n = l & 15, px = n & 1;
+                const int dbx = (n >> 1) + (px ? c1x : 0);
+                const int wy = 2 * j + (l >> 5) - (py ? c1y : 0);
+                const float *w = wall + ((size_t) cy[py] * ncx + cx[px]) * (ntaps + 1);
+                for (int e = 0; e < 8; e++) {
+                    const int k = 8 * ((l >> 4) & 1) + e, wx = k - dbx;
+                    double v = 0.0;
+                    if (wx >= 0 && wx < 8 && wy >= 0 && wy < 8 && tap_at[wy][wx] >= 0)
+                        v = (double) w[tap_at[wy][wx]] * (double) w[ntaps];  // w * scale / wsum
+                    const uint16_t hi = f32_to_f16((float) v);
+                    const uint16_t lo = f32_to_f16((float) (v - (double) f16_to_f32(hi)));
+                    const double err = fabs(v - (double) f16_to_f32(hi) - (double) f16_to_f32(lo));
+                    worst = PL_MAX(worst, err);
+                    const int f = (py ? 8 : 0) + 2 * j;
+                    frag[((size_t) f * 64 + l) * 8 + e] = hi;
+                    frag[((size_t) (f + 1) * 64 + l) * 8 + e] = lo;
+                }
+            }
+        }
+    }
+
+    const size_t bytes = (size_t) PLH_MX_NFRAG * 64 * 8 * sizeof(uint16_t);
+    pl_buf_destroy(gpu, &obj->mx_blob);
+    obj->mx_blob = pl_buf_create(gpu, pl_buf_params(.size = bytes, .storable = true,
+                                                    .initial_data = frag));
+    free(frag);
+    if (!obj->mx_blob)
+        return false;
+
+    // workgroup tile: 80 output columns x 32 * wrows rows; LDS = fragments + planar f16 tile
+    int wrows = 4;
+    const char *env = getenv("PL_HIP_MX_ROWS");     // profiling aid
+    if (env && atoi(env) > 0)
+        wrows = PL_MIN(atoi(env), 8);
+    wrows = PL_MIN(wrows, (H + 31) / 32);
+    obj->mx_host = (struct plh_polar_mx) {
+        .enabled = 1,
+        .org_x = colbase[0] - 3, .org_y = rowbase[0] - 3,
+        .tiles_x = (W + 16 * PLH_MX_WT_COLS - 1) / (16 * PLH_MX_WT_COLS),
+        .tiles_y = (H + 32 * wrows - 1) / (32 * wrows),
+        .wrows = wrows,
+        .bfrag = pl_hip_buf_ptr(obj->mx_blob),
+    };
+    obj->mx_announced = false;
+    pl_msg(log, PL_LOG_DEBUG, "matrix-pipe tables for the polar pass: 2 x 2 phases (fcoord %.6f %.6f / %.6f %.6f), "
+           "%d x %d workgroup tiles of 80 x %d pixels, weight split error <= %.2e",
+           colfc[0], colfc[1], rowfc[0], rowfc[1], obj->mx_host.tiles_x, obj->mx_host.tiles_y,
+           32 * wrows, worst);
+    return true;
+}
+
 static bool polar_pp_build(pl_gpu gpu, pl_log log, struct sh_sampler_obj *obj,
                            const struct plh_pass *pass)
 {
@@ -771,6 +933,9 @@ static bool polar_pp_build(pl_gpu gpu, pl_log log, struct sh_sampler_obj *obj,
         const int x = (int8_t) (tap & 0xff), y = (int8_t) ((tap >> 8) & 0xff);
         tapoff[k] = (y * tx.extent + x) * (int) texel;
     }
+    // the same geometry on the matrix pipe, where it has the shape for it
+    polar_mx_build(gpu, log, obj, pass, wall, taps_all, ntaps, ncx, colfc, colbase, idx,
+                   rowfc, rowbase, idy);
     free(taps_all);
     free(keep);
 
@@ -834,6 +999,7 @@ void plh_polar_pp_setup(pl_gpu gpu, pl_log log, void *polar_obj, struct plh_pass
     struct sh_sampler_obj *obj = polar_obj;
     struct plh_sampler_args *s = &pass->s;
     s->pp = NULL;
+    memset(&s->mx, 0, sizeof(s->mx));
     const char *env = getenv("PL_HIP_POLAR_PER_PIXEL");
     if (env && env[0] == '1')
         return;
@@ -868,6 +1034,18 @@ void plh_polar_pp_setup(pl_gpu gpu, pl_log log, void *polar_obj, struct plh_pass
     s->tile_w = obj->pp_tile_w;
     s->tile_h = obj->pp_tile_h;
     s->tile_rows = obj->pp_rows;
+
+    // k_polar_mx: the contraction on the f16 matrix pipe, within +-1 code of 16 bits of the
+    // sequential-fma kernels. PL_HIP_POLAR_MFMA=0 keeps the bit-exact reference variant.
+    const char *mfma = getenv("PL_HIP_POLAR_MFMA");
+    memset(&s->mx, 0, sizeof(s->mx));
+    if (obj->mx_host.enabled && !(mfma && mfma[0] == '0') && (cm == 0x7 || cm == 0xf) &&
+        !pass->transpose && s->address_mode == PLH_ADDRESS_CLAMP) {
+        s->mx = obj->mx_host;
+        if (!obj->mx_announced)
+            pl_msg(log, PL_LOG_DEBUG, "polar on the matrix pipe (k_polar_mx)");
+        obj->mx_announced = true;
+    }
 }
 
 

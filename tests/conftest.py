@@ -8,6 +8,14 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 
+# Which polar kernel the suite runs by default. The library's default for an exact 2x upscale is
+# k_polar_mx (the contraction on the f16 matrix pipe), whose parity statement is "+-1 code of 16
+# bits": tests/test_gpu_polar_mfma.py and tests/test_gpu_metric.py switch it on explicitly and
+# hold it to that, at the same geometries. Every other test pins k_polar_pp, the sequential-fma
+# kernel that evaluates the taps in the reference's order and must match the oracle BIT FOR BIT.
+os.environ.setdefault("PL_HIP_POLAR_MFMA", "0")
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu)")
 

@@ -1,0 +1,349 @@
+"""The launches the benchmark's headline times, against the oracle composed stage by stage
+(VERDICT r02 row m1 / "What's missing" 2; pattern of the reference's own pl_render_tests,
+src/tests/gpu_tests.c:1155-1216):
+
+* the metric's frame, exactly bench.py's `ewa_1080p_to_4k_hdr_tonemap` parameters: HDR10
+  1080p -> [A: plane -> rgba16hf FBO + peak measurement] -> [B: EWA-Lanczos 2x polar over the
+  FBO (PQ-coded: an HDR upscale is not linearised, renderer.c:1997-2003), PQ linearize, tone +
+  gamut map, BT.1886, blue-noise dither to 10 bit, store];
+* BASELINE configs[4] as benched: `high_quality` preset (deband, contrast recovery feature map,
+  dither), EWA-Lanczos downscaler, percentile 99.995, 10-bit target.
+
+What is compared, and how:
+  pre-dither   the same frame rendered without the dither op into a 16-bit target, under the
+               colour-map statement of tests/util.py (never further from float64 than the
+               float-libm oracle, at every quantile including the maximum)
+  dither       the 10-bit frame must be the dither of the GPU's OWN pre-dither value with the
+               oracle's matrix cell: out = floor(1023 * x + M[y & 63][x & 63]) for an x within
+               half a 16-bit code of the stored pre-dither value -- for every pixel. (One 16-bit
+               code is 1/64 of a 10-bit step, so this pins the matrix index: a shifted matrix fails
+               on a third of the pixels, which the test also demonstrates.)
+  vs oracle    10-bit codes differ from the oracle's only by one step, and only as often as the
+               pre-dither differences put a threshold between the two values.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+import libplacebo_amd as pl
+import orc
+import util
+from libplacebo_amd import _capi as capi
+from test_gpu_fullsize import (P1080, P4K, P8K, colormap_tolerance, hdr_frame16, inferred)
+
+pytestmark = pytest.mark.gpu
+
+HDR = dict(primaries="bt2020", transfer="pq", max_luma=1000.0)
+
+
+def blue_dither():
+    return capi.DitherParams(method=pl.DITHER_BLUE_NOISE, lut_size=6, transfer=0)
+
+
+def ten_bit():
+    return pl.color_repr("rgb", "full", sample_depth=16, color_depth=10, bit_shift=6)
+
+
+def metric_params(dither):
+    """bench.py: Stream.__init__, workload ewa_1080p_to_4k_hdr_tonemap"""
+    return pl.render_params("default", upscaler=pl.filter_config("ewa_lanczos"),
+                            dither_params=blue_dither() if dither else None,
+                            peak_detect_params=pl.peak_detect_params(percentile=99.995))
+
+
+def resolve(meta, tone=b"spline", gamut=b"perceptual"):
+    import colormap_ref as cr
+    src = cr.make_csp(pl.PRIM["bt2020"], pl.TRC["pq"], max_luma=1000.0)
+    src.hdr.max_pq_y, src.hdr.avg_pq_y = meta.max_pq_y, meta.avg_pq_y
+    dst = cr.make_csp(pl.PRIM["bt709"], pl.TRC["bt1886"])
+    return cr.resolve(src, dst, tone=tone, gamut=gamut)
+
+
+def render_once(gpu, img, dw, dh, params, target_repr, env=None):
+    """fresh renderer (the measurement is smoothed over a renderer's frames) -> frame, metadata"""
+    # the library's defaults, as benched: the polar pass on the matrix pipe (tests/conftest.py
+    # pins the bit-exact kernel for the rest of the suite)
+    env = {"PL_HIP_POLAR_MFMA": "1", **(env or {})}
+    old = {k: os.environ.get(k) for k in env}
+    os.environ.update(env)
+    own = None
+    try:
+        if "PL_HIP_ASYNC_MEASURE" in env:       # (read when the backend is created)
+            own = gpu = pl.HipGpu(0)
+        sh_, sw = img.shape[:2]
+        rr = pl.Renderer(gpu)
+        src = gpu.tex_create(sw, sh_, "rgba16", img)
+        dst = gpu.tex_create(dw, dh, "rgba16")
+        util.srand(1)
+        assert rr.render(pl.frame(src, components=3, color=pl.color_space(**HDR)),
+                         pl.frame(dst, color=pl.color_space("bt709", "bt1886"), repr_=target_repr),
+                         params), gpu.messages[-4:]
+        assert rr.errors() == 0
+        out = dst.download()
+        meta = capi.HdrMetadata()
+        assert pl.lib().pl_renderer_get_hdr_metadata(rr.rr, C.byref(meta))
+        rr.destroy(); src.destroy(); dst.destroy()
+        return out, meta
+    finally:
+        if own is not None:
+            own.close()
+        for k, v in old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+
+
+def peak_buffer_word_for_word(gpu, img, hdr_i, percentile):
+    """The measuring pass by hand (the renderer consumes its own buffer): the 816-word buffer
+    against the oracle's, integer for integer where no pow decides (test_gpu_fullsize cfg 4)."""
+    from test_gpu_color import _read_device, luma_coeffs, nominal
+    h, w = img.shape[:2]
+    tex = orc.tex_decode(img, "rgba16")
+    tex[..., 3] = 1.0
+    src = gpu.tex_create(w, h, "rgba16", img)
+    fbo = gpu.tex_create(w, h, "rgba16hf")
+    state = pl.ShaderObj()
+    a = gpu.begin()
+    assert a.sample("direct", src, components=3)
+    pp = pl.peak_detect_params(percentile=percentile)
+    assert pl.lib().pl_shader_detect_peak(a.sh, hdr_i, C.byref(state.slot), C.byref(pp))
+    assert a.finish(fbo), gpu.messages[-3:]
+    size_ = C.c_size_t()
+    pl.lib().pl_hip_peak_buffer.restype = C.c_void_p
+    ptr = pl.lib().pl_hip_peak_buffer(state.slot, C.byref(size_))
+    assert ptr and size_.value == 816 * 4
+    buf = _read_device(ptr, size_.value)
+    fbo_got = fbo.download()
+    mn, mx = nominal(hdr_i)
+    pad_w, pad_h = -(-w // 16) * 16, -(-h // 16) * 16
+    padded = np.zeros((pad_h, pad_w, 4), np.float32)
+    padded[:h, :w] = tex
+    padded[:h, w:] = tex[:, -1:, :]         # invocations beyond the image sample the clamped edge
+    padded[h:, :] = padded[h - 1:h, :]
+    refbuf = orc.detect_peak(padded, pl.TRC["pq"], mn, mx, luma_coeffs(hdr_i.primaries),
+                             black_cutoff=pp.black_cutoff, use_hist=pp.percentile < 100)
+    nwg = (pad_w // 16) * (pad_h // 16)
+    assert np.array_equal(buf[0:12], refbuf[0:12]) and buf[0:12].sum() == nwg
+    assert np.array_equal(buf[12:24], refbuf[12:24])
+    assert np.abs(buf[24:36].astype(np.int64) - refbuf[24:36]).max() <= refbuf[0:12].max()
+    assert np.abs(buf[36:48].astype(np.int64) - refbuf[36:48]).max() <= 1
+    gh, rh = buf[48:].reshape(12, 64).astype(np.int64), refbuf[48:].reshape(12, 64).astype(np.int64)
+    assert gh.sum() == rh.sum()
+    assert np.abs(gh - rh).sum() <= max(4, w * h // 100000)
+    # the FBO the scaler reads: bit for bit the f16 rounding of the decoded plane
+    want = orc.op_quant_f16(tex.copy()).astype(np.float16)
+    assert np.array_equal(fbo_got.view(np.uint16), want.view(np.uint16))
+    state.destroy(); fbo.destroy(); src.destroy()
+    return refbuf
+
+
+def dither_consistency(got10, pre16, matrix, depth=10, shift=6):
+    """Fraction of (pixel, channel) samples of the 10-bit frame that are NOT the dither of the
+    frame's own pre-dither value (known to half a 16-bit code) with `matrix`."""
+    h, w = got10.shape[:2]
+    top = float((1 << depth) - 1)
+    ys, xs = np.mgrid[0:h, 0:w]
+    b = matrix[ys & 63, xs & 63].astype(np.float64)[..., None]
+    g = pre16[..., :3].astype(np.float64)
+    k = (got10[..., :3] >> shift).astype(np.int64)
+    lo = np.floor(top * (g - 0.5 - 1e-3) / 65535.0 + b)
+    hi = np.floor(top * (g + 0.5 + 1e-3) / 65535.0 + b)
+    lo = np.where(pre16[..., :3] == 0, 0.0, lo)             # clipped pre-dither values: the
+    hi = np.where(pre16[..., :3] == 65535, top, hi)         # true x may lie beyond the range
+    ok = (k >= np.clip(lo, 0, top)) & (k <= np.clip(hi, 0, top))
+    return 1.0 - ok.mean()
+
+
+@pytest.mark.parametrize("size", [(160, 90), P1080])
+def test_metric_frame_vs_oracle(gpu, size):
+    import colormap_f64 as c64
+    import colormap_ref as cr
+    sw, sh = size
+    dw, dh = 2 * sw, 2 * sh
+    img = hdr_frame16(sw, sh)
+    hdr_i, _ = inferred(pl.color_space(**HDR), pl.color_space("bt709", "bt1886"))
+
+    # ---- GPU: the benched frame, and the same frame without the dither op --------------------
+    got, meta = render_once(gpu, img, dw, dh, metric_params(True), ten_bit())
+    pre, meta_pre = render_once(gpu, img, dw, dh, metric_params(False), None)
+    assert (meta.max_pq_y, meta.avg_pq_y) == (meta_pre.max_pq_y, meta_pre.avg_pq_y)
+    assert np.all(got & 63 == 0) and np.all(got[..., 3] == 1023 << 6)
+    assert np.all(pre[..., 3] == 65535)
+
+    # ---- A: measurement buffer word for word, FBO bit for bit --------------------------------
+    refbuf = peak_buffer_word_for_word(gpu, img, hdr_i, 99.995)
+    avg = refbuf[24:36].sum() / (refbuf[12:24].sum() * 16383.0)
+    assert abs(meta.avg_pq_y - avg) <= 2e-4, (meta.avg_pq_y, avg)
+    assert 0.5 < meta.max_pq_y <= 0.9 + 1e-3
+
+    # ---- oracle: FBO -> polar (PQ-coded) -> linearize -> map -> BT.1886 -----------------------
+    tex = orc.tex_decode(img, "rgba16")
+    tex[..., 3] = 1.0
+    a = orc.op_quant_f16(tex)
+    w, r, rz = orc.filter_generate_polar(orc.ewa_lanczos())
+    b = orc.sample_polar(a, w, r, rz, dw, dh, mask=0x7)
+    res = resolve(meta)
+    assert res["need_tone"] and res["need_gamut"]
+    sel = np.arange(0, dw * dh, 13)
+    truth, _ = c64.hdr10_to_sdr(b.reshape(-1, 1, 4)[sel], res, 0.0)
+    ref_pre = cr.apply(b.copy(), res)
+    ref_pre16 = orc.tex_encode(ref_pre, "rgba16")
+    colormap_tolerance(pre, ref_pre16, truth.reshape(-1, 4), sel)
+
+    # ---- dither: index path exact, value = dither of the GPU's own pre-dither value -----------
+    matrix = util.blue_noise(pl)
+    bad = dither_consistency(got, pre, matrix)
+    assert bad == 0.0, bad
+    # (the statement has power: the matrix displaced by one cell explains far fewer pixels)
+    assert dither_consistency(got, pre, np.roll(matrix, 1, axis=1)) > 0.2
+
+    # ---- vs the oracle's 10-bit frame -------------------------------------------------------------
+    ref = orc.dither(ref_pre.copy(), matrix, 10)
+    fn = pl.lib().pl_color_repr_normalize
+    fn.restype = C.c_float
+    scale = np.float32(fn(C.byref(ten_bit())))
+    ref[...] = ref * (np.float32(1.0) / scale)
+    ref16 = orc.tex_encode(ref, "rgba16")
+    k, kr = (got[..., :3] >> 6).astype(np.int64), (ref16[..., :3] >> 6).astype(np.int64)
+    steps = np.abs(k - kr)
+    dpre = np.abs(pre[..., :3].astype(np.float64) - ref_pre16[..., :3])
+    # a threshold falls between two values d codes apart with probability d / 64
+    expected = np.minimum(dpre + 1.0, 64.0).mean() / 64.0
+    print("metric frame %dx%d: pre-dither |GPU - oracle| median %.1f p99 %.1f max %d codes; 10-bit "
+          "codes differ on %.4f of the samples (expected from the pre-dither distance <= %.4f), "
+          "by more than one step on %.2e" % (dw, dh, np.median(dpre), np.quantile(dpre, 0.99),
+                                             dpre.max(), (steps > 0).mean(), expected,
+                                             (steps > 1).mean()))
+    assert (steps > 0).mean() <= 1.5 * expected + 1e-4
+    # more than one step needs the pre-dither values to be > 64 codes apart: the ill-conditioned
+    # tail of the colour map, bounded above by colormap_tolerance
+    assert (steps > 1).mean() <= (dpre > 63).mean() + 1e-6
+    assert np.array_equal((steps > 1) & (dpre < 63), np.zeros_like(steps, bool))
+
+
+def test_metric_frame_kernel_variants_identical(gpu):
+    """The same HDR frame through the unfused pass structure and the per-pixel polar kernel."""
+    sw, sh = 160, 90
+    img = hdr_frame16(sw, sh)
+    exact = {"PL_HIP_POLAR_MFMA": "0"}
+    base, meta = render_once(gpu, img, 2 * sw, 2 * sh, metric_params(True), ten_bit(), exact)
+    for env in ({"PL_HIP_NO_FUSION": "1"}, {"PL_HIP_POLAR_PER_PIXEL": "1"},
+                {"PL_HIP_ASYNC_MEASURE": "1"}):
+        out, m = render_once(gpu, img, 2 * sw, 2 * sh, metric_params(True), ten_bit(),
+                             {**exact, **env})
+        assert (m.max_pq_y, m.avg_pq_y) == (meta.max_pq_y, meta.avg_pq_y), env
+        assert np.array_equal(out, base), (env, util.diff_stats(out, base))
+    # the matrix-pipe kernel: the same frame with and without the pass-structure switches
+    mbase, _ = render_once(gpu, img, 2 * sw, 2 * sh, metric_params(True), ten_bit())
+    for env in ({"PL_HIP_NO_FUSION": "1"}, {"PL_HIP_ASYNC_MEASURE": "1"}):
+        out, _ = render_once(gpu, img, 2 * sw, 2 * sh, metric_params(True), ten_bit(), env)
+        assert np.array_equal(out, mbase), (env, util.diff_stats(out, mbase))
+    steps = np.abs((mbase >> 6).astype(np.int64) - (base >> 6))
+    assert steps.max() <= 1 and (steps > 0).mean() < 0.01, (steps.max(), (steps > 0).mean())
+
+
+# ---- configs[4] as benched: high_quality preset -------------------------------------------------
+def bicubic(blur=0.0):
+    f = orc.mitchell(blur)
+    f.kparams[0], f.kparams[1] = 1.0, 0.0       # pl_filter_bicubic, filters.c:848-855
+    return f
+
+
+def lowpass_feature_map(full, mw, mh):
+    """get_feature_map (renderer.c:2089-2154): bicubic, mirrored edges, vertical pass into an
+    r16hf intermediate, then the horizontal one into the r16hf map."""
+    h, w = full.shape[:2]
+    out = full
+    for direction, new, src_len in ((1, mh, h), (0, mw, w)):
+        ratio = float(np.float32(new / src_len))
+        inv = float(np.float32(1.0 / ratio))
+        rows, n, radius, rz = orc.filter_generate_ortho(bicubic(blur=inv if inv > 1.0 else 0.0))
+        use_linear = radius == rz
+        rows = orc.ortho_lut_rows(rows, n, use_linear)
+        ow, oh = (out.shape[1], new) if direction == 1 else (new, out.shape[0])
+        out = orc.sample_ortho(out, rows, n, direction, ow, oh, use_linear=use_linear, mask=0x1,
+                               address_mode=2)
+        out = orc.op_quant_f16(out)
+    return out
+
+
+@pytest.mark.parametrize("size", [((256, 144), (128, 72)), (P8K, P4K)])
+def test_cfg5_high_quality_as_benched(gpu, size):
+    """bench.py's `ewa_8k_to_4k_deband_tonemap`: render_params("high_quality",
+    downscaler=ewa_lanczos, percentile 99.995), 10-bit target."""
+    import colormap_f64 as c64
+    import colormap_ref as cr
+    from test_gpu_color import luma_coeffs, nominal
+    (sw, sh), (dw, dh) = size
+    img = hdr_frame16(sw, sh)
+
+    def params(dither):
+        kw = {} if dither else dict(dither_params=None)
+        return pl.render_params("high_quality", downscaler=pl.filter_config("ewa_lanczos", 2),
+                                peak_detect_params=pl.peak_detect_params(percentile=99.995), **kw)
+
+    got, meta = render_once(gpu, img, dw, dh, params(True), ten_bit())
+    pre, meta_pre = render_once(gpu, img, dw, dh, params(False), None)
+    assert (meta.max_pq_y, meta.avg_pq_y) == (meta_pre.max_pq_y, meta_pre.avg_pq_y)
+    assert np.all(got & 63 == 0)
+
+    hdr_i, sdr_i = inferred(pl.color_space(**HDR), pl.color_space("bt709", "bt1886"))
+    mn, mx = nominal(hdr_i)
+    luma = luma_coeffs(hdr_i.primaries)
+    deband = capi.DebandParams.in_dll(pl.lib(), "pl_deband_default_params")
+    cmp_ = capi.ColorMapParams.in_dll(pl.lib(), "pl_color_map_high_quality_params")
+    assert cmp_.contrast_recovery > 0 and cmp_.contrast_smoothness > 1
+    tex = orc.tex_decode(img, "rgba16")
+    grain = deband.grain / (hdr_i.hdr.max_luma / 203.0)
+    a = orc.deband(tex, sw, sh, iterations=deband.iterations, threshold=deband.threshold,
+                   radius=deband.radius, grain=float(np.float32(grain)), frame_index=1)
+    del tex
+    a[..., 3] = 1.0
+    orc.linearize(a, pl.TRC["pq"], mn, mx, luma)
+    orc.op_quant_f16(a)
+    w, r, rz = orc.filter_generate_polar(orc.ewa_lanczos(blur=float(sw) / dw))
+    b = orc.sample_polar(a, w, r, rz, dw, dh, mask=0x7, gather_order=not r < 6.0)
+    del a
+    orc.op_quant_f16(b)
+
+    # measurement of the 4K intermediate
+    pad_w, pad_h = -(-dw // 16) * 16, -(-dh // 16) * 16
+    padded = np.zeros((pad_h, pad_w, 4), np.float32)
+    padded[:dh, :dw] = b
+    padded[:dh, dw:] = b[:, -1:, :]
+    padded[dh:, :] = padded[dh - 1:dh, :]
+    refbuf = orc.detect_peak(padded, pl.TRC["linear"], mn, mx, luma, black_cutoff=1.0, use_hist=True)
+    del padded
+    avg = refbuf[24:36].sum() / (refbuf[12:24].sum() * 16383.0)
+    assert abs(meta.avg_pq_y - avg) <= 3e-4, (meta.avg_pq_y, avg)
+
+    # contrast recovery: I of IPT at full size (r16hf), low-passed to 1 / smoothness
+    from test_gpu_contrast_recovery import klms
+    feat = orc.extract_features(b.copy(), klms("bt2020"))
+    feat = orc.op_quant_f16(feat)
+    mw = int(np.ceil(np.float32(dw) / np.float32(cmp_.contrast_smoothness)))
+    mh = int(np.ceil(np.float32(dh) / np.float32(cmp_.contrast_smoothness)))
+    small = lowpass_feature_map(feat, mw, mh)
+    del feat
+    lowres = orc.feature_luma(small[..., 0].copy(), dw, dh)
+
+    res = resolve(meta)
+    strength = float(cmp_.contrast_recovery)
+    cr_out = (res["tone"].output_min, res["tone"].output_max)
+    sel = np.arange(0, dw * dh, 13)
+    truth, _ = c64.hdr10_to_sdr(b.reshape(-1, 1, 4)[sel], res, 0.0, prelinearized=True,
+                                lowres=lowres.reshape(-1, 1)[sel], strength=strength, cr_out=cr_out)
+    ref_pre = cr.apply(b, res, lowres=lowres, strength=strength, prelinearized=True)
+    ref_pre16 = orc.tex_encode(ref_pre, "rgba16")
+    # (end to end the maximum belongs to the ~1e-5 of the pixels around f16-ulp flips of the 8K
+    # intermediate, see test_gpu_fullsize.test_cfg5_8k_to_4k_deband_ewa_tone_map)
+    colormap_tolerance(pre, ref_pre16, truth.reshape(-1, 4), sel, quantiles=(0.5, 0.9, 0.99, 0.999))
+    far = np.abs(pre[..., :3].astype(np.int64) - ref_pre16[..., :3]).max(axis=2) > 300
+    assert far.mean() <= 2e-5, far.sum()
+
+    matrix = util.blue_noise(pl)
+    assert dither_consistency(got, pre, matrix) == 0.0
+    assert dither_consistency(got, pre, np.roll(matrix, 1, axis=0)) > 0.2

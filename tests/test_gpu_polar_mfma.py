@@ -1,0 +1,180 @@
+"""k_polar_mx -- the EWA 2x upscale as a tile contraction on the f16 matrix pipe (the library's
+default for that geometry) -- against k_polar_pp, the sequential-fma kernel that is bit-exact
+with the oracle (tests/test_gpu_fullsize.py, PL_HIP_POLAR_MFMA=0), and against the oracle itself.
+
+Parity statement (north star: +-1 code of 16 bits per channel, dither index bit-exact):
+  * before any quantisation (rgba32f target): |mx - pp| <= 4e-6 of full scale (a quarter of a
+    16-bit code): f16 hi + lo weight halves, exact products, fp32 sums in another order;
+  * rgba16 target: never more than one code apart, identical on the bulk;
+  * 10-bit dithered target: never more than one 10-bit step apart, and only where the value
+    lies within that quarter code of a dither threshold (a fraction of a percent).
+Same geometries as the bit-exact tests: the BASELINE frame (chirp and white noise), odd sizes
+whose edge tiles are clipped, sampled alpha, an rgba16hf source (no fused pass), the HDR colour
+map behind it (full interpreter in the epilogue), flipped and offset targets.
+"""
+import os
+
+import numpy as np
+import pytest
+
+import libplacebo_amd as pl
+import orc
+import util
+from libplacebo_amd import _capi as capi
+
+pytestmark = pytest.mark.gpu
+
+TEN_BIT = dict(sample_depth=16, color_depth=10, bit_shift=6)
+
+
+class env:
+    def __init__(self, **kw):
+        self.kw = kw
+
+    def __enter__(self):
+        self.old = {k: os.environ.get(k) for k in self.kw}
+        os.environ.update(self.kw)
+
+    def __exit__(self, *exc):
+        for k, v in self.old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+
+
+def dither10():
+    return dict(dither_params=capi.DitherParams(method=pl.DITHER_BLUE_NOISE, lut_size=6, transfer=0),
+                disable_dither_gamma_correction=True)
+
+
+def render(img, dw, dh, params, mfma, src_fmt="rgba16", dst_fmt="rgba16", ten_bit=False,
+           components=3, image_kw=None, target_kw=None, expect_mx=None):
+    """one frame through pl_render_image on a fresh backend whose log is kept (the kernel choice
+    is logged at debug level)"""
+    with env(PL_HIP_POLAR_MFMA="1" if mfma else "0"):
+        with pl.HipGpu(0, log_level=5) as g:
+            sh, sw = img.shape[:2]
+            src = g.tex_create(sw, sh, src_fmt, img)
+            dst = g.tex_create(dw, dh, dst_fmt)
+            rr = pl.Renderer(g)
+            util.srand(1)
+            image = pl.frame(src, components=components, **(image_kw or {}))
+            target = pl.frame(dst, repr_=pl.color_repr("rgb", "full", **TEN_BIT) if ten_bit else None,
+                              **(target_kw or {}))
+            assert rr.render(image, target, params), g.messages[-4:]
+            assert rr.errors() == 0
+            out = dst.download()
+            used = any("polar on the matrix pipe" in m for _, m in g.messages)
+            rr.destroy(); src.destroy(); dst.destroy()
+    if expect_mx is not None:
+        assert used == expect_mx, "kernel choice: matrix pipe %s" % used
+    return out
+
+
+def ewa(**kw):
+    return pl.render_params("fast", upscaler=pl.filter_config("ewa_lanczos"), **kw)
+
+
+def assert_codes(mx, pp, step=1, max_frac=0.15):
+    d = np.abs(mx.astype(np.int64) - pp.astype(np.int64))
+    assert d.max() <= step, (int(d.max()), int((d > step).sum()))
+    assert (d > 0).mean() <= max_frac, float((d > 0).mean())
+    return float((d > 0).mean())
+
+
+@pytest.mark.parametrize("size", [(96, 64), (130, 77), (1920, 1080)])
+@pytest.mark.parametrize("content", ["chirp", "noise"])
+def test_mx_vs_reference_kernel_and_oracle(size, content):
+    sw, sh = size
+    img = util.chirp_rgba16(sw, sh) if content == "chirp" else util.random_rgba16(sw, sh, seed=3)
+    dw, dh = 2 * sw, 2 * sh
+    # -- unquantised
+    f_mx = render(img, dw, dh, ewa(), True, dst_fmt="rgba32f", expect_mx=True)
+    f_pp = render(img, dw, dh, ewa(), False, dst_fmt="rgba32f", expect_mx=False)
+    err = np.abs(f_mx[..., :3].astype(np.float64) - f_pp[..., :3])
+    print("k_polar_mx vs k_polar_pp %dx%d %s: max |diff| %.2e, mean %.2e (one 16-bit code = 1.5e-5)"
+          % (sw, sh, content, err.max(), err.mean()))
+    assert err.max() <= 4e-6, err.max()
+    assert np.array_equal(f_mx[..., 3], f_pp[..., 3])
+    # -- 16-bit target, against the reference kernel and against the oracle
+    q_mx = render(img, dw, dh, ewa(), True, expect_mx=True)
+    q_pp = render(img, dw, dh, ewa(), False)
+    assert_codes(q_mx, q_pp)
+    a = orc.tex_decode(img, "rgba16")
+    a[..., 3] = 1.0
+    a = orc.op_quant_f16(a)
+    w, r, rz = orc.filter_generate_polar(orc.ewa_lanczos())
+    ref16 = orc.tex_encode(orc.sample_polar(a, w, r, rz, dw, dh, mask=0x7), "rgba16")
+    assert np.array_equal(q_pp, ref16)      # (the reference variant IS the oracle, bit for bit)
+    assert_codes(q_mx, ref16)
+    # -- 10-bit blue-noise dither: a step only where a threshold lies within the difference
+    d_mx = render(img, dw, dh, ewa(**dither10()), True, ten_bit=True, expect_mx=True)
+    d_pp = render(img, dw, dh, ewa(**dither10()), False, ten_bit=True)
+    assert np.all(d_mx & 63 == 0)
+    frac = assert_codes(d_mx >> 6, d_pp >> 6, step=1, max_frac=0.004)
+    print("  10-bit dithered frames differ on %.5f of the samples, by one step" % frac)
+
+
+def test_mx_sampled_alpha_and_f16_source():
+    """4-channel tile; an rgba16hf source is copied into the planes bit for bit (no fused pass)"""
+    sw, sh = 120, 70
+    rng = np.random.default_rng(9)
+    img = rng.random((sh, sw, 4), dtype=np.float32).astype(np.float16)
+    for comps in (3, 4):
+        mx = render(img, 2 * sw, 2 * sh, ewa(), True, src_fmt="rgba16hf", dst_fmt="rgba32f",
+                    components=comps, expect_mx=True)
+        pp = render(img, 2 * sw, 2 * sh, ewa(), False, src_fmt="rgba16hf", dst_fmt="rgba32f",
+                    components=comps)
+        err = np.abs(mx.astype(np.float64) - pp)
+        assert err.max() <= 4e-6, (comps, err.max())
+    img16 = util.random_rgba16(sw, sh, seed=4)
+    mx = render(img16, 2 * sw, 2 * sh, ewa(**dither10()), True, ten_bit=True, components=4,
+                image_kw=dict(repr_=pl.color_repr("rgb", "full", alpha="independent")), expect_mx=True)
+    pp = render(img16, 2 * sw, 2 * sh, ewa(**dither10()), False, ten_bit=True, components=4,
+                image_kw=dict(repr_=pl.color_repr("rgb", "full", alpha="independent")))
+    assert_codes(mx >> 6, pp >> 6, max_frac=0.01)
+
+
+def test_mx_offset_and_flipped_targets():
+    """target crop (offset store, gl_FragCoord offset of the dither) and a flipped target"""
+    sw, sh = 100, 60
+    img = util.chirp_rgba16(sw, sh)
+    for crop in [(16.0, 8.0, 216.0, 128.0), (200.0, 120.0, 0.0, 0.0)]:
+        kw = dict(target_kw=dict(crop=crop), ten_bit=True)
+        mx = render(img, 232, 140, ewa(**dither10()), True, **kw)
+        pp = render(img, 232, 140, ewa(**dither10()), False, **kw)
+        assert_codes(mx >> 6, pp >> 6, max_frac=0.01)
+
+
+def test_mx_not_used_where_it_does_not_apply():
+    """other ratios keep the phase-class kernel; both switches give the same frame there"""
+    sw, sh = 96, 64
+    img = util.chirp_rgba16(sw, sh)
+    for dw, dh in ((288, 192), (144, 96), (192, 96)):
+        a = render(img, dw, dh, ewa(), True, expect_mx=False)
+        b = render(img, dw, dh, ewa(), False, expect_mx=False)
+        assert np.array_equal(a, b)
+
+
+def test_mx_hdr_colour_map_epilogue():
+    """the metric's second pass at small size: f16 intermediate -> polar on the matrix pipe ->
+    PQ linearize, tone + gamut map, BT.1886, dither in the epilogue (full interpreter).
+    Pre-dither the two kernels must agree to the conditioning of the colour map."""
+    from test_gpu_fullsize import hdr_frame16
+    sw, sh = 160, 90
+    img = hdr_frame16(sw, sh)
+    hdr = pl.color_space("bt2020", "pq", max_luma=1000.0)
+    sdr = pl.color_space("bt709", "bt1886")
+    params = pl.render_params("default", upscaler=pl.filter_config("ewa_lanczos"), dither_params=None,
+                              peak_detect_params=pl.peak_detect_params(percentile=99.995))
+    kw = dict(image_kw=dict(color=hdr), target_kw=dict(color=sdr))
+    mx = render(img, 2 * sw, 2 * sh, params, True, expect_mx=True, **kw)
+    pp = render(img, 2 * sw, 2 * sh, params, False, **kw)
+    d = np.abs(mx[..., :3].astype(np.int64) - pp[..., :3])
+    print("HDR epilogue: |mx - pp| codes: median %.1f p99 %.1f max %d" %
+          (np.median(d), np.quantile(d, 0.99), d.max()))
+    # a quarter code into the PQ EOTF and the inverse display gamma: a few codes at most,
+    # identical or adjacent on the bulk
+    assert np.quantile(d, 0.5) <= 1 and np.quantile(d, 0.99) <= 4 and d.max() <= 64
+    assert np.array_equal(mx[..., 3], pp[..., 3])
