@@ -12,6 +12,7 @@
  *   ortho filter / LUT        sampling.c:914-942, 1004-1063
  *   deband constants          sampling.c:183-275
  */
+#include <float.h>
 #include <math.h>
 #include <stdlib.h>
 #include <string.h>
@@ -677,7 +678,9 @@ static bool mx_axis(const float *fc, const int32_t *base, const uint16_t *ids, i
         const int q = i & 1;
         if (base[i] != base[0] + (i >> 1) + (q ? *c1 : 0))
             return false;
-        if (fabsf(fc[i] - fc[q]) > 1e-5f)
+        // the phase of a column differs from its parity's by the fp32 rounding of the attribute
+        // interpolation, which grows with the coordinate: a few ulps of the source position
+        if (fabsf(fc[i] - fc[q]) > 1e-5f + 1.5f * FLT_EPSILON * (float) len)
             return false;
     }
     return true;
@@ -696,11 +699,17 @@ static bool polar_mx_build(pl_gpu gpu, pl_log log, struct sh_sampler_obj *obj,
     const int W = pass->width, H = pass->height;
     obj->mx_host = (struct plh_polar_mx) {0};
     if (s->bound > 4 || s->tile_fp32 || s->address_mode != PLH_ADDRESS_CLAMP || pass->transpose ||
-        s->src.w < 2 || s->antiring > 0)
+        s->src.w < 2 || s->antiring > 0) {
+        pl_msg(log, PL_LOG_DEBUG, "matrix-pipe polar: not this pass (bound %d, fp32 tile %d, address "
+               "mode %d, transpose %d, antiring %g)", s->bound, s->tile_fp32, s->address_mode,
+               pass->transpose, s->antiring);
         return false;
+    }
     int cx[2], cy[2], c1x, c1y;
-    if (!mx_axis(colfc, colbase, idx, W, cx, &c1x) || !mx_axis(rowfc, rowbase, idy, H, cy, &c1y))
+    if (!mx_axis(colfc, colbase, idx, W, cx, &c1x) || !mx_axis(rowfc, rowbase, idy, H, cy, &c1y)) {
+        pl_msg(log, PL_LOG_DEBUG, "matrix-pipe polar: not an exact 2x geometry");
         return false;
+    }
 
     // tap (x, y) -> index in the list, x, y in [-3, 4]
     int tap_at[8][8];
@@ -766,9 +775,14 @@ static bool polar_mx_build(pl_gpu gpu, pl_log log, struct sh_sampler_obj *obj,
         .bfrag = pl_hip_buf_ptr(obj->mx_blob),
     };
     obj->mx_announced = false;
-    pl_msg(log, PL_LOG_DEBUG, "matrix-pipe tables for the polar pass: 2 x 2 phases (fcoord %.6f %.6f / %.6f %.6f), "
-           "%d x %d workgroup tiles of 80 x %d pixels, weight split error <= %.2e",
-           colfc[0], colfc[1], rowfc[0], rowfc[1], obj->mx_host.tiles_x, obj->mx_host.tiles_y,
+    float dev = 0.0f;   // how far a pixel's own phase lies from the one its parity is given
+    for (int i = 0; i < W; i++)
+        dev = fmaxf(dev, fabsf(colfc[i] - colfc[i & 1]));
+    for (int i = 0; i < H; i++)
+        dev = fmaxf(dev, fabsf(rowfc[i] - rowfc[i & 1]));
+    pl_msg(log, PL_LOG_DEBUG, "matrix-pipe tables for the polar pass: 2 x 2 phases (fcoord %.6f %.6f / %.6f %.6f, "
+           "per-pixel phases within %.2e), %d x %d workgroup tiles of 80 x %d pixels, weight split error <= %.2e",
+           colfc[0], colfc[1], rowfc[0], rowfc[1], dev, obj->mx_host.tiles_x, obj->mx_host.tiles_y,
            32 * wrows, worst);
     return true;
 }
