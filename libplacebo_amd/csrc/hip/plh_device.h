@@ -94,16 +94,19 @@ struct plh_polar_pp {
 // 16-row x 16-column block of same-phase outputs is a small GEMM  out[m][n] = sum_k A[m][k] B[k][n]
 // with A = rows of the f16 source tile (LDS, channel-planar) and B = a banded (Toeplitz) matrix
 // of the filter weights, split into f16 hi + lo halves (the products are exact in fp32, the sums
-// are fp32). One v_mfma_f32_16x16x32_f16 covers two source rows x 16 source columns.
-// The host builds B once per (filter, geometry) in fragment order: frag f, lane l, element e.
-#define PLH_MX_NFRAG 18     // (py = 0: 4 row pairs, py = 1: 5) x {hi, lo}
-#define PLH_MX_WT_COLS 5    // wave tiles (16 output columns each) per workgroup row
+// are fp32), plus the first-order terms in the per-pixel phase deviation: B' = d B / d fcoord_x
+// and d B / d fcoord_y, scaled by 2^-PLH_MX_DSHIFT, against dfx[] / dfy[] scaled by 2^+PLH_MX_DSHIFT.
+// One v_mfma_f32_16x16x32_f16 covers two source rows x 16 source columns.
+// The host builds B once per (filter, geometry) in fragment order: frag f, lane l, element e,
+// f = 4 * (py ? 4 + j : j) + {hi, lo, d/dx, d/dy} for row pair j (py = 0: 4 pairs, py = 1: 5).
+#define PLH_MX_NFRAG 36
+#define PLH_MX_DSHIFT 11
+#define PLH_MX_PAD 128      // dfx / dfy are padded to a multiple of this many outputs (the widest tile)
 struct plh_polar_mx {
     int32_t enabled;
-    int32_t org_x, org_y;   // source texel held by LDS tile (0, 0) of workgroup (0, 0)
-    int32_t tiles_x, tiles_y;
-    int32_t wrows;          // wave tiles (32 output rows each) per workgroup column
+    int32_t org_x, org_y;   // source texel held by LDS tile (0, 0) of workgroup tile (0, 0)
     const void *bfrag;      // device: [PLH_MX_NFRAG][64 lanes][8] f16
+    const float *dfx, *dfy; // device: phase deviation of every output column / row, x 2^PLH_MX_DSHIFT
 };
 
 struct plh_sampler_args {

@@ -14,6 +14,7 @@
  */
 #include <float.h>
 #include <math.h>
+#include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 
@@ -686,14 +687,17 @@ static bool mx_axis(const float *fc, const int32_t *base, const uint16_t *ids, i
     return true;
 }
 
-// B fragments (plh_device.h): frag f = (py ? 8 + 2 j : 2 j) + hl, lane l, element e hold
+// B fragments (plh_device.h): frag f = 4 * (py ? 4 + j : j) + kind, lane l, element e hold
 //   T(py, wy)[k][n] with n = l & 15, k = 8 * ((l >> 4) & 1) + e, wy = 2 j + (l >> 5) - cy(py),
-//   = w'(phase py, phase n & 1, tap (k - dbx[n] - 3, wy - 3)), hi or lo f16 half
+//   = w'(phase py, phase n & 1, tap (k - dbx[n] - 3, wy - 3)): kind 0 / 1 its hi / lo f16 halves,
+//   kind 2 / 3 its derivative in fcoord_x / fcoord_y times 2^-PLH_MX_DSHIFT.
+// The derivatives are the slopes of a least-squares line through the normalised weights of the
+// phase classes of that parity -- the weights the per-pixel kernels actually use for them.
 static bool polar_mx_build(pl_gpu gpu, pl_log log, struct sh_sampler_obj *obj,
                            const struct plh_pass *pass, const float *wall, const uint32_t *taps,
-                           int ntaps, int ncx, const float *colfc, const int32_t *colbase,
-                           const uint16_t *idx, const float *rowfc, const int32_t *rowbase,
-                           const uint16_t *idy)
+                           int ntaps, int ncx, int ncy, const float *clsx, const float *clsy,
+                           const float *colfc, const int32_t *colbase, const uint16_t *idx,
+                           const float *rowfc, const int32_t *rowbase, const uint16_t *idy)
 {
     const struct plh_sampler_args *s = &pass->s;
     const int W = pass->width, H = pass->height;
@@ -724,9 +728,54 @@ static bool polar_mx_build(pl_gpu gpu, pl_log log, struct sh_sampler_obj *obj,
         tap_at[y + 3][x + 3] = t;
     }
 
-    uint16_t *frag = calloc((size_t) PLH_MX_NFRAG * 64 * 8, sizeof(uint16_t));
-    if (!frag)
+    // normalised weight (w * scale / wsum) of tap t for the class pair (kx, ky)
+#define WN(kx, ky, t) ((double) wall[((size_t) (ky) * ncx + (kx)) * (ntaps + 1) + (t)] * \
+                       (double) wall[((size_t) (ky) * ncx + (kx)) * (ntaps + 1) + ntaps])
+    // d w' / d fcoord along one axis at the class pair (cx[px], cy[py])
+    double *slope[2];       // [axis][(py * 2 + px) * ntaps + t]
+    slope[0] = calloc((size_t) 4 * PL_MAX(ntaps, 1), sizeof(double));
+    slope[1] = calloc((size_t) 4 * PL_MAX(ntaps, 1), sizeof(double));
+    const size_t nfx = ((size_t) W + PLH_MX_PAD - 1) / PLH_MX_PAD * PLH_MX_PAD;
+    const size_t nfy = ((size_t) H + PLH_MX_PAD - 1) / PLH_MX_PAD * PLH_MX_PAD;
+    const size_t frag_bytes = (size_t) PLH_MX_NFRAG * 64 * 8 * sizeof(uint16_t);
+    const size_t o_dfx = frag_bytes, o_dfy = o_dfx + nfx * 4;
+    const size_t bytes = o_dfy + nfy * 4;
+    uint8_t *blob = calloc(1, bytes);
+    if (!slope[0] || !slope[1] || !blob) {
+        free(slope[0]); free(slope[1]); free(blob);
         return false;
+    }
+    for (int py = 0; py < 2; py++) {
+        for (int px = 0; px < 2; px++) {
+            double *sx = slope[0] + (size_t) (py * 2 + px) * ntaps;
+            double *sy = slope[1] + (size_t) (py * 2 + px) * ntaps;
+            double den = 0.0;
+            for (int c = 0; c < ncx; c++) {
+                const double d = (double) clsx[c] - (double) clsx[cx[px]];
+                if (fabs(d) > 0.01)
+                    continue;   // the other parity
+                den += d * d;
+                for (int t = 0; t < ntaps; t++)
+                    sx[t] += d * (WN(c, cy[py], t) - WN(cx[px], cy[py], t));
+            }
+            for (int t = 0; t < ntaps; t++)
+                sx[t] = den > 0.0 ? sx[t] / den : 0.0;
+            den = 0.0;
+            for (int c = 0; c < ncy; c++) {
+                const double d = (double) clsy[c] - (double) clsy[cy[py]];
+                if (fabs(d) > 0.01)
+                    continue;
+                den += d * d;
+                for (int t = 0; t < ntaps; t++)
+                    sy[t] += d * (WN(cx[px], c, t) - WN(cx[px], cy[py], t));
+            }
+            for (int t = 0; t < ntaps; t++)
+                sy[t] = den > 0.0 ? sy[t] / den : 0.0;
+        }
+    }
+
+    uint16_t *frag = (uint16_t *) blob;
+    const double dscale = ldexp(1.0, -PLH_MX_DSHIFT);
     double worst = 0.0;
     for (int py = 0; py < 2; py++) {
         for (int j = 0; j < (py ? 5 : 4); j++) {
@@ -734,56 +783,65 @@ static bool polar_mx_build(pl_gpu gpu, pl_log log, struct sh_sampler_obj *obj,
                 const int n = l & 15, px = n & 1;
                 const int dbx = (n >> 1) + (px ? c1x : 0);
                 const int wy = 2 * j + (l >> 5) - (py ? c1y : 0);
-                const float *w = wall + ((size_t) cy[py] * ncx + cx[px]) * (ntaps + 1);
                 for (int e = 0; e < 8; e++) {
                     const int k = 8 * ((l >> 4) & 1) + e, wx = k - dbx;
-                    double v = 0.0;
-                    if (wx >= 0 && wx < 8 && wy >= 0 && wy < 8 && tap_at[wy][wx] >= 0)
-                        v = (double) w[tap_at[wy][wx]] * (double) w[ntaps];  // w * scale / wsum
+                    double v = 0.0, vx = 0.0, vy = 0.0;
+                    if (wx >= 0 && wx < 8 && wy >= 0 && wy < 8 && tap_at[wy][wx] >= 0) {
+                        const int t = tap_at[wy][wx];
+                        v = WN(cx[px], cy[py], t);
+                        vx = slope[0][(size_t) (py * 2 + px) * ntaps + t];
+                        vy = slope[1][(size_t) (py * 2 + px) * ntaps + t];
+                    }
                     const uint16_t hi = f32_to_f16((float) v);
                     const uint16_t lo = f32_to_f16((float) (v - (double) f16_to_f32(hi)));
                     const double err = fabs(v - (double) f16_to_f32(hi) - (double) f16_to_f32(lo));
                     worst = PL_MAX(worst, err);
-                    const int f = (py ? 8 : 0) + 2 * j;
-                    frag[((size_t) f * 64 + l) * 8 + e] = hi;
-                    frag[((size_t) (f + 1) * 64 + l) * 8 + e] = lo;
+                    const size_t f = 4 * (size_t) (py ? 4 + j : j);
+                    frag[((f + 0) * 64 + l) * 8 + e] = hi;
+                    frag[((f + 1) * 64 + l) * 8 + e] = lo;
+                    frag[((f + 2) * 64 + l) * 8 + e] = f32_to_f16((float) (vx * dscale));
+                    frag[((f + 3) * 64 + l) * 8 + e] = f32_to_f16((float) (vy * dscale));
                 }
             }
         }
     }
+#undef WN
+    free(slope[0]);
+    free(slope[1]);
 
-    const size_t bytes = (size_t) PLH_MX_NFRAG * 64 * 8 * sizeof(uint16_t);
+    // how far a pixel's own phase lies from the one its parity is expanded about
+    float *dfx = (float *) (blob + o_dfx), *dfy = (float *) (blob + o_dfy);
+    float dev = 0.0f;
+    const float up = ldexpf(1.0f, PLH_MX_DSHIFT);
+    for (int i = 0; i < W; i++) {
+        const float d = colfc[i] - colfc[i & 1];
+        dev = fmaxf(dev, fabsf(d));
+        dfx[i] = d * up;
+    }
+    for (int i = 0; i < H; i++) {
+        const float d = rowfc[i] - rowfc[i & 1];
+        dev = fmaxf(dev, fabsf(d));
+        dfy[i] = d * up;
+    }
+
     pl_buf_destroy(gpu, &obj->mx_blob);
     obj->mx_blob = pl_buf_create(gpu, pl_buf_params(.size = bytes, .storable = true,
-                                                    .initial_data = frag));
-    free(frag);
+                                                    .initial_data = blob));
+    free(blob);
     if (!obj->mx_blob)
         return false;
 
-    // workgroup tile: 80 output columns x 32 * wrows rows; LDS = fragments + planar f16 tile
-    int wrows = 4;
-    const char *env = getenv("PL_HIP_MX_ROWS");     // profiling aid
-    if (env && atoi(env) > 0)
-        wrows = PL_MIN(atoi(env), 8);
-    wrows = PL_MIN(wrows, (H + 31) / 32);
+    const char *base = pl_hip_buf_ptr(obj->mx_blob);
     obj->mx_host = (struct plh_polar_mx) {
         .enabled = 1,
         .org_x = colbase[0] - 3, .org_y = rowbase[0] - 3,
-        .tiles_x = (W + 16 * PLH_MX_WT_COLS - 1) / (16 * PLH_MX_WT_COLS),
-        .tiles_y = (H + 32 * wrows - 1) / (32 * wrows),
-        .wrows = wrows,
-        .bfrag = pl_hip_buf_ptr(obj->mx_blob),
+        .bfrag = base,
+        .dfx = (const float *) (base + o_dfx), .dfy = (const float *) (base + o_dfy),
     };
     obj->mx_announced = false;
-    float dev = 0.0f;   // how far a pixel's own phase lies from the one its parity is given
-    for (int i = 0; i < W; i++)
-        dev = fmaxf(dev, fabsf(colfc[i] - colfc[i & 1]));
-    for (int i = 0; i < H; i++)
-        dev = fmaxf(dev, fabsf(rowfc[i] - rowfc[i & 1]));
     pl_msg(log, PL_LOG_DEBUG, "matrix-pipe tables for the polar pass: 2 x 2 phases (fcoord %.6f %.6f / %.6f %.6f, "
-           "per-pixel phases within %.2e), %d x %d workgroup tiles of 80 x %d pixels, weight split error <= %.2e",
-           colfc[0], colfc[1], rowfc[0], rowfc[1], dev, obj->mx_host.tiles_x, obj->mx_host.tiles_y,
-           32 * wrows, worst);
+           "per-pixel phases within %.2e: first-order terms), weight split error <= %.2e",
+           colfc[0], colfc[1], rowfc[0], rowfc[1], dev, worst);
     return true;
 }
 
@@ -948,8 +1006,8 @@ static bool polar_pp_build(pl_gpu gpu, pl_log log, struct sh_sampler_obj *obj,
         tapoff[k] = (y * tx.extent + x) * (int) texel;
     }
     // the same geometry on the matrix pipe, where it has the shape for it
-    polar_mx_build(gpu, log, obj, pass, wall, taps_all, ntaps, ncx, colfc, colbase, idx,
-                   rowfc, rowbase, idy);
+    polar_mx_build(gpu, log, obj, pass, wall, taps_all, ntaps, ncx, ncy, clsx, clsy, colfc, colbase,
+                   idx, rowfc, rowbase, idy);
     free(taps_all);
     free(keep);
 

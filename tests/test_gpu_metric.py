@@ -132,7 +132,9 @@ def peak_buffer_word_for_word(gpu, img, hdr_i, percentile):
     assert np.abs(buf[36:48].astype(np.int64) - refbuf[36:48]).max() <= 1
     gh, rh = buf[48:].reshape(12, 64).astype(np.int64), refbuf[48:].reshape(12, 64).astype(np.int64)
     assert gh.sum() == rh.sum()
-    assert np.abs(gh - rh).sum() <= max(4, w * h // 100000)
+    # a pixel whose 14-bit code comes out one apart (native pow: a few per cent of them) changes
+    # bins when it sits on one of the 128-code bin boundaries; each such pixel counts twice
+    assert np.abs(gh - rh).sum() <= max(4, w * h // 1280), np.abs(gh - rh).sum()
     # the FBO the scaler reads: bit for bit the f16 rounding of the decoded plane
     want = orc.op_quant_f16(tex.copy()).astype(np.float16)
     assert np.array_equal(fbo_got.view(np.uint16), want.view(np.uint16))
@@ -345,7 +347,7 @@ def test_cfg5_high_quality_as_benched(gpu, size):
     # intermediate, see test_gpu_fullsize.test_cfg5_8k_to_4k_deband_ewa_tone_map)
     colormap_tolerance(pre, ref_pre16, truth.reshape(-1, 4), sel, quantiles=(0.5, 0.9, 0.99, 0.999))
     far = np.abs(pre[..., :3].astype(np.int64) - ref_pre16[..., :3]).max(axis=2) > 300
-    assert far.mean() <= 2e-5, far.sum()
+    assert far.sum() <= max(1, int(2e-5 * far.size)), far.sum()
 
     matrix = util.blue_noise(pl)
     assert dither_consistency(got, pre, matrix) == 0.0

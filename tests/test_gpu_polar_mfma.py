@@ -111,7 +111,7 @@ def test_mx_vs_reference_kernel_and_oracle(size, content):
     # -- 10-bit blue-noise dither: a step only where a threshold lies within the difference
     d_mx = render(img, dw, dh, ewa(**dither10()), True, ten_bit=True, expect_mx=True)
     d_pp = render(img, dw, dh, ewa(**dither10()), False, ten_bit=True)
-    assert np.all(d_mx & 63 == 0)
+    assert np.all((d_mx & 63 == 0) | (d_mx == 65535))   # (samples dithered beyond 1: clamped by the store)
     frac = assert_codes(d_mx >> 6, d_pp >> 6, step=1, max_frac=0.004)
     print("  10-bit dithered frames differ on %.5f of the samples, by one step" % frac)
 

@@ -1,0 +1,12 @@
+cd $GRAFT_REPO_ROOT; export TMPDIR=/tmp
+run() { python bench.py --workload $1 --steps 200 --warmup 20 --no-cpu-baseline --no-companions --no-traffic --no-concurrent 2>/dev/null | python -c "
+import json,sys
+d=json.loads(sys.stdin.read()); print('$2', d['ms_per_step'], d['roofline']['kernel_us'], list(d['roofline']['passes_us'].values()))"; }
+run ewa_lanczos_1080p_to_4k_dither10 cfg3
+for d in 1 4 8 13; do PL_HIP_PP_DEBUG=$d run ewa_lanczos_1080p_to_4k_dither10 dbg=$d; done
+run ewa_1080p_to_4k_hdr_tonemap metric
+PL_HIP_MX_PROF=/tmp/mxprof.bin run ewa_lanczos_1080p_to_4k_dither10 cfg3prof
+python tools/scratch/prof_mx.py /tmp/mxprof.bin 512 | head -8
+PL_HIP_MX_PROF=/tmp/mxprof2.bin run ewa_1080p_to_4k_hdr_tonemap metricprof
+python tools/scratch/prof_mx.py /tmp/mxprof2.bin 512 | head -8
+timeout 900 python -m pytest tests/test_gpu_polar_mfma.py -q -m gpu 2>&1 | tail -8
