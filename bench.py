@@ -35,7 +35,11 @@ timed on this box's host cores, 1 thread and all threads, CPU model stated.
 Frames rotate over a pool of source/target textures larger than the 256 MiB Infinity Cache so
 that every frame's compulsory traffic really crosses HBM.
 
-Multi-GPU (--gpus N>1, launched by torch.distributed.run): streams are independent, one per
+Multi-GPU (--gpus N>1): launched by torch.distributed.run (the driver's form), or started plain
+as `python bench.py --gpus N`, in which case it spawns its N ranks itself (spawn_ranks). Either
+way: one process per GPU, RCCL process group, barrier + device sync on both sides of the K steps,
+max over ranks. tests/c/bench_streams.c is the same shape in ONE process from C (a host thread +
+pl_hip + pl_renderer per device). Streams are independent, one per
 GPU, no data-path collective -> weak scaling; value = frames of all ranks /
 max-over-ranks time. With --scene-peak-allreduce the ranks render frames of ONE scene: after
 every frame's measurement pass the 816-word peak buffer is all-reduced over RCCL (SUM, MAX for
@@ -633,6 +637,61 @@ def baseline_metric():
         return "Mpixels/s (and frames/s) for EWA-Lanczos 1080p->4K + HDR tonemap, 1/2/4/8 GPU"
 
 
+def spawn_ranks(n):
+    """`python bench.py --gpus N` without a launcher: start N copies of this command, one rank per
+    GPU, with the environment torch.distributed.run would have given them (RANK, LOCAL_RANK,
+    WORLD_SIZE, MASTER_ADDR = 127.0.0.1, a free MASTER_PORT). Rank 0 owns stdout (the one JSON
+    line); the exit status is the worst of the ranks'. A rank that dies takes the others down."""
+    import socket
+    import subprocess
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n),
+                   LOCAL_WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=None if r == 0 else subprocess.DEVNULL))
+    rc = 0
+    try:
+        pending = list(procs)
+        while pending:
+            for pr in list(pending):
+                code = pr.poll()
+                if code is None:
+                    continue
+                pending.remove(pr)
+                rc = rc or code
+                if code:
+                    for other in pending:   # (exact PIDs of our own children)
+                        other.terminate()
+            time.sleep(0.05)
+    finally:
+        for pr in procs:
+            if pr.poll() is None:
+                pr.kill()
+    return rc
+
+
+def launcher_selftest():
+    import torch
+    import torch.distributed as dist
+    rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
+    if world > 1:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    t = torch.tensor([float(rank + 1)])
+    if world > 1:
+        dist.all_reduce(t)
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps({"launcher_selftest": True, "world": world, "sum": float(t.item()),
+                          "local_rank": int(os.environ.get("LOCAL_RANK", "0"))}), flush=True)
+    return 0
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -656,7 +715,16 @@ def main():
                     help="skip the several-streams-on-one-GPU companion measurement")
     ap.add_argument("--bare", action="store_true",
                     help="timed loop only (what the --pmc child processes run)")
+    ap.add_argument("--launcher-selftest", action="store_true",
+                    help="(CPU) every rank joins a gloo group, all-reduces its rank, rank 0 prints "
+                         "the sum: exercises the rank launcher without a GPU")
     args = ap.parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # started as plain `python bench.py --gpus N` (the form of the driver's N = 1 command):
+        # become the launcher, one rank per GPU; torch.distributed.run is not needed
+        sys.exit(spawn_ranks(args.gpus))
+    if args.launcher_selftest:
+        sys.exit(launcher_selftest())
     Stream.async_measure = bool(args.async_measure)
     if args.bare:
         args.no_cpu_baseline = args.no_companions = args.no_traffic = args.no_concurrent = True

@@ -70,3 +70,21 @@ def test_bench_rank_env_contract():
     for key in ('"RANK"', '"WORLD_SIZE"', '"LOCAL_RANK"', "MASTER_ADDR", '"nccl"',
                 "dist.barrier", "ReduceOp.MAX"):
         assert key in src, key
+
+
+def test_bench_spawns_its_own_ranks():
+    """`python bench.py --gpus 2` started without torchrun becomes its own launcher (one process
+    per rank, RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* as torch.distributed.run sets them); the
+    selftest mode joins a gloo group on the CPU, so the rendezvous itself is exercised here."""
+    import json
+    import subprocess
+    root = os.path.dirname(HERE)
+    env = {k: v for k, v in os.environ.items()
+           if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--launcher-selftest"],
+                       capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode == 0, r.stdout + r.stderr
+    line = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(line) == 1, r.stdout      # rank 0 alone owns stdout
+    out = json.loads(line[0])
+    assert out["world"] == 2 and out["sum"] == 3.0 and out["local_rank"] == 0

@@ -5,6 +5,7 @@ host): same picture, exchanges counted, no RCCL error; (b) a host callback that 
 rank measured the identical tile": SUM words double, MAX words stay -- averages, percentiles and
 therefore the picture must not move."""
 import ctypes as C
+import os
 
 import numpy as np
 import pytest
@@ -137,3 +138,28 @@ def test_concurrent_streams_on_one_gpu():
     assert not failures, failures
     for a, b in zip(alone, together):
         assert np.array_equal(a, b)
+
+
+def test_c_worker_streams_in_one_process(gpu):
+    """tests/c/bench_streams.c: SURVEY 8(e)'s shape from plain C -- one host thread + pl_hip +
+    pl_renderer per stream -- at the sizes this box has: 1 stream, 2 streams on the one device,
+    and (world size 1) the RCCL scene-peak exchange through ncclCommInitAll."""
+    import json
+    import subprocess
+    exe = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "c", "build",
+                       "bench_streams")
+    assert os.path.exists(exe), "tests/c/build/bench_streams missing: run build()"
+
+    def run(*args):
+        r = subprocess.run([exe, *args], capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stdout + r.stderr
+        return json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+
+    one = run("1", "60")
+    assert one["streams"] == 1 and one["render_errors"] == 0 and one["value"] > 1000.0
+    two = run("2", "60")
+    assert two["streams"] == 2 and two["render_errors"] == 0
+    # two independent streams on one device never render fewer pixels per second than one
+    assert two["value"] > 0.9 * one["value"], (one, two)
+    peak = run("1", "40", "--scene-peak")
+    assert peak["scene_peak_allreduce"] and peak["peak_exchanges"] >= 40 and peak["exchange_errors"] == 0
