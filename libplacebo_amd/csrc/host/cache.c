@@ -464,49 +464,67 @@ static void object_path(char *out, size_t len, const char *prefix, uint64_t key)
     snprintf(out, len, "%s%016llx", prefix, (unsigned long long) key);
 }
 
-void pl_cache_set_file(void *path, pl_cache_obj obj)
+// File layout = the reference's (src/cache.c:474-521): header, ONE entry, exactly `size` payload
+// bytes -- no padding, unlike an entry inside a stream -- so that a directory can be shared with
+// other builds of libplacebo.
+void pl_cache_set_file(void *priv, pl_cache_obj obj)
 {
-    char name[4096];
-    object_path(name, sizeof(name), path, obj.key);
+    const char *dir = priv;
+    if (!dir || !dir[0])
+        return;
+    char name[4096], tmp[4096 + 32];
+    object_path(name, sizeof(name), dir, obj.key);
     if (!obj.size) {
         unlink(name);
         return;
     }
-    FILE *f = fopen(name, "wb");
+    // an existing file is left alone (it is validated when it is read)
+    if (access(name, F_OK) == 0)
+        return;
+    // written under a private name and renamed: a concurrent reader sees the whole file or none
+    snprintf(tmp, sizeof(tmp), "%s.%ld.tmp", name, (long) getpid());
+    FILE *f = fopen(tmp, "wb");
     if (!f)
         return;
     struct stream_head h = { .version = STREAM_VERSION, .count = 1 };
     memcpy(h.magic, magic, sizeof(magic));
-    pl_write_file_cb(f, sizeof(h), &h);
-    write_obj(pl_write_file_cb, f, obj);
-    fclose(f);
+    const struct stream_entry e = { obj.key, obj.size, plh_mem_hash(obj.data, obj.size) };
+    bool ok = fwrite(&h, sizeof(h), 1, f) == 1 && fwrite(&e, sizeof(e), 1, f) == 1 &&
+              fwrite(obj.data, 1, obj.size, f) == obj.size;
+    ok = fclose(f) == 0 && ok;
+    if (!ok || rename(tmp, name) != 0)
+        unlink(tmp);
 }
 
-pl_cache_obj pl_cache_get_file(void *path, uint64_t key)
+pl_cache_obj pl_cache_get_file(void *priv, uint64_t key)
 {
+    const char *dir = priv;
+    if (!dir || !dir[0])
+        return (pl_cache_obj) {0};
     char name[4096];
-    object_path(name, sizeof(name), path, key);
+    object_path(name, sizeof(name), dir, key);
     FILE *f = fopen(name, "rb");
     if (!f)
         return (pl_cache_obj) {0};
 
-    pl_cache_obj obj = {0};
     struct stream_head h;
-    if (pl_read_file_cb(f, sizeof(h), &h) && !memcmp(h.magic, magic, sizeof(magic)) &&
-        h.version == STREAM_VERSION && h.count == 1)
-    {
-        obj = read_obj(NULL, pl_read_file_cb, f);
-        if (obj.size && obj.key != key) {
-            obj.free(obj.data);
-            obj = (pl_cache_obj) {0};
-        }
+    struct stream_entry e;
+    void *data = NULL;
+    bool ok = fread(&h, sizeof(h), 1, f) == 1 && !memcmp(h.magic, magic, sizeof(magic)) &&
+              h.version == STREAM_VERSION && h.count == 1 &&
+              fread(&e, sizeof(e), 1, f) == 1 && e.key == key && e.size && e.size <= SIZE_MAX;
+    if (ok) {
+        // exactly e.size bytes; whatever follows them (padding written by another version) is ignored
+        data = malloc(e.size);
+        ok = data && fread(data, 1, e.size, f) == e.size && plh_mem_hash(data, e.size) == e.digest;
     }
     fclose(f);
-    if (!obj.size) {
+    if (!ok) {
+        free(data);
         unlink(name);   // stale or corrupt
         return (pl_cache_obj) {0};
     }
-    return obj;
+    return (pl_cache_obj) { .key = key, .data = data, .size = e.size, .free = free };
 }
 
 bool plh_cache_memoize(pl_cache cache, uint64_t signature, void *data, size_t size,

@@ -362,7 +362,40 @@ pl_buf pl_buf_create(pl_gpu gpu, const struct pl_buf_params *params)
                "buffer handles (wrap device memory with pl_hip_wrap instead)");
         return NULL;
     }
-    return GPU_FNS(gpu)->buf_create(gpu, params);
+    // what each use of a buffer may ask for (src/gpu.c:595-604); limits.max_mapped_size is 0 on
+    // this backend, so a host_mapped buffer is refused here instead of coming back without `data`
+    const struct { bool wanted; size_t limit; const char *what; } uses[] = {
+        { params->uniform, gpu->limits.max_ubo_size, "uniform" },
+        { params->storable, gpu->limits.max_ssbo_size, "storable" },
+        { params->drawable, gpu->limits.max_vbo_size, "drawable" },
+        { params->host_mapped, gpu->limits.max_mapped_size, "host_mapped" },
+        { params->host_mapped && params->memory_type == PL_BUF_MEM_DEVICE,
+          gpu->limits.max_mapped_vram, "host_mapped in device memory" },
+    };
+    for (size_t i = 0; i < PL_ARRAY_SIZE(uses); i++) {
+        if (uses[i].wanted && params->size > uses[i].limit) {
+            pl_msg(gpu->log, PL_LOG_ERR, "pl_buf_create: %zu bytes exceed the limit for %s buffers "
+                   "(%zu)%s%s", params->size, uses[i].what, uses[i].limit,
+                   params->debug_tag ? " for buffer: " : "", params->debug_tag ? params->debug_tag : "");
+            return NULL;
+        }
+    }
+    if (params->format) {
+        pl_fmt fmt = params->format;
+        if (params->size > gpu->limits.max_buffer_texels * fmt->texel_size ||
+            (params->uniform && !(fmt->caps & PL_FMT_CAP_TEXEL_UNIFORM)) ||
+            (params->storable && !(fmt->caps & PL_FMT_CAP_TEXEL_STORAGE))) {
+            pl_msg(gpu->log, PL_LOG_ERR, "pl_buf_create: format '%s' cannot back this texel buffer",
+                   fmt->name);
+            return NULL;
+        }
+    }
+    pl_buf buf = GPU_FNS(gpu)->buf_create(gpu, params);
+    if (buf && params->host_mapped && !buf->data) {
+        pl_msg(gpu->log, PL_LOG_ERR, "pl_buf_create: backend returned an unmapped host_mapped buffer");
+        pl_buf_destroy(gpu, &buf);
+    }
+    return buf;
 }
 
 void pl_buf_destroy(pl_gpu gpu, pl_buf *buf)
@@ -375,8 +408,18 @@ void pl_buf_destroy(pl_gpu gpu, pl_buf *buf)
 
 bool pl_buf_recreate(pl_gpu gpu, pl_buf *buf, const struct pl_buf_params *params)
 {
-    if (*buf && (*buf)->params.size == params->size && !params->initial_data)
-        return true;
+    // reusable iff the existing buffer can do everything the new one is asked to
+    // (pl_buf_params_superset, src/gpu.c:630-641)
+    if (*buf && !params->initial_data) {
+        const struct pl_buf_params *have = &(*buf)->params;
+        const bool covers = have->size >= params->size &&
+            have->memory_type == params->memory_type && have->format == params->format &&
+            have->host_writable >= params->host_writable && have->host_readable >= params->host_readable &&
+            have->host_mapped >= params->host_mapped && have->uniform >= params->uniform &&
+            have->storable >= params->storable && have->drawable >= params->drawable;
+        if (covers)
+            return true;
+    }
     pl_buf_destroy(gpu, buf);
     *buf = pl_buf_create(gpu, params);
     return !!*buf;

@@ -439,7 +439,7 @@ bool pl_render_image_mix(pl_renderer rr, const struct pl_frame_mix *mix,
         for (int i = 0; i < mix->num_frames && n < RR_MAX_MIX_FRAMES; i++) {
             const struct pl_frame *image = mix->frames[i];
             float weight;
-            if (image->rotation != nearest->rotation ||
+            if (pl_rotation_normalize(image->rotation - nearest->rotation) != 0 ||
                 !frame_weight(mix, i, &ms, nearest, &weight))
                 continue;
 

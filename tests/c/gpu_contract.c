@@ -63,6 +63,21 @@ int main(void)
     REJECTED(pl_buf_copy(gpu, rw, 0, rw, 128, 64));                // same buffer
     REJECTED(CHECK(!pl_buf_create(gpu, pl_buf_params(.size = 0))));
     REJECTED(CHECK(!pl_buf_create(gpu, pl_buf_params(.size = 64, .export_handle = PL_HANDLE_FD))));
+    // no host-visible mappings on this backend (limits.max_mapped_size == 0): refused, never a
+    // buffer whose `data` is NULL (src/gpu.c:595-611)
+    REJECTED(CHECK(!pl_buf_create(gpu, pl_buf_params(.size = 64, .host_mapped = true))));
+    {
+        // pl_buf_recreate keeps a buffer only if it covers every capability asked for (:630-641)
+        pl_buf b = pl_buf_create(gpu, pl_buf_params(.size = 128, .host_writable = true));
+        CHECK(b);
+        pl_buf first = b;
+        CHECK(pl_buf_recreate(gpu, &b, pl_buf_params(.size = 96, .host_writable = true)) && b == first);
+        CHECK(pl_buf_recreate(gpu, &b, pl_buf_params(.size = 96, .host_writable = true, .host_readable = true)));
+        CHECK(b->params.host_readable && b->params.size == 96);
+        uint8_t probe[4] = {0};
+        CHECK(pl_buf_read(gpu, b, 0, probe, 4));
+        pl_buf_destroy(gpu, &b);
+    }
     // none of the above touched the buffer
     CHECK(pl_buf_read(gpu, rw, 0, back, 256));
     CHECK(!memcmp(back, pattern, 64) && !memcmp(back + 64, pattern, 32) && !memcmp(back + 96, pattern + 96, 160));

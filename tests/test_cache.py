@@ -191,3 +191,52 @@ def test_stream_interchange_with_the_reference_build(lib):
             assert impl.pl_cache_get(c, o) and payload(o) == b
             release(o)
         cc = C.c_void_p(c); impl.pl_cache_destroy(C.byref(cc))
+
+
+def test_object_files_interchange_with_the_reference_build(lib, tmp_path):
+    """pl_cache_set_file / pl_cache_get_file (src/cache.c:474-560): one file per object -- header,
+    entry, exactly `size` payload bytes (no padding, unlike a stream) -- written by either
+    implementation and read by the other, for sizes that are not multiples of four; no
+    directory = no file; an existing file is never overwritten; a corrupt one is removed."""
+    path = os.path.join(os.path.dirname(__file__), "..", "oracle", "_ref", "libplref.so")
+    if not os.path.exists(path):
+        pytest.skip("oracle/_ref/libplref.so not built")
+    ref = C.CDLL(path)
+    for impl in (lib, ref):
+        impl.pl_cache_set_file.restype = None
+        impl.pl_cache_set_file.argtypes = [C.c_char_p, Obj]
+        impl.pl_cache_get_file.restype = Obj
+        impl.pl_cache_get_file.argtypes = [C.c_char_p, C.c_uint64]
+    import numpy as np
+    rng = np.random.default_rng(11)
+    for wname, w, r in (("ours", lib, ref), ("ref", ref, lib)):
+        prefix = str(tmp_path / (wname + "_")).encode()
+        for n in (1, 2, 3, 5, 7, 64, 1001):
+            key, blob = int(rng.integers(1, 2 ** 63)), rng.bytes(n)
+            w.pl_cache_set_file(prefix, obj(key, blob))
+            name = prefix.decode() + "%016x" % key
+            assert os.path.getsize(name) == 16 + 24 + n          # nothing but the payload follows
+            for reader in (r, w):
+                o = reader.pl_cache_get_file(prefix, key)
+                assert o.size == n and payload(o) == blob, (wname, n)
+                release(o)
+            assert os.path.exists(name)                          # reading never deletes a valid file
+    # ours: guards and overwrite policy
+    for empty in (None, b""):
+        lib.pl_cache_set_file(empty, obj(KEY1, b"abc"))
+        assert lib.pl_cache_get_file(empty, KEY1).size == 0
+    assert not os.path.exists("%016x" % KEY1)                    # (nothing landed in the CWD)
+    prefix = str(tmp_path / "keep_").encode()
+    lib.pl_cache_set_file(prefix, obj(KEY2, b"first"))
+    lib.pl_cache_set_file(prefix, obj(KEY2, b"second!"))
+    o = lib.pl_cache_get_file(prefix, KEY2)
+    assert payload(o) == b"first"
+    release(o)
+    assert not [f for f in os.listdir(tmp_path) if f.endswith(".tmp")]
+    name = prefix.decode() + "%016x" % KEY2
+    with open(name, "r+b") as f:
+        f.seek(16 + 24)
+        f.write(b"X")
+    assert lib.pl_cache_get_file(prefix, KEY2).size == 0 and not os.path.exists(name)
+    lib.pl_cache_set_file(prefix, obj(KEY2, b""))                # size 0 = delete
+    assert not os.path.exists(name)
