@@ -138,6 +138,19 @@ void pl_shader_decode_color(pl_shader sh, struct pl_color_repr *repr,
     pl_shader_set_alpha(sh, repr, PL_ALPHA_INDEPENDENT);
 }
 
+static bool transform_is_identity(const pl_transform3x3 *t)
+{
+    for (int i = 0; i < 3; i++) {
+        if (t->c[i] != 0.0f)
+            return false;
+        for (int j = 0; j < 3; j++) {
+            if (t->mat.m[i][j] != (i == j ? 1.0f : 0.0f))
+                return false;
+        }
+    }
+    return true;
+}
+
 void pl_shader_encode_color(pl_shader sh, const struct pl_color_repr *repr)
 {
     if (!sh_require(sh, PL_SHADER_SIG_COLOR, 0, 0))
@@ -166,16 +179,12 @@ void pl_shader_encode_color(pl_shader sh, const struct pl_color_repr *repr)
         break;
     }
 
-    // skip the matrix when it is the identity by construction
-    bool skip = true;
-    skip &= PL_DEF(repr->sys, PL_COLOR_SYSTEM_RGB) == PL_COLOR_SYSTEM_RGB;
-    skip &= PL_DEF(repr->levels, PL_COLOR_LEVELS_FULL) == PL_COLOR_LEVELS_FULL;
-    skip &= !repr->bits.sample_depth || !repr->bits.color_depth ||
-             repr->bits.sample_depth == repr->bits.color_depth;
-    skip &= !repr->bits.bit_shift;
-    if (!skip) {
-        struct pl_color_repr copy = *repr;
-        pl_transform3x3 tr = pl_color_repr_decode(&copy, NULL);
+    // code values = M^-1 (colour - c): recorded unless it is the identity. (Full-range RGB at
+    // equal sample and colour depth decodes with an exactly-unit matrix; applying it would not
+    // change a bit, so nothing is recorded for it.)
+    struct pl_color_repr copy = *repr;
+    pl_transform3x3 tr = pl_color_repr_decode(&copy, NULL);
+    if (!transform_is_identity(&tr)) {
         pl_transform3x3_invert(&tr);
         op_affine(sh, &tr, "encode");
     }
@@ -927,106 +936,47 @@ void pl_shader_color_map_ex(pl_shader sh, const struct pl_color_map_params *para
         return;
 
     pl_gpu gpu = SH_GPU(sh);
-    struct pl_color_space src = args->src, dst = args->dst;
+    struct pl_color_space measured = args->src;
     struct sh_color_map_obj *obj = NULL;
     if (args->state) {
-        pl_get_detected_hdr_metadata(*args->state, &src.hdr);
+        pl_get_detected_hdr_metadata(*args->state, &measured.hdr);
         obj = SH_OBJ(sh, args->state, PL_SHADER_OBJ_COLOR_MAP, struct sh_color_map_obj,
                      sh_color_map_uninit);
         if (!obj)
             return;
     }
 
-    pl_color_space_infer_map(&src, &dst);
-    if (pl_color_space_equal(&src, &dst)) {
+    // every decision of the request, as one value (colormap_plan.c)
+    struct plh_colormap_plan plan;
+    plh_colormap_resolve(&plan, params, &measured, &args->dst, args->state != NULL);
+    params = PL_DEF(params, &pl_color_map_default_params);
+    const struct pl_color_space src = plan.src, dst = plan.dst;
+    const struct pl_tone_map_params tone = plan.tone;
+    const struct pl_gamut_map_params gamut = plan.gamut;
+    const bool can_fast = plan.closed_form, need_tone_map = plan.need_tone;
+    const bool need_gamut_map = plan.need_gamut;
+    if (plan.identity) {
         if (args->prelinearized)
             pl_shader_delinearize(sh, &dst);
         return;
     }
-
-    params = PL_DEF(params, &pl_color_map_default_params);
-
-    struct pl_tone_map_params tone = {
-        .function       = PL_DEF(params->tone_mapping_function, &pl_tone_map_clip),
-        .constants      = params->tone_constants,
-        .param          = params->tone_mapping_param,
-        .input_scaling  = PL_HDR_PQ,
-        .output_scaling = PL_HDR_PQ,
-        .lut_size       = PL_DEF(params->lut_size, pl_color_map_default_params.lut_size),
-        .hdr            = src.hdr,
-    };
-
-    pl_color_space_nominal_luma_ex(pl_nominal_luma_params(
-        .color = &src, .metadata = params->metadata, .scaling = tone.input_scaling,
-        .out_min = &tone.input_min, .out_max = &tone.input_max, .out_avg = &tone.input_avg,
-    ));
-    pl_color_space_nominal_luma_ex(pl_nominal_luma_params(
-        .color = &dst, .metadata = PL_HDR_METADATA_HDR10, .scaling = tone.output_scaling,
-        .out_min = &tone.output_min, .out_max = &tone.output_max,
-    ));
-    pl_tone_map_params_infer(&tone);
-
-    // merge near-identical end points
-    if (fabs(tone.input_max - tone.output_max) < 1e-6)
-        tone.output_max = tone.input_max;
-    if (fabs(tone.input_min - tone.output_min) < 1e-6)
-        tone.output_min = tone.input_min;
-    if (!params->inverse_tone_mapping)
-        tone.output_max = PL_MIN(tone.output_max, tone.input_max);
-
-    const int *lut3d_def = pl_color_map_default_params.lut3d_size;
-    struct pl_gamut_map_params gamut = {
-        .function     = PL_DEF(params->gamut_mapping, &pl_gamut_map_clip),
-        .constants    = params->gamut_constants,
-        .input_gamut  = src.hdr.prim,
-        .output_gamut = dst.hdr.prim,
-        .lut_size_I   = PL_DEF(params->lut3d_size[0], lut3d_def[0]),
-        .lut_size_C   = PL_DEF(params->lut3d_size[1], lut3d_def[1]),
-        .lut_size_h   = PL_DEF(params->lut3d_size[2], lut3d_def[2]),
-        .lut_stride   = 3,
-    };
-
-    pl_color_space_nominal_luma_ex(pl_nominal_luma_params(
-        .color = &dst, .metadata = PL_HDR_METADATA_HDR10, .scaling = PL_HDR_PQ,
-        .out_min = &gamut.min_luma, .out_max = &gamut.max_luma,
-    ));
-
-    // without expansion, clip the target gamut to the source gamut
-    if (!params->gamut_expansion && gamut.function->bidirectional) {
-        if (pl_primaries_compatible(&gamut.input_gamut, &gamut.output_gamut))
-            gamut.output_gamut = pl_primaries_clip(&gamut.output_gamut, &gamut.input_gamut);
-    }
-
-    bool can_fast = !params->force_tone_mapping_lut;
-    if (!args->state) {
-        // no state object: only stateless methods
-        can_fast = true;
-        if (tone.function != &pl_tone_map_clip)
-            tone.function = &pl_tone_map_linear;
-        if (gamut.function != &pl_gamut_map_clip)
-            gamut.function = &pl_gamut_map_saturation;
-    }
-
-    const bool need_tone_map = !pl_tone_map_params_noop(&tone);
-    bool need_gamut_map = !pl_gamut_map_params_noop(&gamut);
 
     if (!args->prelinearized)
         pl_shader_linearize(sh, &src);
 
     pl_matrix3x3 rgb2lms = pl_ipt_rgb2lms(pl_raw_primaries_get(src.primaries));
     pl_matrix3x3 lms2rgb = pl_ipt_lms2rgb(pl_raw_primaries_get(dst.primaries));
-
-    if (need_gamut_map && gamut.function == &pl_gamut_map_saturation && can_fast) {
+    if (plan.fold_saturation) {
+        // LMS -> source gamut -> (same coordinates read as) target gamut -> LMS, then out
         const pl_matrix3x3 lms2src = pl_ipt_lms2rgb(&gamut.input_gamut);
         const pl_matrix3x3 dst2lms = pl_ipt_rgb2lms(&gamut.output_gamut);
         sh_describef(sh, "gamut map (saturation)");
         pl_matrix3x3_mul(&lms2rgb, &dst2lms);
         pl_matrix3x3_mul(&lms2rgb, &lms2src);
-        need_gamut_map = false;
     }
 
     if (!need_tone_map && !need_gamut_map) {
-        // fast path: a single 3x3
+        // nothing non-linear left: RGB -> LMS -> RGB is a single 3x3
         if (src.primaries != dst.primaries) {
             sh_describef(sh, "colorspace conversion");
             pl_matrix3x3_mul(&lms2rgb, &rgb2lms);

@@ -1179,6 +1179,64 @@ bool plh_shader_sample_polar_fused(pl_shader sh, const pl_shader pre,
 
 /* ---- separable (orthogonal) filters: pl_shader_sample_ortho2, sampling.c:950-1104 -------- */
 
+// The axis a separable pass filters along: the one whose size changes. -1 if both do.
+enum ortho_axis { ORTHO_VERT = 0, ORTHO_HORIZ = 1 };
+static int ortho_axis_of(const struct src_info *info, float *ratio)
+{
+    const bool keeps_x = fabs(info->ratio_x - 1.0f) < 1e-6f;
+    const bool keeps_y = fabs(info->ratio_y - 1.0f) < 1e-6f;
+    if (keeps_x) {
+        *ratio = info->ratio_y;
+        return ORTHO_VERT;
+    }
+    if (keeps_y) {
+        *ratio = info->ratio_x;
+        return ORTHO_HORIZ;
+    }
+    return -1;
+}
+
+// The filter a pass runs: the caller's, with the renderer-wide anti-ringing as its default and
+// its kernel stretched by the downscaling factor (a downscale by k sums over k times the
+// support) unless widening is switched off.
+static struct pl_filter_config effective_filter(const struct pl_sample_filter_params *params, float ratio)
+{
+    struct pl_filter_config cfg = params->filter;
+    float stretch = 1.0 / ratio;
+    if (stretch < 1.0f || params->no_widening)
+        stretch = 1.0;
+    if (!cfg.antiring)
+        cfg.antiring = params->antiring;
+    cfg.blur = (cfg.blur ? cfg.blur : 1.0f) * stretch;
+    return cfg;
+}
+
+// Rows of the weight table as the kernel reads them. Filters without negative lobes use the
+// "linear trick" (sampling.c:914-942): taps are fetched in pairs through the bilinear unit, so
+// a row holds (w0 + w1, w1 / (w0 + w1)) per pair, the padding repeating the last group.
+static float *ortho_rows(pl_filter filt, bool paired)
+{
+    const int taps = filt->row_size, stride = filt->row_stride;
+    const size_t entries = (size_t) SCALER_LUT_SIZE * stride;
+    float *rows = malloc(entries * sizeof(float));
+    if (!rows)
+        return NULL;
+    memcpy(rows, filt->weights, entries * sizeof(float));
+    if (!paired)
+        return rows;
+    for (int phase = 0; phase < SCALER_LUT_SIZE; phase++) {
+        float *row = rows + (size_t) phase * stride;
+        for (int t = 0; t < taps; t += 2) {
+            const float sum = row[t] + row[t + 1];
+            row[t + 1] = row[t + 1] / sum;
+            row[t] = sum;
+        }
+        for (int t = (taps + 1) & ~1; t < stride; t++)
+            row[t] = t >= 4 ? row[t - 4] : 0.0f;
+    }
+    return rows;
+}
+
 bool pl_shader_sample_ortho2(pl_shader sh, const struct pl_sample_src *src,
                              const struct pl_sample_filter_params *params)
 {
@@ -1186,91 +1244,56 @@ bool pl_shader_sample_ortho2(pl_shader sh, const struct pl_sample_src *src,
         SH_FAIL(sh, "Trying to use separated sampling with a polar filter?");
         return false;
     }
-
     struct src_info info;
     if (!setup_src(sh, src, &info, false, REQ_LINEAR))
         return false;
-
-    int pass;
-    if (fabs(info.ratio_x - 1.0f) < 1e-6f) {
-        pass = 0; // SEP_VERT
-    } else if (fabs(info.ratio_y - 1.0f) < 1e-6f) {
-        pass = 1; // SEP_HORIZ
-    } else {
+    float ratio;
+    const int pass = ortho_axis_of(&info, &ratio);
+    if (pass < 0) {
         SH_FAIL(sh, "Trying to use pl_shader_sample_ortho with a pl_sample_src that requires "
                 "scaling in multiple directions (rx=%f, ry=%f), this is not possible!",
                 info.ratio_x, info.ratio_y);
         return false;
     }
-    const float ratio = pass ? info.ratio_x : info.ratio_y;
 
+    // state: one sampler object per axis, the horizontal one hanging off the vertical one
+    // (anamorphic content filters the two axes differently, sampling.c:985-995)
     pl_gpu gpu = SH_GPU(sh);
     struct sh_sampler_obj *obj = SH_OBJ(sh, params->lut, PL_SHADER_OBJ_SAMPLER,
                                         struct sh_sampler_obj, sh_sampler_uninit);
+    if (obj && pass == ORTHO_HORIZ)
+        obj = SH_OBJ(sh, &obj->pass2, PL_SHADER_OBJ_SAMPLER, struct sh_sampler_obj, sh_sampler_uninit);
     if (!obj)
         return false;
-    if (pass != 0) {
-        // one sampler object per dimension (anamorphic content, sampling.c:985-995)
-        obj = SH_OBJ(sh, &obj->pass2, PL_SHADER_OBJ_SAMPLER, struct sh_sampler_obj,
-                     sh_sampler_uninit);
-        if (!obj)
-            return false;
-    }
 
-    float inv_scale = 1.0 / ratio;
-    inv_scale = PL_MAX(inv_scale, 1.0);
-    if (params->no_widening)
-        inv_scale = 1.0;
-
-    struct pl_filter_config cfg = params->filter;
-    cfg.antiring = PL_DEF(cfg.antiring, params->antiring);
-    cfg.blur = PL_DEF(cfg.blur, 1.0f) * inv_scale;
+    const struct pl_filter_config cfg = effective_filter(params, ratio);
     const bool update = !obj->filter || !pl_filter_config_eq(&obj->filter->params.config, &cfg);
     if (update) {
         pl_filter_free(&obj->filter);
         obj->filter = pl_filter_generate(sh->log, pl_filter_params(
-            .config             = cfg,
-            .lut_entries        = SCALER_LUT_SIZE,
-            .max_row_size       = gpu->limits.max_tex_2d_dim / 4,
-            .row_stride_align   = 4,
+            .config = cfg, .lut_entries = SCALER_LUT_SIZE, .row_stride_align = 4,
+            .max_row_size = gpu->limits.max_tex_2d_dim / 4,
         ));
         if (!obj->filter) {
             SH_FAIL(sh, "Failed initializing separated filter!");
             return false;
         }
     }
-
     pl_filter filt = obj->filter;
     const int N = filt->row_size, stride = filt->row_stride;
+    // no negative lobe = the first zero crossing is the radius: pairs of taps per fetch, and
+    // nothing for anti-ringing to clamp
     const bool use_linear = filt->radius == filt->radius_zero;
-    bool use_ar = cfg.antiring > 0 && ratio > 1.0;
-    use_ar &= !use_linear; // filter has no negative weights
+    const bool use_ar = cfg.antiring > 0 && ratio > 1.0 && !use_linear;
 
     if (update || !obj->lut) {
-        // fill_ortho_lut (sampling.c:914-942)
-        const size_t entries = (size_t) SCALER_LUT_SIZE * stride;
-        float *rows = malloc(entries * sizeof(float));
+        float *rows = ortho_rows(filt, use_linear);
         if (!rows)
             return false;
-        if (use_linear) {
-            for (int n = 0; n < SCALER_LUT_SIZE; n++) {
-                const float *weights = filt->weights + (size_t) n * stride;
-                float *row = rows + (size_t) n * stride;
-                int i = 0;
-                for (; i < N; i += 2) {
-                    const float w0 = weights[i], w1 = weights[i + 1];
-                    row[i] = w0 + w1;
-                    row[i + 1] = w1 / (w0 + w1);
-                }
-                for (; i < stride; i++)
-                    row[i] = i >= 4 ? row[i - 4] : 0;
-            }
-        } else {
-            memcpy(rows, filt->weights, entries * sizeof(float));
-        }
         pl_buf_destroy(gpu, &obj->lut);
         obj->lut = pl_buf_create(gpu, pl_buf_params(
-            .size = entries * sizeof(float), .storable = true, .initial_data = rows));
+            .size = (size_t) SCALER_LUT_SIZE * stride * sizeof(float), .storable = true,
+            .initial_data = rows));
         free(rows);
         if (!obj->lut) {
             SH_FAIL(sh, "Failed initializing separated LUT!");

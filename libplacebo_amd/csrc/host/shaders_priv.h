@@ -7,6 +7,7 @@
 #define PLH_SHADERS_PRIV_H_
 
 #include <libplacebo/shaders.h>
+#include <libplacebo/shaders/colorspace.h>
 #include <libplacebo/colorspace.h>
 
 #include "gpu_priv.h"
@@ -94,6 +95,21 @@ bool plh_shader_sample_polar_fused(pl_shader sh, const pl_shader pre,
                                    const struct pl_sample_filter_params *params);
 
 // called by the dispatch once the target geometry of a POLAR pass is known
+// What a colour-mapping request resolves to (colormap_plan.c): a pure function of the request.
+struct plh_colormap_plan {
+    struct pl_color_space src, dst;     // after pl_color_space_infer_map
+    bool identity;                      // equal spaces: nothing to map (the rest is unset)
+    struct pl_tone_map_params tone;     // end points snapped, function degraded if stateless
+    struct pl_gamut_map_params gamut;   // target gamut clipped to the source unless expanding
+    bool closed_form;                   // closed-form steps allowed (no state, or LUT not forced)
+    bool need_tone, need_gamut;         // steps that remain (need_gamut false when folded)
+    bool tone_direct;                   // clip / linear evaluated without a LUT
+    bool fold_saturation;               // `saturation` gamut step folded into the output matrix
+};
+void plh_colormap_resolve(struct plh_colormap_plan *plan, const struct pl_color_map_params *params,
+                                 const struct pl_color_space *src, const struct pl_color_space *dst,
+                                 bool stateful);
+
 void plh_polar_pp_setup(pl_gpu gpu, pl_log log, void *polar_obj, struct plh_pass *pass);
 
 void plh_peak_pass_launched(pl_gpu gpu, pl_shader_obj state, int on, uint64_t seq);
