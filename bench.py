@@ -295,7 +295,9 @@ def kernel_symbol(workload, name):
     if "peak detection" in name and "scaling" not in name and "map" not in name:
         return "k_pass_peak"
     if "polar" in name:
-        return "k_polar_pp"
+        # k_polar_mx (the contraction on the matrix pipe: exact 2x upscales) or k_polar_pp (phase
+        # classes, sequential fma); which one ran is read off the kernel trace (trace["name"])
+        return "k_polar_"
     if "ortho" in name:
         return "k_ortho_fast"
     if "debanding" in name:
@@ -387,7 +389,8 @@ def measure_traffic(workload, symbol, timeout=240):
             vals = []
             for fn in glob.glob(os.path.join(td, "**", "*counter_collection.csv"), recursive=True):
                 for row in csv.DictReader(open(fn)):
-                    if symbol in row["Kernel_Name"] and row["Counter_Name"] == counter:
+                    if symbol in row["Kernel_Name"] and row["Counter_Name"] == counter and \
+                            "classify" not in row["Kernel_Name"] and "weights" not in row["Kernel_Name"]:
                         vals.append(float(row["Counter_Value"]))
             if not vals:
                 print(f"bench: traffic probe ({counter}): no launches of {symbol}* in "
@@ -434,7 +437,7 @@ def measure_trace(workload, symbol, timeout=240):
         best = None
         for fn in glob.glob(os.path.join(td, "**", "*kernel_stats.csv"), recursive=True):
             for row in csv.DictReader(open(fn)):
-                if symbol in row["Name"]:
+                if symbol in row["Name"] and "classify" not in row["Name"] and "weights" not in row["Name"]:
                     cand = (float(row["TotalDurationNs"]), float(row["AverageNs"]), int(row["Calls"]),
                             row["Name"])
                     best = max(best, cand) if best else cand
@@ -562,6 +565,7 @@ def config_block(device, workload, steps=60, warmup=8, trace=False):
     if trace:
         tr = measure_trace(workload, block["kernel"].split(" ")[0])
         if tr:
+            block["kernel"] = block["kernel"].replace("k_polar_ ", tr["name"].split("(")[0].replace("void ", "") + " ", 1)
             block["trace"] = dict(tr, achieved=round(block["algorithmic_bytes"] / tr["kernel_us"] / 1e3, 1))
             block["trace"]["frac"] = round(block["trace"]["achieved"] / block["peak"], 4)
     return block
@@ -812,6 +816,7 @@ def main():
             tr = measure_trace(args.workload, roofline["kernel"].split(" ")[0])
             if tr:
                 # the same kernel in a rocprofv3 kernel trace (what profiles/ holds)
+                roofline["kernel"] = roofline["kernel"].replace("k_polar_ ", tr["name"].split("(")[0].replace("void ", "") + " ", 1)
                 roofline["trace"] = dict(tr, achieved=round(roofline["algorithmic_bytes"] /
                                                             tr["kernel_us"] / 1e3, 1))
                 roofline["trace"]["frac"] = round(roofline["trace"]["achieved"] / roofline["peak"], 4)

@@ -1,0 +1,8 @@
+cd $GRAFT_REPO_ROOT; export TMPDIR=/tmp
+run() { python bench.py --workload $1 --steps 200 --warmup 20 --no-cpu-baseline --no-companions --no-traffic --no-concurrent 2>/dev/null | python -c "
+import json,sys
+d=json.loads(sys.stdin.read()); print('$2', d['ms_per_step'], d['roofline']['kernel_us'], list(d['roofline']['passes_us'].values()))"; }
+run ewa_1080p_to_4k_hdr_tonemap metric
+run hdr10_4k_tonemap cfg4
+run ewa_8k_to_4k_deband_tonemap cfg5
+timeout 1500 python -m pytest tests/test_gpu_color.py tests/test_gpu_fullsize.py tests/test_gpu_metric.py tests/test_gpu_contrast_recovery.py tests/test_gpu_multigpu.py -q -m gpu 2>&1 | tail -8
