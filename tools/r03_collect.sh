@@ -1,0 +1,28 @@
+#!/bin/bash
+# round-3 collection (same as tools/r02_final.sh): the default bench line, the same command under rocprofv3 --kernel-trace --stats
+# (without the concurrent-stream / async companions, whose launches overlap), per-workload kernel stats,
+# and the GPU test log. Outputs under gpurun_out/<tag>_*. Usage: tools/r02_final.sh <tag> [bench] [trace] [stats] [tests]
+cd $GRAFT_REPO_ROOT
+export TMPDIR=/tmp
+mkdir -p gpurun_out
+tag=$1; shift
+what=${@:-"bench trace stats tests"}
+for w in $what; do case $w in
+bench)
+  timeout 900 python bench.py > gpurun_out/${tag}_bench.json 2> gpurun_out/${tag}_bench.err
+  tail -c 300 gpurun_out/${tag}_bench.err ;;
+trace)
+  out=/tmp/prof_default; rm -rf $out
+  (cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $out -- python $GRAFT_REPO_ROOT/bench.py --no-traffic --no-cpu-baseline --no-concurrent > $GRAFT_REPO_ROOT/gpurun_out/${tag}_default_bench_under_rocprof.json 2> /tmp/prof_default.err)
+  find $out -name "*kernel_stats.csv" -exec cp {} gpurun_out/${tag}_default_bench_kernel_stats.csv \;
+  head -4 gpurun_out/${tag}_default_bench_kernel_stats.csv | cut -c1-140 ;;
+stats)
+  for wl in ewa_1080p_to_4k_hdr_tonemap ewa_lanczos_1080p_to_4k_dither10 bilinear_1080p_to_4k hdr10_4k_tonemap ewa_8k_to_4k_deband_tonemap lanczos_1080p_to_4k_dither10; do
+    out=/tmp/st_$wl; rm -rf $out
+    (cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out -- python $GRAFT_REPO_ROOT/bench.py --bare --steps 40 --warmup 10 --workload $wl > /tmp/st_$wl.log 2>&1)
+    find $out -name "*kernel_stats.csv" -exec cp {} gpurun_out/${tag}_${wl}_kernel_stats.csv \;
+  done ;;
+tests)
+  timeout 1500 python -m pytest tests -q -m gpu 2>&1 | grep -v "^RCCL\|^HIP version\|^ROCm version\|^Hostname\|^Librccl" | tail -6 > gpurun_out/${tag}_gputests.log
+  cat gpurun_out/${tag}_gputests.log ;;
+esac; done
