@@ -282,6 +282,113 @@ void k_pass_peak(const plh_pass p_)
     plh_store_n<PEAK_NPX>(p.dst, sx, sy, ok, c, p.nt_store);
 }
 
+/*
+ * k_peak_fast: the renderer's measuring pass as its own kernel -- a plane read texel for texel
+ * (identity rect, rgba16 or rgba16hf), the optional identity PLANE_MAP, the measurement, and the
+ * rgba16hf intermediate (or no target: the measurement of an existing FBO). Same measurement
+ * code (peak_measure: integer sums / maxima / histogram per 16x16 tile, order-free) and the same
+ * f16 codes as k_pass_peak, without the sampler switch, the attribute interpolation, the op
+ * interpreter and the generic store: a lane owns two horizontally adjacent pixels on two rows
+ * (one 16-byte load and store per row) instead of four single pixels.
+ */
+template <bool F16SRC, bool STORE>
+__global__ __launch_bounds__(64 * PEAK_WAVES)
+void k_peak_fast(const plh_pass p_)
+{
+    const plh_pass &p = plh_kernarg_pass();
+    const plh_sampler_args &s = p.s;
+    __shared__ uint32_t hists[PEAK_WAVES][PEAK_HIST_BINS];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int tiles_x = (p.width + PEAK_BW - 1) / PEAK_BW;
+    const int tiles_y = (p.height + PEAK_BH - 1) / PEAK_BH;
+    const uint32_t wg_idx = blockIdx.x * PEAK_WAVES + wave;
+    if (wg_idx >= (uint32_t) (tiles_x * tiles_y))
+        return;     // whole wave
+    const int tx = wg_idx % tiles_x, ty = wg_idx / tiles_x;
+    const int w = p.width, h = p.height;
+    const bool has_map = p.num_ops == 2;    // [identity PLANE_MAP] PEAK_DETECT
+    const plh_op &o_map = p.ops[0], &o_pk = p.ops[p.num_ops - 1];
+
+    // pixels (x0, y), (x0 + 1, y) for y = y0, y0 + 8: lanes beyond the image measure the clamped
+    // edge texel, as the padding invocations of the reference's workgroups do
+    const int x0 = tx * PEAK_BW + 2 * (lane & 7), y0 = ty * PEAK_BH + (lane >> 3);
+    const char *sp = (const char *) s.src.ptr;
+    float4_t c[PEAK_NPX];
+#pragma unroll
+    for (int k = 0; k < 2; k++) {
+        const int y = min(y0 + 8 * k, h - 1);
+        const char *row = sp + (size_t) y * s.src.pitch;
+        uint4 v;
+        if (x0 + 1 < w) {
+            v = *(const uint4 *) (row + (size_t) x0 * 8);
+        } else {
+            const uint2 e = *(const uint2 *) (row + (size_t) min(x0, w - 1) * 8);
+            v = make_uint4(e.x, e.y, e.x, e.y);
+        }
+        const uint32_t q[4] = { v.x, v.y, v.z, v.w };
+#pragma unroll
+        for (int i = 0; i < 2; i++) {
+            const uint32_t lo = q[2 * i], hi = q[2 * i + 1];
+            float4_t t;
+            if (F16SRC)
+                t = { plh_h2f(lo & 0xffff), plh_h2f(lo >> 16), plh_h2f(hi & 0xffff), plh_h2f(hi >> 16) };
+            else
+                t = { plh_un16(lo & 0xffff), plh_un16(lo >> 16), plh_un16(hi & 0xffff), plh_un16(hi >> 16) };
+            // identity PLANE_MAP of the first i1 components: the others take their neutral values
+            if (has_map) {
+                if (o_map.i1 < 4) t.w = o_map.f[3];
+                if (o_map.i1 < 3) t.z = o_map.f[2];
+                if (o_map.i1 < 2) t.y = o_map.f[1];
+            }
+            c[2 * k + i] = t;
+        }
+    }
+    peak_measure(c, o_pk, hists[wave], wg_idx, p.peak_scratch);
+
+    if constexpr (STORE) {
+#pragma unroll
+        for (int k = 0; k < 2; k++) {
+            const int y = y0 + 8 * k;
+            if (y >= h || x0 >= w)
+                continue;
+            uint32_t o[4];
+#pragma unroll
+            for (int i = 0; i < 2; i++) {
+                const float4_t &t = c[2 * k + i];
+                o[2 * i] = (uint32_t) plh_f2h(t.x) | ((uint32_t) plh_f2h(t.y) << 16);
+                o[2 * i + 1] = (uint32_t) plh_f2h(t.z) | ((uint32_t) plh_f2h(t.w) << 16);
+            }
+            char *d = (char *) p.dst.ptr + (size_t) y * p.dst.pitch + (size_t) x0 * 8;
+            if (x0 + 1 < w)
+                *(uint4 *) d = make_uint4(o[0], o[1], o[2], o[3]);
+            else
+                *(uint2 *) d = make_uint2(o[0], o[1]);
+        }
+    }
+}
+
+// the shape k_peak_fast is written for
+static bool peak_fast_applies(const plh_pass *pass)
+{
+    const plh_sampler_args &s = pass->s;
+    const char *env = getenv("PL_HIP_PEAK_FAST");
+    if (env && env[0] == '0')
+        return false;
+    const bool native = pass->width == s.src.w && pass->height == s.src.h &&
+        s.pos[0][0] == 0.0f && s.pos[0][1] == 0.0f && s.pos[3][0] == 1.0f && s.pos[3][1] == 1.0f &&
+        s.pos[1][0] == 1.0f && s.pos[1][1] == 0.0f && s.pos[2][0] == 0.0f && s.pos[2][1] == 1.0f;
+    const bool target = pass->dst.ptr != NULL;
+    return native && s.type == PLH_SAMPLE_NEAREST && s.scale == 1.0f &&
+           (s.src.fmt == PLH_FMT_RGBA16 || s.src.fmt == PLH_FMT_RGBA16F) &&
+           s.address_mode == PLH_ADDRESS_CLAMP && !pass->transpose && !pass->num_pre_ops &&
+           (!target || (pass->dst.fmt == PLH_FMT_RGBA16F && pass->base_x == 0 && pass->base_y == 0 &&
+                        pass->dir_x == 1 && pass->dir_y == 1 && pass->dst.w >= pass->width &&
+                        pass->dst.h >= pass->height)) &&
+           ((pass->num_ops == 1 && pass->ops[0].kind == PLH_OP_PEAK_DETECT) ||
+            (pass->num_ops == 2 && pass->ops[0].kind == PLH_OP_PLANE_MAP && pass->ops[0].i2 &&
+             pass->ops[0].i1 >= 1 && pass->ops[1].kind == PLH_OP_PEAK_DETECT));
+}
+
 // Sum (maximum for frame_max_pq) of the PLH_PEAK_COPIES partial buffers. 13 blocks of 64 words x
 // 4 copy groups: every lane has 16 independent loads in flight, one memory round trip for the
 // whole fold (a single block takes 12 us: one CU cannot pull 200 KiB any faster). The block
@@ -355,7 +462,13 @@ int plh_launch_peak(hipStream_t stream, const plh_pass *pass)
             break;
         }
     }
-    if (plh_ops_lite(pass, 0, pk_op) && plh_ops_lite(pass, PL_MIN_INT(pk_op + 1, pass->num_ops), pass->num_ops))
+    if (peak_fast_applies(pass)) {
+        const bool f16 = pass->s.src.fmt == PLH_FMT_RGBA16F, store = pass->dst.ptr != NULL;
+        if (f16 && store)       hipLaunchKernelGGL((k_peak_fast<true, true>), grid, block, 0, stream, *pass);
+        else if (f16)           hipLaunchKernelGGL((k_peak_fast<true, false>), grid, block, 0, stream, *pass);
+        else if (store)         hipLaunchKernelGGL((k_peak_fast<false, true>), grid, block, 0, stream, *pass);
+        else                    hipLaunchKernelGGL((k_peak_fast<false, false>), grid, block, 0, stream, *pass);
+    } else if (plh_ops_lite(pass, 0, pk_op) && plh_ops_lite(pass, PL_MIN_INT(pk_op + 1, pass->num_ops), pass->num_ops))
         hipLaunchKernelGGL(k_pass_peak<true>, grid, block, 0, stream, *pass);
     else
         hipLaunchKernelGGL(k_pass_peak<false>, grid, block, 0, stream, *pass);
