@@ -497,6 +497,117 @@ void k_nearest_fast(const plh_pass p_)
     }
 }
 
+/* ------------------------------------------------------------------------ */
+/*
+ * k_pass_native: a pass that reads its source texel for texel (identity rect, nearest) -- the
+ * colour-map pass behind an intermediate, a plane decode -- with the op interpreter of
+ * k_pass_generic but none of its geometry: no attribute interpolation, no texel-coordinate
+ * arithmetic, no format switches; a lane owns two horizontally adjacent pixels (one 16-byte
+ * load, one 16-byte store). Same ops, same values: the source coordinate of output pixel
+ * (x, y) IS (x, y) there (k_pass_generic computes floor(((x + 0.5) / w) * w) = x).
+ */
+template <bool LITE, bool F16SRC, bool F16DST>
+__global__ __launch_bounds__(PASS_BW * PASS_BH)
+void k_pass_native(const plh_pass p_)
+{
+    const plh_pass &p = plh_kernarg_pass();
+    const plh_sampler_args &s = p.s;
+    const int cx = blockIdx.x * PASS_BW + threadIdx.x;
+    const int w = p.width, h = p.height;
+    const int x0 = 2 * cx;
+#pragma unroll 1
+    for (int it = 0; it < PASS_ITERS; it++) {
+        const int y = (blockIdx.y * PASS_ITERS + it) * PASS_BH + threadIdx.y;
+        if (x0 >= w || y >= h)
+            continue;
+        const bool two = x0 + 1 < w;
+        const char *row = (const char *) s.src.ptr + (size_t) y * s.src.pitch + (size_t) x0 * 8;
+        uint4 v;
+        if (two) {
+            v = *(const uint4 *) row;
+        } else {
+            const uint2 e = *(const uint2 *) row;
+            v = make_uint4(e.x, e.y, e.x, e.y);
+        }
+        float4_t c[2];
+        frag_t fcs[2];
+        const uint32_t q[4] = { v.x, v.y, v.z, v.w };
+#pragma unroll
+        for (int i = 0; i < 2; i++) {
+            const uint32_t lo = q[2 * i], hi = q[2 * i + 1];
+            if (F16SRC)
+                c[i] = { plh_h2f(lo & 0xffff), plh_h2f(lo >> 16), plh_h2f(hi & 0xffff), plh_h2f(hi >> 16) };
+            else
+                c[i] = { plh_un16(lo & 0xffff), plh_un16(lo >> 16), plh_un16(hi & 0xffff), plh_un16(hi >> 16) };
+            if (s.scale != 1.0f)
+                c[i] = scale4(c[i], s.scale);
+            const int idx = x0 + i;
+            fcs[i] = { (float) (idx + p.frag_x0) + 0.5f, (float) (y + p.frag_y0) + 0.5f, 0.0f, 0,
+                       p.out_scale[0] * ((float) idx + 0.5f), p.out_scale[1] * ((float) y + 0.5f) };
+        }
+        apply_ops_n<2, false, LITE>(c, p.ops, 0, p.num_ops, fcs);
+        uint32_t o[4];
+#pragma unroll
+        for (int i = 0; i < 2; i++) {
+            if (F16DST) {
+                o[2 * i] = (uint32_t) plh_f2h(c[i].x) | ((uint32_t) plh_f2h(c[i].y) << 16);
+                o[2 * i + 1] = (uint32_t) plh_f2h(c[i].z) | ((uint32_t) plh_f2h(c[i].w) << 16);
+            } else {
+                o[2 * i] = plh_unorm16x2(c[i].x, c[i].y);
+                o[2 * i + 1] = plh_unorm16x2(c[i].z, c[i].w);
+            }
+        }
+        char *d = (char *) p.dst.ptr + (size_t) y * p.dst.pitch + (size_t) x0 * 8;
+        if (two) {
+            const plh_u32x4 pk = { o[0], o[1], o[2], o[3] };
+            if (p.nt_store)
+                __builtin_nontemporal_store(pk, (plh_u32x4 *) d);
+            else
+                *(plh_u32x4 *) d = pk;
+        } else {
+            *(uint2 *) d = make_uint2(o[0], o[1]);
+        }
+    }
+}
+
+// the shape k_pass_native is written for
+static bool pass_native_applies(const plh_pass *pass)
+{
+    const plh_sampler_args &s = pass->s;
+    const char *env = getenv("PL_HIP_PASS_NATIVE");
+    if (env && env[0] == '0')
+        return false;
+    const bool native = pass->width == s.src.w && pass->height == s.src.h &&
+        s.pos[0][0] == 0.0f && s.pos[0][1] == 0.0f && s.pos[3][0] == 1.0f && s.pos[3][1] == 1.0f &&
+        s.pos[1][0] == 1.0f && s.pos[1][1] == 0.0f && s.pos[2][0] == 0.0f && s.pos[2][1] == 1.0f;
+    if (!native || s.type != PLH_SAMPLE_NEAREST || s.address_mode != PLH_ADDRESS_CLAMP ||
+        pass->transpose || pass->num_pre_ops || pass->base_x || pass->base_y || pass->dir_x != 1 ||
+        pass->dir_y != 1 || pass->dst.w < pass->width || pass->dst.h < pass->height ||
+        (s.src.fmt != PLH_FMT_RGBA16 && s.src.fmt != PLH_FMT_RGBA16F) ||
+        (pass->dst.fmt != PLH_FMT_RGBA16 && pass->dst.fmt != PLH_FMT_RGBA16F))
+        return false;
+    for (int i = 0; i < pass->num_ops; i++) {
+        const int k = pass->ops[i].kind;
+        if (k == PLH_OP_MIX_ADD || k == PLH_OP_MIX_END || k == PLH_OP_PEAK_DETECT ||
+            (k == PLH_OP_GAMUT_LUT && pass->ops[i].f[3] != 0.0f))
+            return false;   // (frame mixing, the measurement and the tricubic lookup have their own kernels)
+    }
+    return true;
+}
+
+template <bool LITE>
+static void launch_pass_native(hipStream_t stream, const plh_pass *pass)
+{
+    const dim3 block(PASS_BW, PASS_BH);
+    const int cells_w = (pass->width + 1) / 2, bh = PASS_BH * PASS_ITERS;
+    const dim3 grid((cells_w + PASS_BW - 1) / PASS_BW, (pass->height + bh - 1) / bh);
+    const bool fs = pass->s.src.fmt == PLH_FMT_RGBA16F, fd = pass->dst.fmt == PLH_FMT_RGBA16F;
+    if (fs && fd)       hipLaunchKernelGGL((k_pass_native<LITE, true, true>), grid, block, 0, stream, *pass);
+    else if (fs)        hipLaunchKernelGGL((k_pass_native<LITE, true, false>), grid, block, 0, stream, *pass);
+    else if (fd)        hipLaunchKernelGGL((k_pass_native<LITE, false, true>), grid, block, 0, stream, *pass);
+    else                hipLaunchKernelGGL((k_pass_native<LITE, false, false>), grid, block, 0, stream, *pass);
+}
+
 static bool nearest_fast_ok(plh_pass *pass)
 {
     const char *e = getenv("PL_HIP_BILIN_ITERS");   // (0 = the generic kernel, as for bilinear)
@@ -630,6 +741,15 @@ extern "C" int plh_launch_pass(plh_stream stream_, const struct plh_pass *pass)
             const hipError_t err = hipGetLastError();
             return err == hipSuccess ? 0 : -(int) err;
         }
+    }
+
+    if (pass_native_applies(pass)) {
+        if (plh_ops_lite(pass, 0, pass->num_ops))
+            launch_pass_native<true>(stream, pass);
+        else
+            launch_pass_native<false>(stream, pass);
+        const hipError_t err = hipGetLastError();
+        return err == hipSuccess ? 0 : -(int) err;
     }
 
     const dim3 block(PASS_BW, PASS_BH);

@@ -394,3 +394,42 @@ def test_peak_fast_equals_generic(gpu, size, src_fmt, trc, store):
     assert np.array_equal(buf_f, buf_g)
     if store:
         assert np.array_equal(fbo_f, fbo_g) and fbo_g.any()
+
+
+@pytest.mark.parametrize("size", [(97, 61), (256, 130)])
+def test_pass_native_equals_generic(gpu, size):
+    """k_pass_native (a pass that reads its source texel for texel: the colour-map pass behind an
+    intermediate, the plane decode in front of a separable scaler) against k_pass_generic: the
+    same frames, bit for bit -- HDR10 -> SDR tone + gamut map with dither (full interpreter) and
+    the default preset's decode / linearize / sigmoid pass (odd widths: the last column is a
+    single pixel)."""
+    from test_gpu_fullsize import hdr_frame16
+    w, h = size
+    hdr = hdr_frame16(w, h)
+    sdr = util.chirp_rgba16(w, h)
+    cases = [
+        (hdr, w, h, pl.render_params("default", peak_detect_params=pl.peak_detect_params(percentile=99.995)),
+         dict(color=pl.color_space("bt2020", "pq", max_luma=1000.0)), dict(color=pl.color_space("bt709", "bt1886"))),
+        (sdr, 2 * w, 2 * h, pl.render_params("default"), {}, {}),
+    ]
+    for img, dw, dh, params, ikw, tkw in cases:
+        outs = []
+        for native in ("1", "0"):
+            old = os.environ.get("PL_HIP_PASS_NATIVE")
+            os.environ["PL_HIP_PASS_NATIVE"] = native
+            try:
+                src = gpu.tex_create(w, h, "rgba16", img)
+                dst = gpu.tex_create(dw, dh, "rgba16")
+                rr = pl.Renderer(gpu)
+                util.srand(1)
+                assert rr.render(pl.frame(src, components=3, **ikw),
+                                 pl.frame(dst, repr_=pl.color_repr("rgb", "full", **TEN_BIT), **tkw), params)
+                assert rr.errors() == 0
+                outs.append(dst.download())
+                rr.destroy(); src.destroy(); dst.destroy()
+            finally:
+                if old is None:
+                    os.environ.pop("PL_HIP_PASS_NATIVE", None)
+                else:
+                    os.environ["PL_HIP_PASS_NATIVE"] = old
+        assert np.array_equal(outs[0], outs[1]) and outs[0][..., :3].std() > 1000

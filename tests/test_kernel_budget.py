@@ -58,6 +58,8 @@ BUDGET = [
     (r"k_bilinear_fast<(true|false), 4, (true|false)>", 4),
     (r"k_nearest_fast<(true|false)>", 8),
     (r"k_pass_generic<.*>", 4),
+    (r"k_pass_native<true, .*>", 8),
+    (r"k_pass_native<false, .*>", 4),
     (r"k_peak_fast<(true|false), (true|false)>", 8),
     (r"k_pass_peak<true>", 4),
     (r"k_pass_peak<false>", 3),
