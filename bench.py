@@ -108,10 +108,12 @@ class Stream:
 
     # pl_hip_params.async_measure (include/libplacebo/hip.h): the measuring pass of frame N+1 on a
     # second HIP stream beside the scaler of frame N. Same frames bit for bit
-    # (tests/test_gpu_async_measure.py). Off in the headline run -- one stream, every kernel with
-    # the GPU to itself, which is what the roofline block and profiles/ describe; the JSON line
-    # carries the same workload with the option on as a companion ("async_measure").
-    async_measure = False
+    # (tests/test_gpu_async_measure.py, tests/test_gpu_metric.py). It is the library's default
+    # (PL_HIP_DEFAULTS, as async_compute is pl_vulkan_params' default) and therefore what `value`
+    # times; the JSON line carries the same workload with the option off as a companion
+    # ("single_stream"). Per-kernel times (roofline, passes_us) are taken with the frames kept
+    # apart, so that a kernel's duration is its own.
+    async_measure = True
 
     def __init__(self, device, workload, pool, async_measure=None):
         on = Stream.async_measure if async_measure is None else async_measure
@@ -304,7 +306,17 @@ def kernel_symbol(workload, name):
         return "k_deband"
     if workload == "bilinear_1080p_to_4k":
         return "k_bilinear_fast"
-    return "k_pass_generic"
+    # k_pass_native (source read texel for texel) or k_pass_generic: read off the trace
+    return "k_pass_"
+
+
+def relabel(label, traced):
+    """`<symbol prefix> (<pass description>)` -> the kernel's name as the trace has it"""
+    name = traced.split("(")[0].replace("void ", "")
+    for prefix in ("k_polar_ ", "k_pass_ "):
+        if label.startswith(prefix):
+            return name + " " + label[len(prefix):]
+    return label
 
 
 def measure_passes(st, frames=48):
@@ -561,11 +573,12 @@ def config_block(device, workload, steps=60, warmup=8, trace=False):
                  render_errors=st.rr.errors())
     st.close()
     if workload in ASYNC_WORKLOADS:
-        block["async_measure"] = async_measure_block(device, workload, steps, warmup)
+        key = "single_stream" if Stream.async_measure else "async_measure"
+        block[key] = async_measure_block(device, workload, steps, warmup, on=not Stream.async_measure)
     if trace:
         tr = measure_trace(workload, block["kernel"].split(" ")[0])
         if tr:
-            block["kernel"] = block["kernel"].replace("k_polar_ ", tr["name"].split("(")[0].replace("void ", "") + " ", 1)
+            block["kernel"] = relabel(block["kernel"], tr["name"])
             block["trace"] = dict(tr, achieved=round(block["algorithmic_bytes"] / tr["kernel_us"] / 1e3, 1))
             block["trace"]["frac"] = round(block["trace"]["achieved"] / block["peak"], 4)
     return block
@@ -618,14 +631,15 @@ def concurrent_block(device, workload, nstreams, steps=120, warmup=12):
 ASYNC_WORKLOADS = ("ewa_1080p_to_4k_hdr_tonemap", "hdr10_4k_tonemap")
 
 
-def async_measure_block(device, workload, steps, warmup):
-    """The same single stream with pl_hip_params.async_measure: frame rate only (the kernels are
-    the same; what changes is that two of them share the GPU for part of every frame)."""
+def async_measure_block(device, workload, steps, warmup, on):
+    """The same single stream with pl_hip_params.async_measure switched the other way: frame rate
+    only (the kernels are the same; what changes is whether two of them share the GPU for part
+    of every frame)."""
     (sw, sh), (dw, dh), _, _ = WORKLOADS[workload]
     per_frame = (sw * sh + dw * dh) * 8
-    st = Stream(device, workload, max(4, -(-800_000_000 // per_frame)), async_measure=True)
+    st = Stream(device, workload, max(4, -(-800_000_000 // per_frame)), async_measure=on)
     dt = run_timed(st, steps, warmup)
-    block = {"pl_hip_params": {"async_measure": True}, "steps": steps,
+    block = {"pl_hip_params": {"async_measure": bool(on)}, "steps": steps,
              "mpixels_per_s": round(steps * dw * dh / dt / 1e6, 1),
              "ms_per_step": round(dt / steps * 1e3, 4), "render_errors": st.rr.errors()}
     st.close()
@@ -708,9 +722,9 @@ def main():
     ap.add_argument("--scene-peak-allreduce", action="store_true",
                     help="ranks render frames of one scene: all-reduce the peak-detection buffer "
                          "over RCCL every frame (BASELINE configs[4])")
-    ap.add_argument("--async-measure", type=int, default=0, choices=[0, 1],
-                    help="pl_hip_params.async_measure for every stream (default 0; the default run "
-                         "reports the option's effect in its \"async_measure\" block)")
+    ap.add_argument("--async-measure", type=int, default=1, choices=[0, 1],
+                    help="pl_hip_params.async_measure for every stream (default 1 = the library's "
+                         "default; the default run reports the other setting as a companion block)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-companions", action="store_true",
                     help="skip the per-config 'rooflines' blocks")
@@ -816,15 +830,17 @@ def main():
             tr = measure_trace(args.workload, roofline["kernel"].split(" ")[0])
             if tr:
                 # the same kernel in a rocprofv3 kernel trace (what profiles/ holds)
-                roofline["kernel"] = roofline["kernel"].replace("k_polar_ ", tr["name"].split("(")[0].replace("void ", "") + " ", 1)
+                roofline["kernel"] = relabel(roofline["kernel"], tr["name"])
                 roofline["trace"] = dict(tr, achieved=round(roofline["algorithmic_bytes"] /
                                                             tr["kernel_us"] / 1e3, 1))
                 roofline["trace"]["frac"] = round(roofline["trace"]["achieved"] / roofline["peak"], 4)
         if not args.no_companions:
             out["rooflines"] = {w: config_block(local_rank, w, trace=not args.no_traffic)
                                 for w in BASELINE_CONFIGS if w != args.workload}
-        if not args.no_concurrent and not args.async_measure and args.workload in ASYNC_WORKLOADS:
-            out["async_measure"] = async_measure_block(local_rank, args.workload, args.steps, args.warmup)
+        if not args.no_concurrent and args.workload in ASYNC_WORKLOADS:
+            key = "single_stream" if args.async_measure else "async_measure"
+            out[key] = async_measure_block(local_rank, args.workload, args.steps, args.warmup,
+                                           on=not args.async_measure)
         if not args.no_concurrent:
             # companion only: `value` stays the single-stream figure
             out["concurrent_streams_one_gpu"] = [concurrent_block(local_rank, args.workload, n)

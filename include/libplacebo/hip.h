@@ -33,14 +33,19 @@ struct pl_hip_params {
     // Run the HDR measurement pass of a frame (pl_shader_detect_peak: source plane -> FBO +
     // brightness statistics) on a second HIP stream, so that it overlaps the previous frame's
     // scaling / colour-mapping pass, which is still running when the next pl_render_image call
-    // arrives. The counterpart of pl_vulkan_params.async_compute (vulkan.h). Results are
-    // identical; the renderer keeps two FBOs for that pass. Ignored (one stream) when `stream`
-    // is given or a peak exchange is installed. Off by default; the environment variable
-    // PL_HIP_ASYNC_MEASURE=0|1 overrides it.
+    // arrives. The counterpart of pl_vulkan_params.async_compute (vulkan.h:270-272) and, like it,
+    // ON by default (PL_HIP_DEFAULTS). Results are identical; the renderer keeps its own
+    // intermediates for that pass. Ignored (one stream) when `stream` is given or a peak
+    // exchange is installed. The environment variable PL_HIP_ASYNC_MEASURE=0|1 overrides it.
     bool async_measure;
 };
 
-#define pl_hip_params(...) (&(struct pl_hip_params) { __VA_ARGS__ })
+// Default values of `pl_hip_params` (the pattern of PL_VULKAN_DEFAULTS, vulkan.h:285-292): a
+// later designated initialiser in pl_hip_params(...) overrides them.
+#define PL_HIP_DEFAULTS     \
+    .async_measure = true,
+
+#define pl_hip_params(...) (&(struct pl_hip_params) { PL_HIP_DEFAULTS __VA_ARGS__ })
 PL_API extern const struct pl_hip_params pl_hip_default_params;
 
 // Number of HIP devices visible to this process (0 if no GPU / no runtime).

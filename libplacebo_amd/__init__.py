@@ -292,7 +292,8 @@ class Shader:
 class HipGpu:
     """pl_hip backend + a pl_dispatch, as a context manager."""
 
-    def __init__(self, device=0, stream=None, log_level=3, max_shmem_size=0, async_measure=False):
+    def __init__(self, device=0, stream=None, log_level=3, max_shmem_size=0, async_measure=None):
+        """async_measure: None = the library's default (pl_hip_default_params: on)"""
         L = lib()
         self._msgs = []
 
@@ -302,8 +303,10 @@ class HipGpu:
         self._cb = capi.LOG_CB(_cb)
         lp = capi.LogParams(log_cb=self._cb, log_priv=None, log_level=log_level)
         self.log = C.c_void_p(L.pl_log_create_365(365, C.byref(lp)))
+        if async_measure is None:
+            async_measure = capi.HipParams.in_dll(L, "pl_hip_default_params").async_measure
         hp = capi.HipParams(device=device, stream=stream, max_shmem_size=max_shmem_size,
-                            async_measure=async_measure)
+                            async_measure=bool(async_measure))
         self.hip = L.pl_hip_create(self.log, C.byref(hp))
         if not self.hip:
             raise RuntimeError("pl_hip_create failed: " + "; ".join(m for _, m in self._msgs))

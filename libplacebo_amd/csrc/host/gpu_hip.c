@@ -15,7 +15,7 @@
 #include "shaders_priv.h"
 #include "cache_priv.h"
 
-const struct pl_hip_params pl_hip_default_params = {0};
+const struct pl_hip_params pl_hip_default_params = { PL_HIP_DEFAULTS };
 static const struct plh_gpu_fns hip_fns;
 
 /* ------------------------------------------------------------------------ */
