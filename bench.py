@@ -753,16 +753,52 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     dist = None
+    # PL_BENCH_DEVICES="0,0": the device of each local rank (testing aid: two ranks on the one GPU
+    # of a development box; RCCL refuses two ranks per device, hence PL_BENCH_DIST_BACKEND=gloo)
+    def init_gloo():
+        # (gloo announces its connections on stdout, which belongs to the one JSON line)
+        sys.stdout.flush()
+        keep = os.dup(1)
+        os.dup2(2, 1)
+        try:
+            dist.init_process_group("gloo")
+        finally:
+            os.dup2(keep, 1)
+            os.close(keep)
+
+    devmap = os.environ.get("PL_BENCH_DEVICES")
+    device = int(devmap.split(",")[local_rank]) if devmap else local_rank
+    reduce_on = "cuda"
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        torch.cuda.set_device(device)
+        backend = os.environ.get("PL_BENCH_DIST_BACKEND", "nccl")
+        try:
+            if backend == "nccl":
+                dist.init_process_group("nccl", device_id=torch.device("cuda", device))
+                # (communicators are created lazily: make the first collective happen here, where
+                # a failure can still be handled)
+                dist.barrier()
+            else:
+                init_gloo()
+        except Exception as e:      # noqa: BLE001
+            # The process group only carries the barrier around the timed region and the maximum
+            # of the ranks' times -- no frame data: if RCCL cannot come up on this box, the same
+            # two collectives over gloo (CPU) measure the same thing.
+            print(f"bench: rank {rank}: {backend} process group failed ({e}); using gloo for the "
+                  "barrier and the max-over-ranks", file=sys.stderr, flush=True)
+            if dist.is_initialized():
+                dist.destroy_process_group()
+            backend = "gloo"
+            init_gloo()
+        if backend != "nccl":
+            reduce_on = "cpu"
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
     # torch's device state is created now, not by the first torch.cuda.synchronize() of the timed
     # region's bracket: its lazy initialisation leaves work behind that a later device-wide
     # synchronize waits for (seen as a constant ~40 ms on top of any number of frames)
-    torch.cuda.set_device(local_rank)
+    torch.cuda.set_device(device)
     torch.cuda.synchronize()
 
     def barrier():
@@ -772,13 +808,13 @@ def main():
     (sw, sh), (dw, dh), alg_bytes, dominant = WORKLOADS[args.workload]
     per_frame = (sw * sh + dw * dh) * 8
     pool = args.pool or max(4, -(-800_000_000 // per_frame))
-    st = Stream(local_rank, args.workload, pool)
+    st = Stream(device, args.workload, pool)
     if args.scene_peak_allreduce:
         st.enable_scene_peak_allreduce(dist)
 
     elapsed = run_timed(st, args.steps, args.warmup, sync=torch.cuda.synchronize, barrier=barrier)
     if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed], dtype=torch.float64, device=reduce_on)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
@@ -835,15 +871,15 @@ def main():
                                                             tr["kernel_us"] / 1e3, 1))
                 roofline["trace"]["frac"] = round(roofline["trace"]["achieved"] / roofline["peak"], 4)
         if not args.no_companions:
-            out["rooflines"] = {w: config_block(local_rank, w, trace=not args.no_traffic)
+            out["rooflines"] = {w: config_block(device, w, trace=not args.no_traffic)
                                 for w in BASELINE_CONFIGS if w != args.workload}
         if not args.no_concurrent and args.workload in ASYNC_WORKLOADS:
             key = "single_stream" if args.async_measure else "async_measure"
-            out[key] = async_measure_block(local_rank, args.workload, args.steps, args.warmup,
+            out[key] = async_measure_block(device, args.workload, args.steps, args.warmup,
                                            on=not args.async_measure)
         if not args.no_concurrent:
             # companion only: `value` stays the single-stream figure
-            out["concurrent_streams_one_gpu"] = [concurrent_block(local_rank, args.workload, n)
+            out["concurrent_streams_one_gpu"] = [concurrent_block(device, args.workload, n)
                                                  for n in (2, 4)]
         if not args.no_cpu_baseline:
             cb = cpu_baseline()

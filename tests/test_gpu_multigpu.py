@@ -163,3 +163,27 @@ def test_c_worker_streams_in_one_process(gpu):
     assert two["value"] > 0.9 * one["value"], (one, two)
     peak = run("1", "40", "--scene-peak")
     assert peak["scene_peak_allreduce"] and peak["peak_exchanges"] >= 40 and peak["exchange_errors"] == 0
+
+
+def test_bench_two_ranks_end_to_end(gpu):
+    """`python bench.py --gpus 2` as the driver's scaling run starts it, on the one GPU this box
+    has: both ranks on device 0 (PL_BENCH_DEVICES), the barrier and the max-over-ranks over gloo
+    (RCCL refuses two ranks per device). Rank 0 alone owns stdout: exactly one JSON line."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items()
+           if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(PL_BENCH_DEVICES="0,0", PL_BENCH_DIST_BACKEND="gloo")
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "40",
+                        "--warmup", "10", "--no-cpu-baseline", "--no-companions", "--no-traffic",
+                        "--no-concurrent"], capture_output=True, text=True, timeout=900, env=env)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, lines
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["steps"] == 40 and out["scaling"] == "weak"
+    assert out["config"]["render_errors"] == 0
+    # two ranks' frames over the slower rank's time
+    assert abs(out["value"] - 2 * 40 * 3840 * 2160 / (out["ms_per_step"] * 40 * 1e-3) / 1e6) < 0.01 * out["value"]
