@@ -419,10 +419,13 @@ def measure_traffic(workload, symbol, timeout=240):
             "method": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, FETCH x2 (gfx950)"}
 
 
-def measure_trace(workload, symbol, timeout=240):
+def measure_trace(workload, symbol, timeout=240, async_measure=0):
     """Average duration of the kernel `symbol` in a rocprofv3 kernel trace of a short run of this
     script (the same figure profiles/*_kernel_stats.csv holds). An event pair bracketing ONE launch
-    also times ~3-4 us of launch latency, which shows on 20 us kernels; the trace does not."""
+    also times ~3-4 us of launch latency, which shows on 20 us kernels; the trace does not.
+    Traced on one stream by default, like the event times of measure_passes: a kernel's duration
+    is then its own. With async_measure=1 the trace shows the kernel as it runs in the timed loop,
+    sharing the CUs with the next frame's measuring pass (longer, while the frame is shorter)."""
     import csv
     import glob
     import shutil
@@ -435,7 +438,7 @@ def measure_trace(workload, symbol, timeout=240):
         env = dict(os.environ, TMPDIR="/tmp", PL_BENCH_CHILD="1")
         cmd = [rocprof, "--kernel-trace", "--stats", "--output-format", "csv", "-d", td, "--",
                sys.executable, os.path.abspath(__file__), "--workload", workload, "--steps", "40",
-               "--warmup", "8", "--bare"]
+               "--warmup", "8", "--bare", "--async-measure", str(int(async_measure))]
         try:
             r = subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, text=True,
                                timeout=timeout)
@@ -870,6 +873,10 @@ def main():
                 roofline["trace"] = dict(tr, achieved=round(roofline["algorithmic_bytes"] /
                                                             tr["kernel_us"] / 1e3, 1))
                 roofline["trace"]["frac"] = round(roofline["trace"]["achieved"] / roofline["peak"], 4)
+                if args.async_measure and args.workload in ASYNC_WORKLOADS:
+                    ov = measure_trace(args.workload, roofline["kernel"].split(" ")[0], async_measure=1)
+                    if ov:
+                        roofline["trace"]["kernel_us_beside_measuring_pass"] = ov["kernel_us"]
         if not args.no_companions:
             out["rooflines"] = {w: config_block(device, w, trace=not args.no_traffic)
                                 for w in BASELINE_CONFIGS if w != args.workload}

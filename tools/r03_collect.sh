@@ -1,7 +1,7 @@
 #!/bin/bash
-# round-3 collection (same as tools/r02_final.sh): the default bench line, the same command under rocprofv3 --kernel-trace --stats
+# round-3 collection (successor of tools/r02_final.sh): the default bench line, the same command under rocprofv3 --kernel-trace --stats
 # (without the concurrent-stream / async companions, whose launches overlap), per-workload kernel stats,
-# and the GPU test log. Outputs under gpurun_out/<tag>_*. Usage: tools/r02_final.sh <tag> [bench] [trace] [stats] [tests]
+# and the GPU test log. Outputs under gpurun_out/<tag>_*. Usage: tools/r03_collect.sh <tag> [bench] [trace] [stats] [tests]
 cd $GRAFT_REPO_ROOT
 export TMPDIR=/tmp
 mkdir -p gpurun_out
@@ -19,8 +19,15 @@ trace)
 stats)
   for wl in ewa_1080p_to_4k_hdr_tonemap ewa_lanczos_1080p_to_4k_dither10 bilinear_1080p_to_4k hdr10_4k_tonemap ewa_8k_to_4k_deband_tonemap lanczos_1080p_to_4k_dither10; do
     out=/tmp/st_$wl; rm -rf $out
-    (cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out -- python $GRAFT_REPO_ROOT/bench.py --bare --steps 40 --warmup 10 --workload $wl > /tmp/st_$wl.log 2>&1)
+    # one stream: every kernel's duration is its own (what bench.py's event times and "trace" report)
+    (cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out -- python $GRAFT_REPO_ROOT/bench.py --bare --steps 40 --warmup 10 --async-measure 0 --workload $wl > /tmp/st_$wl.log 2>&1)
     find $out -name "*kernel_stats.csv" -exec cp {} gpurun_out/${tag}_${wl}_kernel_stats.csv \;
+    case $wl in ewa_1080p_to_4k_hdr_tonemap|hdr10_4k_tonemap)
+      # the library default: the measuring pass beside the previous frame's long pass (both stretch, the frame shrinks)
+      rm -rf $out
+      (cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out -- python $GRAFT_REPO_ROOT/bench.py --bare --steps 40 --warmup 10 --workload $wl > /tmp/st_$wl.log 2>&1)
+      find $out -name "*kernel_stats.csv" -exec cp {} gpurun_out/${tag}_${wl}_async_kernel_stats.csv \; ;;
+    esac
   done ;;
 tests)
   timeout 1500 python -m pytest tests -q -m gpu 2>&1 | grep -v "^RCCL\|^HIP version\|^ROCm version\|^Hostname\|^Librccl" | tail -6 > gpurun_out/${tag}_gputests.log
