@@ -570,6 +570,85 @@ void k_pass_native(const plh_pass p_)
     }
 }
 
+/*
+ * k_pass_chain: k_pass_native for the one op list an HDR map pass records (struct plh_map_chain,
+ * plh_device.h) behind an rgba16 target -- no interpreter at all: decode, the chain's device
+ * functions, the fused epilogue (op_dither's plain path and the SCALE op, fastepi.hiph), store.
+ * Bit-identical to k_pass_native / k_pass_generic on such a pass; NP pixels per lane.
+ */
+#ifndef CHAIN_NP
+#define CHAIN_NP 2
+#endif
+template <bool F16SRC, int NP>
+__global__ __launch_bounds__(PASS_BW * PASS_BH)
+void k_pass_chain(const plh_pass p_)
+{
+    const plh_pass &p = plh_kernarg_pass();
+    const plh_sampler_args &s = p.s;
+    const int x0 = NP * (blockIdx.x * PASS_BW + threadIdx.x);
+    const int y = blockIdx.y * PASS_BH + threadIdx.y;
+    const int w = p.width, h = p.height;
+    if (x0 >= w || y >= h)
+        return;
+    const bool all = x0 + NP - 1 < w;
+    const char *row = (const char *) s.src.ptr + (size_t) y * s.src.pitch + (size_t) x0 * 8;
+    uint32_t q[2 * NP];
+    if (NP == 2 && all) {
+        const uint4 v = *(const uint4 *) row;
+        q[0] = v.x; q[1] = v.y; q[2] = v.z; q[3] = v.w;
+    } else {
+        const uint2 e = *(const uint2 *) row;
+#pragma unroll
+        for (int i = 0; i < NP; i++) {
+            q[2 * i] = e.x;
+            q[2 * i + 1] = e.y;
+        }
+    }
+    // the dither values, asked for before the arithmetic that hides their latency
+    const plh_fast_epi &e = p.epi;
+    float bias[NP];
+#pragma unroll
+    for (int i = 0; i < NP; i++) {
+        const int ix = (x0 + i + p.frag_x0) & e.mask, iy = (y + p.frag_y0) & e.mask;
+        bias[i] = e.has_dither ? e.matrix[iy * e.size + ix] : 0.0f;
+    }
+    float4_t c[NP];
+#pragma unroll
+    for (int i = 0; i < NP; i++) {
+        const uint32_t lo = q[2 * i], hi = q[2 * i + 1];
+        if (F16SRC)
+            c[i] = { plh_h2f(lo & 0xffff), plh_h2f(lo >> 16), plh_h2f(hi & 0xffff), plh_h2f(hi >> 16) };
+        else
+            c[i] = { plh_un16(lo & 0xffff), plh_un16(lo >> 16), plh_un16(hi & 0xffff), plh_un16(hi >> 16) };
+        if (s.scale != 1.0f)
+            c[i] = scale4(c[i], s.scale);
+    }
+    run_map_chain<NP>(c, p);
+    uint32_t o[2 * NP];
+#pragma unroll
+    for (int i = 0; i < NP; i++) {
+        if (e.has_dither) {
+            const float b = bias[i], ds = e.dscale, di = e.dinv;
+            c[i] = { __builtin_floorf(ds * c[i].x + b) * di, __builtin_floorf(ds * c[i].y + b) * di,
+                     __builtin_floorf(ds * c[i].z + b) * di, __builtin_floorf(ds * c[i].w + b) * di };
+        }
+        if (e.has_scale)
+            c[i] = scale4(c[i], e.scale);
+        o[2 * i] = plh_unorm16x2(c[i].x, c[i].y);
+        o[2 * i + 1] = plh_unorm16x2(c[i].z, c[i].w);
+    }
+    char *d = (char *) p.dst.ptr + (size_t) y * p.dst.pitch + (size_t) x0 * 8;
+    if (NP == 2 && all) {
+        const plh_u32x4 pk = { o[0], o[1], o[2], o[3] };
+        if (p.nt_store)
+            __builtin_nontemporal_store(pk, (plh_u32x4 *) d);
+        else
+            *(plh_u32x4 *) d = pk;
+    } else {
+        *(uint2 *) d = make_uint2(o[0], o[1]);
+    }
+}
+
 // the shape k_pass_native is written for
 static bool pass_native_applies(const plh_pass *pass)
 {
@@ -744,7 +823,17 @@ extern "C" int plh_launch_pass(plh_stream stream_, const struct plh_pass *pass)
     }
 
     if (pass_native_applies(pass)) {
-        if (plh_ops_lite(pass, 0, pass->num_ops))
+        plh_pass local = *pass;
+        plh_match_map_chain(&local);
+        if (local.chain.enabled) {
+            const dim3 block(PASS_BW, PASS_BH);
+            const int cells_w = (local.width + CHAIN_NP - 1) / CHAIN_NP;
+            const dim3 grid((cells_w + PASS_BW - 1) / PASS_BW, (local.height + PASS_BH - 1) / PASS_BH);
+            if (local.s.src.fmt == PLH_FMT_RGBA16F)
+                hipLaunchKernelGGL((k_pass_chain<true, CHAIN_NP>), grid, block, 0, stream, local);
+            else
+                hipLaunchKernelGGL((k_pass_chain<false, CHAIN_NP>), grid, block, 0, stream, local);
+        } else if (plh_ops_lite(pass, 0, pass->num_ops))
             launch_pass_native<true>(stream, pass);
         else
             launch_pass_native<false>(stream, pass);

@@ -319,12 +319,17 @@ static int launch_mask(hipStream_t stream, const plh_pass *pass, dim3 grid, dim3
 int plh_launch_polar(hipStream_t stream, const plh_pass *pass_in)
 {
     plh_pass local = *pass_in;
-    plh_match_fast_epilogue(&local);
     const plh_pass *pass = &local;
     const dim3 block(POLAR_BW, POLAR_BH);
     const uint32_t cm = pass->s.comp_mask & 0xf;
-    if (pass->s.pp && pass->s.mx.enabled && (cm == 0x7 || cm == 0xf))
+    if (pass->s.pp && pass->s.mx.enabled && (cm == 0x7 || cm == 0xf)) {
+        // (the matrix-pipe kernel has a variant for the map chain of an HDR pass)
+        plh_match_map_chain(&local);
+        if (!local.chain.enabled)
+            plh_match_fast_epilogue(&local);
         return plh_launch_polar_mx(stream, pass);
+    }
+    plh_match_fast_epilogue(&local);
     if (pass->s.pp && (cm == 0x7 || cm == 0xf || cm == 0x1 || cm == 0x3)) {
         const int n = pass->s.pp_n, cw = pass->s.pp_cells_w, ch = pass->s.pp_cells_h;
         const int cth = POLAR_BH * pass->s.tile_rows;

