@@ -579,7 +579,7 @@ void k_pass_native(const plh_pass p_)
 #ifndef CHAIN_NP
 #define CHAIN_NP 2
 #endif
-template <bool F16SRC, int NP>
+template <bool F16SRC, int NP, bool CR>
 __global__ __launch_bounds__(PASS_BW * PASS_BH)
 void k_pass_chain(const plh_pass p_)
 {
@@ -623,7 +623,15 @@ void k_pass_chain(const plh_pass p_)
         if (s.scale != 1.0f)
             c[i] = scale4(c[i], s.scale);
     }
-    run_map_chain<NP>(c, p);
+    float pos[NP][2];
+    if (CR) {
+#pragma unroll
+        for (int i = 0; i < NP; i++) {
+            pos[i][0] = p.out_scale[0] * ((float) (x0 + i) + 0.5f);
+            pos[i][1] = p.out_scale[1] * ((float) y + 0.5f);
+        }
+    }
+    run_map_chain<NP, CR>(c, p, pos);
     uint32_t o[2 * NP];
 #pragma unroll
     for (int i = 0; i < NP; i++) {
@@ -824,15 +832,19 @@ extern "C" int plh_launch_pass(plh_stream stream_, const struct plh_pass *pass)
 
     if (pass_native_applies(pass)) {
         plh_pass local = *pass;
-        plh_match_map_chain(&local);
+        plh_match_map_chain(&local, true);
         if (local.chain.enabled) {
             const dim3 block(PASS_BW, PASS_BH);
             const int cells_w = (local.width + CHAIN_NP - 1) / CHAIN_NP;
             const dim3 grid((cells_w + PASS_BW - 1) / PASS_BW, (local.height + PASS_BH - 1) / PASS_BH);
-            if (local.s.src.fmt == PLH_FMT_RGBA16F)
-                hipLaunchKernelGGL((k_pass_chain<true, CHAIN_NP>), grid, block, 0, stream, local);
-            else
-                hipLaunchKernelGGL((k_pass_chain<false, CHAIN_NP>), grid, block, 0, stream, local);
+            const bool f16 = local.s.src.fmt == PLH_FMT_RGBA16F;
+            if (local.chain.contrast_recovery) {
+                if (f16) hipLaunchKernelGGL((k_pass_chain<true, CHAIN_NP, true>), grid, block, 0, stream, local);
+                else     hipLaunchKernelGGL((k_pass_chain<false, CHAIN_NP, true>), grid, block, 0, stream, local);
+            } else {
+                if (f16) hipLaunchKernelGGL((k_pass_chain<true, CHAIN_NP, false>), grid, block, 0, stream, local);
+                else     hipLaunchKernelGGL((k_pass_chain<false, CHAIN_NP, false>), grid, block, 0, stream, local);
+            }
         } else if (plh_ops_lite(pass, 0, pass->num_ops))
             launch_pass_native<true>(stream, pass);
         else

@@ -254,6 +254,7 @@ struct plh_fast_epi {
 struct plh_map_chain {
     int32_t enabled;
     int32_t lin, in, tone, gamut, out, delin;
+    int32_t contrast_recovery;  // the tone op reads a feature map (its i2 != 0)
 };
 
 struct plh_pass {
