@@ -324,7 +324,8 @@ int plh_launch_polar(hipStream_t stream, const plh_pass *pass_in)
     const uint32_t cm = pass->s.comp_mask & 0xf;
     if (pass->s.pp && pass->s.mx.enabled && (cm == 0x7 || cm == 0xf)) {
         // (the matrix-pipe kernel has a variant for the map chain of an HDR pass)
-        plh_match_map_chain(&local);
+        if (cm == 0x7)
+            plh_match_map_chain(&local, true);
         if (!local.chain.enabled)
             plh_match_fast_epilogue(&local);
         return plh_launch_polar_mx(stream, pass);

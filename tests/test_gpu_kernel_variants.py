@@ -433,3 +433,63 @@ def test_pass_native_equals_generic(gpu, size):
                 else:
                     os.environ["PL_HIP_PASS_NATIVE"] = old
         assert np.array_equal(outs[0], outs[1]) and outs[0][..., :3].std() > 1000
+
+
+def _env(name, value):
+    class _E:
+        def __enter__(self):
+            self.old = os.environ.get(name)
+            os.environ[name] = value
+        def __exit__(self, *a):
+            if self.old is None:
+                os.environ.pop(name, None)
+            else:
+                os.environ[name] = self.old
+    return _E()
+
+
+@pytest.mark.parametrize("case", ["map_pass", "map_pass_contrast_recovery", "ewa_2x_map", "ewa_2x_map_no_peak"])
+@pytest.mark.parametrize("size", [(97, 61), (256, 130)])
+def test_map_chain_equals_interpreter(gpu, case, size):
+    """The op list of an HDR map pass as straight-line code (struct plh_map_chain: k_pass_chain, the
+    CHAIN epilogue of k_polar_mx) against the same pass through the op interpreter
+    (PL_HIP_MAP_CHAIN=0): the same device functions in the same order, so the frames must agree
+    bit for bit -- HDR10 -> BT.1886 with a 10-bit dither behind an intermediate (with and without
+    contrast recovery reading the feature map) and behind the EWA 2x upscale on the matrix pipe
+    (the metric's launch), odd sizes included (single-pixel last column, partial tiles)."""
+    from test_gpu_fullsize import hdr_frame16
+    w, h = size
+    hdr = hdr_frame16(w, h)
+    peak = pl.peak_detect_params(percentile=99.995)
+    if case == "map_pass":
+        dw, dh, params = w, h, pl.render_params("default", peak_detect_params=peak)
+    elif case == "map_pass_contrast_recovery":
+        dw, dh, params = w, h, pl.render_params("high_quality", peak_detect_params=peak)
+    elif case == "ewa_2x_map":
+        dw, dh, params = 2 * w, 2 * h, pl.render_params("default", upscaler=pl.filter_config("ewa_lanczos"), peak_detect_params=peak)
+    else:
+        dw, dh, params = 2 * w, 2 * h, pl.render_params("default", upscaler=pl.filter_config("ewa_lanczos"), peak_detect_params=None)
+    outs = []
+    for chain in ("1", "0"):
+        with _env("PL_HIP_MAP_CHAIN", chain), _env("PL_HIP_POLAR_MFMA", "1"):
+            src = gpu.tex_create(w, h, "rgba16", hdr)
+            dst = gpu.tex_create(dw, dh, "rgba16")
+            rr = pl.Renderer(gpu)
+            util.srand(1)
+            assert rr.render(pl.frame(src, components=3, color=pl.color_space("bt2020", "pq", max_luma=1000.0)),
+                             pl.frame(dst, repr_=pl.color_repr("rgb", "full", **TEN_BIT),
+                                      color=pl.color_space("bt709", "bt1886")), params)
+            assert rr.errors() == 0
+            outs.append(dst.download())
+            rr.destroy(); src.destroy(); dst.destroy()
+    assert outs[0][..., :3].std() > 1000
+    if case == "map_pass_contrast_recovery":
+        # The interpreter keeps contrast recovery on its per-op path (op_tone_map between
+        # op_rgb2ipt and op_ipt2rgb, IEEE divisions); the chain has it inside the fused map
+        # (cm_fused<NP, true>: reciprocal + Newton step, the well-conditioned PQ pair). Same
+        # formulas, both within the oracle's tolerance (test_gpu_metric.py): behind a 10-bit
+        # dither they may differ by one 10-bit step on a few samples.
+        d = np.abs(outs[0].astype(np.int64) - outs[1].astype(np.int64))
+        assert d.max() <= 65 and (d > 0).mean() < 0.01, (d.max(), (d > 0).mean())
+    else:
+        assert np.array_equal(outs[0], outs[1])

@@ -51,7 +51,7 @@ BUDGET = [
     (r"k_polar_pp<float, \d+u, 1, false, false>", 3),
     # the matrix-pipe polar kernel (exact 2x upscales): 8-wave tiles at 4 waves per SIMD for the
     # fast epilogue and for the colour map (RGB); 4-wave tiles at 3 otherwise
-    (r"k_polar_mx<3, true, (0|2), 8>", 4),
+    (r"k_polar_mx<3, true, (0|2|3|4), 8>", 4),
     (r"k_polar_mx<3, (true|false), [012], 4>", 3),
     (r"k_polar_mx<4, true, [01], 4>", 3),
     (r"k_polar_mx<4, (true|false), 2, 4>", 2),
@@ -60,6 +60,9 @@ BUDGET = [
     (r"k_pass_generic<.*>", 4),
     (r"k_pass_native<true, .*>", 8),
     (r"k_pass_native<false, .*>", 4),
+    # the map chain as straight-line code: all 8 wave slots (7 with contrast recovery compiled in)
+    (r"k_pass_chain<(true|false), 2, false>", 8),
+    (r"k_pass_chain<(true|false), 2, true>", 7),
     (r"k_peak_fast<(true|false), (true|false)>", 8),
     (r"k_pass_peak<true>", 4),
     (r"k_pass_peak<false>", 3),
