@@ -657,8 +657,55 @@ void k_pass_chain(const plh_pass p_)
     }
 }
 
+/*
+ * k_pass_features: pl_shader_extract_features as its own pass (renderer.c:1404-1440: the
+ * contrast-recovery feature map, one FEATURES op from the linear-light intermediate into an r16hf
+ * plane) without the interpreter: two pixels per lane, 16 bytes in, 4 bytes out. op_features
+ * itself, so bit-identical to k_pass_generic.
+ */
+template <bool F16SRC>
+__global__ __launch_bounds__(PASS_BW * PASS_BH)
+void k_pass_features(const plh_pass p_)
+{
+    const plh_pass &p = plh_kernarg_pass();
+    const plh_sampler_args &s = p.s;
+    const int x0 = 2 * (blockIdx.x * PASS_BW + threadIdx.x);
+    const int y = blockIdx.y * PASS_BH + threadIdx.y;
+    if (x0 >= p.width || y >= p.height)
+        return;
+    const bool two = x0 + 1 < p.width;
+    const char *row = (const char *) s.src.ptr + (size_t) y * s.src.pitch + (size_t) x0 * 8;
+    uint32_t q[4];
+    if (two) {
+        const uint4 v = *(const uint4 *) row;
+        q[0] = v.x; q[1] = v.y; q[2] = v.z; q[3] = v.w;
+    } else {
+        const uint2 e = *(const uint2 *) row;
+        q[0] = q[2] = e.x; q[1] = q[3] = e.y;
+    }
+    uint32_t o[2];
+#pragma unroll
+    for (int i = 0; i < 2; i++) {
+        const uint32_t lo = q[2 * i], hi = q[2 * i + 1];
+        float4_t c;
+        if (F16SRC)
+            c = { plh_h2f(lo & 0xffff), plh_h2f(lo >> 16), plh_h2f(hi & 0xffff), plh_h2f(hi >> 16) };
+        else
+            c = { plh_un16(lo & 0xffff), plh_un16(lo >> 16), plh_un16(hi & 0xffff), plh_un16(hi >> 16) };
+        if (s.scale != 1.0f)
+            c = scale4(c, s.scale);
+        op_features(c, p.ops[0]);
+        o[i] = plh_f2h(c.x);
+    }
+    char *d = (char *) p.dst.ptr + (size_t) y * p.dst.pitch + (size_t) x0 * 2;
+    if (two)
+        *(uint32_t *) d = o[0] | (o[1] << 16);
+    else
+        *(uint16_t *) d = (uint16_t) o[0];
+}
+
 // the shape k_pass_native is written for
-static bool pass_native_applies(const plh_pass *pass)
+static bool pass_native_applies(const plh_pass *pass, bool features = false)
 {
     const plh_sampler_args &s = pass->s;
     const char *env = getenv("PL_HIP_PASS_NATIVE");
@@ -670,8 +717,11 @@ static bool pass_native_applies(const plh_pass *pass)
     if (!native || s.type != PLH_SAMPLE_NEAREST || s.address_mode != PLH_ADDRESS_CLAMP ||
         pass->transpose || pass->num_pre_ops || pass->base_x || pass->base_y || pass->dir_x != 1 ||
         pass->dir_y != 1 || pass->dst.w < pass->width || pass->dst.h < pass->height ||
-        (s.src.fmt != PLH_FMT_RGBA16 && s.src.fmt != PLH_FMT_RGBA16F) ||
-        (pass->dst.fmt != PLH_FMT_RGBA16 && pass->dst.fmt != PLH_FMT_RGBA16F))
+        (s.src.fmt != PLH_FMT_RGBA16 && s.src.fmt != PLH_FMT_RGBA16F))
+        return false;
+    if (features)   // (k_pass_features: the one op into an r16hf plane)
+        return pass->dst.fmt == PLH_FMT_R16F && pass->num_ops == 1 && pass->ops[0].kind == PLH_OP_FEATURES;
+    if (pass->dst.fmt != PLH_FMT_RGBA16 && pass->dst.fmt != PLH_FMT_RGBA16F)
         return false;
     for (int i = 0; i < pass->num_ops; i++) {
         const int k = pass->ops[i].kind;
@@ -828,6 +878,17 @@ extern "C" int plh_launch_pass(plh_stream stream_, const struct plh_pass *pass)
             const hipError_t err = hipGetLastError();
             return err == hipSuccess ? 0 : -(int) err;
         }
+    }
+
+    if (pass_native_applies(pass, true)) {
+        const dim3 block(PASS_BW, PASS_BH);
+        const dim3 grid(((pass->width + 1) / 2 + PASS_BW - 1) / PASS_BW, (pass->height + PASS_BH - 1) / PASS_BH);
+        if (pass->s.src.fmt == PLH_FMT_RGBA16F)
+            hipLaunchKernelGGL(k_pass_features<true>, grid, block, 0, stream, *pass);
+        else
+            hipLaunchKernelGGL(k_pass_features<false>, grid, block, 0, stream, *pass);
+        const hipError_t err = hipGetLastError();
+        return err == hipSuccess ? 0 : -(int) err;
     }
 
     if (pass_native_applies(pass)) {

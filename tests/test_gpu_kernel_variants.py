@@ -493,3 +493,28 @@ def test_map_chain_equals_interpreter(gpu, case, size):
         assert d.max() <= 65 and (d > 0).mean() < 0.01, (d.max(), (d > 0).mean())
     else:
         assert np.array_equal(outs[0], outs[1])
+
+
+@pytest.mark.parametrize("size", [(97, 61), (256, 130)])
+def test_features_pass_equals_generic(gpu, size):
+    """k_pass_features (pl_shader_extract_features as its own pass, the feature map of contrast
+    recovery) against k_pass_generic: the high_quality preset on an HDR10 frame, everything else
+    held on the interpreter (PL_HIP_MAP_CHAIN=0), must give the same frame bit for bit."""
+    from test_gpu_fullsize import hdr_frame16
+    w, h = size
+    hdr = hdr_frame16(w, h)
+    params = pl.render_params("high_quality", peak_detect_params=pl.peak_detect_params(percentile=99.995))
+    outs = []
+    for native in ("1", "0"):
+        with _env("PL_HIP_MAP_CHAIN", "0"), _env("PL_HIP_PASS_NATIVE", native):
+            src = gpu.tex_create(w, h, "rgba16", hdr)
+            dst = gpu.tex_create(w, h, "rgba16")
+            rr = pl.Renderer(gpu)
+            util.srand(1)
+            assert rr.render(pl.frame(src, components=3, color=pl.color_space("bt2020", "pq", max_luma=1000.0)),
+                             pl.frame(dst, repr_=pl.color_repr("rgb", "full", **TEN_BIT),
+                                      color=pl.color_space("bt709", "bt1886")), params)
+            assert rr.errors() == 0
+            outs.append(dst.download())
+            rr.destroy(); src.destroy(); dst.destroy()
+    assert np.array_equal(outs[0], outs[1]) and outs[0][..., :3].std() > 1000
