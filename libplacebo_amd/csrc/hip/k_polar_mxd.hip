@@ -1,0 +1,238 @@
+/*
+ * libplacebo-hip -- k_polar_mxd: the polar (EWA) 2 : 1 downscale as a tile contraction on the f16
+ * matrix pipe (struct plh_polar_mx with enabled == 2, plh_device.h; the upscale is k_polar_mx.hiph,
+ * whose header explains the numerics: f16 source tile = the reference's rgba16hf intermediate,
+ * weights as f16 hi + lo halves, exact products, fp32 sums, first-order terms in the per-pixel
+ * phase deviation).
+ *
+ * What the reference computes per output pixel (src/shaders/sampling.c:503-558, 723-783), for an
+ * exact halving: the filter is widened by the ratio (radius 3.24 -> 6.48 texels: taps -6 .. 7 on
+ * both axes, 148 inside the disc), the base texel of output (X, Y) is (2 X, 2 Y) + origin and
+ * fcoord = 1/2 on both axes up to the fp32 rounding of pos * size (1e-3 at 8K):
+ *     out[Y][X] = sum_j sum_i w'(j, i) S[2 Y + j][2 X + i]          (w' = w * scale / wsum)
+ * With m = output row, n = output column of a 16 x 16 wave tile and k = source column:
+ *     out[m][n] = sum_j sum_k S[2 m + j][k] * T_j[k - 2 n]
+ * -- per source row offset j a GEMM whose A operand is 16 (every second) rows x 32 columns of the
+ * tile and whose B operand is a constant banded matrix; the 16 outputs need k in [0, 44): two
+ * 32-column blocks. Per j and block: hi, lo (+ dfx(X) * d/dx, folded in registers: v_pk_fma_f16)
+ * into one accumulator set, dfy-term into a second one that the epilogue folds in with the row's
+ * own dfy(Y). At fcoord = (1/2, 1/2) the weights of rows j and 13 - j are the same (d/dy: opposite),
+ * so B is stored for j < 7 only: 56 fragments = 56 KiB of LDS.
+ *
+ * Shape. A workgroup of 8 waves renders 64 x 32 outputs (4 x 2 wave tiles) from a 140 x 76 source
+ * tile, channel-planar f16 with a row pitch of 304 bytes (16-byte aligned rows; every second row
+ * of 16 lanes + the 16-byte column step fall on distinct bank groups: conflict-free
+ * ds_read_b128). LDS 56 + 67.7 KiB: one workgroup per CU, 2 waves per SIMD with the whole
+ * register file. Per wave: 14 x 2 x (3 A reads + 9 MFMAs) + 56 B reads = 252 v_mfma_f32_16x16x32_f16.
+ * This first version handles what BASELINE configs[4] runs: an rgba16hf source without fused
+ * pre-ops (or behind an identity PLANE_MAP), RGB, no post-ops, an rgba16hf target; everything else
+ * stays on k_polar_pp.
+ */
+#include "polar_common.hiph"
+
+#define MXD_TW      64                      // output columns per workgroup tile
+#define MXD_TH      32                      // output rows
+#define MXD_SRC_W   (2 * MXD_TW + 12)       // 140 source columns
+#define MXD_SRC_H   (2 * MXD_TH + 12)       // 76 source rows
+#define MXD_PITCH   304                     // bytes per tile row of one channel (16 * 19)
+#define MXD_PLANE   (MXD_SRC_H * MXD_PITCH)
+#define MXD_B_BYTES (PLH_MXD_NFRAG * 64 * 16)
+#define MXD_NT      512
+#define MXD_HP      (MXD_SRC_W / 2)         // texel pairs per tile row
+#define MXD_NPAIRS  (MXD_HP * MXD_SRC_H)
+#define MXD_NV      ((MXD_NPAIRS + MXD_NT - 1) / MXD_NT)
+
+typedef _Float16 mxd_f16x8 __attribute__((ext_vector_type(8)));
+typedef float mxd_f32x4 __attribute__((ext_vector_type(4)));
+
+__global__ __launch_bounds__(MXD_NT)
+void k_polar_mxd(const plh_pass p_)
+{
+    const plh_pass &p = plh_kernarg_pass();
+    const plh_sampler_args &s = p.s;
+    const plh_polar_mx &mx = s.mx;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned char *bl = smem;
+    unsigned char *tile = smem + MXD_B_BYTES;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int dbg = s.pp_debug;     // profiling aid: 1 = no contraction, 4 = no stores, 8 = no tile loads
+
+    // XCD x works on the x-th contiguous eighth of the tiles (k_polar_mx.hiph)
+    const int tiles_x = (p.width + MXD_TW - 1) / MXD_TW;
+    int bx, by;
+    {
+        const uint32_t total = gridDim.x, lin = blockIdx.x;
+        const uint32_t q = total >> 3, r = total & 7u;
+        const uint32_t xcd = lin & 7u, k = lin >> 3;
+        const uint32_t t = xcd * q + min(xcd, r) + k;
+        by = (int) (t / (uint32_t) tiles_x);
+        bx = (int) (t - (uint32_t) by * (uint32_t) tiles_x);
+    }
+    const int ox = mx.org_x + 2 * MXD_TW * bx;      // source texel of LDS (0, 0)
+    const int oy = mx.org_y + 2 * MXD_TH * by;
+
+    // ---- B fragments: global (L2 resident) -> LDS, one global_load_lds_dwordx4 per fragment -------
+#pragma unroll
+    for (int f = wave; f < PLH_MXD_NFRAG; f += MXD_NT / 64) {
+        const unsigned char *g = (const unsigned char *) mx.bfrag + ((size_t) f * 64 + lane) * 16;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *) g,
+                                         (__attribute__((address_space(3))) void *) (bl + f * 1024), 16, 0, 0);
+    }
+
+    // columns 140 .. 151 of every tile row (and 16 bytes behind the tile) are read by the last
+    // column block, where they only meet zero weights: make them zeros, not whatever LDS held
+    for (int i = tid; i < 3 * MXD_SRC_H; i += MXD_NT) {
+        uint32_t *d = (uint32_t *) (tile + i * MXD_PITCH + MXD_SRC_W * 2);
+#pragma unroll
+        for (int k = 0; k < (MXD_PITCH - MXD_SRC_W * 2) / 4; k++)
+            d[k] = 0;
+    }
+    if (tid < 4)
+        ((uint32_t *) (tile + 3 * MXD_PLANE))[tid] = 0;
+
+    // ---- source tile -> LDS: pairs of horizontally adjacent rgba16hf texels, one 16-byte load
+    // each, all issued together; the f16 codes move bit for bit into the channel planes ----------
+    {
+        int sw = s.src.w, sh = s.src.h, u_spitch = s.src.pitch;
+        uintptr_t u_sptr = (uintptr_t) s.src.ptr;
+        asm volatile("" : "+s"(sw), "+s"(sh), "+s"(u_spitch), "+s"(u_sptr));
+        const bool edge = ox < 0 || ox + MXD_SRC_W > sw;
+        uint4 v[MXD_NV];
+        int ty[MXD_NV], tp[MXD_NV], sx[MXD_NV];
+#pragma unroll
+        for (int u = 0; u < MXD_NV; u++) {
+            const int i = min(tid + u * MXD_NT, MXD_NPAIRS - 1);
+            ty[u] = (int) (((float) i + 0.5f) * (1.0f / (float) MXD_HP));   // exact: i < 2^22
+            tp[u] = i - ty[u] * MXD_HP;
+            sx[u] = ox + 2 * tp[u];
+            const int sy = min(max(oy + ty[u], 0), sh - 1);
+            const int px = min(max(sx[u], 0), sw - 2);
+            const plh_u32x4 q = *(const __attribute__((address_space(1))) plh_u32x4 *)
+                                    (u_sptr + (size_t) sy * (size_t) u_spitch + (size_t) px * 8);
+            v[u] = (dbg & 8) ? make_uint4(tid, u, 0, 0) : make_uint4(q.x, q.y, q.z, q.w);
+        }
+        if (edge) {
+            // a pair at clamped positions: beyond the left edge both texels are the pair's first,
+            // beyond the right edge both its second
+#pragma unroll
+            for (int u = 0; u < MXD_NV; u++) {
+                const uint4 w = v[u];
+                const bool ldup = sx[u] < 0, hdup = sx[u] > sw - 2;
+                const uint32_t ax = hdup ? w.z : w.x, ay = hdup ? w.w : w.y;
+                const uint32_t bx_ = ldup ? w.x : w.z, by_ = ldup ? w.y : w.w;
+                v[u] = make_uint4(ax, ay, bx_, by_);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < MXD_NV; u++) {
+            const uint4 w = v[u];
+            if (tid + u * MXD_NT < MXD_NPAIRS) {
+                unsigned char *d = tile + ty[u] * MXD_PITCH + tp[u] * 4;
+                *(uint32_t *) d = (w.x & 0xffffu) | (w.z << 16);
+                *(uint32_t *) (d + MXD_PLANE) = (w.x >> 16) | (w.z & 0xffff0000u);
+                *(uint32_t *) (d + 2 * MXD_PLANE) = (w.y & 0xffffu) | (w.w << 16);
+            }
+        }
+    }
+
+    // ---- the wave's 16 x 16 outputs ---------------------------------------------------------------
+    const int ln = lane & 15, lg = lane >> 4;
+    const int wc = wave & 3, wr = wave >> 2;
+    const int X = MXD_TW * bx + 16 * wc + ln;           // the lane's output column (B / D operand: n = ln)
+    const int Y0 = MXD_TH * by + 16 * wr + 4 * lg;      // its four output rows Y0 .. Y0 + 3 (D: m = 4 lg + r)
+    const _Float16 dxh = (_Float16) mx.dfx[X];
+    const mxd_f16x8 dx8 = { dxh, dxh, dxh, dxh, dxh, dxh, dxh, dxh };
+    float dfy[4];
+#pragma unroll
+    for (int r = 0; r < 4; r++)
+        dfy[r] = mx.dfy[Y0 + r];
+    __syncthreads();
+
+    mxd_f32x4 acc[3], accy[3];
+#pragma unroll
+    for (int ch = 0; ch < 3; ch++) {
+        acc[ch] = (mxd_f32x4) (0.0f);
+        accy[ch] = (mxd_f32x4) (0.0f);
+    }
+    // A fragment of lane l for source row offset j, column block kb: the 16 bytes at tile row
+    // 2 * (16 wr + ln) + j, column 32 wc + 32 kb + 8 lg
+    const unsigned char *ab = tile + (2 * (16 * wr + ln)) * MXD_PITCH + (32 * wc + 8 * lg) * 2;
+    const unsigned char *bfl = bl + lane * 16;
+    if (!(dbg & 1)) {
+#pragma unroll 1
+        for (int j = 0; j < PLH_MXD_TAPS / 2; j++) {
+#pragma unroll
+            for (int kb = 0; kb < 2; kb++) {
+                const unsigned char *bf = bfl + 4 * (2 * j + kb) * 1024;
+                const mxd_f16x8 bhi = *(const mxd_f16x8 *) bf;
+                // (the column-phase term rides on the lo half, k_polar_mx.hiph)
+                const mxd_f16x8 blo = *(const mxd_f16x8 *) (bf + 2048) * dx8 + *(const mxd_f16x8 *) (bf + 1024);
+                const mxd_f16x8 bdy = *(const mxd_f16x8 *) (bf + 3072);
+                const mxd_f16x8 bdn = -bdy;
+#pragma unroll
+                for (int half = 0; half < 2; half++) {
+                    // rows j and 13 - j share the weights; d/dy changes sign
+                    const int jj = half ? PLH_MXD_TAPS - 1 - j : j;
+                    const unsigned char *a0 = ab + jj * MXD_PITCH + 64 * kb;
+#pragma unroll
+                    for (int ch = 0; ch < 3; ch++) {
+                        const mxd_f16x8 a = *(const mxd_f16x8 *) (a0 + ch * MXD_PLANE);
+                        acc[ch] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, bhi, acc[ch], 0, 0, 0);
+                        acc[ch] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, blo, acc[ch], 0, 0, 0);
+                        accy[ch] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, half ? bdn : bdy, accy[ch], 0, 0, 0);
+                    }
+                }
+            }
+        }
+    }
+
+    // ---- epilogue: rgba16hf store, guarded (dispatch.c:1126-1142) --------------------------------
+    const int cpos = p.base_x + p.dir_x * X;
+    const bool cok = X < p.width && p.out_scale[0] * (float) X < 1.0f && cpos >= 0 && cpos < p.dst.w;
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+        const int Y = Y0 + r;
+        const int rpos = p.base_y + p.dir_y * Y;
+        const bool ok = cok && Y < p.height && p.out_scale[1] * (float) Y < 1.0f && rpos >= 0 && rpos < p.dst.h;
+        float o[3];
+#pragma unroll
+        for (int ch = 0; ch < 3; ch++)
+            o[ch] = __builtin_fmaf(dfy[r], accy[ch][r], acc[ch][r]);
+        plh_u32x2 px;
+        px.x = (uint32_t) plh_f2h(o[0]) | ((uint32_t) plh_f2h(o[1]) << 16);
+        px.y = (uint32_t) plh_f2h(o[2]) | 0x3c000000u;      // alpha = 1 (not sampled)
+        if (ok && !(dbg & 4))
+            *(plh_u32x2 *) ((char *) p.dst.ptr + (size_t) rpos * p.dst.pitch + (size_t) cpos * 8) = px;
+    }
+}
+
+// the pass k_polar_mxd is written for (file header)
+bool plh_polar_mxd_applies(const plh_pass *pass)
+{
+    const plh_sampler_args &s = pass->s;
+    // (a fused identity PLANE_MAP of a plane that carries r, g, b changes none of them; nor does a
+    // SCALE by exactly one, which is what encoding into a float target records)
+    bool plain = pass->num_pre_ops <= 1 && pass->num_ops - pass->num_pre_ops <= 1;
+    if (pass->num_pre_ops == 1) {
+        const plh_op &op = pass->ops[0];
+        plain = plain && op.kind == PLH_OP_PLANE_MAP && op.i2 && op.i1 >= 3;
+    }
+    if (pass->num_ops > pass->num_pre_ops) {
+        const plh_op &op = pass->ops[pass->num_pre_ops];
+        plain = plain && op.kind == PLH_OP_SCALE && op.f[0] == 1.0f && op.f[1] == 1.0f && op.f[2] == 1.0f &&
+                op.f[3] == 1.0f;
+    }
+    return s.mx.enabled == 2 && (s.comp_mask & 0xf) == 0x7 && s.src.fmt == PLH_FMT_RGBA16F &&
+           pass->dst.fmt == PLH_FMT_RGBA16F && plain && !pass->transpose;
+}
+
+int plh_launch_polar_mxd(hipStream_t stream, const plh_pass *pass)
+{
+    const int tiles_x = (pass->width + MXD_TW - 1) / MXD_TW;
+    const int tiles_y = (pass->height + MXD_TH - 1) / MXD_TH;
+    const size_t shmem = MXD_B_BYTES + (size_t) 3 * MXD_PLANE + 16;
+    (void) hipFuncSetAttribute((const void *) k_polar_mxd, hipFuncAttributeMaxDynamicSharedMemorySize, (int) shmem);
+    hipLaunchKernelGGL(k_polar_mxd, dim3(tiles_x * tiles_y), dim3(MXD_NT), shmem, stream, *pass);
+    const hipError_t err = hipGetLastError();
+    return err == hipSuccess ? 0 : -(int) err;
+}

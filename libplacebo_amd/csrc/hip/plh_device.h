@@ -99,11 +99,18 @@ struct plh_polar_pp {
 // One v_mfma_f32_16x16x32_f16 covers two source rows x 16 source columns.
 // The host builds B once per (filter, geometry) in fragment order: frag f, lane l, element e,
 // f = 4 * (py ? 4 + j : j) + {hi, lo, d/dx, d/dy} for row pair j (py = 0: 4 pairs, py = 1: 5).
+// An exact 2 : 1 DOWNSCALE (enabled == 2, k_polar_mxd.hip) has ONE phase per axis, fcoord = 1/2, and
+// a 14 x 14 footprint that moves two texels per output: out[m][n] = sum_j sum_k S[2 m + j][k] *
+// T_j[k - 2 n], K = 44 source columns = two 32-column blocks per source row j. The weights at
+// fcoord = (1/2, 1/2) are symmetric in j (T_j = T_13-j, d/dx too, d/dy antisymmetric), so only rows
+// j < 7 are stored: frag f = 4 * (2 * j + kb) + {hi, lo, d/dx, d/dy}.
+#define PLH_MXD_NFRAG 56
+#define PLH_MXD_TAPS 14     // taps per axis, offsets -6 .. 7
 #define PLH_MX_NFRAG 36
 #define PLH_MX_DSHIFT 11
 #define PLH_MX_PAD 128      // dfx / dfy are padded to a multiple of this many outputs (the widest tile)
 struct plh_polar_mx {
-    int32_t enabled;
+    int32_t enabled;        // 1: the 2x upscale (k_polar_mx), 2: the 2 : 1 downscale (k_polar_mxd)
     int32_t org_x, org_y;   // source texel held by LDS tile (0, 0) of workgroup tile (0, 0)
     const void *bfrag;      // device: [PLH_MX_NFRAG][64 lanes][8] f16
     const float *dfx, *dfy; // device: phase deviation of every output column / row, x 2^PLH_MX_DSHIFT

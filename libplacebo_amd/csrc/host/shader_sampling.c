@@ -687,6 +687,12 @@ static bool mx_axis(const float *fc, const int32_t *base, const uint16_t *ids, i
     return true;
 }
 
+static bool polar_mxd_build(pl_gpu gpu, pl_log log, struct sh_sampler_obj *obj,
+                            const struct plh_pass *pass, const float *wall, const uint32_t *taps,
+                            int ntaps, int ncx, int ncy, const float *clsx, const float *clsy,
+                            const float *colfc, const int32_t *colbase,
+                            const float *rowfc, const int32_t *rowbase);
+
 // B fragments (plh_device.h): frag f = 4 * (py ? 4 + j : j) + kind, lane l, element e hold
 //   T(py, wy)[k][n] with n = l & 15, k = 8 * ((l >> 4) & 1) + e, wy = 2 j + (l >> 5) - cy(py),
 //   = w'(phase py, phase n & 1, tap (k - dbx[n] - 3, wy - 3)): kind 0 / 1 its hi / lo f16 halves,
@@ -1006,8 +1012,10 @@ static bool polar_pp_build(pl_gpu gpu, pl_log log, struct sh_sampler_obj *obj,
         tapoff[k] = (y * tx.extent + x) * (int) texel;
     }
     // the same geometry on the matrix pipe, where it has the shape for it
-    polar_mx_build(gpu, log, obj, pass, wall, taps_all, ntaps, ncx, ncy, clsx, clsy, colfc, colbase,
-                   idx, rowfc, rowbase, idy);
+    if (!polar_mx_build(gpu, log, obj, pass, wall, taps_all, ntaps, ncx, ncy, clsx, clsy, colfc, colbase,
+                        idx, rowfc, rowbase, idy))
+        polar_mxd_build(gpu, log, obj, pass, wall, taps_all, ntaps, ncx, ncy, clsx, clsy, colfc, colbase,
+                        rowfc, rowbase);
     free(taps_all);
     free(keep);
 
@@ -1115,9 +1123,175 @@ void plh_polar_pp_setup(pl_gpu gpu, pl_log log, void *polar_obj, struct plh_pass
         !pass->transpose && s->address_mode == PLH_ADDRESS_CLAMP) {
         s->mx = obj->mx_host;
         if (!obj->mx_announced)
-            pl_msg(log, PL_LOG_DEBUG, "polar on the matrix pipe (k_polar_mx)");
+            pl_msg(log, PL_LOG_DEBUG, "polar on the matrix pipe (%s)",
+                   s->mx.enabled == 2 ? "k_polar_mxd, where the pass has its shape" : "k_polar_mx");
         obj->mx_announced = true;
     }
+}
+
+
+/* ---- the 2 : 1 downscale on the matrix pipe ------------------------------------------------------ */
+
+// every output i has its base texel at base[0] + 2 i and a phase within `tol` of 1/2
+static bool mxd_axis(const float *fc, const int32_t *base, int len, float *dev)
+{
+    if (len < 2)
+        return false;
+    for (int i = 0; i < len; i++) {
+        if (base[i] != base[0] + 2 * i)
+            return false;
+        const float d = fabsf(fc[i] - 0.5f);
+        // (first-order expansion about 1/2: its neglected term is (d / a texel)^2 of a weight)
+        if (d > 4e-3f)
+            return false;
+        *dev = fmaxf(*dev, d);
+    }
+    return true;
+}
+
+// B fragments of k_polar_mxd (plh_device.h): frag f = 4 * (2 j + kb) + kind, lane l, element e hold
+//   T_j[i], i = 32 kb + k - 2 n, n = l & 15, k = 8 * (l >> 4) + e  (0 outside the 14 taps),
+// T_j[i] = the normalised weight w' of tap (i - 6, j - 6) at fcoord (1/2, 1/2) -- kind 0 / 1 its f16
+// hi / lo halves -- and kind 2 / 3 its derivative in fcoord_x / fcoord_y (least-squares slope over
+// the phase classes that occur) times 2^-PLH_MX_DSHIFT. Rows j and 13 - j are averaged (they agree
+// to rounding: the distance of a tap to the sample point is the same).
+static bool polar_mxd_build(pl_gpu gpu, pl_log log, struct sh_sampler_obj *obj,
+                            const struct plh_pass *pass, const float *wall, const uint32_t *taps,
+                            int ntaps, int ncx, int ncy, const float *clsx, const float *clsy,
+                            const float *colfc, const int32_t *colbase,
+                            const float *rowfc, const int32_t *rowbase)
+{
+    const struct plh_sampler_args *s = &pass->s;
+    const int W = pass->width, H = pass->height;
+    enum { NT = PLH_MXD_TAPS };
+    if (s->tile_fp32 || s->address_mode != PLH_ADDRESS_CLAMP || pass->transpose || s->src.w < 2 ||
+        s->antiring > 0)
+        return false;
+    float dev = 0.0f;
+    if (!mxd_axis(colfc, colbase, W, &dev) || !mxd_axis(rowfc, rowbase, H, &dev))
+        return false;
+    // the class pair at exactly (1/2, 1/2): the expansion point
+    int c0x = -1, c0y = -1;
+    for (int c = 0; c < ncx; c++)
+        c0x = clsx[c] == 0.5f ? c : c0x;
+    for (int c = 0; c < ncy; c++)
+        c0y = clsy[c] == 0.5f ? c : c0y;
+    if (c0x < 0 || c0y < 0) {
+        pl_msg(log, PL_LOG_DEBUG, "matrix-pipe downscale: no output at phase 1/2 exactly");
+        return false;
+    }
+    int tap_at[NT][NT];
+    for (int y = 0; y < NT; y++) {
+        for (int x = 0; x < NT; x++)
+            tap_at[y][x] = -1;
+    }
+    for (int t = 0; t < ntaps; t++) {
+        const int x = (int8_t) (taps[t] & 0xff), y = (int8_t) ((taps[t] >> 8) & 0xff);
+        if (x < -6 || x > 7 || y < -6 || y > 7)
+            return false;
+        tap_at[y + 6][x + 6] = t;
+    }
+#define WN(kx, ky, t) ((double) wall[((size_t) (ky) * ncx + (kx)) * (ntaps + 1) + (t)] * \
+                       (double) wall[((size_t) (ky) * ncx + (kx)) * (ntaps + 1) + ntaps])
+    double *sx = calloc(PL_MAX(ntaps, 1), sizeof(double)), *sy = calloc(PL_MAX(ntaps, 1), sizeof(double));
+    const size_t nfx = ((size_t) W + PLH_MX_PAD - 1) / PLH_MX_PAD * PLH_MX_PAD;
+    const size_t nfy = ((size_t) H + PLH_MX_PAD - 1) / PLH_MX_PAD * PLH_MX_PAD;
+    const size_t frag_bytes = (size_t) PLH_MXD_NFRAG * 64 * 8 * sizeof(uint16_t);
+    const size_t o_dfx = frag_bytes, o_dfy = o_dfx + nfx * 4, bytes = o_dfy + nfy * 4;
+    uint8_t *blob = calloc(1, bytes);
+    if (!sx || !sy || !blob) {
+        free(sx); free(sy); free(blob);
+        return false;
+    }
+    double den = 0.0;
+    for (int c = 0; c < ncx; c++) {
+        const double d = (double) clsx[c] - 0.5;
+        den += d * d;
+        for (int t = 0; t < ntaps; t++)
+            sx[t] += d * (WN(c, c0y, t) - WN(c0x, c0y, t));
+    }
+    for (int t = 0; t < ntaps; t++)
+        sx[t] = den > 0.0 ? sx[t] / den : 0.0;
+    den = 0.0;
+    for (int c = 0; c < ncy; c++) {
+        const double d = (double) clsy[c] - 0.5;
+        den += d * d;
+        for (int t = 0; t < ntaps; t++)
+            sy[t] += d * (WN(c0x, c, t) - WN(c0x, c0y, t));
+    }
+    for (int t = 0; t < ntaps; t++)
+        sy[t] = den > 0.0 ? sy[t] / den : 0.0;
+
+    uint16_t *frag = (uint16_t *) blob;
+    const double dscale = ldexp(1.0, -PLH_MX_DSHIFT);
+    double worst = 0.0, asym = 0.0;
+    for (int j = 0; j < NT / 2; j++) {
+        for (int kb = 0; kb < 2; kb++) {
+            for (int l = 0; l < 64; l++) {
+                const int n = l & 15;
+                for (int e = 0; e < 8; e++) {
+                    const int i = 32 * kb + 8 * (l >> 4) + e - 2 * n;
+                    double v = 0.0, vx = 0.0, vy = 0.0;
+                    if (i >= 0 && i < NT) {
+                        const int ta = tap_at[j][i], tb = tap_at[NT - 1 - j][i];
+                        if ((ta < 0) != (tb < 0)) {
+                            free(sx); free(sy); free(blob);
+                            return false;   // (a tap list that is not symmetric: not this filter)
+                        }
+                        if (ta >= 0) {
+                            const double wa = WN(c0x, c0y, ta), wb = WN(c0x, c0y, tb);
+                            asym = PL_MAX(asym, fabs(wa - wb));
+                            v = 0.5 * (wa + wb);
+                            vx = 0.5 * (sx[ta] + sx[tb]);
+                            vy = 0.5 * (sy[ta] - sy[tb]);
+                        }
+                    }
+                    const uint16_t hi = f32_to_f16((float) v);
+                    const uint16_t lo = f32_to_f16((float) (v - (double) f16_to_f32(hi)));
+                    worst = PL_MAX(worst, fabs(v - (double) f16_to_f32(hi) - (double) f16_to_f32(lo)));
+                    const size_t f = 4 * (size_t) (2 * j + kb);
+                    frag[((f + 0) * 64 + l) * 8 + e] = hi;
+                    frag[((f + 1) * 64 + l) * 8 + e] = lo;
+                    frag[((f + 2) * 64 + l) * 8 + e] = f32_to_f16((float) (vx * dscale));
+                    frag[((f + 3) * 64 + l) * 8 + e] = f32_to_f16((float) (vy * dscale));
+                }
+            }
+        }
+    }
+#undef WN
+    free(sx);
+    free(sy);
+    if (asym > 1e-7) {
+        pl_msg(log, PL_LOG_DEBUG, "matrix-pipe downscale: weights not symmetric about the sample "
+               "point (%.2e)", asym);
+        free(blob);
+        return false;
+    }
+    float *dfx = (float *) (blob + o_dfx), *dfy = (float *) (blob + o_dfy);
+    const float up = ldexpf(1.0f, PLH_MX_DSHIFT);
+    for (int i = 0; i < W; i++)
+        dfx[i] = (colfc[i] - 0.5f) * up;
+    for (int i = 0; i < H; i++)
+        dfy[i] = (rowfc[i] - 0.5f) * up;
+
+    pl_buf_destroy(gpu, &obj->mx_blob);
+    obj->mx_blob = pl_buf_create(gpu, pl_buf_params(.size = bytes, .storable = true,
+                                                    .initial_data = blob));
+    free(blob);
+    if (!obj->mx_blob)
+        return false;
+    const char *base = pl_hip_buf_ptr(obj->mx_blob);
+    obj->mx_host = (struct plh_polar_mx) {
+        .enabled = 2,
+        .org_x = colbase[0] - 6, .org_y = rowbase[0] - 6,
+        .bfrag = base,
+        .dfx = (const float *) (base + o_dfx), .dfy = (const float *) (base + o_dfy),
+    };
+    obj->mx_announced = false;
+    pl_msg(log, PL_LOG_DEBUG, "matrix-pipe tables for the polar pass: 2 : 1 downscale, one phase (1/2, 1/2), "
+           "per-pixel phases within %.2e: first-order terms; row symmetry %.1e, weight split error <= %.2e",
+           dev, asym, worst);
+    return true;
 }
 
 

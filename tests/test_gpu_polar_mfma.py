@@ -178,3 +178,28 @@ def test_mx_hdr_colour_map_epilogue():
     # identical or adjacent on the bulk
     assert np.quantile(d, 0.5) <= 1 and np.quantile(d, 0.99) <= 4 and d.max() <= 64
     assert np.array_equal(mx[..., 3], pp[..., 3])
+
+
+def ewa_down(**kw):
+    return pl.render_params("fast", downscaler=pl.filter_config("ewa_lanczos"), disable_linear_scaling=True, **kw)
+
+
+@pytest.mark.parametrize("size", [(128, 64), (300, 170), (2048, 1024), (3840, 2160)])
+def test_mxd_2to1_downscale_vs_reference_kernel(size):
+    """k_polar_mxd -- the widened EWA 2 : 1 downscale (148 taps) on the matrix pipe, rgba16hf source
+    to rgba16hf target, the pass of BASELINE configs[4] -- against k_polar_pp (bit-exact with the
+    oracle, test_gpu_fullsize.py): the results are fp32 sums in another order rounded to half
+    precision, so they are identical on the bulk and never more than one f16 ulp apart."""
+    dw, dh = size
+    rng = np.random.default_rng(11)
+    img = (0.05 + 0.9 * rng.random((2 * dh, 2 * dw, 4), dtype=np.float32)).astype(np.float16)
+    img[..., 3] = 1.0
+    mx = render(img, dw, dh, ewa_down(), True, src_fmt="rgba16hf", dst_fmt="rgba16hf", expect_mx=True)
+    pp = render(img, dw, dh, ewa_down(), False, src_fmt="rgba16hf", dst_fmt="rgba16hf", expect_mx=False)
+    assert np.array_equal(mx[..., 3], pp[..., 3])
+    a, b = mx[..., :3].view(np.uint16).astype(np.int64), pp[..., :3].view(np.uint16).astype(np.int64)
+    d = np.abs(a - b)       # (positive halves: the code distance is the ulp distance)
+    print("k_polar_mxd vs k_polar_pp %dx%d: %.4f of the samples differ, max %d f16 ulp"
+          % (dw, dh, (d > 0).mean(), d.max()))
+    assert d.max() <= 1 and (d > 0).mean() < 0.02, (int(d.max()), float((d > 0).mean()))
+    assert pp[..., :3].astype(np.float32).std() > 0.01
