@@ -57,19 +57,22 @@ void k_polar_mxd(const plh_pass p_)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int dbg = s.pp_debug;     // profiling aid: 1 = no contraction, 4 = no stores, 8 = no tile loads
 
-    // XCD x works on the x-th contiguous eighth of the tiles (k_polar_mx.hiph)
+    // Persistent workgroups, one per CU: the B fragments are loaded once, and the loads of the next
+    // tile are in flight (in registers) while this one is contracted. Workgroups go to the 8 XCDs
+    // round-robin and every XCD has its own L2: XCD x works on the x-th contiguous eighth of the
+    // tiles (row-major), its workgroups side by side on consecutive tiles -- neighbours share 12
+    // source rows / columns of halo.
     const int tiles_x = (p.width + MXD_TW - 1) / MXD_TW;
-    int bx, by;
+    const int tiles_y = (p.height + MXD_TH - 1) / MXD_TH;
+    int band_first, band_size, stride, first;
     {
-        const uint32_t total = gridDim.x, lin = blockIdx.x;
-        const uint32_t q = total >> 3, r = total & 7u;
-        const uint32_t xcd = lin & 7u, k = lin >> 3;
-        const uint32_t t = xcd * q + min(xcd, r) + k;
-        by = (int) (t / (uint32_t) tiles_x);
-        bx = (int) (t - (uint32_t) by * (uint32_t) tiles_x);
+        const uint32_t total = (uint32_t) tiles_x * (uint32_t) tiles_y, groups = gridDim.x, lin = blockIdx.x;
+        const uint32_t q = total >> 3, r = total & 7u, xcd = lin & 7u;
+        band_first = (int) (xcd * q + min(xcd, r));
+        band_size = (int) (q + (xcd < r ? 1u : 0u));
+        stride = (int) ((groups - xcd + 7u) >> 3);      // workgroups of this XCD
+        first = (int) (lin >> 3);
     }
-    const int ox = mx.org_x + 2 * MXD_TW * bx;      // source texel of LDS (0, 0)
-    const int oy = mx.org_y + 2 * MXD_TH * by;
 
     // ---- B fragments: global (L2 resident) -> LDS, one global_load_lds_dwordx4 per fragment -------
 #pragma unroll
@@ -78,7 +81,6 @@ void k_polar_mxd(const plh_pass p_)
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *) g,
                                          (__attribute__((address_space(3))) void *) (bl + f * 1024), 16, 0, 0);
     }
-
     // columns 140 .. 151 of every tile row (and 16 bytes behind the tile) are read by the last
     // column block, where they only meet zero weights: make them zeros, not whatever LDS held
     for (int i = tid; i < 3 * MXD_SRC_H; i += MXD_NT) {
@@ -90,34 +92,70 @@ void k_polar_mxd(const plh_pass p_)
     if (tid < 4)
         ((uint32_t *) (tile + 3 * MXD_PLANE))[tid] = 0;
 
-    // ---- source tile -> LDS: pairs of horizontally adjacent rgba16hf texels, one 16-byte load
-    // each, all issued together; the f16 codes move bit for bit into the channel planes ----------
-    {
-        int sw = s.src.w, sh = s.src.h, u_spitch = s.src.pitch;
-        uintptr_t u_sptr = (uintptr_t) s.src.ptr;
-        asm volatile("" : "+s"(sw), "+s"(sh), "+s"(u_spitch), "+s"(u_sptr));
-        const bool edge = ox < 0 || ox + MXD_SRC_W > sw;
-        uint4 v[MXD_NV];
-        int ty[MXD_NV], tp[MXD_NV], sx[MXD_NV];
+    int sw = s.src.w, sh = s.src.h, u_spitch = s.src.pitch;
+    uintptr_t u_sptr = (uintptr_t) s.src.ptr, u_dfx = (uintptr_t) mx.dfx, u_dfy = (uintptr_t) mx.dfy;
+    asm volatile("" : "+s"(sw), "+s"(sh), "+s"(u_spitch), "+s"(u_sptr), "+s"(u_dfx), "+s"(u_dfy));
+
+    // texel pair u of this lane: tile row, pair within the row (the same for every tile)
+    int ty[MXD_NV], tp[MXD_NV];
+#pragma unroll
+    for (int u = 0; u < MXD_NV; u++) {
+        const int i = min(tid + u * MXD_NT, MXD_NPAIRS - 1);
+        ty[u] = (int) (((float) i + 0.5f) * (1.0f / (float) MXD_HP));   // exact: i < 2^22
+        tp[u] = i - ty[u] * MXD_HP;
+    }
+    // the source tile of workgroup tile t: pairs of horizontally adjacent rgba16hf texels, one
+    // 16-byte load each, all issued together
+    const int ln = lane & 15, lg = lane >> 4;
+    const int wc = wave & 3, wr = wave >> 2;
+    // ... and with them the phase deviations of the lane's output column and four output rows:
+    // everything a tile needs from memory arrives together, one wait at the top of its turn
+    uint4 v[MXD_NV];
+    float nx_dfx, nx_dfy[4];
+    typedef __attribute__((address_space(1))) const float mxd_gfloat;
+    auto tile_load = [&](int t) {
+        const int by = (int) ((uint32_t) t / (uint32_t) tiles_x), bx = t - by * tiles_x;
+        const int ox = mx.org_x + 2 * MXD_TW * bx, oy = mx.org_y + 2 * MXD_TH * by;
 #pragma unroll
         for (int u = 0; u < MXD_NV; u++) {
-            const int i = min(tid + u * MXD_NT, MXD_NPAIRS - 1);
-            ty[u] = (int) (((float) i + 0.5f) * (1.0f / (float) MXD_HP));   // exact: i < 2^22
-            tp[u] = i - ty[u] * MXD_HP;
-            sx[u] = ox + 2 * tp[u];
             const int sy = min(max(oy + ty[u], 0), sh - 1);
-            const int px = min(max(sx[u], 0), sw - 2);
+            const int px = min(max(ox + 2 * tp[u], 0), sw - 2);
             const plh_u32x4 q = *(const __attribute__((address_space(1))) plh_u32x4 *)
                                     (u_sptr + (size_t) sy * (size_t) u_spitch + (size_t) px * 8);
-            v[u] = (dbg & 8) ? make_uint4(tid, u, 0, 0) : make_uint4(q.x, q.y, q.z, q.w);
+            v[u] = make_uint4(q.x, q.y, q.z, q.w);
         }
-        if (edge) {
+        nx_dfx = ((mxd_gfloat *) u_dfx)[MXD_TW * bx + 16 * wc + ln];
+#pragma unroll
+        for (int r = 0; r < 4; r++)
+            nx_dfy[r] = ((mxd_gfloat *) u_dfy)[MXD_TH * by + 16 * wr + 4 * lg + r];
+    };
+    // A fragment of lane l for source row offset j, column block kb: the 16 bytes at tile row
+    // 2 * (16 wr + ln) + j, column 32 wc + 32 kb + 8 lg
+    const unsigned char *ab = tile + (2 * (16 * wr + ln)) * MXD_PITCH + (32 * wc + 8 * lg) * 2;
+    const unsigned char *bfl = bl + lane * 16;
+
+    for (int u = 0; u < MXD_NV; u++)
+        v[u] = make_uint4(tid, u, 0, 0);
+    nx_dfx = 0.0f;
+    for (int r = 0; r < 4; r++)
+        nx_dfy[r] = 0.0f;
+    if (first < band_size && !(dbg & 8))
+        tile_load(band_first + first);
+#pragma unroll 1
+    for (int it = first; it < band_size; it += stride) {
+        const int t = band_first + it;
+        const int by = (int) ((uint32_t) t / (uint32_t) tiles_x), bx = t - by * tiles_x;
+        const int ox = mx.org_x + 2 * MXD_TW * bx;
+
+        // ---- registers -> LDS: the f16 codes move bit for bit into the channel planes ------------
+        if (ox < 0 || ox + MXD_SRC_W > sw) {
             // a pair at clamped positions: beyond the left edge both texels are the pair's first,
             // beyond the right edge both its second
 #pragma unroll
             for (int u = 0; u < MXD_NV; u++) {
                 const uint4 w = v[u];
-                const bool ldup = sx[u] < 0, hdup = sx[u] > sw - 2;
+                const int sx = ox + 2 * tp[u];
+                const bool ldup = sx < 0, hdup = sx > sw - 2;
                 const uint32_t ax = hdup ? w.z : w.x, ay = hdup ? w.w : w.y;
                 const uint32_t bx_ = ldup ? w.x : w.z, by_ = ldup ? w.y : w.w;
                 v[u] = make_uint4(ax, ay, bx_, by_);
@@ -133,76 +171,100 @@ void k_polar_mxd(const plh_pass p_)
                 *(uint32_t *) (d + 2 * MXD_PLANE) = (w.y & 0xffffu) | (w.w << 16);
             }
         }
-    }
 
-    // ---- the wave's 16 x 16 outputs ---------------------------------------------------------------
-    const int ln = lane & 15, lg = lane >> 4;
-    const int wc = wave & 3, wr = wave >> 2;
-    const int X = MXD_TW * bx + 16 * wc + ln;           // the lane's output column (B / D operand: n = ln)
-    const int Y0 = MXD_TH * by + 16 * wr + 4 * lg;      // its four output rows Y0 .. Y0 + 3 (D: m = 4 lg + r)
-    const _Float16 dxh = (_Float16) mx.dfx[X];
-    const mxd_f16x8 dx8 = { dxh, dxh, dxh, dxh, dxh, dxh, dxh, dxh };
-    float dfy[4];
+        // ---- the wave's 16 x 16 outputs ----------------------------------------------------------
+        const int X = MXD_TW * bx + 16 * wc + ln;           // the lane's output column (B / D operand: n = ln)
+        const int Y0 = MXD_TH * by + 16 * wr + 4 * lg;      // its four output rows Y0 .. Y0 + 3 (D: m = 4 lg + r)
+        const _Float16 dxh = (_Float16) nx_dfx;
+        const mxd_f16x8 dx8 = { dxh, dxh, dxh, dxh, dxh, dxh, dxh, dxh };
+        float dfy[4];
 #pragma unroll
-    for (int r = 0; r < 4; r++)
-        dfy[r] = mx.dfy[Y0 + r];
-    __syncthreads();
+        for (int r = 0; r < 4; r++)
+            dfy[r] = nx_dfy[r];
+        __syncthreads();
+        // the next tile's texels: asked for now, used after this tile's contraction
+        if (it + stride < band_size && !(dbg & 8))
+            tile_load(t + stride);
 
-    mxd_f32x4 acc[3], accy[3];
+        // Accumulators: per channel, one set for source rows j < 7 and one for their mirror rows
+        // 13 - j -- which share the B fragments, d/dy with the opposite sign (the epilogue subtracts)
+        // -- so that consecutive MFMAs never wait for each other's result. The fragments of the
+        // next (j, kb) step are read from LDS while this step's 18 MFMAs run.
+        mxd_f32x4 acc[2][3], accy[2][3];
 #pragma unroll
-    for (int ch = 0; ch < 3; ch++) {
-        acc[ch] = (mxd_f32x4) (0.0f);
-        accy[ch] = (mxd_f32x4) (0.0f);
-    }
-    // A fragment of lane l for source row offset j, column block kb: the 16 bytes at tile row
-    // 2 * (16 wr + ln) + j, column 32 wc + 32 kb + 8 lg
-    const unsigned char *ab = tile + (2 * (16 * wr + ln)) * MXD_PITCH + (32 * wc + 8 * lg) * 2;
-    const unsigned char *bfl = bl + lane * 16;
-    if (!(dbg & 1)) {
-#pragma unroll 1
-        for (int j = 0; j < PLH_MXD_TAPS / 2; j++) {
+        for (int h = 0; h < 2; h++) {
 #pragma unroll
-            for (int kb = 0; kb < 2; kb++) {
-                const unsigned char *bf = bfl + 4 * (2 * j + kb) * 1024;
-                const mxd_f16x8 bhi = *(const mxd_f16x8 *) bf;
-                // (the column-phase term rides on the lo half, k_polar_mx.hiph)
-                const mxd_f16x8 blo = *(const mxd_f16x8 *) (bf + 2048) * dx8 + *(const mxd_f16x8 *) (bf + 1024);
-                const mxd_f16x8 bdy = *(const mxd_f16x8 *) (bf + 3072);
-                const mxd_f16x8 bdn = -bdy;
-#pragma unroll
-                for (int half = 0; half < 2; half++) {
-                    // rows j and 13 - j share the weights; d/dy changes sign
-                    const int jj = half ? PLH_MXD_TAPS - 1 - j : j;
-                    const unsigned char *a0 = ab + jj * MXD_PITCH + 64 * kb;
-#pragma unroll
-                    for (int ch = 0; ch < 3; ch++) {
-                        const mxd_f16x8 a = *(const mxd_f16x8 *) (a0 + ch * MXD_PLANE);
-                        acc[ch] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, bhi, acc[ch], 0, 0, 0);
-                        acc[ch] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, blo, acc[ch], 0, 0, 0);
-                        accy[ch] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, half ? bdn : bdy, accy[ch], 0, 0, 0);
-                    }
-                }
+            for (int ch = 0; ch < 3; ch++) {
+                acc[h][ch] = (mxd_f32x4) (0.0f);
+                accy[h][ch] = (mxd_f32x4) (0.0f);
             }
         }
-    }
+        struct fragset { mxd_f16x8 bhi, blo, bdy, a[2][3]; };
+        auto read_frags = [&](fragset &f, int j, int kb) {
+            const unsigned char *bf = bfl + 4 * (2 * j + kb) * 1024;
+            f.bhi = *(const mxd_f16x8 *) bf;
+            // (the column-phase term rides on the lo half, k_polar_mx.hiph)
+            f.blo = *(const mxd_f16x8 *) (bf + 2048) * dx8 + *(const mxd_f16x8 *) (bf + 1024);
+            f.bdy = *(const mxd_f16x8 *) (bf + 3072);
+#pragma unroll
+            for (int h = 0; h < 2; h++) {
+                const unsigned char *a0 = ab + (h ? PLH_MXD_TAPS - 1 - j : j) * MXD_PITCH + 64 * kb;
+#pragma unroll
+                for (int ch = 0; ch < 3; ch++)
+                    f.a[h][ch] = *(const mxd_f16x8 *) (a0 + ch * MXD_PLANE);
+            }
+        };
+        auto contract = [&](const fragset &f) {
+#pragma unroll
+            for (int h = 0; h < 2; h++) {
+#pragma unroll
+                for (int ch = 0; ch < 3; ch++)
+                    acc[h][ch] = __builtin_amdgcn_mfma_f32_16x16x32_f16(f.a[h][ch], f.bhi, acc[h][ch], 0, 0, 0);
+            }
+#pragma unroll
+            for (int h = 0; h < 2; h++) {
+#pragma unroll
+                for (int ch = 0; ch < 3; ch++)
+                    accy[h][ch] = __builtin_amdgcn_mfma_f32_16x16x32_f16(f.a[h][ch], f.bdy, accy[h][ch], 0, 0, 0);
+            }
+#pragma unroll
+            for (int h = 0; h < 2; h++) {
+#pragma unroll
+                for (int ch = 0; ch < 3; ch++)
+                    acc[h][ch] = __builtin_amdgcn_mfma_f32_16x16x32_f16(f.a[h][ch], f.blo, acc[h][ch], 0, 0, 0);
+            }
+        };
+        if (!(dbg & 1)) {
+            fragset f0, f1;
+            read_frags(f0, 0, 0);
+#pragma unroll 1
+            for (int j = 0; j < PLH_MXD_TAPS / 2; j++) {
+                read_frags(f1, j, 1);
+                contract(f0);
+                read_frags(f0, min(j + 1, PLH_MXD_TAPS / 2 - 1), 0);    // (the last one is not used)
+                contract(f1);
+            }
+        }
 
-    // ---- epilogue: rgba16hf store, guarded (dispatch.c:1126-1142) --------------------------------
-    const int cpos = p.base_x + p.dir_x * X;
-    const bool cok = X < p.width && p.out_scale[0] * (float) X < 1.0f && cpos >= 0 && cpos < p.dst.w;
+        // ---- epilogue: rgba16hf store, guarded (dispatch.c:1126-1142) ----------------------------
+        const int cpos = p.base_x + p.dir_x * X;
+        const bool cok = X < p.width && p.out_scale[0] * (float) X < 1.0f && cpos >= 0 && cpos < p.dst.w;
 #pragma unroll
-    for (int r = 0; r < 4; r++) {
-        const int Y = Y0 + r;
-        const int rpos = p.base_y + p.dir_y * Y;
-        const bool ok = cok && Y < p.height && p.out_scale[1] * (float) Y < 1.0f && rpos >= 0 && rpos < p.dst.h;
-        float o[3];
+        for (int r = 0; r < 4; r++) {
+            const int Y = Y0 + r;
+            const int rpos = p.base_y + p.dir_y * Y;
+            const bool ok = cok && Y < p.height && p.out_scale[1] * (float) Y < 1.0f && rpos >= 0 && rpos < p.dst.h;
+            float o[3];
 #pragma unroll
-        for (int ch = 0; ch < 3; ch++)
-            o[ch] = __builtin_fmaf(dfy[r], accy[ch][r], acc[ch][r]);
-        plh_u32x2 px;
-        px.x = (uint32_t) plh_f2h(o[0]) | ((uint32_t) plh_f2h(o[1]) << 16);
-        px.y = (uint32_t) plh_f2h(o[2]) | 0x3c000000u;      // alpha = 1 (not sampled)
-        if (ok && !(dbg & 4))
-            *(plh_u32x2 *) ((char *) p.dst.ptr + (size_t) rpos * p.dst.pitch + (size_t) cpos * 8) = px;
+            for (int ch = 0; ch < 3; ch++)
+                o[ch] = __builtin_fmaf(dfy[r], accy[0][ch][r] - accy[1][ch][r], acc[0][ch][r] + acc[1][ch][r]);
+            plh_u32x2 px;
+            px.x = (uint32_t) plh_f2h(o[0]) | ((uint32_t) plh_f2h(o[1]) << 16);
+            px.y = (uint32_t) plh_f2h(o[2]) | 0x3c000000u;      // alpha = 1 (not sampled)
+            if (ok && !(dbg & 4))
+                *(plh_u32x2 *) ((char *) p.dst.ptr + (size_t) rpos * p.dst.pitch + (size_t) cpos * 8) = px;
+        }
+        __syncthreads();    // (everyone is done with this tile before the next one overwrites it)
     }
 }
 
@@ -232,7 +294,12 @@ int plh_launch_polar_mxd(hipStream_t stream, const plh_pass *pass)
     const int tiles_y = (pass->height + MXD_TH - 1) / MXD_TH;
     const size_t shmem = MXD_B_BYTES + (size_t) 3 * MXD_PLANE + 16;
     (void) hipFuncSetAttribute((const void *) k_polar_mxd, hipFuncAttributeMaxDynamicSharedMemorySize, (int) shmem);
-    hipLaunchKernelGGL(k_polar_mxd, dim3(tiles_x * tiles_y), dim3(MXD_NT), shmem, stream, *pass);
+    // one persistent workgroup per CU (LDS: 124 KiB each)
+    int dev = 0, cus = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0)
+        cus = 256;
+    const int groups = tiles_x * tiles_y < cus ? tiles_x * tiles_y : cus;
+    hipLaunchKernelGGL(k_polar_mxd, dim3(groups), dim3(MXD_NT), shmem, stream, *pass);
     const hipError_t err = hipGetLastError();
     return err == hipSuccess ? 0 : -(int) err;
 }
