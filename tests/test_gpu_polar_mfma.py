@@ -203,3 +203,22 @@ def test_mxd_2to1_downscale_vs_reference_kernel(size):
           % (dw, dh, (d > 0).mean(), d.max()))
     assert d.max() <= 1 and (d > 0).mean() < 0.02, (int(d.max()), float((d > 0).mean()))
     assert pp[..., :3].astype(np.float32).std() > 0.01
+
+
+def test_mxd_cropped_source_and_clipped_tiles():
+    """a source rectangle that starts inside the plane (even and odd offsets: the tile's texel
+    pairs are then unaligned) and an output whose size is no multiple of the 64 x 32 tile; a
+    fractional offset has other phases than 1/2 and must stay on k_polar_pp"""
+    dw, dh = 200, 90
+    rng = np.random.default_rng(12)
+    img = (0.05 + 0.9 * rng.random((2 * dh + 40, 2 * dw + 40, 4), dtype=np.float32)).astype(np.float16)
+    img[..., 3] = 1.0
+    for x0, y0, expect in ((2, 4, True), (7, 13, True), (2.5, 4.0, False)):
+        kw = dict(image_kw=dict(crop=(x0, y0, x0 + 2 * dw, y0 + 2 * dh)))
+        mx = render(img, dw, dh, ewa_down(), True, src_fmt="rgba16hf", dst_fmt="rgba16hf", **kw)
+        pp = render(img, dw, dh, ewa_down(), False, src_fmt="rgba16hf", dst_fmt="rgba16hf", **kw)
+        d = np.abs(mx[..., :3].view(np.uint16).astype(np.int64) - pp[..., :3].view(np.uint16).astype(np.int64))
+        if expect:
+            assert 0 < (d > 0).mean() < 0.02 and d.max() <= 1, (x0, y0, int(d.max()), float((d > 0).mean()))
+        else:
+            assert d.max() == 0, (x0, y0)
