@@ -111,8 +111,8 @@ class Stream:
     # (tests/test_gpu_async_measure.py, tests/test_gpu_metric.py). It is the library's default
     # (PL_HIP_DEFAULTS, as async_compute is pl_vulkan_params' default) and therefore what `value`
     # times; the JSON line carries the same workload with the option off as a companion
-    # ("single_stream"). Per-kernel times (roofline, passes_us) are taken with the frames kept
-    # apart, so that a kernel's duration is its own.
+    # ("single_stream"). Per-kernel times (roofline, passes_us) are taken on a one-stream instance
+    # (measure_passes), so that a kernel's duration is its own.
     async_measure = True
 
     def __init__(self, device, workload, pool, async_measure=None):
@@ -120,6 +120,7 @@ class Stream:
         self.async_on = bool(on)
         self.g = pl.HipGpu(device, async_measure=self.async_on)
         self.rr = pl.Renderer(self.g)
+        self.device = device
         self.workload = workload
         (sw, sh), (dw, dh), _, _ = WORKLOADS[workload]
         frame = synthetic_frame(workload, sw, sh)
@@ -321,19 +322,28 @@ def relabel(label, traced):
 
 def measure_passes(st, frames=48):
     """per-pass GPU time: HIP events recorded around every launch on the stream the launches go
-    to (pl_timer), reported through pl_render_params.info_callback. With async_measure the frames
-    are kept apart here (pl_gpu_finish after each): a kernel's duration is its own, not that of two
-    kernels of neighbouring frames sharing the CUs -- the overlap shows in `value`, not here."""
+    to (pl_timer), reported through pl_render_params.info_callback, frames back to back as in the
+    timed loop. With async_measure two kernels of neighbouring frames share the CUs there, so the
+    passes are timed on a second, one-stream instance of the same workload: a kernel's duration is
+    then its own, at the clocks of a busy GPU (frames kept apart by a sync instead measure 5-8 %
+    short of what a kernel trace of the loop shows) -- the overlap shows in `value`, not here."""
+    own = None
+    if st.async_on:
+        own = st = Stream(st.device, st.workload, st.pool, async_measure=False)
+        for _ in range(8):
+            st.step()
+        st.g.finish()
     st.params.info_callback = C.cast(st._cb, C.c_void_p)
     st.pass_ns.clear()
     for _ in range(frames):
         st.step()
-        if st.async_on:
-            st.g.finish()
     st.g.finish()
     st.step()           # drains the last timers
     st.g.finish()
-    return {k: float(np.mean(v)) for k, v in st.pass_ns.items() if v}
+    passes = {k: float(np.mean(v)) for k, v in st.pass_ns.items() if v}
+    if own:
+        own.close()
+    return passes
 
 
 def roofline_block(workload, passes):
