@@ -214,9 +214,11 @@ static void plh_pass_choose_cells(struct plh_pass *pass)
 
 // PL_DITHER_WHITE_NOISE is recorded as (i1 = 2, i0 = seed). The kernels only know dither
 // matrices: now that the size of the pass is known, evaluate the PRNG for its fragment
-// coordinates into the corner of a power-of-two square and turn the op into a plain LUT
-// dither over it (k_noise.hip says why).
-static bool realize_white_noise(pl_gpu gpu, pl_buf *noise, struct plh_pass *pass)
+// coordinates into a plane whose row stride is a power of two (the matrix lookup wraps x and y
+// with one mask; rows beyond the pass' height are never addressed, so they are not allocated:
+// 4096 x 2160 floats for a 4K pass) and turn the op into a plain LUT dither over it (k_noise.hip
+// says why). Generated on `stream`, the stream the pass itself is launched on.
+static bool realize_white_noise(pl_gpu gpu, plh_stream stream, pl_buf *noise, struct plh_pass *pass)
 {
     for (int i = 0; i < pass->num_ops; i++) {
         struct plh_op *op = &pass->ops[i];
@@ -225,14 +227,14 @@ static bool realize_white_noise(pl_gpu gpu, pl_buf *noise, struct plh_pass *pass
         int side = 16;
         while (side < pass->width || side < pass->height)
             side <<= 1;
-        const size_t size = (size_t) side * side * sizeof(float);
+        const size_t size = (size_t) side * pass->height * sizeof(float);
         if (!*noise || (*noise)->params.size < size) {
             pl_buf_destroy(gpu, noise);
             *noise = pl_buf_create(gpu, pl_buf_params(.size = size, .storable = true));
             if (!*noise)
                 return false;
         }
-        if (plh_launch_white_noise(plh_gpu_stream(gpu), pl_hip_buf_ptr(*noise), side,
+        if (plh_launch_white_noise(stream, pl_hip_buf_ptr(*noise), side,
                                    pass->width, pass->height, pass->frag_x0, pass->frag_y0,
                                    (uint32_t) op->i0))
             return false;
@@ -266,11 +268,10 @@ int plh_pass_execute(pl_gpu gpu, pl_log log, const struct plh_pass_exec *x, pl_t
     if (pass->s.type == PLH_SAMPLE_POLAR && x->polar_obj)
         plh_polar_pp_setup(gpu, log, x->polar_obj, pass);
     plh_pass_choose_cells(pass);
-    if (!realize_white_noise(gpu, noise, pass)) {
-        return -1005;
-    }
     // which stream (gpu_hip.c "two streams"); every call here is a no-op in one-stream mode
     const int on = x->on_aux && plh_gpu_async(gpu) && !plh_gpu_has_peak_exchange(gpu);
+    if (!realize_white_noise(gpu, plh_gpu_stream_n(gpu, on), noise, pass))
+        return -1005;
     if (on)
         plh_gpu_order_after(gpu, 1, x->aux_after);
     const uint64_t seq = plh_tex_order(gpu, on, x->src_tex, target);
@@ -408,7 +409,7 @@ bool pl_dispatch_compute(pl_dispatch dp, const struct pl_dispatch_compute_params
         pass->transpose = 0;
         pass->frag_x0 = pass->frag_y0 = 0;
         plh_pass_choose_cells(pass);
-        if (!realize_white_noise(dp->gpu, &dp->noise, pass))
+        if (!realize_white_noise(dp->gpu, plh_gpu_stream(dp->gpu), &dp->noise, pass))
             goto done;
         if (timer)
             plh_timer_begin(dp->gpu, timer, 0);
