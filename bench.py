@@ -340,7 +340,15 @@ def measure_passes(st, frames=48):
     st.g.finish()
     st.step()           # drains the last timers
     st.g.finish()
-    passes = {k: float(np.mean(v)) for k, v in st.pass_ns.items() if v}
+    # (a pass' description carries the tone curve's knee values, which move while the measured
+    # peak converges: one pass, one entry, under its last name)
+    import re
+    merged, names = {}, {}
+    for k, v in st.pass_ns.items():
+        key = re.sub(r"\(\d+ -> \d+\)", "(*)", k)
+        merged.setdefault(key, []).extend(v)
+        names[key] = k
+    passes = {names[k]: float(np.mean(v)) for k, v in merged.items() if v}
     if own:
         own.close()
     return passes
