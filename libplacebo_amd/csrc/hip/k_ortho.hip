@@ -181,7 +181,8 @@ void k_ortho(const plh_pass p_)
  *   - weights: the two LUT rows bracketing fcoord as 16-byte loads (rows are 16-byte aligned)
  *   - all texel loads of both pixels in flight before the first fma
  *   - EPI 0: no colour ops; 1: fused epilogue (fastepi.hiph) -> rgba16; 2 / 3: LITE / full op
- *     interpreter (3 = pl_render_default_params: unsigmoidize + delinearize + dither)
+ *     interpreter; 4: the map chain (struct plh_map_chain) + fused epilogue as straight-line code
+ *     (pl_render_default_params: unsigmoidize + delinearize + dither)
  */
 // SRC = the source's plh format: the 8-byte RGBA formats (plane / FBO of packed frames) and the
 // one- / two-component planes of planar video (their passes carry no colour ops: EPI 0 only)
@@ -303,7 +304,7 @@ void k_ortho_fast(const plh_pass p_)
 
     // (the dither values are requested now, not after the convolution: one round trip less)
     float bias[2] = { 0.0f, 0.0f };
-    if constexpr (EPI == 1) {
+    if constexpr (EPI == 1 || EPI == 4) {
         if (p.epi.has_dither) {
 #pragma unroll
             for (int q = 0; q < 2; q++) {
@@ -414,7 +415,11 @@ void k_ortho_fast(const plh_pass p_)
         ok[q] = p.out_scale[0] * (float) idx < 1.0f && p.out_scale[1] * (float) idy < 1.0f &&
                 sx[q] >= 0 && sy[q] >= 0 && sx[q] < p.dst.w && sy[q] < p.dst.h;
     }
-    if constexpr (EPI == 1) {
+    if constexpr (EPI == 1 || EPI == 4) {
+        // EPI 4: the recorded chain in front of the fused epilogue as straight-line code
+        // (struct plh_map_chain: the default preset's unsigmoidize + delinearize, an HDR map)
+        if constexpr (EPI == 4)
+            run_map_chain<2>(outs, p);
 #pragma unroll
         for (int q = 0; q < 2; q++) {
             float4_t &o = outs[q];
@@ -470,6 +475,7 @@ static void launch_ortho_fast(hipStream_t stream, const plh_pass *pass, int epi)
         if (epi == 0)      LAUNCH(0);
         else if (epi == 1) LAUNCH(1);
         else if (epi == 2) LAUNCH(2);
+        else if (epi == 4) LAUNCH(4);
         else               LAUNCH(3);
     } else {
         LAUNCH(0);      // plane passes: no colour ops (ortho_fast_variant)
@@ -527,6 +533,9 @@ static int ortho_fast_variant(plh_pass *pass)
     plh_match_fast_epilogue(pass, true);
     if (pass->epi.enabled)
         return 1;
+    plh_match_map_chain(pass);
+    if (pass->chain.enabled)
+        return 4;
     for (int i = 0; i < pass->num_ops; i++) {
         const int k = pass->ops[i].kind;
         if (k == PLH_OP_PEAK_DETECT || k == PLH_OP_MIX_ADD)

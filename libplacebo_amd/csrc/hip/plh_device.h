@@ -251,17 +251,20 @@ struct plh_fast_epi {
     float alpha;
 };
 
-// The recorded post-ops of an HDR map pass have one shape (pl_shader_color_map_ex between the
-// scaler and the encoder, renderer.c:2935-3040):
-//   [LINEARIZE] RGB2IPT [TONE_MAP] [GAMUT_LUT] IPT2RGB [DELINEARIZE]  + the fused epilogue above.
-// Kernels with a CHAIN variant run exactly these device functions as straight-line code -- op
-// indices here, -1 = absent -- instead of walking the interpreter, whose register budget is that
-// of its largest op: the same arithmetic in the same order (bit-identical), 14 % fewer
+// The recorded post-ops of the renderer's final passes have one shape (the colour management
+// between the scaler and the encoder, renderer.c:2935-3040):
+//   [UNSIGMOIDIZE] [LINEARIZE] [RGB2IPT [TONE_MAP] [GAMUT_LUT] IPT2RGB] [DELINEARIZE] [SIGMOIDIZE]
+//   + the fused epilogue above
+// -- the HDR map pass (LINEARIZE .. DELINEARIZE), the SDR presets' last scaler pass (UNSIGMOIDIZE
+// DELINEARIZE). Kernels with a CHAIN variant run exactly these device functions as straight-line
+// code -- op indices here, -1 = absent -- instead of walking the interpreter, whose register budget
+// is that of its largest op: the same arithmetic in the same order (bit-identical), 14 % fewer
 // instructions and half the registers. Filled by the launchers (fastepi.hiph).
 struct plh_map_chain {
     int32_t enabled;
     int32_t lin, in, tone, gamut, out, delin;
     int32_t contrast_recovery;  // the tone op reads a feature map (its i2 != 0)
+    int32_t unsig, sig;
 };
 
 struct plh_pass {

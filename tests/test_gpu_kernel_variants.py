@@ -518,3 +518,19 @@ def test_features_pass_equals_generic(gpu, size):
             outs.append(dst.download())
             rr.destroy(); src.destroy(); dst.destroy()
     assert np.array_equal(outs[0], outs[1]) and outs[0][..., :3].std() > 1000
+
+
+@pytest.mark.parametrize("scaler", ["lanczos", "ewa_lanczos", "mitchell"])
+@pytest.mark.parametrize("size", [(90, 62), (256, 130)])
+def test_sdr_chain_equals_interpreter(gpu, scaler, size):
+    """pl_render_default_params on an SDR frame: the last scaler pass carries UNSIGMOIDIZE +
+    DELINEARIZE + dither + scale -- the chain without a colour map (k_ortho_fast EPI 4, the CHAIN
+    epilogue of k_polar_mx) against the op interpreter (PL_HIP_MAP_CHAIN=0): bit-identical."""
+    sw, sh = size
+    img = util.chirp_rgba16(sw, sh)
+    params = pl.render_params("default", upscaler=pl.filter_config(scaler))
+    outs = []
+    for chain in ("1", "0"):
+        with _env("PL_HIP_MAP_CHAIN", chain), _env("PL_HIP_POLAR_MFMA", "1"):
+            outs.append(render(gpu, img, 2 * sw, 2 * sh, params, True, {}))
+    assert np.array_equal(outs[0], outs[1]) and outs[0][..., :3].std() > 1000
