@@ -579,7 +579,7 @@ void k_pass_native(const plh_pass p_)
 #ifndef CHAIN_NP
 #define CHAIN_NP 2
 #endif
-template <bool F16SRC, int NP, bool CR>
+template <bool F16SRC, int NP, bool CR, bool F16DST = false>
 __global__ __launch_bounds__(PASS_BW * PASS_BH)
 void k_pass_chain(const plh_pass p_)
 {
@@ -635,6 +635,12 @@ void k_pass_chain(const plh_pass p_)
     uint32_t o[2 * NP];
 #pragma unroll
     for (int i = 0; i < NP; i++) {
+        if (F16DST) {
+            // an rgba16hf intermediate: no epilogue (plh_match_map_chain)
+            o[2 * i] = (uint32_t) plh_f2h(c[i].x) | ((uint32_t) plh_f2h(c[i].y) << 16);
+            o[2 * i + 1] = (uint32_t) plh_f2h(c[i].z) | ((uint32_t) plh_f2h(c[i].w) << 16);
+            continue;
+        }
         if (e.has_dither) {
             const float b = bias[i], ds = e.dscale, di = e.dinv;
             c[i] = { __builtin_floorf(ds * c[i].x + b) * di, __builtin_floorf(ds * c[i].y + b) * di,
@@ -893,8 +899,16 @@ extern "C" int plh_launch_pass(plh_stream stream_, const struct plh_pass *pass)
 
     if (pass_native_applies(pass)) {
         plh_pass local = *pass;
-        plh_match_map_chain(&local, true);
-        if (local.chain.enabled) {
+        plh_match_map_chain(&local, true, true, true);
+        if (local.chain.enabled && local.dst.fmt == PLH_FMT_RGBA16F && !local.chain.contrast_recovery) {
+            const dim3 block(PASS_BW, PASS_BH);
+            const int cells_w = (local.width + CHAIN_NP - 1) / CHAIN_NP;
+            const dim3 grid((cells_w + PASS_BW - 1) / PASS_BW, (local.height + PASS_BH - 1) / PASS_BH);
+            if (local.s.src.fmt == PLH_FMT_RGBA16F)
+                hipLaunchKernelGGL((k_pass_chain<true, CHAIN_NP, false, true>), grid, block, 0, stream, local);
+            else
+                hipLaunchKernelGGL((k_pass_chain<false, CHAIN_NP, false, true>), grid, block, 0, stream, local);
+        } else if (local.chain.enabled && local.dst.fmt == PLH_FMT_RGBA16) {
             const dim3 block(PASS_BW, PASS_BH);
             const int cells_w = (local.width + CHAIN_NP - 1) / CHAIN_NP;
             const dim3 grid((cells_w + PASS_BW - 1) / PASS_BW, (local.height + PASS_BH - 1) / PASS_BH);

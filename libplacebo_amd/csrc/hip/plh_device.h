@@ -253,10 +253,10 @@ struct plh_fast_epi {
 
 // The recorded post-ops of the renderer's final passes have one shape (the colour management
 // between the scaler and the encoder, renderer.c:2935-3040):
-//   [UNSIGMOIDIZE] [LINEARIZE] [RGB2IPT [TONE_MAP] [GAMUT_LUT] IPT2RGB] [DELINEARIZE] [SIGMOIDIZE]
-//   + the fused epilogue above
+//   [PLANE_MAP] [UNSIGMOIDIZE] [LINEARIZE] [RGB2IPT [TONE_MAP] [GAMUT_LUT] IPT2RGB] [DELINEARIZE]
+//   [SIGMOIDIZE] + the fused epilogue above (rgba16 target) or nothing (rgba16hf intermediate)
 // -- the HDR map pass (LINEARIZE .. DELINEARIZE), the SDR presets' last scaler pass (UNSIGMOIDIZE
-// DELINEARIZE). Kernels with a CHAIN variant run exactly these device functions as straight-line
+// DELINEARIZE) and their first pass (PLANE_MAP LINEARIZE SIGMOIDIZE into the intermediate). Kernels with a CHAIN variant run exactly these device functions as straight-line
 // code -- op indices here, -1 = absent -- instead of walking the interpreter, whose register budget
 // is that of its largest op: the same arithmetic in the same order (bit-identical), 14 % fewer
 // instructions and half the registers. Filled by the launchers (fastepi.hiph).
@@ -265,6 +265,7 @@ struct plh_map_chain {
     int32_t lin, in, tone, gamut, out, delin;
     int32_t contrast_recovery;  // the tone op reads a feature map (its i2 != 0)
     int32_t unsig, sig;
+    int32_t pmap;               // a leading identity PLANE_MAP (missing components := neutral)
 };
 
 struct plh_pass {
