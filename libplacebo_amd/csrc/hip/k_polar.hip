@@ -334,7 +334,11 @@ int plh_launch_polar(hipStream_t stream, const plh_pass *pass_in)
             plh_match_fast_epilogue(&local);
         return plh_launch_polar_mx(stream, pass);
     }
-    plh_match_fast_epilogue(&local);
+    // the phase-class kernels have a CHAIN variant for RGB / RGBA tiles (k_polar_pp.hiph)
+    if (pass->s.pp && (cm == 0x7 || cm == 0xf))
+        plh_match_map_chain(&local);
+    if (!local.chain.enabled)
+        plh_match_fast_epilogue(&local);
     if (pass->s.pp && (cm == 0x7 || cm == 0xf || cm == 0x1 || cm == 0x3)) {
         const int n = pass->s.pp_n, cw = pass->s.pp_cells_w, ch = pass->s.pp_cells_h;
         const int cth = POLAR_BH * pass->s.tile_rows;

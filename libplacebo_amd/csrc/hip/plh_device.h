@@ -266,6 +266,7 @@ struct plh_map_chain {
     int32_t contrast_recovery;  // the tone op reads a feature map (its i2 != 0)
     int32_t unsig, sig;
     int32_t pmap;               // a leading identity PLANE_MAP (missing components := neutral)
+    int32_t tail;               // first op of the fused epilogue
 };
 
 struct plh_pass {

@@ -534,3 +534,36 @@ def test_sdr_chain_equals_interpreter(gpu, scaler, size):
         with _env("PL_HIP_MAP_CHAIN", chain), _env("PL_HIP_POLAR_MFMA", "1"):
             outs.append(render(gpu, img, 2 * sw, 2 * sh, params, True, {}))
     assert np.array_equal(outs[0], outs[1]) and outs[0][..., :3].std() > 1000
+
+
+@pytest.mark.parametrize("case", ["hdr_2x", "hdr_1.5x", "sdr_default_1.5x", "hdr_rgba_2x"])
+def test_polar_pp_chain_equals_interpreter(gpu, case):
+    """The CHAIN variant of the phase-class polar kernel (k_polar_pp: every EWA geometry that is not
+    on the matrix pipe, and the bit-exact variant of those that are) against its full-interpreter
+    variant (PL_HIP_MAP_CHAIN=0): the HDR colour map behind a 2x and a 1.5x upscale, the default
+    preset's unsigmoidize + delinearize behind a 1.5x one, sampled alpha. Bit-identical."""
+    from test_gpu_fullsize import hdr_frame16
+    sw, sh = 120, 70
+    hdr = case.startswith("hdr")
+    img = hdr_frame16(sw, sh) if hdr else util.chirp_rgba16(sw, sh)
+    scale = 2.0 if "2x" in case else 1.5
+    dw, dh = int(sw * scale), int(sh * scale)
+    kw = dict(upscaler=pl.filter_config("ewa_lanczos"))
+    if hdr:
+        kw["peak_detect_params"] = pl.peak_detect_params(percentile=99.995)
+    params = pl.render_params("default", **kw)
+    outs = []
+    for chain in ("1", "0"):
+        with _env("PL_HIP_MAP_CHAIN", chain), _env("PL_HIP_POLAR_MFMA", "0"):
+            src = gpu.tex_create(sw, sh, "rgba16", img)
+            dst = gpu.tex_create(dw, dh, "rgba16")
+            rr = pl.Renderer(gpu)
+            util.srand(1)
+            ikw = dict(color=pl.color_space("bt2020", "pq", max_luma=1000.0)) if hdr else {}
+            tkw = dict(color=pl.color_space("bt709", "bt1886")) if hdr else {}
+            assert rr.render(pl.frame(src, components=4 if "rgba" in case else 3, **ikw),
+                             pl.frame(dst, repr_=pl.color_repr("rgb", "full", **TEN_BIT), **tkw), params)
+            assert rr.errors() == 0
+            outs.append(dst.download())
+            rr.destroy(); src.destroy(); dst.destroy()
+    assert np.array_equal(outs[0], outs[1]) and outs[0][..., :3].std() > 1000

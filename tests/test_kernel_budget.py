@@ -32,8 +32,9 @@ def usage(built):
 
 # The one tolerated spill: the matrix-pipe polar kernel with the colour map in its epilogue is held
 # to 128 registers (4 waves per SIMD: worth 183 -> 172 us) and parks three dwords once per wave
-# tile, before the contraction, outside every loop body.
-TOLERATED_SPILL = {"k_polar_mx<3, true, 2, 8>": 16}
+# tile, before the contraction, outside every loop body. Likewise the CHAIN variant of the
+# phase-class polar kernel on RGB f16 tiles (129 registers held to 128: 4 waves per SIMD).
+TOLERATED_SPILL = {"k_polar_mx<3, true, 2, 8>": 16, "k_polar_pp<__half, 7u, 2, true, true, true>": 12}
 
 
 def test_no_kernel_spills(usage):
@@ -44,11 +45,11 @@ def test_no_kernel_spills(usage):
 # (pattern, minimum waves per SIMD)
 BUDGET = [
     # LITE polar variants on the f16 tile (scaler + dither: BASELINE configs[2]): 4 waves
-    (r"k_polar_pp<__half, (7|15)u, [12], true, (true|false)>", 4),
-    (r"k_polar_pp<__half, (1|3)u, [12], true, (true|false)>", 4),
+    (r"k_polar_pp<__half, (7|15)u, [12], true, (true|false), (true|false)>", 4),
+    (r"k_polar_pp<__half, (1|3)u, [12], true, (true|false), false>", 4),
     # with the full colour interpreter (the metric's EWA + tone-map launch): 3 waves
-    (r"k_polar_pp<__half, \d+u, [12], false, false>", 3),
-    (r"k_polar_pp<float, \d+u, 1, false, false>", 3),
+    (r"k_polar_pp<__half, \d+u, [12], false, false, false>", 3),
+    (r"k_polar_pp<float, \d+u, 1, false, false, false>", 3),
     # the matrix-pipe polar kernel (exact 2x upscales): 8-wave tiles at 4 waves per SIMD for the
     # fast epilogue and for the colour map (RGB); 4-wave tiles at 3 otherwise
     (r"k_polar_mx<3, true, (0|2|3|4), 8>", 4),
