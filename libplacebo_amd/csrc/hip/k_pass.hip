@@ -710,6 +710,125 @@ void k_pass_features(const plh_pass p_)
         *(uint16_t *) d = (uint16_t) o[0];
 }
 
+/*
+ * k_pass_merge: the pass that assembles a planar frame (renderer.c:1874-1920: the reference plane
+ * sampled texel for texel, the other planes -- already scaled to its size -- fetched at the same
+ * position, YCbCr -> RGB, and whatever colour management follows) without the interpreter:
+ *   PLANE_MAP, one or two PLANE_FETCH, [AFFINE], [the map chain], then the fused epilogue into
+ *   rgba16 or a plain store into an rgba16hf intermediate.
+ * The device functions of the interpreter's cases, in its order: bit-identical. Any source format
+ * (plh_fetch); two horizontally adjacent pixels per lane.
+ */
+struct plh_merge { int32_t pmap, fetch0, fetch1, affine; };
+
+template <bool F16DST>
+__global__ __launch_bounds__(PASS_BW * PASS_BH)
+void k_pass_merge(const plh_pass p_, const plh_merge m)
+{
+    const plh_pass &p = plh_kernarg_pass();
+    const plh_sampler_args &s = p.s;
+    constexpr int NP = 2;
+    const int x0 = NP * (blockIdx.x * PASS_BW + threadIdx.x);
+    const int y = blockIdx.y * PASS_BH + threadIdx.y;
+    if (x0 >= p.width || y >= p.height)
+        return;
+    const bool all = x0 + 1 < p.width;
+    const plh_fast_epi &e = p.epi;
+    float bias[NP];
+#pragma unroll
+    for (int i = 0; i < NP; i++) {
+        const int ix = (x0 + i + p.frag_x0) & e.mask, iy = (y + p.frag_y0) & e.mask;
+        bias[i] = !F16DST && e.has_dither ? e.matrix[iy * e.size + ix] : 0.0f;
+    }
+    float4_t c[NP];
+    const float my = p.out_scale[1] * ((float) y + 0.5f);
+#pragma unroll
+    for (int i = 0; i < NP; i++) {
+        const int x = all ? x0 + i : x0;
+        c[i] = plh_fetch(s.src, x, y);
+        if (s.scale != 1.0f)
+            c[i] = scale4(c[i], s.scale);
+        const float mx = p.out_scale[0] * ((float) x + 0.5f);
+        if (m.pmap >= 0)
+            op_plane_map(c[i], p.ops[m.pmap]);
+        op_plane_fetch(c[i], p.ops[m.fetch0], mx, my);
+        if (m.fetch1 >= 0)
+            op_plane_fetch(c[i], p.ops[m.fetch1], mx, my);
+        if (m.affine >= 0)
+            op_affine(c[i], p.ops[m.affine].f);
+    }
+    if (p.chain.enabled)
+        run_map_chain<NP>(c, p);
+    uint32_t o[2 * NP];
+#pragma unroll
+    for (int i = 0; i < NP; i++) {
+        if (F16DST) {
+            o[2 * i] = (uint32_t) plh_f2h(c[i].x) | ((uint32_t) plh_f2h(c[i].y) << 16);
+            o[2 * i + 1] = (uint32_t) plh_f2h(c[i].z) | ((uint32_t) plh_f2h(c[i].w) << 16);
+            continue;
+        }
+        if (e.has_dither) {
+            const float b = bias[i], ds = e.dscale, di = e.dinv;
+            c[i] = { __builtin_floorf(ds * c[i].x + b) * di, __builtin_floorf(ds * c[i].y + b) * di,
+                     __builtin_floorf(ds * c[i].z + b) * di, __builtin_floorf(ds * c[i].w + b) * di };
+        }
+        if (e.has_scale)
+            c[i] = scale4(c[i], e.scale);
+        o[2 * i] = plh_unorm16x2(c[i].x, c[i].y);
+        o[2 * i + 1] = plh_unorm16x2(c[i].z, c[i].w);
+    }
+    char *d = (char *) p.dst.ptr + (size_t) y * p.dst.pitch + (size_t) x0 * 8;
+    if (all) {
+        const plh_u32x4 pk = { o[0], o[1], o[2], o[3] };
+        if (p.nt_store)
+            __builtin_nontemporal_store(pk, (plh_u32x4 *) d);
+        else
+            *(plh_u32x4 *) d = pk;
+    } else {
+        *(uint2 *) d = make_uint2(o[0], o[1]);
+    }
+}
+
+// Is this the merge pass k_pass_merge is written for? Fills `m`, pass->chain and pass->epi.
+static bool pass_merge_applies(plh_pass *pass, plh_merge *m)
+{
+    const plh_sampler_args &s = pass->s;
+    const char *env = getenv("PL_HIP_PASS_NATIVE");
+    if (env && env[0] == '0')
+        return false;
+    const bool native = pass->width == s.src.w && pass->height == s.src.h &&
+        s.pos[0][0] == 0.0f && s.pos[0][1] == 0.0f && s.pos[3][0] == 1.0f && s.pos[3][1] == 1.0f &&
+        s.pos[1][0] == 1.0f && s.pos[1][1] == 0.0f && s.pos[2][0] == 0.0f && s.pos[2][1] == 1.0f;
+    if (!native || s.type != PLH_SAMPLE_NEAREST || s.address_mode != PLH_ADDRESS_CLAMP ||
+        pass->transpose || pass->num_pre_ops || pass->base_x || pass->base_y || pass->dir_x != 1 ||
+        pass->dir_y != 1 || pass->dst.w < pass->width || pass->dst.h < pass->height ||
+        (pass->dst.fmt != PLH_FMT_RGBA16 && pass->dst.fmt != PLH_FMT_RGBA16F))
+        return false;
+    const int n = pass->num_ops;
+    int i = 0;
+    *m = plh_merge{ -1, -1, -1, -1 };
+    if (i < n && pass->ops[i].kind == PLH_OP_PLANE_MAP)
+        m->pmap = i++;
+    if (!(i < n && pass->ops[i].kind == PLH_OP_PLANE_FETCH))
+        return false;
+    m->fetch0 = i++;
+    if (i < n && pass->ops[i].kind == PLH_OP_PLANE_FETCH)
+        m->fetch1 = i++;
+    if (i < n && pass->ops[i].kind == PLH_OP_AFFINE)
+        m->affine = i++;
+    pass->chain = plh_map_chain{ 0, -1, -1, -1, -1, -1, -1, 0, -1, -1, -1, 0 };
+    pass->epi = plh_fast_epi{};
+    if (i == n)
+        return pass->dst.fmt == PLH_FMT_RGBA16F;    // (an rgba16 target stores through the epilogue)
+    plh_match_map_chain(pass, false, false, true, i);
+    if (pass->chain.enabled)
+        return true;
+    if (pass->dst.fmt != PLH_FMT_RGBA16)
+        return false;
+    plh_match_fast_epilogue(pass, false, i);
+    return pass->epi.enabled;
+}
+
 // the shape k_pass_native is written for
 static bool pass_native_applies(const plh_pass *pass, bool features = false)
 {
@@ -881,6 +1000,21 @@ extern "C" int plh_launch_pass(plh_stream stream_, const struct plh_pass *pass)
                 launch_bilinear_fast<true>(stream, &local, iters);
             else
                 launch_bilinear_fast<false>(stream, &local, iters);
+            const hipError_t err = hipGetLastError();
+            return err == hipSuccess ? 0 : -(int) err;
+        }
+    }
+
+    {
+        plh_pass local = *pass;
+        plh_merge m;
+        if (pass_merge_applies(&local, &m)) {
+            const dim3 block(PASS_BW, PASS_BH);
+            const dim3 grid(((local.width + 1) / 2 + PASS_BW - 1) / PASS_BW, (local.height + PASS_BH - 1) / PASS_BH);
+            if (local.dst.fmt == PLH_FMT_RGBA16F)
+                hipLaunchKernelGGL(k_pass_merge<true>, grid, block, 0, stream, local, m);
+            else
+                hipLaunchKernelGGL(k_pass_merge<false>, grid, block, 0, stream, local, m);
             const hipError_t err = hipGetLastError();
             return err == hipSuccess ? 0 : -(int) err;
         }

@@ -567,3 +567,33 @@ def test_polar_pp_chain_equals_interpreter(gpu, case):
             outs.append(dst.download())
             rr.destroy(); src.destroy(); dst.destroy()
     assert np.array_equal(outs[0], outs[1]) and outs[0][..., :3].std() > 1000
+
+
+@pytest.mark.parametrize("preset", ["fast", "default", "high_quality"])
+@pytest.mark.parametrize("semi,bits,sub", [(True, 8, (2, 2)), (False, 8, (2, 2)), (True, 16, (2, 1))])
+def test_merge_pass_equals_generic(gpu, preset, semi, bits, sub):
+    """k_pass_merge (the pass that assembles a planar frame: reference plane + fetched planes + YCbCr
+    matrix + the preset's linearize / sigmoidize, odd widths included) against k_pass_generic
+    (PL_HIP_PASS_NATIVE=0), NV12 / I420 / P216-style input through three presets: bit-identical."""
+    from test_gpu_renderer import planar_frame
+    w, h = 66, 46
+    outs = []
+    for native in ("1", "0"):
+        with _env("PL_HIP_PASS_NATIVE", native):
+            f, texs, _ = planar_frame(gpu, w, h, seed=5, sub=sub, bits=bits, semi=semi)
+            f.repr = pl.color_repr("bt709", "limited", sample_depth=bits, color_depth=bits)
+            f.color = pl.color_space("bt709", "bt1886")
+            pl.lib().pl_frame_set_chroma_location.argtypes = [C.POINTER(capi.Frame), C.c_int]
+            pl.lib().pl_frame_set_chroma_location(C.byref(f), 1)
+            dst = gpu.tex_create(2 * w, 2 * h, "rgba16")
+            rr = pl.Renderer(gpu)
+            util.srand(1)
+            assert rr.render(f, pl.frame(dst, repr_=pl.color_repr("rgb", "full", **TEN_BIT),
+                                         color=pl.color_space("bt709", "bt1886")),
+                             pl.render_params(preset, deband_params=None)), gpu.messages[-4:]
+            assert rr.errors() == 0
+            outs.append(dst.download())
+            rr.destroy(); dst.destroy()
+            for t in texs:
+                t.destroy()
+    assert np.array_equal(outs[0], outs[1]) and outs[0][..., :3].std() > 1000
