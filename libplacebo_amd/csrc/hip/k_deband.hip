@@ -195,8 +195,10 @@ void k_deband_fast(const plh_pass p_)
 #pragma unroll
             for (int k = 0; k < 4; k++) {
                 const float qx = px + s.pt[0] * ox[k], qy = py + s.pt[1] * oy[k];
-                const int tx = min(max((int) __builtin_floorf(qx * sw), 0), srcw - 1);
-                const int ty = min(max((int) __builtin_floorf(qy * sh), 0), srch - 1);
+                // (clamp(floor(v), 0, n - 1): the conversion truncates toward zero, which differs
+                // from floor only for negative v -- where both end up clamped to 0)
+                const int tx = min(max((int) (qx * sw), 0), srcw - 1);
+                const int ty = min(max((int) (qy * sh), 0), srch - 1);
                 raw[k] = *(const uint2 *) (sp + (uint32_t) ty * spitch + (uint32_t) tx * 8u);
             }
             float avg[3] = {0.0f, 0.0f, 0.0f};
