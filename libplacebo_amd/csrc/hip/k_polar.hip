@@ -275,7 +275,7 @@ int plh_launch_polar_pp_f32_c12(hipStream_t stream, const plh_pass *pass, dim3 g
                                 size_t shmem, int n);
 // k_polar_mx.hip
 int plh_launch_polar_mx(hipStream_t stream, const plh_pass *pass);
-bool plh_polar_mxd_applies(const plh_pass *pass);
+bool plh_polar_mxd_applies(plh_pass *pass);
 int plh_launch_polar_mxd(hipStream_t stream, const plh_pass *pass);
 
 int plh_launch_polar_classify(plh_stream stream, const plh_pass *pass, void *out)
@@ -324,7 +324,7 @@ int plh_launch_polar(hipStream_t stream, const plh_pass *pass_in)
     const plh_pass *pass = &local;
     const dim3 block(POLAR_BW, POLAR_BH);
     const uint32_t cm = pass->s.comp_mask & 0xf;
-    if (pass->s.pp && plh_polar_mxd_applies(pass))
+    if (pass->s.pp && plh_polar_mxd_applies(&local))
         return plh_launch_polar_mxd(stream, pass);     // the 2 : 1 downscale on the matrix pipe
     if (pass->s.pp && pass->s.mx.enabled == 1 && (cm == 0x7 || cm == 0xf)) {
         // (the matrix-pipe kernel has a variant for the map chain of an HDR pass)

@@ -24,9 +24,9 @@
  * of 16 lanes + the 16-byte column step fall on distinct bank groups: conflict-free
  * ds_read_b128). LDS 56 + 67.7 KiB: one workgroup per CU, 2 waves per SIMD with the whole
  * register file. Per wave: 14 x 2 x (3 A reads + 9 MFMAs) + 56 B reads = 252 v_mfma_f32_16x16x32_f16.
- * This first version handles what BASELINE configs[4] runs: an rgba16hf source without fused
- * pre-ops (or behind an identity PLANE_MAP), RGB, no post-ops, an rgba16hf target; everything else
- * stays on k_polar_pp.
+ * Handled: an rgba16hf (BASELINE configs[4]) or rgba16 source without fused pre-ops or behind an
+ * identity PLANE_MAP, RGB; an rgba16hf target without post-ops, or an rgba16 target behind the fused
+ * epilogue (dither + scale); everything else stays on k_polar_pp.
  */
 #include "polar_common.hiph"
 
@@ -45,6 +45,10 @@
 typedef _Float16 mxd_f16x8 __attribute__((ext_vector_type(8)));
 typedef float mxd_f32x4 __attribute__((ext_vector_type(4)));
 
+// UNORM: an rgba16 source (decoded and rounded to f16 while staged: the reference's rgba16hf
+// intermediate, fused) instead of an rgba16hf one; F16DST: an rgba16hf target, else rgba16 through
+// the fused epilogue (dither + scale, fastepi.hiph).
+template <bool UNORM, bool F16DST>
 __global__ __launch_bounds__(MXD_NT)
 void k_polar_mxd(const plh_pass p_)
 {
@@ -166,9 +170,24 @@ void k_polar_mxd(const plh_pass p_)
             const uint4 w = v[u];
             if (tid + u * MXD_NT < MXD_NPAIRS) {
                 unsigned char *d = tile + ty[u] * MXD_PITCH + tp[u] * 4;
-                *(uint32_t *) d = (w.x & 0xffffu) | (w.z << 16);
-                *(uint32_t *) (d + MXD_PLANE) = (w.x >> 16) | (w.z & 0xffff0000u);
-                *(uint32_t *) (d + 2 * MXD_PLANE) = (w.y & 0xffffu) | (w.w << 16);
+                if (UNORM) {
+                    // decode to fp32, THEN round to f16 (what the rgba16hf store + load of the unfused
+                    // pass does). The two roundings are kept apart on purpose: left alone the compiler
+                    // folds the last fma of the decode into v_fma_mixlo_f16, which rounds once -- one
+                    // f16 ulp off for the codes whose fp32 value is a tie (65519 -> 1 - 2^-12).
+                    float t[6] = { plh_un16(w.x & 0xffffu), plh_un16(w.z & 0xffffu), plh_un16(w.x >> 16),
+                                   plh_un16(w.z >> 16), plh_un16(w.y & 0xffffu), plh_un16(w.w & 0xffffu) };
+#pragma unroll
+                    for (int k = 0; k < 6; k++)
+                        asm volatile("" : "+v"(t[k]));
+                    *(uint32_t *) d = (uint32_t) plh_f2h(t[0]) | ((uint32_t) plh_f2h(t[1]) << 16);
+                    *(uint32_t *) (d + MXD_PLANE) = (uint32_t) plh_f2h(t[2]) | ((uint32_t) plh_f2h(t[3]) << 16);
+                    *(uint32_t *) (d + 2 * MXD_PLANE) = (uint32_t) plh_f2h(t[4]) | ((uint32_t) plh_f2h(t[5]) << 16);
+                } else {
+                    *(uint32_t *) d = (w.x & 0xffffu) | (w.z << 16);
+                    *(uint32_t *) (d + MXD_PLANE) = (w.x >> 16) | (w.z & 0xffff0000u);
+                    *(uint32_t *) (d + 2 * MXD_PLANE) = (w.y & 0xffffu) | (w.w << 16);
+                }
             }
         }
 
@@ -259,8 +278,29 @@ void k_polar_mxd(const plh_pass p_)
             for (int ch = 0; ch < 3; ch++)
                 o[ch] = __builtin_fmaf(dfy[r], accy[0][ch][r] - accy[1][ch][r], acc[0][ch][r] + acc[1][ch][r]);
             plh_u32x2 px;
-            px.x = (uint32_t) plh_f2h(o[0]) | ((uint32_t) plh_f2h(o[1]) << 16);
-            px.y = (uint32_t) plh_f2h(o[2]) | 0x3c000000u;      // alpha = 1 (not sampled)
+            if (F16DST) {
+                px.x = (uint32_t) plh_f2h(o[0]) | ((uint32_t) plh_f2h(o[1]) << 16);
+                px.y = (uint32_t) plh_f2h(o[2]) | 0x3c000000u;      // alpha = 1 (not sampled)
+            } else {
+                // op_dither (plain path) and the SCALE op, as k_polar_mx's fast epilogue
+                float a = 1.0f;
+                if (p.epi.has_dither) {
+                    const int ix = (X + p.frag_x0) & p.epi.mask, iy = (Y + p.frag_y0) & p.epi.mask;
+                    const float b = p.epi.matrix[iy * p.epi.size + ix], ds = p.epi.dscale, di = p.epi.dinv;
+#pragma unroll
+                    for (int ch = 0; ch < 3; ch++)
+                        o[ch] = __builtin_floorf(ds * o[ch] + b) * di;
+                    a = __builtin_floorf(ds * a + b) * di;
+                }
+                if (p.epi.has_scale) {
+#pragma unroll
+                    for (int ch = 0; ch < 3; ch++)
+                        o[ch] *= p.epi.scale;
+                    a *= p.epi.scale;
+                }
+                px.x = plh_unorm16x2(o[0], o[1]);
+                px.y = plh_unorm16x2(o[2], a);
+            }
             if (ok && !(dbg & 4))
                 *(plh_u32x2 *) ((char *) p.dst.ptr + (size_t) rpos * p.dst.pitch + (size_t) cpos * 8) = px;
         }
@@ -268,24 +308,37 @@ void k_polar_mxd(const plh_pass p_)
     }
 }
 
-// the pass k_polar_mxd is written for (file header)
-bool plh_polar_mxd_applies(const plh_pass *pass)
+// the pass k_polar_mxd is written for (file header); fills pass->epi for an rgba16 target
+bool plh_polar_mxd_applies(plh_pass *pass)
 {
     const plh_sampler_args &s = pass->s;
-    // (a fused identity PLANE_MAP of a plane that carries r, g, b changes none of them; nor does a
-    // SCALE by exactly one, which is what encoding into a float target records)
-    bool plain = pass->num_pre_ops <= 1 && pass->num_ops - pass->num_pre_ops <= 1;
+    if (s.mx.enabled != 2 || (s.comp_mask & 0xf) != 0x7 || pass->transpose ||
+        (s.src.fmt != PLH_FMT_RGBA16F && s.src.fmt != PLH_FMT_RGBA16))
+        return false;
+    // pre-ops: none, or a fused identity PLANE_MAP of a plane that carries r, g, b (changes none)
+    if (pass->num_pre_ops > 1)
+        return false;
     if (pass->num_pre_ops == 1) {
         const plh_op &op = pass->ops[0];
-        plain = plain && op.kind == PLH_OP_PLANE_MAP && op.i2 && op.i1 >= 3;
+        if (op.kind != PLH_OP_PLANE_MAP || !op.i2 || op.i1 < 3)
+            return false;
     }
-    if (pass->num_ops > pass->num_pre_ops) {
-        const plh_op &op = pass->ops[pass->num_pre_ops];
-        plain = plain && op.kind == PLH_OP_SCALE && op.f[0] == 1.0f && op.f[1] == 1.0f && op.f[2] == 1.0f &&
-                op.f[3] == 1.0f;
+    if (pass->dst.fmt == PLH_FMT_RGBA16F) {
+        // post-ops: none, or a SCALE by exactly one (what encoding into a float target records)
+        const int post = pass->num_ops - pass->num_pre_ops;
+        if (post > 1)
+            return false;
+        if (post == 1) {
+            const plh_op &op = pass->ops[pass->num_pre_ops];
+            if (op.kind != PLH_OP_SCALE || op.f[0] != 1.0f || op.f[1] != 1.0f || op.f[2] != 1.0f || op.f[3] != 1.0f)
+                return false;
+        }
+        return true;
     }
-    return s.mx.enabled == 2 && (s.comp_mask & 0xf) == 0x7 && s.src.fmt == PLH_FMT_RGBA16F &&
-           pass->dst.fmt == PLH_FMT_RGBA16F && plain && !pass->transpose;
+    if (pass->dst.fmt != PLH_FMT_RGBA16)
+        return false;
+    plh_match_fast_epilogue(pass);      // [DITHER] [SCALE] -> rgba16
+    return pass->epi.enabled && !pass->epi.has_alpha;
 }
 
 int plh_launch_polar_mxd(hipStream_t stream, const plh_pass *pass)
@@ -293,13 +346,21 @@ int plh_launch_polar_mxd(hipStream_t stream, const plh_pass *pass)
     const int tiles_x = (pass->width + MXD_TW - 1) / MXD_TW;
     const int tiles_y = (pass->height + MXD_TH - 1) / MXD_TH;
     const size_t shmem = MXD_B_BYTES + (size_t) 3 * MXD_PLANE + 16;
-    (void) hipFuncSetAttribute((const void *) k_polar_mxd, hipFuncAttributeMaxDynamicSharedMemorySize, (int) shmem);
     // one persistent workgroup per CU (LDS: 124 KiB each)
     int dev = 0, cus = 0;
     if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0)
         cus = 256;
     const int groups = tiles_x * tiles_y < cus ? tiles_x * tiles_y : cus;
-    hipLaunchKernelGGL(k_polar_mxd, dim3(groups), dim3(MXD_NT), shmem, stream, *pass);
+    const bool unorm = pass->s.src.fmt == PLH_FMT_RGBA16, f16dst = pass->dst.fmt == PLH_FMT_RGBA16F;
+#define MXD_LAUNCH(U, F) do { \
+        (void) hipFuncSetAttribute((const void *) k_polar_mxd<U, F>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) shmem); \
+        hipLaunchKernelGGL((k_polar_mxd<U, F>), dim3(groups), dim3(MXD_NT), shmem, stream, *pass); \
+    } while (0)
+    if (unorm && f16dst)  MXD_LAUNCH(true, true);
+    else if (unorm)       MXD_LAUNCH(true, false);
+    else if (f16dst)      MXD_LAUNCH(false, true);
+    else                  MXD_LAUNCH(false, false);
+#undef MXD_LAUNCH
     const hipError_t err = hipGetLastError();
     return err == hipSuccess ? 0 : -(int) err;
 }

@@ -222,3 +222,26 @@ def test_mxd_cropped_source_and_clipped_tiles():
             assert 0 < (d > 0).mean() < 0.02 and d.max() <= 1, (x0, y0, int(d.max()), float((d > 0).mean()))
         else:
             assert d.max() == 0, (x0, y0)
+
+
+@pytest.mark.parametrize("size", [(200, 90), (1920, 1080)])
+def test_mxd_unorm_source_and_rgba16_target(size):
+    """The other variants of k_polar_mxd: an rgba16 source (decoded and rounded to f16 while it is
+    staged = the fused PASS A) and an rgba16 target behind the fused epilogue, 16-bit and 10-bit
+    dithered -- the plain SDR 2 : 1 EWA downscale (4K -> 1080p) -- against k_polar_pp: never more
+    than one code / one 10-bit step apart, identical on the bulk."""
+    dw, dh = size
+    img = util.random_rgba16(2 * dw, 2 * dh, seed=5)
+    q_mx = render(img, dw, dh, ewa_down(), True, expect_mx=True)
+    q_pp = render(img, dw, dh, ewa_down(), False, expect_mx=False)
+    frac = assert_codes(q_mx, q_pp)
+    f_mx = render(img, dw, dh, ewa_down(), True, dst_fmt="rgba16hf", expect_mx=True)
+    f_pp = render(img, dw, dh, ewa_down(), False, dst_fmt="rgba16hf")
+    d = np.abs(f_mx[..., :3].view(np.uint16).astype(np.int64) - f_pp[..., :3].view(np.uint16).astype(np.int64))
+    assert d.max() <= 1 and (d > 0).mean() < 0.02
+    d_mx = render(img, dw, dh, ewa_down(**dither10()), True, ten_bit=True, expect_mx=True)
+    d_pp = render(img, dw, dh, ewa_down(**dither10()), False, ten_bit=True)
+    assert np.all((d_mx & 63 == 0) | (d_mx == 65535))
+    frac10 = assert_codes(d_mx >> 6, d_pp >> 6, step=1, max_frac=0.004)
+    print("k_polar_mxd rgba16 -> rgba16 %dx%d: %.4f of the 16-bit samples one code apart; 10-bit dithered: %.5f"
+          % (dw, dh, frac, frac10))

@@ -59,7 +59,7 @@ BUDGET = [
     (r"k_polar_mx<4, true, [01], 4>", 3),
     (r"k_polar_mx<4, (true|false), 2, 4>", 2),
     # the 2 : 1 downscale on the matrix pipe: one persistent workgroup per CU, 2 waves per SIMD
-    (r"k_polar_mxd", 2),
+    (r"k_polar_mxd<(true|false), (true|false)>", 2),
     (r"k_bilinear_fast<(true|false), 4, (true|false)>", 4),
     (r"k_nearest_fast<(true|false)>", 8),
     (r"k_pass_generic<.*>", 4),
