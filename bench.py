@@ -81,6 +81,8 @@ WORKLOADS = {
     "nv12_1080p_to_4k_default_preset": (P1080, P4K, px(P1080) * 3 // 2 + px(P4K) * 8, "ortho"),
     # pl_render_default_params as shipped: lanczos in linear, sigmoidized light + dither
     "default_preset_1080p_to_4k": (P1080, P4K, px(P1080) * 8 + px(P4K) * 8, "ortho"),
+    # the plain SDR downscale: 4K -> 1080p EWA (widened, 148 taps), 10-bit dither, one launch
+    "ewa_lanczos_4k_to_1080p_dither10": (P4K, P1080, px(P4K) * 8 + px(P1080) * 8, "polar"),
     "hdr10_4k_tonemap": (P4K, P4K, 3 * px(P4K) * 8, "tone map"),
     "ewa_8k_to_4k_deband_tonemap": (P8K, P4K, px(P8K) * 8 + px(P4K) * 8, "polar"),
     # the metric's two halves in one frame: 1080p HDR10 -> EWA 2x upscale -> tone map -> 4K SDR
@@ -153,6 +155,11 @@ class Stream:
         elif workload == "ewa_lanczos_1080p_to_4k_dither10":
             self.params = pl.render_params("fast", upscaler=pl.filter_config("ewa_lanczos"),
                                            dither_params=dither,
+                                           disable_dither_gamma_correction=True)
+            icsp, tcsp, trepr = sdr, sdr, ten_bit
+        elif workload == "ewa_lanczos_4k_to_1080p_dither10":
+            self.params = pl.render_params("fast", downscaler=pl.filter_config("ewa_lanczos"),
+                                           dither_params=dither, disable_linear_scaling=True,
                                            disable_dither_gamma_correction=True)
             icsp, tcsp, trepr = sdr, sdr, ten_bit
         elif workload == "lanczos_1080p_to_4k_dither10":
