@@ -343,8 +343,7 @@ void k_peak_fast(const plh_pass p_)
             c[2 * k + i] = t;
         }
     }
-    peak_measure(c, o_pk, hists[wave], wg_idx, p.peak_scratch);
-
+    // (the intermediate goes out first: its stores are in flight while the measurement computes)
     if constexpr (STORE) {
 #pragma unroll
         for (int k = 0; k < 2; k++) {
@@ -365,6 +364,7 @@ void k_peak_fast(const plh_pass p_)
                 *(uint2 *) d = make_uint2(o[0], o[1]);
         }
     }
+    peak_measure(c, o_pk, hists[wave], wg_idx, p.peak_scratch);
 }
 
 // the shape k_peak_fast is written for
