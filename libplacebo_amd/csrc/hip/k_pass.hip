@@ -577,7 +577,7 @@ void k_pass_native(const plh_pass p_)
  * Bit-identical to k_pass_native / k_pass_generic on such a pass; NP pixels per lane.
  */
 #ifndef CHAIN_NP
-#define CHAIN_NP 2
+#define CHAIN_NP 1      // (one pixel per lane: 101.5 us against 104.0 with two on configs[3]'s map pass)
 #endif
 template <bool F16SRC, int NP, bool CR, bool F16DST = false>
 __global__ __launch_bounds__(PASS_BW * PASS_BH)

@@ -68,8 +68,8 @@ BUDGET = [
     # the map chain as straight-line code: all 8 wave slots (7 with contrast recovery compiled in)
     (r"k_pass_features<(true|false)>", 8),
     (r"k_pass_merge<(true|false)>.*", 8),
-    (r"k_pass_chain<(true|false), 2, false, (true|false)>", 8),
-    (r"k_pass_chain<(true|false), 2, true, false>", 7),
+    (r"k_pass_chain<(true|false), 1, false, (true|false)>", 8),
+    (r"k_pass_chain<(true|false), 1, true, false>", 8),
     (r"k_peak_fast<(true|false), (true|false)>", 8),
     (r"k_pass_peak<true>", 4),
     (r"k_pass_peak<false>", 3),
