@@ -1108,3 +1108,40 @@ extern "C" int plh_launch_pass(plh_stream stream_, const struct plh_pass *pass)
     const hipError_t err = hipGetLastError();
     return err == hipSuccess ? 0 : -(int) err;
 }
+
+// Test hook (tests/test_chain_match.py, CPU): plh_match_map_chain on an op list described by its
+// kinds and one flag word per op -- TONE_MAP: 1 = contrast recovery; GAMUT_LUT: 1 = tricubic;
+// PLANE_MAP: 1 = not an identity mapping; DITHER: 1 = not the plain LUT path; SCALE: 1 = not uniform.
+extern "C" __attribute__((visibility("default")))
+int plh_test_match_chain(const int *kinds, const int *flags, int n, int num_pre, int dst_fmt, int transpose,
+                         int allow_cr, int allow_plane_map, int allow_f16_dst, int *out)
+{
+    static plh_pass pass;   // (2.5 KB)
+    pass = plh_pass{};
+    if (n > PLH_MAX_OPS)
+        return -1;
+    pass.num_ops = n;
+    pass.num_pre_ops = num_pre;
+    pass.dst.fmt = dst_fmt;
+    pass.transpose = transpose;
+    for (int i = 0; i < n; i++) {
+        plh_op &op = pass.ops[i];
+        op.kind = kinds[i];
+        switch (kinds[i]) {
+        case PLH_OP_TONE_MAP:   op.i2 = flags[i] ? 0x100010 : 0; break;
+        case PLH_OP_GAMUT_LUT:  op.f[3] = flags[i] ? 1.0f : 0.0f; break;
+        case PLH_OP_PLANE_MAP:  op.i2 = !flags[i]; op.i1 = 3; op.f[3] = 1.0f; break;
+        case PLH_OP_DITHER:     op.i0 = 64; op.i1 = flags[i] ? 1 : 0; op.f[0] = 1023.0f; op.f[1] = 1.0f;
+                                op.f[3] = 10.0f; op.f[8] = 1.0f / 1023.0f; break;
+        case PLH_OP_SCALE:      op.f[0] = op.f[1] = op.f[2] = 0.5f; op.f[3] = flags[i] ? 0.25f : 0.5f; break;
+        default: break;
+        }
+    }
+    plh_match_map_chain(&pass, allow_cr != 0, allow_plane_map != 0, allow_f16_dst != 0);
+    const plh_map_chain &c = pass.chain;
+    const int v[15] = { c.enabled, c.lin, c.in, c.tone, c.gamut, c.out, c.delin, c.contrast_recovery, c.unsig, c.sig,
+                        c.pmap, c.tail, pass.epi.enabled, pass.epi.has_dither, pass.epi.has_scale };
+    for (int i = 0; i < 15; i++)
+        out[i] = v[i];
+    return c.enabled;
+}
