@@ -57,11 +57,29 @@ PL_API extern const struct pl_filter_function pl_filter_function_spline16;
 PL_API extern const struct pl_filter_function pl_filter_function_spline36;
 PL_API extern const struct pl_filter_function pl_filter_function_spline64;
 PL_API extern const struct pl_filter_function pl_filter_function_oversample;
+// named members of the cubic family, kept as objects of their own by the reference's older
+// configuration API (filters.h:142-147; the configs pl_filter_bicubic ... supersede them)
+PL_DEPRECATED_IN(v6.341) PL_API extern const struct pl_filter_function pl_filter_function_bicubic;
+PL_DEPRECATED_IN(v6.341) PL_API extern const struct pl_filter_function pl_filter_function_bcspline;
+PL_DEPRECATED_IN(v6.341) PL_API extern const struct pl_filter_function pl_filter_function_catmull_rom;
+PL_DEPRECATED_IN(v6.341) PL_API extern const struct pl_filter_function pl_filter_function_mitchell;
+PL_DEPRECATED_IN(v6.341) PL_API extern const struct pl_filter_function pl_filter_function_robidoux;
+PL_DEPRECATED_IN(v6.341) PL_API extern const struct pl_filter_function pl_filter_function_robidouxsharp;
 
 // NULL-terminated list of all functions, and lookup by name.
 PL_API extern const struct pl_filter_function * const pl_filter_functions[];
 PL_API extern const int pl_num_filter_functions;
 PL_API const struct pl_filter_function *pl_find_filter_function(const char *name);
+
+// The older name -> function table (filters.h:175-185): how applications written against the
+// previous configuration API select a kernel / window by name. {0}-terminated; "none" -> NULL.
+struct pl_filter_function_preset {
+    const char *name;
+    const struct pl_filter_function *function;
+};
+PL_API extern const struct pl_filter_function_preset pl_filter_function_presets[];
+PL_API extern const int pl_num_filter_function_presets; // excluding the trailing {0}
+PL_API const struct pl_filter_function_preset *pl_find_filter_function_preset(const char *name);
 
 enum pl_filter_usage {
     PL_FILTER_UPSCALING    = (1 << 0),
@@ -130,6 +148,18 @@ PL_API extern const struct pl_filter_config * const pl_filter_configs[];
 PL_API extern const int pl_num_filter_configs;
 PL_API const struct pl_filter_config *
 pl_find_filter_config(const char *name, enum pl_filter_usage usage);
+
+// The older name -> config table (filters.h:316-329): what mpv / vf_libplacebo style option
+// parsers call to select "ewa_lanczos" by name. {0}-terminated; "none" -> NULL filter (built-in
+// sampling); aliases have no description.
+struct pl_filter_preset {
+    const char *name;
+    const struct pl_filter_config *filter;
+    const char *description;
+};
+PL_API extern const struct pl_filter_preset pl_filter_presets[];
+PL_API extern const int pl_num_filter_presets; // excluding the trailing {0}
+PL_API const struct pl_filter_preset *pl_find_filter_preset(const char *name);
 
 struct pl_filter_params {
     struct pl_filter_config config;

@@ -62,7 +62,7 @@ PL_API void pl_renderer_reset_errors(pl_renderer rr, const struct pl_render_erro
 
 enum pl_clear_mode {
     PL_CLEAR_COLOR = 0, // set to the background colour
-    PL_CLEAR_TILES,     // (treated as PL_CLEAR_COLOR by this backend)
+    PL_CLEAR_TILES,     // blend against / fill with the two-colour tile pattern
     PL_CLEAR_SKIP,      // leave untouched
     PL_CLEAR_BLUR,      // (unsupported: treated as PL_CLEAR_COLOR)
     PL_CLEAR_MODE_COUNT,
@@ -249,6 +249,22 @@ PL_API void pl_frame_set_chroma_location(struct pl_frame *frame,
 
 // true if the frame's crop does not cover its whole reference plane
 PL_API bool pl_frame_is_cropped(const struct pl_frame *frame);
+
+// Fill every plane of `frame` with one colour, given as sRGB and converted to the frame's colour
+// space and encoding (renderer.h:672-690 in the reference; premultiplied frames get rgb * alpha).
+// What applications call on a target before / instead of rendering into a part of it.
+PL_API void pl_frame_clear_rgba(pl_gpu gpu, const struct pl_frame *frame, const float rgba[4]);
+
+static inline void pl_frame_clear(pl_gpu gpu, const struct pl_frame *frame, const float rgb[3])
+{
+    const float rgba[4] = { rgb[0], rgb[1], rgb[2], 1.0f };
+    pl_frame_clear_rgba(gpu, frame, rgba);
+}
+
+// Fill every plane of `frame` with two-colour tiles of `tile_size` reference-plane texels
+// (subsampled planes: scaled by their subsampling ratio); alpha is set to 1.
+PL_API void pl_frame_clear_tiles(pl_gpu gpu, const struct pl_frame *frame,
+                                 const float tile_colors[2][3], int tile_size);
 
 // Fill in what pl_render_image would infer (crop, bit depths, colour spaces)
 PL_API void pl_frames_infer(pl_renderer rr, struct pl_frame *image, struct pl_frame *target);

@@ -31,6 +31,11 @@ int plh_dev_count(void);
 const char *plh_strerror(int err);
 int plh_dev_open(int device, struct plh_dev_info *info);
 int plh_stream_create(int device, plh_stream *out);
+// the device that owns `s` (not the calling thread's current one) and, optionally, its CU count
+int plh_stream_device(plh_stream s, int *cus);
+// raise a kernel's dynamic-LDS limit on the stream's device, once per (kernel, device); `done` =
+// the caller's static per-kernel device mask
+int plh_kernel_needs_lds(const void *kernel, plh_stream s, size_t bytes, uint64_t *done);
 void plh_stream_destroy(plh_stream s);
 int plh_stream_sync(plh_stream s);
 int plh_stream_idle(plh_stream s);   // 1 idle, 0 busy, < 0 error
@@ -62,6 +67,10 @@ int plh_event_elapsed_ns(plh_event a, plh_event b, uint64_t *ns);
 
 // fills the whole texture with a constant colour (pl_tex_clear_ex)
 int plh_launch_clear(plh_stream s, const struct plh_view *dst, const float color[4]);
+// fills the whole texture with two-colour tiles (pl_frame_clear_tiles): texel (x, y) takes c0 where
+// fract((x + 1/2) * kx) < 1/2 and fract((y + 1/2) * ky) < 1/2 agree, c1 where they differ
+int plh_launch_clear_tiles(plh_stream s, const struct plh_view *dst, const float c0[4],
+                           const float c1[4], float kx, float ky);
 // k_noise.hip: plane[y * stride + x] = pcg3d(x + x0, y + y0, seed).x for x < w, y < h
 int plh_launch_white_noise(plh_stream s, float *plane, int stride, int w, int h, int x0, int y0,
                            uint32_t seed);

@@ -58,6 +58,55 @@ int plh_dev_open(int device, struct plh_dev_info *info)
     return 0;
 }
 
+// ---- what a launcher needs to know about the device that owns its stream -------------------
+// The calling thread's current device is not necessarily that device (a host thread may drive
+// several pl_gpu objects; hipSetDevice is only called where memory and streams are created), so
+// launchers ask the stream. Cached per device: the CU count, and -- per kernel -- whether the
+// dynamic-LDS limit has been raised there (hipFuncSetAttribute acts on the current device and
+// costs a runtime call: once per kernel and device, not once per launch).
+#define PLH_MAX_DEVICES 64
+static int g_dev_cus[PLH_MAX_DEVICES];
+
+int plh_stream_device(plh_stream s, int *cus)
+{
+    hipDevice_t dev = 0;
+    if (!s || hipStreamGetDevice((hipStream_t) s, &dev) != hipSuccess)
+        (void) hipGetDevice(&dev);      // (the null stream: the current device's)
+    if (dev < 0 || dev >= PLH_MAX_DEVICES)
+        dev = 0;
+    if (cus) {
+        int n = __atomic_load_n(&g_dev_cus[dev], __ATOMIC_RELAXED);
+        if (n <= 0) {
+            if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0)
+                n = 256;
+            __atomic_store_n(&g_dev_cus[dev], n, __ATOMIC_RELAXED);
+        }
+        *cus = n;
+    }
+    return dev;
+}
+
+// Raise `kernel`'s dynamic-LDS limit to `bytes` on the device that owns `s`; `done` is the
+// caller's per-kernel bit mask of devices already served (a static uint64_t next to the launch).
+int plh_kernel_needs_lds(const void *kernel, plh_stream s, size_t bytes, uint64_t *done)
+{
+    const int dev = plh_stream_device(s, NULL);
+    const uint64_t bit = 1ull << dev;
+    if (__atomic_load_n(done, __ATOMIC_ACQUIRE) & bit)
+        return 0;
+    int cur = dev;
+    (void) hipGetDevice(&cur);
+    if (cur != dev && hipSetDevice(dev) != hipSuccess)
+        return -(int) hipErrorInvalidDevice;
+    const hipError_t err = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int) bytes);
+    if (cur != dev)
+        (void) hipSetDevice(cur);
+    if (err != hipSuccess)
+        return -(int) err;
+    __atomic_fetch_or(done, bit, __ATOMIC_RELEASE);
+    return 0;
+}
+
 int plh_stream_create(int device, plh_stream *out)
 {
     CHK(hipSetDevice(device));
@@ -226,6 +275,31 @@ extern "C" int plh_launch_clear(plh_stream s, const struct plh_view *dst, const 
     const dim3 block(64, 4), grid((dst->w + 63) / 64, (dst->h + 3) / 4);
     float4_t c = { color[0], color[1], color[2], color[3] };
     hipLaunchKernelGGL(k_clear, grid, block, 0, (hipStream_t) s, *dst, c);
+    const hipError_t err = hipGetLastError();
+    return err == hipSuccess ? 0 : -(int) err;
+}
+
+// pl_frame_clear_tiles (src/renderer.c:4116-4170): the reference fills a plane through a fragment
+// shader -- outcoord = gl_FragCoord.xy * (1 / size_x, 1 / size_y); tile = lessThan(fract(outcoord),
+// 0.5); color.rgb = tile.x == tile.y ? c0 : c1; color.a = 1 -- here a kernel of its own: the same
+// fp32 arithmetic on gl_FragCoord = texel + 1/2, one texel per lane, stores through plh_store.
+__global__ void k_clear_tiles(const plh_view dst, float4_t c0, float4_t c1, float kx, float ky)
+{
+    const int x = blockIdx.x * blockDim.x + threadIdx.x;
+    const int y = blockIdx.y * blockDim.y + threadIdx.y;
+    if (x >= dst.w || y >= dst.h)
+        return;
+    const float ox = ((float) x + 0.5f) * kx, oy = ((float) y + 0.5f) * ky;
+    const bool tx = ox - __builtin_floorf(ox) < 0.5f, ty = oy - __builtin_floorf(oy) < 0.5f;
+    plh_store(dst, x, y, tx == ty ? c0 : c1);
+}
+
+extern "C" int plh_launch_clear_tiles(plh_stream s, const struct plh_view *dst, const float c0[4],
+                                      const float c1[4], float kx, float ky)
+{
+    const dim3 block(64, 4), grid((dst->w + 63) / 64, (dst->h + 3) / 4);
+    const float4_t a = { c0[0], c0[1], c0[2], c0[3] }, b = { c1[0], c1[1], c1[2], c1[3] };
+    hipLaunchKernelGGL(k_clear_tiles, grid, block, 0, (hipStream_t) s, *dst, a, b, kx, ky);
     const hipError_t err = hipGetLastError();
     return err == hipSuccess ? 0 : -(int) err;
 }

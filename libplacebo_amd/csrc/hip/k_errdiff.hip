@@ -22,6 +22,7 @@
  * round() is round-half-even here and in the oracle (v_rndne_f32 / rintf).
  */
 #include "devmath.hiph"
+#include "backend.h"
 
 __global__ __launch_bounds__(1024)
 void k_errdiff(const plh_errdiff_args a)
@@ -100,14 +101,10 @@ extern "C" int plh_launch_errdiff(plh_stream stream, const plh_errdiff_args *arg
     const size_t shmem = (size_t) args->ring_rows * args->ring_cols * sizeof(uint32_t);
     if (shmem > 160 * 1024)
         return -1000;
-    static bool configured = false;
-    if (!configured) {
-        // opt in to more than the default 64 KiB of dynamic LDS
-        if (hipFuncSetAttribute((const void *) k_errdiff,
-                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
-            (void) hipGetLastError();
-        configured = true;
-    }
+    // opt in to more than the default 64 KiB of dynamic LDS, once per device
+    static uint64_t lds_done;
+    if (shmem > 64 * 1024)
+        (void) plh_kernel_needs_lds((const void *) k_errdiff, stream, 160 * 1024, &lds_done);
     hipLaunchKernelGGL(k_errdiff, dim3(1), dim3(args->block_size), shmem, (hipStream_t) stream,
                        *args);
     const hipError_t err = hipGetLastError();

@@ -346,14 +346,16 @@ int plh_launch_polar_mxd(hipStream_t stream, const plh_pass *pass)
     const int tiles_x = (pass->width + MXD_TW - 1) / MXD_TW;
     const int tiles_y = (pass->height + MXD_TH - 1) / MXD_TH;
     const size_t shmem = MXD_B_BYTES + (size_t) 3 * MXD_PLANE + 16;
-    // one persistent workgroup per CU (LDS: 124 KiB each)
-    int dev = 0, cus = 0;
-    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0)
-        cus = 256;
+    // one persistent workgroup per CU (LDS: 124 KiB each) of the device that owns the stream
+    int cus = 256;
+    (void) plh_stream_device((plh_stream) stream, &cus);
     const int groups = tiles_x * tiles_y < cus ? tiles_x * tiles_y : cus;
     const bool unorm = pass->s.src.fmt == PLH_FMT_RGBA16, f16dst = pass->dst.fmt == PLH_FMT_RGBA16F;
 #define MXD_LAUNCH(U, F) do { \
-        (void) hipFuncSetAttribute((const void *) k_polar_mxd<U, F>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) shmem); \
+        static uint64_t lds_done; \
+        const int e = plh_kernel_needs_lds((const void *) k_polar_mxd<U, F>, (plh_stream) stream, shmem, &lds_done); \
+        if (e) \
+            return e; \
         hipLaunchKernelGGL((k_polar_mxd<U, F>), dim3(groups), dim3(MXD_NT), shmem, stream, *pass); \
     } while (0)
     if (unorm && f16dst)  MXD_LAUNCH(true, true);

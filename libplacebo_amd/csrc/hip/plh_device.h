@@ -217,6 +217,10 @@ enum plh_op_kind {
     // pl_shader_custom_lut (shaders/lut.c:212-280): ptr = rgba32f texels, i0 i1 i2 = sizes
     // (1D: i1 = i2 = 0 -> per-channel linear lookup; 3D -> tetrahedral interpolation)
     PLH_OP_CUSTOM_LUT,
+    // blend against the tile pattern (renderer.c:2734-2756): outcoord = gl_FragCoord.xy * f[8];
+    // tile = lessThan(fract(outcoord), 0.5); color.rgb += (1 - color.a) * (tile.x == tile.y ?
+    // f[0..2] : f[4..6]); color.a = 1
+    PLH_OP_BLEND_TILES,
 };
 
 // flags in plh_op.i1 of LINEARIZE / DELINEARIZE / PEAK_DETECT

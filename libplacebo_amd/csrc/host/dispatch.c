@@ -215,9 +215,12 @@ static void plh_pass_choose_cells(struct plh_pass *pass)
 // PL_DITHER_WHITE_NOISE is recorded as (i1 = 2, i0 = seed). The kernels only know dither
 // matrices: now that the size of the pass is known, evaluate the PRNG for its fragment
 // coordinates into a plane whose row stride is a power of two (the matrix lookup wraps x and y
-// with one mask; rows beyond the pass' height are never addressed, so they are not allocated:
-// 4096 x 2160 floats for a 4K pass) and turn the op into a plain LUT dither over it (k_noise.hip
-// says why). Generated on `stream`, the stream the pass itself is launched on.
+// with one mask) and turn the op into a plain LUT dither over it (k_noise.hip says why). Rows at
+// and beyond the pass' height carry no noise but ARE addressed: every kernel fetches the dither
+// value of the lanes its tiles pad the rect with before the store guard drops them (8 rows for
+// k_pass_generic, up to 128 for the polar tiles), so the plane is allocated up to the next
+// multiple of 256 rows -- 4096 x 2304 floats for a 4K pass -- and never past `side` rows, which
+// the row mask cannot exceed. Generated on `stream`, the stream the pass itself is launched on.
 static bool realize_white_noise(pl_gpu gpu, plh_stream stream, pl_buf *noise, struct plh_pass *pass)
 {
     for (int i = 0; i < pass->num_ops; i++) {
@@ -227,7 +230,8 @@ static bool realize_white_noise(pl_gpu gpu, plh_stream stream, pl_buf *noise, st
         int side = 16;
         while (side < pass->width || side < pass->height)
             side <<= 1;
-        const size_t size = (size_t) side * pass->height * sizeof(float);
+        const int rows = PL_MIN(side, (pass->height + 255) & ~255);
+        const size_t size = (size_t) side * rows * sizeof(float);
         if (!*noise || (*noise)->params.size < size) {
             pl_buf_destroy(gpu, noise);
             *noise = pl_buf_create(gpu, pl_buf_params(.size = size, .storable = true));

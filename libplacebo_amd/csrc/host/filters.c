@@ -17,6 +17,8 @@
 #include <stdlib.h>
 #include <string.h>
 
+// (this file DEFINES the objects the header marks as deprecated)
+#define PL_DEPRECATED_IN(VER)
 #include <libplacebo/filters.h>
 #include "host_common.h"
 
@@ -185,14 +187,21 @@ FN(pl_filter_function_oversample,"oversample",zero,      0.0, .params = {0.0}, .
 static FN(fn_alias_dirichlet, "dirichlet", box,       1.0, .resizable = true);
 static FN(fn_alias_hanning,   "hanning",   hann,      1.0);
 static FN(fn_alias_quadric,   "quadric",   quadratic, 1.5);
-static FN(fn_alias_bicubic,   "bicubic",   cubic,     2.0, .params = {1.0, 0.0}, .tunable = {true, true});
-static FN(fn_alias_bcspline,  "bcspline",  cubic,     2.0, .params = {1.0, 0.0}, .tunable = {true, true});
-static FN(fn_alias_catmull,   "catmull_rom", cubic,   2.0, .params = {0.0, 0.5}, .tunable = {true, true});
-static FN(fn_alias_mitchell,  "mitchell",  cubic,     2.0, .params = {1/3.0, 1/3.0}, .tunable = {true, true});
-static FN(fn_alias_robidoux,  "robidoux",  cubic,     2.0,
-          .params = {12 / (19 + 9 * M_SQRT2), 113 / (58 + 216 * M_SQRT2)}, .tunable = {true, true});
-static FN(fn_alias_robidouxsharp, "robidouxsharp", cubic, 2.0,
-          .params = {6 / (13 + 7 * M_SQRT2), 7 / (2 + 12 * M_SQRT2)}, .tunable = {true, true});
+// (exported objects in the reference: filters.c:505-551)
+FN(pl_filter_function_bicubic,  "bicubic",  cubic,     2.0, .params = {1.0, 0.0}, .tunable = {true, true});
+FN(pl_filter_function_bcspline, "bcspline", cubic,     2.0, .params = {1.0, 0.0}, .tunable = {true, true});
+FN(pl_filter_function_catmull_rom, "catmull_rom", cubic, 2.0, .params = {0.0, 0.5}, .tunable = {true, true});
+FN(pl_filter_function_mitchell, "mitchell", cubic,     2.0, .params = {1/3.0, 1/3.0}, .tunable = {true, true});
+FN(pl_filter_function_robidoux, "robidoux", cubic,     2.0,
+   .params = {12 / (19 + 9 * M_SQRT2), 113 / (58 + 216 * M_SQRT2)}, .tunable = {true, true});
+FN(pl_filter_function_robidouxsharp, "robidouxsharp", cubic, 2.0,
+   .params = {6 / (13 + 7 * M_SQRT2), 7 / (2 + 12 * M_SQRT2)}, .tunable = {true, true});
+#define fn_alias_bicubic       pl_filter_function_bicubic
+#define fn_alias_bcspline      pl_filter_function_bcspline
+#define fn_alias_catmull       pl_filter_function_catmull_rom
+#define fn_alias_mitchell      pl_filter_function_mitchell
+#define fn_alias_robidoux      pl_filter_function_robidoux
+#define fn_alias_robidouxsharp pl_filter_function_robidouxsharp
 
 const struct pl_filter_function * const pl_filter_functions[] = {
     &pl_filter_function_box,      &fn_alias_dirichlet,
@@ -221,6 +230,37 @@ const struct pl_filter_function *pl_find_filter_function(const char *name)
     for (int i = 0; name && i < pl_num_filter_functions; i++) {
         if (!strcmp(name, pl_filter_functions[i]->name))
             return pl_filter_functions[i];
+    }
+    return NULL;
+}
+
+// the older name -> function table (filters.c:998-1044): every entry of pl_filter_functions but the
+// opaque oversampler, under its own name, behind a leading "none"
+const struct pl_filter_function_preset pl_filter_function_presets[] = {
+    {"none", NULL},
+#define P(fn) {(fn).name, &(fn)}
+    P(pl_filter_function_box), P(fn_alias_dirichlet), P(pl_filter_function_triangle),
+    P(pl_filter_function_cosine), P(pl_filter_function_hann), P(fn_alias_hanning),
+    P(pl_filter_function_hamming), P(pl_filter_function_welch), P(pl_filter_function_kaiser),
+    P(pl_filter_function_blackman), P(pl_filter_function_bohman), P(pl_filter_function_gaussian),
+    P(pl_filter_function_quadratic), P(fn_alias_quadric), P(pl_filter_function_sinc),
+    P(pl_filter_function_jinc), P(pl_filter_function_sphinx), P(pl_filter_function_cubic),
+    P(pl_filter_function_hermite), P(pl_filter_function_bicubic), P(pl_filter_function_bcspline),
+    P(pl_filter_function_catmull_rom), P(pl_filter_function_mitchell), P(pl_filter_function_robidoux),
+    P(pl_filter_function_robidouxsharp), P(pl_filter_function_spline16),
+    P(pl_filter_function_spline36), P(pl_filter_function_spline64),
+#undef P
+    {0},
+};
+
+const int pl_num_filter_function_presets =
+    sizeof(pl_filter_function_presets) / sizeof(pl_filter_function_presets[0]) - 1;
+
+const struct pl_filter_function_preset *pl_find_filter_function_preset(const char *name)
+{
+    for (int i = 0; name && i < pl_num_filter_function_presets; i++) {
+        if (!strcmp(name, pl_filter_function_presets[i].name))
+            return &pl_filter_function_presets[i];
     }
     return NULL;
 }
@@ -335,6 +375,40 @@ pl_find_filter_config(const char *name, enum pl_filter_usage usage)
         const struct pl_filter_config *c = pl_filter_configs[i];
         if ((c->allowed & usage) == usage && !strcmp(name, c->name))
             return c;
+    }
+    return NULL;
+}
+
+// the older name -> config table (filters.h:28-58 COMMON_FILTER_PRESETS, filters.c:1046-1065):
+// recommended scalers first, then the rest, then two aliases without a description
+const struct pl_filter_preset pl_filter_presets[] = {
+    {"none", NULL, "Built-in sampling"},
+#define P(cfg, desc) {(cfg).name, &(cfg), desc}
+    P(pl_filter_bilinear, "Bilinear"), P(pl_filter_nearest, "Nearest neighbour"),
+    P(pl_filter_bicubic, "Bicubic"), P(pl_filter_lanczos, "Lanczos"),
+    P(pl_filter_ewa_lanczos, "Jinc (EWA Lanczos)"), P(pl_filter_ewa_lanczossharp, "Sharpened Jinc"),
+    P(pl_filter_ewa_lanczos4sharpest, "Sharpened Jinc-AR, 4 taps"), P(pl_filter_gaussian, "Gaussian"),
+    P(pl_filter_spline16, "Spline (2 taps)"), P(pl_filter_spline36, "Spline (3 taps)"),
+    P(pl_filter_spline64, "Spline (4 taps)"), P(pl_filter_mitchell, "Mitchell-Netravali"),
+    P(pl_filter_sinc, "Sinc (unwindowed)"), P(pl_filter_ginseng, "Ginseng (Jinc-Sinc)"),
+    P(pl_filter_ewa_jinc, "EWA Jinc (unwindowed)"), P(pl_filter_ewa_ginseng, "EWA Ginseng"),
+    P(pl_filter_ewa_hann, "EWA Hann"), P(pl_filter_hermite, "Hermite"),
+    P(pl_filter_catmull_rom, "Catmull-Rom"), P(pl_filter_robidoux, "Robidoux"),
+    P(pl_filter_robidouxsharp, "RobidouxSharp"), P(pl_filter_ewa_robidoux, "EWA Robidoux"),
+    P(pl_filter_ewa_robidouxsharp, "EWA RobidouxSharp"),
+#undef P
+    {"triangle", &pl_filter_bilinear, NULL},
+    {"ewa_hanning", &pl_filter_ewa_hann, NULL},
+    {0},
+};
+
+const int pl_num_filter_presets = sizeof(pl_filter_presets) / sizeof(pl_filter_presets[0]) - 1;
+
+const struct pl_filter_preset *pl_find_filter_preset(const char *name)
+{
+    for (int i = 0; name && i < pl_num_filter_presets; i++) {
+        if (!strcmp(name, pl_filter_presets[i].name))
+            return &pl_filter_presets[i];
     }
     return NULL;
 }

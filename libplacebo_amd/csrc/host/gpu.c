@@ -408,9 +408,15 @@ void pl_buf_destroy(pl_gpu gpu, pl_buf *buf)
 
 bool pl_buf_recreate(pl_gpu gpu, pl_buf *buf, const struct pl_buf_params *params)
 {
-    // reusable iff the existing buffer can do everything the new one is asked to
-    // (pl_buf_params_superset, src/gpu.c:630-641)
-    if (*buf && !params->initial_data) {
+    // (src/gpu.c:644-660: a recreated buffer has no defined contents, so asking for some is an error)
+    if (params->initial_data) {
+        pl_msg(gpu->log, PL_LOG_ERR, "pl_buf_recreate may not be used with `initial_data`!");
+        return false;
+    }
+    // reusable iff the existing buffer can do everything the new one is asked to -- a LARGER
+    // buffer too, as in the reference (pl_buf_params_superset, src/gpu.c:630-641): callers read
+    // the size they asked for from their own parameters, not from buf->params
+    if (*buf) {
         const struct pl_buf_params *have = &(*buf)->params;
         const bool covers = have->size >= params->size &&
             have->memory_type == params->memory_type && have->format == params->format &&

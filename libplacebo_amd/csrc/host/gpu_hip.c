@@ -502,6 +502,19 @@ static void hip_tex_clear_ex(pl_gpu gpu, pl_tex dst, const union pl_clear_color 
         pl_msg(gpu->log, PL_LOG_ERR, "pl_tex_clear: %s", plh_strerror(err));
 }
 
+// (not part of struct pl_gpu_fns: the reference has no such entry point either, it dispatches a
+// shader; renderer.c's pl_frame_clear_tiles is the one caller)
+void plh_tex_clear_tiles(pl_gpu gpu, pl_tex dst, const float c0[4], const float c1[4],
+                         float kx, float ky)
+{
+    struct plh_view v;
+    plh_tex_view(dst, &v);
+    plh_tex_order(gpu, 0, NULL, dst);
+    const int err = plh_launch_clear_tiles(GPU_PRIV(gpu)->stream, &v, c0, c1, kx, ky);
+    if (err)
+        pl_msg(gpu->log, PL_LOG_ERR, "pl_frame_clear_tiles: %s", plh_strerror(err));
+}
+
 // A blit is a pass with a bare nearest / bilinear sampler and no colour stages: the same
 // kernels the renderer uses (the reference emulates blits with a compute shader the same way
 // on backends without a native one, src/gpu/utils.c:852).

@@ -128,6 +128,9 @@ struct pl_timer_t {
 #define GPU_FNS(g)   (GPU_PRIV(g)->fns)
 
 void plh_tex_view(pl_tex tex, struct plh_view *out);
+// two-colour tiles over the whole texture (k_clear_tiles; kx, ky = 1 / tile period in texels)
+void plh_tex_clear_tiles(pl_gpu gpu, pl_tex dst, const float c0[4], const float c1[4],
+                         float kx, float ky);
 void plh_timer_begin(pl_gpu gpu, pl_timer t, int on);    // `on`: stream index, see below
 void plh_timer_end(pl_gpu gpu, pl_timer t, int on);
 

@@ -25,6 +25,7 @@ struct pl_hip_rccl_t {
     void *dl;
     allreduce_fn all_reduce;
     uint32_t *maxima;       // device scratch: the MAX words travel separately
+    uint32_t *summed;       // device scratch: the SUM arrives here, not over the local measurement
     int exchanges, errors;
 };
 
@@ -68,7 +69,8 @@ pl_hip_rccl pl_hip_rccl_create(pl_gpu gpu, void *nccl_comm, void *nccl_all_reduc
         return NULL;
     }
     x->maxima = plh_malloc(plh_gpu_device(gpu), MAX_COUNT * sizeof(uint32_t));
-    if (!x->maxima)
+    x->summed = plh_malloc(plh_gpu_device(gpu), PEAK_WORDS * sizeof(uint32_t));
+    if (!x->maxima || !x->summed)
         pl_hip_rccl_destroy(&x);
     return x;
 }
@@ -78,9 +80,10 @@ void pl_hip_rccl_destroy(pl_hip_rccl *px)
     struct pl_hip_rccl_t *x = px ? *px : NULL;
     if (!x)
         return;
-    if (x->maxima) {
+    if (x->maxima || x->summed) {
         plh_stream_sync(plh_gpu_stream(x->gpu));
         plh_free(x->maxima);
+        plh_free(x->summed);
     }
     if (x->dl)
         dlclose(x->dl);
@@ -95,9 +98,12 @@ int pl_hip_rccl_stats(pl_hip_rccl x, int *out_errors)
     return x->exchanges;
 }
 
-// SUM over everything, MAX over the frame_max_pq words: set the maxima aside, sum in place
-// (which leaves garbage in the max words), reduce the copy with MAX, put it back. Three tiny
-// stream-ordered operations + two latency-bound collectives (3.3 KB / 48 B).
+// SUM over everything, MAX over the frame_max_pq words: the maxima are set aside and reduced with
+// MAX, the whole buffer is summed OUT OF PLACE, and only when every step was accepted do the two
+// results replace the local measurement (the sum first -- its max words are garbage -- then the
+// maxima over them). A refused collective therefore leaves `words` exactly as the measuring pass
+// wrote it: the renderer tone-maps with this GPU's own measurement instead of a half-reduced
+// buffer. Four tiny stream-ordered copies + two latency-bound collectives (3.3 KB / 48 B).
 void pl_hip_rccl_peak_exchange(void *priv, void *words, size_t size, void *stream)
 {
     struct pl_hip_rccl_t *x = priv;
@@ -106,14 +112,23 @@ void pl_hip_rccl_peak_exchange(void *priv, void *words, size_t size, void *strea
         return;
     }
     uint32_t *w = words;
-    const size_t mbytes = MAX_COUNT * sizeof(uint32_t);
-    int rc = plh_copy2d_d2d(stream, x->maxima, mbytes, w + MAX_FIRST, mbytes, mbytes, 1);
-    rc |= x->all_reduce(w, w, PEAK_WORDS, NCCL_UINT32, NCCL_SUM, x->comm, stream);
-    rc |= x->all_reduce(x->maxima, x->maxima, MAX_COUNT, NCCL_UINT32, NCCL_MAX, x->comm, stream);
-    rc |= plh_copy2d_d2d(stream, w + MAX_FIRST, mbytes, x->maxima, mbytes, mbytes, 1);
+    const size_t mbytes = MAX_COUNT * sizeof(uint32_t), bytes = PEAK_WORDS * sizeof(uint32_t);
     x->exchanges++;
+    int rc = plh_copy2d_d2d(stream, x->maxima, mbytes, w + MAX_FIRST, mbytes, mbytes, 1);
+    if (!rc)
+        rc = x->all_reduce(w, x->summed, PEAK_WORDS, NCCL_UINT32, NCCL_SUM, x->comm, stream);
+    if (!rc)
+        rc = x->all_reduce(x->maxima, x->maxima, MAX_COUNT, NCCL_UINT32, NCCL_MAX, x->comm, stream);
     if (rc) {
         x->errors++;
-        pl_msg(x->gpu->log, PL_LOG_ERR, "peak exchange over RCCL failed (status %d)", rc);
+        pl_msg(x->gpu->log, PL_LOG_ERR, "peak exchange over RCCL failed (status %d): this frame is "
+               "tone-mapped with the local measurement", rc);
+        return;
+    }
+    rc = plh_copy2d_d2d(stream, w, bytes, x->summed, bytes, bytes, 1);
+    rc |= plh_copy2d_d2d(stream, w + MAX_FIRST, mbytes, x->maxima, mbytes, mbytes, 1);
+    if (rc) {
+        x->errors++;
+        pl_msg(x->gpu->log, PL_LOG_ERR, "peak exchange: copying the reduced measurement back failed (%d)", rc);
     }
 }

@@ -508,10 +508,11 @@ void rp_plan_output(const struct pl_render_params *params, const struct pl_frame
         out->background = PL_CLEAR_SKIP;
     if (params->skip_target_clearing)
         out->border = PL_CLEAR_SKIP;
-    // tiles and blur are not implemented here: they show the background colour
-    if (out->background == PL_CLEAR_TILES || out->background == PL_CLEAR_BLUR)
+    // a blurred background / border is not implemented here: it shows the background colour
+    // (what the reference does when its blur pass is unavailable, :2500, PL_RENDER_ERR_BLUR)
+    if (out->background == PL_CLEAR_BLUR)
         out->background = PL_CLEAR_COLOR;
-    if (out->border == PL_CLEAR_TILES || out->border == PL_CLEAR_BLUR)
+    if (out->border == PL_CLEAR_BLUR)
         out->border = PL_CLEAR_COLOR;
     // fully transparent background on a target with alpha: nothing to blend against
     if (params->background_transparency >= 1.0 && target_alpha)
@@ -529,6 +530,12 @@ void rp_plan_output(const struct pl_render_params *params, const struct pl_frame
                 alpha = PL_ALPHA_NONE;
                 comps = 3;
             }
+        } else if (out->background == PL_CLEAR_TILES) {
+            // :2734-2756: blended against the tile pattern, alpha becomes 1
+            out->blend = true;
+            out->drop_alpha = true;
+            alpha = PL_ALPHA_NONE;
+            comps = 3;
         }
     }
 

@@ -1117,47 +1117,120 @@ void plh_stage_colors(struct frame_job *job)
 
 /* ---- stage 4: output ------------------------------------------------------------------------ */
 
-// the sRGB background colour in the target's colour space (:2557-2584)
+// An sRGB colour (background, tiles, pl_frame_clear_*) in the colour space `csp` (:2555-2584).
+// The display-referred gamma curves (BT.1886, sRGB, gamma 2.2) are taken to be the curve the
+// colour was given in -- the round trip through linear light then changes nothing but the
+// primaries, and black keeps the target's level; for every other target the colour is read as
+// sRGB of infinite contrast, so that no black point is lifted into it.
 static void background_in(const struct pl_color_space *csp, const float srgb[3], float out[3])
 {
+    struct pl_color_space from = pl_color_space_srgb;
+    const bool gamma_like = csp->transfer == PL_COLOR_TRC_BT_1886 ||
+                            csp->transfer == PL_COLOR_TRC_SRGB ||
+                            csp->transfer == PL_COLOR_TRC_GAMMA22;
+    if (gamma_like)
+        from.transfer = csp->transfer;
+    from.hdr.min_luma = gamma_like ? csp->hdr.min_luma : PL_COLOR_HDR_BLACK;
+
     memcpy(out, srgb, 3 * sizeof(float));
-    if (csp->primaries == PL_COLOR_PRIM_BT_709 && csp->transfer == PL_COLOR_TRC_SRGB)
-        return;
-    const struct pl_color_space from = pl_color_space_srgb;
     pl_color_linearize(&from, out);
-    if (csp->primaries != PL_COLOR_PRIM_BT_709) {
-        const pl_matrix3x3 m = pl_get_color_mapping_matrix(
-            pl_raw_primaries_get(PL_COLOR_PRIM_BT_709), pl_raw_primaries_get(csp->primaries),
-            PL_INTENT_RELATIVE_COLORIMETRIC);
-        pl_matrix3x3_apply(&m, out);
-    }
+    const pl_matrix3x3 m = pl_get_color_mapping_matrix(
+        pl_raw_primaries_get(from.primaries), pl_raw_primaries_get(csp->primaries),
+        PL_INTENT_RELATIVE_COLORIMETRIC);
+    pl_matrix3x3_apply(&m, out);
     pl_color_delinearize(csp, out);
 }
 
-// fill every plane of the target with the (encoded) background colour
-static void clear_planes(struct frame_job *job, float scale)
+// the inverse of the frame's decoding: normalised RGB -> the values its planes hold
+static pl_transform3x3 frame_encoding(const struct pl_frame *frame)
+{
+    struct pl_color_repr repr = frame->repr;
+    pl_transform3x3 enc = pl_color_repr_decode(&repr, NULL);
+    pl_transform3x3_invert(&enc);
+    return enc;
+}
+
+// :4172-4199
+void pl_frame_clear_rgba(pl_gpu gpu, const struct pl_frame *frame, const float rgba[4])
+{
+    float enc[3];
+    background_in(&frame->color, rgba, enc);
+    const pl_transform3x3 tr = frame_encoding(frame);
+    pl_transform3x3_apply(&tr, enc);
+
+    const float cover = frame->repr.alpha == PL_ALPHA_PREMULTIPLIED ? rgba[3] : 1.0f;
+    for (int i = 0; i < frame->num_planes; i++) {
+        const struct pl_plane *pl = &frame->planes[i];
+        float texel[4] = { 0.0f, 0.0f, 0.0f, rgba[3] };
+        for (int c = 0; c < pl->components; c++) {
+            const int ch = pl->component_mapping[c];
+            if (ch >= 0 && ch < 3)
+                texel[c] = cover * enc[ch];
+        }
+        pl_tex_clear(gpu, pl->texture, texel);
+    }
+}
+
+// :4116-4170. The tile period of a plane follows its size relative to the reference plane, rounded
+// to a whole (or whole-reciprocal) ratio; the period is an integer number of texels.
+void pl_frame_clear_tiles(pl_gpu gpu, const struct pl_frame *frame,
+                          const float tile_colors[2][3], int tile_size)
+{
+    if (!frame->num_planes || tile_size <= 0)
+        return;
+    const pl_transform3x3 tr = frame_encoding(frame);
+    float enc[2][3];
+    for (int t = 0; t < 2; t++) {
+        background_in(&frame->color, tile_colors[t], enc[t]);
+        pl_transform3x3_apply(&tr, enc[t]);
+    }
+
+    pl_tex ref = frame->planes[rp_reference_plane(frame)].texture;
+    for (int i = 0; i < frame->num_planes; i++) {
+        const struct pl_plane *pl = &frame->planes[i];
+        float tiles[2][4] = { { 0.0f, 0.0f, 0.0f, 1.0f }, { 0.0f, 0.0f, 0.0f, 1.0f } };
+        for (int c = 0; c < pl->components; c++) {
+            const int ch = pl->component_mapping[c];
+            if (ch >= 0 && ch < 3) {
+                tiles[0][c] = enc[0][ch];
+                tiles[1][c] = enc[1][ch];
+            }
+        }
+        const float rx = (float) pl->texture->params.w / ref->params.w,
+                    ry = (float) pl->texture->params.h / ref->params.h;
+        const float sx = rx >= 1 ? roundf(rx) : 1.0 / roundf(1.0 / rx),
+                    sy = ry >= 1 ? roundf(ry) : 1.0 / roundf(1.0 / ry);
+        const int period_x = tile_size * sx, period_y = tile_size * sy;
+        if (period_x <= 0 || period_y <= 0)
+            continue;   // (a plane subsampled beyond the tile size has no tiles to show)
+        if (!pl->texture->params.blit_dst && !pl->texture->params.renderable) {
+            pl_msg(gpu->log, PL_LOG_ERR, "pl_frame_clear_tiles: plane %d is neither renderable nor blit_dst", i);
+            continue;
+        }
+        plh_tex_clear_tiles(gpu, pl->texture, tiles[0], tiles[1],
+                            (float) (1.0 / period_x), (float) (1.0 / period_y));
+    }
+}
+
+// the border of a cropped target: every plane filled before the image is drawn into its rect
+// (:2941-2964: colour -> pl_frame_clear_rgba, tiles -> pl_frame_clear_tiles)
+static void clear_planes(struct frame_job *job, enum pl_clear_mode mode)
 {
     const struct pl_render_params *params = job->params;
     const struct pl_frame *target = &job->target;
-    float rgb[3];
-    background_in(&target->color, params->background_color, rgb);
-    struct pl_color_repr repr = target->repr;
-    pl_transform3x3 enc = pl_color_repr_decode(&repr, NULL);
-    pl_transform3x3_invert(&enc);
-    pl_transform3x3_apply(&enc, rgb);
-
-    for (int i = 0; i < target->num_planes; i++) {
-        const struct pl_plane *pl = &target->planes[i];
-        float texel[4] = {0};
-        for (int c = 0; c < pl->components; c++) {
-            const int ch = pl->component_mapping[c];
-            if (ch == PL_CHANNEL_A)
-                texel[c] = 1.0 - params->background_transparency;
-            else if (ch >= 0 && ch < 3)
-                texel[c] = rgb[ch] / scale;
-        }
-        pl_tex_clear(job->rr->gpu, pl->texture, texel);
+    if (mode == PL_CLEAR_TILES) {
+        static const float unset[2][3] = {{0}};
+        const bool custom = memcmp(params->tile_colors, unset, sizeof(unset)) != 0;
+        pl_frame_clear_tiles(job->rr->gpu, target,
+                             custom ? params->tile_colors : pl_render_default_params.tile_colors,
+                             PL_DEF(params->tile_size, pl_render_default_params.tile_size));
+        return;
     }
+    const float rgba[4] = {
+        params->background_color[0], params->background_color[1], params->background_color[2],
+        1.0 - params->background_transparency,
+    };
+    pl_frame_clear_rgba(job->rr->gpu, target, rgba);
 }
 
 // color = (0, 0, 0, 1) with color[c] = previous[mapping[c]] (reference swizzle_color :791-808)
@@ -1232,7 +1305,19 @@ bool plh_stage_output(struct frame_job *job)
 
     if (out.premultiply)
         pl_shader_set_alpha(sh, &img->repr, PL_ALPHA_PREMULTIPLIED);
-    if (out.blend) {
+    if (out.blend && out.background == PL_CLEAR_TILES) {
+        struct plh_op *op = sh_op(sh, PLH_OP_BLEND_TILES);
+        if (!op)
+            return false;
+        static const float unset[2][3] = {{0}};
+        const float (*tc)[3] = memcmp(params->tile_colors, unset, sizeof(unset))
+                             ? params->tile_colors : pl_render_default_params.tile_colors;
+        background_in(&target->color, tc[0], op->f);
+        background_in(&target->color, tc[1], op->f + 4);
+        op->f[8] = 1.0 / PL_DEF(params->tile_size, pl_render_default_params.tile_size);
+        sh_listf(sh, "blend_tiles(%g %g %g | %g %g %g, 1/%g)\n", op->f[0], op->f[1], op->f[2],
+                 op->f[4], op->f[5], op->f[6], 1.0 / op->f[8]);
+    } else if (out.blend) {
         struct plh_op *op = sh_op(sh, PLH_OP_BLEND_BG);
         if (!op)
             return false;
@@ -1266,7 +1351,7 @@ bool plh_stage_output(struct frame_job *job)
         sh->transpose = true;
     }
     if (out.clear_border)
-        clear_planes(job, out.scale);
+        clear_planes(job, out.border);
 
     // a planar target samples the finished image once per plane
     pl_tex finished = NULL;
@@ -1357,8 +1442,13 @@ static bool render_nothing(pl_renderer rr, const struct pl_frame *ptarget,
     } else {
         rp_complete_frame(&job.target);
         pl_color_space_infer(&job.target.color);
-        struct pl_color_repr repr = job.target.repr;
-        clear_planes(&job, pl_color_repr_normalize(&repr));
+        // (draw_empty_overlays -> clear_target, :2491-2553: the border mode decides; a blurred
+        // border has nothing to blur without an image)
+        enum pl_clear_mode mode = params->skip_target_clearing ? PL_CLEAR_SKIP : params->border;
+        if (mode == PL_CLEAR_BLUR)
+            mode = PL_CLEAR_COLOR;
+        if (mode != PL_CLEAR_SKIP)
+            clear_planes(&job, mode);
     }
     plh_job_end(&job);
     return !bad;

@@ -210,7 +210,7 @@ struct sh_sampler_obj {
     // matrix-pipe variant of the same geometry (k_polar_mx): B fragments + tile origin
     pl_buf mx_blob;
     struct plh_polar_mx mx_host;    // .enabled = 0: geometry not eligible
-    bool mx_announced;
+    bool mx_announced, mx_declined;
 };
 
 static void sh_sampler_uninit(pl_gpu gpu, void *ptr)
@@ -708,6 +708,14 @@ static bool polar_mx_build(pl_gpu gpu, pl_log log, struct sh_sampler_obj *obj,
     const struct plh_sampler_args *s = &pass->s;
     const int W = pass->width, H = pass->height;
     obj->mx_host = (struct plh_polar_mx) {0};
+    // LDS of the widest variant (RGBA tile, 4 wave-tile columns: 36 KiB of B fragments + 4 planes
+    // of 41 rows x 96 B; the RGB tile of 8 columns needs 55.5 KiB) against the limit the backend
+    // was created with (pl_hip_params.max_shmem_size)
+    if (gpu->glsl.max_shmem_size < 64 * 1024) {
+        pl_msg(log, PL_LOG_DEBUG, "matrix-pipe polar: needs 64 KiB of shared memory, the limit is %zu",
+               (size_t) gpu->glsl.max_shmem_size);
+        return false;
+    }
     if (s->bound > 4 || s->tile_fp32 || s->address_mode != PLH_ADDRESS_CLAMP || pass->transpose ||
         s->src.w < 2 || s->antiring > 0) {
         pl_msg(log, PL_LOG_DEBUG, "matrix-pipe polar: not this pass (bound %d, fp32 tile %d, address "
@@ -1117,9 +1125,32 @@ void plh_polar_pp_setup(pl_gpu gpu, pl_log log, void *polar_obj, struct plh_pass
 
     // k_polar_mx: the contraction on the f16 matrix pipe, within +-1 code of 16 bits of the
     // sequential-fma kernels. PL_HIP_POLAR_MFMA=0 keeps the bit-exact reference variant.
+    //
+    // Where it may not run: the contraction is within ~1e-6 of full scale of the sequential sums,
+    // which is a tenth of a 16-bit code -- unless what follows the sampler amplifies it. A pass
+    // that scales in LINEAR or SIGMOIDIZED light continues with UNSIGMOIDIZE (slope up to 17 at
+    // the dark end) and / or DELINEARIZE (a display gamma's inverse: (1 / 2.4) x^-0.58, 340 at
+    // x = 1e-5), and where dark pixels have bright neighbours 1e-6 then becomes tens of codes
+    // (tests/test_gpu_default_kernels.py measures it). Those passes keep k_polar_pp; a pass over a
+    // PQ- or gamma-coded signal (the HDR upscale, renderer.c:1997-2003; the `fast` preset; linear
+    // scaling disabled) continues with LINEARIZE or the encoder and is safe. PL_HIP_POLAR_MFMA=2
+    // overrides the rule (measurements only).
     const char *mfma = getenv("PL_HIP_POLAR_MFMA");
     memset(&s->mx, 0, sizeof(s->mx));
-    if (obj->mx_host.enabled && !(mfma && mfma[0] == '0') && (cm == 0x7 || cm == 0xf) &&
+    bool amplifies = false;
+    for (int i = pass->num_pre_ops; i < pass->num_ops; i++) {
+        const int kind = pass->ops[i].kind;
+        if (kind == PLH_OP_PLANE_MAP || kind == PLH_OP_ALPHA_ONE || kind == PLH_OP_SWIZZLE)
+            continue;
+        amplifies = kind == PLH_OP_UNSIGMOIDIZE || kind == PLH_OP_DELINEARIZE;
+        break;
+    }
+    if (amplifies && !(mfma && mfma[0] == '2')) {
+        if (obj->mx_host.enabled && !obj->mx_declined)
+            pl_msg(log, PL_LOG_DEBUG, "polar pass in linear / sigmoidized light: the sequential-fma "
+                   "kernel (the matrix pipe's 1e-6 would be amplified by the inverse curves)");
+        obj->mx_declined = true;
+    } else if (obj->mx_host.enabled && !(mfma && mfma[0] == '0') && (cm == 0x7 || cm == 0xf) &&
         !pass->transpose && s->address_mode == PLH_ADDRESS_CLAMP) {
         s->mx = obj->mx_host;
         if (!obj->mx_announced)
@@ -1167,6 +1198,12 @@ static bool polar_mxd_build(pl_gpu gpu, pl_log log, struct sh_sampler_obj *obj,
     if (s->tile_fp32 || s->address_mode != PLH_ADDRESS_CLAMP || pass->transpose || s->src.w < 2 ||
         s->antiring > 0)
         return false;
+    // (56 KiB of B fragments + a 140 x 76 tile of three f16 planes: one workgroup per CU)
+    if (gpu->glsl.max_shmem_size < 124 * 1024) {
+        pl_msg(log, PL_LOG_DEBUG, "matrix-pipe downscale: needs 124 KiB of shared memory, the limit is %zu",
+               (size_t) gpu->glsl.max_shmem_size);
+        return false;
+    }
     float dev = 0.0f;
     if (!mxd_axis(colfc, colbase, W, &dev) || !mxd_axis(rowfc, rowbase, H, &dev))
         return false;

@@ -118,3 +118,63 @@ class RcclPeakExchange:
         self.L.pl_hip_rccl_destroy(_C.byref(self.x))
         self.rccl.ncclCommDestroy.argtypes = [_C.c_void_p]
         self.rccl.ncclCommDestroy(self.comm)
+
+
+# ---- the same exchange over a host-side transport (gloo, MPI, a socket ...) -----------------------
+def _hip_runtime():
+    """the HIP runtime libplacebo_hip.so itself is linked against (the system one), not a copy
+    another package in the process may have mapped"""
+    paths = []
+    with open("/proc/self/maps") as f:
+        for ln in f:
+            if "libamdhip64" in ln:
+                path = ln.split()[-1]
+                if path not in paths:
+                    paths.append(path)
+    mine = [p for p in paths if "/torch/" not in p] or paths or ["libamdhip64.so"]
+    return _C.CDLL(mine[0])
+
+
+class HostPeakExchange:
+    """pl_hip_set_peak_exchange with the reduction done on the host: the 816-word measurement is
+    read back when the renderer is about to consume it, handed to `reduce(words)` -- a callable
+    that all-reduces an int64 numpy array of 816 words in place across the ranks (SUM everywhere,
+    MAX on words 36..47; `gloo_reduce(dist)` below) -- and written back. For ranks that share no
+    xGMI / RCCL communicator (several processes on one device, several hosts): correctness is the
+    same as the RCCL entry, the cost is one stream sync + 6.5 KB over PCIe per measured frame."""
+
+    def __init__(self, gpu, reduce):
+        import numpy as np
+        from . import lib
+        self.gpu, self.L, self.hip, self.calls = gpu, lib(), _hip_runtime(), 0
+        np_ = np
+
+        @_C.CFUNCTYPE(None, _C.c_void_p, _C.c_void_p, _C.c_size_t, _C.c_void_p)
+        def exchange(priv, words, size, stream):
+            assert size == PEAK_WORDS * 4
+            assert self.hip.hipStreamSynchronize(_C.c_void_p(stream)) == 0
+            buf = np_.zeros(PEAK_WORDS, np_.uint32)
+            assert self.hip.hipMemcpy(buf.ctypes.data_as(_C.c_void_p), _C.c_void_p(words), size, 2) == 0
+            wide = buf.astype(np_.int64)
+            reduce(wide)
+            buf[:] = wide.astype(np_.uint32)
+            assert self.hip.hipMemcpy(_C.c_void_p(words), buf.ctypes.data_as(_C.c_void_p), size, 1) == 0
+            self.calls += 1
+
+        self._cb = exchange     # (keep the trampoline alive)
+        self.L.pl_hip_set_peak_exchange.argtypes = [_C.c_void_p, _C.c_void_p, _C.c_void_p]
+        self.L.pl_hip_set_peak_exchange(gpu.gpu, _C.cast(exchange, _C.c_void_p), None)
+
+    def close(self):
+        self.L.pl_hip_set_peak_exchange(self.gpu.gpu, None, None)
+
+
+def gloo_reduce(dist):
+    """reduce(words) for HostPeakExchange over a torch.distributed process group (any backend that
+    takes CPU tensors)"""
+    import torch
+
+    def reduce(words):
+        t = torch.from_numpy(words)
+        allreduce_peak_buffer(t, dist)
+    return reduce

@@ -76,6 +76,11 @@ int main(void)
         CHECK(b->params.host_readable && b->params.size == 96);
         uint8_t probe[4] = {0};
         CHECK(pl_buf_read(gpu, b, 0, probe, 4));
+        // ... and never takes initial contents: an error, the buffer stays what it was (:647-650)
+        pl_buf kept = b;
+        REJECTED(CHECK(!pl_buf_recreate(gpu, &b, pl_buf_params(.size = 96, .host_writable = true,
+                                                               .host_readable = true, .initial_data = probe))));
+        CHECK(b == kept);
         pl_buf_destroy(gpu, &b);
     }
     // none of the above touched the buffer

@@ -11,6 +11,12 @@
  * tests/test_gpu_c_abi.py runs both on the GPU and requires identical output that also matches
  * the oracle. This is the drop-in property of SURVEY.md 8(b) exercised from C, not ctypes.
  *
+ * Written the way a player (mpv's vo_gpu_next, FFmpeg's vf_libplacebo) uses the API: the scaler is
+ * selected BY NAME through the preset tables (pl_find_filter_preset, filters.h:316-329) and targets
+ * are cleared with pl_frame_clear_rgba / pl_frame_clear_tiles (renderer.h:672-690) -- the entry
+ * points VERDICT r03 found missing from the library. The frame is followed in the output file by a
+ * 32 x 16 frame cleared to one colour and the same frame cleared to tiles.
+ *
  * usage: render_frame <out.raw> [src_w src_h]
  */
 #include <math.h>
@@ -94,7 +100,23 @@ int main(int argc, char **argv)
 
     pl_renderer rr = pl_renderer_create(log, gpu);
     struct pl_render_params params = pl_render_fast_params;
-    params.upscaler = &pl_filter_ewa_lanczos;
+    const struct pl_filter_preset *preset = pl_find_filter_preset("ewa_lanczos");
+    if (!preset || preset->filter != &pl_filter_ewa_lanczos || !preset->description)
+        die("pl_find_filter_preset(\"ewa_lanczos\")");
+    if (pl_find_filter_preset("no such filter") || !pl_find_filter_preset("none") ||
+        pl_find_filter_preset("none")->filter || pl_find_filter_preset("triangle")->filter != &pl_filter_bilinear)
+        die("pl_find_filter_preset: none / aliases / unknown names");
+    const struct pl_filter_function_preset *fpreset = pl_find_filter_function_preset("jinc");
+    if (!fpreset || fpreset->function != &pl_filter_function_jinc || pl_find_filter_function_preset("nope"))
+        die("pl_find_filter_function_preset");
+    int counted = 0;
+    while (pl_filter_presets[counted].name)
+        counted++;
+    if (counted != pl_num_filter_presets || pl_filter_function_presets[pl_num_filter_function_presets].name)
+        die("preset tables are not {0}-terminated at their advertised length");
+    params.upscaler = preset->filter;
+    // (the whole target is drawn over: what the clear leaves must not show)
+    pl_frame_clear_rgba(gpu, &target, (const float[4]) {1.0f, 0.0f, 1.0f, 1.0f});
     if (!pl_render_image(rr, &image, &target, &params))
         die("pl_render_image failed");
     if (pl_renderer_get_errors(rr).errors)
@@ -108,7 +130,28 @@ int main(int argc, char **argv)
     if (!f)
         die("cannot open the output file");
     fwrite(out, sizeof(uint16_t), (size_t) dw * dh * 4, f);
+
+    // a small frame of its own, cleared to a colour and then to tiles
+    enum { CW = 32, CH = 16 };
+    pl_tex small = pl_tex_create(gpu, pl_tex_params(
+        .w = CW, .h = CH, .format = fmt,
+        .renderable = true, .storable = true, .blit_dst = true, .host_readable = true,
+    ));
+    if (!small)
+        die("texture creation failed");
+    struct pl_frame cleared = target;
+    cleared.planes[0].texture = small;
+    uint16_t texels[CW * CH * 4];
+    pl_frame_clear_rgba(gpu, &cleared, (const float[4]) {0.25f, 0.5f, 0.75f, 0.5f});
+    if (!pl_tex_download(gpu, pl_tex_transfer_params(.tex = small, .ptr = texels)))
+        die("download failed");
+    fwrite(texels, sizeof(uint16_t), CW * CH * 4, f);
+    pl_frame_clear_tiles(gpu, &cleared, pl_render_default_params.tile_colors, 4);
+    if (!pl_tex_download(gpu, pl_tex_transfer_params(.tex = small, .ptr = texels)))
+        die("download failed");
+    fwrite(texels, sizeof(uint16_t), CW * CH * 4, f);
     fclose(f);
+    pl_tex_destroy(gpu, &small);
 
     uint64_t sum = 0;
     for (size_t i = 0; i < (size_t) dw * dh * 4; i++)

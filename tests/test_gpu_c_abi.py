@@ -31,7 +31,22 @@ def test_c_program_renders_through_the_c_abi(gpu, tmp_path):
     ours = os.path.join(BUILD, "render_frame_ours")
     assert os.path.exists(ours), "tests/c/build/render_frame_ours missing: run build()"
     log = run("render_frame_ours", str(tmp_path / "ours.raw"), sw, sh)
-    got = np.fromfile(tmp_path / "ours.raw", np.uint16).reshape(2 * sh, 2 * sw, 4)
+    raw = np.fromfile(tmp_path / "ours.raw", np.uint16)
+    n = 2 * sh * 2 * sw * 4
+    got = raw[:n].reshape(2 * sh, 2 * sw, 4)
+    # pl_frame_clear_rgba / pl_frame_clear_tiles on a 32 x 16 sRGB frame (renderer.c:4116-4199):
+    # one colour, alpha included; then 4-texel tiles of the default colours, alpha 1
+    cleared, tiles = raw[n:n + 32 * 16 * 4].reshape(16, 32, 4), raw[n + 32 * 16 * 4:].reshape(16, 32, 4)
+    want = np.rint(np.float32([0.25, 0.5, 0.75, 0.5]).astype(np.float64) * 65535).astype(np.uint16)
+    assert np.all(cleared == want), cleared[0, 0]
+    yy, xx = np.mgrid[0:16, 0:32]
+    kx = np.float32(1.0 / 4)
+    fx = (np.float32(xx + 0.5) * kx) % 1 < 0.5
+    fy = (np.float32(yy + 0.5) * kx) % 1 < 0.5
+    c0, c1 = (np.uint16(round(np.float32(v) * 65535.0)) for v in (0.93, 0.87))
+    assert np.array_equal(tiles[..., 0], np.where(fx == fy, c0, c1)), (tiles[0, :9, 0], c0, c1)
+    assert np.all(tiles[..., 1] == tiles[..., 0]) and np.all(tiles[..., 2] == tiles[..., 0])
+    assert np.all(tiles[..., 3] == 65535)
 
     # the same frame through the oracle (pattern = the C program's, bench.c:32-51)
     yc, xc = (sh - 1) / 2.0, (sw - 1) / 2.0
@@ -54,8 +69,8 @@ def test_c_program_renders_through_the_c_abi(gpu, tmp_path):
     if not os.path.exists(os.path.join(BUILD, "render_frame_ref")):
         pytest.skip("render_frame_ref was not built (reference headers absent at build time)")
     log2 = run("render_frame_ref", str(tmp_path / "ref.raw"), sw, sh)
-    got2 = np.fromfile(tmp_path / "ref.raw", np.uint16).reshape(2 * sh, 2 * sw, 4)
-    assert np.array_equal(got2, got), (log, log2)
+    raw2 = np.fromfile(tmp_path / "ref.raw", np.uint16)
+    assert np.array_equal(raw2, raw), (log, log2)
     # both report the reference's struct sizes
     assert "sizeof(pl_frame)=736" in log and "sizeof(pl_frame)=736" in log2, (log, log2)
 

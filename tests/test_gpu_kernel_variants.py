@@ -531,7 +531,9 @@ def test_sdr_chain_equals_interpreter(gpu, scaler, size):
     params = pl.render_params("default", upscaler=pl.filter_config(scaler))
     outs = []
     for chain in ("1", "0"):
-        with _env("PL_HIP_MAP_CHAIN", chain), _env("PL_HIP_POLAR_MFMA", "1"):
+        # ("2": the matrix-pipe kernel even though the library keeps linear-light passes off it --
+        # its CHAIN epilogue against its interpreter epilogue, tests/test_gpu_default_kernels.py)
+        with _env("PL_HIP_MAP_CHAIN", chain), _env("PL_HIP_POLAR_MFMA", "2"):
             outs.append(render(gpu, img, 2 * sw, 2 * sh, params, True, {}))
     assert np.array_equal(outs[0], outs[1]) and outs[0][..., :3].std() > 1000
 

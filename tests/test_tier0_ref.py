@@ -70,6 +70,65 @@ def test_every_filter_config_lut_bit_identical(libs):
                 assert bits_equal(res[0][4], res[1][4]), (rc.name, blur, cutoff)
 
 
+class FilterPreset(C.Structure):
+    _fields_ = [("name", C.c_char_p), ("filter", C.POINTER(capi.FilterConfig)),
+                ("description", C.c_char_p)]
+
+
+class FilterFunctionPreset(C.Structure):
+    _fields_ = [("name", C.c_char_p), ("function", C.POINTER(capi.FilterFunction))]
+
+
+def test_filter_preset_tables_match_the_reference(libs):
+    """pl_filter_presets / pl_filter_function_presets (the older name -> object tables players
+    select scalers through, filters.h:175-185, 316-329): same entries in the same order, the same
+    descriptions, each naming the equivalent object; pl_find_*_preset agree on every name."""
+    ref, our = libs
+    for lib in libs:
+        lib.pl_find_filter_preset.restype = C.POINTER(FilterPreset)
+        lib.pl_find_filter_preset.argtypes = [C.c_char_p]
+        lib.pl_find_filter_function_preset.restype = C.POINTER(FilterFunctionPreset)
+        lib.pl_find_filter_function_preset.argtypes = [C.c_char_p]
+    n = C.c_int.in_dll(ref, "pl_num_filter_presets").value
+    assert n == C.c_int.in_dll(our, "pl_num_filter_presets").value
+    RA = (FilterPreset * (n + 1)).in_dll(ref, "pl_filter_presets")
+    OA = (FilterPreset * (n + 1)).in_dll(our, "pl_filter_presets")
+    assert not RA[n].name and not OA[n].name
+    for i in range(n):
+        r, o = RA[i], OA[i]
+        assert (r.name, r.description) == (o.name, o.description), (i, r.name, o.name)
+        assert bool(r.filter) == bool(o.filter)
+        if r.filter:
+            rc, oc = r.filter.contents, o.filter.contents
+            assert (rc.name, rc.radius, rc.polar, rc.blur, rc.antiring, list(rc.params), rc.allowed) == \
+                   (oc.name, oc.radius, oc.polar, oc.blur, oc.antiring, list(oc.params), oc.allowed), r.name
+            assert rc.kernel.contents.name == oc.kernel.contents.name
+        f_r, f_o = ref.pl_find_filter_preset(r.name), our.pl_find_filter_preset(r.name)
+        assert f_r and f_o and f_o.contents.name == r.name
+        assert C.addressof(f_o.contents) == C.addressof(OA) + i * C.sizeof(FilterPreset)
+    assert not our.pl_find_filter_preset(b"nope") and not our.pl_find_filter_preset(None)
+
+    n = C.c_int.in_dll(ref, "pl_num_filter_function_presets").value
+    assert n == C.c_int.in_dll(our, "pl_num_filter_function_presets").value
+    RA = (FilterFunctionPreset * (n + 1)).in_dll(ref, "pl_filter_function_presets")
+    OA = (FilterFunctionPreset * (n + 1)).in_dll(our, "pl_filter_function_presets")
+    assert not RA[n].name and not OA[n].name
+    for i in range(n):
+        r, o = RA[i], OA[i]
+        assert r.name == o.name and bool(r.function) == bool(o.function), (i, r.name, o.name)
+        if r.function:
+            rf, of = r.function.contents, o.function.contents
+            assert (rf.name, rf.radius, rf.resizable, list(rf.params), list(rf.tunable)) == \
+                   (of.name, of.radius, of.resizable, list(of.params), list(of.tunable)), r.name
+        assert our.pl_find_filter_function_preset(r.name).contents.name == r.name
+    assert not our.pl_find_filter_function_preset(b"nope")
+    # the named members of the cubic family are objects of their own in both
+    for sym in ("bicubic", "bcspline", "catmull_rom", "mitchell", "robidoux", "robidouxsharp"):
+        rf = capi.FilterFunction.in_dll(ref, "pl_filter_function_" + sym)
+        of = capi.FilterFunction.in_dll(our, "pl_filter_function_" + sym)
+        assert (rf.name, list(rf.params), rf.radius) == (of.name, list(of.params), of.radius)
+
+
 def test_dither_matrices_bit_identical(libs):
     ref, our = libs
     for size in (2, 4, 8, 16, 64):
