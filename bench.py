@@ -129,6 +129,15 @@ class Stream:
         self.srcs = [self.g.tex_create(sw, sh, "rgba16", np.roll(frame, 7 * i, axis=1))
                      for i in range(pool)]
         self.dsts = [self.g.tex_create(dw, dh, "rgba16") for _ in range(pool)]
+        # every target is written once before anything is timed: device memory is mapped on
+        # first touch, and with the driver's short command (--steps 20 --warmup 5, a pool of 10)
+        # half of the timed frames would otherwise pay for mapping the 66 MB target they are the
+        # first to write -- setup, not rendering (inputs and outputs resident in HBM, as the
+        # contract asks)
+        black = (C.c_float * 4)(0.0, 0.0, 0.0, 1.0)
+        for t in self.dsts:
+            pl.lib().pl_tex_clear(self.g.gpu, t.ptr, black)
+        self.g.finish()
         self.pool = pool
         self.i = 0
         self.pass_ns = {}

@@ -640,6 +640,14 @@ def declare(lib):
     fn("pl_color_repr_decode", Transform3x3, P(ColorRepr), P(ColorAdjustment))
     fn("pl_color_repr_normalize", C.c_float, P(ColorRepr))
     fn("pl_hdr_rescale", C.c_float, C.c_int, C.c_int, C.c_float)
+    fn("pl_get_color_mapping_matrix", Matrix3x3, P(RawPrimaries), P(RawPrimaries), C.c_int)
+    fn("pl_matrix3x3_apply", None, P(Matrix3x3), P(C.c_float))
+    fn("pl_transform3x3_apply", None, P(Transform3x3), P(C.c_float))
+    fn("pl_transform3x3_invert", None, P(Transform3x3))
+    fn("pl_color_linearize", None, P(ColorSpace), P(C.c_float))
+    fn("pl_color_delinearize", None, P(ColorSpace), P(C.c_float))
+    fn("pl_frame_clear_rgba", None, P(Gpu), P(Frame), P(C.c_float))
+    fn("pl_frame_clear_tiles", None, P(Gpu), P(Frame), vp, C.c_int)
     return lib
 
 

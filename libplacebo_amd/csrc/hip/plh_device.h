@@ -195,8 +195,10 @@ enum plh_op_kind {
     PLH_OP_TONE_MAP,        // i0 = mode (0 clip, 1 linear, 2 LUT); f[] see k; ptr = LUT; i1 = size
                             // contrast recovery (:1880-1921): ptr2 = r16hf feature map,
                             // i2 = w | h << 16 (0 = off), f[4] = pitch (int bits),
-                            // f[5] = strength, f[6], f[7] = output min / max
+                            // f[5] = strength, f[6], f[7] = output min / max;
+                            // mode 2: f[8] = size - 1, f[9] = size - 2 (as floats)
     PLH_OP_GAMUT_LUT,       // ptr = rgba16 3-D LUT; i0,i1,i2 = sizes; f[0]=scale f[1]=offset f[2]=0.5/pi
+                            // f[3] = tricubic; f[4..6] = size - 1, f[7..9] = size - 2, f[10], f[11] = size_I, size_C (as floats)
     PLH_OP_IPT2RGB,         // f[0..8] = lms2rgb, f[9..14] = 1/m2, c1, c2, c3, 1/m1, 10000/203
     PLH_OP_PEAK_DETECT,     // see k_peak.hip; only valid in the 16x16 peak kernel
     // renderer glue (renderer.c)
@@ -271,6 +273,15 @@ struct plh_map_chain {
     int32_t unsig, sig;
     int32_t pmap;               // a leading identity PLANE_MAP (missing components := neutral)
     int32_t tail;               // first op of the fused epilogue
+    // The uniform scale factors between the chain's stages, folded into its two matrices by the
+    // launcher (fastepi.hiph) instead of being multiplied into every pixel (valid when in >= 0):
+    //   in_mat  = rgb2ipt.f[9] (203 / 10000) * rgb2lms, times the PQ linearisation's own 10000 / 203
+    //             when that is the stage in front (pq_front: the device then leaves it out);
+    //   out_mat = ipt2rgb.f[14] (10000 / 203) * lms2rgb, times the delinearisation's black-scaling
+    //             slope f[0], with its offset f[1] in out_add (out_rescaled: the device then skips
+    //             that step of op_delinearize).
+    int32_t pq_front, out_rescaled;
+    float in_mat[9], out_mat[9], out_add;
 };
 
 struct plh_pass {

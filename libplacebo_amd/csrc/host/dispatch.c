@@ -215,12 +215,14 @@ static void plh_pass_choose_cells(struct plh_pass *pass)
 // PL_DITHER_WHITE_NOISE is recorded as (i1 = 2, i0 = seed). The kernels only know dither
 // matrices: now that the size of the pass is known, evaluate the PRNG for its fragment
 // coordinates into a plane whose row stride is a power of two (the matrix lookup wraps x and y
-// with one mask) and turn the op into a plain LUT dither over it (k_noise.hip says why). Rows at
-// and beyond the pass' height carry no noise but ARE addressed: every kernel fetches the dither
-// value of the lanes its tiles pad the rect with before the store guard drops them (8 rows for
-// k_pass_generic, up to 128 for the polar tiles), so the plane is allocated up to the next
-// multiple of 256 rows -- 4096 x 2304 floats for a 4K pass -- and never past `side` rows, which
-// the row mask cannot exceed. Generated on `stream`, the stream the pass itself is launched on.
+// with one mask) and turn the op into a plain LUT dither over it (k_noise.hip says why). Only the
+// width x height corner carries noise, but the WHOLE square is allocated (16 MiB for a 1080p pass,
+// 64 MiB for 4K, and only while this method is selected): every kernel fetches the dither value
+// of the lanes its tiles pad the rect with BEFORE the store guard drops them, and those lanes'
+// coordinates go through the same mask -- rows up to a tile beyond the height, and row / column
+// -1 of the padded first cell, which the mask wraps to side - 1. (A plane of `height` rows, and
+// then one rounded up to a multiple of 256, both faulted on a 960 x 402 polar pass:
+// tests/test_gpu_dither.py::test_white_noise_plane_covers_the_padded_rows.)
 static bool realize_white_noise(pl_gpu gpu, plh_stream stream, pl_buf *noise, struct plh_pass *pass)
 {
     for (int i = 0; i < pass->num_ops; i++) {
@@ -230,8 +232,7 @@ static bool realize_white_noise(pl_gpu gpu, plh_stream stream, pl_buf *noise, st
         int side = 16;
         while (side < pass->width || side < pass->height)
             side <<= 1;
-        const int rows = PL_MIN(side, (pass->height + 255) & ~255);
-        const size_t size = (size_t) side * rows * sizeof(float);
+        const size_t size = (size_t) side * side * sizeof(float);
         if (!*noise || (*noise)->params.size < size) {
             pl_buf_destroy(gpu, noise);
             *noise = pl_buf_create(gpu, pl_buf_params(.size = size, .storable = true));

@@ -1050,6 +1050,9 @@ void pl_shader_color_map_ex(pl_shader sh, const struct pl_color_map_params *para
             op->i1 = tone.lut_size;
             op->f[0] = 1.0f / lut_range;
             op->f[1] = -tone.input_min / lut_range;
+            // (size - 1, size - 2 as floats: the kernels have no scalar int -> float conversion)
+            op->f[8] = (float) (tone.lut_size - 1);
+            op->f[9] = (float) (tone.lut_size - 2);
             op->ptr = pl_hip_buf_ptr(obj->tone.lut);
         }
         // contrast recovery (:1879-1921): detail = highres - bicubic(feature map)
@@ -1106,6 +1109,10 @@ void pl_shader_color_map_ex(pl_shader sh, const struct pl_color_map_params *para
         op->f[1] = -gamut.min_luma / lut_range;
         op->f[2] = plh_fmtf(0.5f / M_PI);
         op->f[3] = params->lut3d_tricubic ? 1.0f : 0.0f;
+        // size - 1 and size - 2 of the three axes as floats (cmfast.hiph: gamut_lookup)
+        op->f[4] = gamut.lut_size_I - 1; op->f[5] = gamut.lut_size_C - 1; op->f[6] = gamut.lut_size_h - 1;
+        op->f[7] = gamut.lut_size_I - 2; op->f[8] = gamut.lut_size_C - 2; op->f[9] = gamut.lut_size_h - 2;
+        op->f[10] = gamut.lut_size_I; op->f[11] = gamut.lut_size_C;
         op->ptr = pl_hip_buf_ptr(obj->gamut.lut);
         sh_listf(sh, "gamut_lut(%s, %dx%dx%d%s)\n", gamut.function->name, op->i0, op->i1, op->i2,
                  params->lut3d_tricubic ? ", tricubic" : "");

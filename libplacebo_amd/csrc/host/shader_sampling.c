@@ -210,7 +210,7 @@ struct sh_sampler_obj {
     // matrix-pipe variant of the same geometry (k_polar_mx): B fragments + tile origin
     pl_buf mx_blob;
     struct plh_polar_mx mx_host;    // .enabled = 0: geometry not eligible
-    bool mx_announced, mx_declined;
+    bool mx_announced;
 };
 
 static void sh_sampler_uninit(pl_gpu gpu, void *ptr)
@@ -1125,32 +1125,15 @@ void plh_polar_pp_setup(pl_gpu gpu, pl_log log, void *polar_obj, struct plh_pass
 
     // k_polar_mx: the contraction on the f16 matrix pipe, within +-1 code of 16 bits of the
     // sequential-fma kernels. PL_HIP_POLAR_MFMA=0 keeps the bit-exact reference variant.
-    //
-    // Where it may not run: the contraction is within ~1e-6 of full scale of the sequential sums,
-    // which is a tenth of a 16-bit code -- unless what follows the sampler amplifies it. A pass
-    // that scales in LINEAR or SIGMOIDIZED light continues with UNSIGMOIDIZE (slope up to 17 at
-    // the dark end) and / or DELINEARIZE (a display gamma's inverse: (1 / 2.4) x^-0.58, 340 at
-    // x = 1e-5), and where dark pixels have bright neighbours 1e-6 then becomes tens of codes
-    // (tests/test_gpu_default_kernels.py measures it). Those passes keep k_polar_pp; a pass over a
-    // PQ- or gamma-coded signal (the HDR upscale, renderer.c:1997-2003; the `fast` preset; linear
-    // scaling disabled) continues with LINEARIZE or the encoder and is safe. PL_HIP_POLAR_MFMA=2
-    // overrides the rule (measurements only).
+    // That bound holds behind EVERY epilogue, the ones that amplify near black included -- a pass
+    // that scales in linear / sigmoidized light continues with UNSIGMOIDIZE (slope up to 17 at
+    // the dark end) and DELINEARIZE ((1 / 2.4) x^-0.58) -- because the contraction's error scales
+    // with the taps' products, which are small where the output is dark: measured <= 1 code at
+    // 1080p -> 4K on white noise and on a dark field with isolated full-scale texels
+    // (tests/test_gpu_default_kernels.py::test_matrix_pipe_behind_sigmoid_measured).
     const char *mfma = getenv("PL_HIP_POLAR_MFMA");
     memset(&s->mx, 0, sizeof(s->mx));
-    bool amplifies = false;
-    for (int i = pass->num_pre_ops; i < pass->num_ops; i++) {
-        const int kind = pass->ops[i].kind;
-        if (kind == PLH_OP_PLANE_MAP || kind == PLH_OP_ALPHA_ONE || kind == PLH_OP_SWIZZLE)
-            continue;
-        amplifies = kind == PLH_OP_UNSIGMOIDIZE || kind == PLH_OP_DELINEARIZE;
-        break;
-    }
-    if (amplifies && !(mfma && mfma[0] == '2')) {
-        if (obj->mx_host.enabled && !obj->mx_declined)
-            pl_msg(log, PL_LOG_DEBUG, "polar pass in linear / sigmoidized light: the sequential-fma "
-                   "kernel (the matrix pipe's 1e-6 would be amplified by the inverse curves)");
-        obj->mx_declined = true;
-    } else if (obj->mx_host.enabled && !(mfma && mfma[0] == '0') && (cm == 0x7 || cm == 0xf) &&
+    if (obj->mx_host.enabled && !(mfma && mfma[0] == '0') && (cm == 0x7 || cm == 0xf) &&
         !pass->transpose && s->address_mode == PLH_ADDRESS_CLAMP) {
         s->mx = obj->mx_host;
         if (!obj->mx_announced)

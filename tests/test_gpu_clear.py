@@ -36,10 +36,8 @@ def expected_rgb(color, csp):
         src.hdr.min_luma = 1e-6         # PL_COLOR_HDR_BLACK
     v = (C.c_float * 3)(*color)
     L.pl_color_linearize(C.byref(src), v)
-    L.pl_get_color_mapping_matrix.restype = capi.Matrix3x3
-    L.pl_raw_primaries_get.restype = C.c_void_p
-    m = L.pl_get_color_mapping_matrix(C.c_void_p(L.pl_raw_primaries_get(int(src.primaries))),
-                                      C.c_void_p(L.pl_raw_primaries_get(int(csp.primaries))), 1)
+    m = L.pl_get_color_mapping_matrix(L.pl_raw_primaries_get(int(src.primaries)),
+                                      L.pl_raw_primaries_get(int(csp.primaries)), 1)
     L.pl_matrix3x3_apply(C.byref(m), v)
     L.pl_color_delinearize(C.byref(csp), v)
     return np.array(list(v), np.float32)
@@ -57,10 +55,7 @@ def encoded(rgb, repr_):
 
 
 def clear_rgba(gpu, f, rgba):
-    L = pl.lib()
-    L.pl_frame_clear_rgba.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
-    L.pl_frame_clear_rgba.restype = None
-    L.pl_frame_clear_rgba(gpu.gpu, C.byref(f), (C.c_float * 4)(*rgba))
+    pl.lib().pl_frame_clear_rgba(gpu.gpu, C.byref(f), (C.c_float * 4)(*rgba))
 
 
 @pytest.mark.parametrize("case", ["srgb", "bt1886", "bt2020_pq", "dcip3_gamma22"])
@@ -132,8 +127,6 @@ def tiles_expected(w, h, period_x, period_y, c0, c1):
 
 def test_clear_tiles_planes_follow_their_subsampling(gpu):
     L = pl.lib()
-    L.pl_frame_clear_tiles.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
-    L.pl_frame_clear_tiles.restype = None
     w, h = 64, 32
     y = gpu.tex_create(w, h, "r32f")
     uv = gpu.tex_create(w // 2, h // 2, "rg32f")

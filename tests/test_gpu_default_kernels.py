@@ -20,14 +20,13 @@ involved, 0 where none is. After the dither: every sample is the dither of the f
 pre-dither value with the oracle's matrix cell (dither index path bit-exact), as in
 tests/test_gpu_metric.py.
 
-Where the matrix pipe may NOT run. The contraction is within ~1e-6 of full scale of the
-sequential-fma sums (fp32 sums in another order inside the MFMA). Behind a PQ-coded or gamma-coded
-upscale that is a tenth of a code. Behind a LINEAR-LIGHT / sigmoidized upscale the epilogue
-amplifies it near black -- unsigmoidize by up to 17x (its slope at y = 0.0076), the display gamma's
-inverse by (1 / 2.4) x^-0.58, i.e. 340x at x = 1e-5 -- so on content whose dark pixels have bright
-neighbours (white noise) 1e-6 becomes tens of codes. Such passes therefore stay on k_polar_pp
-(csrc/host/shader_sampling.c: plh_polar_pp_setup) and this file checks BOTH halves: the kernel
-choice, and that the frame is then within a code of the oracle.
+Behind an epilogue that amplifies near black. A pass that scales in LINEAR / sigmoidized light
+continues with unsigmoidize (slope up to 17 at y = 0.0076) and the display gamma's inverse
+((1 / 2.4) x^-0.58, 340 at x = 1e-5); VERDICT r03 asked whether the contraction's ~1e-6 of full
+scale survives that. It does: its error scales with the tap products, which are small where the
+output is dark -- <= 1 code at 1080p -> 4K on white noise and on a dark field with isolated
+full-scale texels ("stars": every dark output within three texels of a star is a small difference
+of large products), test_matrix_pipe_behind_sigmoid. So the default preset stays on the matrix pipe.
 """
 import ctypes as C
 import os
@@ -71,6 +70,9 @@ def repr_bits(depth, container):
                          bit_shift=container - depth)
 
 
+LAST_LOG = []
+
+
 def render(img, dw, dh, params, mfma, dst_fmt="rgba16", target_repr=None, src_fmt="rgba16",
            image_color=None, target_color=None, extra_env=None):
     """one frame through pl_render_image on a fresh backend; returns (frame, used the matrix pipe)"""
@@ -88,6 +90,7 @@ def render(img, dw, dh, params, mfma, dst_fmt="rgba16", target_repr=None, src_fm
             assert rr.errors() == 0
             out = dst.download()
             used = any("polar on the matrix pipe" in m for _, m in g.messages)
+            LAST_LOG[:] = [m for _, m in g.messages if "matrix" in m or "polar" in m]
             rr.destroy(); src.destroy(); dst.destroy()
     return out, used
 
@@ -102,6 +105,15 @@ def report(tag, d):
 
 
 def content(kind, w, h):
+    if kind == "stars":
+        # the worst case for an epilogue that amplifies near black: a dark, slightly noisy field
+        # (codes 600 .. 3000 of 65535) with isolated full-scale texels -- every dark output within
+        # three texels of a star is a small difference of large tap products
+        rng = np.random.default_rng(8)
+        img = rng.integers(600, 3000, (h, w, 4)).astype(np.uint16)
+        img[rng.random((h, w)) < 0.01] = 65535
+        img[..., 3] = 65535
+        return img
     return util.chirp_rgba16(w, h) if kind == "chirp" else util.random_rgba16(w, h, seed=5)
 
 
@@ -156,9 +168,10 @@ def inferred(csp):
 @pytest.mark.parametrize("size", [(166, 93), P1080])
 @pytest.mark.parametrize("kind", ["chirp", "noise"])
 def test_default_preset_sdr_2x_ewa(size, kind):
-    """pl_render_default_params, upscaler = ewa_lanczos, BT.709 / BT.1886 in and out. The upscale
-    runs in sigmoidized linear light: NOT on the matrix pipe (module docstring). Held to the
-    oracle: <= 1 code of 16 bits before the dither, the dither index path exact, rgba8 <= 1."""
+    """pl_render_default_params, upscaler = ewa_lanczos, BT.709 / BT.1886 in and out: the upscale
+    runs in sigmoidized linear light, on the matrix pipe (non-PRE_LITE staging, CHAIN epilogue).
+    Held to k_polar_pp and to the oracle: <= 1 code of 16 bits before the dither, the dither
+    index path exact, rgba8 <= 1."""
     sw, sh = size
     dw, dh = 2 * sw, 2 * sh
     img = content(kind, sw, sh)
@@ -170,9 +183,12 @@ def test_default_preset_sdr_2x_ewa(size, kind):
 
     # the library as shipped (PL_HIP_POLAR_MFMA unset = 1): which kernel, and what it renders
     pre, used = render(img, dw, dh, nodither, True, **kw)
-    assert not used, "a sigmoidized linear-light upscale must stay on the sequential-fma kernel"
-    pre_pp, _ = render(img, dw, dh, nodither, False, **kw)
-    assert np.array_equal(pre, pre_pp)
+    assert used
+    pre_pp, used_pp = render(img, dw, dh, nodither, False, **kw)
+    assert not used_pp
+    d = codes(pre, pre_pp)
+    report("default preset SDR 2x %dx%d %s, matrix pipe vs k_polar_pp" % (sw, sh, kind), d)
+    assert d.max() <= 1 and (d > 0).mean() < 0.05, (d.max(), (d > 0).mean())
 
     # ---- stage by stage (each stage fed the GPU's output of the previous one), then end to end.
     # PASS A ends in an rgba16hf store: where native pow and libm put a value on different sides
@@ -187,9 +203,11 @@ def test_default_preset_sdr_2x_ewa(size, kind):
           "max %d ulp" % (sw, sh, kind, (ulps > 0).mean(), ulps.max()))
     assert ulps.max() <= 1 and (ulps > 0).mean() < 2e-3
     ref_b = oracle_pass_b(fbo.astype(np.float32), dw, dh, csp_i)
-    d = codes(pre, orc.tex_encode(ref_b, "rgba16"))
-    report("default preset SDR 2x %dx%d %s, PASS B vs oracle on the GPU's intermediate" % (sw, sh, kind), d)
-    assert d.max() <= 1 and (d > 0).mean() < 0.25, (d.max(), (d > 0).mean())
+    ref_b16 = orc.tex_encode(ref_b, "rgba16")
+    for tag, frame in (("k_polar_pp", pre_pp), ("matrix pipe", pre)):
+        d = codes(frame, ref_b16)
+        report("   PASS B, %s vs oracle on the GPU's intermediate" % tag, d)
+        assert d.max() <= 1 and (d > 0).mean() < 0.05, (tag, d.max(), (d > 0).mean())
     ref = oracle_pass_b(want.astype(np.float32), dw, dh, csp_i)
     ref16 = orc.tex_encode(ref, "rgba16")
     d = codes(pre, ref16)
@@ -212,26 +230,25 @@ def test_default_preset_sdr_2x_ewa(size, kind):
     assert d8.max() <= 1 and (d8 > 0).mean() < 0.01, (d8.max(), (d8 > 0).mean())
 
 
-@pytest.mark.parametrize("kind", ["chirp", "noise"])
-def test_matrix_pipe_behind_sigmoid_measured(kind):
-    """What the gate above protects against, measured (PL_HIP_POLAR_MFMA=2 forces the matrix pipe
-    for passes whose epilogue amplifies): the forced frame vs the sequential-fma one. Smooth
-    content stays within a code; white noise does not -- which is why the default is what it is.
-    The assertion is on the smooth case only; the noise figure is printed for DESIGN.md."""
-    sw, sh = 480, 270
+@pytest.mark.parametrize("kind,size", [("chirp", (480, 270)), ("noise", P1080), ("stars", P1080)])
+def test_matrix_pipe_behind_sigmoid(kind, size):
+    """The matrix pipe behind unsigmoidize + delinearize (module docstring), in codes of 16 bits
+    against the sequential-fma kernel, with the dark samples -- where the inverse curves amplify
+    -- reported on their own."""
+    sw, sh = size
     img = content(kind, sw, sh)
     csp = pl.color_space("bt709", "bt1886")
     kw = dict(image_color=csp, target_color=csp)
     p = pl.render_params("default", upscaler=pl.filter_config("ewa_lanczos"), dither_params=None)
     pp, _ = render(img, 2 * sw, 2 * sh, p, False, **kw)
-    with env(PL_HIP_POLAR_MFMA="2"):
-        forced, used = render(img, 2 * sw, 2 * sh, p, True, extra_env={"PL_HIP_POLAR_MFMA": "2"}, **kw)
+    mx, used = render(img, 2 * sw, 2 * sh, p, True, **kw)
     assert used
-    d = codes(forced, pp)
-    report("matrix pipe FORCED behind unsigmoidize + delinearize, %s" % kind, d)
-    print("   quantiles (50, 99, 99.9, 100 %%): %s" % np.quantile(d, (0.5, 0.99, 0.999, 1.0)))
-    if kind == "chirp":
-        assert d.max() <= 2
+    d = codes(mx, pp)
+    report("matrix pipe behind unsigmoidize + delinearize, %s %dx%d" % (kind, sw, sh), d)
+    dark = pp[..., :3] < 4000
+    print("   among the %.3f of samples below code 4000: max %d, > 0 on %.4f" %
+          (dark.mean(), int(d[dark].max()), float((d[dark] > 0).mean())))
+    assert d.max() <= 1 and (d > 0).mean() < 0.05
 
 
 @pytest.mark.parametrize("size", [(166, 93), P1080])
@@ -271,23 +288,20 @@ def test_gamma_light_2x_ewa_on_the_matrix_pipe(size):
 @pytest.mark.parametrize("kind", ["chirp", "noise"])
 def test_high_quality_preset_2x(kind):
     """pl_render_high_quality_params at 2x on SDR video (ewa_lanczossharp in sigmoidized linear
-    light, debanding in front: the scaler reads an rgba16hf intermediate): the kernel the library
-    picks vs the sequential-fma kernel -- identical, because the sigmoid gate applies -- and, with
-    linear scaling off, the matrix pipe within a code of it."""
+    light, debanding in front: the scaler reads an rgba16hf intermediate), and the same with linear
+    scaling off: the matrix pipe within a code of the sequential-fma kernel."""
     sw, sh = 320, 180
     img = content(kind, sw, sh)
     csp = pl.color_space("bt709", "bt1886")
     kw = dict(image_color=csp, target_color=csp)
-    p = pl.render_params("high_quality", dither_params=None)
-    got, used = render(img, 2 * sw, 2 * sh, p, True, **kw)
-    pp, _ = render(img, 2 * sw, 2 * sh, p, False, **kw)
-    assert not used and np.array_equal(got, pp)
-    p = pl.render_params("high_quality", dither_params=None, disable_linear_scaling=True)
-    mx, used = render(img, 2 * sw, 2 * sh, p, True, **kw)
-    pp, _ = render(img, 2 * sw, 2 * sh, p, False, **kw)
-    d = codes(mx, pp)
-    report("high_quality 2x (gamma light) %s, matrix pipe vs k_polar_pp" % kind, d)
-    assert used and d.max() <= 1 and (d > 0).mean() < 0.15
+    for linear in (True, False):
+        p = pl.render_params("high_quality", dither_params=None, disable_linear_scaling=not linear)
+        mx, used = render(img, 2 * sw, 2 * sh, p, True, **kw)
+        pp, _ = render(img, 2 * sw, 2 * sh, p, False, **kw)
+        d = codes(mx, pp)
+        report("high_quality 2x (%s light) %s, matrix pipe vs k_polar_pp" %
+               ("sigmoidized linear" if linear else "gamma", kind), d)
+        assert used and d.max() <= 1 and (d > 0).mean() < 0.15
 
 
 @pytest.mark.parametrize("post", ["lite", "full"])
@@ -315,7 +329,7 @@ def test_interpreter_epilogues_behind_a_plain_encode(post):
         assert used and d.max() <= 1 and (d > 0).mean() < 0.15, (used, d.max(), (d > 0).mean())
 
 
-@pytest.mark.parametrize("size", [((332, 188), (166, 94)), ((3840, 2160), P1080)])
+@pytest.mark.parametrize("size", [((600, 340), (300, 170)), ((3840, 2160), P1080)])
 def test_ewa_4k_to_1080p_dither10_through_the_renderer(size):
     """bench.py's `ewa_lanczos_4k_to_1080p_dither10`: the plain SDR downscale (widened EWA-Lanczos,
     148 taps, gamma light), 10-bit blue-noise dither, ONE k_polar_mxd launch (rgba16 source decoded
@@ -332,7 +346,7 @@ def test_ewa_4k_to_1080p_dither10_through_the_renderer(size):
                                     dither_params=blue() if dither else None,
                                     disable_linear_scaling=True, disable_dither_gamma_correction=True)
         mx, used = render(img, dw, dh, params(False), True, **kw)
-        assert used
+        assert used, LAST_LOG
         pp, used_pp = render(img, dw, dh, params(False), False, **kw)
         assert not used_pp
         a = orc.op_quant_f16(orc.tex_decode(img, "rgba16"))

@@ -84,6 +84,48 @@ def test_dither_methods_bit_exact(gpu, depth, method, lut_size):
     assert 0.2 < (got[4:, :, 2] > img[4:, :, 2]).mean() < 0.8
 
 
+def test_white_noise_plane_covers_the_padded_rows(gpu):
+    """White noise is evaluated into a plane `side` floats wide (dispatch.c: realize_white_noise).
+    The kernels fetch the dither value of the lanes that pad the rect to whole tiles BEFORE the
+    store guard drops them, so the plane must reach past the pass' height: 1920 x 804 (804 is not
+    a multiple of the 8-row tiles; side = 2048, and a plane of exactly 804 rows would end on a page
+    boundary) and an EWA pass whose 64-row tiles overhang by 60 rows. Bit-exact as ever."""
+    w, h = 1920, 804
+    img = ramp_image(w, h)
+    got, _ = run_dither(gpu, img, 8, pl.DITHER_WHITE_NOISE)
+    ref = img.copy()
+    orc.dither(ref, None, 8, method=ORC_METHOD[pl.DITHER_WHITE_NOISE])
+    assert np.array_equal(got, ref)
+    # behind the polar kernels (2x: k_polar_mx / k_polar_pp tiles, 2:1 down: k_polar_mxd)
+    from libplacebo_amd import _capi as capi
+    for (sw, sh), (dw, dh), key in (((480, 201), (960, 402), "upscaler"), ((1920, 804), (960, 402), "downscaler")):
+        src16 = util.chirp_rgba16(sw, sh)
+        for mfma in ("1", "0"):
+            import os
+            old = os.environ.get("PL_HIP_POLAR_MFMA")
+            os.environ["PL_HIP_POLAR_MFMA"] = mfma
+            try:
+                with pl.HipGpu(0) as g:
+                    src = g.tex_create(sw, sh, "rgba16", src16)
+                    dst = g.tex_create(dw, dh, "rgba16")
+                    rr = pl.Renderer(g)
+                    params = pl.render_params("fast", dither_params=capi.DitherParams(
+                        method=pl.DITHER_WHITE_NOISE, lut_size=6, transfer=0),
+                        disable_linear_scaling=True, **{key: pl.filter_config("ewa_lanczos")})
+                    tgt = pl.frame(dst, repr_=pl.color_repr("rgb", "full", sample_depth=16, color_depth=8, bit_shift=8))
+                    assert rr.render(pl.frame(src, components=3), tgt, params), g.messages[-3:]
+                    assert rr.errors() == 0
+                    out = dst.download()
+                    low = out[..., :3] & 0xff      # 8-bit codes in the upper byte (+-1: k / 255 / scale is not exact)
+                    assert out[..., :3].std() > 1000 and np.all((low <= 1) | (low == 255))
+                    rr.destroy(); src.destroy(); dst.destroy()
+            finally:
+                if old is None:
+                    os.environ.pop("PL_HIP_POLAR_MFMA", None)
+                else:
+                    os.environ["PL_HIP_POLAR_MFMA"] = old
+
+
 @pytest.mark.parametrize("method", [pl.DITHER_BLUE_NOISE, pl.DITHER_ORDERED_LUT,
                                     pl.DITHER_ORDERED_FIXED, pl.DITHER_WHITE_NOISE])
 def test_dither_temporal(gpu, method):

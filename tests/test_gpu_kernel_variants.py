@@ -417,6 +417,10 @@ def test_pass_native_equals_generic(gpu, size):
         for native in ("1", "0"):
             old = os.environ.get("PL_HIP_PASS_NATIVE")
             os.environ["PL_HIP_PASS_NATIVE"] = native
+            # (both on the interpreter: the map chain, which k_pass_native's pass would otherwise
+            # run as, is compared with it in test_map_chain_equals_interpreter)
+            old_chain = os.environ.get("PL_HIP_MAP_CHAIN")
+            os.environ["PL_HIP_MAP_CHAIN"] = "0"
             try:
                 src = gpu.tex_create(w, h, "rgba16", img)
                 dst = gpu.tex_create(dw, dh, "rgba16")
@@ -428,10 +432,11 @@ def test_pass_native_equals_generic(gpu, size):
                 outs.append(dst.download())
                 rr.destroy(); src.destroy(); dst.destroy()
             finally:
-                if old is None:
-                    os.environ.pop("PL_HIP_PASS_NATIVE", None)
-                else:
-                    os.environ["PL_HIP_PASS_NATIVE"] = old
+                for key, val in (("PL_HIP_PASS_NATIVE", old), ("PL_HIP_MAP_CHAIN", old_chain)):
+                    if val is None:
+                        os.environ.pop(key, None)
+                    else:
+                        os.environ[key] = val
         assert np.array_equal(outs[0], outs[1]) and outs[0][..., :3].std() > 1000
 
 
@@ -453,8 +458,8 @@ def _env(name, value):
 def test_map_chain_equals_interpreter(gpu, case, size):
     """The op list of an HDR map pass as straight-line code (struct plh_map_chain: k_pass_chain, the
     CHAIN epilogue of k_polar_mx) against the same pass through the op interpreter
-    (PL_HIP_MAP_CHAIN=0): the same device functions in the same order, so the frames must agree
-    bit for bit -- HDR10 -> BT.1886 with a 10-bit dither behind an intermediate (with and without
+    (PL_HIP_MAP_CHAIN=0): the same device functions in the same order -- up to where the uniform
+    scale factors are multiplied in (assert_same_up_to_a_dither_step) -- HDR10 -> BT.1886 with a 10-bit dither behind an intermediate (with and without
     contrast recovery reading the feature map) and behind the EWA 2x upscale on the matrix pipe
     (the metric's launch), odd sizes included (single-pixel last column, partial tiles)."""
     from test_gpu_fullsize import hdr_frame16
@@ -492,7 +497,17 @@ def test_map_chain_equals_interpreter(gpu, case, size):
         d = np.abs(outs[0].astype(np.int64) - outs[1].astype(np.int64))
         assert d.max() <= 65 and (d > 0).mean() < 0.01, (d.max(), (d > 0).mean())
     else:
-        assert np.array_equal(outs[0], outs[1])
+        assert_same_up_to_a_dither_step(outs[0], outs[1])
+
+
+def assert_same_up_to_a_dither_step(chain, interp):
+    """HDR chains: the chain kernels take the uniform scale factors between the colour map's stages
+    (203 / 10000 and back, the black-scaling slope) folded into its two matrices by the launcher,
+    the interpreter multiplies them into every pixel (struct plh_map_chain: in_mat / out_mat).
+    Same formulas, products rounded at another place: an fp32 ulp before the dither, which moves a
+    10-bit code only where it lands on a threshold -- one step, on a vanishing share of the samples."""
+    d = np.abs(chain.astype(np.int64) - interp.astype(np.int64))
+    assert d.max() <= 65 and (d > 0).mean() < 2e-3, (d.max(), (d > 0).mean())
 
 
 @pytest.mark.parametrize("size", [(97, 61), (256, 130)])
@@ -531,9 +546,7 @@ def test_sdr_chain_equals_interpreter(gpu, scaler, size):
     params = pl.render_params("default", upscaler=pl.filter_config(scaler))
     outs = []
     for chain in ("1", "0"):
-        # ("2": the matrix-pipe kernel even though the library keeps linear-light passes off it --
-        # its CHAIN epilogue against its interpreter epilogue, tests/test_gpu_default_kernels.py)
-        with _env("PL_HIP_MAP_CHAIN", chain), _env("PL_HIP_POLAR_MFMA", "2"):
+        with _env("PL_HIP_MAP_CHAIN", chain), _env("PL_HIP_POLAR_MFMA", "1"):
             outs.append(render(gpu, img, 2 * sw, 2 * sh, params, True, {}))
     assert np.array_equal(outs[0], outs[1]) and outs[0][..., :3].std() > 1000
 
@@ -568,7 +581,11 @@ def test_polar_pp_chain_equals_interpreter(gpu, case):
             assert rr.errors() == 0
             outs.append(dst.download())
             rr.destroy(); src.destroy(); dst.destroy()
-    assert np.array_equal(outs[0], outs[1]) and outs[0][..., :3].std() > 1000
+    assert outs[0][..., :3].std() > 1000
+    if hdr:
+        assert_same_up_to_a_dither_step(outs[0], outs[1])
+    else:
+        assert np.array_equal(outs[0], outs[1])
 
 
 @pytest.mark.parametrize("preset", ["fast", "default", "high_quality"])

@@ -240,6 +240,14 @@ def test_metric_frame_kernel_variants_identical(gpu):
         out, m = render_once(gpu, img, 2 * sw, 2 * sh, metric_params(True), ten_bit(),
                              {**exact, **env})
         assert (m.max_pq_y, m.avg_pq_y) == (meta.max_pq_y, meta.avg_pq_y), env
+        if "PL_HIP_POLAR_PER_PIXEL" in env:
+            # the per-pixel kernel runs the colour map through the op interpreter, the others as the
+            # map chain, which takes the uniform scale factors folded into its matrices (struct
+            # plh_map_chain): an fp32 ulp before the dither = one 10-bit step on a few samples
+            # (tests/test_gpu_kernel_variants.py::assert_same_up_to_a_dither_step)
+            d = np.abs(out.astype(np.int64) - base.astype(np.int64))
+            assert d.max() <= 65 and (d > 0).mean() < 2e-3, (env, util.diff_stats(out, base))
+            continue
         assert np.array_equal(out, base), (env, util.diff_stats(out, base))
     # the matrix-pipe kernel: the same frame with and without the pass-structure switches
     mbase, _ = render_once(gpu, img, 2 * sw, 2 * sh, metric_params(True), ten_bit())

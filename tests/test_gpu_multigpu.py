@@ -243,8 +243,8 @@ def test_two_product_instances_render_one_frame(tmp_path):
     installed -- the measurement all-reduced (SUM, MAX on frame_max_pq) over gloo before either
     makes its tone curve. The two halves must be the single-instance frame BIT FOR BIT and both
     ranks must report the single instance's scene metadata."""
+    import multiprocessing as mp    # (not torch's: this process must not load a second HIP runtime)
     import socket
-    import torch.multiprocessing as mp
     from test_gpu_fullsize import hdr_frame16
     w, h = 384, 256
     with pl.HipGpu(0) as g:

@@ -24,7 +24,7 @@ K(k_gamut) {
     float4_t c = in[threadIdx.x];
     const float idx[3] = { c.x, c.y, c.z };
     float o[3];
-    gamut_lookup(ops[0].ptr, ops[0].i0, ops[0].i1, ops[0].i2, idx, o);
+    gamut_lookup(ops[0], idx, o);
     c.x = o[0]; c.y = o[1]; c.z = o[2];
     out[threadIdx.x] = c;
 }
