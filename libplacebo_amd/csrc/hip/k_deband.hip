@@ -126,13 +126,19 @@ void k_deband(const plh_pass p_)
 /*
  * k_deband_fast: the renderer's debanding pass as one small kernel -- a whole rgba16 plane at
  * native resolution (output pixel (x, y) sits on texel (x, y)), clamp addressing, RGB mask,
- * ops = [identity PLANE_MAP] [LINEARIZE], rgba16hf target. Same arithmetic as k_deband statement
- * for statement (the PRNG, the tap positions from the interpolated attribute, the order of the
- * four additions, op_linearize itself), bit-identical output (tests/test_gpu_ortho_deband.py
- * renders with both); what goes is what the general kernel pays for being general: the op
- * interpreter, format and address-mode switches, 64-bit address arithmetic, the alpha channel of
- * the four taps, half of the store instructions. Two horizontally adjacent pixels per lane: one
- * 16-byte load for the two centre texels, one 16-byte store.
+ * ops = [identity PLANE_MAP] [LINEARIZE], rgba16hf target. Same arithmetic as k_deband (the PRNG,
+ * the tap positions from the interpolated attribute, the comparison, op_linearize itself) with
+ * one exception: the four taps of a channel are summed AS INTEGERS and decoded once
+ * (S / 262140, one rounding) where the general kernel decodes each tap (v / 65535) and adds the
+ * floats (four roundings) -- 21 instead of 57 instructions per pixel, an average that is closer to
+ * the exact one, and an rgba16hf result that differs from the general kernel's by one f16 ulp on
+ * a fraction of a percent of the samples (tests/test_gpu_ortho_deband.py renders with both). What
+ * else goes is what the general kernel pays for being general: the op interpreter, format and
+ * address-mode switches, 64-bit address arithmetic (the taps: one 24-bit multiply-add against a
+ * uniform base), the alpha channel of the four taps and of a plane that has none, the IEEE
+ * division by the iteration count when there is one iteration, half of the store instructions.
+ * Two horizontally adjacent pixels per lane: one 16-byte load for the two centre texels, one
+ * 16-byte store.
  */
 #define DBF_BW 64
 #define DBF_BH 4
@@ -152,21 +158,25 @@ void k_deband_fast(const plh_pass p_)
     const int idy = by * DBF_BH + threadIdx.y;
     if (idx0 >= p.width || idy >= p.height)
         return;
-    const char *sp = (const char *) s.src.ptr;
+    typedef __attribute__((address_space(1))) const unsigned char gbyte;
+    gbyte *sp = (gbyte *) (uintptr_t) s.src.ptr;
     const uint32_t spitch = s.src.pitch;
     const int srcw = s.src.w, srch = s.src.h;
     const float sw = (float) srcw, sh = (float) srch;
     const bool has_map = p.num_ops == 2;    // [identity PLANE_MAP] LINEARIZE, or LINEARIZE alone
     const plh_op &o_map = p.ops[0], &o_lin = p.ops[p.num_ops - 1];
+    const bool has_alpha = !has_map || o_map.i1 >= 4;   // else alpha is the PLANE_MAP's neutral value
     const float my = p.out_scale[1] * ((float) idy + 0.5f);
 
     // the two centre texels (idx0 is even and rows are 256-byte aligned: 16-byte aligned)
     const bool two = idx0 + 1 < p.width;
+    const uint32_t coff = __umul24((uint32_t) idy, spitch) + ((uint32_t) idx0 << 3);
     uint4 centre;
     if (two) {
-        centre = *(const uint4 *) (sp + (uint32_t) idy * spitch + (uint32_t) idx0 * 8u);
+        const plh_u32x4 c4 = *(const __attribute__((address_space(1))) plh_u32x4 *) (sp + coff);
+        centre = make_uint4(c4.x, c4.y, c4.z, c4.w);
     } else {
-        const uint2 c0 = *(const uint2 *) (sp + (uint32_t) idy * spitch + (uint32_t) idx0 * 8u);
+        const plh_u32x2 c0 = *(const __attribute__((address_space(1))) plh_u32x2 *) (sp + coff);
         centre = make_uint4(c0.x, c0.y, c0.x, c0.y);
     }
 
@@ -177,8 +187,9 @@ void k_deband_fast(const plh_pass p_)
         const float mx = p.out_scale[0] * ((float) idx + 0.5f);
         const float px = plh_attr(s.pos, 0, mx, my), py = plh_attr(s.pos, 1, mx, my);
         const uint32_t cx = q ? centre.z : centre.x, cy = q ? centre.w : centre.y;
-        float4_t color = { plh_un16(cx & 0xffffu), plh_un16(cx >> 16), plh_un16(cy & 0xffffu),
-                           plh_un16(cy >> 16) };
+        float4_t color = { plh_un16(cx & 0xffffu), plh_un16(cx >> 16), plh_un16(cy & 0xffffu), 1.0f };
+        if (has_alpha)
+            color.w = plh_un16(cy >> 16);
         float res[3] = { color.x, color.y, color.z };
 
         prng3 st = { (uint32_t) ((float) (idx + p.frag_x0) + 0.5f),
@@ -191,7 +202,7 @@ void k_deband_fast(const plh_pass p_)
             const float dy = dx * __builtin_amdgcn_sinf(rev);
             dx = dx * __builtin_amdgcn_cosf(rev);
             const float ox[4] = { dx, -dx, -dx, dx }, oy[4] = { dy, dy, -dy, -dy };
-            uint2 raw[4];
+            plh_u32x2 raw[4];
 #pragma unroll
             for (int k = 0; k < 4; k++) {
                 const float qx = px + s.pt[0] * ox[k], qy = py + s.pt[1] * oy[k];
@@ -199,21 +210,22 @@ void k_deband_fast(const plh_pass p_)
                 // from floor only for negative v -- where both end up clamped to 0)
                 const int tx = min(max((int) (qx * sw), 0), srcw - 1);
                 const int ty = min(max((int) (qy * sh), 0), srch - 1);
-                raw[k] = *(const uint2 *) (sp + (uint32_t) ty * spitch + (uint32_t) tx * 8u);
+                // (pitch < 2^24 and rows < 2^24: one v_mad_u32_u24; the plane is < 4 GiB)
+                const uint32_t off = __umul24((uint32_t) ty, spitch) + ((uint32_t) tx << 3);
+                raw[k] = *(const __attribute__((address_space(1))) plh_u32x2 *) (sp + off);
             }
-            float avg[3] = {0.0f, 0.0f, 0.0f};
-#pragma unroll
-            for (int k = 0; k < 4; k++) {
-                avg[0] += plh_un16(raw[k].x & 0xffffu);
-                avg[1] += plh_un16(raw[k].x >> 16);
-                avg[2] += plh_un16(raw[k].y & 0xffffu);
-            }
-            const float bound = s.db_threshold / (float) i;
+            // the four taps of a channel: integer sum (< 2^18), one conversion, one product
+            const uint32_t s0 = (raw[0].x & 0xffffu) + (raw[1].x & 0xffffu) + (raw[2].x & 0xffffu) + (raw[3].x & 0xffffu);
+            const uint32_t s1 = (raw[0].x >> 16) + (raw[1].x >> 16) + (raw[2].x >> 16) + (raw[3].x >> 16);
+            const uint32_t s2 = (raw[0].y & 0xffffu) + (raw[1].y & 0xffffu) + (raw[2].y & 0xffffu) + (raw[3].y & 0xffffu);
+            const float avg[3] = { (float) s0 * (1.0f / 262140.0f), (float) s1 * (1.0f / 262140.0f),
+                                   (float) s2 * (1.0f / 262140.0f) };
+            // (i = 1, the presets' one iteration: no IEEE division)
+            const float bound = i == 1 ? s.db_threshold : s.db_threshold / (float) i;
 #pragma unroll
             for (int c = 0; c < 3; c++) {
-                const float a = avg[c] * 0.25f;
-                const float diff = __builtin_fabsf(res[c] - a);
-                res[c] = diff > bound ? res[c] : a;
+                const float diff = __builtin_fabsf(res[c] - avg[c]);
+                res[c] = diff > bound ? res[c] : avg[c];
             }
         }
         if (s.db_grain > 0.0f) {

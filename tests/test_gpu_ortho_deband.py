@@ -198,10 +198,13 @@ def test_deband_prng_is_temporal(gpu):
                                 dict(grain=0.0, threshold=8.0)])
 @pytest.mark.parametrize("size", [(201, 75), (128, 64)])
 @pytest.mark.parametrize("trc", ["pq", "bt1886"])
-def test_deband_fast_kernel_is_bit_identical(gpu, kw, size, trc, monkeypatch):
+def test_deband_fast_kernel_against_the_general_one(gpu, kw, size, trc, monkeypatch):
     """k_deband_fast (native-resolution rgba16 plane, [PLANE_MAP] LINEARIZE, rgba16hf target --
-    the renderer's debanding pass) against the general kernel (PL_HIP_DEBAND_FAST=0): the same
-    arithmetic, so the same f16 codes; odd widths exercise the single-pixel tail"""
+    the renderer's debanding pass) against the general kernel (PL_HIP_DEBAND_FAST=0). Same PRNG,
+    same tap positions, same comparison; the average of the four taps is the integer sum decoded
+    once (one rounding, closer to the exact average) where the general kernel adds four decoded
+    floats: the same f16 codes but for a fraction of a percent that land on the neighbouring code,
+    and none where no average is taken (iterations = 0). Odd widths exercise the single-pixel tail."""
     w, h = size
     img = util.random_rgba16(w, h, seed=17)
     t = gpu.tex_create(w, h, "rgba16", img)
@@ -216,5 +219,9 @@ def test_deband_fast_kernel_is_bit_identical(gpu, kw, size, trc, monkeypatch):
         assert sh.finish(d), gpu.messages[-3:]
         outs.append(d.download().view(np.uint16))
         d.destroy()
-    assert np.array_equal(outs[0], outs[1]), util.diff_stats(outs[0], outs[1])
+    if kw.get("iterations", 1) == 0:
+        assert np.array_equal(outs[0], outs[1]), util.diff_stats(outs[0], outs[1])
+    else:
+        ulps = np.abs(outs[0].astype(np.int64) - outs[1].astype(np.int64))
+        assert ulps.max() <= 1 and (ulps > 0).mean() < 5e-3, (ulps.max(), (ulps > 0).mean())
     t.destroy()
