@@ -60,6 +60,32 @@ def test_bilinear_fast_equals_generic(gpu, scale, ten_bit):
     assert outs[0][..., :3].std() > 1000
 
 
+@pytest.mark.parametrize("size", [((100, 58), (200, 116)), ((101, 59), (202, 118)), ((96, 64), (288, 128)),
+                                  ((1920, 1080), (3840, 2160))])
+@pytest.mark.parametrize("ten_bit", [False, True])
+def test_bilinear_tables_equal_per_pixel_geometry(gpu, size, ten_bit):
+    """k_bilinear_tab (geometry from per-column / per-row tables, proven for the geometry by
+    k_bilinear_tab_build) against k_bilinear_fast (PL_HIP_BILIN_TABLES=0: per-pixel attribute
+    interpolation, floor, fract) and the generic kernel: the same frames bit for bit -- 2x at even
+    and odd sizes, 3x2 (where a cell's two columns do not share a texel: the tables decline and
+    both runs are the per-pixel kernel), the BASELINE frame; rgba16hf source too."""
+    (sw, sh), (dw, dh) = size
+    img = util.chirp_rgba16(sw, sh)
+    kw = dict(dither_params=dither(), disable_dither_gamma_correction=True) if ten_bit else {}
+    params = pl.render_params("fast", **kw)
+    tab = render(gpu, img, dw, dh, params, ten_bit, {"PL_HIP_BILIN_TABLES": "1"})
+    per_px = render(gpu, img, dw, dh, params, ten_bit, {"PL_HIP_BILIN_TABLES": "0"})
+    assert np.array_equal(tab, per_px), util.diff_stats(tab, per_px)
+    if sw < 1000:
+        generic = render(gpu, img, dw, dh, params, ten_bit, {"PL_HIP_BILIN_ITERS": "0"})
+        assert np.array_equal(tab, generic)
+        f16 = (img.astype(np.float32) / 65535.0).astype(np.float16)
+        a = render(gpu, f16, dw, dh, params, ten_bit, {"PL_HIP_BILIN_TABLES": "1"}, src_fmt="rgba16hf")
+        b = render(gpu, f16, dw, dh, params, ten_bit, {"PL_HIP_BILIN_TABLES": "0"}, src_fmt="rgba16hf")
+        assert np.array_equal(a, b)
+    assert tab[..., :3].std() > 1000
+
+
 def test_bilinear_fast_crop_and_flip(gpu):
     sw, sh = 96, 64
     img = util.chirp_rgba16(sw, sh)
