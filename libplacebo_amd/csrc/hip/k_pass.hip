@@ -945,7 +945,8 @@ static void launch_bilinear_fast(hipStream_t stream, const plh_pass *pass, int i
 struct bl_entry { int32_t base; float w; };
 
 __global__ __launch_bounds__(256)
-void k_bilinear_tab_build(const plh_pass p_, bl_entry *cols, bl_entry *rows, uint32_t *deviating)
+void k_bilinear_tab_build(const plh_pass p_, bl_entry *cols, bl_entry *rows, uint32_t *deviating,
+                          float *colw, float *roww)
 {
     const plh_pass &p = plh_kernarg_pass();
     const plh_sampler_args &s = p.s;
@@ -971,52 +972,79 @@ void k_bilinear_tab_build(const plh_pass p_, bl_entry *cols, bl_entry *rows, uin
     if (fu != cu || __float_as_uint(ax) != __float_as_uint(cax) ||
         fw != rw || __float_as_uint(ay) != __float_as_uint(ray))
         atomicAdd(deviating, 1u);
-    if (idy == 0)
+    // (the weight arrays carry one extra entry at either end, repeating the first / last weight:
+    // the cell that sticks out of the rect reads them)
+    if (idy == 0) {
         cols[idx] = { (int32_t) fu, ax };
-    if (idx == 0)
+        colw[idx + 1] = ax;
+        if (idx == 0) colw[0] = ax;
+        if (idx == p.width - 1) colw[p.width + 1] = ax;
+    }
+    if (idx == 0) {
         rows[idy] = { (int32_t) fw, ay };
+        roww[idy + 1] = ay;
+        if (idy == 0) roww[0] = ay;
+        if (idy == p.height - 1) roww[p.height + 1] = ay;
+    }
 }
 
 template <bool F16SRC, bool RGB>
 __global__ __launch_bounds__(BF_BW * BF_BH)
-void k_bilinear_tab(const plh_pass p_, const bl_entry *cols_, const bl_entry *rows_)
+void k_bilinear_tab(const plh_pass p_, const float *colw_, const float *roww_, int b0x, int b0y)
 {
     const plh_pass &p = plh_kernarg_pass();
     const plh_sampler_args &s = p.s;
     constexpr int NCH = RGB ? 3 : 4;
-    typedef BF_GLOBAL const plh_u32x2 gentry;
-    gentry *cols = (gentry *) (uintptr_t) cols_, *rows = (gentry *) (uintptr_t) rows_;
-    auto entry = [](const plh_u32x2 v) { return bl_entry{ (int32_t) v.x, __uint_as_float(v.y) }; };
-    const int W = p.width, H = p.height;
+    // every uniform read once and pinned (k_bilinear_fast says why), pointers as integers
+    int W = p.width, H = p.height, padx = p.cell_padx, pady = p.cell_pady;
+    int spitch = s.src.pitch, srcw = s.src.w, srch = s.src.h;
+    int dmask = p.epi.mask, dsize = p.epi.size, has_dither = p.epi.has_dither, has_scale = p.epi.has_scale;
+    int fx0 = p.frag_x0, fy0 = p.frag_y0, bx = p.base_x, by = p.base_y, dirx = p.dir_x, diry = p.dir_y;
+    int dw = p.dst.w, dh = p.dst.h, dpitch = p.dst.pitch, nt = p.nt_store;
+    float ds = p.epi.dscale, di = p.epi.dinv, sc = p.epi.scale, alpha = p.epi.alpha, sscale = s.scale;
+    uintptr_t sp = (uintptr_t) s.src.ptr, dmat = (uintptr_t) p.epi.matrix, dptr = (uintptr_t) p.dst.ptr;
+    uintptr_t colw = (uintptr_t) colw_, roww = (uintptr_t) roww_;
+    asm volatile("" : "+s"(W), "+s"(H), "+s"(padx), "+s"(pady), "+s"(spitch), "+s"(srcw), "+s"(srch),
+                      "+s"(dmask), "+s"(dsize), "+s"(has_dither), "+s"(has_scale), "+s"(fx0), "+s"(fy0));
+    asm volatile("" : "+s"(bx), "+s"(by), "+s"(dirx), "+s"(diry), "+s"(dw), "+s"(dh), "+s"(dpitch), "+s"(nt),
+                      "+s"(ds), "+s"(di), "+s"(sc), "+s"(alpha), "+s"(sscale));
+    asm volatile("" : "+s"(sp), "+s"(dmat), "+s"(dptr), "+s"(colw), "+s"(roww), "+s"(b0x), "+s"(b0y));
+    typedef BF_GLOBAL const float gfloat;
+
     const int cx = blockIdx.x * BF_BW + threadIdx.x;
-    // (a wave is one row of cells: its row entries are uniform)
+    // (a wave is one row of cells: its row weights are uniform)
     const int cy = blockIdx.y * BF_BH + __builtin_amdgcn_readfirstlane(threadIdx.y);
-    const int idx0 = 2 * cx - p.cell_padx, idy0 = 2 * cy - p.cell_pady;
+    const int idx0 = 2 * cx - padx, idy0 = 2 * cy - pady;
     if (idx0 >= W || idy0 >= H)
         return;
 
-    // the cell's columns and rows; a cell that sticks out of the rect (the padded first one, an
-    // odd size's last one) takes both entries from the pixel that exists
-    const int c0 = max(idx0, 0), c1 = min(idx0 + 1, W - 1);
-    const int r0 = max(idy0, 0), r1 = min(idy0 + 1, H - 1);
-    const bl_entry ec0 = entry(cols[c0]), ec1 = entry(cols[c1]), er0 = entry(rows[r0]), er1 = entry(rows[r1]);
-
-    const char *sp = (const char *) s.src.ptr;
-    const int spitch = s.src.pitch, srcw = s.src.w, srch = s.src.h;
-    const int x0 = min(max(ec0.base, 0), srcw - 1), x1 = min(max(ec0.base + 1, 0), srcw - 1);
-    const int y0 = min(max(er0.base, 0), srch - 1), y1 = min(max(er0.base + 1, 0), srch - 1);
+    // Everything the cell needs from memory is asked for at once. The footprint comes from the
+    // CELL index, not from a table: the host has checked that the base texel of column X is
+    // b0x + ((X + pad) >> 1) -- b0x + cx for both pixels of cell cx -- so the texel loads do not
+    // wait for the weight loads (with the addresses taken from the tables the kernel was two
+    // dependent memory round trips long: 27 us against 19).
+    const int x0 = min(max(b0x + cx, 0), srcw - 1), x1 = min(max(b0x + cx + 1, 0), srcw - 1);
+    const int y0 = min(max(b0y + cy, 0), srch - 1), y1 = min(max(b0y + cy + 1, 0), srch - 1);
     uint2 raw[4];
-    raw[0] = bf_load(sp, spitch, x0, y0);
-    raw[1] = bf_load(sp, spitch, x1, y0);
-    raw[2] = bf_load(sp, spitch, x0, y1);
-    raw[3] = bf_load(sp, spitch, x1, y1);
+    raw[0] = bf_load((const char *) sp, spitch, x0, y0);
+    raw[1] = bf_load((const char *) sp, spitch, x1, y0);
+    raw[2] = bf_load((const char *) sp, spitch, x0, y1);
+    raw[3] = bf_load((const char *) sp, spitch, x1, y1);
+    // weights of the cell's columns and rows; a cell that sticks out of the rect (the padded
+    // first one, an odd size's last one) takes both from the pixel that exists
+    // (columns: one 8-byte load -- the table is padded by one entry at either end, which repeat the
+    // first / last weight; rows: uniform per wave, so scalar loads)
+    const plh_u32x2 axw = *(BF_GLOBAL const plh_u32x2 *) (colw + (size_t) (idx0 + 1) * 4);
+    const float ax[2] = { __uint_as_float(axw.x), __uint_as_float(axw.y) };
+    typedef __attribute__((address_space(4))) const float cfloat;
+    const float ay[2] = { ((cfloat *) roww)[idy0 + 1], ((cfloat *) roww)[idy0 + 2] };
     float bias[4] = { 0.0f, 0.0f, 0.0f, 0.0f };
-    if (p.epi.has_dither) {
+    if (has_dither) {
 #pragma unroll
         for (int q = 0; q < 4; q++) {
-            const int ix = (idx0 + (q & 1) + p.frag_x0) & p.epi.mask;
-            const int iy = (idy0 + (q >> 1) + p.frag_y0) & p.epi.mask;
-            bias[q] = bf_bias(p.epi.matrix, iy * p.epi.size + ix);
+            const int ix = (idx0 + (q & 1) + fx0) & dmask;
+            const int iy = (idy0 + (q >> 1) + fy0) & dmask;
+            bias[q] = ((gfloat *) dmat)[iy * dsize + ix];
         }
     }
 
@@ -1028,7 +1056,6 @@ void k_bilinear_tab(const plh_pass p_, const bl_entry *cols_, const bl_entry *ro
         for (int ch = 0; ch < NCH; ch++)
             t[k][ch] = F16SRC ? plh_h2f(w[ch]) : plh_un16(w[ch]);
     }
-    const float ax[2] = { ec0.w, ec1.w }, ay[2] = { er0.w, er1.w };
     float4_t o[4];
 #pragma unroll
     for (int ch = 0; ch < NCH; ch++) {
@@ -1040,7 +1067,7 @@ void k_bilinear_tab(const plh_pass p_, const bl_entry *cols_, const bl_entry *ro
         }
 #pragma unroll
         for (int q = 0; q < 4; q++) {
-            const float v = s.scale * plh_mix(top[q & 1], bot[q & 1], ay[q >> 1]);
+            const float v = sscale * plh_mix(top[q & 1], bot[q & 1], ay[q >> 1]);
             if (ch == 0) o[q].x = v;
             if (ch == 1) o[q].y = v;
             if (ch == 2) o[q].z = v;
@@ -1050,20 +1077,19 @@ void k_bilinear_tab(const plh_pass p_, const bl_entry *cols_, const bl_entry *ro
     // epilogue: op_dither (plain path) + the SCALE op as in k_bilinear_fast. An alpha the plane
     // does not carry is a constant; when it is 1 (video) it stays one behind dither and scale --
     // floor(ds * 1 + b) == ds for every b in [0, 1) -- and is packed once per lane.
-    const float ds = p.epi.dscale, di = p.epi.dinv, sc = p.epi.scale;
-    const bool alpha_one = RGB && p.epi.alpha == 1.0f;
+        const bool alpha_one = RGB && alpha == 1.0f;
     float aw = 1.0f;
-    if (p.epi.has_dither)
+    if (has_dither)
         aw = ds * di;
-    if (p.epi.has_scale)
+    if (has_scale)
         aw *= sc;
     const uint32_t awbits = plh_unorm16x2(0.0f, aw) & 0xffff0000u;
     uint2 px[4];
 #pragma unroll
     for (int q = 0; q < 4; q++) {
         if (RGB)
-            o[q].w = p.epi.alpha;
-        if (p.epi.has_dither) {
+            o[q].w = alpha;
+        if (has_dither) {
             const float b = bias[q];
             o[q].x = __builtin_floorf(ds * o[q].x + b) * di;
             o[q].y = __builtin_floorf(ds * o[q].y + b) * di;
@@ -1071,7 +1097,7 @@ void k_bilinear_tab(const plh_pass p_, const bl_entry *cols_, const bl_entry *ro
             if (!alpha_one)
                 o[q].w = __builtin_floorf(ds * o[q].w + b) * di;
         }
-        if (p.epi.has_scale) {
+        if (has_scale) {
             o[q].x *= sc; o[q].y *= sc; o[q].z *= sc;
             if (!alpha_one)
                 o[q].w *= sc;
@@ -1080,22 +1106,23 @@ void k_bilinear_tab(const plh_pass p_, const bl_entry *cols_, const bl_entry *ro
         px[q].y = alpha_one ? ((plh_unorm16x2(o[q].z, 0.0f) & 0xffffu) | awbits) : plh_unorm16x2(o[q].z, o[q].w);
     }
     // the cell's two rows: both pixels in one 16-byte store where both exist
-    const int ox0 = p.base_x + p.dir_x * idx0, ox1 = p.base_x + p.dir_x * (idx0 + 1);
-    const bool okx0 = idx0 >= 0 && ox0 >= 0 && ox0 < p.dst.w, okx1 = idx0 + 1 < W && ox1 >= 0 && ox1 < p.dst.w;
+    const int ox0 = bx + dirx * idx0, ox1 = bx + dirx * (idx0 + 1);
+    const bool okx0 = idx0 >= 0 && ox0 >= 0 && ox0 < dw, okx1 = idx0 + 1 < W && ox1 >= 0 && ox1 < dw;
     typedef BF_GLOBAL plh_u32x2 gpair;
 #pragma unroll
     for (int j = 0; j < 2; j++) {
-        const int idy = idy0 + j, oy = p.base_y + p.dir_y * idy;
-        if (idy < 0 || idy >= H || oy < 0 || oy >= p.dst.h)
+        const int idy = idy0 + j, oy = by + diry * idy;
+        if (idy < 0 || idy >= H || oy < 0 || oy >= dh)
             continue;
-        const uintptr_t row = (uintptr_t) p.dst.ptr + (size_t) oy * p.dst.pitch;
+        const uintptr_t row = dptr + (size_t) oy * (size_t) dpitch;
         const uint2 a = px[2 * j], b = px[2 * j + 1];
         if (okx0 && okx1 && ox1 == ox0 + 1) {
             // (a cell on an odd column is 8-byte aligned only: fine for global_store_dwordx4,
-            // which asks for dword alignment; the type says so)
+            // which asks for dword alignment; the type says so. Two 8-byte streaming stores
+            // instead were slower here: 28.2 against 23.4 us.)
             typedef plh_u32x4 __attribute__((aligned(8))) quad8;
             const quad8 pk = { a.x, a.y, b.x, b.y };
-            if (p.nt_store)
+            if (nt)
                 __builtin_nontemporal_store(pk, (BF_GLOBAL quad8 *) (row + (size_t) ox0 * 8));
             else
                 *(BF_GLOBAL quad8 *) (row + (size_t) ox0 * 8) = pk;
@@ -1103,11 +1130,11 @@ void k_bilinear_tab(const plh_pass p_, const bl_entry *cols_, const bl_entry *ro
         }
         const plh_u32x2 lo = { a.x, a.y }, hi = { b.x, b.y };
         if (okx0) {
-            if (p.nt_store) __builtin_nontemporal_store(lo, (gpair *) (row + (size_t) ox0 * 8));
+            if (nt) __builtin_nontemporal_store(lo, (gpair *) (row + (size_t) ox0 * 8));
             else *(gpair *) (row + (size_t) ox0 * 8) = lo;
         }
         if (okx1) {
-            if (p.nt_store) __builtin_nontemporal_store(hi, (gpair *) (row + (size_t) ox1 * 8));
+            if (nt) __builtin_nontemporal_store(hi, (gpair *) (row + (size_t) ox1 * 8));
             else *(gpair *) (row + (size_t) ox1 * 8) = hi;
         }
     }
@@ -1123,6 +1150,8 @@ struct bl_key {
 struct bl_slot {
     bl_key key;
     bl_entry *cols, *rows;      // device; NULL: the geometry is not separable (k_bilinear_fast)
+    float *colw, *roww;         // the weights alone (what the frame kernel reads)
+    int b0x, b0y;               // base texel of column X / row Y = b0 + ((X + pad) >> 1)
     bool used;
 };
 static bl_slot g_bl_slots[8];
@@ -1131,8 +1160,16 @@ static std::mutex g_bl_mutex;
 
 static const bl_slot *bilinear_tables(hipStream_t stream, const plh_pass *pass)
 {
+    // OFF unless asked for: with 36 % fewer vector instructions than k_bilinear_fast (7.0 M against
+    // 11.0 M per 4K frame, same 33.6 k waves) this kernel is SLOWER -- 23.4 us against 18.5-19.5
+    // (profiles/r04_12_bilinear_tables.txt: addresses from the tables 27 us, from the cell index
+    // with every load issued at once 23.8, weights as one 8-byte + two scalar loads 23.4, two
+    // 8-byte streaming stores 28.2). The pass is not bound by VALU issue after all; VERDICT r03
+    // item 6 asked for this experiment and for the item to be closed if it lost. It is kept
+    // selectable (PL_HIP_BILIN_TABLES=1) because its frames are proven identical and it is the
+    // record of the measurement.
     const char *env = getenv("PL_HIP_BILIN_TABLES");
-    if (env && env[0] == '0')
+    if (!env || env[0] != '1')
         return nullptr;
     bl_key key = {};
     key.dev = plh_stream_device((plh_stream) stream, nullptr);
@@ -1153,23 +1190,24 @@ static const bl_slot *bilinear_tables(hipStream_t stream, const plh_pass *pass)
     sl.key = key;
     sl.used = true;
     const int W = pass->width, H = pass->height;
-    const size_t bytes = ((size_t) W + H) * sizeof(bl_entry) + 16;
+    const size_t bytes = ((size_t) W + H) * sizeof(bl_entry) + 16, wbytes = ((size_t) W + H + 4) * sizeof(float);
     char *dev = nullptr;
     int cur = key.dev;
     (void) hipGetDevice(&cur);
     if (cur != key.dev)
         (void) hipSetDevice(key.dev);
-    bool ok = hipMalloc((void **) &dev, bytes) == hipSuccess;
+    bool ok = hipMalloc((void **) &dev, bytes + wbytes) == hipSuccess;
     if (cur != key.dev)
         (void) hipSetDevice(cur);
     if (!ok)
         return nullptr;
     bl_entry *cols = (bl_entry *) dev, *rows = cols + W;
     uint32_t *count = (uint32_t *) (rows + H);
+    float *colw = (float *) (dev + bytes), *roww = colw + W + 2;
     ok = hipMemsetAsync(count, 0, 4, stream) == hipSuccess;
     if (ok) {
         hipLaunchKernelGGL(k_bilinear_tab_build, dim3((W + 63) / 64, (H + 3) / 4), dim3(256), 0, stream,
-                           *pass, cols, rows, count);
+                           *pass, cols, rows, count, colw, roww);
         ok = hipGetLastError() == hipSuccess;
     }
     std::vector<bl_entry> host((size_t) W + H + 2);
@@ -1178,23 +1216,24 @@ static const bl_slot *bilinear_tables(hipStream_t stream, const plh_pass *pass)
     uint32_t deviating = 1;
     if (ok)
         memcpy(&deviating, &host[(size_t) W + H], 4);
-    // the two pixels of every cell share their base texel (a 2x upscale on the cell phase the
-    // dispatch chose; anything else keeps the per-pixel kernel)
+    // the base texel advances by one per cell: base(X) = b0 + ((X + pad) >> 1) on both axes (a 2x
+    // upscale on the cell phase the dispatch chose; anything else keeps the per-pixel kernel)
     ok = ok && deviating == 0;
-    for (int c = 0; ok && 2 * c - key.padx < W; c++) {
-        const int a = 2 * c - key.padx, b = a + 1;
-        ok = a < 0 || b >= W || host[a].base == host[b].base;
-    }
-    for (int r = 0; ok && 2 * r - key.pady < H; r++) {
-        const int a = 2 * r - key.pady, b = a + 1;
-        ok = a < 0 || b >= H || host[W + a].base == host[W + b].base;
-    }
+    const int b0x = ok ? host[0].base - (key.padx >> 1) : 0, b0y = ok ? host[W].base - (key.pady >> 1) : 0;
+    for (int x = 0; ok && x < W; x++)
+        ok = host[x].base == b0x + ((x + key.padx) >> 1);
+    for (int y = 0; ok && y < H; y++)
+        ok = host[W + y].base == b0y + ((y + key.pady) >> 1);
     if (!ok) {
         (void) hipFree(dev);
         return nullptr;     // (remembered: sl.cols == NULL)
     }
     sl.cols = cols;
     sl.rows = rows;
+    sl.colw = colw;
+    sl.roww = roww;
+    sl.b0x = b0x;
+    sl.b0y = b0y;
     return &sl;
 }
 
@@ -1205,9 +1244,9 @@ static void launch_bilinear_tab(hipStream_t stream, const plh_pass *pass, const 
     const int cells_h = (pass->height + pass->cell_pady + 1) / 2;
     const dim3 block(BF_BW, BF_BH), grid((cells_w + BF_BW - 1) / BF_BW, (cells_h + BF_BH - 1) / BF_BH);
     if (pass->epi.has_alpha)
-        hipLaunchKernelGGL((k_bilinear_tab<F16SRC, true>), grid, block, 0, stream, *pass, tab->cols, tab->rows);
+        hipLaunchKernelGGL((k_bilinear_tab<F16SRC, true>), grid, block, 0, stream, *pass, tab->colw, tab->roww, tab->b0x, tab->b0y);
     else
-        hipLaunchKernelGGL((k_bilinear_tab<F16SRC, false>), grid, block, 0, stream, *pass, tab->cols, tab->rows);
+        hipLaunchKernelGGL((k_bilinear_tab<F16SRC, false>), grid, block, 0, stream, *pass, tab->colw, tab->roww, tab->b0x, tab->b0y);
 }
 
 /* ------------------------------------------------------------------------ */

@@ -73,7 +73,7 @@ def test_bilinear_tables_equal_per_pixel_geometry(gpu, size, ten_bit):
     img = util.chirp_rgba16(sw, sh)
     kw = dict(dither_params=dither(), disable_dither_gamma_correction=True) if ten_bit else {}
     params = pl.render_params("fast", **kw)
-    tab = render(gpu, img, dw, dh, params, ten_bit, {"PL_HIP_BILIN_TABLES": "1"})
+    tab = render(gpu, img, dw, dh, params, ten_bit, {"PL_HIP_BILIN_TABLES": "1"})    # (opt-in: it lost, profiles/r04_12)
     per_px = render(gpu, img, dw, dh, params, ten_bit, {"PL_HIP_BILIN_TABLES": "0"})
     assert np.array_equal(tab, per_px), util.diff_stats(tab, per_px)
     if sw < 1000:
