@@ -291,7 +291,11 @@ void k_pass_peak(const plh_pass p_)
  * interpreter and the generic store: a lane owns two horizontally adjacent pixels on two rows
  * (one 16-byte load and store per row) instead of four single pixels.
  */
-template <bool F16SRC, bool STORE>
+// STORE: 0 = no target (the measurement of an existing intermediate), 1 = the rgba16hf
+// intermediate, 2 = ops are [PEAK_DETECT] [FEATURES] and the target is the r16hf feature plane of
+// contrast recovery (pl_shader_extract_features on the measured colours: the renderer merges the
+// two passes that read the same intermediate, renderer.c: measure_peak)
+template <bool F16SRC, int STORE>
 __global__ __launch_bounds__(64 * PEAK_WAVES)
 void k_peak_fast(const plh_pass p_)
 {
@@ -306,8 +310,8 @@ void k_peak_fast(const plh_pass p_)
         return;     // whole wave
     const int tx = wg_idx % tiles_x, ty = wg_idx / tiles_x;
     const int w = p.width, h = p.height;
-    const bool has_map = p.num_ops == 2;    // [identity PLANE_MAP] PEAK_DETECT
-    const plh_op &o_map = p.ops[0], &o_pk = p.ops[p.num_ops - 1];
+    const bool has_map = STORE != 2 && p.num_ops == 2;  // [identity PLANE_MAP] PEAK_DETECT
+    const plh_op &o_map = p.ops[0], &o_pk = p.ops[STORE == 2 ? 0 : p.num_ops - 1];
 
     // pixels (x0, y), (x0 + 1, y) for y = y0, y0 + 8: lanes beyond the image measure the clamped
     // edge texel, as the padding invocations of the reference's workgroups do
@@ -343,8 +347,30 @@ void k_peak_fast(const plh_pass p_)
             c[2 * k + i] = t;
         }
     }
+    if constexpr (STORE == 2) {
+        // the feature plane: I of IPT of every pixel (op_features itself: bit-identical to the pass
+        // of its own, k_pass_features), two f16 per row and lane
+#pragma unroll
+        for (int k = 0; k < 2; k++) {
+            const int y = y0 + 8 * k;
+            if (y >= h || x0 >= w)
+                continue;
+            uint32_t o[2];
+#pragma unroll
+            for (int i = 0; i < 2; i++) {
+                float4_t t = c[2 * k + i];
+                op_features(t, p.ops[1]);
+                o[i] = plh_f2h(t.x);
+            }
+            char *d = (char *) p.dst.ptr + (size_t) y * p.dst.pitch + (size_t) x0 * 2;
+            if (x0 + 1 < w)
+                *(uint32_t *) d = o[0] | (o[1] << 16);
+            else
+                *(uint16_t *) d = (uint16_t) o[0];
+        }
+    }
     // (the intermediate goes out first: its stores are in flight while the measurement computes)
-    if constexpr (STORE) {
+    if constexpr (STORE == 1) {
 #pragma unroll
         for (int k = 0; k < 2; k++) {
             const int y = y0 + 8 * k;
@@ -378,6 +404,15 @@ static bool peak_fast_applies(const plh_pass *pass)
         s.pos[0][0] == 0.0f && s.pos[0][1] == 0.0f && s.pos[3][0] == 1.0f && s.pos[3][1] == 1.0f &&
         s.pos[1][0] == 1.0f && s.pos[1][1] == 0.0f && s.pos[2][0] == 0.0f && s.pos[2][1] == 1.0f;
     const bool target = pass->dst.ptr != NULL;
+    const bool plain_target = pass->base_x == 0 && pass->base_y == 0 && pass->dir_x == 1 && pass->dir_y == 1 &&
+                              pass->dst.w >= pass->width && pass->dst.h >= pass->height;
+    // [PEAK_DETECT] [FEATURES] into the r16hf feature plane (STORE = 2)
+    if (native && s.type == PLH_SAMPLE_NEAREST && s.scale == 1.0f &&
+        (s.src.fmt == PLH_FMT_RGBA16 || s.src.fmt == PLH_FMT_RGBA16F) &&
+        s.address_mode == PLH_ADDRESS_CLAMP && !pass->transpose && !pass->num_pre_ops && target &&
+        pass->dst.fmt == PLH_FMT_R16F && plain_target && pass->num_ops == 2 &&
+        pass->ops[0].kind == PLH_OP_PEAK_DETECT && pass->ops[1].kind == PLH_OP_FEATURES)
+        return true;
     return native && s.type == PLH_SAMPLE_NEAREST && s.scale == 1.0f &&
            (s.src.fmt == PLH_FMT_RGBA16 || s.src.fmt == PLH_FMT_RGBA16F) &&
            s.address_mode == PLH_ADDRESS_CLAMP && !pass->transpose && !pass->num_pre_ops &&
@@ -464,10 +499,13 @@ int plh_launch_peak(hipStream_t stream, const plh_pass *pass)
     }
     if (peak_fast_applies(pass)) {
         const bool f16 = pass->s.src.fmt == PLH_FMT_RGBA16F, store = pass->dst.ptr != NULL;
-        if (f16 && store)       hipLaunchKernelGGL((k_peak_fast<true, true>), grid, block, 0, stream, *pass);
-        else if (f16)           hipLaunchKernelGGL((k_peak_fast<true, false>), grid, block, 0, stream, *pass);
-        else if (store)         hipLaunchKernelGGL((k_peak_fast<false, true>), grid, block, 0, stream, *pass);
-        else                    hipLaunchKernelGGL((k_peak_fast<false, false>), grid, block, 0, stream, *pass);
+        const bool feat = store && pass->dst.fmt == PLH_FMT_R16F;
+        if (f16 && feat)        hipLaunchKernelGGL((k_peak_fast<true, 2>), grid, block, 0, stream, *pass);
+        else if (feat)          hipLaunchKernelGGL((k_peak_fast<false, 2>), grid, block, 0, stream, *pass);
+        else if (f16 && store)  hipLaunchKernelGGL((k_peak_fast<true, 1>), grid, block, 0, stream, *pass);
+        else if (f16)           hipLaunchKernelGGL((k_peak_fast<true, 0>), grid, block, 0, stream, *pass);
+        else if (store)         hipLaunchKernelGGL((k_peak_fast<false, 1>), grid, block, 0, stream, *pass);
+        else                    hipLaunchKernelGGL((k_peak_fast<false, 0>), grid, block, 0, stream, *pass);
     } else if (plh_ops_lite(pass, 0, pk_op) && plh_ops_lite(pass, PL_MIN_INT(pk_op + 1, pass->num_ops), pass->num_ops))
         hipLaunchKernelGGL(k_pass_peak<true>, grid, block, 0, stream, *pass);
     else

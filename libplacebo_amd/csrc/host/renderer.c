@@ -870,11 +870,30 @@ static void measure_peak(struct frame_job *job)
         pl_tex tex = plh_work_texture(job, img);
         bool ok = tex != NULL;
         if (ok) {
+            // If the tone mapper is going to ask for a contrast-recovery feature map of this very
+            // image, the pass that reads it for the measurement extracts the features as well: ONE
+            // read of the intermediate instead of two (66 MB each at 4K). The reference runs them
+            // as two passes (renderer.c:2089-2154 after :1964-2087); the values are the same, the
+            // measurement sees the colours before the FEATURES op replaces them.
+            int mw, mh;
+            pl_tex full = NULL;
+            const char *off = getenv("PL_HIP_FUSED_FEATURES");
+            if (!(off && off[0] == '0') && !job->features_full &&
+                rp_wants_feature_map(&job->caps, params, &img->color, &job->target.color,
+                                     abs(pl_rect_w(job->geo.dst)), abs(pl_rect_h(job->geo.dst)), &mw, &mh))
+                full = borrow_fbo(job, img->w, img->h, NULL, 1);
             pl_shader probe = pl_dispatch_begin(rr->dp);
             ok = pl_shader_sample_direct(probe, pl_sample_src( .tex = tex )) &&
                  pl_shader_detect_peak(probe, img->color, &rr->tone_map_state,
                                        params->peak_detect_params);
-            if (ok) {
+            if (ok && full) {
+                pl_shader_extract_features(probe, img->color);
+                ok = pl_dispatch_finish(rr->dp, pl_dispatch_params( .shader = &probe, .target = full ));
+                if (ok) {
+                    job->features_full = full;
+                    job->features_src = tex;
+                }
+            } else if (ok) {
                 ok = pl_dispatch_compute(rr->dp, pl_dispatch_compute_params(
                     .shader = &probe, .width = tex->params.w, .height = tex->params.h,
                 ));
@@ -993,10 +1012,15 @@ static pl_tex make_feature_map(struct frame_job *job)
     if (!plh_work_texture(job, img))
         return NULL;
 
-    pl_tex full = borrow_fbo(job, img->w, img->h, NULL, 1);
+    // (the full-size plane may exist already: the measuring pass of this image writes it when it
+    // can, measure_peak)
+    // -- valid only while the image is still that texture: anything recorded on it since (cone
+    // distortion, an alpha conversion) made plh_work_texture above produce another one
+    const bool have = job->features_full && job->features_src == img->tex;
+    pl_tex full = have ? job->features_full : borrow_fbo(job, img->w, img->h, NULL, 1);
     pl_tex small = borrow_fbo(job, mw, mh, NULL, 1);
     bool ok = full && small;
-    if (ok) {
+    if (ok && !have) {
         pl_shader sh = pl_dispatch_begin(rr->dp);
         pl_shader_sample_direct(sh, pl_sample_src( .tex = img->tex ));
         pl_shader_extract_features(sh, img->color);

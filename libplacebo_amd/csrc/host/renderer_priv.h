@@ -93,6 +93,9 @@ struct frame_job {
     bool fbo_busy[RR_MAX_FBOS];
     bool peak_pending;          // a same-frame measurement rides on `img.rec`
     pl_tex measure_fbo;         // the member of rr->measure_fbo this frame wrote, if any
+    pl_tex features_full;       // full-size feature plane written by the measuring pass (renderer.c:
+                                // measure_peak), for make_feature_map to start from
+    pl_tex features_src;        // ... and the image (resident texture) it was extracted from
     bool image_acquired, target_acquired;
     bool target_borrowed;       // the target belongs to an enclosing job: neither acquire nor release
     struct pl_render_info info;

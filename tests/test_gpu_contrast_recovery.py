@@ -123,3 +123,41 @@ def test_high_quality_preset_runs_contrast_recovery(gpu):
         return np.abs(y[1:-1, 1:-1] * 4 - y[:-2, 1:-1] - y[2:, 1:-1] - y[1:-1, :-2] - y[1:-1, 2:]).mean()
     assert hp_energy(outs["hq"]) > hp_energy(outs["off"])
     src.destroy(); dst.destroy()
+
+
+@pytest.mark.parametrize("size", [((256, 144), (128, 72)), ((300, 170), (150, 85)), ((192, 108), (192, 108))])
+def test_measuring_pass_extracts_the_features_too(gpu, size, monkeypatch):
+    """high_quality on HDR10 with peak detection: the pass that reads the scaled intermediate for
+    the measurement also writes the contrast-recovery feature plane ([PEAK_DETECT] [FEATURES] into
+    an r16hf target: k_peak_fast<.., 2>) instead of a second pass reading the same image
+    (PL_HIP_FUSED_FEATURES=0 keeps the two passes; the generic measuring kernel with the fused op
+    list: PL_HIP_PEAK_FAST=0). Same measurement, same feature plane, so the same frame bit for bit
+    and the same scene metadata -- behind an EWA 2:1 downscale (the measurement of an existing
+    intermediate: configs[4]) and at 1:1 (where the measurement rides on the decoding pass and
+    nothing is merged)."""
+    import ctypes as C
+    import util
+    from libplacebo_amd import _capi as capi
+    (sw, sh), (dw, dh) = size
+    outs = []
+    for env in ({"PL_HIP_FUSED_FEATURES": "1"}, {"PL_HIP_FUSED_FEATURES": "0"},
+                {"PL_HIP_FUSED_FEATURES": "1", "PL_HIP_PEAK_FAST": "0"}):
+        for k in ("PL_HIP_FUSED_FEATURES", "PL_HIP_PEAK_FAST"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        src, dst, image, target = hdr_frames(gpu, sw, sh, dw, dh)
+        params = pl.render_params("high_quality", downscaler=pl.filter_config("ewa_lanczos", 2),
+                                  peak_detect_params=pl.peak_detect_params(percentile=99.995))
+        rr = pl.Renderer(gpu)
+        util.srand(1)
+        assert rr.render(image, target, params), gpu.messages[-4:]
+        assert rr.errors() == 0
+        meta = capi.HdrMetadata()
+        assert pl.lib().pl_renderer_get_hdr_metadata(rr.rr, C.byref(meta))
+        outs.append((dst.download(), (meta.max_pq_y, meta.avg_pq_y)))
+        rr.destroy(); src.destroy(); dst.destroy()
+    for out, meta in outs[1:]:
+        assert meta == outs[0][1]
+        assert np.array_equal(out, outs[0][0]), util.diff_stats(out, outs[0][0])
+    assert outs[0][0][..., :3].std() > 1000

@@ -192,8 +192,11 @@ def test_metric_frame_vs_oracle(gpu, size):
     b = orc.sample_polar(a, w, r, rz, dw, dh, mask=0x7)
     res = resolve(meta)
     assert res["need_tone"] and res["need_gamut"]
-    sel = np.arange(0, dw * dh, 13)
-    truth, _ = c64.hdr10_to_sdr(b.reshape(-1, 1, 4)[sel], res, 0.0)
+    # float64 truth on EVERY pixel of the frame (not a sample), in chunks
+    sel = np.arange(dw * dh)
+    flat = b.reshape(-1, 1, 4)
+    truth = np.concatenate([c64.hdr10_to_sdr(flat[i:i + (1 << 20)], res, 0.0)[0]
+                            for i in range(0, dw * dh, 1 << 20)])
     ref_pre = cr.apply(b.copy(), res)
     ref_pre16 = orc.tex_encode(ref_pre, "rgba16")
     colormap_tolerance(pre, ref_pre16, truth.reshape(-1, 4), sel)
