@@ -210,20 +210,25 @@ void k_polar_mxd(const plh_pass p_)
         // -- so that consecutive MFMAs never wait for each other's result. The fragments of the
         // next (j, kb) step are read from LDS while this step's 18 MFMAs run.
         mxd_f32x4 acc[2][3], accy[2][3];
+        // (zeroed inside the contraction's branch: the zeros are then the first step's inline
+        // constant instead of 48 v_mov per tile and lane -- k_polar_mx.hiph says how the compiler
+        // hoists them otherwise)
+        auto init_acc = [&](float v) {
 #pragma unroll
-        for (int h = 0; h < 2; h++) {
+            for (int h = 0; h < 2; h++) {
 #pragma unroll
-            for (int ch = 0; ch < 3; ch++) {
-                acc[h][ch] = (mxd_f32x4) (0.0f);
-                accy[h][ch] = (mxd_f32x4) (0.0f);
+                for (int ch = 0; ch < 3; ch++) {
+                    acc[h][ch] = (mxd_f32x4) (v);
+                    accy[h][ch] = (mxd_f32x4) (v);
+                }
             }
-        }
+        };
         struct fragset { mxd_f16x8 bhi, blo, bdy, a[2][3]; };
         auto read_frags = [&](fragset &f, int j, int kb) {
             const unsigned char *bf = bfl + 4 * (2 * j + kb) * 1024;
             f.bhi = *(const mxd_f16x8 *) bf;
             // (the column-phase term rides on the lo half, k_polar_mx.hiph)
-            f.blo = *(const mxd_f16x8 *) (bf + 2048) * dx8 + *(const mxd_f16x8 *) (bf + 1024);
+            f.blo = __builtin_elementwise_fma(*(const mxd_f16x8 *) (bf + 2048), dx8, *(const mxd_f16x8 *) (bf + 1024));
             f.bdy = *(const mxd_f16x8 *) (bf + 3072);
 #pragma unroll
             for (int h = 0; h < 2; h++) {
@@ -253,11 +258,19 @@ void k_polar_mxd(const plh_pass p_)
                     acc[h][ch] = __builtin_amdgcn_mfma_f32_16x16x32_f16(f.a[h][ch], f.blo, acc[h][ch], 0, 0, 0);
             }
         };
-        if (!(dbg & 1)) {
+        if (dbg & 1) {
+            init_acc((float) (tid & 1) * 0.25f);
+        } else {
+            init_acc(0.0f);
             fragset f0, f1;
             read_frags(f0, 0, 0);
+            // (first step peeled: its accumulators are the constant 0)
+            read_frags(f1, 0, 1);
+            contract(f0);
+            read_frags(f0, 1, 0);
+            contract(f1);
 #pragma unroll 1
-            for (int j = 0; j < PLH_MXD_TAPS / 2; j++) {
+            for (int j = 1; j < PLH_MXD_TAPS / 2; j++) {
                 read_frags(f1, j, 1);
                 contract(f0);
                 read_frags(f0, min(j + 1, PLH_MXD_TAPS / 2 - 1), 0);    // (the last one is not used)

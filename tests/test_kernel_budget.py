@@ -31,10 +31,10 @@ def usage(built):
 
 
 # The one tolerated spill: the matrix-pipe polar kernel with the colour map in its epilogue is held
-# to 128 registers (4 waves per SIMD: worth 183 -> 172 us) and parks three dwords once per wave
+# to 128 registers (4 waves per SIMD: worth 183 -> 172 us) and parks up to five dwords once per wave
 # tile, before the contraction, outside every loop body. Likewise the CHAIN variant of the
 # phase-class polar kernel on RGB f16 tiles (129 registers held to 128: 4 waves per SIMD).
-TOLERATED_SPILL = {"k_polar_mx<3, true, 2, 8>": 16, "k_polar_pp<__half, 7u, 2, true, true, true>": 12}
+TOLERATED_SPILL = {"k_polar_mx<3, true, 2, 8>": 20, "k_polar_pp<__half, 7u, 2, true, true, true>": 12}
 
 
 def test_no_kernel_spills(usage):
@@ -68,7 +68,7 @@ BUDGET = [
     (r"k_pass_merge<(true|false)>.*", 8),
     (r"k_pass_chain<(true|false), 1, false, (true|false)>", 8),
     (r"k_pass_chain<(true|false), 1, true, false>", 8),
-    (r"k_peak_fast<(true|false), (true|false)>", 8),
+    (r"k_peak_fast<(true|false), [012]>", 8),
     (r"k_pass_peak<true>", 4),
     (r"k_pass_peak<false>", 3),
     (r"k_deband_fast", 8),
