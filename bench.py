@@ -64,6 +64,7 @@ from libplacebo_amd import _capi as capi  # noqa: E402
 HBM_PEAK_GBS = 8000.0  # MI355X spec (MI355X_MICROARCH.md); ~6.3 TB/s achievable
 
 P1080, P4K, P8K = (1920, 1080), (3840, 2160), (7680, 4320)
+P720, P540 = (1280, 720), (960, 540)
 
 
 def px(dim):
@@ -74,6 +75,10 @@ WORKLOADS = {
     # name: (src dims, dst dims, algorithmic bytes per frame, dominant pass)
     "ewa_lanczos_1080p_to_4k_dither10": (P1080, P4K, px(P1080) * 8 + px(P4K) * 8, "polar"),
     "bilinear_1080p_to_4k": (P1080, P4K, px(P1080) * 8 + px(P4K) * 8, None),
+    # integer ratios other than 2: 720p -> 4K is 3x, 960x540 -> 4K is 4x (k_polar_mxr)
+    "ewa_lanczos_720p_to_4k_dither10": (P720, P4K, px(P720) * 8 + px(P4K) * 8, "polar"),
+    "ewa_lanczos_540p_to_4k_dither10": (P540, P4K, px(P540) * 8 + px(P4K) * 8, "polar"),
+    "ewa_720p_to_4k_hdr_tonemap": (P720, P4K, 2 * px(P720) * 8 + px(P4K) * 8, "polar"),
     # the separable counterpart of the headline (pl_render_default_params' upscaler): two passes
     "lanczos_1080p_to_4k_dither10": (P1080, P4K, px(P1080) * 8 + px(P4K) * 8, "ortho"),
     # real video ingest: NV12 (8-bit 4:2:0, BT.709 limited) -> EWA 2x -> RGB, 10-bit dither
@@ -180,7 +185,8 @@ class Stream:
         if workload == "bilinear_1080p_to_4k":
             self.params = pl.render_params("fast")
             icsp, tcsp, trepr = sdr, sdr, None
-        elif workload == "ewa_lanczos_1080p_to_4k_dither10":
+        elif workload in ("ewa_lanczos_1080p_to_4k_dither10", "ewa_lanczos_720p_to_4k_dither10",
+                          "ewa_lanczos_540p_to_4k_dither10"):
             self.params = pl.render_params("fast", upscaler=pl.filter_config("ewa_lanczos"),
                                            dither_params=dither,
                                            disable_dither_gamma_correction=True)
@@ -220,7 +226,7 @@ class Stream:
             icsp, tcsp, trepr = bt1886, bt1886, ten_bit
             self.queue = pl.Queue(self.g)
             self.pts, self.fed = 0.0, 0
-        elif workload == "ewa_1080p_to_4k_hdr_tonemap":
+        elif workload in ("ewa_1080p_to_4k_hdr_tonemap", "ewa_720p_to_4k_hdr_tonemap"):
             self.params = pl.render_params(
                 "default", upscaler=pl.filter_config("ewa_lanczos"), dither_params=dither,
                 peak_detect_params=pl.peak_detect_params(percentile=99.995))
@@ -731,7 +737,7 @@ def concurrent_block(device, workload, nstreams, steps=120, warmup=12):
 
 
 # workloads with a measuring pass the option can move (the others render the same either way)
-ASYNC_WORKLOADS = ("ewa_1080p_to_4k_hdr_tonemap", "hdr10_4k_tonemap")
+ASYNC_WORKLOADS = ("ewa_1080p_to_4k_hdr_tonemap", "hdr10_4k_tonemap", "ewa_720p_to_4k_hdr_tonemap")
 
 
 def async_measure_block(device, workload, steps, warmup, on):

@@ -277,6 +277,8 @@ int plh_launch_polar_pp_f32_c12(hipStream_t stream, const plh_pass *pass, dim3 g
 int plh_launch_polar_mx(hipStream_t stream, const plh_pass *pass);
 bool plh_polar_mxd_applies(plh_pass *pass);
 int plh_launch_polar_mxd(hipStream_t stream, const plh_pass *pass);
+bool plh_polar_mxr_applies(plh_pass *pass);
+int plh_launch_polar_mxr(hipStream_t stream, const plh_pass *pass);
 
 int plh_launch_polar_classify(plh_stream stream, const plh_pass *pass, void *out)
 {
@@ -326,6 +328,12 @@ int plh_launch_polar(hipStream_t stream, const plh_pass *pass_in)
     const uint32_t cm = pass->s.comp_mask & 0xf;
     if (pass->s.pp && plh_polar_mxd_applies(&local))
         return plh_launch_polar_mxd(stream, pass);     // the 2 : 1 downscale on the matrix pipe
+    if (pass->s.pp && pass->s.mx.enabled == 3) {
+        // an integer upscale by 3 or 4 on the matrix pipe, where the pass has the kernel's shape
+        plh_pass probe = local;
+        if (plh_polar_mxr_applies(&probe))
+            return plh_launch_polar_mxr(stream, &probe);
+    }
     if (pass->s.pp && pass->s.mx.enabled == 1 && (cm == 0x7 || cm == 0xf)) {
         // (the matrix-pipe kernel has a variant for the map chain of an HDR pass)
         if (cm == 0x7)

@@ -109,8 +109,18 @@ struct plh_polar_pp {
 #define PLH_MX_NFRAG 36
 #define PLH_MX_DSHIFT 11
 #define PLH_MX_PAD 128      // dfx / dfy are padded to a multiple of this many outputs (the widest tile)
+// An exact INTEGER upscale by R = 3 or 4 (enabled == 3, k_polar_mxr.hip) has R phases per axis;
+// output column X belongs to base index (X + sx) / R and phase (X + sx) % R (rows: sy), every phase
+// of a base shares the base texel, so each row phase py is a GEMM over the same four row pairs.
+// A wave owns 8 base columns = two 16-column halves h of 4 bases x R phases (4 R <= 16 columns
+// used); the 128 fragments of R = 4 do not fit the LDS next to the tile, so they are staged per
+// row phase: frag f = 4 * (2 * (4 * py + j) + h) + {hi, lo, d/dx, d/dy}, 32 per row phase.
+#define PLH_MXR_FRAGS_PER_PHASE 32
+#define PLH_MXR_MAX_RATIO 4
 struct plh_polar_mx {
-    int32_t enabled;        // 1: the 2x upscale (k_polar_mx), 2: the 2 : 1 downscale (k_polar_mxd)
+    int32_t enabled;        // 1: the 2x upscale (k_polar_mx), 2: the 2 : 1 downscale (k_polar_mxd),
+                            // 3: an integer upscale by `ratio` (k_polar_mxr)
+    int32_t ratio, sx, sy;  // enabled == 3
     int32_t org_x, org_y;   // source texel held by LDS tile (0, 0) of workgroup tile (0, 0)
     const void *bfrag;      // device: [PLH_MX_NFRAG][64 lanes][8] f16
     const float *dfx, *dfy; // device: phase deviation of every output column / row, x 2^PLH_MX_DSHIFT

@@ -859,6 +859,244 @@ static bool polar_mx_build(pl_gpu gpu, pl_log log, struct sh_sampler_obj *obj,
     return true;
 }
 
+// The geometry k_polar_mxr covers: an axis of an exact integer upscale by R. Output i belongs to
+// base index (i + shift) / R and phase (i + shift) % R; every phase of a base index shares the base
+// texel base[0] + index; the phase of an output is its phase class' up to the fp32 rounding of the
+// attribute interpolation. An ODD ratio has a phase at fcoord = 0, where that rounding decides
+// between (base b, fcoord +eps) and (base b - 1, fcoord 1 - eps): the same sample position -- the
+// tap that enters at one end and the one that leaves at the other lie beyond the filter's radius --
+// so such an output is taken as (b, fcoord - 1), a small negative deviation from the phase
+// (`canon`: the outputs' canonical fcoord, which the caller turns into the deviations). Returns
+// the shift and a representative, unwrapped output of every phase.
+static bool mxr_axis(const float *fc, const int32_t *base, int len, int R, int *shift,
+                     int rep[PLH_MXR_MAX_RATIO], float *canon)
+{
+    if (len < 2 * R)
+        return false;
+    int32_t first = 0;
+    for (int i = 0; i < len; i++) {
+        const bool wrapped = fc[i] > 0.98f;
+        canon[i] = wrapped ? fc[i] - 1.0f : fc[i];
+        const int32_t b = base[i] + (wrapped ? 1 : 0);
+        if (i == 0)
+            first = b;
+        if (b < first)
+            return false;
+    }
+    // the shift: R minus the number of leading outputs on the first canonical base
+    int lead = 0;
+    while (lead < len && base[lead] + (fc[lead] > 0.98f ? 1 : 0) == first)
+        lead++;
+    if (lead < 1 || lead > R)
+        return false;
+    *shift = R - lead;
+    for (int q = 0; q < R; q++)
+        rep[q] = -1;
+    for (int i = 0; i < len; i++) {
+        const int q = (i + *shift) % R;
+        const bool wrapped = fc[i] > 0.98f;
+        if (base[i] + (wrapped ? 1 : 0) != first + (i + *shift) / R)
+            return false;
+        if (rep[q] < 0 && !wrapped)
+            rep[q] = i;
+    }
+    for (int q = 0; q < R; q++) {
+        if (rep[q] < 0)
+            return false;
+    }
+    for (int i = 0; i < len; i++) {
+        const int q = (i + *shift) % R;
+        if (fabsf(canon[i] - fc[rep[q]]) > 1e-5f + 1.5f * FLT_EPSILON * (float) len)
+            return false;
+    }
+    return true;
+}
+
+// B fragments of k_polar_mxr (plh_device.h): frag f = 4 * (2 * (4 * py + j) + h) + kind, lane l,
+// element e hold T(py, j, h)[k][n], n = l & 15 the output column within half h of the wave's 8
+// bases -- base bi = 4 h + n / R, phase px = n % R, n < 4 R -- and K index (row 2 j + (l >> 5) of the
+// base's eight tap rows, column k = 8 * ((l >> 4) & 1) + e of the wave's 16-column window):
+//   = w'(py, px, tap (k - bi - 3, 2 j + (l >> 5) - 3)), kinds as in polar_mx_build.
+static bool polar_mxr_build(pl_gpu gpu, pl_log log, struct sh_sampler_obj *obj,
+                            const struct plh_pass *pass, const float *wall, const uint32_t *taps,
+                            int ntaps, int ncx, int ncy, const float *clsx, const float *clsy,
+                            const float *colfc, const int32_t *colbase, const uint16_t *idx,
+                            const float *rowfc, const int32_t *rowbase, const uint16_t *idy)
+{
+    const struct plh_sampler_args *s = &pass->s;
+    const int W = pass->width, H = pass->height;
+    const char *env = getenv("PL_HIP_POLAR_MXR");
+    if (env && env[0] == '0')
+        return false;
+    if (gpu->glsl.max_shmem_size < 64 * 1024 || s->bound > 4 || s->tile_fp32 ||
+        s->address_mode != PLH_ADDRESS_CLAMP || pass->transpose || s->src.w < 2 || s->antiring > 0)
+        return false;
+    int R = 0, sx = 0, sy = 0, repx[PLH_MXR_MAX_RATIO], repy[PLH_MXR_MAX_RATIO];
+    float *canx = malloc(((size_t) W + H) * sizeof(float)), *cany = canx ? canx + W : NULL;
+    if (!canx)
+        return false;
+    for (int r = 3; r <= PLH_MXR_MAX_RATIO && !R; r++) {
+        if (mxr_axis(colfc, colbase, W, r, &sx, repx, canx) && mxr_axis(rowfc, rowbase, H, r, &sy, repy, cany))
+            R = r;
+    }
+    if (!R) {
+        pl_msg(log, PL_LOG_DEBUG, "matrix-pipe polar: not an exact 3x / 4x geometry either");
+        free(canx);
+        return false;
+    }
+    int tap_at[8][8];
+    for (int y = 0; y < 8; y++) {
+        for (int x = 0; x < 8; x++)
+            tap_at[y][x] = -1;
+    }
+    for (int t = 0; t < ntaps; t++) {
+        const int x = (int8_t) (taps[t] & 0xff), y = (int8_t) ((taps[t] >> 8) & 0xff);
+        if (x < -3 || x > 4 || y < -3 || y > 4) {
+            free(canx);
+            return false;
+        }
+        tap_at[y + 3][x + 3] = t;
+    }
+#define WN(kx, ky, t) ((double) wall[((size_t) (ky) * ncx + (kx)) * (ntaps + 1) + (t)] * \
+                       (double) wall[((size_t) (ky) * ncx + (kx)) * (ntaps + 1) + ntaps])
+    int cx[PLH_MXR_MAX_RATIO], cy[PLH_MXR_MAX_RATIO];
+    for (int q = 0; q < R; q++) {
+        cx[q] = idx[repx[q]];
+        cy[q] = idy[repy[q]];
+    }
+    // d w' / d fcoord at every phase pair: least-squares slopes over the classes of that phase
+    const size_t nt = (size_t) PL_MAX(ntaps, 1);
+    double *slx = calloc((size_t) R * R * nt, sizeof(double)), *sly = calloc((size_t) R * R * nt, sizeof(double));
+    const size_t nfx = ((size_t) W + PLH_MX_PAD - 1) / PLH_MX_PAD * PLH_MX_PAD;
+    const size_t nfy = ((size_t) H + PLH_MX_PAD - 1) / PLH_MX_PAD * PLH_MX_PAD;
+    const size_t frag_bytes = (size_t) R * PLH_MXR_FRAGS_PER_PHASE * 64 * 8 * sizeof(uint16_t);
+    const size_t o_dfx = frag_bytes, o_dfy = o_dfx + nfx * 4, bytes = o_dfy + nfy * 4;
+    uint8_t *blob = calloc(1, bytes);
+    if (!slx || !sly || !blob) {
+        free(slx); free(sly); free(blob); free(canx);
+        return false;
+    }
+    // tap t sits at (tapx[t], tapy[t]) of the 8 x 8 footprint
+    int tapx[64], tapy[64];
+    for (int y = 0; y < 8; y++) {
+        for (int x = 0; x < 8; x++) {
+            if (tap_at[y][x] >= 0 && tap_at[y][x] < 64) {
+                tapx[tap_at[y][x]] = x;
+                tapy[tap_at[y][x]] = y;
+            }
+        }
+    }
+    if (ntaps > 64) {
+        free(slx); free(sly); free(blob); free(canx);
+        return false;
+    }
+    // The classes a slope is fitted through: those within 0.01 of the phase -- and, for the phase at
+    // fcoord = 0 of an odd ratio, the WRAPPED ones on the other side of it (fcoord 1 - eps on the
+    // base one texel lower = -eps on this base: their weight for footprint position (x, y) is their
+    // own weight one position further along the axis). Without them that phase may have a single
+    // class, fcoord = 0 exactly, no slope, and its wrapped outputs -- up to 1e-4 away -- no
+    // first-order term (4 codes on white noise at 720p -> 4K).
+    for (int py = 0; py < R; py++) {
+        for (int px = 0; px < R; px++) {
+            double *vx = slx + (size_t) (py * R + px) * nt, *vy = sly + (size_t) (py * R + px) * nt;
+            double den = 0.0;
+            for (int c = 0; c < ncx; c++) {
+                const bool wrapped = clsx[c] > 0.98f;
+                const double d = (double) clsx[c] - (wrapped ? 1.0 : 0.0) - (double) clsx[cx[px]];
+                if (fabs(d) > 0.01)
+                    continue;   // another phase
+                den += d * d;
+                for (int t = 0; t < ntaps; t++) {
+                    const int ts = !wrapped ? t : tapx[t] + 1 < 8 ? tap_at[tapy[t]][tapx[t] + 1] : -1;
+                    vx[t] += d * ((ts >= 0 ? WN(c, cy[py], ts) : 0.0) - WN(cx[px], cy[py], t));
+                }
+            }
+            for (int t = 0; t < ntaps; t++)
+                vx[t] = den > 0.0 ? vx[t] / den : 0.0;
+            den = 0.0;
+            for (int c = 0; c < ncy; c++) {
+                const bool wrapped = clsy[c] > 0.98f;
+                const double d = (double) clsy[c] - (wrapped ? 1.0 : 0.0) - (double) clsy[cy[py]];
+                if (fabs(d) > 0.01)
+                    continue;
+                den += d * d;
+                for (int t = 0; t < ntaps; t++) {
+                    const int ts = !wrapped ? t : tapy[t] + 1 < 8 ? tap_at[tapy[t] + 1][tapx[t]] : -1;
+                    vy[t] += d * ((ts >= 0 ? WN(cx[px], c, ts) : 0.0) - WN(cx[px], cy[py], t));
+                }
+            }
+            for (int t = 0; t < ntaps; t++)
+                vy[t] = den > 0.0 ? vy[t] / den : 0.0;
+        }
+    }
+    uint16_t *frag = (uint16_t *) blob;
+    const double dscale = ldexp(1.0, -PLH_MX_DSHIFT);
+    double worst = 0.0;
+    for (int py = 0; py < R; py++) {
+        for (int j = 0; j < 4; j++) {
+            for (int h = 0; h < 2; h++) {
+                const size_t f = 4 * (size_t) (2 * (4 * py + j) + h);
+                for (int l = 0; l < 64; l++) {
+                    const int n = l & 15, px = n % R, bi = 4 * h + n / R;
+                    const int wy = 2 * j + (l >> 5);
+                    for (int e = 0; e < 8; e++) {
+                        const int k = 8 * ((l >> 4) & 1) + e, wx = k - bi;
+                        double v = 0.0, vx = 0.0, vy = 0.0;
+                        if (n < 4 * R && wx >= 0 && wx < 8 && tap_at[wy][wx] >= 0) {
+                            const int t = tap_at[wy][wx];
+                            v = WN(cx[px], cy[py], t);
+                            vx = slx[(size_t) (py * R + px) * nt + t];
+                            vy = sly[(size_t) (py * R + px) * nt + t];
+                        }
+                        const uint16_t hi = f32_to_f16((float) v);
+                        const uint16_t lo = f32_to_f16((float) (v - (double) f16_to_f32(hi)));
+                        worst = PL_MAX(worst, fabs(v - (double) f16_to_f32(hi) - (double) f16_to_f32(lo)));
+                        frag[((f + 0) * 64 + l) * 8 + e] = hi;
+                        frag[((f + 1) * 64 + l) * 8 + e] = lo;
+                        frag[((f + 2) * 64 + l) * 8 + e] = f32_to_f16((float) (vx * dscale));
+                        frag[((f + 3) * 64 + l) * 8 + e] = f32_to_f16((float) (vy * dscale));
+                    }
+                }
+            }
+        }
+    }
+#undef WN
+    free(slx);
+    free(sly);
+    float *dfx = (float *) (blob + o_dfx), *dfy = (float *) (blob + o_dfy);
+    float dev = 0.0f;
+    const float up = ldexpf(1.0f, PLH_MX_DSHIFT);
+    for (int i = 0; i < W; i++) {
+        const float d = canx[i] - colfc[repx[(i + sx) % R]];
+        dev = fmaxf(dev, fabsf(d));
+        dfx[i] = d * up;
+    }
+    for (int i = 0; i < H; i++) {
+        const float d = cany[i] - rowfc[repy[(i + sy) % R]];
+        dev = fmaxf(dev, fabsf(d));
+        dfy[i] = d * up;
+    }
+    // (the first canonical base: where a wrapped first output sits one texel lower)
+    const int bx0 = colbase[0] + (colfc[0] > 0.98f ? 1 : 0), by0 = rowbase[0] + (rowfc[0] > 0.98f ? 1 : 0);
+    free(canx);
+    pl_buf_destroy(gpu, &obj->mx_blob);
+    obj->mx_blob = pl_buf_create(gpu, pl_buf_params(.size = bytes, .storable = true, .initial_data = blob));
+    free(blob);
+    if (!obj->mx_blob)
+        return false;
+    const char *base = pl_hip_buf_ptr(obj->mx_blob);
+    obj->mx_host = (struct plh_polar_mx) {
+        .enabled = 3, .ratio = R, .sx = sx, .sy = sy,
+        .org_x = bx0 - 3, .org_y = by0 - 3,
+        .bfrag = base,
+        .dfx = (const float *) (base + o_dfx), .dfy = (const float *) (base + o_dfy),
+    };
+    obj->mx_announced = false;
+    pl_msg(log, PL_LOG_DEBUG, "matrix-pipe tables for the polar pass: %d x %d phases (integer upscale, shifts %d / %d, "
+           "per-pixel phases within %.2e: first-order terms), weight split error <= %.2e", R, R, sx, sy, dev, worst);
+    return true;
+}
+
 static bool polar_pp_build(pl_gpu gpu, pl_log log, struct sh_sampler_obj *obj,
                            const struct plh_pass *pass)
 {
@@ -1021,7 +1259,9 @@ static bool polar_pp_build(pl_gpu gpu, pl_log log, struct sh_sampler_obj *obj,
     }
     // the same geometry on the matrix pipe, where it has the shape for it
     if (!polar_mx_build(gpu, log, obj, pass, wall, taps_all, ntaps, ncx, ncy, clsx, clsy, colfc, colbase,
-                        idx, rowfc, rowbase, idy))
+                        idx, rowfc, rowbase, idy) &&
+        !polar_mxr_build(gpu, log, obj, pass, wall, taps_all, ntaps, ncx, ncy, clsx, clsy, colfc, colbase,
+                         idx, rowfc, rowbase, idy))
         polar_mxd_build(gpu, log, obj, pass, wall, taps_all, ntaps, ncx, ncy, clsx, clsy, colfc, colbase,
                         rowfc, rowbase);
     free(taps_all);
@@ -1138,7 +1378,8 @@ void plh_polar_pp_setup(pl_gpu gpu, pl_log log, void *polar_obj, struct plh_pass
         s->mx = obj->mx_host;
         if (!obj->mx_announced)
             pl_msg(log, PL_LOG_DEBUG, "polar on the matrix pipe (%s)",
-                   s->mx.enabled == 2 ? "k_polar_mxd, where the pass has its shape" : "k_polar_mx");
+                   s->mx.enabled == 2 ? "k_polar_mxd, where the pass has its shape" :
+                   s->mx.enabled == 3 ? "k_polar_mxr, where the pass has its shape" : "k_polar_mx");
         obj->mx_announced = true;
     }
 }

@@ -151,8 +151,12 @@ def dither_consistency(got10, pre16, matrix, depth=10, shift=6):
     b = matrix[ys & 63, xs & 63].astype(np.float64)[..., None]
     g = pre16[..., :3].astype(np.float64)
     k = (got10[..., :3] >> shift).astype(np.int64)
-    lo = np.floor(top * (g - 0.5 - 1e-3) / 65535.0 + b)
-    hi = np.floor(top * (g + 0.5 + 1e-3) / 65535.0 + b)
+    # slack: the kernels form x * top + noise in fp32; next to the top code one ulp of that sum is
+    # 2^-14 of a 10-bit step = 0.004 of a 16-bit code (one sample in 2.5e7 lands that close to a
+    # boundary on a 4K frame), so two ulps
+    slack = 8e-3
+    lo = np.floor(top * (g - 0.5 - slack) / 65535.0 + b)
+    hi = np.floor(top * (g + 0.5 + slack) / 65535.0 + b)
     lo = np.where(pre16[..., :3] == 0, 0.0, lo)             # clipped pre-dither values: the
     hi = np.where(pre16[..., :3] == 65535, top, hi)         # true x may lie beyond the range
     ok = (k >= np.clip(lo, 0, top)) & (k <= np.clip(hi, 0, top))

@@ -78,6 +78,12 @@ def ewa(**kw):
 
 def assert_codes(mx, pp, step=1, max_frac=0.15):
     d = np.abs(mx.astype(np.int64) - pp.astype(np.int64))
+    if d.max() > step:
+        ys, xs = np.nonzero((d > step).any(axis=-1))
+        print("samples more than %d apart: %d, rows %d..%d, columns %d..%d; distinct rows %d, distinct columns %d; "
+              "x mod 12: %s, y mod 12: %s" % (step, len(ys), ys.min(), ys.max(), xs.min(), xs.max(),
+                                             len(np.unique(ys)), len(np.unique(xs)),
+                                             np.bincount(xs % 12, minlength=12), np.bincount(ys % 12, minlength=12)))
     assert d.max() <= step, (int(d.max()), int((d > step).sum()))
     assert (d > 0).mean() <= max_frac, float((d > 0).mean())
     return float((d > 0).mean())
@@ -148,13 +154,75 @@ def test_mx_offset_and_flipped_targets():
 
 
 def test_mx_not_used_where_it_does_not_apply():
-    """other ratios keep the phase-class kernel; both switches give the same frame there"""
+    """non-integer and anisotropic ratios keep the phase-class kernel; both switches give the same
+    frame there"""
     sw, sh = 96, 64
     img = util.chirp_rgba16(sw, sh)
-    for dw, dh in ((288, 192), (144, 96), (192, 96)):
+    for dw, dh in ((144, 96), (192, 96), (240, 160)):
         a = render(img, dw, dh, ewa(), True, expect_mx=False)
         b = render(img, dw, dh, ewa(), False, expect_mx=False)
         assert np.array_equal(a, b)
+
+
+@pytest.mark.parametrize("ratio", [3, 4])
+@pytest.mark.parametrize("size", [(80, 48), (131, 77), (1280, 720)])
+@pytest.mark.parametrize("content", ["chirp", "noise"])
+def test_mxr_integer_upscale_vs_reference_kernel_and_oracle(ratio, size, content):
+    """k_polar_mxr -- the EWA upscale by exactly 3 or 4 on the matrix pipe (720p -> 4K is 3x) --
+    against k_polar_pp, which IS the oracle bit for bit, at sizes whose edge tiles are clipped and
+    at the real one. Same statement as the 2x kernel: <= 1 code of 16 bits, identical on the bulk;
+    a 10-bit dithered frame differs by one step on a fraction of a percent, and every sample of
+    it is the dither of the frame's own pre-dither value (index path exact)."""
+    from test_gpu_metric import dither_consistency
+    sw, sh = size
+    if ratio == 4 and sw > 1000:
+        sw, sh = 960, 540
+    img = util.chirp_rgba16(sw, sh) if content == "chirp" else util.random_rgba16(sw, sh, seed=3)
+    dw, dh = ratio * sw, ratio * sh
+    q_mx = render(img, dw, dh, ewa(), True, expect_mx=True)
+    q_pp = render(img, dw, dh, ewa(), False, expect_mx=False)
+    frac = assert_codes(q_mx, q_pp)
+    print("k_polar_mxr %dx %dx%d %s: 16-bit frames differ on %.4f of the samples, by one code" %
+          (ratio, sw, sh, content, frac))
+    if sw < 1000:
+        a = orc.tex_decode(img, "rgba16")
+        a[..., 3] = 1.0
+        a = orc.op_quant_f16(a)
+        w, r, rz = orc.filter_generate_polar(orc.ewa_lanczos())
+        ref16 = orc.tex_encode(orc.sample_polar(a, w, r, rz, dw, dh, mask=0x7), "rgba16")
+        assert np.array_equal(q_pp, ref16)
+        assert_codes(q_mx, ref16)
+    d_mx = render(img, dw, dh, ewa(**dither10()), True, ten_bit=True, expect_mx=True)
+    d_pp = render(img, dw, dh, ewa(**dither10()), False, ten_bit=True)
+    assert_codes(d_mx >> 6, d_pp >> 6, step=1, max_frac=0.004)
+    assert dither_consistency(d_mx, q_mx, util.blue_noise(pl)) == 0.0
+
+
+@pytest.mark.parametrize("ratio", [3, 4])
+def test_mxr_hdr_colour_map_epilogue_and_f16_source(ratio):
+    """the HDR map chain behind the 3x / 4x upscale (720p HDR10 -> 4K SDR: the metric's frame from a
+    720p source) and an rgba16hf source (no fused decode): within the conditioning of the colour
+    map of the sequential-fma kernel, as for 2x (test_mx_hdr_colour_map_epilogue)"""
+    from test_gpu_fullsize import hdr_frame16
+    sw, sh = 150, 84
+    img = hdr_frame16(sw, sh)
+    hdr = pl.color_space("bt2020", "pq", max_luma=1000.0)
+    sdr = pl.color_space("bt709", "bt1886")
+    params = pl.render_params("default", upscaler=pl.filter_config("ewa_lanczos"), dither_params=None,
+                              peak_detect_params=pl.peak_detect_params(percentile=99.995))
+    kw = dict(image_kw=dict(color=hdr), target_kw=dict(color=sdr))
+    mx = render(img, ratio * sw, ratio * sh, params, True, expect_mx=True, **kw)
+    pp = render(img, ratio * sw, ratio * sh, params, False, **kw)
+    d = np.abs(mx[..., :3].astype(np.int64) - pp[..., :3])
+    print("HDR epilogue %dx: |mxr - pp| codes: median %.1f p99 %.1f max %d" %
+          (ratio, np.median(d), np.quantile(d, 0.99), d.max()))
+    assert np.quantile(d, 0.5) <= 1 and np.quantile(d, 0.99) <= 4 and d.max() <= 64
+    assert np.array_equal(mx[..., 3], pp[..., 3])
+    rng = np.random.default_rng(9)
+    f16 = rng.random((sh, sw, 4), dtype=np.float32).astype(np.float16)
+    a = render(f16, ratio * sw, ratio * sh, ewa(), True, src_fmt="rgba16hf", expect_mx=True)
+    b = render(f16, ratio * sw, ratio * sh, ewa(), False, src_fmt="rgba16hf")
+    assert_codes(a, b)
 
 
 def test_mx_hdr_colour_map_epilogue():
