@@ -64,7 +64,7 @@ from libplacebo_amd import _capi as capi  # noqa: E402
 HBM_PEAK_GBS = 8000.0  # MI355X spec (MI355X_MICROARCH.md); ~6.3 TB/s achievable
 
 P1080, P4K, P8K = (1920, 1080), (3840, 2160), (7680, 4320)
-P720, P540 = (1280, 720), (960, 540)
+P720, P540, P1440 = (1280, 720), (960, 540), (2560, 1440)
 
 
 def px(dim):
@@ -78,6 +78,7 @@ WORKLOADS = {
     # integer ratios other than 2: 720p -> 4K is 3x, 960x540 -> 4K is 4x (k_polar_mxr)
     "ewa_lanczos_720p_to_4k_dither10": (P720, P4K, px(P720) * 8 + px(P4K) * 8, "polar"),
     "ewa_lanczos_540p_to_4k_dither10": (P540, P4K, px(P540) * 8 + px(P4K) * 8, "polar"),
+    "ewa_lanczos_1440p_to_4k_dither10": (P1440, P4K, px(P1440) * 8 + px(P4K) * 8, "polar"),      # 3 : 2
     "ewa_720p_to_4k_hdr_tonemap": (P720, P4K, 2 * px(P720) * 8 + px(P4K) * 8, "polar"),
     # the separable counterpart of the headline (pl_render_default_params' upscaler): two passes
     "lanczos_1080p_to_4k_dither10": (P1080, P4K, px(P1080) * 8 + px(P4K) * 8, "ortho"),
@@ -186,7 +187,7 @@ class Stream:
             self.params = pl.render_params("fast")
             icsp, tcsp, trepr = sdr, sdr, None
         elif workload in ("ewa_lanczos_1080p_to_4k_dither10", "ewa_lanczos_720p_to_4k_dither10",
-                          "ewa_lanczos_540p_to_4k_dither10"):
+                          "ewa_lanczos_540p_to_4k_dither10", "ewa_lanczos_1440p_to_4k_dither10"):
             self.params = pl.render_params("fast", upscaler=pl.filter_config("ewa_lanczos"),
                                            dither_params=dither,
                                            disable_dither_gamma_correction=True)

@@ -26,26 +26,40 @@
  * identity PLANE_MAP in front (the fused PASS A of a plain plane); epilogues: FAST (dither + scale
  * into rgba16) and CHAIN (the map chain of an HDR pass in front of that tail). Everything else
  * keeps k_polar_pp (plh_polar_mxr_applies).
+ *
+ * 3 : 2 (720p -> 1080p, 1440p -> 4K; template parameter G = 2): a base index is a GROUP of two
+ * source texels whose three outputs start at texel offsets the host has folded into the weights'
+ * placement. M = 16 groups of rows = 32 source rows; the A fragment of M row m and row pair j is
+ * source row 2 m + 2 j + (l >> 5), so the tile is kept as an even-row and an odd-row half and the
+ * fragment addressing stays that of G = 1. A group's footprint is 10 rows (five row pairs); a
+ * wave's 8 source columns are 4 groups x 3 phases = ONE half of 12 columns. 45 MFMAs per 16 x 12
+ * outputs of a row phase (0.23 per pixel).
  */
 #include "k_polar_mx.hiph"
 
 #define MXR_WAVES   8
 #define MXR_NT      (64 * MXR_WAVES)
-#define MXR_TBX     (8 * MXR_WAVES)         // base columns per workgroup tile
+#define MXR_TSX     (8 * MXR_WAVES)         // source columns per workgroup tile (without the halo)
 #define MXR_TBY     16                      // base rows per workgroup tile
-#define MXR_SRC_W   (MXR_TBX + 8)
-#define MXR_SRC_H   (MXR_TBY + 8)           // (+1: the row that only meets zero weights)
+#define MXR_SRC_W   (MXR_TSX + 8)
 #define MXR_PITCH   160
-#define MXR_PLANE   (MXR_SRC_H * MXR_PITCH)
 #define MXR_B_BYTES (PLH_MXR_FRAGS_PER_PHASE * 1024)
 #define MXR_HP      (MXR_SRC_W / 2)
-#define MXR_NPAIRS  (MXR_HP * MXR_SRC_H)
-#define MXR_NV      ((MXR_NPAIRS + MXR_NT - 1) / MXR_NT)
 
-template <int R, bool CHAIN>
+template <int R, int G, bool CHAIN>
 __global__ __launch_bounds__(MXR_NT) __attribute__((amdgpu_waves_per_eu(4)))
 void k_polar_mxr(const plh_pass p_)
 {
+    constexpr int MXR_TBX = MXR_TSX / G;            // base columns per workgroup tile
+    constexpr int MXR_BW = 8 / G;                   // ... per wave
+    constexpr int MXR_NH = MXR_BW / 4;              // halves of 4 bases x R phases
+    constexpr int MXR_NJ = G == 1 ? 4 : 5;          // row pairs of a base's footprint
+    constexpr int MXR_SRC_H = G * MXR_TBY + 8;      // (+1: the row that only meets zero weights)
+    constexpr int MXR_PLANE = MXR_SRC_H * MXR_PITCH;
+    constexpr int MXR_HALF = (MXR_SRC_H / 2) * MXR_PITCH;   // G = 2: the odd rows' half of a plane
+    constexpr int MXR_NPAIRS = MXR_HP * MXR_SRC_H;
+    constexpr int MXR_NV = (MXR_NPAIRS + MXR_NT - 1) / MXR_NT;
+    constexpr int MXR_NFRAG = 4 * MXR_NJ * MXR_NH;  // fragments of a row phase
     const plh_pass &p = plh_kernarg_pass();
     const plh_sampler_args &s = p.s;
     const plh_polar_mx &mx = s.mx;
@@ -86,7 +100,7 @@ void k_polar_mxr(const plh_pass p_)
         bx = (int) (t - (uint32_t) by * (uint32_t) tiles_x);
     }
     // source texel of LDS (0, 0): base index 0 sits on source column org_x + 3
-    const int ox = mx.org_x + MXR_TBX * bx, oy = mx.org_y + MXR_TBY * by;
+    const int ox = mx.org_x + MXR_TSX * bx, oy = mx.org_y + G * MXR_TBY * by;
 
     // ---- source tile -> LDS: pairs of horizontally adjacent texels, one 16-byte load each, all
     // issued together; decode (unorm sources: the reference's PASS A fused, rounded to f16 as the
@@ -136,7 +150,8 @@ void k_polar_mxr(const plh_pass p_)
                 }
             }
             if (tid + u * MXR_NT < MXR_NPAIRS) {
-                unsigned char *d = tile + ty[u] * MXR_PITCH + tp[u] * 4;
+                const int trow = G == 1 ? ty[u] * MXR_PITCH : (ty[u] & 1) * MXR_HALF + (ty[u] >> 1) * MXR_PITCH;
+                unsigned char *d = tile + trow + tp[u] * 4;
                 *(uint32_t *) d = o[0];
                 *(uint32_t *) (d + MXR_PLANE) = o[1];
                 *(uint32_t *) (d + 2 * MXR_PLANE) = o[2];
@@ -147,9 +162,12 @@ void k_polar_mxr(const plh_pass p_)
     // the lane's output columns: half h, column n = ln of it -> base 4 h + n / R, phase n % R
     // (n / R and n % R for n < 16 without a division: R is a template parameter)
     const int nb = ln / R, px = ln - nb * R;
-    // A fragment of lane l for row pair j: the 16 bytes at tile row (l & 15) + (l >> 5) + 2 j, column
-    // 8 wave + 8 ((l >> 4) & 1) -- k_polar_mx's, with one wave tile per wave
-    const unsigned char *ab = tile + (ln + (lg >> 1)) * MXR_PITCH + (8 * wave + 8 * (lg & 1)) * 2;
+    // A fragment of lane l for row pair j: the 16 bytes at tile row G (l & 15) + (l >> 5) + 2 j, column
+    // 8 wave + 8 ((l >> 4) & 1) -- k_polar_mx's, with one wave tile per wave (G = 2: row (l >> 5) of
+    // the pair picks the even / odd half, (l & 15) + j the row within it)
+    const unsigned char *ab = tile + (G == 1 ? (ln + (lg >> 1)) * MXR_PITCH : (lg >> 1) * MXR_HALF + ln * MXR_PITCH) +
+                              (8 * wave + 8 * (lg & 1)) * 2;
+    constexpr int MXR_JSTEP = G == 1 ? 2 * MXR_PITCH : MXR_PITCH;
     const unsigned char *bfl = bl + lane * 16;
 
     // the rows that may be stored form one interval [ylo, ylo + ny) (k_polar_mx.hiph)
@@ -177,7 +195,7 @@ void k_polar_mxr(const plh_pass p_)
         // ---- this row phase's B fragments: global (L2) -> LDS, no registers --------------------
         __syncthreads();    // (everyone is done with the previous phase's fragments / the tile is complete)
 #pragma unroll
-        for (int f = wave; f < PLH_MXR_FRAGS_PER_PHASE; f += MXR_WAVES) {
+        for (int f = wave; f < MXR_NFRAG; f += MXR_WAVES) {
             const uintptr_t g = u_bfrag + ((size_t) (py * PLH_MXR_FRAGS_PER_PHASE + f) * 64 + lane) * 16;
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *) g,
                                              (__attribute__((address_space(3))) void *) (bl + f * 1024), 16, 0, 0);
@@ -194,8 +212,8 @@ void k_polar_mxr(const plh_pass p_)
         // one half (4 bases x R phases of columns) at a time: contraction, then the epilogue of its
         // 4 rows -- 24 accumulator registers live instead of 48
 #pragma unroll 1
-        for (int h = 0; h < 2; h++) {
-            const int X = R * (MXR_TBX * bx + 8 * wave + 4 * h + nb) + px - u_sx;
+        for (int h = 0; h < MXR_NH; h++) {
+            const int X = R * (MXR_TBX * bx + MXR_BW * wave + 4 * h + nb) + px - u_sx;
             const int cpos = u_base_x + u_dir_x * X;
             const bool cok = ln < 4 * R && X >= 0 && X < u_w && cpos >= 0 && cpos < u_dst_w;
             const _Float16 dxh = (_Float16) ((gfloat *) u_dfx)[min(max(X, 0), u_w - 1)];
@@ -212,15 +230,15 @@ void k_polar_mxr(const plh_pass p_)
                 for (int ch = 0; ch < 3; ch++)
                     acc[ch] = ay[ch] = (mx_f32x4) (0.0f);
 #pragma unroll
-                for (int j = 0; j < 4; j++) {
-                    const unsigned char *bf = bfl + 4 * (2 * j + h) * 1024;
+                for (int j = 0; j < MXR_NJ; j++) {
+                    const unsigned char *bf = bfl + 4 * (MXR_NH * j + h) * 1024;
                     const mx_f16x8 bhi = *(const mx_f16x8 *) bf;
                     const mx_f16x8 blo = __builtin_elementwise_fma(*(const mx_f16x8 *) (bf + 2048), dx8,
                                                                    *(const mx_f16x8 *) (bf + 1024));
                     const mx_f16x8 bdy = *(const mx_f16x8 *) (bf + 3072);
 #pragma unroll
                     for (int ch = 0; ch < 3; ch++) {
-                        const mx_f16x8 a = *(const mx_f16x8 *) (ab + ch * MXR_PLANE + 2 * j * MXR_PITCH);
+                        const mx_f16x8 a = *(const mx_f16x8 *) (ab + ch * MXR_PLANE + j * MXR_JSTEP);
                         acc[ch] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, bhi, acc[ch], 0, 0, 0);
                         acc[ch] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, blo, acc[ch], 0, 0, 0);
                         ay[ch] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, bdy, ay[ch], 0, 0, 0);
@@ -338,16 +356,23 @@ bool plh_polar_mxr_applies(plh_pass *pass)
 
 int plh_launch_polar_mxr(hipStream_t stream, const plh_pass *pass)
 {
-    const int R = pass->s.mx.ratio;
+    const int R = pass->s.mx.ratio, G = pass->s.mx.group;
+    if (G != 1 && G != 2)
+        return -1000;
     const int nbx = (pass->width - 1 + pass->s.mx.sx) / R + 1, nby = (pass->height - 1 + pass->s.mx.sy) / R + 1;
-    const int tiles = ((nbx + MXR_TBX - 1) / MXR_TBX) * ((nby + MXR_TBY - 1) / MXR_TBY);
-    const size_t shmem = MXR_B_BYTES + (size_t) 3 * MXR_PLANE;
+    const int tbx = MXR_TSX / G;
+    const int tiles = ((nbx + tbx - 1) / tbx) * ((nby + MXR_TBY - 1) / MXR_TBY);
+    const size_t shmem = MXR_B_BYTES + (size_t) 3 * (G * MXR_TBY + 8) * MXR_PITCH;
     const bool chain = pass->chain.enabled;
-#define MXR_LAUNCH(RR, CH) hipLaunchKernelGGL((k_polar_mxr<RR, CH>), dim3(tiles), dim3(MXR_NT), shmem, stream, *pass)
-    if (R == 3 && chain)        MXR_LAUNCH(3, true);
-    else if (R == 3)            MXR_LAUNCH(3, false);
-    else if (R == 4 && chain)   MXR_LAUNCH(4, true);
-    else if (R == 4)            MXR_LAUNCH(4, false);
+#define MXR_LAUNCH(RR, GG, CH) hipLaunchKernelGGL((k_polar_mxr<RR, GG, CH>), dim3(tiles), dim3(MXR_NT), shmem, stream, *pass)
+    if (G == 2 && R == 3 && chain)  MXR_LAUNCH(3, 2, true);
+    else if (G == 2 && R == 3)      MXR_LAUNCH(3, 2, false);
+    else if (G == 2)
+        return -1000;
+    else if (R == 3 && chain)       MXR_LAUNCH(3, 1, true);
+    else if (R == 3)                MXR_LAUNCH(3, 1, false);
+    else if (R == 4 && chain)       MXR_LAUNCH(4, 1, true);
+    else if (R == 4)                MXR_LAUNCH(4, 1, false);
     else
         return -1000;
 #undef MXR_LAUNCH

@@ -115,12 +115,17 @@ struct plh_polar_pp {
 // A wave owns 8 base columns = two 16-column halves h of 4 bases x R phases (4 R <= 16 columns
 // used); the 128 fragments of R = 4 do not fit the LDS next to the tile, so they are staged per
 // row phase: frag f = 4 * (2 * (4 * py + j) + h) + {hi, lo, d/dx, d/dy}, 32 per row phase.
-#define PLH_MXR_FRAGS_PER_PHASE 32
+// The 3 : 2 upscale (720p -> 1080p, 1440p -> 4K) is the same with a base index standing for a GROUP
+// of two source texels (ratio 3, group 2): the outputs of a group start at texel offsets 0 .. 2 of
+// it (in the weights' placement only), a base's footprint is 10 rows = five row pairs, a wave's 8
+// source columns are 4 groups = ONE half: frag f = 4 * (5 * py + j) + kind, 20 per row phase.
+#define PLH_MXR_FRAGS_PER_PHASE 32      // (the stride of a row phase in the blob, either way)
 #define PLH_MXR_MAX_RATIO 4
 struct plh_polar_mx {
     int32_t enabled;        // 1: the 2x upscale (k_polar_mx), 2: the 2 : 1 downscale (k_polar_mxd),
-                            // 3: an integer upscale by `ratio` (k_polar_mxr)
+                            // 3: an upscale by ratio : group, 3, 4 or 3 : 2 (k_polar_mxr)
     int32_t ratio, sx, sy;  // enabled == 3
+    int32_t group, pad_;    // enabled == 3: source texels per base index (1, or 2 for 3 : 2)
     int32_t org_x, org_y;   // source texel held by LDS tile (0, 0) of workgroup tile (0, 0)
     const void *bfrag;      // device: [PLH_MX_NFRAG][64 lanes][8] f16
     const float *dfx, *dfy; // device: phase deviation of every output column / row, x 2^PLH_MX_DSHIFT

@@ -13,6 +13,7 @@
  *   deband constants          sampling.c:183-275
  */
 #include <float.h>
+#include <limits.h>
 #include <math.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -859,64 +860,81 @@ static bool polar_mx_build(pl_gpu gpu, pl_log log, struct sh_sampler_obj *obj,
     return true;
 }
 
-// The geometry k_polar_mxr covers: an axis of an exact integer upscale by R. Output i belongs to
-// base index (i + shift) / R and phase (i + shift) % R; every phase of a base index shares the base
-// texel base[0] + index; the phase of an output is its phase class' up to the fp32 rounding of the
-// attribute interpolation. An ODD ratio has a phase at fcoord = 0, where that rounding decides
-// between (base b, fcoord +eps) and (base b - 1, fcoord 1 - eps): the same sample position -- the
-// tap that enters at one end and the one that leaves at the other lie beyond the filter's radius --
-// so such an output is taken as (b, fcoord - 1), a small negative deviation from the phase
-// (`canon`: the outputs' canonical fcoord, which the caller turns into the deviations). Returns
-// the shift and a representative, unwrapped output of every phase.
-static bool mxr_axis(const float *fc, const int32_t *base, int len, int R, int *shift,
-                     int rep[PLH_MXR_MAX_RATIO], float *canon)
+// The geometry k_polar_mxr covers: an axis of an exact upscale by R : G (R outputs per G source
+// texels; G = 1: the integer ratios). Output i belongs to base index (i + shift) / R and phase
+// (i + shift) % R; the base texel of an output is origin + G * index + off[phase] with the same small
+// offset for every output of a phase (G = 1: none); the phase of an output is its phase class' up
+// to the fp32 rounding of the attribute interpolation. A phase at fcoord = 0 (odd integer ratios
+// have one) is where that rounding decides between (base b, fcoord +eps) and (base b - 1, fcoord
+// 1 - eps): the same sample position -- the tap that enters at one end and the one that leaves at
+// the other lie beyond the filter's radius -- so such an output is taken as (b, fcoord - 1), a small
+// negative deviation from the phase (`canon`: the outputs' canonical fcoord, which the caller turns
+// into the deviations). Returns the shift, the origin, the offsets and a representative, unwrapped
+// output of every phase.
+static bool mxr_axis(const float *fc, const int32_t *base, int len, int R, int G, int *shift,
+                     int *origin, int off[PLH_MXR_MAX_RATIO], int rep[PLH_MXR_MAX_RATIO], float *canon)
 {
-    if (len < 2 * R)
+    if (len < 3 * R)
         return false;
-    int32_t first = 0;
-    for (int i = 0; i < len; i++) {
-        const bool wrapped = fc[i] > 0.98f;
-        canon[i] = wrapped ? fc[i] - 1.0f : fc[i];
-        const int32_t b = base[i] + (wrapped ? 1 : 0);
-        if (i == 0)
-            first = b;
-        if (b < first)
-            return false;
+    for (int i = 0; i < len; i++)
+        canon[i] = fc[i] > 0.98f ? fc[i] - 1.0f : fc[i];
+#define CANON_BASE(i) (base[i] + (fc[i] > 0.98f ? 1 : 0))
+    // the shift: the one under which the offsets are consistent and smallest
+    int best = -1, best_max = 0, best_org = 0;
+    for (int sh = 0; sh < R; sh++) {
+        int org = INT_MAX;
+        for (int i = 0; i < 2 * R; i++)
+            org = PL_MIN(org, CANON_BASE(i) - G * ((i + sh) / R));
+        int o[PLH_MXR_MAX_RATIO], omax = 0;
+        bool ok = true;
+        for (int q = 0; q < R; q++)
+            o[q] = -1;
+        for (int i = 0; i < len && ok; i++) {
+            const int q = (i + sh) % R;
+            const int d = CANON_BASE(i) - G * ((i + sh) / R) - org;
+            if (o[q] < 0)
+                o[q] = d;
+            ok = d == o[q] && d >= 0 && d <= (G == 1 ? 0 : 2);
+            omax = PL_MAX(omax, d);
+        }
+        if (ok && (best < 0 || omax < best_max)) {
+            best = sh;
+            best_max = omax;
+            best_org = org;
+        }
     }
-    // the shift: R minus the number of leading outputs on the first canonical base
-    int lead = 0;
-    while (lead < len && base[lead] + (fc[lead] > 0.98f ? 1 : 0) == first)
-        lead++;
-    if (lead < 1 || lead > R)
+    if (best < 0)
         return false;
-    *shift = R - lead;
+    *shift = best;
+    *origin = best_org;
     for (int q = 0; q < R; q++)
-        rep[q] = -1;
+        rep[q] = off[q] = -1;
     for (int i = 0; i < len; i++) {
-        const int q = (i + *shift) % R;
-        const bool wrapped = fc[i] > 0.98f;
-        if (base[i] + (wrapped ? 1 : 0) != first + (i + *shift) / R)
-            return false;
-        if (rep[q] < 0 && !wrapped)
+        const int q = (i + best) % R;
+        if (off[q] < 0)
+            off[q] = CANON_BASE(i) - G * ((i + best) / R) - best_org;
+        if (rep[q] < 0 && !(fc[i] > 0.98f))
             rep[q] = i;
     }
+#undef CANON_BASE
     for (int q = 0; q < R; q++) {
-        if (rep[q] < 0)
+        if (rep[q] < 0 || off[q] < 0)
             return false;
     }
     for (int i = 0; i < len; i++) {
-        const int q = (i + *shift) % R;
+        const int q = (i + best) % R;
         if (fabsf(canon[i] - fc[rep[q]]) > 1e-5f + 1.5f * FLT_EPSILON * (float) len)
             return false;
     }
     return true;
 }
 
-// B fragments of k_polar_mxr (plh_device.h): frag f = 4 * (2 * (4 * py + j) + h) + kind, lane l,
-// element e hold T(py, j, h)[k][n], n = l & 15 the output column within half h of the wave's 8
+// B fragments of k_polar_mxr (plh_device.h): frag f = 32 py + 4 * (NH * j + h) + kind, lane l,
+// element e hold T(py, j, h)[k][n], n = l & 15 the output column within half h of the wave's 8 / G
 // bases -- base bi = 4 h + n / R, phase px = n % R, n < 4 R -- and K index (row 2 j + (l >> 5) of the
-// base's eight tap rows, column k = 8 * ((l >> 4) & 1) + e of the wave's 16-column window):
-//   = w'(py, px, tap (k - bi - 3, 2 j + (l >> 5) - 3)), kinds as in polar_mx_build.
+// base's footprint rows, column k = 8 * ((l >> 4) & 1) + e of the wave's 16-column window):
+//   = w'(py, px, tap (k - G bi - offx[px] - 3, 2 j + (l >> 5) - offy[py] - 3)), kinds as in
+// polar_mx_build. NH halves and NJ row pairs: 2 and 4 for the integer ratios, 1 and 5 for 3 : 2.
 static bool polar_mxr_build(pl_gpu gpu, pl_log log, struct sh_sampler_obj *obj,
                             const struct plh_pass *pass, const float *wall, const uint32_t *taps,
                             int ntaps, int ncx, int ncy, const float *clsx, const float *clsy,
@@ -931,19 +949,25 @@ static bool polar_mxr_build(pl_gpu gpu, pl_log log, struct sh_sampler_obj *obj,
     if (gpu->glsl.max_shmem_size < 64 * 1024 || s->bound > 4 || s->tile_fp32 ||
         s->address_mode != PLH_ADDRESS_CLAMP || pass->transpose || s->src.w < 2 || s->antiring > 0)
         return false;
-    int R = 0, sx = 0, sy = 0, repx[PLH_MXR_MAX_RATIO], repy[PLH_MXR_MAX_RATIO];
+    int R = 0, G = 0, sx = 0, sy = 0, repx[PLH_MXR_MAX_RATIO], repy[PLH_MXR_MAX_RATIO];
+    int bx0 = 0, by0 = 0, offx[PLH_MXR_MAX_RATIO], offy[PLH_MXR_MAX_RATIO];
     float *canx = malloc(((size_t) W + H) * sizeof(float)), *cany = canx ? canx + W : NULL;
     if (!canx)
         return false;
-    for (int r = 3; r <= PLH_MXR_MAX_RATIO && !R; r++) {
-        if (mxr_axis(colfc, colbase, W, r, &sx, repx, canx) && mxr_axis(rowfc, rowbase, H, r, &sy, repy, cany))
-            R = r;
+    static const int ratios[][2] = { {3, 1}, {4, 1}, {3, 2} };
+    for (int r = 0; r < 3 && !R; r++) {
+        if (mxr_axis(colfc, colbase, W, ratios[r][0], ratios[r][1], &sx, &bx0, offx, repx, canx) &&
+            mxr_axis(rowfc, rowbase, H, ratios[r][0], ratios[r][1], &sy, &by0, offy, repy, cany)) {
+            R = ratios[r][0];
+            G = ratios[r][1];
+        }
     }
     if (!R) {
-        pl_msg(log, PL_LOG_DEBUG, "matrix-pipe polar: not an exact 3x / 4x geometry either");
+        pl_msg(log, PL_LOG_DEBUG, "matrix-pipe polar: not an exact 3x / 4x / 3 : 2 geometry either");
         free(canx);
         return false;
     }
+    const int NJ = G == 1 ? 4 : 5, NH = G == 1 ? 2 : 1;
     int tap_at[8][8];
     for (int y = 0; y < 8; y++) {
         for (int x = 0; x < 8; x++)
@@ -1033,16 +1057,16 @@ static bool polar_mxr_build(pl_gpu gpu, pl_log log, struct sh_sampler_obj *obj,
     const double dscale = ldexp(1.0, -PLH_MX_DSHIFT);
     double worst = 0.0;
     for (int py = 0; py < R; py++) {
-        for (int j = 0; j < 4; j++) {
-            for (int h = 0; h < 2; h++) {
-                const size_t f = 4 * (size_t) (2 * (4 * py + j) + h);
+        for (int j = 0; j < NJ; j++) {
+            for (int h = 0; h < NH; h++) {
+                const size_t f = (size_t) py * PLH_MXR_FRAGS_PER_PHASE + 4 * (size_t) (NH * j + h);
                 for (int l = 0; l < 64; l++) {
                     const int n = l & 15, px = n % R, bi = 4 * h + n / R;
-                    const int wy = 2 * j + (l >> 5);
+                    const int wy = 2 * j + (l >> 5) - offy[py];
                     for (int e = 0; e < 8; e++) {
-                        const int k = 8 * ((l >> 4) & 1) + e, wx = k - bi;
+                        const int k = 8 * ((l >> 4) & 1) + e, wx = k - G * bi - offx[px];
                         double v = 0.0, vx = 0.0, vy = 0.0;
-                        if (n < 4 * R && wx >= 0 && wx < 8 && tap_at[wy][wx] >= 0) {
+                        if (n < 4 * R && wx >= 0 && wx < 8 && wy >= 0 && wy < 8 && tap_at[wy][wx] >= 0) {
                             const int t = tap_at[wy][wx];
                             v = WN(cx[px], cy[py], t);
                             vx = slx[(size_t) (py * R + px) * nt + t];
@@ -1076,8 +1100,6 @@ static bool polar_mxr_build(pl_gpu gpu, pl_log log, struct sh_sampler_obj *obj,
         dev = fmaxf(dev, fabsf(d));
         dfy[i] = d * up;
     }
-    // (the first canonical base: where a wrapped first output sits one texel lower)
-    const int bx0 = colbase[0] + (colfc[0] > 0.98f ? 1 : 0), by0 = rowbase[0] + (rowfc[0] > 0.98f ? 1 : 0);
     free(canx);
     pl_buf_destroy(gpu, &obj->mx_blob);
     obj->mx_blob = pl_buf_create(gpu, pl_buf_params(.size = bytes, .storable = true, .initial_data = blob));
@@ -1086,14 +1108,14 @@ static bool polar_mxr_build(pl_gpu gpu, pl_log log, struct sh_sampler_obj *obj,
         return false;
     const char *base = pl_hip_buf_ptr(obj->mx_blob);
     obj->mx_host = (struct plh_polar_mx) {
-        .enabled = 3, .ratio = R, .sx = sx, .sy = sy,
-        .org_x = bx0 - 3, .org_y = by0 - 3,
+        .enabled = 3, .ratio = R, .group = G, .sx = sx, .sy = sy,
+        .org_x = bx0 - 3, .org_y = by0 - 3,     // (bx0, by0: the texel of base index 0, offset 0)
         .bfrag = base,
         .dfx = (const float *) (base + o_dfx), .dfy = (const float *) (base + o_dfy),
     };
     obj->mx_announced = false;
-    pl_msg(log, PL_LOG_DEBUG, "matrix-pipe tables for the polar pass: %d x %d phases (integer upscale, shifts %d / %d, "
-           "per-pixel phases within %.2e: first-order terms), weight split error <= %.2e", R, R, sx, sy, dev, worst);
+    pl_msg(log, PL_LOG_DEBUG, "matrix-pipe tables for the polar pass: %d x %d phases (%d : %d upscale, shifts %d / %d, "
+           "per-pixel phases within %.2e: first-order terms), weight split error <= %.2e", R, R, R, G, sx, sy, dev, worst);
     return true;
 }
 

@@ -158,18 +158,18 @@ def test_mx_not_used_where_it_does_not_apply():
     frame there"""
     sw, sh = 96, 64
     img = util.chirp_rgba16(sw, sh)
-    for dw, dh in ((144, 96), (192, 96), (240, 160)):
+    for dw, dh in ((168, 112), (192, 96), (240, 160)):
         a = render(img, dw, dh, ewa(), True, expect_mx=False)
         b = render(img, dw, dh, ewa(), False, expect_mx=False)
         assert np.array_equal(a, b)
 
 
-@pytest.mark.parametrize("ratio", [3, 4])
+@pytest.mark.parametrize("ratio", [3, 4, 1.5])
 @pytest.mark.parametrize("size", [(80, 48), (131, 77), (1280, 720)])
 @pytest.mark.parametrize("content", ["chirp", "noise"])
 def test_mxr_integer_upscale_vs_reference_kernel_and_oracle(ratio, size, content):
-    """k_polar_mxr -- the EWA upscale by exactly 3 or 4 on the matrix pipe (720p -> 4K is 3x) --
-    against k_polar_pp, which IS the oracle bit for bit, at sizes whose edge tiles are clipped and
+    """k_polar_mxr -- the EWA upscale by exactly 3, 4 or 3 : 2 on the matrix pipe (720p -> 4K is 3x,
+    1440p -> 4K is 3 : 2) -- against k_polar_pp, which IS the oracle bit for bit, at sizes whose edge tiles are clipped and
     at the real one. Same statement as the 2x kernel: <= 1 code of 16 bits, identical on the bulk;
     a 10-bit dithered frame differs by one step on a fraction of a percent, and every sample of
     it is the dither of the frame's own pre-dither value (index path exact)."""
@@ -177,12 +177,14 @@ def test_mxr_integer_upscale_vs_reference_kernel_and_oracle(ratio, size, content
     sw, sh = size
     if ratio == 4 and sw > 1000:
         sw, sh = 960, 540
+    if ratio == 1.5:
+        sw, sh = {80: (80, 48), 131: (130, 78), 1280: (2560, 1440)}[sw]
     img = util.chirp_rgba16(sw, sh) if content == "chirp" else util.random_rgba16(sw, sh, seed=3)
-    dw, dh = ratio * sw, ratio * sh
+    dw, dh = int(ratio * sw), int(ratio * sh)
     q_mx = render(img, dw, dh, ewa(), True, expect_mx=True)
     q_pp = render(img, dw, dh, ewa(), False, expect_mx=False)
     frac = assert_codes(q_mx, q_pp)
-    print("k_polar_mxr %dx %dx%d %s: 16-bit frames differ on %.4f of the samples, by one code" %
+    print("k_polar_mxr %gx %dx%d %s: 16-bit frames differ on %.4f of the samples, by one code" %
           (ratio, sw, sh, content, frac))
     if sw < 1000:
         a = orc.tex_decode(img, "rgba16")
@@ -198,7 +200,7 @@ def test_mxr_integer_upscale_vs_reference_kernel_and_oracle(ratio, size, content
     assert dither_consistency(d_mx, q_mx, util.blue_noise(pl)) == 0.0
 
 
-@pytest.mark.parametrize("ratio", [3, 4])
+@pytest.mark.parametrize("ratio", [3, 4, 1.5])
 def test_mxr_hdr_colour_map_epilogue_and_f16_source(ratio):
     """the HDR map chain behind the 3x / 4x upscale (720p HDR10 -> 4K SDR: the metric's frame from a
     720p source) and an rgba16hf source (no fused decode): within the conditioning of the colour
@@ -211,17 +213,18 @@ def test_mxr_hdr_colour_map_epilogue_and_f16_source(ratio):
     params = pl.render_params("default", upscaler=pl.filter_config("ewa_lanczos"), dither_params=None,
                               peak_detect_params=pl.peak_detect_params(percentile=99.995))
     kw = dict(image_kw=dict(color=hdr), target_kw=dict(color=sdr))
-    mx = render(img, ratio * sw, ratio * sh, params, True, expect_mx=True, **kw)
-    pp = render(img, ratio * sw, ratio * sh, params, False, **kw)
+    dw, dh = int(ratio * sw), int(ratio * sh)
+    mx = render(img, dw, dh, params, True, expect_mx=True, **kw)
+    pp = render(img, dw, dh, params, False, **kw)
     d = np.abs(mx[..., :3].astype(np.int64) - pp[..., :3])
-    print("HDR epilogue %dx: |mxr - pp| codes: median %.1f p99 %.1f max %d" %
+    print("HDR epilogue %gx: |mxr - pp| codes: median %.1f p99 %.1f max %d" %
           (ratio, np.median(d), np.quantile(d, 0.99), d.max()))
     assert np.quantile(d, 0.5) <= 1 and np.quantile(d, 0.99) <= 4 and d.max() <= 64
     assert np.array_equal(mx[..., 3], pp[..., 3])
     rng = np.random.default_rng(9)
     f16 = rng.random((sh, sw, 4), dtype=np.float32).astype(np.float16)
-    a = render(f16, ratio * sw, ratio * sh, ewa(), True, src_fmt="rgba16hf", expect_mx=True)
-    b = render(f16, ratio * sw, ratio * sh, ewa(), False, src_fmt="rgba16hf")
+    a = render(f16, dw, dh, ewa(), True, src_fmt="rgba16hf", expect_mx=True)
+    b = render(f16, dw, dh, ewa(), False, src_fmt="rgba16hf")
     assert_codes(a, b)
 
 
