@@ -98,6 +98,48 @@ def test_transfer_vs_oracle(gpu, trc, direction):
     assert np.abs(got - ref).max() <= tol, np.abs(got - ref).max()
 
 
+def test_pq_pair_error_bound_over_every_code(gpu):
+    """pqmath.hiph's pq_eotf_acc1 / pq_oetf_acc1 (every PQ conversion of the image path) against a
+    float64 evaluation of the reference's formulas (colorspace.c:645-651, :749-755, with the
+    six-decimal constants it prints), for ALL 65536 sixteen-bit PQ codes. The bound that matters is
+    the distance to one 16-bit code: 1.5e-5 relative at the steepest point of the curve; the
+    EOTF is evaluated as exp2(log2(inner) * 6.277) with native log / exp and plain reciprocals
+    (ADVICE r03), so its error is stated and held here: <= 5e-6 relative over the whole range,
+    near black included, and the OETF puts every code's linear value back within 0.1 code."""
+    import colormap_f64 as c64
+    codes = np.arange(65536, dtype=np.float64)
+    v = (codes / 65535.0).reshape(256, 256)
+    src = np.zeros((256, 256, 4), np.float32)
+    src[..., 0] = v
+    src[..., 1] = v[::-1, ::-1]
+    src[..., 2] = v.T
+    src[..., 3] = 1.0
+    csp = pl.color_space("bt2020", "pq")
+    pl.lib().pl_color_space_infer(C.byref(csp))
+    got = run_ops(gpu, src, lambda sh: sh.linearize(csp)).astype(np.float64)
+    ref = c64.pq_eotf(src[..., :3].astype(np.float64)) * c64.K10
+    nz = src[..., :3] > 0
+    rel = np.abs(got[..., :3] - ref)[nz] / ref[nz]
+    dark = (src[..., :3] < 0.1)[nz]
+    print("PQ EOTF vs float64: max relative error %.2e (codes below 0.1: %.2e, mean %.2e)" %
+          (rel.max(), rel[dark].max(), rel.mean()))
+    assert rel.max() <= 5e-6
+    assert np.all(got[..., :3][~nz] == 0.0)
+    # ... and back: the OETF of the float64 linear value is the code it came from
+    lin = np.zeros_like(src)
+    lin[..., :3] = ref.astype(np.float32)
+    lin[..., 3] = 1.0
+    back = run_ops(gpu, lin, lambda sh: sh.delinearize(csp)).astype(np.float64)
+    err = np.abs(back[..., :3] - src[..., :3].astype(np.float64)) * 65535.0
+    # (the fp32 rounding of the INPUT alone moves the result by up to 6e-8 * slope: near black,
+    # where a code is 1e-7 of the linear range, that is the dominant term)
+    truth = c64.pq_oetf(lin[..., :3].astype(np.float64) / c64.K10)
+    own = np.abs(back[..., :3] - truth) * 65535.0
+    print("PQ OETF vs float64: max %.3f codes of 16 bits (%.3f against the float64 OETF of the fp32 input)"
+          % (err.max(), own.max()))
+    assert own.max() <= 0.1 and err.max() <= 0.6
+
+
 @pytest.mark.parametrize("inverse", [False, True])
 def test_sigmoid_vs_oracle(gpu, inverse):
     rng = np.random.default_rng(4)
