@@ -89,6 +89,12 @@ WORKLOADS = {
     "default_preset_1080p_to_4k": (P1080, P4K, px(P1080) * 8 + px(P4K) * 8, "ortho"),
     # the plain SDR downscale: 4K -> 1080p EWA (widened, 148 taps), 10-bit dither, one launch
     "ewa_lanczos_4k_to_1080p_dither10": (P4K, P1080, px(P4K) * 8 + px(P1080) * 8, "polar"),
+    # ... in linear light (what the reference does by default in front of a downscaler): the
+    # linearisation fused into the tile staging, the inverse curve in front of the dither
+    "ewa_lanczos_4k_to_1080p_linear_dither10": (P4K, P1080, px(P4K) * 8 + px(P1080) * 8, "polar"),
+    # HDR10 8K -> 4K without debanding: PQ plane -> (fused linearisation) EWA 2 : 1 -> linear f16
+    # intermediate -> measurement -> tone map
+    "ewa_8k_to_4k_hdr_tonemap": (P8K, P4K, px(P8K) * 8 + 4 * px(P4K) * 8, "polar"),
     "hdr10_4k_tonemap": (P4K, P4K, 3 * px(P4K) * 8, "tone map"),
     "ewa_8k_to_4k_deband_tonemap": (P8K, P4K, px(P8K) * 8 + px(P4K) * 8, "polar"),
     # the metric's two halves in one frame: 1080p HDR10 -> EWA 2x upscale -> tone map -> 4K SDR
@@ -111,6 +117,8 @@ KERNEL_BYTES = {
     "ewa_lanczos_4k_to_1080p_dither10": px(P4K) * 8 + px(P1080) * 8,
     "hdr10_4k_tonemap": 2 * px(P4K) * 8,                    # the map pass: f16 intermediate in, rgba16 out
     "ewa_8k_to_4k_deband_tonemap": px(P8K) * 8 + px(P4K) * 8,  # the polar pass: 8K f16 in, 4K f16 out
+    "ewa_8k_to_4k_hdr_tonemap": px(P8K) * 8 + px(P4K) * 8,
+    "ewa_lanczos_4k_to_1080p_linear_dither10": px(P4K) * 8 + px(P1080) * 8,
     "ewa_1080p_to_4k_hdr_tonemap": px(P1080) * 8 + px(P4K) * 8,    # polar + map launch: 1080p f16 in, 4K out
 }
 
@@ -197,6 +205,15 @@ class Stream:
                                            dither_params=dither, disable_linear_scaling=True,
                                            disable_dither_gamma_correction=True)
             icsp, tcsp, trepr = sdr, sdr, ten_bit
+        elif workload == "ewa_lanczos_4k_to_1080p_linear_dither10":
+            self.params = pl.render_params("fast", downscaler=pl.filter_config("ewa_lanczos"),
+                                           dither_params=dither, disable_dither_gamma_correction=True)
+            icsp, tcsp, trepr = sdr, sdr, ten_bit
+        elif workload == "ewa_8k_to_4k_hdr_tonemap":
+            self.params = pl.render_params(
+                "default", downscaler=pl.filter_config("ewa_lanczos"), dither_params=dither,
+                peak_detect_params=pl.peak_detect_params(percentile=99.995))
+            icsp, tcsp, trepr = hdr, bt1886, ten_bit
         elif workload == "lanczos_1080p_to_4k_dither10":
             self.params = pl.render_params("fast", upscaler=pl.filter_config("lanczos"),
                                            dither_params=dither,

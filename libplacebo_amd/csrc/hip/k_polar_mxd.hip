@@ -26,9 +26,15 @@
  * register file. Per wave: 14 x 2 x (3 A reads + 9 MFMAs) + 56 B reads = 252 v_mfma_f32_16x16x32_f16.
  * Handled: an rgba16hf (BASELINE configs[4]) or rgba16 source without fused pre-ops or behind an
  * identity PLANE_MAP, RGB; an rgba16hf target without post-ops, or an rgba16 target behind the fused
- * epilogue (dither + scale); everything else stays on k_polar_pp.
+ * epilogue (dither + scale). Round 4: the passes of a LINEAR-LIGHT downscale -- the reference
+ * linearises in front of a downscaler (src/renderer.c:1997-2003) -- i.e. an rgba16 source with
+ * PLANE_MAP + LINEARIZE as fused pre-ops (the reference's PASS A: plane -> linear rgba16hf
+ * intermediate; HDR 8K -> 4K without debanding, into the intermediate the measurement reads) and a
+ * DELINEARIZE in front of the fused epilogue (SDR 4K -> 1080p in linear light). Everything else
+ * stays on k_polar_pp.
  */
 #include "polar_common.hiph"
+#include "transfer.hiph"
 
 #define MXD_TW      64                      // output columns per workgroup tile
 #define MXD_TH      32                      // output rows
@@ -48,7 +54,79 @@ typedef float mxd_f32x4 __attribute__((ext_vector_type(4)));
 // UNORM: an rgba16 source (decoded and rounded to f16 while staged: the reference's rgba16hf
 // intermediate, fused) instead of an rgba16hf one; F16DST: an rgba16hf target, else rgba16 through
 // the fused epilogue (dither + scale, fastepi.hiph).
-template <bool UNORM, bool F16DST>
+// The curve of a LINEARIZE / DELINEARIZE op over N independent values with the transfer as a
+// compile-time constant: op_linearize per texel has a uniform switch per channel, i.e. a chain of
+// basic blocks per value, and the compiler does not interleave the values' log -> mul -> exp chains
+// across them (measured: the staging of an 8K PQ frame 2.7 x its instruction count). The clamp
+// and the black scaling are applied branch-free (max against -inf, 1 * x + 0: exact no-ops).
+template <int TRC, int N>
+DEV void mxd_lin_n(float (&v)[N], const plh_op &op)
+{
+    const float lo = (op.i1 & PLH_TRC_CLAMP0) ? 0.0f : -__builtin_inff();
+    const bool rs = op.i1 & PLH_TRC_RESCALE;
+    const float f0 = rs ? op.f[0] : 1.0f, f1 = rs ? op.f[1] : 0.0f;
+#pragma unroll
+    for (int k = 0; k < N; k++) {
+        const float x = lin1(fmaxf(v[k], lo), TRC, op.f);
+        v[k] = f0 * x + f1;
+    }
+}
+
+template <int TRC, int N>
+DEV void mxd_delin_n(float (&v)[N], const plh_op &op)
+{
+    const float lo = (op.i1 & PLH_TRC_CLAMP0) ? 0.0f : -__builtin_inff();
+    const bool rs = op.i1 & PLH_TRC_RESCALE;
+    const float f0 = rs ? op.f[0] : 1.0f, f1 = rs ? op.f[1] : 0.0f;
+#pragma unroll
+    for (int k = 0; k < N; k++)
+        v[k] = delin1(fmaxf(f0 * v[k] + f1, lo), TRC, op.f);
+}
+
+// N = 3 x texels, texel-major (r g b r g b ...)
+template <int N>
+DEV void mxd_linearize(float (&v)[N], const plh_op &op)
+{
+    switch (op.i0) {
+    case TRC_SRGB:      mxd_lin_n<TRC_SRGB>(v, op); break;
+    case TRC_BT_1886:   mxd_lin_n<TRC_BT_1886>(v, op); break;
+    case TRC_PQ:        mxd_lin_n<TRC_PQ>(v, op); break;
+    case TRC_UNKNOWN: case TRC_GAMMA18: case TRC_GAMMA20: case TRC_GAMMA22:
+    case TRC_GAMMA24: case TRC_GAMMA26: case TRC_GAMMA28:
+                        mxd_lin_n<TRC_GAMMA22>(v, op); break;
+    default:
+#pragma unroll
+        for (int t = 0; t < N / 3; t++) {
+            float4_t c = { v[3 * t], v[3 * t + 1], v[3 * t + 2], 1.0f };
+            op_linearize(c, op);
+            v[3 * t] = c.x; v[3 * t + 1] = c.y; v[3 * t + 2] = c.z;
+        }
+    }
+}
+
+template <int N>
+DEV void mxd_delinearize(float (&v)[N], const plh_op &op)
+{
+    switch (op.i0) {
+    case TRC_SRGB:      mxd_delin_n<TRC_SRGB>(v, op); break;
+    case TRC_BT_1886:   mxd_delin_n<TRC_BT_1886>(v, op); break;
+    case TRC_PQ:        mxd_delin_n<TRC_PQ>(v, op); break;
+    case TRC_UNKNOWN: case TRC_GAMMA18: case TRC_GAMMA20: case TRC_GAMMA22:
+    case TRC_GAMMA24: case TRC_GAMMA26: case TRC_GAMMA28:
+                        mxd_delin_n<TRC_GAMMA22>(v, op); break;
+    default:
+#pragma unroll
+        for (int t = 0; t < N / 3; t++) {
+            float4_t c = { v[3 * t], v[3 * t + 1], v[3 * t + 2], 1.0f };
+            op_delinearize(c, op);
+            v[3 * t] = c.x; v[3 * t + 1] = c.y; v[3 * t + 2] = c.z;
+        }
+    }
+}
+
+// PRE: a LINEARIZE pre-op (the last one) on the staged texels -- UNORM sources only; DELIN: a
+// DELINEARIZE as the first post-op.
+template <bool UNORM, bool F16DST, bool PRE = false, bool DELIN = false>
 __global__ __launch_bounds__(MXD_NT)
 void k_polar_mxd(const plh_pass p_)
 {
@@ -170,7 +248,12 @@ void k_polar_mxd(const plh_pass p_)
             const uint4 w = v[u];
             if (tid + u * MXD_NT < MXD_NPAIRS) {
                 unsigned char *d = tile + ty[u] * MXD_PITCH + tp[u] * 4;
-                if (UNORM) {
+                if (UNORM && PRE) {
+                    // the raw codes, converted in place below
+                    *(uint32_t *) d = (w.x & 0xffffu) | (w.z << 16);
+                    *(uint32_t *) (d + MXD_PLANE) = (w.x >> 16) | (w.z & 0xffff0000u);
+                    *(uint32_t *) (d + 2 * MXD_PLANE) = (w.y & 0xffffu) | (w.w << 16);
+                } else if (UNORM) {
                     // decode to fp32, THEN round to f16 (what the rgba16hf store + load of the unfused
                     // pass does). The two roundings are kept apart on purpose: left alone the compiler
                     // folds the last fma of the decode into v_fma_mixlo_f16, which rounds once -- one
@@ -188,6 +271,31 @@ void k_polar_mxd(const plh_pass p_)
                     *(uint32_t *) (d + MXD_PLANE) = (w.x >> 16) | (w.z & 0xffff0000u);
                     *(uint32_t *) (d + 2 * MXD_PLANE) = (w.y & 0xffffu) | (w.w << 16);
                 }
+            }
+        }
+
+        if constexpr (PRE) {
+            // decode + linearize + f16 rounding (= the reference's PASS A into its rgba16hf
+            // intermediate) of the texel pairs this lane has just stored: a rolled loop, so that the
+            // curve's code exists once (LDS keeps a wave's own accesses in order: no barrier)
+            const plh_op &lop = p.ops[p.num_pre_ops - 1];
+#pragma unroll 1
+            for (int u = 0; u < MXD_NV; u++) {
+                const int i = tid + u * MXD_NT;
+                if (i >= MXD_NPAIRS)
+                    break;
+                const int y = (int) (((float) i + 0.5f) * (1.0f / (float) MXD_HP));
+                unsigned char *d = tile + y * MXD_PITCH + (i - y * MXD_HP) * 4;
+                const uint32_t q0 = *(const uint32_t *) d, q1 = *(const uint32_t *) (d + MXD_PLANE),
+                               q2 = *(const uint32_t *) (d + 2 * MXD_PLANE);
+                float c[6] = { plh_un16(q0 & 0xffffu), plh_un16(q1 & 0xffffu), plh_un16(q2 & 0xffffu),
+                               plh_un16(q0 >> 16), plh_un16(q1 >> 16), plh_un16(q2 >> 16) };
+                mxd_linearize(c, lop);
+                // (fp32 result, THEN the f16 rounding: see the decode above)
+                asm volatile("" : "+v"(c[0]), "+v"(c[1]), "+v"(c[2]), "+v"(c[3]), "+v"(c[4]), "+v"(c[5]));
+                *(uint32_t *) d = (uint32_t) plh_f2h(c[0]) | ((uint32_t) plh_f2h(c[3]) << 16);
+                *(uint32_t *) (d + MXD_PLANE) = (uint32_t) plh_f2h(c[1]) | ((uint32_t) plh_f2h(c[4]) << 16);
+                *(uint32_t *) (d + 2 * MXD_PLANE) = (uint32_t) plh_f2h(c[2]) | ((uint32_t) plh_f2h(c[5]) << 16);
             }
         }
 
@@ -281,15 +389,21 @@ void k_polar_mxd(const plh_pass p_)
         // ---- epilogue: rgba16hf store, guarded (dispatch.c:1126-1142) ----------------------------
         const int cpos = p.base_x + p.dir_x * X;
         const bool cok = X < p.width && p.out_scale[0] * (float) X < 1.0f && cpos >= 0 && cpos < p.dst.w;
+        float oall[12];
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+#pragma unroll
+            for (int ch = 0; ch < 3; ch++)
+                oall[3 * r + ch] = __builtin_fmaf(dfy[r], accy[0][ch][r] - accy[1][ch][r], acc[0][ch][r] + acc[1][ch][r]);
+        }
+        if constexpr (DELIN)
+            mxd_delinearize(oall, p.ops[p.num_pre_ops]);
 #pragma unroll
         for (int r = 0; r < 4; r++) {
             const int Y = Y0 + r;
             const int rpos = p.base_y + p.dir_y * Y;
             const bool ok = cok && Y < p.height && p.out_scale[1] * (float) Y < 1.0f && rpos >= 0 && rpos < p.dst.h;
-            float o[3];
-#pragma unroll
-            for (int ch = 0; ch < 3; ch++)
-                o[ch] = __builtin_fmaf(dfy[r], accy[0][ch][r] - accy[1][ch][r], acc[0][ch][r] + acc[1][ch][r]);
+            float o[3] = { oall[3 * r], oall[3 * r + 1], oall[3 * r + 2] };
             plh_u32x2 px;
             if (F16DST) {
                 px.x = (uint32_t) plh_f2h(o[0]) | ((uint32_t) plh_f2h(o[1]) << 16);
@@ -328,21 +442,29 @@ bool plh_polar_mxd_applies(plh_pass *pass)
     if (s.mx.enabled != 2 || (s.comp_mask & 0xf) != 0x7 || pass->transpose ||
         (s.src.fmt != PLH_FMT_RGBA16F && s.src.fmt != PLH_FMT_RGBA16))
         return false;
-    // pre-ops: none, or a fused identity PLANE_MAP of a plane that carries r, g, b (changes none)
-    if (pass->num_pre_ops > 1)
-        return false;
-    if (pass->num_pre_ops == 1) {
-        const plh_op &op = pass->ops[0];
-        if (op.kind != PLH_OP_PLANE_MAP || !op.i2 || op.i1 < 3)
+    // pre-ops: [an identity PLANE_MAP of a plane that carries r, g, b (changes none)] [LINEARIZE]
+    int i = 0;
+    if (i < pass->num_pre_ops && pass->ops[i].kind == PLH_OP_PLANE_MAP) {
+        const plh_op &op = pass->ops[i];
+        if (!op.i2 || op.i1 < 3)
             return false;
+        i++;
     }
+    if (i < pass->num_pre_ops && pass->ops[i].kind == PLH_OP_LINEARIZE && s.src.fmt == PLH_FMT_RGBA16)
+        i++;
+    if (i != pass->num_pre_ops)
+        return false;
+    // post-ops: [DELINEARIZE], then nothing / a SCALE by exactly one (what encoding into a float
+    // target records) into an rgba16hf target, or the fused epilogue into an rgba16 one
+    int first = pass->num_pre_ops;
+    if (first < pass->num_ops && pass->ops[first].kind == PLH_OP_DELINEARIZE)
+        first++;
     if (pass->dst.fmt == PLH_FMT_RGBA16F) {
-        // post-ops: none, or a SCALE by exactly one (what encoding into a float target records)
-        const int post = pass->num_ops - pass->num_pre_ops;
+        const int post = pass->num_ops - first;
         if (post > 1)
             return false;
         if (post == 1) {
-            const plh_op &op = pass->ops[pass->num_pre_ops];
+            const plh_op &op = pass->ops[first];
             if (op.kind != PLH_OP_SCALE || op.f[0] != 1.0f || op.f[1] != 1.0f || op.f[2] != 1.0f || op.f[3] != 1.0f)
                 return false;
         }
@@ -350,7 +472,7 @@ bool plh_polar_mxd_applies(plh_pass *pass)
     }
     if (pass->dst.fmt != PLH_FMT_RGBA16)
         return false;
-    plh_match_fast_epilogue(pass);      // [DITHER] [SCALE] -> rgba16
+    plh_match_fast_epilogue(pass, false, first);    // [DITHER] [SCALE] -> rgba16
     return pass->epi.enabled && !pass->epi.has_alpha;
 }
 
@@ -364,17 +486,30 @@ int plh_launch_polar_mxd(hipStream_t stream, const plh_pass *pass)
     (void) plh_stream_device((plh_stream) stream, &cus);
     const int groups = tiles_x * tiles_y < cus ? tiles_x * tiles_y : cus;
     const bool unorm = pass->s.src.fmt == PLH_FMT_RGBA16, f16dst = pass->dst.fmt == PLH_FMT_RGBA16F;
-#define MXD_LAUNCH(U, F) do { \
+    const bool pre = pass->num_pre_ops && pass->ops[pass->num_pre_ops - 1].kind == PLH_OP_LINEARIZE;
+    const bool delin = pass->num_pre_ops < pass->num_ops && pass->ops[pass->num_pre_ops].kind == PLH_OP_DELINEARIZE;
+#define MXD_LAUNCH(U, F, P, D) do { \
         static uint64_t lds_done; \
-        const int e = plh_kernel_needs_lds((const void *) k_polar_mxd<U, F>, (plh_stream) stream, shmem, &lds_done); \
+        const int e = plh_kernel_needs_lds((const void *) k_polar_mxd<U, F, P, D>, (plh_stream) stream, shmem, &lds_done); \
         if (e) \
             return e; \
-        hipLaunchKernelGGL((k_polar_mxd<U, F>), dim3(groups), dim3(MXD_NT), shmem, stream, *pass); \
+        hipLaunchKernelGGL((k_polar_mxd<U, F, P, D>), dim3(groups), dim3(MXD_NT), shmem, stream, *pass); \
     } while (0)
-    if (unorm && f16dst)  MXD_LAUNCH(true, true);
-    else if (unorm)       MXD_LAUNCH(true, false);
-    else if (f16dst)      MXD_LAUNCH(false, true);
-    else                  MXD_LAUNCH(false, false);
+    if (pre || delin) {
+        // the passes of a linear-light downscale
+        if (unorm && pre && f16dst && !delin)           MXD_LAUNCH(true, true, true, false);
+        else if (unorm && pre && f16dst)                MXD_LAUNCH(true, true, true, true);
+        else if (unorm && pre && delin)                 MXD_LAUNCH(true, false, true, true);
+        else if (unorm && pre)                          MXD_LAUNCH(true, false, true, false);
+        else if (!unorm && !pre && !f16dst)             MXD_LAUNCH(false, false, false, true);
+        else if (!unorm && !pre)                        MXD_LAUNCH(false, true, false, true);
+        else
+            return -1000;
+    }
+    else if (unorm && f16dst)  MXD_LAUNCH(true, true, false, false);
+    else if (unorm)       MXD_LAUNCH(true, false, false, false);
+    else if (f16dst)      MXD_LAUNCH(false, true, false, false);
+    else                  MXD_LAUNCH(false, false, false, false);
 #undef MXD_LAUNCH
     const hipError_t err = hipGetLastError();
     return err == hipSuccess ? 0 : -(int) err;

