@@ -30,6 +30,7 @@
 #include "colorops.hiph"
 #include "prng.hiph"
 #include "samplers.hiph"
+#include "backend.h"
 
 #define DEBAND_BW 64
 #define DEBAND_BH 4
@@ -180,73 +181,99 @@ void k_deband_fast(const plh_pass p_)
         centre = make_uint4(c0.x, c0.y, c0.x, c0.y);
     }
 
-    uint32_t packed[2][2];
+    // The lane's two pixels side by side, stage by stage: both pixels' random offsets, then all
+    // eight gathers, then the comparisons -- one memory round trip per iteration and wave instead
+    // of two (the kernel is bound by each wave's latency chain PRNG -> sin / cos -> address ->
+    // gather -> compare, not by any pipe: DESIGN.md 9), and the six linearisations as independent
+    // chains under one switch (transfer.hiph: op_linearize_values).
+    float px[2], py[2], res[2][3], alpha[2];
+    prng3 st[2];
 #pragma unroll
     for (int q = 0; q < 2; q++) {
         const int idx = idx0 + q;
         const float mx = p.out_scale[0] * ((float) idx + 0.5f);
-        const float px = plh_attr(s.pos, 0, mx, my), py = plh_attr(s.pos, 1, mx, my);
+        px[q] = plh_attr(s.pos, 0, mx, my);
+        py[q] = plh_attr(s.pos, 1, mx, my);
         const uint32_t cx = q ? centre.z : centre.x, cy = q ? centre.w : centre.y;
-        float4_t color = { plh_un16(cx & 0xffffu), plh_un16(cx >> 16), plh_un16(cy & 0xffffu), 1.0f };
-        if (has_alpha)
-            color.w = plh_un16(cy >> 16);
-        float res[3] = { color.x, color.y, color.z };
-
-        prng3 st = { (uint32_t) ((float) (idx + p.frag_x0) + 0.5f),
-                     (uint32_t) ((float) (idy + p.frag_y0) + 0.5f), s.prng_seed };
-        float rnd[3];
-        for (int i = 1; i <= s.iterations; i++) {
-            pcg3d(st, rnd);
-            float dx = rnd[0] * ((float) i * s.db_radius);
-            const float rev = (rnd[1] * 6.283185f) * 0.15915494309189532f;
+        res[q][0] = plh_un16(cx & 0xffffu);
+        res[q][1] = plh_un16(cx >> 16);
+        res[q][2] = plh_un16(cy & 0xffffu);
+        alpha[q] = has_alpha ? plh_un16(cy >> 16) : 1.0f;
+        st[q] = { (uint32_t) ((float) (idx + p.frag_x0) + 0.5f),
+                  (uint32_t) ((float) (idy + p.frag_y0) + 0.5f), s.prng_seed };
+    }
+    float rnd[2][3];
+    for (int i = 1; i <= s.iterations; i++) {
+        plh_u32x2 raw[2][4];
+#pragma unroll
+        for (int q = 0; q < 2; q++) {
+            pcg3d(st[q], rnd[q]);
+            float dx = rnd[q][0] * ((float) i * s.db_radius);
+            const float rev = (rnd[q][1] * 6.283185f) * 0.15915494309189532f;
             const float dy = dx * __builtin_amdgcn_sinf(rev);
             dx = dx * __builtin_amdgcn_cosf(rev);
             const float ox[4] = { dx, -dx, -dx, dx }, oy[4] = { dy, dy, -dy, -dy };
-            plh_u32x2 raw[4];
 #pragma unroll
             for (int k = 0; k < 4; k++) {
-                const float qx = px + s.pt[0] * ox[k], qy = py + s.pt[1] * oy[k];
+                const float qx = px[q] + s.pt[0] * ox[k], qy = py[q] + s.pt[1] * oy[k];
                 // (clamp(floor(v), 0, n - 1): the conversion truncates toward zero, which differs
                 // from floor only for negative v -- where both end up clamped to 0)
                 const int tx = min(max((int) (qx * sw), 0), srcw - 1);
                 const int ty = min(max((int) (qy * sh), 0), srch - 1);
                 // (pitch < 2^24 and rows < 2^24: one v_mad_u32_u24; the plane is < 4 GiB)
                 const uint32_t off = __umul24((uint32_t) ty, spitch) + ((uint32_t) tx << 3);
-                raw[k] = *(const __attribute__((address_space(1))) plh_u32x2 *) (sp + off);
+                raw[q][k] = *(const __attribute__((address_space(1))) plh_u32x2 *) (sp + off);
             }
+        }
+        // (i = 1, the presets' one iteration: no IEEE division)
+        const float bound = i == 1 ? s.db_threshold : s.db_threshold / (float) i;
+#pragma unroll
+        for (int q = 0; q < 2; q++) {
+            const plh_u32x2 *r = raw[q];
             // the four taps of a channel: integer sum (< 2^18), one conversion, one product
-            const uint32_t s0 = (raw[0].x & 0xffffu) + (raw[1].x & 0xffffu) + (raw[2].x & 0xffffu) + (raw[3].x & 0xffffu);
-            const uint32_t s1 = (raw[0].x >> 16) + (raw[1].x >> 16) + (raw[2].x >> 16) + (raw[3].x >> 16);
-            const uint32_t s2 = (raw[0].y & 0xffffu) + (raw[1].y & 0xffffu) + (raw[2].y & 0xffffu) + (raw[3].y & 0xffffu);
+            const uint32_t s0 = (r[0].x & 0xffffu) + (r[1].x & 0xffffu) + (r[2].x & 0xffffu) + (r[3].x & 0xffffu);
+            const uint32_t s1 = (r[0].x >> 16) + (r[1].x >> 16) + (r[2].x >> 16) + (r[3].x >> 16);
+            const uint32_t s2 = (r[0].y & 0xffffu) + (r[1].y & 0xffffu) + (r[2].y & 0xffffu) + (r[3].y & 0xffffu);
             const float avg[3] = { (float) s0 * (1.0f / 262140.0f), (float) s1 * (1.0f / 262140.0f),
                                    (float) s2 * (1.0f / 262140.0f) };
-            // (i = 1, the presets' one iteration: no IEEE division)
-            const float bound = i == 1 ? s.db_threshold : s.db_threshold / (float) i;
 #pragma unroll
             for (int c = 0; c < 3; c++) {
-                const float diff = __builtin_fabsf(res[c] - avg[c]);
-                res[c] = diff > bound ? res[c] : avg[c];
+                const float diff = __builtin_fabsf(res[q][c] - avg[c]);
+                res[q][c] = diff > bound ? res[q][c] : avg[c];
             }
         }
-        if (s.db_grain > 0.0f) {
-            pcg3d(st, rnd);
+    }
+    if (s.db_grain > 0.0f) {
+#pragma unroll
+        for (int q = 0; q < 2; q++) {
+            pcg3d(st[q], rnd[q]);
 #pragma unroll
             for (int c = 0; c < 3; c++) {
-                const float strength = fminf(__builtin_fabsf(res[c] - s.db_neutral[c]), s.db_grain);
-                res[c] += strength * (rnd[c] - 0.5f);
+                const float strength = fminf(__builtin_fabsf(res[q][c] - s.db_neutral[c]), s.db_grain);
+                res[q][c] += strength * (rnd[q][c] - 0.5f);
             }
         }
-        color.x = res[0] * s.scale; color.y = res[1] * s.scale; color.z = res[2] * s.scale;
-        color.w *= s.scale;
+    }
+    float lin[6];
+#pragma unroll
+    for (int q = 0; q < 2; q++) {
+        lin[3 * q] = res[q][0] * s.scale;
+        lin[3 * q + 1] = res[q][1] * s.scale;
+        lin[3 * q + 2] = res[q][2] * s.scale;
+        alpha[q] *= s.scale;
         // identity PLANE_MAP of the first i1 components: the others take their neutral values
         if (has_map) {
-            if (o_map.i1 < 4) color.w = o_map.f[3];
-            if (o_map.i1 < 3) color.z = o_map.f[2];
-            if (o_map.i1 < 2) color.y = o_map.f[1];
+            if (o_map.i1 < 4) alpha[q] = o_map.f[3];
+            if (o_map.i1 < 3) lin[3 * q + 2] = o_map.f[2];
+            if (o_map.i1 < 2) lin[3 * q + 1] = o_map.f[1];
         }
-        op_linearize(color, o_lin);
-        packed[q][0] = (uint32_t) plh_f2h(color.x) | ((uint32_t) plh_f2h(color.y) << 16);
-        packed[q][1] = (uint32_t) plh_f2h(color.z) | ((uint32_t) plh_f2h(color.w) << 16);
+    }
+    op_linearize_values(lin, o_lin);
+    uint32_t packed[2][2];
+#pragma unroll
+    for (int q = 0; q < 2; q++) {
+        packed[q][0] = (uint32_t) plh_f2h(lin[3 * q]) | ((uint32_t) plh_f2h(lin[3 * q + 1]) << 16);
+        packed[q][1] = (uint32_t) plh_f2h(lin[3 * q + 2]) | ((uint32_t) plh_f2h(alpha[q]) << 16);
     }
 
     char *dp = (char *) p.dst.ptr + (size_t) idy * p.dst.pitch + (size_t) idx0 * 8;
@@ -254,6 +281,173 @@ void k_deband_fast(const plh_pass p_)
         *(uint4 *) dp = make_uint4(packed[0][0], packed[0][1], packed[1][0], packed[1][1]);
     else
         *(uint2 *) dp = make_uint2(packed[0][0], packed[0][1]);
+}
+
+/*
+ * k_deband_lds: k_deband_fast with the taps gathered from an LDS window instead of from memory.
+ * k_deband_fast's four taps per pixel are 8-byte gathers at random offsets within +-16 texels:
+ * every lane touches its own cache line, a wave's taps cover ~330 lines (42 KiB: more than a CU's
+ * L1), so nearly every tap moves a whole 128-byte line from L2 for 8 useful bytes -- 33 M pixels
+ * x 4 taps x 128 B = 17 GB per 8K plane, which at the L2's aggregate rate IS the 376 us the
+ * kernel takes (and explains what rounds 2-4 measured: fewer instructions bought nothing, and
+ * concentrating each XCD on one band made it slower). Here a workgroup of 8 waves stages the
+ * 98 x 98 texels around its 64 x 64 pixels once (coalesced 8-byte loads, 2.35 x the plane through
+ * L1 instead of 64 x), and the taps are ds_read_b64. Same arithmetic as k_deband_fast, bit for
+ * bit (same PRNG, positions, integer tap sums); for radius * iterations <= 16.
+ */
+#define DBL_TW 64
+#define DBL_TH 64
+#define DBL_HALO 17         // 16 + one texel of rounding slack
+#define DBL_WW (DBL_TW + 2 * DBL_HALO)
+#define DBL_WH (DBL_TH + 2 * DBL_HALO)
+#define DBL_NT 512
+#define DBL_NLOAD ((DBL_WW * DBL_WH + DBL_NT - 1) / DBL_NT)
+
+__global__ __launch_bounds__(DBL_NT)
+void k_deband_lds(const plh_pass p_)
+{
+    const plh_pass &p = plh_kernarg_pass();
+    const plh_sampler_args &s = p.s;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    plh_u32x2 *win = (plh_u32x2 *) smem;
+    const int tid = threadIdx.x;
+    const int x0 = blockIdx.x * DBL_TW, y0 = blockIdx.y * DBL_TH;
+    const int wx0 = x0 - DBL_HALO, wy0 = y0 - DBL_HALO;
+    typedef __attribute__((address_space(1))) const unsigned char gbyte;
+    gbyte *sp = (gbyte *) (uintptr_t) s.src.ptr;
+    const uint32_t spitch = s.src.pitch;
+    const int srcw = s.src.w, srch = s.src.h;
+    const float sw = (float) srcw, sh = (float) srch;
+
+    // ---- the window: every texel once, clamped at the frame's edges (the taps clamp the same way,
+    // so a position outside the frame is never addressed) ------------------------------------------
+    {
+        plh_u32x2 v[DBL_NLOAD];
+#pragma unroll
+        for (int u = 0; u < DBL_NLOAD; u++) {
+            const int i = min(tid + u * DBL_NT, DBL_WW * DBL_WH - 1);
+            const int wy = (int) (((float) i + 0.5f) * (1.0f / (float) DBL_WW));     // exact: i < 2^22
+            const int wx = i - wy * DBL_WW;
+            const int cx = min(max(wx0 + wx, 0), srcw - 1), cy = min(max(wy0 + wy, 0), srch - 1);
+            v[u] = *(const __attribute__((address_space(1))) plh_u32x2 *)
+                       (sp + __umul24((uint32_t) cy, spitch) + ((uint32_t) cx << 3));
+        }
+#pragma unroll
+        for (int u = 0; u < DBL_NLOAD; u++) {
+            if (tid + u * DBL_NT < DBL_WW * DBL_WH)
+                win[tid + u * DBL_NT] = v[u];
+        }
+    }
+    __syncthreads();
+
+    const bool has_map = p.num_ops == 2;    // [identity PLANE_MAP] LINEARIZE, or LINEARIZE alone
+    const plh_op &o_map = p.ops[0], &o_lin = p.ops[p.num_ops - 1];
+    const bool has_alpha = !has_map || o_map.i1 >= 4;   // else alpha is the PLANE_MAP's neutral value
+
+    // 32 lanes cover a row of the tile (two pixels each), a wave two rows, the workgroup 16 rows
+    // per step
+#pragma unroll 1
+    for (int step = 0; step < DBL_TH / 16; step++) {
+        const int ly = step * 16 + (tid >> 5), lx = 2 * (tid & 31);
+        const int idx0 = x0 + lx, idy = y0 + ly;
+        if (idx0 >= p.width || idy >= p.height)
+            continue;
+        const bool two = idx0 + 1 < p.width;
+        const float my = p.out_scale[1] * ((float) idy + 0.5f);
+        const plh_u32x2 *crow = win + (ly + DBL_HALO) * DBL_WW + lx + DBL_HALO;
+        const plh_u32x2 c0 = crow[0], c1 = crow[two ? 1 : 0];
+
+        float px[2], py[2], res[2][3], alpha[2];
+        prng3 st[2];
+#pragma unroll
+        for (int q = 0; q < 2; q++) {
+            const int idx = idx0 + q;
+            const float mx = p.out_scale[0] * ((float) idx + 0.5f);
+            px[q] = plh_attr(s.pos, 0, mx, my);
+            py[q] = plh_attr(s.pos, 1, mx, my);
+            const uint32_t cx = q ? c1.x : c0.x, cy = q ? c1.y : c0.y;
+            res[q][0] = plh_un16(cx & 0xffffu);
+            res[q][1] = plh_un16(cx >> 16);
+            res[q][2] = plh_un16(cy & 0xffffu);
+            alpha[q] = has_alpha ? plh_un16(cy >> 16) : 1.0f;
+            st[q] = { (uint32_t) ((float) (idx + p.frag_x0) + 0.5f),
+                      (uint32_t) ((float) (idy + p.frag_y0) + 0.5f), s.prng_seed };
+        }
+        float rnd[2][3];
+        for (int i = 1; i <= s.iterations; i++) {
+            plh_u32x2 raw[2][4];
+#pragma unroll
+            for (int q = 0; q < 2; q++) {
+                pcg3d(st[q], rnd[q]);
+                float dx = rnd[q][0] * ((float) i * s.db_radius);
+                const float rev = (rnd[q][1] * 6.283185f) * 0.15915494309189532f;
+                const float dy = dx * __builtin_amdgcn_sinf(rev);
+                dx = dx * __builtin_amdgcn_cosf(rev);
+                const float ox[4] = { dx, -dx, -dx, dx }, oy[4] = { dy, dy, -dy, -dy };
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    const float qx = px[q] + s.pt[0] * ox[k], qy = py[q] + s.pt[1] * oy[k];
+                    const int tx = min(max((int) (qx * sw), 0), srcw - 1);
+                    const int ty = min(max((int) (qy * sh), 0), srch - 1);
+                    // (within the window by construction; the clamp keeps a wild radius from
+                    // reading beyond it)
+                    const int ox_ = min(max(tx - wx0, 0), DBL_WW - 1), oy_ = min(max(ty - wy0, 0), DBL_WH - 1);
+                    raw[q][k] = win[oy_ * DBL_WW + ox_];
+                }
+            }
+            const float bound = i == 1 ? s.db_threshold : s.db_threshold / (float) i;
+#pragma unroll
+            for (int q = 0; q < 2; q++) {
+                const plh_u32x2 *r = raw[q];
+                const uint32_t s0 = (r[0].x & 0xffffu) + (r[1].x & 0xffffu) + (r[2].x & 0xffffu) + (r[3].x & 0xffffu);
+                const uint32_t s1 = (r[0].x >> 16) + (r[1].x >> 16) + (r[2].x >> 16) + (r[3].x >> 16);
+                const uint32_t s2 = (r[0].y & 0xffffu) + (r[1].y & 0xffffu) + (r[2].y & 0xffffu) + (r[3].y & 0xffffu);
+                const float avg[3] = { (float) s0 * (1.0f / 262140.0f), (float) s1 * (1.0f / 262140.0f),
+                                       (float) s2 * (1.0f / 262140.0f) };
+#pragma unroll
+                for (int c = 0; c < 3; c++) {
+                    const float diff = __builtin_fabsf(res[q][c] - avg[c]);
+                    res[q][c] = diff > bound ? res[q][c] : avg[c];
+                }
+            }
+        }
+        if (s.db_grain > 0.0f) {
+#pragma unroll
+            for (int q = 0; q < 2; q++) {
+                pcg3d(st[q], rnd[q]);
+#pragma unroll
+                for (int c = 0; c < 3; c++) {
+                    const float strength = fminf(__builtin_fabsf(res[q][c] - s.db_neutral[c]), s.db_grain);
+                    res[q][c] += strength * (rnd[q][c] - 0.5f);
+                }
+            }
+        }
+        float lin[6];
+#pragma unroll
+        for (int q = 0; q < 2; q++) {
+            lin[3 * q] = res[q][0] * s.scale;
+            lin[3 * q + 1] = res[q][1] * s.scale;
+            lin[3 * q + 2] = res[q][2] * s.scale;
+            alpha[q] *= s.scale;
+            if (has_map) {
+                if (o_map.i1 < 4) alpha[q] = o_map.f[3];
+                if (o_map.i1 < 3) lin[3 * q + 2] = o_map.f[2];
+                if (o_map.i1 < 2) lin[3 * q + 1] = o_map.f[1];
+            }
+        }
+        op_linearize_values(lin, o_lin);
+        uint32_t packed[2][2];
+#pragma unroll
+        for (int q = 0; q < 2; q++) {
+            packed[q][0] = (uint32_t) plh_f2h(lin[3 * q]) | ((uint32_t) plh_f2h(lin[3 * q + 1]) << 16);
+            packed[q][1] = (uint32_t) plh_f2h(lin[3 * q + 2]) | ((uint32_t) plh_f2h(alpha[q]) << 16);
+        }
+        char *dp = (char *) p.dst.ptr + (size_t) idy * p.dst.pitch + (size_t) idx0 * 8;
+        if (two)
+            *(uint4 *) dp = make_uint4(packed[0][0], packed[0][1], packed[1][0], packed[1][1]);
+        else
+            *(uint2 *) dp = make_uint2(packed[0][0], packed[0][1]);
+    }
 }
 
 // the shape k_deband_fast is written for
@@ -280,6 +474,19 @@ static bool deband_fast_applies(const plh_pass *pass)
 int plh_launch_deband(hipStream_t stream, const plh_pass *pass)
 {
     if (deband_fast_applies(pass)) {
+        const char *lds = getenv("PL_HIP_DEBAND_LDS");
+        const plh_sampler_args &s = pass->s;
+        if (!(lds && lds[0] == '0') && s.iterations >= 1 && s.db_radius * (float) s.iterations <= 16.0f) {
+            const size_t shmem = (size_t) DBL_WW * DBL_WH * 8;
+            static uint64_t lds_done;
+            const int e = plh_kernel_needs_lds((const void *) k_deband_lds, (plh_stream) stream, shmem, &lds_done);
+            if (e)
+                return e;
+            const dim3 grid((pass->width + DBL_TW - 1) / DBL_TW, (pass->height + DBL_TH - 1) / DBL_TH);
+            hipLaunchKernelGGL(k_deband_lds, grid, dim3(DBL_NT), shmem, stream, *pass);
+            const hipError_t err = hipGetLastError();
+            return err == hipSuccess ? 0 : -(int) err;
+        }
         const int nbx = (pass->width + 2 * DBF_BW - 1) / (2 * DBF_BW);
         const int nby = (pass->height + DBF_BH - 1) / DBF_BH;
         const dim3 grid(nbx, nby);

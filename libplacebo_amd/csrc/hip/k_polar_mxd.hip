@@ -54,76 +54,6 @@ typedef float mxd_f32x4 __attribute__((ext_vector_type(4)));
 // UNORM: an rgba16 source (decoded and rounded to f16 while staged: the reference's rgba16hf
 // intermediate, fused) instead of an rgba16hf one; F16DST: an rgba16hf target, else rgba16 through
 // the fused epilogue (dither + scale, fastepi.hiph).
-// The curve of a LINEARIZE / DELINEARIZE op over N independent values with the transfer as a
-// compile-time constant: op_linearize per texel has a uniform switch per channel, i.e. a chain of
-// basic blocks per value, and the compiler does not interleave the values' log -> mul -> exp chains
-// across them (measured: the staging of an 8K PQ frame 2.7 x its instruction count). The clamp
-// and the black scaling are applied branch-free (max against -inf, 1 * x + 0: exact no-ops).
-template <int TRC, int N>
-DEV void mxd_lin_n(float (&v)[N], const plh_op &op)
-{
-    const float lo = (op.i1 & PLH_TRC_CLAMP0) ? 0.0f : -__builtin_inff();
-    const bool rs = op.i1 & PLH_TRC_RESCALE;
-    const float f0 = rs ? op.f[0] : 1.0f, f1 = rs ? op.f[1] : 0.0f;
-#pragma unroll
-    for (int k = 0; k < N; k++) {
-        const float x = lin1(fmaxf(v[k], lo), TRC, op.f);
-        v[k] = f0 * x + f1;
-    }
-}
-
-template <int TRC, int N>
-DEV void mxd_delin_n(float (&v)[N], const plh_op &op)
-{
-    const float lo = (op.i1 & PLH_TRC_CLAMP0) ? 0.0f : -__builtin_inff();
-    const bool rs = op.i1 & PLH_TRC_RESCALE;
-    const float f0 = rs ? op.f[0] : 1.0f, f1 = rs ? op.f[1] : 0.0f;
-#pragma unroll
-    for (int k = 0; k < N; k++)
-        v[k] = delin1(fmaxf(f0 * v[k] + f1, lo), TRC, op.f);
-}
-
-// N = 3 x texels, texel-major (r g b r g b ...)
-template <int N>
-DEV void mxd_linearize(float (&v)[N], const plh_op &op)
-{
-    switch (op.i0) {
-    case TRC_SRGB:      mxd_lin_n<TRC_SRGB>(v, op); break;
-    case TRC_BT_1886:   mxd_lin_n<TRC_BT_1886>(v, op); break;
-    case TRC_PQ:        mxd_lin_n<TRC_PQ>(v, op); break;
-    case TRC_UNKNOWN: case TRC_GAMMA18: case TRC_GAMMA20: case TRC_GAMMA22:
-    case TRC_GAMMA24: case TRC_GAMMA26: case TRC_GAMMA28:
-                        mxd_lin_n<TRC_GAMMA22>(v, op); break;
-    default:
-#pragma unroll
-        for (int t = 0; t < N / 3; t++) {
-            float4_t c = { v[3 * t], v[3 * t + 1], v[3 * t + 2], 1.0f };
-            op_linearize(c, op);
-            v[3 * t] = c.x; v[3 * t + 1] = c.y; v[3 * t + 2] = c.z;
-        }
-    }
-}
-
-template <int N>
-DEV void mxd_delinearize(float (&v)[N], const plh_op &op)
-{
-    switch (op.i0) {
-    case TRC_SRGB:      mxd_delin_n<TRC_SRGB>(v, op); break;
-    case TRC_BT_1886:   mxd_delin_n<TRC_BT_1886>(v, op); break;
-    case TRC_PQ:        mxd_delin_n<TRC_PQ>(v, op); break;
-    case TRC_UNKNOWN: case TRC_GAMMA18: case TRC_GAMMA20: case TRC_GAMMA22:
-    case TRC_GAMMA24: case TRC_GAMMA26: case TRC_GAMMA28:
-                        mxd_delin_n<TRC_GAMMA22>(v, op); break;
-    default:
-#pragma unroll
-        for (int t = 0; t < N / 3; t++) {
-            float4_t c = { v[3 * t], v[3 * t + 1], v[3 * t + 2], 1.0f };
-            op_delinearize(c, op);
-            v[3 * t] = c.x; v[3 * t + 1] = c.y; v[3 * t + 2] = c.z;
-        }
-    }
-}
-
 // PRE: a LINEARIZE pre-op (the last one) on the staged texels -- UNORM sources only; DELIN: a
 // DELINEARIZE as the first post-op.
 template <bool UNORM, bool F16DST, bool PRE = false, bool DELIN = false>
@@ -290,7 +220,7 @@ void k_polar_mxd(const plh_pass p_)
                                q2 = *(const uint32_t *) (d + 2 * MXD_PLANE);
                 float c[6] = { plh_un16(q0 & 0xffffu), plh_un16(q1 & 0xffffu), plh_un16(q2 & 0xffffu),
                                plh_un16(q0 >> 16), plh_un16(q1 >> 16), plh_un16(q2 >> 16) };
-                mxd_linearize(c, lop);
+                op_linearize_values(c, lop);
                 // (fp32 result, THEN the f16 rounding: see the decode above)
                 asm volatile("" : "+v"(c[0]), "+v"(c[1]), "+v"(c[2]), "+v"(c[3]), "+v"(c[4]), "+v"(c[5]));
                 *(uint32_t *) d = (uint32_t) plh_f2h(c[0]) | ((uint32_t) plh_f2h(c[3]) << 16);
@@ -397,7 +327,7 @@ void k_polar_mxd(const plh_pass p_)
                 oall[3 * r + ch] = __builtin_fmaf(dfy[r], accy[0][ch][r] - accy[1][ch][r], acc[0][ch][r] + acc[1][ch][r]);
         }
         if constexpr (DELIN)
-            mxd_delinearize(oall, p.ops[p.num_pre_ops]);
+            op_delinearize_values(oall, p.ops[p.num_pre_ops]);
 #pragma unroll
         for (int r = 0; r < 4; r++) {
             const int Y = Y0 + r;
