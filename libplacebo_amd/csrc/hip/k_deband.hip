@@ -296,12 +296,17 @@ void k_deband_fast(const plh_pass p_)
  * bit (same PRNG, positions, integer tap sums); for radius * iterations <= 16.
  */
 #define DBL_TW 64
-#define DBL_TH 64
+#ifndef DBL_TH
+#define DBL_TH 32
+#endif
 #define DBL_HALO 17         // 16 + one texel of rounding slack
 #define DBL_WW (DBL_TW + 2 * DBL_HALO)
 #define DBL_WH (DBL_TH + 2 * DBL_HALO)
 #define DBL_NT 512
 #define DBL_NLOAD ((DBL_WW * DBL_WH + DBL_NT - 1) / DBL_NT)
+#ifndef DBL_NP
+#define DBL_NP 2         // pixels a lane works on at a time (2, 4 or 8)
+#endif
 
 __global__ __launch_bounds__(DBL_NT)
 void k_deband_lds(const plh_pass p_)
@@ -309,9 +314,28 @@ void k_deband_lds(const plh_pass p_)
     const plh_pass &p = plh_kernarg_pass();
     const plh_sampler_args &s = p.s;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    plh_u32x2 *win = (plh_u32x2 *) smem;
+    // (an LDS pointer type: 32-bit index arithmetic -- through a generic pointer every tap's address
+    // was a v_mad_u64_u32)
+    typedef __attribute__((address_space(3))) plh_u32x2 lds_px;
+    lds_px *win = (lds_px *) (__attribute__((address_space(3))) unsigned char *) smem;
     const int tid = threadIdx.x;
-    const int x0 = blockIdx.x * DBL_TW, y0 = blockIdx.y * DBL_TH;
+    // Workgroups go to the 8 XCDs round-robin and every XCD has its own L2: XCD x works down the
+    // x-th vertical band of tile columns, row-major within the band, so that the 34 of 98 window
+    // columns AND rows a tile shares with its neighbours are found in that L2 (a band's tile row
+    // is < 1 MB) instead of being fetched from HBM once per tile (2.35 x the plane).
+    int bx, by;
+    {
+        const uint32_t tiles_x = (uint32_t) (p.width + DBL_TW - 1) / DBL_TW;
+        const uint32_t tiles_y = (uint32_t) (p.height + DBL_TH - 1) / DBL_TH;
+        const uint32_t lin = blockIdx.x, xcd = lin & 7u, k = lin >> 3;
+        const uint32_t q = tiles_x >> 3, r = tiles_x & 7u;
+        const uint32_t bw = q + (xcd < r ? 1u : 0u), bstart = xcd * q + min(xcd, r);
+        if (k >= bw * tiles_y)
+            return;
+        by = (int) (k / bw);
+        bx = (int) (bstart + (k - (uint32_t) by * bw));
+    }
+    const int x0 = bx * DBL_TW, y0 = by * DBL_TH;
     const int wx0 = x0 - DBL_HALO, wy0 = y0 - DBL_HALO;
     typedef __attribute__((address_space(1))) const unsigned char gbyte;
     gbyte *sp = (gbyte *) (uintptr_t) s.src.ptr;
@@ -320,22 +344,31 @@ void k_deband_lds(const plh_pass p_)
     const float sw = (float) srcw, sh = (float) srch;
 
     // ---- the window: every texel once, clamped at the frame's edges (the taps clamp the same way,
-    // so a position outside the frame is never addressed) ------------------------------------------
+    // so a position outside the frame is never addressed). Wave w takes rows w, w + 8, ...: the row
+    // (clamp, pitch) is scalar arithmetic, a lane's two columns (l and 64 + l) are computed once,
+    // and every load / store is base + constant -- 2 vector instructions per texel instead of 17 --
     {
-        plh_u32x2 v[DBL_NLOAD];
+        const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+        const uint32_t colA = (uint32_t) min(max(wx0 + lane, 0), srcw - 1) << 3;
+        const uint32_t colB = (uint32_t) min(max(wx0 + 64 + lane, 0), srcw - 1) << 3;
+        const bool hasB = lane < DBL_WW - 64;
+        constexpr int ROWS = (DBL_WH + 7) / 8;
+        plh_u32x2 va[ROWS], vb[ROWS];
 #pragma unroll
-        for (int u = 0; u < DBL_NLOAD; u++) {
-            const int i = min(tid + u * DBL_NT, DBL_WW * DBL_WH - 1);
-            const int wy = (int) (((float) i + 0.5f) * (1.0f / (float) DBL_WW));     // exact: i < 2^22
-            const int wx = i - wy * DBL_WW;
-            const int cx = min(max(wx0 + wx, 0), srcw - 1), cy = min(max(wy0 + wy, 0), srch - 1);
-            v[u] = *(const __attribute__((address_space(1))) plh_u32x2 *)
-                       (sp + __umul24((uint32_t) cy, spitch) + ((uint32_t) cx << 3));
+        for (int u = 0; u < ROWS; u++) {
+            const int r = min(wave + 8 * u, DBL_WH - 1);
+            gbyte *row = sp + (size_t) min(max(wy0 + r, 0), srch - 1) * (size_t) spitch;
+            va[u] = *(const __attribute__((address_space(1))) plh_u32x2 *) (row + colA);
+            vb[u] = *(const __attribute__((address_space(1))) plh_u32x2 *) (row + colB);
         }
+        lds_px *wa = win + wave * DBL_WW + lane;
 #pragma unroll
-        for (int u = 0; u < DBL_NLOAD; u++) {
-            if (tid + u * DBL_NT < DBL_WW * DBL_WH)
-                win[tid + u * DBL_NT] = v[u];
+        for (int u = 0; u < ROWS; u++) {
+            if (wave + 8 * u < DBL_WH) {
+                wa[8 * u * DBL_WW] = va[u];
+                if (hasB)
+                    wa[8 * u * DBL_WW + 64] = vb[u];
+            }
         }
     }
     __syncthreads();
@@ -344,40 +377,42 @@ void k_deband_lds(const plh_pass p_)
     const plh_op &o_map = p.ops[0], &o_lin = p.ops[p.num_ops - 1];
     const bool has_alpha = !has_map || o_map.i1 >= 4;   // else alpha is the PLANE_MAP's neutral value
 
-    // 32 lanes cover a row of the tile (two pixels each), a wave two rows, the workgroup 16 rows
-    // per step
+    // 32 lanes cover a row of the tile (two pixels each), a wave two rows, the workgroup 16 rows; a
+    // lane works on DBL_NP pixels at a time -- pairs 16 rows apart -- stage by stage (all their
+    // random offsets, all their taps, all their comparisons): the workgroup's LDS caps the CU at 4
+    // waves per SIMD, so the independent chains have to come from inside the wave
+    constexpr int NP = DBL_NP, PAIRS = NP / 2;
 #pragma unroll 1
-    for (int step = 0; step < DBL_TH / 16; step++) {
-        const int ly = step * 16 + (tid >> 5), lx = 2 * (tid & 31);
-        const int idx0 = x0 + lx, idy = y0 + ly;
-        if (idx0 >= p.width || idy >= p.height)
-            continue;
+    for (int step = 0; step < DBL_TH / (16 * PAIRS); step++) {
+        const int lx = 2 * (tid & 31), idx0 = x0 + lx;
         const bool two = idx0 + 1 < p.width;
-        const float my = p.out_scale[1] * ((float) idy + 0.5f);
-        const plh_u32x2 *crow = win + (ly + DBL_HALO) * DBL_WW + lx + DBL_HALO;
-        const plh_u32x2 c0 = crow[0], c1 = crow[two ? 1 : 0];
-
-        float px[2], py[2], res[2][3], alpha[2];
-        prng3 st[2];
+        int idy[PAIRS];
+        float px[NP], py[NP], res[NP][3], alpha[NP];
+        prng3 st[NP];
 #pragma unroll
-        for (int q = 0; q < 2; q++) {
-            const int idx = idx0 + q;
+        for (int q = 0; q < NP; q++) {
+            const int ly = (step * PAIRS + (q >> 1)) * 16 + (tid >> 5);
+            idy[q >> 1] = y0 + ly;
+            const int idx = idx0 + (q & 1);
             const float mx = p.out_scale[0] * ((float) idx + 0.5f);
+            const float my = p.out_scale[1] * ((float) (y0 + ly) + 0.5f);
             px[q] = plh_attr(s.pos, 0, mx, my);
             py[q] = plh_attr(s.pos, 1, mx, my);
-            const uint32_t cx = q ? c1.x : c0.x, cy = q ? c1.y : c0.y;
-            res[q][0] = plh_un16(cx & 0xffffu);
-            res[q][1] = plh_un16(cx >> 16);
-            res[q][2] = plh_un16(cy & 0xffffu);
-            alpha[q] = has_alpha ? plh_un16(cy >> 16) : 1.0f;
+            // (pixels beyond the frame are computed from the window's clamped texels and dropped at
+            // the store)
+            const plh_u32x2 c = win[(ly + DBL_HALO) * DBL_WW + lx + DBL_HALO + ((q & 1) && two ? 1 : 0)];
+            res[q][0] = plh_un16(c.x & 0xffffu);
+            res[q][1] = plh_un16(c.x >> 16);
+            res[q][2] = plh_un16(c.y & 0xffffu);
+            alpha[q] = has_alpha ? plh_un16(c.y >> 16) : 1.0f;
             st[q] = { (uint32_t) ((float) (idx + p.frag_x0) + 0.5f),
-                      (uint32_t) ((float) (idy + p.frag_y0) + 0.5f), s.prng_seed };
+                      (uint32_t) ((float) (y0 + ly + p.frag_y0) + 0.5f), s.prng_seed };
         }
-        float rnd[2][3];
+        float rnd[NP][3];
         for (int i = 1; i <= s.iterations; i++) {
-            plh_u32x2 raw[2][4];
+            plh_u32x2 raw[NP][4];
 #pragma unroll
-            for (int q = 0; q < 2; q++) {
+            for (int q = 0; q < NP; q++) {
                 pcg3d(st[q], rnd[q]);
                 float dx = rnd[q][0] * ((float) i * s.db_radius);
                 const float rev = (rnd[q][1] * 6.283185f) * 0.15915494309189532f;
@@ -389,15 +424,15 @@ void k_deband_lds(const plh_pass p_)
                     const float qx = px[q] + s.pt[0] * ox[k], qy = py[q] + s.pt[1] * oy[k];
                     const int tx = min(max((int) (qx * sw), 0), srcw - 1);
                     const int ty = min(max((int) (qy * sh), 0), srch - 1);
-                    // (within the window by construction; the clamp keeps a wild radius from
-                    // reading beyond it)
-                    const int ox_ = min(max(tx - wx0, 0), DBL_WW - 1), oy_ = min(max(ty - wy0, 0), DBL_WH - 1);
-                    raw[q][k] = win[oy_ * DBL_WW + ox_];
+                    // (within the window by construction: the launcher checks radius * iterations
+                    // <= 16, the halo has one texel of slack, and clamping to the frame only moves a
+                    // tap towards the pixel)
+                    raw[q][k] = win[(ty - wy0) * DBL_WW + (tx - wx0)];
                 }
             }
             const float bound = i == 1 ? s.db_threshold : s.db_threshold / (float) i;
 #pragma unroll
-            for (int q = 0; q < 2; q++) {
+            for (int q = 0; q < NP; q++) {
                 const plh_u32x2 *r = raw[q];
                 const uint32_t s0 = (r[0].x & 0xffffu) + (r[1].x & 0xffffu) + (r[2].x & 0xffffu) + (r[3].x & 0xffffu);
                 const uint32_t s1 = (r[0].x >> 16) + (r[1].x >> 16) + (r[2].x >> 16) + (r[3].x >> 16);
@@ -413,7 +448,7 @@ void k_deband_lds(const plh_pass p_)
         }
         if (s.db_grain > 0.0f) {
 #pragma unroll
-            for (int q = 0; q < 2; q++) {
+            for (int q = 0; q < NP; q++) {
                 pcg3d(st[q], rnd[q]);
 #pragma unroll
                 for (int c = 0; c < 3; c++) {
@@ -422,9 +457,9 @@ void k_deband_lds(const plh_pass p_)
                 }
             }
         }
-        float lin[6];
+        float lin[3 * NP];
 #pragma unroll
-        for (int q = 0; q < 2; q++) {
+        for (int q = 0; q < NP; q++) {
             lin[3 * q] = res[q][0] * s.scale;
             lin[3 * q + 1] = res[q][1] * s.scale;
             lin[3 * q + 2] = res[q][2] * s.scale;
@@ -436,17 +471,22 @@ void k_deband_lds(const plh_pass p_)
             }
         }
         op_linearize_values(lin, o_lin);
-        uint32_t packed[2][2];
 #pragma unroll
-        for (int q = 0; q < 2; q++) {
-            packed[q][0] = (uint32_t) plh_f2h(lin[3 * q]) | ((uint32_t) plh_f2h(lin[3 * q + 1]) << 16);
-            packed[q][1] = (uint32_t) plh_f2h(lin[3 * q + 2]) | ((uint32_t) plh_f2h(alpha[q]) << 16);
+        for (int r = 0; r < PAIRS; r++) {
+            uint32_t packed[2][2];
+#pragma unroll
+            for (int q = 0; q < 2; q++) {
+                const float *v = lin + 3 * (2 * r + q);
+                packed[q][0] = (uint32_t) plh_f2h(v[0]) | ((uint32_t) plh_f2h(v[1]) << 16);
+                packed[q][1] = (uint32_t) plh_f2h(v[2]) | ((uint32_t) plh_f2h(alpha[2 * r + q]) << 16);
+            }
+            const bool inside = idx0 < p.width && idy[r] < p.height;
+            char *dp = (char *) p.dst.ptr + (size_t) idy[r] * p.dst.pitch + (size_t) idx0 * 8;
+            if (inside && two)
+                *(uint4 *) dp = make_uint4(packed[0][0], packed[0][1], packed[1][0], packed[1][1]);
+            else if (inside)
+                *(uint2 *) dp = make_uint2(packed[0][0], packed[0][1]);
         }
-        char *dp = (char *) p.dst.ptr + (size_t) idy * p.dst.pitch + (size_t) idx0 * 8;
-        if (two)
-            *(uint4 *) dp = make_uint4(packed[0][0], packed[0][1], packed[1][0], packed[1][1]);
-        else
-            *(uint2 *) dp = make_uint2(packed[0][0], packed[0][1]);
     }
 }
 
@@ -482,7 +522,9 @@ int plh_launch_deband(hipStream_t stream, const plh_pass *pass)
             const int e = plh_kernel_needs_lds((const void *) k_deband_lds, (plh_stream) stream, shmem, &lds_done);
             if (e)
                 return e;
-            const dim3 grid((pass->width + DBL_TW - 1) / DBL_TW, (pass->height + DBL_TH - 1) / DBL_TH);
+            // (8 bands of tile columns, padded to the widest: k_deband_lds)
+            const int tiles_x = (pass->width + DBL_TW - 1) / DBL_TW, tiles_y = (pass->height + DBL_TH - 1) / DBL_TH;
+            const dim3 grid(8 * ((tiles_x + 7) / 8) * tiles_y);
             hipLaunchKernelGGL(k_deband_lds, grid, dim3(DBL_NT), shmem, stream, *pass);
             const hipError_t err = hipGetLastError();
             return err == hipSuccess ? 0 : -(int) err;

@@ -225,3 +225,29 @@ def test_deband_fast_kernel_against_the_general_one(gpu, kw, size, trc, monkeypa
         ulps = np.abs(outs[0].astype(np.int64) - outs[1].astype(np.int64))
         assert ulps.max() <= 1 and (ulps > 0).mean() < 5e-3, (ulps.max(), (ulps > 0).mean())
     t.destroy()
+
+
+@pytest.mark.parametrize("kw", [dict(), dict(iterations=2, radius=8.0), dict(radius=5.5, grain=0.0),
+                                dict(iterations=4, radius=4.0)])
+@pytest.mark.parametrize("size", [(201, 75), (131, 130), (640, 200)])
+def test_deband_lds_window_is_the_gather_kernel_bit_for_bit(gpu, kw, size, monkeypatch):
+    """k_deband_lds (round 4: the taps from a 98 x 98 LDS window around a workgroup's 64 x 64 pixels,
+    for radius * iterations <= 16) against k_deband_fast, which gathers from memory: the same
+    arithmetic, so the same f16 codes everywhere -- frame edges (clamped taps), clipped edge tiles
+    and the single-pixel tail of an odd width included."""
+    w, h = size
+    img = util.random_rgba16(w, h, seed=23)
+    t = gpu.tex_create(w, h, "rgba16", img)
+    csp = pl.color_space("bt2020", "pq")
+    outs = []
+    for lds in ("1", "0"):
+        monkeypatch.setenv("PL_HIP_DEBAND_LDS", lds)
+        d = gpu.tex_create(w, h, "rgba16hf")
+        sh = gpu.begin()
+        assert sh.deband(t, components=3, **kw), gpu.messages[-3:]
+        sh.linearize(csp)
+        assert sh.finish(d), gpu.messages[-3:]
+        outs.append(d.download().view(np.uint16))
+        d.destroy()
+    assert np.array_equal(outs[0], outs[1]), util.diff_stats(outs[0], outs[1])
+    t.destroy()
