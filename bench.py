@@ -96,7 +96,7 @@ WORKLOADS = {
     # intermediate -> measurement -> tone map
     "ewa_8k_to_4k_hdr_tonemap": (P8K, P4K, px(P8K) * 8 + 4 * px(P4K) * 8, "polar"),
     "hdr10_4k_tonemap": (P4K, P4K, 3 * px(P4K) * 8, "tone map"),
-    "ewa_8k_to_4k_deband_tonemap": (P8K, P4K, px(P8K) * 8 + px(P4K) * 8, "polar"),
+    "ewa_8k_to_4k_deband_tonemap": (P8K, P4K, px(P8K) * 8 + px(P4K) * 8, "debanding"),
     # the metric's two halves in one frame: 1080p HDR10 -> EWA 2x upscale -> tone map -> 4K SDR
     "ewa_1080p_to_4k_hdr_tonemap": (P1080, P4K, 2 * px(P1080) * 8 + px(P4K) * 8, "polar"),
     # 24 fps -> 60 Hz through pl_queue + pl_render_image_mix (oversampling mixer): a step is one
@@ -116,7 +116,7 @@ KERNEL_BYTES = {
     "lanczos_1080p_to_4k_dither10": px(P1080) * 8 + px((1920, 2160)) * 8,   # vertical pass: f16 in, f16 out
     "ewa_lanczos_4k_to_1080p_dither10": px(P4K) * 8 + px(P1080) * 8,
     "hdr10_4k_tonemap": 2 * px(P4K) * 8,                    # the map pass: f16 intermediate in, rgba16 out
-    "ewa_8k_to_4k_deband_tonemap": px(P8K) * 8 + px(P4K) * 8,  # the polar pass: 8K f16 in, 4K f16 out
+    "ewa_8k_to_4k_deband_tonemap": 2 * px(P8K) * 8,         # the debanding pass (the longest): 8K rgba16 in, 8K f16 out
     "ewa_8k_to_4k_hdr_tonemap": px(P8K) * 8 + px(P4K) * 8,
     "ewa_lanczos_4k_to_1080p_linear_dither10": px(P4K) * 8 + px(P1080) * 8,
     "ewa_1080p_to_4k_hdr_tonemap": px(P1080) * 8 + px(P4K) * 8,    # polar + map launch: 1080p f16 in, 4K out
