@@ -13,6 +13,9 @@ if ROOT not in sys.path:
 # bits": tests/test_gpu_polar_mfma.py and tests/test_gpu_metric.py switch it on explicitly and
 # hold it to that, at the same geometries. Every other test pins k_polar_pp, the sequential-fma
 # kernel that evaluates the taps in the reference's order and must match the oracle BIT FOR BIT.
+# The whole suite also runs on the library's defaults (`PL_HIP_POLAR_MFMA=1 pytest -m gpu`,
+# profiles/r04_*_gputests_mfma_forced.log): every comparison that involves a polar pass goes
+# through util.assert_polar_equal, which is exact here and "at most one code / one f16 ulp" there.
 os.environ.setdefault("PL_HIP_POLAR_MFMA", "0")
 
 

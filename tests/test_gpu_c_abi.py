@@ -63,7 +63,8 @@ def test_c_program_renders_through_the_c_abi(gpu, tmp_path):
     a = orc.op_quant_f16(a)
     w, r, rz = orc.filter_generate_polar(orc.ewa_lanczos())
     ref = orc.tex_encode(orc.sample_polar(a, w, r, rz, 2 * sw, 2 * sh, mask=0x7), "rgba16")
-    assert np.array_equal(got, ref), (log, int(np.abs(got.astype(int) - ref.astype(int)).max()))
+    import util
+    util.assert_polar_equal(got, ref, what=log)
 
     # and the binary built against libplacebo's own headers
     if not os.path.exists(os.path.join(BUILD, "render_frame_ref")):

@@ -101,3 +101,36 @@ def assert_colormap_parity(got, ref, truth=None, scale=65535.0,
         assert qg <= qo + 1.0, ("GPU further from float64 than the oracle", q, qg, qo)
         # (quantiles are not sub-additive sample by sample: allow half as much again)
         assert np.quantile(d, q) <= 1.5 * (qg + qo) + 2.0, (q, np.quantile(d, q), qg, qo)
+
+
+def polar_exact():
+    """Does this run pin the sequential-fma polar kernel (tests/conftest.py's default)? With
+    PL_HIP_POLAR_MFMA=1 the whole suite runs on the library's defaults -- the matrix-pipe kernels for
+    the exact ratios -- whose statement is "never more than one code from k_polar_pp"."""
+    import os
+    return os.environ.get("PL_HIP_POLAR_MFMA", "1") == "0"
+
+
+def assert_polar_equal(got, ref, step=1, max_frac=0.05, what=None):
+    """`got == ref` bit for bit where the polar pass runs on k_polar_pp; where the matrix-pipe
+    kernels may have run (PL_HIP_POLAR_MFMA=1: ADVICE r03, the suite on the library's defaults) at
+    most `step` apart -- one code of the target's depth (64 for 10 bits in 16), one f16 ulp for
+    half-float arrays, 4e-6 for fp32 -- on at most `max_frac` of the samples."""
+    assert got.shape == ref.shape, (got.shape, ref.shape)
+    if polar_exact():
+        assert np.array_equal(got, ref), (what, diff_stats(got, ref))
+        return
+    if got.dtype == np.float32:
+        d = np.abs(got.astype(np.float64) - ref.astype(np.float64))
+        assert d.max() <= 4e-6 * step, (what, float(d.max()))
+        return
+    if got.dtype == np.float16:
+        # one ulp -- or, for values so small that an ulp is less than the contraction's absolute
+        # error (1.3e-6 of the data's scale: dark linear-light texels), that absolute error
+        d = np.abs(got.view(np.int16).astype(np.int64) - ref.view(np.int16).astype(np.int64))
+        scale = max(1.0, float(np.abs(ref.astype(np.float32)).max()))
+        small = np.abs(got.astype(np.float32) - ref.astype(np.float32)) <= 4e-6 * scale
+        d = np.where(small & (d > 1), 1, d)
+    else:
+        d = np.abs(got.astype(np.int64) - ref.astype(np.int64))
+    assert d.max() <= step and (d > 0).mean() <= max_frac, (what, int(d.max()), float((d > 0).mean()))
