@@ -87,6 +87,9 @@ WORKLOADS = {
     "nv12_1080p_to_4k_default_preset": (P1080, P4K, px(P1080) * 3 // 2 + px(P4K) * 8, "ortho"),
     # pl_render_default_params as shipped: lanczos in linear, sigmoidized light + dither
     "default_preset_1080p_to_4k": (P1080, P4K, px(P1080) * 8 + px(P4K) * 8, "ortho"),
+    # ... with the polar scaler: linearize + sigmoidize while the tile is staged, EWA, inverse
+    # sigmoid + delinearize + dither in the epilogue: ONE launch
+    "default_preset_ewa_1080p_to_4k": (P1080, P4K, px(P1080) * 8 + px(P4K) * 8, "polar"),
     # the plain SDR downscale: 4K -> 1080p EWA (widened, 148 taps), 10-bit dither, one launch
     "ewa_lanczos_4k_to_1080p_dither10": (P4K, P1080, px(P4K) * 8 + px(P1080) * 8, "polar"),
     # ... in linear light (what the reference does by default in front of a downscaler): the
@@ -229,6 +232,9 @@ class Stream:
             icsp, tcsp, trepr = pl.color_space("bt709", "bt1886"), pl.color_space("bt709", "bt1886"), ten_bit
         elif workload == "default_preset_1080p_to_4k":
             self.params = pl.render_params("default")
+            icsp, tcsp, trepr = sdr, sdr, ten_bit
+        elif workload == "default_preset_ewa_1080p_to_4k":
+            self.params = pl.render_params("default", upscaler=pl.filter_config("ewa_lanczos"))
             icsp, tcsp, trepr = sdr, sdr, ten_bit
         elif workload == "hdr10_4k_tonemap":
             self.params = pl.render_params(
