@@ -432,6 +432,26 @@ static bool try_fused_polar(struct frame_job *job, pl_shader sh, const struct pl
     const float ar = sc.filter->antiring ? sc.filter->antiring : params->antiringing_strength;
     if (ar > 0)
         return false;   // the anti-ringing variant has no fused form
+    // An UPSCALE whose pending ops need transcendentals (LINEARIZE + SIGMOIDIZE in front of the
+    // scaler: pl_render_default_params on SDR video) is better off with the reference's two
+    // passes: the intermediate is the small side (1080p: 16.6 MB written and read), while fused
+    // the polar kernel stages its tile through the full op interpreter at three waves per SIMD --
+    // 1080p -> 4K measured 0.113 ms fused against 0.063 ms as k_pass_chain + k_polar_mx with the
+    // chain epilogue (profiles/r04_44_default_preset_ewa_fusion.txt). A downscale keeps the fusion:
+    // its intermediate is the large side, and k_polar_mxd linearises while it stages.
+    // PL_HIP_NO_FUSION=0 forces the fused form (tests compare the two: bit-identical).
+    if (sc.dir == RP_DIR_UP && !(off && off[0] == '0')) {
+        const struct plh_pass *pp = &pre->pass;
+        for (int i = 0; i < pp->num_ops; i++) {
+            switch (pp->ops[i].kind) {
+            case PLH_OP_SCALE: case PLH_OP_AFFINE: case PLH_OP_PREMULTIPLY: case PLH_OP_ALPHA_ONE:
+            case PLH_OP_QUANT_F16: case PLH_OP_SWIZZLE: case PLH_OP_CLAMP01: case PLH_OP_PLANE_MAP:
+                break;
+            default:
+                return false;
+            }
+        }
+    }
 
     const struct pl_sample_filter_params fp = {
         .filter      = *sc.filter,

@@ -447,3 +447,31 @@ def test_hdr_downscale_with_fused_pq_linearisation():
     # then amplify on a few dark saturated pixels)
     assert np.quantile(d, 0.5) <= 1 and np.quantile(d, 0.99) <= 4 and np.quantile(d, 0.999) <= 16
     assert d.max() <= 256 and (d > 8).mean() < 2e-3
+
+
+@pytest.mark.parametrize("mfma", [True, False])
+def test_default_preset_ewa_pass_structures_identical(mfma):
+    """pl_render_default_params + ewa_lanczos, SDR 2x: since round 4 the renderer keeps the
+    reference's two passes for an upscale whose pending ops need transcendentals (PASS A =
+    k_pass_chain into the rgba16hf intermediate, then the polar kernel with the chain epilogue:
+    0.063 ms against 0.113 ms fused at 1080p -> 4K). The fused launch (PL_HIP_NO_FUSION=0) and the
+    forced two-pass structure (=1) render the same frame: bit for bit on k_polar_pp, within the
+    matrix-pipe kernels' one code (here: one 10-bit step on < 1 % of the samples) on k_polar_mx."""
+    sw, sh = 166, 93
+    img = content("noise", sw, sh)
+    csp = inferred(pl.color_space("bt709", "bt1886"))
+    p = pl.render_params("default", upscaler=pl.filter_config("ewa_lanczos"), dither_params=blue(),
+                         disable_dither_gamma_correction=True)
+    kw = dict(image_color=csp, target_color=csp, target_repr=repr_bits(10, 16))
+    base, used = render(img, 2 * sw, 2 * sh, p, mfma, **kw)
+    assert used == mfma
+    for v in ("0", "1"):
+        o, used = render(img, 2 * sw, 2 * sh, p, mfma, extra_env={"PL_HIP_NO_FUSION": v}, **kw)
+        assert used == mfma
+        if mfma:
+            # (the fused launch is another variant of the matrix-pipe kernel -- interpreter epilogue,
+            # the row-phase term on the A fragments: the kernels' "one code" statement, dithered)
+            d = codes(o, base)
+            assert d.max() <= 64 and (d > 0).mean() < 0.01, (v, int(d.max()), float((d > 0).mean()))
+        else:
+            assert np.array_equal(o, base), (v, util.diff_stats(o, base))

@@ -24,7 +24,7 @@ trace)
   find $out -name "*kernel_stats.csv" -exec cp {} gpurun_out/${tag}_default_bench_kernel_stats.csv \;
   head -4 gpurun_out/${tag}_default_bench_kernel_stats.csv | cut -c1-140 ;;
 stats)
-  for wl in ewa_1080p_to_4k_hdr_tonemap ewa_lanczos_1080p_to_4k_dither10 bilinear_1080p_to_4k hdr10_4k_tonemap ewa_8k_to_4k_deband_tonemap lanczos_1080p_to_4k_dither10 ewa_lanczos_720p_to_4k_dither10 ewa_lanczos_540p_to_4k_dither10 ewa_lanczos_1440p_to_4k_dither10 ewa_720p_to_4k_hdr_tonemap ewa_lanczos_4k_to_1080p_dither10 ewa_lanczos_4k_to_1080p_linear_dither10 ewa_8k_to_4k_hdr_tonemap; do
+  for wl in ewa_1080p_to_4k_hdr_tonemap ewa_lanczos_1080p_to_4k_dither10 bilinear_1080p_to_4k hdr10_4k_tonemap ewa_8k_to_4k_deband_tonemap lanczos_1080p_to_4k_dither10 ewa_lanczos_720p_to_4k_dither10 ewa_lanczos_540p_to_4k_dither10 ewa_lanczos_1440p_to_4k_dither10 ewa_720p_to_4k_hdr_tonemap ewa_lanczos_4k_to_1080p_dither10 ewa_lanczos_4k_to_1080p_linear_dither10 ewa_8k_to_4k_hdr_tonemap default_preset_1080p_to_4k default_preset_ewa_1080p_to_4k; do
     out=/tmp/st_$wl; rm -rf $out
     # one stream: every kernel's duration is its own (what bench.py's event times and "trace" report)
     (cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out -- python $GRAFT_REPO_ROOT/bench.py --bare --steps 40 --warmup 10 --async-measure 0 --workload $wl > /tmp/st_$wl.log 2>&1)
