@@ -87,6 +87,9 @@ WORKLOADS = {
     "nv12_1080p_to_4k_default_preset": (P1080, P4K, px(P1080) * 3 // 2 + px(P4K) * 8, "ortho"),
     # pl_render_default_params as shipped: lanczos in linear, sigmoidized light + dither
     "default_preset_1080p_to_4k": (P1080, P4K, px(P1080) * 8 + px(P4K) * 8, "ortho"),
+    # pl_render_high_quality_params on SDR video: deband, ewa_lanczossharp in sigmoidized linear
+    # light, dither
+    "high_quality_preset_1080p_to_4k": (P1080, P4K, px(P1080) * 8 + px(P4K) * 8, "polar"),
     # ... with the polar scaler: linearize + sigmoidize while the tile is staged, EWA, inverse
     # sigmoid + delinearize + dither in the epilogue: ONE launch
     "default_preset_ewa_1080p_to_4k": (P1080, P4K, px(P1080) * 8 + px(P4K) * 8, "polar"),
@@ -232,6 +235,9 @@ class Stream:
             icsp, tcsp, trepr = pl.color_space("bt709", "bt1886"), pl.color_space("bt709", "bt1886"), ten_bit
         elif workload == "default_preset_1080p_to_4k":
             self.params = pl.render_params("default")
+            icsp, tcsp, trepr = sdr, sdr, ten_bit
+        elif workload == "high_quality_preset_1080p_to_4k":
+            self.params = pl.render_params("high_quality")
             icsp, tcsp, trepr = sdr, sdr, ten_bit
         elif workload == "default_preset_ewa_1080p_to_4k":
             self.params = pl.render_params("default", upscaler=pl.filter_config("ewa_lanczos"))

@@ -127,7 +127,7 @@ void k_deband(const plh_pass p_)
 /*
  * k_deband_fast: the renderer's debanding pass as one small kernel -- a whole rgba16 plane at
  * native resolution (output pixel (x, y) sits on texel (x, y)), clamp addressing, RGB mask,
- * ops = [identity PLANE_MAP] [LINEARIZE], rgba16hf target. Same arithmetic as k_deband (the PRNG,
+ * ops = [identity PLANE_MAP] [LINEARIZE] [SIGMOIDIZE] (each optional), rgba16hf target. Same arithmetic as k_deband (the PRNG,
  * the tap positions from the interpolated attribute, the comparison, op_linearize itself) with
  * one exception: the four taps of a channel are summed AS INTEGERS and decoded once
  * (S / 262140, one rounding) where the general kernel decodes each tap (v / 65535) and adds the
@@ -164,8 +164,12 @@ void k_deband_fast(const plh_pass p_)
     const uint32_t spitch = s.src.pitch;
     const int srcw = s.src.w, srch = s.src.h;
     const float sw = (float) srcw, sh = (float) srch;
-    const bool has_map = p.num_ops == 2;    // [identity PLANE_MAP] LINEARIZE, or LINEARIZE alone
-    const plh_op &o_map = p.ops[0], &o_lin = p.ops[p.num_ops - 1];
+    // ops: [identity PLANE_MAP] [LINEARIZE] [SIGMOIDIZE] (deband_fast_applies)
+    const bool has_map = p.num_ops > 0 && p.ops[0].kind == PLH_OP_PLANE_MAP;
+    const int i_lin = has_map ? 1 : 0;
+    const bool has_lin = i_lin < p.num_ops && p.ops[i_lin].kind == PLH_OP_LINEARIZE;
+    const bool has_sig = p.num_ops > 0 && p.ops[p.num_ops - 1].kind == PLH_OP_SIGMOIDIZE;
+    const plh_op &o_map = p.ops[0], &o_lin = p.ops[i_lin], &o_sig = p.ops[p.num_ops > 0 ? p.num_ops - 1 : 0];
     const bool has_alpha = !has_map || o_map.i1 >= 4;   // else alpha is the PLANE_MAP's neutral value
     const float my = p.out_scale[1] * ((float) idy + 0.5f);
 
@@ -268,7 +272,13 @@ void k_deband_fast(const plh_pass p_)
             if (o_map.i1 < 2) lin[3 * q + 1] = o_map.f[1];
         }
     }
-    op_linearize_values(lin, o_lin);
+    if (has_lin)
+        op_linearize_values(lin, o_lin);
+    if (has_sig) {
+#pragma unroll
+        for (int k = 0; k < 6; k++)
+            lin[k] = sigmoid1(lin[k], o_sig.f);
+    }
     uint32_t packed[2][2];
 #pragma unroll
     for (int q = 0; q < 2; q++) {
@@ -296,21 +306,20 @@ void k_deband_fast(const plh_pass p_)
  * bit (same PRNG, positions, integer tap sums); for radius * iterations <= 16.
  */
 #define DBL_TW 64
-#ifndef DBL_TH
-#define DBL_TH 32
-#endif
 #define DBL_HALO 17         // 16 + one texel of rounding slack
 #define DBL_WW (DBL_TW + 2 * DBL_HALO)
-#define DBL_WH (DBL_TH + 2 * DBL_HALO)
 #define DBL_NT 512
-#define DBL_NLOAD ((DBL_WW * DBL_WH + DBL_NT - 1) / DBL_NT)
 #ifndef DBL_NP
 #define DBL_NP 2         // pixels a lane works on at a time (2, 4 or 8)
 #endif
 
+// DBL_TH: rows of a workgroup's tile -- 32 (three workgroups per CU), or 16 for frames so small
+// that 32-row tiles would not fill the machine twice (four per CU, twice the tiles)
+template <int DBL_TH>
 __global__ __launch_bounds__(DBL_NT)
 void k_deband_lds(const plh_pass p_)
 {
+    constexpr int DBL_WH = DBL_TH + 2 * DBL_HALO;
     const plh_pass &p = plh_kernarg_pass();
     const plh_sampler_args &s = p.s;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -373,8 +382,12 @@ void k_deband_lds(const plh_pass p_)
     }
     __syncthreads();
 
-    const bool has_map = p.num_ops == 2;    // [identity PLANE_MAP] LINEARIZE, or LINEARIZE alone
-    const plh_op &o_map = p.ops[0], &o_lin = p.ops[p.num_ops - 1];
+    // ops: [identity PLANE_MAP] [LINEARIZE] [SIGMOIDIZE] (deband_fast_applies)
+    const bool has_map = p.num_ops > 0 && p.ops[0].kind == PLH_OP_PLANE_MAP;
+    const int i_lin = has_map ? 1 : 0;
+    const bool has_lin = i_lin < p.num_ops && p.ops[i_lin].kind == PLH_OP_LINEARIZE;
+    const bool has_sig = p.num_ops > 0 && p.ops[p.num_ops - 1].kind == PLH_OP_SIGMOIDIZE;
+    const plh_op &o_map = p.ops[0], &o_lin = p.ops[i_lin], &o_sig = p.ops[p.num_ops > 0 ? p.num_ops - 1 : 0];
     const bool has_alpha = !has_map || o_map.i1 >= 4;   // else alpha is the PLANE_MAP's neutral value
 
     // 32 lanes cover a row of the tile (two pixels each), a wave two rows, the workgroup 16 rows; a
@@ -470,7 +483,13 @@ void k_deband_lds(const plh_pass p_)
                 if (o_map.i1 < 2) lin[3 * q + 1] = o_map.f[1];
             }
         }
-        op_linearize_values(lin, o_lin);
+        if (has_lin)
+            op_linearize_values(lin, o_lin);
+        if (has_sig) {
+#pragma unroll
+            for (int k = 0; k < 3 * NP; k++)
+                lin[k] = sigmoid1(lin[k], o_sig.f);
+        }
 #pragma unroll
         for (int r = 0; r < PAIRS; r++) {
             uint32_t packed[2][2];
@@ -490,6 +509,24 @@ void k_deband_lds(const plh_pass p_)
     }
 }
 
+// [identity PLANE_MAP] [LINEARIZE] [SIGMOIDIZE], each optional, in this order, nothing else: the
+// debanding pass of a plain plane in gamma light, in front of a downscaler (linear light) and in
+// front of an upscaler (sigmoidized linear light: pl_render_high_quality_params on SDR video)
+static bool deband_fast_ops(const plh_pass *pass)
+{
+    int i = 0;
+    if (i < pass->num_ops && pass->ops[i].kind == PLH_OP_PLANE_MAP) {
+        if (!pass->ops[i].i2 || pass->ops[i].i1 < 1)
+            return false;
+        i++;
+    }
+    if (i < pass->num_ops && pass->ops[i].kind == PLH_OP_LINEARIZE)
+        i++;
+    if (i < pass->num_ops && pass->ops[i].kind == PLH_OP_SIGMOIDIZE)
+        i++;
+    return i == pass->num_ops;
+}
+
 // the shape k_deband_fast is written for
 static bool deband_fast_applies(const plh_pass *pass)
 {
@@ -505,10 +542,7 @@ static bool deband_fast_applies(const plh_pass *pass)
            pass->base_x == 0 && pass->base_y == 0 && pass->dir_x == 1 && pass->dir_y == 1 &&
            pass->dst.w >= pass->width && pass->dst.h >= pass->height &&
            (size_t) s.src.pitch * s.src.h < (1ull << 32) &&
-           !pass->num_pre_ops &&
-           ((pass->num_ops == 1 && pass->ops[0].kind == PLH_OP_LINEARIZE) ||
-            (pass->num_ops == 2 && pass->ops[0].kind == PLH_OP_PLANE_MAP && pass->ops[0].i2 &&
-             pass->ops[0].i1 >= 1 && pass->ops[1].kind == PLH_OP_LINEARIZE));
+           !pass->num_pre_ops && deband_fast_ops(pass);
 }
 
 int plh_launch_deband(hipStream_t stream, const plh_pass *pass)
@@ -517,15 +551,26 @@ int plh_launch_deband(hipStream_t stream, const plh_pass *pass)
         const char *lds = getenv("PL_HIP_DEBAND_LDS");
         const plh_sampler_args &s = pass->s;
         if (!(lds && lds[0] == '0') && s.iterations >= 1 && s.db_radius * (float) s.iterations <= 16.0f) {
-            const size_t shmem = (size_t) DBL_WW * DBL_WH * 8;
-            static uint64_t lds_done;
-            const int e = plh_kernel_needs_lds((const void *) k_deband_lds, (plh_stream) stream, shmem, &lds_done);
-            if (e)
-                return e;
+            int cus = 256;
+            (void) plh_stream_device((plh_stream) stream, &cus);
+            const int tiles_x = (pass->width + DBL_TW - 1) / DBL_TW;
             // (8 bands of tile columns, padded to the widest: k_deband_lds)
-            const int tiles_x = (pass->width + DBL_TW - 1) / DBL_TW, tiles_y = (pass->height + DBL_TH - 1) / DBL_TH;
-            const dim3 grid(8 * ((tiles_x + 7) / 8) * tiles_y);
-            hipLaunchKernelGGL(k_deband_lds, grid, dim3(DBL_NT), shmem, stream, *pass);
+#define DBL_LAUNCH(TH) do { \
+                const size_t shmem = (size_t) DBL_WW * (TH + 2 * DBL_HALO) * 8; \
+                static uint64_t lds_done; \
+                const int e = plh_kernel_needs_lds((const void *) k_deband_lds<TH>, (plh_stream) stream, shmem, &lds_done); \
+                if (e) \
+                    return e; \
+                const int tiles_y = (pass->height + TH - 1) / TH; \
+                const dim3 grid(8 * ((tiles_x + 7) / 8) * tiles_y); \
+                hipLaunchKernelGGL(k_deband_lds<TH>, grid, dim3(DBL_NT), shmem, stream, *pass); \
+            } while (0)
+            // fewer than two rounds of 32-row tiles (three workgroups per CU): 16-row tiles
+            if (tiles_x * ((pass->height + 31) / 32) < 2 * 3 * cus)
+                DBL_LAUNCH(16);
+            else
+                DBL_LAUNCH(32);
+#undef DBL_LAUNCH
             const hipError_t err = hipGetLastError();
             return err == hipSuccess ? 0 : -(int) err;
         }

@@ -197,7 +197,7 @@ def test_deband_prng_is_temporal(gpu):
 @pytest.mark.parametrize("kw", [dict(), dict(iterations=3, radius=20.0), dict(iterations=0),
                                 dict(grain=0.0, threshold=8.0)])
 @pytest.mark.parametrize("size", [(201, 75), (128, 64)])
-@pytest.mark.parametrize("trc", ["pq", "bt1886"])
+@pytest.mark.parametrize("trc", ["pq", "bt1886", "bt1886+sigmoid", "none"])
 def test_deband_fast_kernel_against_the_general_one(gpu, kw, size, trc, monkeypatch):
     """k_deband_fast (native-resolution rgba16 plane, [PLANE_MAP] LINEARIZE, rgba16hf target --
     the renderer's debanding pass) against the general kernel (PL_HIP_DEBAND_FAST=0). Same PRNG,
@@ -208,14 +208,21 @@ def test_deband_fast_kernel_against_the_general_one(gpu, kw, size, trc, monkeypa
     w, h = size
     img = util.random_rgba16(w, h, seed=17)
     t = gpu.tex_create(w, h, "rgba16", img)
-    csp = pl.color_space("bt2020" if trc == "pq" else "bt709", trc)
+    # (the tails the renderer records behind a debanded plane: linear light in front of a
+    # downscaler, sigmoidized linear light in front of an upscaler -- pl_render_high_quality_params
+    # on SDR video --, nothing in gamma light)
+    curve = trc.split("+")[0]
+    csp = pl.color_space("bt2020" if curve == "pq" else "bt709", curve if curve != "none" else "bt1886")
     outs = []
     for fast in ("1", "0"):
         monkeypatch.setenv("PL_HIP_DEBAND_FAST", fast)
         d = gpu.tex_create(w, h, "rgba16hf")
         sh = gpu.begin()
         assert sh.deband(t, components=3, **kw), gpu.messages[-3:]
-        sh.linearize(csp)
+        if trc != "none":
+            sh.linearize(csp)
+        if trc.endswith("+sigmoid"):
+            sh.sigmoidize()
         assert sh.finish(d), gpu.messages[-3:]
         outs.append(d.download().view(np.uint16))
         d.destroy()

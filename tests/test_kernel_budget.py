@@ -74,7 +74,7 @@ BUDGET = [
     (r"k_pass_peak<true>", 4),
     (r"k_pass_peak<false>", 3),
     (r"k_deband_fast", 8),
-    (r"k_deband_lds", 4),    # (LDS: two workgroups of 8 waves per CU)
+    (r"k_deband_lds<(16|32)>", 4),    # (LDS: two workgroups of 8 waves per CU)
     (r"k_deband<true>", 8),
     (r"k_deband<false>", 5),
     (r"k_ortho_fast<\d, 0, [01], (4|6), false>", 7),
