@@ -1182,6 +1182,15 @@ static bool polar_pp_build(pl_gpu gpu, pl_log log, struct sh_sampler_obj *obj,
     if (env_rows && atoi(env_rows) > 0)
         rows = PL_MIN(atoi(env_rows), 8);
     rows = PL_MIN(rows, 64 / (POLAR_BH * n));   // the kernel stages <= 64 output rows of info
+    // a small output (the chroma planes of 1080p video: 1920 x 1080 = 690 workgroups at 3 rows) does
+    // not fill 256 CUs twice with such tiles, and the kernel lives on latency hiding: fewer rows
+    // per workgroup until there are two rounds of them (NV12 1080p -> 4K, the chroma pass:
+    // 37.5 -> 26.2 us, profiles/r04_49_pp_rows_small.txt)
+    if (!(env_rows && atoi(env_rows) > 0)) {
+        while (rows > 1 && (size_t) ((W + POLAR_BW * n - 1) / (POLAR_BW * n)) *
+                           (size_t) ((H + POLAR_BH * rows * n - 1) / (POLAR_BH * rows * n)) < 1024)
+            rows--;
+    }
     size_t lds_w = 0;
     for (;; rows >>= 1) {
         free_axis_tiles(&tx);
