@@ -832,6 +832,154 @@ static bool pass_merge_applies(plh_pass *pass, plh_merge *m)
     return pass->epi.enabled;
 }
 
+/*
+ * k_pass_mix: the blending pass of pl_render_image_mix (src/renderer.c:3612-4052 -- the cached,
+ * already scaled frames of a vsync, each linearised and weighted: color = sum_i w_i * linear(F_i),
+ * then back to the target's curve, dither, store) without the interpreter:
+ *   [LINEARIZE] MIX_ADD { PLANE_FETCH [LINEARIZE] MIX_ADD }* MIX_END [DELINEARIZE], then the fused
+ *   epilogue into rgba16 or a plain store into rgba16hf.
+ * Through k_pass_generic<.., MIX> that pass took 146 us at 4K for two frames (three waves' worth of
+ * interpreter registers, nine transfer curves per pixel as serial per-channel switches); here the
+ * same device functions in the same order -- bit-identical -- with the curves of a lane's two
+ * pixels as independent chains (transfer.hiph). Two horizontally adjacent pixels per lane.
+ */
+#define PLH_MIX_MAX 8
+struct plh_mixplan { int32_t n, delin; int32_t lin[PLH_MIX_MAX], add[PLH_MIX_MAX], fetch[PLH_MIX_MAX]; };
+
+template <bool F16DST>
+__global__ __launch_bounds__(PASS_BW * PASS_BH)
+void k_pass_mix(const plh_pass p_, const plh_mixplan m)
+{
+    const plh_pass &p = plh_kernarg_pass();
+    const plh_sampler_args &s = p.s;
+    constexpr int NP = 2;
+    const int x0 = NP * (blockIdx.x * PASS_BW + threadIdx.x);
+    const int y = blockIdx.y * PASS_BH + threadIdx.y;
+    if (x0 >= p.width || y >= p.height)
+        return;
+    const bool all = x0 + 1 < p.width;
+    const plh_fast_epi &e = p.epi;
+    float bias[NP];
+#pragma unroll
+    for (int i = 0; i < NP; i++) {
+        const int ix = (x0 + i + p.frag_x0) & e.mask, iy = (y + p.frag_y0) & e.mask;
+        bias[i] = !F16DST && e.has_dither ? e.matrix[iy * e.size + ix] : 0.0f;
+    }
+    float4_t c[NP], mix[NP];
+    float mx[NP];
+    const float my = p.out_scale[1] * ((float) y + 0.5f);
+#pragma unroll
+    for (int i = 0; i < NP; i++) {
+        const int x = all ? x0 + i : x0;
+        c[i] = plh_fetch(s.src, x, y);
+        if (s.scale != 1.0f)
+            c[i] = scale4(c[i], s.scale);
+        mx[i] = p.out_scale[0] * ((float) x + 0.5f);
+        mix[i] = { 0.0f, 0.0f, 0.0f, 0.0f };
+    }
+#pragma unroll 1
+    for (int f = 0; f < m.n; f++) {
+        if (f > 0) {
+#pragma unroll
+            for (int i = 0; i < NP; i++)
+                op_plane_fetch(c[i], p.ops[m.fetch[f]], mx[i], my);
+        }
+        if (m.lin[f] >= 0)
+            op_linearize_px(c, p.ops[m.lin[f]]);
+        const float w = p.ops[m.add[f]].f[0];
+#pragma unroll
+        for (int i = 0; i < NP; i++) {
+            // mix_color += vec4(weight) * color (the interpreter's MIX_ADD: product, then sum)
+            mix[i].x += w * c[i].x; mix[i].y += w * c[i].y; mix[i].z += w * c[i].z; mix[i].w += w * c[i].w;
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < NP; i++)
+        c[i] = mix[i];
+    if (m.delin >= 0)
+        op_delinearize_px(c, p.ops[m.delin]);
+    uint32_t o[2 * NP];
+#pragma unroll
+    for (int i = 0; i < NP; i++) {
+        if (F16DST) {
+            o[2 * i] = (uint32_t) plh_f2h(c[i].x) | ((uint32_t) plh_f2h(c[i].y) << 16);
+            o[2 * i + 1] = (uint32_t) plh_f2h(c[i].z) | ((uint32_t) plh_f2h(c[i].w) << 16);
+            continue;
+        }
+        if (e.has_dither) {
+            const float b = bias[i], ds = e.dscale, di = e.dinv;
+            c[i] = { __builtin_floorf(ds * c[i].x + b) * di, __builtin_floorf(ds * c[i].y + b) * di,
+                     __builtin_floorf(ds * c[i].z + b) * di, __builtin_floorf(ds * c[i].w + b) * di };
+        }
+        if (e.has_scale)
+            c[i] = scale4(c[i], e.scale);
+        o[2 * i] = plh_unorm16x2(c[i].x, c[i].y);
+        o[2 * i + 1] = plh_unorm16x2(c[i].z, c[i].w);
+    }
+    char *d = (char *) p.dst.ptr + (size_t) y * p.dst.pitch + (size_t) x0 * 8;
+    if (all) {
+        const plh_u32x4 pk = { o[0], o[1], o[2], o[3] };
+        if (p.nt_store)
+            __builtin_nontemporal_store(pk, (plh_u32x4 *) d);
+        else
+            *(plh_u32x4 *) d = pk;
+    } else {
+        *(uint2 *) d = make_uint2(o[0], o[1]);
+    }
+}
+
+// Is this the blending pass k_pass_mix is written for? Fills `m` and pass->epi.
+static bool pass_mix_applies(plh_pass *pass, plh_mixplan *m)
+{
+    const plh_sampler_args &s = pass->s;
+    const char *env = getenv("PL_HIP_PASS_NATIVE");
+    if (env && env[0] == '0')
+        return false;
+    const bool native = pass->width == s.src.w && pass->height == s.src.h &&
+        s.pos[0][0] == 0.0f && s.pos[0][1] == 0.0f && s.pos[3][0] == 1.0f && s.pos[3][1] == 1.0f &&
+        s.pos[1][0] == 1.0f && s.pos[1][1] == 0.0f && s.pos[2][0] == 0.0f && s.pos[2][1] == 1.0f;
+    if (!native || s.type != PLH_SAMPLE_NEAREST || s.address_mode != PLH_ADDRESS_CLAMP ||
+        pass->transpose || pass->num_pre_ops || pass->base_x || pass->base_y || pass->dir_x != 1 ||
+        pass->dir_y != 1 || pass->dst.w < pass->width || pass->dst.h < pass->height ||
+        (pass->dst.fmt != PLH_FMT_RGBA16 && pass->dst.fmt != PLH_FMT_RGBA16F))
+        return false;
+    const int n = pass->num_ops;
+    int i = 0;
+    *m = plh_mixplan{};
+    m->delin = -1;
+    for (;;) {
+        if (m->n == PLH_MIX_MAX)
+            return false;
+        const int f = m->n;
+        m->fetch[f] = m->lin[f] = -1;
+        if (f > 0) {
+            if (!(i < n && pass->ops[i].kind == PLH_OP_PLANE_FETCH))
+                return false;
+            m->fetch[f] = i++;
+        }
+        if (i < n && pass->ops[i].kind == PLH_OP_LINEARIZE)
+            m->lin[f] = i++;
+        if (!(i < n && pass->ops[i].kind == PLH_OP_MIX_ADD))
+            return false;
+        m->add[f] = i++;
+        m->n++;
+        if (i < n && pass->ops[i].kind == PLH_OP_MIX_END) {
+            i++;
+            break;
+        }
+    }
+    if (m->n < 2)
+        return false;
+    if (i < n && pass->ops[i].kind == PLH_OP_DELINEARIZE)
+        m->delin = i++;
+    pass->chain = plh_map_chain{ 0, -1, -1, -1, -1, -1, -1, 0, -1, -1, -1, 0 };
+    pass->epi = plh_fast_epi{};
+    if (pass->dst.fmt == PLH_FMT_RGBA16F)
+        return i == n;
+    plh_match_fast_epilogue(pass, false, i);
+    return pass->epi.enabled;
+}
+
 // the shape k_pass_native is written for
 static bool pass_native_applies(const plh_pass *pass, bool features = false)
 {
@@ -1353,6 +1501,21 @@ extern "C" int plh_launch_pass(plh_stream stream_, const struct plh_pass *pass)
                 hipLaunchKernelGGL(k_pass_merge<true>, grid, block, 0, stream, local, m);
             else
                 hipLaunchKernelGGL(k_pass_merge<false>, grid, block, 0, stream, local, m);
+            const hipError_t err = hipGetLastError();
+            return err == hipSuccess ? 0 : -(int) err;
+        }
+    }
+
+    {
+        plh_pass local = *pass;
+        plh_mixplan mp;
+        if (pass_mix_applies(&local, &mp)) {
+            const dim3 block(PASS_BW, PASS_BH);
+            const dim3 grid(((local.width + 1) / 2 + PASS_BW - 1) / PASS_BW, (local.height + PASS_BH - 1) / PASS_BH);
+            if (local.dst.fmt == PLH_FMT_RGBA16F)
+                hipLaunchKernelGGL(k_pass_mix<true>, grid, block, 0, stream, local, mp);
+            else
+                hipLaunchKernelGGL(k_pass_mix<false>, grid, block, 0, stream, local, mp);
             const hipError_t err = hipGetLastError();
             return err == hipSuccess ? 0 : -(int) err;
         }

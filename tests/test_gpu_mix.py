@@ -227,3 +227,37 @@ def test_rejections_and_fallbacks(gpu, rr):
         t.destroy()
     for t in texs:
         t.destroy()
+
+
+@pytest.mark.parametrize("name,ts", [("linear", [-0.7, 0.3]), ("mitchell", [-1.6, -0.6, 0.4, 1.4]),
+                                      ("oversample", [-0.6, 0.4, 1.4])])
+@pytest.mark.parametrize("dither", [False, True])
+def test_blend_kernel_equals_the_interpreter(gpu, name, ts, dither, monkeypatch):
+    """k_pass_mix (round 4: the blending pass as straight-line code -- per cached frame a fetch,
+    LINEARIZE and MIX_ADD, then MIX_END, DELINEARIZE and the fused epilogue) against the same
+    pass through the op interpreter (PL_HIP_PASS_NATIVE=0: k_pass_generic<.., MIX>): the same
+    device functions in the same order, so the same frame bit for bit -- two and four frames,
+    with and without the dither, and the last column of an odd width."""
+    global W
+    outs = []
+    old_w = W
+    try:
+        W = 63
+        for native in ("1", "0"):
+            monkeypatch.setenv("PL_HIP_PASS_NATIVE", native)
+            r = pl.Renderer(gpu)
+            imgs, texs, frames = sources(gpu, len(ts))
+            kw = dict(frame_mixer=mixer(name))
+            if dither:
+                kw.update(dither_params=capi.DitherParams(method=pl.DITHER_BLUE_NOISE, lut_size=6, transfer=0),
+                          disable_dither_gamma_correction=True)
+            params = pl.render_params("fast", **kw)
+            ok, got = run_mix(gpu, r, frames, ts, params)
+            assert ok and r.errors() == 0, gpu.messages[-4:]
+            outs.append(got)
+            r.destroy()
+            for t in texs:
+                t.destroy()
+    finally:
+        W = old_w
+    assert np.array_equal(outs[0], outs[1]), util.diff_stats(outs[0], outs[1])
