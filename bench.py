@@ -102,6 +102,10 @@ WORKLOADS = {
     # intermediate -> measurement -> tone map
     "ewa_8k_to_4k_hdr_tonemap": (P8K, P4K, px(P8K) * 8 + 4 * px(P4K) * 8, "polar"),
     "hdr10_4k_tonemap": (P4K, P4K, 3 * px(P4K) * 8, "tone map"),
+    # ... with pl_render_high_quality_params (deband, contrast recovery, HQ peak detection)
+    "hdr10_4k_tonemap_high_quality": (P4K, P4K, 3 * px(P4K) * 8, "tone map"),
+    # pl_render_default_params downscaling SDR video (hermite, linear light)
+    "default_preset_4k_to_1080p": (P4K, P1080, px(P4K) * 8 + px(P1080) * 8, "ortho"),
     "ewa_8k_to_4k_deband_tonemap": (P8K, P4K, px(P8K) * 8 + px(P4K) * 8, "debanding"),
     # the metric's two halves in one frame: 1080p HDR10 -> EWA 2x upscale -> tone map -> 4K SDR
     "ewa_1080p_to_4k_hdr_tonemap": (P1080, P4K, 2 * px(P1080) * 8 + px(P4K) * 8, "polar"),
@@ -241,6 +245,12 @@ class Stream:
             icsp, tcsp, trepr = sdr, sdr, ten_bit
         elif workload == "default_preset_ewa_1080p_to_4k":
             self.params = pl.render_params("default", upscaler=pl.filter_config("ewa_lanczos"))
+            icsp, tcsp, trepr = sdr, sdr, ten_bit
+        elif workload == "hdr10_4k_tonemap_high_quality":
+            self.params = pl.render_params("high_quality")
+            icsp, tcsp, trepr = hdr, bt1886, ten_bit
+        elif workload == "default_preset_4k_to_1080p":
+            self.params = pl.render_params("default")
             icsp, tcsp, trepr = sdr, sdr, ten_bit
         elif workload == "hdr10_4k_tonemap":
             self.params = pl.render_params(

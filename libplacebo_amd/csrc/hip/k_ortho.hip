@@ -464,11 +464,28 @@ static void launch_ortho_fast(hipStream_t stream, const plh_pass *pass, int epi)
         else                            LAUNCH_N(E, 16); \
     } while (0)
     if (pass->s.use_linear) {
-        // linear-trick filters (bicubic / gaussian / ... low-pass): no colour ops, any tap count
-        if (pass->s.dir)
-            hipLaunchKernelGGL((k_ortho_fast<SRC, 0, 1, 16, true>), grid, block, 0, stream, *pass);
-        else
-            hipLaunchKernelGGL((k_ortho_fast<SRC, 0, 0, 16, true>), grid, block, 0, stream, *pass);
+        // linear-trick filters (bicubic / gaussian / hermite ... low-pass), any tap count; colour
+        // ops behind them only as the fused epilogue / the map chain, packed sources
+        // (the tap count at compile time where it is 4 or 8 -- a halving with hermite / bicubic: the
+        // run-time form issues all 16 loads whatever the count)
+#define LAUNCH_LIN_N(E, NT) do { \
+            if (pass->s.dir) hipLaunchKernelGGL((k_ortho_fast<SRC, E, 1, NT, true>), grid, block, 0, stream, *pass); \
+            else             hipLaunchKernelGGL((k_ortho_fast<SRC, E, 0, NT, true>), grid, block, 0, stream, *pass); \
+        } while (0)
+#define LAUNCH_LIN(E) do { \
+            if (pass->s.row_size == 4)      LAUNCH_LIN_N(E, 4); \
+            else if (pass->s.row_size == 8) LAUNCH_LIN_N(E, 8); \
+            else                            LAUNCH_LIN_N(E, 16); \
+        } while (0)
+        if constexpr (SRC == PLH_FMT_RGBA16 || SRC == PLH_FMT_RGBA16F) {
+            if (epi == 1)      LAUNCH_LIN(1);
+            else if (epi == 4) LAUNCH_LIN(4);
+            else               LAUNCH_LIN(0);
+        } else {
+            LAUNCH_LIN(0);
+        }
+#undef LAUNCH_LIN
+#undef LAUNCH_LIN_N
         return;
     }
     if constexpr (SRC == PLH_FMT_RGBA16 || SRC == PLH_FMT_RGBA16F) {
@@ -513,12 +530,22 @@ static int ortho_fast_variant(plh_pass *pass)
         }
     }
     if (s.use_linear) {
-        // the LIN variant: run-time tap count (even, <= 16), no colour ops
+        // the LIN variant: run-time tap count (even, <= 16); no colour ops, or -- packed sources:
+        // the last pass of a downscale in linear light, pl_render_default_params 4K -> 1080p -- the
+        // fused epilogue / the map chain (DELINEARIZE + dither) behind it
         if (!enabled || !addr_ok || s.linear || (s.row_size & 1) || s.row_size < 2 ||
-            s.row_size > 16 || (s.row_stride & 3) || pass->num_pre_ops || pass->num_ops ||
+            s.row_size > 16 || (s.row_stride & 3) || pass->num_pre_ops ||
             (!ortho_fast_packed(s.src.fmt) && !ortho_fast_plane(s.src.fmt)))
             return -1;
-        return 0;
+        if (!pass->num_ops)
+            return 0;
+        if (!ortho_fast_packed(s.src.fmt))
+            return -1;
+        plh_match_fast_epilogue(pass, true);
+        if (pass->epi.enabled)
+            return 1;
+        plh_match_map_chain(pass);
+        return pass->chain.enabled ? 4 : -1;
     }
     if (!enabled || !addr_ok || s.linear ||
         (s.row_size != 4 && s.row_size != 6 && s.row_size != 8 &&

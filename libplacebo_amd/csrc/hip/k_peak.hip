@@ -356,11 +356,15 @@ void k_peak_fast(const plh_pass p_)
             if (y >= h || x0 >= w)
                 continue;
             uint32_t o[2];
+            float4_t t[2] = { c[2 * k], c[2 * k + 1] };
+            // (an image that is not linear yet -- HDR10 without a scaler in front -- is linearised
+            // for the features: [PEAK_DETECT] LINEARIZE FEATURES)
+            if (p.num_ops == 3)
+                op_linearize_px(t, p.ops[1]);
 #pragma unroll
             for (int i = 0; i < 2; i++) {
-                float4_t t = c[2 * k + i];
-                op_features(t, p.ops[1]);
-                o[i] = plh_f2h(t.x);
+                op_features(t[i], p.ops[p.num_ops - 1]);
+                o[i] = plh_f2h(t[i].x);
             }
             char *d = (char *) p.dst.ptr + (size_t) y * p.dst.pitch + (size_t) x0 * 2;
             if (x0 + 1 < w)
@@ -406,12 +410,13 @@ static bool peak_fast_applies(const plh_pass *pass)
     const bool target = pass->dst.ptr != NULL;
     const bool plain_target = pass->base_x == 0 && pass->base_y == 0 && pass->dir_x == 1 && pass->dir_y == 1 &&
                               pass->dst.w >= pass->width && pass->dst.h >= pass->height;
-    // [PEAK_DETECT] [FEATURES] into the r16hf feature plane (STORE = 2)
+    // PEAK_DETECT [LINEARIZE] FEATURES into the r16hf feature plane (STORE = 2)
     if (native && s.type == PLH_SAMPLE_NEAREST && s.scale == 1.0f &&
         (s.src.fmt == PLH_FMT_RGBA16 || s.src.fmt == PLH_FMT_RGBA16F) &&
         s.address_mode == PLH_ADDRESS_CLAMP && !pass->transpose && !pass->num_pre_ops && target &&
-        pass->dst.fmt == PLH_FMT_R16F && plain_target && pass->num_ops == 2 &&
-        pass->ops[0].kind == PLH_OP_PEAK_DETECT && pass->ops[1].kind == PLH_OP_FEATURES)
+        pass->dst.fmt == PLH_FMT_R16F && plain_target && pass->ops[0].kind == PLH_OP_PEAK_DETECT &&
+        ((pass->num_ops == 2 && pass->ops[1].kind == PLH_OP_FEATURES) ||
+         (pass->num_ops == 3 && pass->ops[1].kind == PLH_OP_LINEARIZE && pass->ops[2].kind == PLH_OP_FEATURES)))
         return true;
     return native && s.type == PLH_SAMPLE_NEAREST && s.scale == 1.0f &&
            (s.src.fmt == PLH_FMT_RGBA16 || s.src.fmt == PLH_FMT_RGBA16F) &&
