@@ -929,6 +929,24 @@ static bool mxr_axis(const float *fc, const int32_t *base, int len, int R, int G
     return true;
 }
 
+// Test hook (tests/test_mxr_axis.py, CPU): mxr_axis on an axis described by its per-output base
+// texels and fcoords. out = { shift, origin, off[0..3], rep[0..3] }; canon: len floats.
+PL_API int plh_test_mxr_axis(const float *fc, const int32_t *base, int len, int R, int G,
+                             int *out, float *canon);
+int plh_test_mxr_axis(const float *fc, const int32_t *base, int len, int R, int G, int *out, float *canon)
+{
+    int shift = 0, origin = 0, off[PLH_MXR_MAX_RATIO] = {0}, rep[PLH_MXR_MAX_RATIO] = {0};
+    if (R < 2 || R > PLH_MXR_MAX_RATIO || !mxr_axis(fc, base, len, R, G, &shift, &origin, off, rep, canon))
+        return 0;
+    out[0] = shift;
+    out[1] = origin;
+    for (int q = 0; q < PLH_MXR_MAX_RATIO; q++) {
+        out[2 + q] = q < R ? off[q] : -1;
+        out[2 + PLH_MXR_MAX_RATIO + q] = q < R ? rep[q] : -1;
+    }
+    return 1;
+}
+
 // B fragments of k_polar_mxr (plh_device.h): frag f = 32 py + 4 * (NH * j + h) + kind, lane l,
 // element e hold T(py, j, h)[k][n], n = l & 15 the output column within half h of the wave's 8 / G
 // bases -- base bi = 4 h + n / R, phase px = n % R, n < 4 R -- and K index (row 2 j + (l >> 5) of the
