@@ -1646,3 +1646,43 @@ int plh_test_match_chain(const int *kinds, const int *flags, int n, int num_pre,
         out[i] = v[i];
     return c.enabled;
 }
+
+// Test hook (tests/test_chain_match.py, CPU): pass_mix_applies on a texel-for-texel NEAREST pass
+// whose op list is given by its kinds (DITHER / SCALE as the plain fused epilogue).
+// out = { frames, delin, epi.enabled, lin[0..3], fetch[0..3] }
+extern "C" __attribute__((visibility("default")))
+int plh_test_match_mix(const int *kinds, int n, int dst_fmt, int sampler, int *out)
+{
+    static plh_pass pass;
+    pass = plh_pass{};
+    if (n > PLH_MAX_OPS)
+        return -1;
+    pass.num_ops = n;
+    pass.width = pass.s.src.w = pass.dst.w = 64;
+    pass.height = pass.s.src.h = pass.dst.h = 48;
+    pass.s.pos[1][0] = pass.s.pos[3][0] = pass.s.pos[2][1] = pass.s.pos[3][1] = 1.0f;
+    pass.s.type = sampler;
+    pass.s.address_mode = PLH_ADDRESS_CLAMP;
+    pass.s.src.fmt = PLH_FMT_RGBA16F;
+    pass.dir_x = pass.dir_y = 1;
+    pass.dst.fmt = dst_fmt;
+    for (int i = 0; i < n; i++) {
+        plh_op &op = pass.ops[i];
+        op.kind = kinds[i];
+        if (kinds[i] == PLH_OP_DITHER) {
+            op.i0 = 64; op.f[0] = 1023.0f; op.f[1] = 1.0f; op.f[3] = 10.0f; op.f[8] = 1.0f / 1023.0f;
+        } else if (kinds[i] == PLH_OP_SCALE) {
+            op.f[0] = op.f[1] = op.f[2] = op.f[3] = 0.5f;
+        }
+    }
+    plh_mixplan m;
+    const bool ok = pass_mix_applies(&pass, &m);
+    out[0] = ok ? m.n : 0;
+    out[1] = m.delin;
+    out[2] = pass.epi.enabled;
+    for (int f = 0; f < 4; f++) {
+        out[3 + f] = f < m.n ? m.lin[f] : -1;
+        out[7 + f] = f < m.n ? m.fetch[f] : -1;
+    }
+    return ok;
+}

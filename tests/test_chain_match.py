@@ -70,3 +70,35 @@ def test_fused_pre_ops_are_not_the_chains_business():
     # ops in front of num_pre_ops belong to the scaler's tile staging (the reference's PASS A)
     m = match([PMAP, UNSIG, DELIN, DITHER, SCALE], num_pre=1)
     assert m["enabled"] and m["unsig"] == 1 and m["tail"] == 3 and m["pmap"] == -1
+
+
+# ---- the blending pass of pl_render_image_mix (k_pass_mix, k_pass.hip) ---------------------------
+MIX_ADD, MIX_END, NEAREST, BILINEAR = 28, 29, 1, 2
+
+
+def match_mix(kinds, dst=RGBA16, sampler=NEAREST):
+    n = len(kinds)
+    out = (C.c_int * 11)()
+    fn = pl.lib().plh_test_match_mix
+    fn.restype = C.c_int
+    ok = fn((C.c_int * n)(*kinds), n, dst, sampler, out)
+    return bool(ok), dict(frames=out[0], delin=out[1], epi=out[2], lin=list(out[3:7]), fetch=list(out[7:11]))
+
+
+def test_blending_pass_shapes():
+    # what render_mix.c records for two cached frames into a 10-bit target (tools/r04_51.sh)
+    ok, m = match_mix([LIN, MIX_ADD, FETCH, LIN, MIX_ADD, MIX_END, DELIN, DITHER, SCALE])
+    assert ok and m["frames"] == 2 and m["lin"][:2] == [0, 3] and m["fetch"][:2] == [-1, 2]
+    assert m["delin"] == 6 and m["epi"]
+    # four frames (a wider mixer), no curves (a linear target), an rgba16hf target without an epilogue
+    ok, m = match_mix([MIX_ADD, FETCH, MIX_ADD, FETCH, MIX_ADD, FETCH, MIX_ADD, MIX_END], dst=RGBA16F)
+    assert ok and m["frames"] == 4 and m["delin"] == -1 and m["fetch"] == [-1, 1, 3, 5]
+    # (the fused epilogue may be empty: a plain rgba16 store)
+    assert match_mix([LIN, MIX_ADD, FETCH, LIN, MIX_ADD, MIX_END, DELIN])[0]
+    assert match_mix([LIN, MIX_ADD, FETCH, LIN, MIX_ADD, MIX_END, DELIN, SCALE])[0]
+    # not its business: one frame, a resampled first frame, anything else between the ops
+    assert not match_mix([LIN, MIX_ADD, MIX_END, DELIN, DITHER, SCALE])[0]
+    assert not match_mix([LIN, MIX_ADD, FETCH, LIN, MIX_ADD, MIX_END, DELIN, DITHER, SCALE], sampler=BILINEAR)[0]
+    assert not match_mix([LIN, AFFINE, MIX_ADD, FETCH, LIN, MIX_ADD, MIX_END, DELIN, DITHER, SCALE])[0]
+    assert not match_mix([LIN, MIX_ADD, FETCH, LIN, MIX_ADD, MIX_END, DELIN, RGB2IPT, DITHER, SCALE])[0]
+    assert not match_mix([LIN, MIX_ADD, FETCH, LIN, MIX_ADD])[0]                         # no MIX_END
