@@ -550,7 +550,7 @@ int plh_launch_deband(hipStream_t stream, const plh_pass *pass)
     if (deband_fast_applies(pass)) {
         const char *lds = getenv("PL_HIP_DEBAND_LDS");
         const plh_sampler_args &s = pass->s;
-        if (!(lds && lds[0] == '0') && s.iterations >= 1 && s.db_radius * (float) s.iterations <= 16.0f) {
+        if (!(lds && lds[0] == '0') && s.db_lds && s.iterations >= 1 && s.db_radius * (float) s.iterations <= 16.0f) {
             int cus = 256;
             (void) plh_stream_device((plh_stream) stream, &cus);
             const int tiles_x = (pass->width + DBL_TW - 1) / DBL_TW;

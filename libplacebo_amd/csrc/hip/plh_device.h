@@ -180,6 +180,7 @@ struct plh_sampler_args {
     float db_threshold, db_radius, db_grain;
     float db_neutral[3];
     uint32_t prng_seed;     // frame index (sh_prng, shaders.c:965-998)
+    int32_t db_lds;         // the backend's shared-memory limit admits k_deband_lds' window (52 KiB)
 };
 
 /* ---- per-pixel colour ops -------------------------------------------------- */

@@ -1838,6 +1838,8 @@ void pl_shader_deband(pl_shader sh, const struct pl_sample_src *src,
             s->db_neutral[c] = params->grain_neutral[k++] / info.scale;
     }
     s->prng_seed = sh->params.index;
+    // (k_deband_lds stages a 98 x 66 texel window: not where the user has lowered the limit)
+    s->db_lds = !SH_GPU(sh) || SH_GPU(sh)->glsl.max_shmem_size >= 52 * 1024;
 
     sh_listf(sh, "deband(iterations=%d, threshold=%g, radius=%g, grain=%g, scale=%g, "
              "mask=0x%x, seed=%u)\n", s->iterations, params->threshold, params->radius,
