@@ -296,13 +296,14 @@ void k_deband_fast(const plh_pass p_)
 /*
  * k_deband_lds: k_deband_fast with the taps gathered from an LDS window instead of from memory.
  * k_deband_fast's four taps per pixel are 8-byte gathers at random offsets within +-16 texels:
- * every lane touches its own cache line, a wave's taps cover ~330 lines (42 KiB: more than a CU's
- * L1), so nearly every tap moves a whole 128-byte line from L2 for 8 useful bytes -- 33 M pixels
- * x 4 taps x 128 B = 17 GB per 8K plane, which at the L2's aggregate rate IS the 376 us the
+ * every lane touches its own cache line (the vector L1 looks them up one by one), a wave's taps
+ * cover ~330 lines (42 KiB: more than a CU's L1). Measured per 8K plane: 152.5 M L1 line accesses
+ * (596 k per CU: 250 us at one per clock) and 46.5 M read requests to L2 (3-6 GB for 265 MB of
+ * image) -- that, not instruction issue or HBM, is the 385 us the
  * kernel takes (and explains what rounds 2-4 measured: fewer instructions bought nothing, and
  * concentrating each XCD on one band made it slower). Here a workgroup of 8 waves stages the
- * 98 x 98 texels around its 64 x 64 pixels once (coalesced 8-byte loads, 2.35 x the plane through
- * L1 instead of 64 x), and the taps are ds_read_b64. Same arithmetic as k_deband_fast, bit for
+ * 98 x 66 texels around its 64 x 32 pixels once (coalesced 8-byte loads: 49.7 M L1 accesses and
+ * 9.5 M L2 requests per plane), and the taps are ds_read_b64. Same arithmetic as k_deband_fast, bit for
  * bit (same PRNG, positions, integer tap sums); for radius * iterations <= 16.
  */
 #define DBL_TW 64
