@@ -3,7 +3,11 @@
  * dense tile contraction on the f16 matrix pipe (struct plh_polar_mx with enabled == 3,
  * plh_device.h). 720p -> 4K is 3x, 540p / 960x540 -> 4K is 4x; k_polar_mx.hiph is the 2x case and
  * explains the numerics (f16 hi + lo weight halves, first-order terms in the per-pixel phase),
- * which are the same here. VERDICT r03 "missing 1".
+ * which are the same here. VERDICT r03 "missing 1". What is computed is the reference's polar
+ * sampler (src/shaders/sampling.c:503-558 polar_sample, :587-912 pl_shader_sample_polar: every tap
+ * within the radius weighted by the LUT at its distance, normalised by the weight sum) -- here with
+ * the weights of each phase tabulated once per geometry by the host (shader_sampling.c:
+ * polar_mxr_build, from the same phase-class weights k_polar_pp uses).
  *
  * What changes with R. An axis has R phases; output X belongs to base index (X + sx) / R and phase
  * (X + sx) % R, and -- with the shift the host reads off the geometry -- every phase of a base index
