@@ -468,6 +468,17 @@ const char *rp_peak_skip_reason(const struct rp_caps *caps, const struct pl_rend
 /* ======================================================================================== */
 /* contrast recovery: :2089-2154 (get_feature_map), conditions + geometry                     */
 
+bool rp_fuse_into_polar(enum rp_direction dir, bool pending_lite, float antiring, int force)
+{
+    if (force == 1 || dir == RP_DIR_NONE)
+        return false;
+    if (antiring > 0)
+        return false;   // the anti-ringing variant has no fused form
+    if (force == 0)
+        return true;
+    return dir == RP_DIR_DOWN || pending_lite;
+}
+
 bool rp_wants_feature_map(const struct rp_caps *caps, const struct pl_render_params *params,
                           const struct pl_color_space *img, const struct pl_color_space *target,
                           int out_w, int out_h, int *map_w, int *map_h)

@@ -131,6 +131,16 @@ const char *rp_peak_skip_reason(const struct rp_caps *caps, const struct pl_rend
                                 const struct pl_color_space *image, const struct pl_color_space *img,
                                 const struct pl_color_space *target);
 
+/* ---- fusing the pending image into a polar main scaler ---- */
+// `pending_lite`: the ops recorded on the pending image need no transcendental (decode, plane map,
+// affine ...); `force`: PL_HIP_NO_FUSION as read by the caller, -1 unset, 0 = fuse wherever it is
+// valid, 1 = never. An upscale keeps the reference's two passes when its pending ops are not lite
+// (LINEARIZE + SIGMOIDIZE: pl_render_default_params on SDR video) -- the intermediate is the small
+// side, and fused the polar kernel would stage its tile through the full op interpreter
+// (1080p -> 4K: 0.113 ms fused, 0.063 ms as two passes); a downscale keeps the fusion (its
+// intermediate is the large side, k_polar_mxd linearises while it stages).
+bool rp_fuse_into_polar(enum rp_direction dir, bool pending_lite, float antiring, int force);
+
 /* ---- contrast recovery ---- */
 bool rp_wants_feature_map(const struct rp_caps *caps, const struct pl_render_params *params,
                           const struct pl_color_space *img, const struct pl_color_space *target,

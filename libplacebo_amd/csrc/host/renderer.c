@@ -416,7 +416,8 @@ static bool try_fused_polar(struct frame_job *job, pl_shader sh, const struct pl
 {
     const struct pl_render_params *params = job->params;
     const char *off = getenv("PL_HIP_NO_FUSION");
-    if (!pre || (off && off[0] == '1'))
+    const int force = off && (off[0] == '0' || off[0] == '1') ? off[0] - '0' : -1;
+    if (!pre || force == 1)
         return false;
     pl_fmt fmt = job->caps.fbo[job->img.comps];
     if (!fmt || fmt->type != PL_FMT_FLOAT || fmt->component_depth[0] != 16)
@@ -427,31 +428,23 @@ static bool try_fused_polar(struct frame_job *job, pl_shader sh, const struct pl
     struct pl_sample_src probe = *req;
     probe.tex = &stand_in;
     const struct rp_scaler sc = rp_pick_scaler(&job->caps, params, RP_USE_MAIN, &probe, fmt);
-    if (sc.kind != RP_SCALER_FILTER || !sc.filter->polar || sc.dir == RP_DIR_NONE)
+    if (sc.kind != RP_SCALER_FILTER || !sc.filter->polar)
         return false;
-    const float ar = sc.filter->antiring ? sc.filter->antiring : params->antiringing_strength;
-    if (ar > 0)
-        return false;   // the anti-ringing variant has no fused form
-    // An UPSCALE whose pending ops need transcendentals (LINEARIZE + SIGMOIDIZE in front of the
-    // scaler: pl_render_default_params on SDR video) is better off with the reference's two
-    // passes: the intermediate is the small side (1080p: 16.6 MB written and read), while fused
-    // the polar kernel stages its tile through the full op interpreter at three waves per SIMD --
-    // 1080p -> 4K measured 0.113 ms fused against 0.063 ms as k_pass_chain + k_polar_mx with the
-    // chain epilogue (profiles/r04_44_default_preset_ewa_fusion.txt). A downscale keeps the fusion:
-    // its intermediate is the large side, and k_polar_mxd linearises while it stages.
-    // PL_HIP_NO_FUSION=0 forces the fused form (tests compare the two: bit-identical).
-    if (sc.dir == RP_DIR_UP && !(off && off[0] == '0')) {
-        const struct plh_pass *pp = &pre->pass;
-        for (int i = 0; i < pp->num_ops; i++) {
-            switch (pp->ops[i].kind) {
-            case PLH_OP_SCALE: case PLH_OP_AFFINE: case PLH_OP_PREMULTIPLY: case PLH_OP_ALPHA_ONE:
-            case PLH_OP_QUANT_F16: case PLH_OP_SWIZZLE: case PLH_OP_CLAMP01: case PLH_OP_PLANE_MAP:
-                break;
-            default:
-                return false;
-            }
+    // (the rule -- which directions fuse, with which pending ops -- is the planner's:
+    // render_plan.h, tests/test_render_plan.py; measured in profiles/r04_44_*)
+    bool pending_lite = true;
+    for (int i = 0; i < pre->pass.num_ops; i++) {
+        switch (pre->pass.ops[i].kind) {
+        case PLH_OP_SCALE: case PLH_OP_AFFINE: case PLH_OP_PREMULTIPLY: case PLH_OP_ALPHA_ONE:
+        case PLH_OP_QUANT_F16: case PLH_OP_SWIZZLE: case PLH_OP_CLAMP01: case PLH_OP_PLANE_MAP:
+            break;
+        default:
+            pending_lite = false;
         }
     }
+    const float ar = sc.filter->antiring ? sc.filter->antiring : params->antiringing_strength;
+    if (!rp_fuse_into_polar(sc.dir, pending_lite, ar, force))
+        return false;
 
     const struct pl_sample_filter_params fp = {
         .filter      = *sc.filter,
@@ -1558,6 +1551,12 @@ void plh_test_op_scale(pl_shader sh, float s)
 
 // Plan a frame from descriptions alone (the textures only need valid `params`) and print the
 // decisions. `fbos`: whether intermediate images (rgba16hf) are available.
+PL_API int plh_test_fuse_into_polar(int dir, int pending_lite, float antiring, int force);
+int plh_test_fuse_into_polar(int dir, int pending_lite, float antiring, int force)
+{
+    return rp_fuse_into_polar((enum rp_direction) dir, pending_lite != 0, antiring, force);
+}
+
 PL_API pl_fmt plh_test_format(const char *name);
 PL_API size_t plh_test_plan(const struct pl_frame *image, const struct pl_frame *target,
                             const struct pl_render_params *params, bool fbos,

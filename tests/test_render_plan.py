@@ -165,3 +165,23 @@ def test_invalid_frames_are_reported(L):
     image, target = frames(L, (16, 16), (16, 16))
     target.num_planes = 5
     assert plan(L, image, target, None).startswith("invalid: invalid number of planes")
+
+
+def test_which_pending_images_are_fused_into_a_polar_scaler(L):
+    """rp_fuse_into_polar: the pending image (plane fetch + colour ops) becomes the fused PASS A of
+    a polar main scaler -- always for a downscale (the intermediate would be the large side;
+    k_polar_mxd linearises while it stages), for an upscale only when its ops need no
+    transcendental: pl_render_default_params on SDR video records LINEARIZE + SIGMOIDIZE there, and
+    two passes (k_pass_chain, then the polar kernel with the chain epilogue) take 0.063 ms where the
+    fused launch took 0.113 (profiles/r04_44_default_preset_ewa_fusion.txt). Anti-ringing has no
+    fused form; PL_HIP_NO_FUSION=0 / 1 overrides (tests compare the structures)."""
+    NONE, UP, DOWN = 0, 1, 2
+    f = L.plh_test_fuse_into_polar
+    f.restype = C.c_int
+    f.argtypes = [C.c_int, C.c_int, C.c_float, C.c_int]
+    assert f(UP, 1, 0.0, -1) and not f(UP, 0, 0.0, -1)          # lite / LINEARIZE + SIGMOIDIZE
+    assert f(DOWN, 1, 0.0, -1) and f(DOWN, 0, 0.0, -1)
+    assert not f(NONE, 1, 0.0, -1)
+    assert not f(UP, 1, 0.8, -1) and not f(DOWN, 0, 0.8, 0)     # anti-ringing: never
+    assert f(UP, 0, 0.0, 0)                                     # PL_HIP_NO_FUSION=0: fuse anyway
+    assert not f(UP, 1, 0.0, 1) and not f(DOWN, 1, 0.0, 1)      # =1: the reference's structure
