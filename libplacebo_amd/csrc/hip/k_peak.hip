@@ -48,6 +48,31 @@ DEV uint32_t wave_max(uint32_t v)
     return v;
 }
 
+// The same over the DPP network (no LDS round trips): a prefix sum along each row of 16 lanes, the
+// rows' totals broadcast into the next row; lane 63 holds the wave's total. Returns it as a scalar.
+#define PEAK_DPP(v, ctrl, rmask) __builtin_amdgcn_update_dpp(0, (int) (v), ctrl, rmask, 0xf, false)
+DEV uint32_t wave_sum_dpp(uint32_t v)
+{
+    v += (uint32_t) PEAK_DPP(v, 0x111, 0xf);    // row_shr:1
+    v += (uint32_t) PEAK_DPP(v, 0x112, 0xf);    // row_shr:2
+    v += (uint32_t) PEAK_DPP(v, 0x114, 0xf);    // row_shr:4
+    v += (uint32_t) PEAK_DPP(v, 0x118, 0xf);    // row_shr:8
+    v += (uint32_t) PEAK_DPP(v, 0x142, 0xa);    // row_bcast:15 into rows 1, 3
+    v += (uint32_t) PEAK_DPP(v, 0x143, 0xc);    // row_bcast:31 into rows 2, 3
+    return (uint32_t) __builtin_amdgcn_readlane((int) v, 63);
+}
+
+DEV uint32_t wave_max_dpp(uint32_t v)
+{
+    v = max(v, (uint32_t) PEAK_DPP(v, 0x111, 0xf));
+    v = max(v, (uint32_t) PEAK_DPP(v, 0x112, 0xf));
+    v = max(v, (uint32_t) PEAK_DPP(v, 0x114, 0xf));
+    v = max(v, (uint32_t) PEAK_DPP(v, 0x118, 0xf));
+    v = max(v, (uint32_t) PEAK_DPP(v, 0x142, 0xa));
+    v = max(v, (uint32_t) PEAK_DPP(v, 0x143, 0xc));
+    return (uint32_t) __builtin_amdgcn_readlane((int) v, 63);
+}
+
 // One wavefront owns one of the reference's 16x16 workgroups: lane l measures the pixels
 // (l & 15, (l >> 4) + 4k), k = 0..3. Nothing crosses waves, so there is no __syncthreads and
 // no LDS state besides the wave's 64-bin histogram; a block is PEAK_WAVES independent tiles.
@@ -65,47 +90,82 @@ DEV uint32_t wave_max(uint32_t v)
 // straightforward PQ EOTF -- two native pows and a Newton-refined reciprocal, 14 instructions per
 // channel -- is as good as the well-conditioned one the image path uses (35): a relative error of
 // 1e-4 in linear light is a tenth of a 14-bit PQ code.
+struct peak_pq_consts {
+    float inv_m2, c1, c2, c3, inv_m1, gain, out_scale, out_add;
+    int flags;
+};
+
+DEV peak_pq_consts peak_load_pq(const plh_op &op)
+{
+    // f[2] = 1/m2, f[3..5] = c1 c2 c3, f[6] = 1/m1, f[7] = 10000/203 (as lin1, transfer.hiph)
+    const float *f = op.f;
+    return { f[2], f[3], f[4], f[5], f[6], f[7], f[0], f[1], op.i1 };
+}
+
+DEV void peak_linearize_pq(float4_t &c, const peak_pq_consts &k)
+{
+    float v[3] = { c.x, c.y, c.z };
+#pragma unroll
+    for (int i = 0; i < 3; i++) {
+        if (k.flags & PLH_TRC_CLAMP0)
+            v[i] = fmaxf(v[i], 0.0f);
+        const float p = plh_powf(v[i], k.inv_m2);
+        const float r = div1(fmaxf(p - k.c1, 0.0f), __builtin_fmaf(-k.c3, p, k.c2));
+        v[i] = plh_powf(r, k.inv_m1) * k.gain;
+        if (k.flags & PLH_TRC_RESCALE)
+            v[i] = k.out_scale * v[i] + k.out_add;
+    }
+    c.x = v[0]; c.y = v[1]; c.z = v[2];
+}
+
 DEV void peak_linearize(float4_t &c, const plh_op &op)
 {
     if (op.i0 != TRC_PQ) {
         op_linearize(c, op);
         return;
     }
-    // f[2] = 1/m2, f[3..5] = c1 c2 c3, f[6] = 1/m1, f[7] = 10000/203 (as lin1, transfer.hiph)
-    const float *f = op.f;
-    float v[3] = { c.x, c.y, c.z };
-#pragma unroll
-    for (int k = 0; k < 3; k++) {
-        if (op.i1 & PLH_TRC_CLAMP0)
-            v[k] = fmaxf(v[k], 0.0f);
-        const float p = plh_powf(v[k], f[2]);
-        const float r = div1(fmaxf(p - f[3], 0.0f), __builtin_fmaf(-f[5], p, f[4]));
-        v[k] = plh_powf(r, f[6]) * f[7];
-        if (op.i1 & PLH_TRC_RESCALE)
-            v[k] = f[0] * v[k] + f[1];
-    }
-    c.x = v[0]; c.y = v[1]; c.z = v[2];
+    peak_linearize_pq(c, peak_load_pq(op));
 }
 
-DEV uint32_t peak_pq14(const float4_t &c_in, const plh_op &op)
+// the constants of the detect stage (the block behind op.ptr2), read once per kernel
+struct peak_consts {
+    float luma[3], white, m1, c1, c2, c3, m2, cutoff;
+};
+
+DEV peak_consts peak_load_consts(const plh_op &op)
 {
     const float *e = (const float *) op.ptr2;
-    float4_t c = c_in;
-    if (op.i0 != TRC_LINEAR)
-        peak_linearize(c, op);
+    return { { e[0], e[1], e[2] }, e[3], e[4], e[5], e[6], e[7], e[8], e[9] };
+}
 
-    float luma = e[0] * c.x + e[1] * c.y + e[2] * c.z;
-    luma *= e[3];
-    luma = plh_powf(plh_clamp(luma, 0.0f, 1.0f), e[4]);
-    luma = div1(e[5] + e[6] * luma, 1.0f + e[7] * luma);
-    luma = plh_powf(luma, e[8]);
-    const float cutoff = e[9];
+// luma of a linear colour -> 14 bits of PQ
+DEV uint32_t peak_luma_pq14(const float4_t &c, const peak_consts &e)
+{
+    float luma = e.luma[0] * c.x + e.luma[1] * c.y + e.luma[2] * c.z;
+    luma *= e.white;
+    luma = plh_powf(plh_clamp(luma, 0.0f, 1.0f), e.m1);
+    luma = div1(e.c1 + e.c2 * luma, 1.0f + e.c3 * luma);
+    luma = plh_powf(luma, e.m2);
+    const float cutoff = e.cutoff;
     if (cutoff != 0.0f) {
         // luma *= smoothstep(0, cutoff, luma)
         const float t = plh_clamp(div1(luma, cutoff), 0.0f, 1.0f);
         luma *= t * t * (3.0f - 2.0f * t);
     }
     return (uint32_t) (16383.0f * luma);
+}
+
+DEV uint32_t peak_pq14(const float4_t &c_in, const plh_op &op, const peak_consts &e)
+{
+    float4_t c = c_in;
+    if (op.i0 != TRC_LINEAR)
+        peak_linearize(c, op);
+    return peak_luma_pq14(c, e);
+}
+
+DEV uint32_t peak_pq14(const float4_t &c_in, const plh_op &op)
+{
+    return peak_pq14(c_in, op, peak_load_consts(op));
 }
 
 DEV void wave_lds_fence()
@@ -397,6 +457,248 @@ void k_peak_fast(const plh_pass p_)
     peak_measure(c, o_pk, hists[wave], wg_idx, p.peak_scratch);
 }
 
+/*
+ * k_peak_tiles: k_peak_fast with the measurement kept on chip. One wave per 16x16 tile and five
+ * global atomics per tile meant 64 scratch copies of the buffer (all tiles of a frame would
+ * otherwise queue on the two cache lines that hold its 48 scalar words) and a second kernel to
+ * add them up. The slice of a tile is `index % 12`: here every workgroup belongs to ONE slice and
+ * its four waves walk that slice's tiles (index = 12 j + slice), so that
+ *   - count / lit count / sum of means / maximum live in registers for the whole walk and the
+ *     histogram in one 64-word LDS array per workgroup (black pixels taken out of bin 0 once, at
+ *     the end: the sums are integer, their order is free);
+ *   - the next tile's texels are in flight while the current one is measured;
+ *   - a workgroup leaves 4 + (bins it touched) global atomics behind, into a layout in which the
+ *     scalar words of a slice have a 128-byte line each (85 workgroups per line and frame);
+ *   - the workgroup that finishes last gathers the 816 words into the result buffer and the
+ *     host's mailbox, zeroes the scratch words and publishes the ticket: no second kernel.
+ * Same per-pixel code, same tiles, same integer sums as k_peak_fast / k_pass_peak: the 816 words
+ * are identical (tests/test_gpu_peak.py).
+ */
+#define PEAK_PAD 32     // words between the scalar accumulators of the scratch layout (one line each)
+#define PEAK_TICKETS 4096    // word offset of the 12 + 1 ticket counters (a line each), behind the 2304 data words
+DEV uint32_t *peak_pad_word(uint32_t *scratch, uint32_t i)
+{
+    // word i of struct peak_buf in the padded scratch layout: the 48 scalars first, then the
+    // histograms (a slice's 64 bins = two lines of their own)
+    return i < 4 * PEAK_SLICES ? scratch + i * PEAK_PAD : scratch + 4 * PEAK_SLICES * PEAK_PAD + (i - 4 * PEAK_SLICES);
+}
+
+// PQ: the measured copy is linearised from PQ (HDR10 sources); else it is linear already (the
+// measurement of a scaler's linear intermediate). STORE: 0 = no target, 1 = the rgba16hf
+// intermediate. Every uniform of the walk is read ONCE in front of it and pinned in SGPRs: inside
+// the loop a kernel-argument field is re-loaded at each use, every load behind a full scalar wait
+// (the first version of this kernel: 174 of them per tile, 108 us for 1080p instead of 13).
+template <bool F16SRC, int STORE, bool PQ>
+__global__ __launch_bounds__(64 * PEAK_WAVES)
+void k_peak_tiles(const plh_pass p_)
+{
+    const plh_pass &p = plh_kernarg_pass();
+    const plh_sampler_args &s = p.s;
+    __shared__ uint32_t blk[4 + PEAK_HIST_BINS];    // count, lit count, sum, max, histogram
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    int w = p.width, h = p.height;
+    const int tiles_x = (w + PEAK_BW - 1) / PEAK_BW;
+    const int tiles_y = (h + PEAK_BH - 1) / PEAK_BH;
+    const uint32_t ntiles = (uint32_t) (tiles_x * tiles_y);
+    const uint32_t slice = blockIdx.x % PEAK_SLICES, bs = blockIdx.x / PEAK_SLICES;
+    const uint32_t stride = (gridDim.x / PEAK_SLICES) * PEAK_WAVES;
+    const uint32_t per_slice = (ntiles + PEAK_SLICES - 1 - slice) / PEAK_SLICES;    // tiles 12 j + slice < ntiles
+    const bool has_map = p.num_ops == 2;    // [identity PLANE_MAP] PEAK_DETECT
+    const plh_op &o_map = p.ops[0], &o_pk = p.ops[p.num_ops - 1];
+    // (the detect stage's block is read through a global pointer: vector loads of one address)
+    auto uni = [](float v) { return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v))); };
+    const peak_consts pcv = peak_load_consts(o_pk);
+    peak_consts pc = { { uni(pcv.luma[0]), uni(pcv.luma[1]), uni(pcv.luma[2]) }, uni(pcv.white), uni(pcv.m1),
+                       uni(pcv.c1), uni(pcv.c2), uni(pcv.c3), uni(pcv.m2), uni(pcv.cutoff) };
+    peak_pq_consts pq = peak_load_pq(o_pk);
+    int use_hist = o_pk.i2;
+    const float rtx = 1.0f / (float) tiles_x;     // (uniform, in a vector register)
+    uintptr_t sp = (uintptr_t) s.src.ptr, dp = (uintptr_t) p.dst.ptr;
+    int spitch = s.src.pitch, dpitch = p.dst.pitch;
+    int map_n = 4;
+    float nt1 = 0.0f, nt2 = 0.0f, nt3 = 1.0f;
+    if (has_map) {
+        map_n = o_map.i1;
+        nt1 = o_map.f[1]; nt2 = o_map.f[2]; nt3 = o_map.f[3];
+    }
+    asm volatile("" : "+s"(w), "+s"(h), "+s"(use_hist), "+s"(sp), "+s"(dp), "+s"(spitch),
+                      "+s"(dpitch), "+s"(map_n), "+s"(nt1), "+s"(nt2), "+s"(nt3));
+    asm volatile("" : "+s"(pc.luma[0]), "+s"(pc.luma[1]), "+s"(pc.luma[2]), "+s"(pc.white), "+s"(pc.m1),
+                      "+s"(pc.c1), "+s"(pc.c2), "+s"(pc.c3), "+s"(pc.m2), "+s"(pc.cutoff));
+    asm volatile("" : "+s"(pq.inv_m2), "+s"(pq.c1), "+s"(pq.c2), "+s"(pq.c3), "+s"(pq.inv_m1), "+s"(pq.gain),
+                      "+s"(pq.out_scale), "+s"(pq.out_add), "+s"(pq.flags));
+    typedef __attribute__((address_space(1))) const plh_u32x4 g_u32x4;
+    typedef __attribute__((address_space(1))) plh_u32x4 g_u32x4_w;
+    typedef __attribute__((address_space(1))) plh_u32x2 g_u32x2_w;
+
+    if (threadIdx.x < 4 + PEAK_HIST_BINS)
+        blk[threadIdx.x] = 0u;
+    __syncthreads();
+
+    // tile j of the slice: origin of the lane's pixels (x0, y0), (x0 + 1, y0), and the same on row
+    // y0 + 8; lanes beyond the image measure the clamped edge texel, as the padding invocations
+    // of the reference's workgroups do
+    auto origin = [&](uint32_t j, int &x0, int &y0) {
+        const uint32_t t = PEAK_SLICES * j + slice;
+        const int ty = (int) (((float) t + 0.5f) * rtx);    // exact: t < 2^22
+        const int tx = (int) t - ty * tiles_x;
+        x0 = tx * PEAK_BW + 2 * (lane & 7);
+        y0 = ty * PEAK_BH + (lane >> 3);
+    };
+    uint32_t n_wg = 0, n_lit = 0, sum_pq = 0, lane_max = 0, black = 0;     // (all but lane_max uniform)
+    // One row of the lane's two at a time, in a rolled loop: the kernel is held to 32 registers so
+    // that one of its waves fits on a SIMD BESIDE the four 120-register waves of the metric's
+    // scaler (k_polar_mx<3, true, 3, 8>) -- the measuring pass of the next frame then runs inside
+    // the scaler's launch instead of between two of them.
+    for (uint32_t j = bs * PEAK_WAVES + (uint32_t) wave; j < per_slice; j += stride) {
+        int x0, y0;
+        origin(j, x0, y0);
+        const int px = min(x0, w - 2);
+        uint32_t lane_sum = 0, nblack = 0;
+#pragma unroll 1
+        for (int k = 0; k < 2; k++) {
+            const int y = y0 + 8 * k;
+            plh_u32x4 v = *(g_u32x4 *) (sp + (size_t) min(y, h - 1) * (size_t) spitch + (size_t) px * 8);
+            if (x0 + 1 >= w) {      // both texels are the row's last one
+                v.x = v.z; v.y = v.w;
+            }
+            const uint32_t q[4] = { v.x, v.y, v.z, v.w };
+            float4_t c[2];
+#pragma unroll
+            for (int i = 0; i < 2; i++) {
+                const uint32_t lo = q[2 * i], hi = q[2 * i + 1];
+                float4_t t;
+                if (F16SRC)
+                    t = { plh_h2f(lo & 0xffff), plh_h2f(lo >> 16), plh_h2f(hi & 0xffff), plh_h2f(hi >> 16) };
+                else
+                    t = { plh_un16(lo & 0xffff), plh_un16(lo >> 16), plh_un16(hi & 0xffff), plh_un16(hi >> 16) };
+                // identity PLANE_MAP of the first i1 components: the others take their neutral values
+                if (map_n < 4) t.w = nt3;
+                if (map_n < 3) t.z = nt2;
+                if (map_n < 2) t.y = nt1;
+                c[i] = t;
+            }
+            // (the intermediate goes out first: its stores are in flight while the measurement computes)
+            if constexpr (STORE == 1) {
+                uint32_t o[4];
+#pragma unroll
+                for (int i = 0; i < 2; i++) {
+                    o[2 * i] = (uint32_t) plh_f2h(c[i].x) | ((uint32_t) plh_f2h(c[i].y) << 16);
+                    o[2 * i + 1] = (uint32_t) plh_f2h(c[i].z) | ((uint32_t) plh_f2h(c[i].w) << 16);
+                }
+                const uintptr_t d = dp + (size_t) y * (size_t) dpitch + (size_t) x0 * 8;
+                if (y < h && x0 + 1 < w)
+                    *(g_u32x4_w *) d = (plh_u32x4) { o[0], o[1], o[2], o[3] };
+                else if (y < h && x0 < w)
+                    *(g_u32x2_w *) d = (plh_u32x2) { o[0], o[1] };
+            }
+            // the measurement (colorspace.c:1279-1348)
+#pragma unroll
+            for (int i = 0; i < 2; i++) {
+                if (PQ)
+                    peak_linearize_pq(c[i], pq);
+                const uint32_t y_pq = peak_luma_pq14(c[i], pc);
+                if (use_hist) {
+                    int bin = (int) y_pq >> (PQ_BITS - HIST_BITS);
+                    bin -= HIST_BIAS;
+                    bin = min(max(bin, 0), PEAK_HIST_BINS - 1);
+                    const int first = __builtin_amdgcn_readfirstlane(bin);
+                    if (__all(bin == first)) {
+                        if (lane == 0)
+                            atomicAdd(&blk[4 + bin], 64u);
+                    } else {
+                        atomicAdd(&blk[4 + bin], 1u);
+                    }
+                }
+                lane_sum += y_pq;
+                lane_max = max(lane_max, y_pq);
+                if (pc.cutoff != 0.0f)
+                    nblack += (uint32_t) __popcll(__ballot(y_pq == 0u));
+            }
+        }
+        const uint32_t wg_sum = wave_sum_dpp(lane_sum);
+        const uint32_t num = PEAK_BW * PEAK_BH - nblack;
+        n_wg += 1u;
+        n_lit += min(num, 1u);
+        if (nblack == 0u)
+            sum_pq += wg_sum / (PEAK_BW * PEAK_BH);
+        else if (num > 0u)
+            sum_pq += wg_sum / num;
+        black += nblack;
+    }
+
+    // the wave's totals into the workgroup's, the workgroup's into the frame's
+    const uint32_t wmax = wave_max_dpp(lane_max);   // (an all-black tile's maximum is 0: no effect)
+    if (lane == 0 && n_wg) {
+        atomicAdd(&blk[0], n_wg);
+        atomicAdd(&blk[1], n_lit);
+        atomicAdd(&blk[2], sum_pq);
+        atomicMax(&blk[3], wmax);
+        if (use_hist && black)
+            atomicSub(&blk[4], black);
+    }
+    __syncthreads();
+    if (wave != 0)
+        return;     // (their registers are free for the next workgroup; wave 0 carries the result out)
+    // No agent-scope fence anywhere below: on this chip that is a write-back of the XCD's whole L2
+    // (buffer_wbl2), and with one per workgroup the kernel took 103 us instead of 13. What the
+    // last workgroup reads are only words that were written by device-scope atomics, and it reads
+    // them with atomics as well (exchange with zero: the read and the clean-up in one): every
+    // access to those words is performed at the point where the XCDs' atomics meet. A workgroup
+    // takes its ticket after its own atomics have RETURNED (their results are consumed here).
+    uint32_t *scratch = (uint32_t *) p.peak_scratch;
+    if (wave == 0) {
+        uint32_t seen = 0;
+        if (lane < 4) {
+            const uint32_t v = blk[lane];
+            uint32_t *d = peak_pad_word(scratch, (uint32_t) lane * PEAK_SLICES + slice);
+            if (lane == 3)
+                seen += atomicMax(d, v);
+            else if (v)
+                seen += atomicAdd(d, v);
+        }
+        const uint32_t n = blk[4 + lane];
+        if (use_hist && n)
+            seen += atomicAdd(peak_pad_word(scratch, 4 * PEAK_SLICES + slice * PEAK_HIST_BINS + (uint32_t) lane), n);
+        asm volatile("" :: "v"(seen));
+    }
+    // tickets in two levels -- per slice, then one for the slices -- so that no word sees more than
+    // gridDim.x / 12 of these returning atomics (2040 on one word were 9 us of the kernel)
+    uint32_t *tickets = scratch + PEAK_TICKETS;
+    const uint32_t groups = gridDim.x / PEAK_SLICES;
+    uint32_t ticket = 0;
+    if (lane == 0) {
+        ticket = atomicAdd(tickets + slice * PEAK_PAD, 1u);
+        if (ticket == groups - 1) {
+            atomicExch(tickets + slice * PEAK_PAD, 0u);
+            ticket = atomicAdd(tickets + PEAK_SLICES * PEAK_PAD, 1u) + groups;     // (last of all: groups + 11)
+        }
+    }
+    if ((uint32_t) __builtin_amdgcn_readfirstlane((int) ticket) != groups + PEAK_SLICES - 1)
+        return;
+    uint32_t *counter = tickets + PEAK_SLICES * PEAK_PAD;
+    uint32_t *dst = (uint32_t *) p.peak_buf, *mailbox = (uint32_t *) p.peak_mailbox;
+    for (uint32_t i = lane; i < PLH_PEAK_WORDS; i += 64) {
+        const uint32_t v = atomicExch(peak_pad_word(scratch, i), 0u);
+        dst[i] = v;         // the whole buffer is rewritten: the host never has to clear it
+        if (mailbox)
+            __hip_atomic_store(&mailbox[i], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+    if (lane == 0)
+        atomicExch(counter, 0u);
+    if (!mailbox)
+        return;
+    // The mailbox words were written through to host memory (system-scope stores); when this
+    // wave's count of outstanding memory operations is back to zero they have arrived, and the
+    // ticket may follow. (A system-scope release would write the XCD's L2 back first -- megabytes
+    // of the intermediate's dirty lines that the host does not read.)
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_s_waitcnt(0);      // vmcnt(0) expcnt(0) lgkmcnt(0)
+    if (lane == 0)
+        __hip_atomic_store(&mailbox[PLH_PEAK_WORDS], p.peak_ticket, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
 // the shape k_peak_fast is written for
 static bool peak_fast_applies(const plh_pass *pass)
 {
@@ -501,6 +803,31 @@ int plh_launch_peak(hipStream_t stream, const plh_pass *pass)
             pk_op = i;
             break;
         }
+    }
+    const char *v2 = getenv("PL_HIP_PEAK_TILES");
+    const int trc = pk_op < pass->num_ops ? pass->ops[pk_op].i0 : -1;
+    const bool feat_target = pass->dst.ptr && pass->dst.fmt == PLH_FMT_R16F;
+    if (peak_fast_applies(pass) && !(v2 && v2[0] == '0') && !feat_target && pass->width >= 2 &&
+        (trc == TRC_PQ || trc == TRC_LINEAR)) {
+        // k_peak_tiles folds its own result (no k_peak_fold behind it)
+        const bool f16 = pass->s.src.fmt == PLH_FMT_RGBA16F, store = pass->dst.ptr != NULL, pq = trc == TRC_PQ;
+        const int per_slice = (tiles + PEAK_SLICES - 1) / PEAK_SLICES;
+        // (two tiles per wave, at most 8 workgroups per CU. Measured beside the metric's scaler and
+        // alone, 1080p and 4K, profiles/r05_06_peak_groups.txt: fewer, longer-lived workgroups suit
+        // the former, more the latter; this is the setting that loses neither)
+        const char *genv = getenv("PL_HIP_PEAK_GROUPS");
+        const int gmax = genv ? atoi(genv) : 170;
+        int groups = (per_slice + 2 * PEAK_WAVES - 1) / (2 * PEAK_WAVES);
+        groups = groups < 1 ? 1 : groups > gmax ? gmax : groups;
+        const dim3 tgrid(PEAK_SLICES * groups);
+#define PEAK_TILES_GO(F, S, Q) hipLaunchKernelGGL((k_peak_tiles<F, S, Q>), tgrid, block, 0, stream, *pass)
+        if (f16 && store)   { if (pq) PEAK_TILES_GO(true, 1, true); else PEAK_TILES_GO(true, 1, false); }
+        else if (f16)       { if (pq) PEAK_TILES_GO(true, 0, true); else PEAK_TILES_GO(true, 0, false); }
+        else if (store)     { if (pq) PEAK_TILES_GO(false, 1, true); else PEAK_TILES_GO(false, 1, false); }
+        else                { if (pq) PEAK_TILES_GO(false, 0, true); else PEAK_TILES_GO(false, 0, false); }
+#undef PEAK_TILES_GO
+        const hipError_t terr = hipGetLastError();
+        return terr == hipSuccess ? 0 : -(int) terr;
     }
     if (peak_fast_applies(pass)) {
         const bool f16 = pass->s.src.fmt == PLH_FMT_RGBA16F, store = pass->dst.ptr != NULL;

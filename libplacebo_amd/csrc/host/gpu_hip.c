@@ -270,6 +270,7 @@ plh_stream plh_gpu_stream_n(pl_gpu gpu, int on)
     struct gpu_priv *p = GPU_PRIV(gpu);
     if (!on || !p->async_measure)
         return p->stream;
+    // (a greatest- or least-priority measuring stream changes nothing: profiles/r05_04_peak_prio.txt)
     if (!p->aux && plh_stream_create(p->device, &p->aux)) {
         pl_msg(gpu->log, PL_LOG_WARN, "pl_hip: no second stream: async_measure disabled");
         p->async_measure = false;

@@ -373,14 +373,18 @@ def test_nearest_fast_equals_generic(gpu, ten_bit, src_fmt):
         assert a[..., :3].std() > 1000
 
 
-@pytest.mark.parametrize("size", [(70, 45), (128, 64), (1920, 1080)])
+@pytest.mark.parametrize("size", [(16, 16), (70, 45), (128, 64), (1920, 1080), (3840, 2160)])
 @pytest.mark.parametrize("src_fmt,trc", [("rgba16", "pq"), ("rgba16hf", "linear")])
 @pytest.mark.parametrize("store", [True, False])
 def test_peak_fast_equals_generic(gpu, size, src_fmt, trc, store):
-    """k_peak_fast (the renderer's measuring pass: plane texel for texel -> f16 intermediate +
-    measurement, or the target-less measurement of an FBO) against k_pass_peak: the 816-word
-    buffer word for word and the intermediate bit for bit, for sizes that are not multiples of
-    the 16 x 16 tiling (padding invocations measure the clamped edge texel)."""
+    """The renderer's measuring pass (plane texel for texel -> f16 intermediate + measurement, or
+    the target-less measurement of an FBO) on its three kernels -- k_peak_tiles (the default: the
+    measurement kept on chip, slice by slice, folded by the last workgroup), k_peak_fast
+    (PL_HIP_PEAK_TILES=0: one wave per tile, scratch copies, k_peak_fold) and k_pass_peak
+    (PL_HIP_PEAK_FAST=0: the interpreter): the 816-word buffer word for word and the intermediate
+    bit for bit, for sizes that are not multiples of the 16 x 16 tiling (padding invocations
+    measure the clamped edge texel). Every kernel measures twice through the same state object:
+    the second result must equal the first (the scratch words are left zeroed)."""
     from test_gpu_color import _read_device
     from test_gpu_fullsize import hdr_frame16, inferred
     w, h = size
@@ -389,37 +393,47 @@ def test_peak_fast_equals_generic(gpu, size, src_fmt, trc, store):
         img = (img.astype(np.float32) / 65535.0 * 4.0).astype(np.float16)
     csp, _ = inferred(pl.color_space("bt2020", trc, max_luma=1000.0), pl.color_space("bt709", "bt1886"))
     res = []
-    for fast in ("1", "0"):
-        old = os.environ.get("PL_HIP_PEAK_FAST")
-        os.environ["PL_HIP_PEAK_FAST"] = fast
+    modes = [{}, {"PL_HIP_PEAK_TILES": "0"}, {"PL_HIP_PEAK_FAST": "0"}]
+    for env in modes:
+        old = {k: os.environ.get(k) for k in ("PL_HIP_PEAK_FAST", "PL_HIP_PEAK_TILES")}
+        for k in old:
+            os.environ.pop(k, None)
+        os.environ.update(env)
         try:
             src = gpu.tex_create(w, h, src_fmt, img)
             fbo = gpu.tex_create(w, h, "rgba16hf")
             state = pl.ShaderObj()
-            a = gpu.begin()
-            assert a.sample("direct", src, components=3)
-            pp = pl.peak_detect_params(percentile=99.995)
-            assert pl.lib().pl_shader_detect_peak(a.sh, csp, C.byref(state.slot), C.byref(pp))
-            if store:
-                assert a.finish(fbo), gpu.messages[-3:]
-            else:
-                assert a.compute(w, h), gpu.messages[-3:]
-            size_ = C.c_size_t()
-            pl.lib().pl_hip_peak_buffer.restype = C.c_void_p
-            ptr = pl.lib().pl_hip_peak_buffer(state.slot, C.byref(size_))
-            assert ptr and size_.value == 816 * 4
-            res.append((_read_device(ptr, size_.value).copy(), fbo.download().view(np.uint16).copy()))
+            bufs = []
+            for rep in range(2):
+                a = gpu.begin()
+                assert a.sample("direct", src, components=3)
+                pp = pl.peak_detect_params(percentile=99.995)
+                assert pl.lib().pl_shader_detect_peak(a.sh, csp, C.byref(state.slot), C.byref(pp))
+                if store:
+                    assert a.finish(fbo), gpu.messages[-3:]
+                else:
+                    assert a.compute(w, h), gpu.messages[-3:]
+                size_ = C.c_size_t()
+                pl.lib().pl_hip_peak_buffer.restype = C.c_void_p
+                ptr = pl.lib().pl_hip_peak_buffer(state.slot, C.byref(size_))
+                assert ptr and size_.value == 816 * 4
+                bufs.append(_read_device(ptr, size_.value).copy())
+            assert np.array_equal(bufs[0], bufs[1]), env
+            res.append((bufs[0], fbo.download().view(np.uint16).copy()))
             state.destroy(); fbo.destroy(); src.destroy()
         finally:
-            if old is None:
-                os.environ.pop("PL_HIP_PEAK_FAST", None)
-            else:
-                os.environ["PL_HIP_PEAK_FAST"] = old
-    (buf_f, fbo_f), (buf_g, fbo_g) = res
+            for k, v in old.items():
+                if v is None:
+                    os.environ.pop(k, None)
+                else:
+                    os.environ[k] = v
+    (buf_t, fbo_t), (buf_f, fbo_f), (buf_g, fbo_g) = res
     assert buf_g[0:12].sum() == (-(-w // 16)) * (-(-h // 16)) and buf_g[24:36].sum() > 0
     assert np.array_equal(buf_f, buf_g)
+    assert np.array_equal(buf_t, buf_g), np.nonzero(buf_t != buf_g)
     if store:
         assert np.array_equal(fbo_f, fbo_g) and fbo_g.any()
+        assert np.array_equal(fbo_t, fbo_g)
 
 
 @pytest.mark.parametrize("size", [(97, 61), (256, 130)])
