@@ -133,7 +133,10 @@ void k_deband(const plh_pass p_)
  * (S / 262140, one rounding) where the general kernel decodes each tap (v / 65535) and adds the
  * floats (four roundings) -- 21 instead of 57 instructions per pixel, an average that is closer to
  * the exact one, and an rgba16hf result that differs from the general kernel's by one f16 ulp on
- * a fraction of a percent of the samples (tests/test_gpu_ortho_deband.py renders with both). What
+ * a fraction of a percent of the samples (tests/test_gpu_ortho_deband.py renders with both; a
+ * sample whose |res - avg| is within that ulp of the threshold may keep its value here and take
+ * the average there -- the general kernel keeps the reference's four-float sum because it is the
+ * one held to the oracle bit for bit on fp32 targets). What
  * else goes is what the general kernel pays for being general: the op interpreter, format and
  * address-mode switches, 64-bit address arithmetic (the taps: one 24-bit multiply-add against a
  * uniform base), the alpha channel of the four taps and of a plane that has none, the IEEE

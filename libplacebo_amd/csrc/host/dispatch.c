@@ -269,6 +269,18 @@ int plh_pass_execute(pl_gpu gpu, pl_log log, const struct plh_pass_exec *x, pl_t
     pass->dir_y = rc.y0 > rc.y1 ? -1 : 1;
     pass->transpose = x->transpose;
     pass->frag_x0 = pass->frag_y0 = 0; // compute passes: rect-relative gl_FragCoord
+    // ... except for the tile pattern under a transparent image, which must continue the border's
+    // (pl_frame_clear_tiles: absolute plane coordinates; the reference's output pass is a raster
+    // pass whose gl_FragCoord is the target pixel, src/renderer.c:2745)
+    for (int i = 0; i < pass->num_ops; i++) {
+        struct plh_op *op = &pass->ops[i];
+        if (op->kind != PLH_OP_BLEND_TILES)
+            continue;
+        op->f[9] = pass->dir_x;
+        op->f[10] = pass->base_x + 0.5f - 0.5f * pass->dir_x;
+        op->f[11] = pass->dir_y;
+        op->f[12] = pass->base_y + 0.5f - 0.5f * pass->dir_y;
+    }
 
     if (pass->s.type == PLH_SAMPLE_POLAR && x->polar_obj)
         plh_polar_pp_setup(gpu, log, x->polar_obj, pass);

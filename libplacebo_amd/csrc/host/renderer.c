@@ -905,6 +905,7 @@ static void measure_peak(struct frame_job *job)
                 if (ok) {
                     job->features_full = full;
                     job->features_src = tex;
+                    job->features_color = img->color;
                 }
             } else if (ok) {
                 ok = pl_dispatch_compute(rr->dp, pl_dispatch_compute_params(
@@ -1011,6 +1012,18 @@ bool plh_stage_scale(struct frame_job *job)
 
 /* ---- stage 3: colours ----------------------------------------------------------------------- */
 
+// What pl_shader_extract_features depends on: the primaries (RGB -> LMS) and the linearisation --
+// which reads the HDR metadata for every curve but the linear one and PQ (black / peak scaling of
+// the SDR curves, HLG's system gamma: plh_fill_linearize, colorspace.c:640-719).
+static bool features_color_same(const struct pl_color_space *a, const struct pl_color_space *b)
+{
+    if (a->primaries != b->primaries || a->transfer != b->transfer)
+        return false;
+    if (a->transfer == PL_COLOR_TRC_LINEAR || a->transfer == PL_COLOR_TRC_PQ)
+        return true;
+    return pl_hdr_metadata_equal(&a->hdr, &b->hdr);
+}
+
 // Low-resolution luminance of the image for the tone mapper's contrast recovery: I of IPT at
 // full size, then low-passed (bicubic, mirrored edges) to 1/smoothness of the output size.
 static pl_tex make_feature_map(struct frame_job *job)
@@ -1029,7 +1042,11 @@ static pl_tex make_feature_map(struct frame_job *job)
     // can, measure_peak)
     // -- valid only while the image is still that texture: anything recorded on it since (cone
     // distortion, an alpha conversion) made plh_work_texture above produce another one
-    const bool have = job->features_full && job->features_src == img->tex;
+    // ... and while it is still described by the colour space the features were extracted with:
+    // the reference extracts them after hdr_update_peak (renderer.c:2089-2154 behind :1964-2087),
+    // and the linearisation of an HLG / BT.1886 image depends on the metadata detected there
+    const bool have = job->features_full && job->features_src == img->tex &&
+                      features_color_same(&job->features_color, &img->color);
     pl_tex full = have ? job->features_full : borrow_fbo(job, img->w, img->h, NULL, 1);
     pl_tex small = borrow_fbo(job, mw, mh, NULL, 1);
     bool ok = full && small;

@@ -96,6 +96,8 @@ struct frame_job {
     pl_tex features_full;       // full-size feature plane written by the measuring pass (renderer.c:
                                 // measure_peak), for make_feature_map to start from
     pl_tex features_src;        // ... and the image (resident texture) it was extracted from
+    struct pl_color_space features_color;   // ... as this colour space (the detected HDR metadata that
+                                // arrives afterwards may change how a non-linear image is linearised)
     bool image_acquired, target_acquired;
     bool target_borrowed;       // the target belongs to an enclosing job: neither acquire nor release
     struct pl_render_info info;

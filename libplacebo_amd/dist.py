@@ -121,18 +121,15 @@ class RcclPeakExchange:
 
 
 # ---- the same exchange over a host-side transport (gloo, MPI, a socket ...) -----------------------
-def _hip_runtime():
-    """the HIP runtime libplacebo_hip.so itself is linked against (the system one), not a copy
-    another package in the process may have mapped"""
-    paths = []
-    with open("/proc/self/maps") as f:
-        for ln in f:
-            if "libamdhip64" in ln:
-                path = ln.split()[-1]
-                if path not in paths:
-                    paths.append(path)
-    mine = [p for p in paths if "/torch/" not in p] or paths or ["libamdhip64.so"]
-    return _C.CDLL(mine[0])
+def _hip_runtime(L):
+    """hipStreamSynchronize / hipMemcpy of the HIP runtime libplacebo_hip.so itself is linked
+    against: looked up THROUGH the library's handle (dlsym on a handle searches the object and its
+    dependency tree), never by path -- another package in the process may have mapped a second
+    runtime, whose streams are not ours."""
+    sync, cpy = L.hipStreamSynchronize, L.hipMemcpy
+    sync.argtypes, sync.restype = [_C.c_void_p], _C.c_int
+    cpy.argtypes, cpy.restype = [_C.c_void_p, _C.c_void_p, _C.c_size_t, _C.c_int], _C.c_int
+    return sync, cpy
 
 
 class HostPeakExchange:
@@ -146,20 +143,37 @@ class HostPeakExchange:
     def __init__(self, gpu, reduce):
         import numpy as np
         from . import lib
-        self.gpu, self.L, self.hip, self.calls = gpu, lib(), _hip_runtime(), 0
+        self.gpu, self.L, self.calls, self.errors, self.last_error = gpu, lib(), 0, 0, None
+        sync, cpy = _hip_runtime(self.L)
         np_ = np
 
+        # An exception raised inside a ctypes callback is printed and swallowed: every failure is
+        # caught here instead and counted (`errors`, `last_error`), and the buffer is then left as
+        # it was -- the rank goes on with its LOCAL measurement, like pl_hip_rccl_peak_exchange
+        # after a failed RCCL step. (A rank that fails BEFORE `reduce` does not enter the
+        # collective: give the process group a timeout if the other ranks must not wait forever.)
         @_C.CFUNCTYPE(None, _C.c_void_p, _C.c_void_p, _C.c_size_t, _C.c_void_p)
         def exchange(priv, words, size, stream):
-            assert size == PEAK_WORDS * 4
-            assert self.hip.hipStreamSynchronize(_C.c_void_p(stream)) == 0
-            buf = np_.zeros(PEAK_WORDS, np_.uint32)
-            assert self.hip.hipMemcpy(buf.ctypes.data_as(_C.c_void_p), _C.c_void_p(words), size, 2) == 0
-            wide = buf.astype(np_.int64)
-            reduce(wide)
-            buf[:] = wide.astype(np_.uint32)
-            assert self.hip.hipMemcpy(_C.c_void_p(words), buf.ctypes.data_as(_C.c_void_p), size, 1) == 0
-            self.calls += 1
+            try:
+                if size != PEAK_WORDS * 4:
+                    raise RuntimeError(f"peak buffer of {size} bytes")
+                rc = sync(stream)
+                if rc:
+                    raise RuntimeError(f"hipStreamSynchronize: {rc}")
+                buf = np_.zeros(PEAK_WORDS, np_.uint32)
+                rc = cpy(buf.ctypes.data, words, size, 2)      # hipMemcpyDeviceToHost
+                if rc:
+                    raise RuntimeError(f"hipMemcpy (device to host): {rc}")
+                wide = buf.astype(np_.int64)
+                reduce(wide)
+                buf[:] = wide.astype(np_.uint32)
+                rc = cpy(words, buf.ctypes.data, size, 1)      # hipMemcpyHostToDevice
+                if rc:
+                    raise RuntimeError(f"hipMemcpy (host to device): {rc}")
+                self.calls += 1
+            except BaseException as e:      # noqa: BLE001 (nothing may leave the trampoline)
+                self.errors += 1
+                self.last_error = repr(e)
 
         self._cb = exchange     # (keep the trampoline alive)
         self.L.pl_hip_set_peak_exchange.argtypes = [_C.c_void_p, _C.c_void_p, _C.c_void_p]

@@ -204,3 +204,33 @@ def test_blend_against_tiles(gpu):
     assert np.abs(got[..., :3] - want).max() < 2e-6, np.abs(got[..., :3] - want).max()
     assert np.all(got[..., 3] == 1.0)
     rr.destroy(); src.destroy(); dst.destroy()
+
+
+def test_tiles_under_a_cropped_image_continue_the_border(gpu):
+    """PL_CLEAR_TILES as border AND as background of a transparent image on a cropped target whose
+    origin is not a multiple of the tile period: one seamless pattern in absolute target
+    coordinates (the reference's output pass is a raster pass: gl_FragCoord is the target pixel,
+    src/renderer.c:2745; pl_frame_clear_tiles: :4153)."""
+    sw, sh = 40, 24
+    rng = np.random.default_rng(9)
+    img = rng.integers(0, 65536, (sh, sw, 4)).astype(np.uint16)
+    img[..., 3] = 0             # fully transparent: the frame IS the pattern
+    src = gpu.tex_create(sw, sh, "rgba16", img)
+    dst = gpu.tex_create(64, 48, "rgba16")
+    rr = pl.Renderer(gpu)
+    csp = pl.color_space("bt709", "bt1886")
+    params = pl.render_params("fast")
+    params.border = 1           # PL_CLEAR_TILES
+    params.background = 1
+    params.tile_size = 8
+    x0, y0 = 13, 7              # (neither a multiple of 8 nor of 4)
+    target = pl.frame(dst, color=csp, crop=(float(x0), float(y0), float(x0 + sw), float(y0 + sh)))
+    image = pl.frame(src, components=4, color=csp, repr_=pl.color_repr("rgb", "full", alpha="independent"))
+    assert rr.render(image, target, params), gpu.messages[-4:]
+    assert rr.errors() == 0
+    got = dst.download()
+    t = tiles_expected(64, 48, 8, 8, [0.93] * 3, [0.87] * 3)
+    want = np.rint(t.astype(np.float64) * 65535)
+    err = np.abs(got[..., :3].astype(np.float64) - want)
+    assert err.max() <= 1, (err.max(), np.argwhere(err > 1)[:4])
+    rr.destroy(); src.destroy(); dst.destroy()

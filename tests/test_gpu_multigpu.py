@@ -208,10 +208,10 @@ def _half_frame_worker(rank, world, port, w, h, out_path):
         ex = HostPeakExchange(g, gloo_reduce(dist))
         out, meta = _render_metric_like(g, part)
         ex.close()
-        calls = ex.calls
+        calls, errors = ex.calls, ex.errors
     dist.barrier()
     dist.destroy_process_group()
-    np.savez(out_path, out=out, meta=np.array(meta, np.float64), calls=calls)
+    np.savez(out_path, out=out, meta=np.array(meta, np.float64), calls=calls, errors=errors)
 
 
 def _render_metric_like(g, img):
@@ -266,10 +266,35 @@ def test_two_product_instances_render_one_frame(tmp_path):
         assert p.exitcode == 0
     halves = [np.load(p) for p in paths]
     for r, d in enumerate(halves):
-        assert int(d["calls"]) == 1
+        assert int(d["calls"]) == 1 and int(d["errors"]) == 0
         assert tuple(d["meta"]) == tuple(np.array(meta_ref, np.float64)), (r, d["meta"], meta_ref)
     got = np.concatenate([d["out"] for d in halves], axis=0)
     assert np.array_equal(got, ref), util.diff_stats(got, ref)
+
+
+def test_host_exchange_failure_keeps_the_local_measurement():
+    """HostPeakExchange whose reduction raises (a lost peer, a closed process group): nothing leaves
+    the ctypes trampoline, the failure is counted, and the frame is the one rendered from the local
+    measurement (`assert` inside the callback was printed and swallowed)."""
+    from libplacebo_amd.dist import HostPeakExchange
+    from test_gpu_fullsize import hdr_frame16
+    img = hdr_frame16(256, 128)
+    with pl.HipGpu(0) as g:
+        ref, meta_ref = _render_metric_like(g, img)
+
+        def refuses(words):
+            raise ConnectionError("peer gone")
+
+        ex = HostPeakExchange(g, refuses)
+        got, meta = _render_metric_like(g, img)
+        ex.close()
+        assert ex.errors == 1 and ex.calls == 0 and "peer gone" in ex.last_error
+        assert meta == meta_ref and np.array_equal(got, ref)
+        # and a reduction that works is counted as a call, not as an error
+        ex = HostPeakExchange(g, lambda words: None)
+        got, meta = _render_metric_like(g, img)
+        ex.close()
+        assert ex.errors == 0 and ex.calls == 1 and np.array_equal(got, ref)
 
 
 def test_rccl_exchange_failure_keeps_the_local_measurement(gpu):

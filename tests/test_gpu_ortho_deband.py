@@ -204,7 +204,12 @@ def test_deband_fast_kernel_against_the_general_one(gpu, kw, size, trc, monkeypa
     same tap positions, same comparison; the average of the four taps is the integer sum decoded
     once (one rounding, closer to the exact average) where the general kernel adds four decoded
     floats: the same f16 codes but for a fraction of a percent that land on the neighbouring code,
-    and none where no average is taken (iterations = 0). Odd widths exercise the single-pixel tail."""
+    and none where no average is taken (iterations = 0). Odd widths exercise the single-pixel tail.
+    (The general kernel keeps the reference's four-float sum: it is the one held to the oracle bit
+    for bit on fp32 targets, test_deband_vs_oracle -- with integer sums 23 % of its fp32 samples
+    differ from the oracle by an ulp, measured in round 5. A sample whose |res - avg| sits within
+    that ulp of the threshold may therefore keep its value in one kernel and take the average in the
+    other: a threshold-sized difference, allowed for below on at most 1e-4 of the samples.)"""
     w, h = size
     img = util.random_rgba16(w, h, seed=17)
     t = gpu.tex_create(w, h, "rgba16", img)
@@ -230,7 +235,7 @@ def test_deband_fast_kernel_against_the_general_one(gpu, kw, size, trc, monkeypa
         assert np.array_equal(outs[0], outs[1]), util.diff_stats(outs[0], outs[1])
     else:
         ulps = np.abs(outs[0].astype(np.int64) - outs[1].astype(np.int64))
-        assert ulps.max() <= 1 and (ulps > 0).mean() < 5e-3, (ulps.max(), (ulps > 0).mean())
+        assert (ulps > 1).mean() <= 1e-4 and (ulps > 0).mean() < 5e-3, (ulps.max(), (ulps > 0).mean())
     t.destroy()
 
 
