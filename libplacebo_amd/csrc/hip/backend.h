@@ -58,6 +58,11 @@ typedef void *plh_event;
 int plh_event_create(plh_event *out);
 void plh_event_destroy(plh_event e);
 int plh_event_record(plh_event e, plh_stream s);
+// An event for the END of the pass launched next on this thread: carried by the launch of the
+// pass's last kernel as its stop event where the launcher supports it (devmath.hiph:
+// PLH_LAUNCH_LAST). plh_launch_stop_taken() after the launch: 1 = it was, 0 = record it yourself.
+void plh_launch_offer_stop(plh_event e);
+int plh_launch_stop_taken(void);
 int plh_stream_wait_event(plh_stream s, plh_event e);
 // 1 = ready, 0 = not yet, <0 error
 int plh_event_query(plh_event e);

@@ -223,6 +223,35 @@ void plh_event_destroy(plh_event e)
         (void) hipEventDestroy((hipEvent_t) e);
 }
 
+// ---- an event offered for the end of the next pass (devmath.hiph: PLH_LAUNCH_LAST) ---------------
+static thread_local hipEvent_t g_stop_offer = nullptr;
+static thread_local bool g_stop_taken = false;
+
+void plh_launch_offer_stop(plh_event e)
+{
+    g_stop_offer = (hipEvent_t) e;
+    g_stop_taken = false;
+}
+
+// 1 = the pass's last kernel carried the event; either way the offer is withdrawn
+int plh_launch_stop_taken(void)
+{
+    const bool taken = g_stop_taken;
+    g_stop_offer = nullptr;
+    g_stop_taken = false;
+    return taken;
+}
+
+hipEvent_t plh_take_stop_event(void)
+{
+    hipEvent_t e = g_stop_offer;
+    if (e) {
+        g_stop_offer = nullptr;
+        g_stop_taken = true;
+    }
+    return e;
+}
+
 int plh_event_record(plh_event e, plh_stream s)
 {
     CHK(hipEventRecord((hipEvent_t) e, (hipStream_t) s));

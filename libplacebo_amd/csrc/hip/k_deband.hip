@@ -567,7 +567,7 @@ int plh_launch_deband(hipStream_t stream, const plh_pass *pass)
                     return e; \
                 const int tiles_y = (pass->height + TH - 1) / TH; \
                 const dim3 grid(8 * ((tiles_x + 7) / 8) * tiles_y); \
-                hipLaunchKernelGGL(k_deband_lds<TH>, grid, dim3(DBL_NT), shmem, stream, *pass); \
+                PLH_LAUNCH_LAST(k_deband_lds<TH>, grid, dim3(DBL_NT), shmem, stream, *pass); \
             } while (0)
             // fewer than two rounds of 32-row tiles (three workgroups per CU): 16-row tiles
             if (tiles_x * ((pass->height + 31) / 32) < 2 * 3 * cus)
@@ -581,7 +581,7 @@ int plh_launch_deband(hipStream_t stream, const plh_pass *pass)
         const int nbx = (pass->width + 2 * DBF_BW - 1) / (2 * DBF_BW);
         const int nby = (pass->height + DBF_BH - 1) / DBF_BH;
         const dim3 grid(nbx, nby);
-        hipLaunchKernelGGL(k_deband_fast, grid, dim3(DBF_BW, DBF_BH), 0, stream, *pass);
+        PLH_LAUNCH_LAST(k_deband_fast, grid, dim3(DBF_BW, DBF_BH), 0, stream, *pass);
         const hipError_t err = hipGetLastError();
         return err == hipSuccess ? 0 : -(int) err;
     }
@@ -589,9 +589,9 @@ int plh_launch_deband(hipStream_t stream, const plh_pass *pass)
     const dim3 grid((pass->width + DEBAND_BW - 1) / DEBAND_BW,
                     (pass->height + DEBAND_BH - 1) / DEBAND_BH);
     if (plh_ops_lite(pass, 0, pass->num_ops))
-        hipLaunchKernelGGL(k_deband<true>, grid, block, 0, stream, *pass);
+        PLH_LAUNCH_LAST(k_deband<true>, grid, block, 0, stream, *pass);
     else
-        hipLaunchKernelGGL(k_deband<false>, grid, block, 0, stream, *pass);
+        PLH_LAUNCH_LAST(k_deband<false>, grid, block, 0, stream, *pass);
     const hipError_t err = hipGetLastError();
     return err == hipSuccess ? 0 : -(int) err;
 }

@@ -454,8 +454,8 @@ static void launch_ortho_fast(hipStream_t stream, const plh_pass *pass, int epi)
     const dim3 grid(((pass->width + 1) / 2 + ORTHO_BW - 1) / ORTHO_BW,
                     (pass->height + ORTHO_BH - 1) / ORTHO_BH);
 #define LAUNCH_N(E, NT) do { \
-        if (pass->s.dir) hipLaunchKernelGGL((k_ortho_fast<SRC, E, 1, NT>), grid, block, 0, stream, *pass); \
-        else             hipLaunchKernelGGL((k_ortho_fast<SRC, E, 0, NT>), grid, block, 0, stream, *pass); \
+        if (pass->s.dir) PLH_LAUNCH_LAST((k_ortho_fast<SRC, E, 1, NT>), grid, block, 0, stream, *pass); \
+        else             PLH_LAUNCH_LAST((k_ortho_fast<SRC, E, 0, NT>), grid, block, 0, stream, *pass); \
     } while (0)
 #define LAUNCH(E) do { \
         if (pass->s.row_size == 4)      LAUNCH_N(E, 4); \
@@ -469,8 +469,8 @@ static void launch_ortho_fast(hipStream_t stream, const plh_pass *pass, int epi)
         // (the tap count at compile time where it is 4 or 8 -- a halving with hermite / bicubic: the
         // run-time form issues all 16 loads whatever the count)
 #define LAUNCH_LIN_N(E, NT) do { \
-            if (pass->s.dir) hipLaunchKernelGGL((k_ortho_fast<SRC, E, 1, NT, true>), grid, block, 0, stream, *pass); \
-            else             hipLaunchKernelGGL((k_ortho_fast<SRC, E, 0, NT, true>), grid, block, 0, stream, *pass); \
+            if (pass->s.dir) PLH_LAUNCH_LAST((k_ortho_fast<SRC, E, 1, NT, true>), grid, block, 0, stream, *pass); \
+            else             PLH_LAUNCH_LAST((k_ortho_fast<SRC, E, 0, NT, true>), grid, block, 0, stream, *pass); \
         } while (0)
 #define LAUNCH_LIN(E) do { \
             if (pass->s.row_size == 4)      LAUNCH_LIN_N(E, 4); \
@@ -595,9 +595,9 @@ int plh_launch_ortho(hipStream_t stream, const plh_pass *pass)
     const dim3 grid((pass->width + ORTHO_BW - 1) / ORTHO_BW,
                     (pass->height + ORTHO_BH - 1) / ORTHO_BH);
     if (plh_ops_lite(pass, 0, pass->num_ops))
-        hipLaunchKernelGGL(k_ortho<true>, grid, block, 0, stream, *pass);
+        PLH_LAUNCH_LAST(k_ortho<true>, grid, block, 0, stream, *pass);
     else
-        hipLaunchKernelGGL(k_ortho<false>, grid, block, 0, stream, *pass);
+        PLH_LAUNCH_LAST(k_ortho<false>, grid, block, 0, stream, *pass);
     const hipError_t err = hipGetLastError();
     return err == hipSuccess ? 0 : -(int) err;
 }

@@ -1015,10 +1015,10 @@ static void launch_pass_native(hipStream_t stream, const plh_pass *pass)
     const int cells_w = (pass->width + 1) / 2, bh = PASS_BH * PASS_ITERS;
     const dim3 grid((cells_w + PASS_BW - 1) / PASS_BW, (pass->height + bh - 1) / bh);
     const bool fs = pass->s.src.fmt == PLH_FMT_RGBA16F, fd = pass->dst.fmt == PLH_FMT_RGBA16F;
-    if (fs && fd)       hipLaunchKernelGGL((k_pass_native<LITE, true, true>), grid, block, 0, stream, *pass);
-    else if (fs)        hipLaunchKernelGGL((k_pass_native<LITE, true, false>), grid, block, 0, stream, *pass);
-    else if (fd)        hipLaunchKernelGGL((k_pass_native<LITE, false, true>), grid, block, 0, stream, *pass);
-    else                hipLaunchKernelGGL((k_pass_native<LITE, false, false>), grid, block, 0, stream, *pass);
+    if (fs && fd)       PLH_LAUNCH_LAST((k_pass_native<LITE, true, true>), grid, block, 0, stream, *pass);
+    else if (fs)        PLH_LAUNCH_LAST((k_pass_native<LITE, true, false>), grid, block, 0, stream, *pass);
+    else if (fd)        PLH_LAUNCH_LAST((k_pass_native<LITE, false, true>), grid, block, 0, stream, *pass);
+    else                PLH_LAUNCH_LAST((k_pass_native<LITE, false, false>), grid, block, 0, stream, *pass);
 }
 
 static bool nearest_fast_ok(plh_pass *pass)
@@ -1058,9 +1058,9 @@ static void launch_bilinear_fast(hipStream_t stream, const plh_pass *pass, int i
     const dim3 grid((cells_w + BF_BW - 1) / BF_BW, (cells_h + bh - 1) / bh);
 #define BF_LAUNCH(IT) do { \
         if (pass->epi.has_alpha) \
-            hipLaunchKernelGGL((k_bilinear_fast<F16SRC, IT, true>), grid, block, 0, stream, *pass); \
+            PLH_LAUNCH_LAST((k_bilinear_fast<F16SRC, IT, true>), grid, block, 0, stream, *pass); \
         else \
-            hipLaunchKernelGGL((k_bilinear_fast<F16SRC, IT, false>), grid, block, 0, stream, *pass); \
+            PLH_LAUNCH_LAST((k_bilinear_fast<F16SRC, IT, false>), grid, block, 0, stream, *pass); \
     } while (0)
     if (iters == 4)
         BF_LAUNCH(4);
@@ -1392,9 +1392,9 @@ static void launch_bilinear_tab(hipStream_t stream, const plh_pass *pass, const 
     const int cells_h = (pass->height + pass->cell_pady + 1) / 2;
     const dim3 block(BF_BW, BF_BH), grid((cells_w + BF_BW - 1) / BF_BW, (cells_h + BF_BH - 1) / BF_BH);
     if (pass->epi.has_alpha)
-        hipLaunchKernelGGL((k_bilinear_tab<F16SRC, true>), grid, block, 0, stream, *pass, tab->colw, tab->roww, tab->b0x, tab->b0y);
+        PLH_LAUNCH_LAST((k_bilinear_tab<F16SRC, true>), grid, block, 0, stream, *pass, tab->colw, tab->roww, tab->b0x, tab->b0y);
     else
-        hipLaunchKernelGGL((k_bilinear_tab<F16SRC, false>), grid, block, 0, stream, *pass, tab->colw, tab->roww, tab->b0x, tab->b0y);
+        PLH_LAUNCH_LAST((k_bilinear_tab<F16SRC, false>), grid, block, 0, stream, *pass, tab->colw, tab->roww, tab->b0x, tab->b0y);
 }
 
 /* ------------------------------------------------------------------------ */
@@ -1461,9 +1461,9 @@ extern "C" int plh_launch_pass(plh_stream stream_, const struct plh_pass *pass)
             const dim3 grid((cells_w + BF_BW - 1) / BF_BW,
                             (local.height + BF_BH * NF_ROWS - 1) / (BF_BH * NF_ROWS));
             if (local.s.src.fmt == PLH_FMT_RGBA16F)
-                hipLaunchKernelGGL(k_nearest_fast<true>, grid, block, 0, stream, local);
+                PLH_LAUNCH_LAST(k_nearest_fast<true>, grid, block, 0, stream, local);
             else
-                hipLaunchKernelGGL(k_nearest_fast<false>, grid, block, 0, stream, local);
+                PLH_LAUNCH_LAST(k_nearest_fast<false>, grid, block, 0, stream, local);
             const hipError_t err = hipGetLastError();
             return err == hipSuccess ? 0 : -(int) err;
         }
@@ -1498,9 +1498,9 @@ extern "C" int plh_launch_pass(plh_stream stream_, const struct plh_pass *pass)
             const dim3 block(PASS_BW, PASS_BH);
             const dim3 grid(((local.width + 1) / 2 + PASS_BW - 1) / PASS_BW, (local.height + PASS_BH - 1) / PASS_BH);
             if (local.dst.fmt == PLH_FMT_RGBA16F)
-                hipLaunchKernelGGL(k_pass_merge<true>, grid, block, 0, stream, local, m);
+                PLH_LAUNCH_LAST(k_pass_merge<true>, grid, block, 0, stream, local, m);
             else
-                hipLaunchKernelGGL(k_pass_merge<false>, grid, block, 0, stream, local, m);
+                PLH_LAUNCH_LAST(k_pass_merge<false>, grid, block, 0, stream, local, m);
             const hipError_t err = hipGetLastError();
             return err == hipSuccess ? 0 : -(int) err;
         }
@@ -1513,9 +1513,9 @@ extern "C" int plh_launch_pass(plh_stream stream_, const struct plh_pass *pass)
             const dim3 block(PASS_BW, PASS_BH);
             const dim3 grid(((local.width + 1) / 2 + PASS_BW - 1) / PASS_BW, (local.height + PASS_BH - 1) / PASS_BH);
             if (local.dst.fmt == PLH_FMT_RGBA16F)
-                hipLaunchKernelGGL(k_pass_mix<true>, grid, block, 0, stream, local, mp);
+                PLH_LAUNCH_LAST(k_pass_mix<true>, grid, block, 0, stream, local, mp);
             else
-                hipLaunchKernelGGL(k_pass_mix<false>, grid, block, 0, stream, local, mp);
+                PLH_LAUNCH_LAST(k_pass_mix<false>, grid, block, 0, stream, local, mp);
             const hipError_t err = hipGetLastError();
             return err == hipSuccess ? 0 : -(int) err;
         }
@@ -1525,9 +1525,9 @@ extern "C" int plh_launch_pass(plh_stream stream_, const struct plh_pass *pass)
         const dim3 block(PASS_BW, PASS_BH);
         const dim3 grid(((pass->width + 1) / 2 + PASS_BW - 1) / PASS_BW, (pass->height + PASS_BH - 1) / PASS_BH);
         if (pass->s.src.fmt == PLH_FMT_RGBA16F)
-            hipLaunchKernelGGL(k_pass_features<true>, grid, block, 0, stream, *pass);
+            PLH_LAUNCH_LAST(k_pass_features<true>, grid, block, 0, stream, *pass);
         else
-            hipLaunchKernelGGL(k_pass_features<false>, grid, block, 0, stream, *pass);
+            PLH_LAUNCH_LAST(k_pass_features<false>, grid, block, 0, stream, *pass);
         const hipError_t err = hipGetLastError();
         return err == hipSuccess ? 0 : -(int) err;
     }
@@ -1540,20 +1540,20 @@ extern "C" int plh_launch_pass(plh_stream stream_, const struct plh_pass *pass)
             const int cells_w = (local.width + CHAIN_NP - 1) / CHAIN_NP;
             const dim3 grid((cells_w + PASS_BW - 1) / PASS_BW, (local.height + PASS_BH - 1) / PASS_BH);
             if (local.s.src.fmt == PLH_FMT_RGBA16F)
-                hipLaunchKernelGGL((k_pass_chain<true, CHAIN_NP, false, true>), grid, block, 0, stream, local);
+                PLH_LAUNCH_LAST((k_pass_chain<true, CHAIN_NP, false, true>), grid, block, 0, stream, local);
             else
-                hipLaunchKernelGGL((k_pass_chain<false, CHAIN_NP, false, true>), grid, block, 0, stream, local);
+                PLH_LAUNCH_LAST((k_pass_chain<false, CHAIN_NP, false, true>), grid, block, 0, stream, local);
         } else if (local.chain.enabled && local.dst.fmt == PLH_FMT_RGBA16) {
             const dim3 block(PASS_BW, PASS_BH);
             const int cells_w = (local.width + CHAIN_NP - 1) / CHAIN_NP;
             const dim3 grid((cells_w + PASS_BW - 1) / PASS_BW, (local.height + PASS_BH - 1) / PASS_BH);
             const bool f16 = local.s.src.fmt == PLH_FMT_RGBA16F;
             if (local.chain.contrast_recovery) {
-                if (f16) hipLaunchKernelGGL((k_pass_chain<true, CHAIN_NP, true>), grid, block, 0, stream, local);
-                else     hipLaunchKernelGGL((k_pass_chain<false, CHAIN_NP, true>), grid, block, 0, stream, local);
+                if (f16) PLH_LAUNCH_LAST((k_pass_chain<true, CHAIN_NP, true>), grid, block, 0, stream, local);
+                else     PLH_LAUNCH_LAST((k_pass_chain<false, CHAIN_NP, true>), grid, block, 0, stream, local);
             } else {
-                if (f16) hipLaunchKernelGGL((k_pass_chain<true, CHAIN_NP, false>), grid, block, 0, stream, local);
-                else     hipLaunchKernelGGL((k_pass_chain<false, CHAIN_NP, false>), grid, block, 0, stream, local);
+                if (f16) PLH_LAUNCH_LAST((k_pass_chain<true, CHAIN_NP, false>), grid, block, 0, stream, local);
+                else     PLH_LAUNCH_LAST((k_pass_chain<false, CHAIN_NP, false>), grid, block, 0, stream, local);
             }
         } else if (plh_ops_lite(pass, 0, pass->num_ops))
             launch_pass_native<true>(stream, pass);
@@ -1586,14 +1586,14 @@ extern "C" int plh_launch_pass(plh_stream stream_, const struct plh_pass *pass)
     const int cells_h = ch == 2 ? (pass->height + pass->cell_pady + 1) / 2 : pass->height;
     const int bh = PASS_BH * PASS_ITERS;
     const dim3 grid((cells_w + PASS_BW - 1) / PASS_BW, (cells_h + bh - 1) / bh);
-#define LAUNCH(L, S, C) hipLaunchKernelGGL((k_pass_generic<L, S, C>), grid, block, 0, stream, *pass)
+#define LAUNCH(L, S, C) PLH_LAUNCH_LAST((k_pass_generic<L, S, C>), grid, block, 0, stream, *pass)
     if (cubic) {
-        hipLaunchKernelGGL((k_pass_generic<false, true, 1, false, true>), grid, block, 0, stream, *pass);
+        PLH_LAUNCH_LAST((k_pass_generic<false, true, 1, false, true>), grid, block, 0, stream, *pass);
     } else if (mixing) {
         // frame mixing: the one variant that carries the second colour register
         if (!simple)
             return -1003;
-        hipLaunchKernelGGL((k_pass_generic<false, true, 1, true>), grid, block, 0, stream, *pass);
+        PLH_LAUNCH_LAST((k_pass_generic<false, true, 1, true>), grid, block, 0, stream, *pass);
     } else if (ch == 2) {
         if (lite && simple) LAUNCH(true, true, 2);
         else if (lite)      LAUNCH(true, false, 2);

@@ -820,7 +820,7 @@ int plh_launch_peak(hipStream_t stream, const plh_pass *pass)
         int groups = (per_slice + 2 * PEAK_WAVES - 1) / (2 * PEAK_WAVES);
         groups = groups < 1 ? 1 : groups > gmax ? gmax : groups;
         const dim3 tgrid(PEAK_SLICES * groups);
-#define PEAK_TILES_GO(F, S, Q) hipLaunchKernelGGL((k_peak_tiles<F, S, Q>), tgrid, block, 0, stream, *pass)
+#define PEAK_TILES_GO(F, S, Q) PLH_LAUNCH_LAST((k_peak_tiles<F, S, Q>), tgrid, block, 0, stream, *pass)
         if (f16 && store)   { if (pq) PEAK_TILES_GO(true, 1, true); else PEAK_TILES_GO(true, 1, false); }
         else if (f16)       { if (pq) PEAK_TILES_GO(true, 0, true); else PEAK_TILES_GO(true, 0, false); }
         else if (store)     { if (pq) PEAK_TILES_GO(false, 1, true); else PEAK_TILES_GO(false, 1, false); }
@@ -843,7 +843,7 @@ int plh_launch_peak(hipStream_t stream, const plh_pass *pass)
     else
         hipLaunchKernelGGL(k_pass_peak<false>, grid, block, 0, stream, *pass);
     static_assert(PLH_PEAK_COPIES % FOLD_GROUPS == 0, "copy groups");
-    hipLaunchKernelGGL(k_peak_fold, dim3((PLH_PEAK_WORDS + FOLD_WORDS - 1) / FOLD_WORDS),
+    PLH_LAUNCH_LAST(k_peak_fold, dim3((PLH_PEAK_WORDS + FOLD_WORDS - 1) / FOLD_WORDS),
                        dim3(FOLD_WORDS * FOLD_GROUPS), 0, stream, (uint32_t *) pass->peak_buf,
                        (uint32_t *) pass->peak_scratch, (uint32_t *) pass->peak_mailbox,
                        pass->peak_ticket);

@@ -302,9 +302,9 @@ template <typename T, uint32_t MASK>
 static int launch_ar(hipStream_t stream, const plh_pass *pass, dim3 grid, dim3 block, size_t shmem)
 {
     if (pass->s.antiring > 0.0f)
-        hipLaunchKernelGGL((k_polar<T, MASK, true>), grid, block, shmem, stream, *pass);
+        PLH_LAUNCH_LAST((k_polar<T, MASK, true>), grid, block, shmem, stream, *pass);
     else
-        hipLaunchKernelGGL((k_polar<T, MASK, false>), grid, block, shmem, stream, *pass);
+        PLH_LAUNCH_LAST((k_polar<T, MASK, false>), grid, block, shmem, stream, *pass);
     const hipError_t err = hipGetLastError();
     return err == hipSuccess ? 0 : -(int) err;
 }

@@ -423,7 +423,7 @@ int plh_launch_polar_mxd(hipStream_t stream, const plh_pass *pass)
         const int e = plh_kernel_needs_lds((const void *) k_polar_mxd<U, F, P, D>, (plh_stream) stream, shmem, &lds_done); \
         if (e) \
             return e; \
-        hipLaunchKernelGGL((k_polar_mxd<U, F, P, D>), dim3(groups), dim3(MXD_NT), shmem, stream, *pass); \
+        PLH_LAUNCH_LAST((k_polar_mxd<U, F, P, D>), dim3(groups), dim3(MXD_NT), shmem, stream, *pass); \
     } while (0)
     if (pre || delin) {
         // the passes of a linear-light downscale

@@ -368,7 +368,7 @@ int plh_launch_polar_mxr(hipStream_t stream, const plh_pass *pass)
     const int tiles = ((nbx + tbx - 1) / tbx) * ((nby + MXR_TBY - 1) / MXR_TBY);
     const size_t shmem = MXR_B_BYTES + (size_t) 3 * (G * MXR_TBY + 8) * MXR_PITCH;
     const bool chain = pass->chain.enabled;
-#define MXR_LAUNCH(RR, GG, CH) hipLaunchKernelGGL((k_polar_mxr<RR, GG, CH>), dim3(tiles), dim3(MXR_NT), shmem, stream, *pass)
+#define MXR_LAUNCH(RR, GG, CH) PLH_LAUNCH_LAST((k_polar_mxr<RR, GG, CH>), dim3(tiles), dim3(MXR_NT), shmem, stream, *pass)
     if (G == 2 && R == 3 && chain)  MXR_LAUNCH(3, 2, true);
     else if (G == 2 && R == 3)      MXR_LAUNCH(3, 2, false);
     else if (G == 2)

@@ -294,11 +294,21 @@ int plh_pass_execute(pl_gpu gpu, pl_log log, const struct plh_pass_exec *x, pl_t
     const uint64_t seq = plh_tex_order(gpu, on, x->src_tex, target);
     if (timer)
         plh_timer_begin(gpu, timer, on);
+    // The event that marks the end of this pass -- the measurement's `written` event, or a fence
+    // of the two-stream bookkeeping -- rides on the launch of the pass's last kernel where the
+    // launcher takes it; recorded behind the pass it is a queue entry that holds the stream's
+    // next kernel back (backend.h: plh_launch_offer_stop).
+    plh_event stop = x->detect_peak ? plh_peak_written_event(x->peak_state)
+                                    : plh_gpu_fence_for_launch(gpu, on, x->src_tex);
+    plh_launch_offer_stop(stop);
     const int err = plh_launch_pass(plh_gpu_stream_n(gpu, on), pass);
+    const bool taken = plh_launch_stop_taken() && !err;
     if (timer)
         plh_timer_end(gpu, timer, on);
     if (!err && x->detect_peak)
-        plh_peak_pass_launched(gpu, x->peak_state, on, seq);
+        plh_peak_pass_launched(gpu, x->peak_state, on, seq, taken);
+    else if (stop)
+        plh_gpu_fence_launched(gpu, on, taken);
     return err;
 }
 
@@ -434,7 +444,7 @@ bool pl_dispatch_compute(pl_dispatch dp, const struct pl_dispatch_compute_params
         if (timer)
             plh_timer_end(dp->gpu, timer, 0);
         if (!err && sh->detect_peak)
-            plh_peak_pass_launched(dp->gpu, sh->peak_state, 0, 0);
+            plh_peak_pass_launched(dp->gpu, sh->peak_state, 0, 0, false);
     }
 
     if (err) {

@@ -108,6 +108,9 @@ struct tex_priv {
     // write (on stream `write_on`) and of the last read per stream
     uint64_t write_seq, read_seq[2];
     int write_on;
+    // the renderer's measured intermediate (written on the measuring stream, read on the main one,
+    // rewritten a few frames on): the launch that reads it carries a fence (plh_gpu_fence_for_launch)
+    bool fence_reads;
 };
 
 struct buf_priv {
@@ -153,6 +156,11 @@ plh_stream plh_gpu_stream_n(pl_gpu gpu, int on);
 // makes the stream wait for whatever the other stream still has to do with them, and notes the
 // launch on both textures. Returns the launch's number on its stream.
 uint64_t plh_tex_order(pl_gpu gpu, int on, pl_tex reads, pl_tex writes);
+// an event to ride on the launch that plh_tex_order has just counted (NULL: none wanted), and what
+// became of it (gpu_hip.c)
+plh_event plh_gpu_fence_for_launch(pl_gpu gpu, int on, pl_tex reads);
+void plh_tex_fence_reads(pl_tex tex);  // (renderer: the measured intermediate)
+void plh_gpu_fence_launched(pl_gpu gpu, int on, bool taken);
 // `tex` has been read by launches on `on` that plh_tex_order did not see, all of them queued by now
 void plh_tex_read_so_far(pl_gpu gpu, pl_tex tex, int on);
 // a number for something just queued on `on` that is no texture (a table upload)...

@@ -235,6 +235,7 @@ static pl_tex borrow_measure_fbo(struct frame_job *job, int w, int h, pl_fmt fmt
         return NULL;
     rr->measure_flip++;
     job->measure_fbo = *slot;
+    plh_tex_fence_reads(*slot);
     return *slot;
 }
 

@@ -705,12 +705,18 @@ static void peak_collect(pl_gpu gpu, struct sh_color_map_obj *obj, bool must)
 }
 
 // dispatch.c, behind the launch of a pass that carries a measurement
-void plh_peak_pass_launched(pl_gpu gpu, pl_shader_obj state, int on, uint64_t seq)
+plh_event plh_peak_written_event(pl_shader_obj state)
+{
+    struct sh_color_map_obj *obj = state ? state->priv : NULL;
+    return obj ? obj->peak.written : NULL;
+}
+
+void plh_peak_pass_launched(pl_gpu gpu, pl_shader_obj state, int on, uint64_t seq, bool recorded)
 {
     struct sh_color_map_obj *obj = state->priv;
     obj->peak.on = on;
     obj->peak.seq = seq;
-    if (!plh_event_record(obj->peak.written, plh_gpu_stream_n(gpu, on)))
+    if (recorded || !plh_event_record(obj->peak.written, plh_gpu_stream_n(gpu, on)))
         obj->peak.launched = true;
 }
 

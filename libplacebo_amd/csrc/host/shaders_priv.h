@@ -112,7 +112,9 @@ void plh_colormap_resolve(struct plh_colormap_plan *plan, const struct pl_color_
 
 void plh_polar_pp_setup(pl_gpu gpu, pl_log log, void *polar_obj, struct plh_pass *pass);
 
-void plh_peak_pass_launched(pl_gpu gpu, pl_shader_obj state, int on, uint64_t seq);
+// (`recorded`: the launch carried the `written` event itself, plh_peak_written_event)
+void plh_peak_pass_launched(pl_gpu gpu, pl_shader_obj state, int on, uint64_t seq, bool recorded);
+plh_event plh_peak_written_event(pl_shader_obj state);
 
 // the finalized, still-alive shader behind a "#pl_hip_pass <ticket>" line; NULL if there is none
 pl_shader plh_shader_from_glsl(const char *glsl);

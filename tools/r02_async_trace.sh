@@ -2,7 +2,7 @@
 # kernel timeline (start / end per launch) with async_measure on: metric workload and hdr10_4k_tonemap
 cd $GRAFT_REPO_ROOT
 export TMPDIR=/tmp
-for w in ewa_1080p_to_4k_hdr_tonemap hdr10_4k_tonemap; do
+for w in ${WLS:-ewa_1080p_to_4k_hdr_tonemap hdr10_4k_tonemap}; do
   out=$GRAFT_REPO_ROOT/gpurun_out/async_trace_$w
   rm -rf $out; mkdir -p $out
   (cd /tmp && timeout 300 rocprofv3 --kernel-trace --output-format csv -d $out -- python $GRAFT_REPO_ROOT/bench.py --bare --steps 40 --warmup 8 --async-measure 1 --workload $w > $out/log.txt 2>&1)
