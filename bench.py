@@ -378,7 +378,7 @@ BASELINE_CONFIGS = {
 def kernel_symbol(workload, name):
     """rocprofv3 kernel name prefix of the pass described by `name`"""
     if "peak detection" in name and "scaling" not in name and "map" not in name:
-        return "k_pass_peak"
+        return "k_peak_"    # k_peak_tiles (k_peak_fast + k_peak_fold for the feature-plane variant)
     if "polar" in name:
         # k_polar_mx (the contraction on the matrix pipe: exact 2x upscales) or k_polar_pp (phase
         # classes, sequential fma); which one ran is read off the kernel trace (trace["name"])
