@@ -286,13 +286,33 @@ void k_ortho_fast(const plh_pass p_)
     // the second pixel's taps are the first one's shifted -> N + 1 loads instead of 2N.
     const int shift = first[1] - first[0];
     const bool overlap = !DIR && o0[1] == o0[0] && (shift == 0 || shift == 1);
+    // Vertical pass over a one-component 16-bit plane (the contrast-recovery feature plane): the
+    // lane's two pixels sit on adjacent columns of the same rows, so ONE 4-byte load per tap row
+    // serves both (the pass is bound by the number of load instructions -- each is 64 addresses
+    // for the texture addresser, whatever it fetches --, not by their bytes).
+    constexpr bool ONE16 = SRC == PLH_FMT_R16 || SRC == PLH_FMT_R16F;
+    const bool pair16 = DIR && ONE16 && shift == 0 && o0[1] == o0[0] + 1;
     uint2 extra = make_uint2(0, 0);
+    if (pair16) {
 #pragma unroll
-    for (int n = 0; n < NT; n++) {
-        const int iw = of_tap(first[0] + min(n, N - 1), na, mirror);
-        raw[0][n] = DIR ? of_load<SRC>(sp, spitch, o0[0], iw) : of_load<SRC>(sp, spitch, iw, o0[0]);
+        for (int n = 0; n < NT; n++) {
+            const int iw = of_tap(first[0] + min(n, N - 1), na, mirror);
+            const OF_GLOBAL char *row = (const OF_GLOBAL char *) (uintptr_t) sp + (size_t) iw * spitch;
+            uint32_t v;     // (2-byte aligned: fine for global memory)
+            __builtin_memcpy(&v, (const void *) (row + (size_t) o0[0] * 2), 4);
+            raw[0][n] = make_uint2(v & 0xffffu, 0);
+            raw[1][n] = make_uint2(v >> 16, 0);
+        }
+    } else {
+#pragma unroll
+        for (int n = 0; n < NT; n++) {
+            const int iw = of_tap(first[0] + min(n, N - 1), na, mirror);
+            raw[0][n] = DIR ? of_load<SRC>(sp, spitch, o0[0], iw) : of_load<SRC>(sp, spitch, iw, o0[0]);
+        }
     }
-    if (overlap) {
+    if (pair16) {
+        // (both pixels' taps are in)
+    } else if (overlap) {
         extra = of_load<SRC>(sp, spitch, of_tap(first[0] + N, na, mirror), o0[0]);
     } else {
 #pragma unroll
