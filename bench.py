@@ -691,18 +691,24 @@ def run_timed(st, steps, warmup, sync=None, barrier=None):
         sync()
     if barrier:
         barrier()
+    debug = os.environ.get("PL_BENCH_DEBUG")
+    stamps = []
     t0 = time.perf_counter()
     for _ in range(steps):
         st.step()
+        if debug:
+            stamps.append(time.perf_counter())
     t1 = time.perf_counter()
     st.g.finish()
     t2 = time.perf_counter()
     if sync:
         sync()
     elapsed = time.perf_counter() - t0
-    if os.environ.get("PL_BENCH_DEBUG"):
+    if debug:
         print(f"bench: steps {1e3 * (t1 - t0):.2f} ms, finish {1e3 * (t2 - t1):.2f} ms, "
               f"device sync {1e3 * (elapsed - (t2 - t0)):.2f} ms", file=sys.stderr)
+        print("bench: host time per step (us): " +
+              " ".join(f"{1e6 * (b - a):.0f}" for a, b in zip([t0] + stamps[:40], stamps[:40])), file=sys.stderr)
     if barrier:
         barrier()
     return elapsed

@@ -324,8 +324,11 @@ struct plh_pass {
     struct plh_fast_epi epi;
     struct plh_map_chain chain;
 
-    // peak detection side output (k_peak): the 816-word measurement buffer and a zeroed
-    // scratch area of PLH_PEAK_COPIES such buffers that spreads the per-workgroup atomics
+    // peak detection side output (k_peak): the 816-word measurement buffer and a zeroed scratch
+    // area (PLH_PEAK_COPIES such buffers + a counter) for the kernels' partial results: k_peak_tiles
+    // keeps padded accumulators and its tickets in the first 4.3 K words, k_peak_fast / k_pass_peak
+    // spread their per-tile atomics over the copies and k_peak_fold adds them up; every kernel
+    // leaves the area zeroed
     void *peak_buf;
     void *peak_scratch;
     // optional host mailbox (pinned, device-visible): the fold kernel also writes the 816 words

@@ -502,7 +502,7 @@ struct sh_color_map_obj {
     // exactly one wait (the read of its result), none when the result may lag a frame.
     struct {
         struct pl_peak_detect_params params;
-        pl_buf buf;             // 816 words, written by k_peak_fold
+        pl_buf buf;             // 816 words, written by the measuring kernel's last workgroup (k_peak.hip)
         struct peak_buf_data *mirror;   // pinned, device-visible: the kernel's mailbox, + 1 word
         uint32_t ticket;        // the value the pass in flight publishes behind its result
         plh_event written;      // recorded by the dispatch behind the measuring pass
@@ -513,7 +513,7 @@ struct sh_color_map_obj {
         uint64_t tables_seq;    // main-stream stamp of the last upload into consts / scratch
         pl_buf consts;          // constant block of the detect stage
         float consts_now[16];   // what `consts` holds
-        pl_buf scratch;         // PLH_PEAK_COPIES zeroed copies of the buffer (k_peak.hip)
+        pl_buf scratch;         // zeroed accumulators of the measuring kernels (k_peak.hip): left zeroed by each
         float avg_pq, max_pq;   // the filtered state
     } peak;
 };
@@ -804,7 +804,8 @@ bool pl_shader_detect_peak(pl_shader sh, struct pl_color_space csp, pl_shader_ob
     }
     op->ptr2 = pl_hip_buf_ptr(obj->peak.consts);
     if (!obj->peak.scratch) {
-        // (+ the block counter of k_peak_fold behind the copies)
+        // (k_peak_tiles uses the first 4.3 K words: padded accumulators + tickets; k_peak_fast /
+        // k_pass_peak all of the copies, + the block counter of k_peak_fold behind them)
         const size_t size = (size_t) PLH_PEAK_COPIES * sizeof(struct peak_buf_data) + 64;
         void *zeros = calloc(1, size);
         obj->peak.scratch = zeros ? pl_buf_create(gpu, pl_buf_params(
