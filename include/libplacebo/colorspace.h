@@ -39,6 +39,8 @@ enum pl_color_system {
 
 PL_API bool pl_color_system_is_ycbcr_like(enum pl_color_system sys);
 PL_API bool pl_color_system_is_linear(enum pl_color_system sys);
+// (the tables behind the three *_name functions: src/include/libplacebo/colorspace.h:60, :202, :262)
+PL_API extern const char *const pl_color_system_names[PL_COLOR_SYSTEM_COUNT];
 PL_API const char *pl_color_system_name(enum pl_color_system sys);
 PL_API enum pl_color_system pl_color_system_guess_ycbcr(int width, int height);
 
@@ -124,6 +126,7 @@ enum pl_color_primaries {
 };
 
 PL_API bool pl_color_primaries_is_wide_gamut(enum pl_color_primaries prim);
+PL_API extern const char *const pl_color_primaries_names[PL_COLOR_PRIM_COUNT];
 PL_API const char *pl_color_primaries_name(enum pl_color_primaries prim);
 PL_API enum pl_color_primaries pl_color_primaries_guess(int width, int height);
 
@@ -149,6 +152,7 @@ enum pl_color_transfer {
     PL_COLOR_TRC_COUNT
 };
 
+PL_API extern const char *const pl_color_transfer_names[PL_COLOR_TRC_COUNT];
 PL_API const char *pl_color_transfer_name(enum pl_color_transfer trc);
 PL_API float pl_color_transfer_nominal_peak(enum pl_color_transfer trc);
 

@@ -73,6 +73,10 @@ PL_API bool pl_dispatch_compute(pl_dispatch dp, const struct pl_dispatch_compute
 
 PL_API void pl_dispatch_abort(pl_dispatch dp, pl_shader *sh);
 
+// Deprecated: the contents of the gpu's pl_cache (src/include/libplacebo/dispatch.h:231-239)
+PL_API size_t pl_dispatch_save(pl_dispatch dp, uint8_t *out_cache);
+PL_API void pl_dispatch_load(pl_dispatch dp, const uint8_t *cache);
+
 PL_API_END
 
 #endif // LIBPLACEBO_DISPATCH_H_

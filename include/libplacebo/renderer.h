@@ -319,6 +319,16 @@ PL_API void pl_frames_infer_mix(pl_renderer rr, const struct pl_frame_mix *mix,
 // Drop cached FBOs / mixing frames / LUT state
 PL_API void pl_renderer_flush_cache(pl_renderer rr);
 
+// Pre-v6 leftovers that callers still reference (src/include/libplacebo/renderer.h:855-880):
+// the {0}-terminated preset lists option parsers walk, and the save / load front ends of the
+// gpu's pl_cache (pl_gpu_set_cache).
+PL_API extern const struct pl_filter_preset pl_frame_mixers[];
+PL_API extern const int pl_num_frame_mixers;    // excluding the trailing {0}
+PL_API extern const struct pl_filter_preset pl_scale_filters[];
+PL_API extern const int pl_num_scale_filters;   // excluding the trailing {0}
+PL_API size_t pl_renderer_save(pl_renderer rr, uint8_t *out_cache);
+PL_API void pl_renderer_load(pl_renderer rr, const uint8_t *cache);
+
 // HDR metadata measured by the last frame's peak detection, if any
 PL_API bool pl_renderer_get_hdr_metadata(pl_renderer rr, struct pl_hdr_metadata *metadata);
 

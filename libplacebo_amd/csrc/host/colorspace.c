@@ -50,7 +50,7 @@ bool pl_color_system_is_linear(enum pl_color_system sys)
                        MEMBER(PL_COLOR_SYSTEM_XYZ));
 }
 
-static const char *const system_names[PL_COLOR_SYSTEM_COUNT] = {
+const char *const pl_color_system_names[PL_COLOR_SYSTEM_COUNT] = {
     [PL_COLOR_SYSTEM_UNKNOWN]       = "Auto (unknown)",
     [PL_COLOR_SYSTEM_BT_601]        = "ITU-R Rec. BT.601 (SD)",
     [PL_COLOR_SYSTEM_BT_709]        = "ITU-R Rec. BT.709 (HD)",
@@ -69,7 +69,7 @@ static const char *const system_names[PL_COLOR_SYSTEM_COUNT] = {
 
 const char *pl_color_system_name(enum pl_color_system sys)
 {
-    return sys >= 0 && sys < PL_COLOR_SYSTEM_COUNT ? system_names[sys] : "?";
+    return sys >= 0 && sys < PL_COLOR_SYSTEM_COUNT ? pl_color_system_names[sys] : "?";
 }
 
 enum pl_color_system pl_color_system_guess_ycbcr(int width, int height)
@@ -155,7 +155,7 @@ bool pl_color_primaries_is_wide_gamut(enum pl_color_primaries prim)
                         MEMBER(PL_COLOR_PRIM_BT_470M) | MEMBER(PL_COLOR_PRIM_EBU_3213));
 }
 
-static const char *const primaries_names[PL_COLOR_PRIM_COUNT] = {
+const char *const pl_color_primaries_names[PL_COLOR_PRIM_COUNT] = {
     [PL_COLOR_PRIM_UNKNOWN]     = "Auto (unknown)",
     [PL_COLOR_PRIM_BT_601_525]  = "ITU-R Rec. BT.601 (525-line = NTSC, SMPTE-C)",
     [PL_COLOR_PRIM_BT_601_625]  = "ITU-R Rec. BT.601 (625-line = PAL, SECAM)",
@@ -178,7 +178,7 @@ static const char *const primaries_names[PL_COLOR_PRIM_COUNT] = {
 
 const char *pl_color_primaries_name(enum pl_color_primaries prim)
 {
-    return prim >= 0 && prim < PL_COLOR_PRIM_COUNT ? primaries_names[prim] : "?";
+    return prim >= 0 && prim < PL_COLOR_PRIM_COUNT ? pl_color_primaries_names[prim] : "?";
 }
 
 enum pl_color_primaries pl_color_primaries_guess(int width, int height)
@@ -198,7 +198,7 @@ enum pl_color_primaries pl_color_primaries_guess(int width, int height)
     return PL_COLOR_PRIM_BT_709;
 }
 
-static const char *const transfer_names[PL_COLOR_TRC_COUNT] = {
+const char *const pl_color_transfer_names[PL_COLOR_TRC_COUNT] = {
     [PL_COLOR_TRC_UNKNOWN]      = "Auto (unknown SDR)",
     [PL_COLOR_TRC_BT_1886]      = "ITU-R Rec. BT.1886 (CRT emulation + OOTF)",
     [PL_COLOR_TRC_SRGB]         = "IEC 61966-2-4 sRGB (CRT emulation)",
@@ -221,7 +221,7 @@ static const char *const transfer_names[PL_COLOR_TRC_COUNT] = {
 
 const char *pl_color_transfer_name(enum pl_color_transfer trc)
 {
-    return trc >= 0 && trc < PL_COLOR_TRC_COUNT ? transfer_names[trc] : "?";
+    return trc >= 0 && trc < PL_COLOR_TRC_COUNT ? pl_color_transfer_names[trc] : "?";
 }
 
 float pl_color_transfer_nominal_peak(enum pl_color_transfer trc)

@@ -312,6 +312,17 @@ int plh_pass_execute(pl_gpu gpu, pl_log log, const struct plh_pass_exec *x, pl_t
     return err;
 }
 
+// Deprecated front ends of the gpu's pl_cache (src/dispatch.c:1624-1632)
+size_t pl_dispatch_save(pl_dispatch dp, uint8_t *out)
+{
+    return pl_cache_save(plh_gpu_cache(dp->gpu), out, out ? SIZE_MAX : 0);
+}
+
+void pl_dispatch_load(pl_dispatch dp, const uint8_t *cache)
+{
+    pl_cache_load(plh_gpu_cache(dp->gpu), cache, SIZE_MAX);
+}
+
 bool pl_dispatch_finish(pl_dispatch dp, const struct pl_dispatch_params *params)
 {
     pl_shader sh = *params->shader;

@@ -383,20 +383,7 @@ pl_find_filter_config(const char *name, enum pl_filter_usage usage)
 // recommended scalers first, then the rest, then two aliases without a description
 const struct pl_filter_preset pl_filter_presets[] = {
     {"none", NULL, "Built-in sampling"},
-#define P(cfg, desc) {(cfg).name, &(cfg), desc}
-    P(pl_filter_bilinear, "Bilinear"), P(pl_filter_nearest, "Nearest neighbour"),
-    P(pl_filter_bicubic, "Bicubic"), P(pl_filter_lanczos, "Lanczos"),
-    P(pl_filter_ewa_lanczos, "Jinc (EWA Lanczos)"), P(pl_filter_ewa_lanczossharp, "Sharpened Jinc"),
-    P(pl_filter_ewa_lanczos4sharpest, "Sharpened Jinc-AR, 4 taps"), P(pl_filter_gaussian, "Gaussian"),
-    P(pl_filter_spline16, "Spline (2 taps)"), P(pl_filter_spline36, "Spline (3 taps)"),
-    P(pl_filter_spline64, "Spline (4 taps)"), P(pl_filter_mitchell, "Mitchell-Netravali"),
-    P(pl_filter_sinc, "Sinc (unwindowed)"), P(pl_filter_ginseng, "Ginseng (Jinc-Sinc)"),
-    P(pl_filter_ewa_jinc, "EWA Jinc (unwindowed)"), P(pl_filter_ewa_ginseng, "EWA Ginseng"),
-    P(pl_filter_ewa_hann, "EWA Hann"), P(pl_filter_hermite, "Hermite"),
-    P(pl_filter_catmull_rom, "Catmull-Rom"), P(pl_filter_robidoux, "Robidoux"),
-    P(pl_filter_robidouxsharp, "RobidouxSharp"), P(pl_filter_ewa_robidoux, "EWA Robidoux"),
-    P(pl_filter_ewa_robidouxsharp, "EWA RobidouxSharp"),
-#undef P
+    PLH_COMMON_FILTER_PRESETS
     {"triangle", &pl_filter_bilinear, NULL},
     {"ewa_hanning", &pl_filter_ewa_hann, NULL},
     {0},

@@ -32,4 +32,22 @@ void pl_msg(pl_log log, enum pl_log_level lev, const char *fmt, ...)
 }
 #endif
 
+// the common filter presets, in the order of the reference's COMMON_FILTER_PRESETS (filters.h:28-58):
+// shared by pl_filter_presets (filters.c) and pl_scale_filters (renderer.c)
+// (a preset's name is its config's: tests/test_host.py)
+#define PLH_PRESET(id, desc) {#id, &pl_filter_##id, desc}
+#define PLH_COMMON_FILTER_PRESETS \
+    PLH_PRESET(bilinear, "Bilinear"), PLH_PRESET(nearest, "Nearest neighbour"), \
+    PLH_PRESET(bicubic, "Bicubic"), PLH_PRESET(lanczos, "Lanczos"), \
+    PLH_PRESET(ewa_lanczos, "Jinc (EWA Lanczos)"), PLH_PRESET(ewa_lanczossharp, "Sharpened Jinc"), \
+    PLH_PRESET(ewa_lanczos4sharpest, "Sharpened Jinc-AR, 4 taps"), PLH_PRESET(gaussian, "Gaussian"), \
+    PLH_PRESET(spline16, "Spline (2 taps)"), PLH_PRESET(spline36, "Spline (3 taps)"), \
+    PLH_PRESET(spline64, "Spline (4 taps)"), PLH_PRESET(mitchell, "Mitchell-Netravali"), \
+    PLH_PRESET(sinc, "Sinc (unwindowed)"), PLH_PRESET(ginseng, "Ginseng (Jinc-Sinc)"), \
+    PLH_PRESET(ewa_jinc, "EWA Jinc (unwindowed)"), PLH_PRESET(ewa_ginseng, "EWA Ginseng"), \
+    PLH_PRESET(ewa_hann, "EWA Hann"), PLH_PRESET(hermite, "Hermite"), \
+    PLH_PRESET(catmull_rom, "Catmull-Rom"), PLH_PRESET(robidoux, "Robidoux"), \
+    PLH_PRESET(robidouxsharp, "RobidouxSharp"), PLH_PRESET(ewa_robidoux, "EWA Robidoux"), \
+    PLH_PRESET(ewa_robidouxsharp, "EWA RobidouxSharp"),
+
 #endif // PLH_HOST_COMMON_H_

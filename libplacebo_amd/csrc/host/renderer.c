@@ -74,6 +74,38 @@ static void slot_release(struct scaler_slot *slot)
     pl_shader_obj_destroy(&slot->down);
 }
 
+// The pre-v6 preset lists some option parsers still walk (src/renderer.c:226-244): the frame
+// mixers, and the scalers = "none", "oversample" and then the common filter presets (the entries of
+// pl_filter_presets behind its own "none").
+const struct pl_filter_preset pl_frame_mixers[] = {
+    { "none",           NULL,                       "No frame mixing" },
+    { "linear",         &pl_filter_bilinear,        "Linear frame mixing" },
+    { "oversample",     &pl_filter_oversample,      "Oversample (AKA SmoothMotion)" },
+    { "mitchell_clamp", &pl_filter_mitchell_clamp,  "Clamped Mitchell spline" },
+    { "hermite",        &pl_filter_hermite,         "Cubic spline (Hermite)" },
+    {0}
+};
+const int pl_num_frame_mixers = sizeof(pl_frame_mixers) / sizeof(pl_frame_mixers[0]) - 1;
+
+const struct pl_filter_preset pl_scale_filters[] = {
+    { "none",       NULL,                   "Built-in sampling" },
+    { "oversample", &pl_filter_oversample,  "Oversample (Aspect-preserving NN)" },
+    PLH_COMMON_FILTER_PRESETS
+    {0}
+};
+const int pl_num_scale_filters = sizeof(pl_scale_filters) / sizeof(pl_scale_filters[0]) - 1;
+
+// Deprecated front ends of the gpu's pl_cache (src/renderer.c:184-192)
+size_t pl_renderer_save(pl_renderer rr, uint8_t *out)
+{
+    return pl_cache_save(plh_gpu_cache(rr->gpu), out, out ? SIZE_MAX : 0);
+}
+
+void pl_renderer_load(pl_renderer rr, const uint8_t *cache)
+{
+    pl_cache_load(plh_gpu_cache(rr->gpu), cache, SIZE_MAX);
+}
+
 void pl_renderer_flush_cache(pl_renderer rr)
 {
     for (int i = 0; i < rr->num_cached; i++)

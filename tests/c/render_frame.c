@@ -114,6 +114,22 @@ int main(int argc, char **argv)
         counted++;
     if (counted != pl_num_filter_presets || pl_filter_function_presets[pl_num_filter_function_presets].name)
         die("preset tables are not {0}-terminated at their advertised length");
+    // the pre-v6 lists and tables option parsers still walk (renderer.h:855-880, colorspace.h:60)
+    if (strcmp(pl_scale_filters[0].name, "none") || strcmp(pl_scale_filters[1].name, "oversample") ||
+        pl_scale_filters[pl_num_scale_filters].name || pl_frame_mixers[pl_num_frame_mixers].name ||
+        pl_frame_mixers[2].filter != &pl_filter_oversample)
+        die("pl_scale_filters / pl_frame_mixers");
+    if (strcmp(pl_color_transfer_names[PL_COLOR_TRC_PQ], pl_color_transfer_name(PL_COLOR_TRC_PQ)) ||
+        !pl_color_system_names[PL_COLOR_SYSTEM_BT_709] || !pl_color_primaries_names[PL_COLOR_PRIM_BT_2020])
+        die("colour name tables");
+    // ICC: this build, like the reference built here, has no lcms2 (src/shaders/icc.c:802-836)
+    if (pl_icc_open(NULL, &(struct pl_icc_profile) {0}, &pl_icc_default_params) ||
+        pl_icc_default_params.intent != PL_INTENT_RELATIVE_COLORIMETRIC)
+        die("pl_icc_open / pl_icc_default_params");
+    // (deprecated) the gpu's cache through the renderer: no pl_cache was set, so there is nothing
+    // to save -- and nothing to crash on
+    if (pl_renderer_save(rr, NULL) != 0)
+        die("pl_renderer_save without a cache");
     params.upscaler = preset->filter;
     // (the whole target is drawn over: what the clear leaves must not show)
     pl_frame_clear_rgba(gpu, &target, (const float[4]) {1.0f, 0.0f, 1.0f, 1.0f});

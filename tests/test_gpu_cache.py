@@ -78,3 +78,49 @@ def test_dither_matrix_and_gamut_lut_are_memoised():
     for c in (cache, warm_cache):
         cc = C.c_void_p(c)
         lib.pl_cache_destroy(C.byref(cc))
+
+
+def test_renderer_and_dispatch_save_load_are_the_gpu_cache():
+    """pl_renderer_save / _load and pl_dispatch_save / _load (deprecated front ends, src/renderer.c:
+    184-192, src/dispatch.c:1624-1632): the bytes pl_cache_save of the gpu's cache writes, and a
+    renderer on another gpu loads them into ITS cache."""
+    lib = bind(pl.lib())
+    L = pl.lib()
+    L.pl_renderer_save.restype = C.c_size_t
+    L.pl_renderer_save.argtypes = [C.c_void_p, C.c_char_p]
+    L.pl_renderer_load.argtypes = [C.c_void_p, C.c_char_p]
+    L.pl_dispatch_save.restype = C.c_size_t
+    L.pl_dispatch_save.argtypes = [C.c_void_p, C.c_char_p]
+    L.pl_dispatch_load.argtypes = [C.c_void_p, C.c_char_p]
+    w, h = 96, 64
+    img = util.chirp_rgba16(w, h)
+    cache = lib.pl_cache_create(C.byref(Params()))
+    with pl.HipGpu(0) as g:
+        L.pl_gpu_set_cache(g.gpu, C.c_void_p(cache))
+        render_once(g, img, w, h)
+        rr = pl.Renderer(g)
+        n = L.pl_renderer_save(rr.rr, None)
+        assert n == lib.pl_cache_save(cache, None, 0) and n > 64 * 64 * 4
+        a, b, c = (C.create_string_buffer(n) for _ in range(3))
+        assert L.pl_renderer_save(rr.rr, a) == n and lib.pl_cache_save(cache, b, n) == n
+        assert L.pl_dispatch_save(g.dp, None) == n and L.pl_dispatch_save(g.dp, c) == n
+        rr.destroy()
+        assert a.raw == b.raw == c.raw
+    other = lib.pl_cache_create(C.byref(Params()))
+    with pl.HipGpu(0) as g:
+        L.pl_gpu_set_cache(g.gpu, C.c_void_p(other))
+        rr = pl.Renderer(g)
+        L.pl_renderer_load(rr.rr, a)
+        assert lib.pl_cache_objects(other) == 2
+        assert lib.pl_cache_signature(other) == lib.pl_cache_signature(cache)
+        rr.destroy()
+    third = lib.pl_cache_create(C.byref(Params()))
+    with pl.HipGpu(0) as g:
+        L.pl_gpu_set_cache(g.gpu, C.c_void_p(third))
+        L.pl_dispatch_load(g.dp, a)
+        assert lib.pl_cache_objects(third) == 2
+    cv = C.c_void_p(third)
+    lib.pl_cache_destroy(C.byref(cv))
+    for cc in (cache, other):
+        cv = C.c_void_p(cc)
+        lib.pl_cache_destroy(C.byref(cv))

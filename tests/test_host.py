@@ -106,3 +106,30 @@ def test_multi_gpu_sharding_plan():
         owners = [s % world for s in range(16)]
         for r in range(world):
             assert owners.count(r) == 16 // world
+
+
+def test_icc_entry_points_of_a_build_without_lcms():
+    """pl_icc_open / _update / _close as the reference compiled without LittleCMS has them
+    (src/shaders/icc.c:802-836): open fails, update clears the object and fails, close is a no-op;
+    the default parameters are the header's PL_ICC_DEFAULTS."""
+    import ctypes as C
+    import libplacebo_amd as pl
+    L = pl.lib()
+
+    class IccParams(C.Structure):
+        _fields_ = [("intent", C.c_int), ("size_r", C.c_int), ("size_g", C.c_int), ("size_b", C.c_int),
+                    ("max_luma", C.c_float), ("force_bpc", C.c_bool), ("cache", C.c_void_p),
+                    ("cache_priv", C.c_void_p), ("cache_save", C.c_void_p), ("cache_load", C.c_void_p)]
+
+    d = IccParams.in_dll(L, "pl_icc_default_params")
+    assert (d.intent, d.size_r, d.max_luma, d.force_bpc) == (1, 0, 203.0, False)   # RELATIVE_COLORIMETRIC
+    L.pl_icc_open.restype = C.c_void_p
+    L.pl_icc_open.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+    assert L.pl_icc_open(None, None, None) is None
+    L.pl_icc_update.restype = C.c_bool
+    L.pl_icc_update.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.c_void_p, C.c_void_p]
+    obj = C.c_void_p(0x1234)
+    assert L.pl_icc_update(None, C.byref(obj), None, None) is False and not obj.value
+    L.pl_icc_close.argtypes = [C.POINTER(C.c_void_p)]
+    L.pl_icc_close(C.byref(obj))
+    assert not obj.value

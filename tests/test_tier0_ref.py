@@ -129,6 +129,36 @@ def test_filter_preset_tables_match_the_reference(libs):
         assert (rf.name, list(rf.params), rf.radius) == (of.name, list(of.params), of.radius)
 
 
+def test_name_tables_and_older_preset_lists(libs):
+    """pl_color_{system,primaries,transfer}_names (colorspace.h:60, :202, :262) against the
+    reference's; pl_scale_filters = "none", "oversample", then the reference's common presets (its
+    pl_filter_presets between its own "none" and the two aliases that carry no description), and
+    pl_frame_mixers (renderer.c:226-244, not part of the reference objects built here: restated)."""
+    ref, our = libs
+    for sym, n in (("pl_color_system_names", 14), ("pl_color_primaries_names", None),
+                   ("pl_color_transfer_names", None)):
+        n = n or {"pl_color_primaries_names": 17, "pl_color_transfer_names": 18}[sym]
+        ra, oa = (C.c_char_p * n).in_dll(ref, sym), (C.c_char_p * n).in_dll(our, sym)
+        assert list(ra) == list(oa) and all(ra), sym
+    n = C.c_int.in_dll(our, "pl_num_scale_filters").value
+    OA = (FilterPreset * (n + 1)).in_dll(our, "pl_scale_filters")
+    assert not OA[n].name
+    names = [OA[i].name for i in range(n)]
+    nr = C.c_int.in_dll(ref, "pl_num_filter_presets").value
+    RA = (FilterPreset * (nr + 1)).in_dll(ref, "pl_filter_presets")
+    common = [RA[i] for i in range(1, nr) if RA[i].description]
+    assert names == [b"none", b"oversample"] + [c.name for c in common]
+    assert not OA[0].filter and OA[1].filter.contents.name == b"oversample"
+    for o, c in zip([OA[i] for i in range(2, n)], common):
+        assert o.description == c.description and o.filter.contents.name == c.filter.contents.name
+    n = C.c_int.in_dll(our, "pl_num_frame_mixers").value
+    MA = (FilterPreset * (n + 1)).in_dll(our, "pl_frame_mixers")
+    assert [(MA[i].name, MA[i].filter.contents.name if MA[i].filter else None) for i in range(n)] == \
+        [(b"none", None), (b"linear", b"bilinear"), (b"oversample", b"oversample"),
+         (b"mitchell_clamp", b"mitchell_clamp"), (b"hermite", b"hermite")]
+    assert not MA[n].name
+
+
 def test_dither_matrices_bit_identical(libs):
     ref, our = libs
     for size in (2, 4, 8, 16, 64):
