@@ -401,11 +401,55 @@ struct pl_var {
     int dim_a;      // array dimension
 };
 
+// Constructors for the GLSL types a variable can have (gpu.h:975-997), the same list tagged by
+// type name and {0}-terminated, and the lookup the other way round (NULL: no such GLSL type; the
+// array dimension is not part of a type name).
+PL_API struct pl_var pl_var_float(const char *name);
+PL_API struct pl_var pl_var_vec2(const char *name);
+PL_API struct pl_var pl_var_vec3(const char *name);
+PL_API struct pl_var pl_var_vec4(const char *name);
+PL_API struct pl_var pl_var_mat2(const char *name);
+PL_API struct pl_var pl_var_mat2x3(const char *name);
+PL_API struct pl_var pl_var_mat2x4(const char *name);
+PL_API struct pl_var pl_var_mat3(const char *name);
+PL_API struct pl_var pl_var_mat3x4(const char *name);
+PL_API struct pl_var pl_var_mat4x2(const char *name);
+PL_API struct pl_var pl_var_mat4x3(const char *name);
+PL_API struct pl_var pl_var_mat4(const char *name);
+PL_API struct pl_var pl_var_int(const char *name);
+PL_API struct pl_var pl_var_ivec2(const char *name);
+PL_API struct pl_var pl_var_ivec3(const char *name);
+PL_API struct pl_var pl_var_ivec4(const char *name);
+PL_API struct pl_var pl_var_uint(const char *name);
+PL_API struct pl_var pl_var_uvec2(const char *name);
+PL_API struct pl_var pl_var_uvec3(const char *name);
+PL_API struct pl_var pl_var_uvec4(const char *name);
+
+struct pl_named_var {
+    const char *glsl_name;
+    struct pl_var var;
+};
+PL_API extern const struct pl_named_var pl_var_glsl_types[];
+PL_API const char *pl_var_glsl_type_name(struct pl_var var);
+// the variable a texel of `fmt` reads as in a shader (normalised formats read as floats)
+PL_API struct pl_var pl_var_from_fmt(pl_fmt fmt, const char *name);
+
 struct pl_var_layout {
     size_t offset;
     size_t stride;
     size_t size;
 };
+
+// Where a variable goes in a buffer (gpu.h:1019-1050): tightly packed on the host, or by the
+// std140 / std430 rules of the GLSL specification (matrices are arrays of columns; vec3 aligns
+// like vec4; std140 rounds the stride of arrays and matrices up to a vec4). `offset` is the first
+// free byte; the layout's own offset is that rounded up to the variable's alignment.
+// memcpy_layout copies a variable column by column between two layouts of it.
+PL_API struct pl_var_layout pl_var_host_layout(size_t offset, const struct pl_var *var);
+PL_API struct pl_var_layout pl_std140_layout(size_t offset, const struct pl_var *var);
+PL_API struct pl_var_layout pl_std430_layout(size_t offset, const struct pl_var *var);
+PL_API void memcpy_layout(void *dst, struct pl_var_layout dst_layout,
+                          const void *src, struct pl_var_layout src_layout);
 
 struct pl_constant {
     enum pl_var_type type;
@@ -429,6 +473,9 @@ enum pl_desc_access {
     PL_DESC_ACCESS_WRITEONLY,
     PL_DESC_ACCESS_COUNT,
 };
+
+// "", "readonly", "writeonly": the GLSL qualifier of an access mode (gpu.h:1102)
+PL_API const char *pl_desc_access_glsl_name(enum pl_desc_access mode);
 
 struct pl_desc {
     const char *name;

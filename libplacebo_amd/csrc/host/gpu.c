@@ -99,6 +99,113 @@ size_t pl_var_type_size(enum pl_var_type type)
     return type == PL_VAR_SINT || type == PL_VAR_UINT || type == PL_VAR_FLOAT ? 4 : 0;
 }
 
+/* ---- shader variables: types and buffer layouts (src/gpu.c:745-948) --------------------------- */
+// One table for the constructors, the named list and the name lookup: GLSL type name, base type,
+// columns, rows. (mat3x2 has a name but, as in the reference, no constructor and no list entry.)
+#define VAR_TYPES(X)                                                                            \
+    X(float, FLOAT, 1, 1) X(vec2, FLOAT, 1, 2) X(vec3, FLOAT, 1, 3) X(vec4, FLOAT, 1, 4)        \
+    X(mat2, FLOAT, 2, 2) X(mat2x3, FLOAT, 2, 3) X(mat2x4, FLOAT, 2, 4) X(mat3, FLOAT, 3, 3)      \
+    X(mat3x4, FLOAT, 3, 4) X(mat4x2, FLOAT, 4, 2) X(mat4x3, FLOAT, 4, 3) X(mat4, FLOAT, 4, 4)    \
+    X(int, SINT, 1, 1) X(ivec2, SINT, 1, 2) X(ivec3, SINT, 1, 3) X(ivec4, SINT, 1, 4)            \
+    X(uint, UINT, 1, 1) X(uvec2, UINT, 1, 2) X(uvec3, UINT, 1, 3) X(uvec4, UINT, 1, 4)
+
+#define X(glsl, T, M, V)                                                                        \
+    struct pl_var pl_var_##glsl(const char *name)                                                \
+    {                                                                                           \
+        return (struct pl_var) { .name = name, .type = PL_VAR_##T, .dim_v = V, .dim_m = M, .dim_a = 1 }; \
+    }
+VAR_TYPES(X)
+#undef X
+
+const struct pl_named_var pl_var_glsl_types[] = {
+#define X(glsl, T, M, V) { #glsl, { .type = PL_VAR_##T, .dim_v = V, .dim_m = M, .dim_a = 1 } },
+    VAR_TYPES(X)
+#undef X
+    {0},
+};
+
+const char *pl_var_glsl_type_name(struct pl_var var)
+{
+    for (const struct pl_named_var *n = pl_var_glsl_types; n->glsl_name; n++) {
+        if (n->var.type == var.type && n->var.dim_m == var.dim_m && n->var.dim_v == var.dim_v)
+            return n->glsl_name;
+    }
+    if (var.type == PL_VAR_FLOAT && var.dim_m == 3 && var.dim_v == 2)
+        return "mat3x2";
+    return NULL;
+}
+
+struct pl_var pl_var_from_fmt(pl_fmt fmt, const char *name)
+{
+    const enum pl_var_type type = fmt->type == PL_FMT_UINT ? PL_VAR_UINT :
+                                  fmt->type == PL_FMT_SINT ? PL_VAR_SINT : PL_VAR_FLOAT;
+    return (struct pl_var) { .name = name, .type = type, .dim_v = fmt->num_components,
+                             .dim_m = 1, .dim_a = 1 };
+}
+
+enum var_packing { PACK_HOST, PACK_STD140, PACK_STD430 };
+
+static struct pl_var_layout var_layout(enum var_packing rule, size_t offset, const struct pl_var *var)
+{
+    const size_t scalar = pl_var_type_size(var->type);
+    const size_t columns = (size_t) var->dim_m * var->dim_a;    // a matrix is an array of columns
+    size_t stride = scalar * var->dim_v, align = 1;
+    if (rule != PACK_HOST) {
+        // a vector aligns to its size, a three-component one like a four-component one; the
+        // columns of an array / matrix are spaced by that alignment, which std140 rounds up to
+        // a vec4's
+        align = scalar * (var->dim_v == 3 ? 4 : var->dim_v);
+        if (columns > 1) {
+            if (rule == PACK_STD140)
+                align = (align + 15) / 16 * 16;
+            stride = align;
+        }
+    }
+    return (struct pl_var_layout) {
+        .offset = (offset + align - 1) / align * align,
+        .stride = stride,
+        .size   = stride * columns,
+    };
+}
+
+struct pl_var_layout pl_var_host_layout(size_t offset, const struct pl_var *var)
+{
+    return var_layout(PACK_HOST, offset, var);
+}
+
+struct pl_var_layout pl_std140_layout(size_t offset, const struct pl_var *var)
+{
+    return var_layout(PACK_STD140, offset, var);
+}
+
+struct pl_var_layout pl_std430_layout(size_t offset, const struct pl_var *var)
+{
+    return var_layout(PACK_STD430, offset, var);
+}
+
+void memcpy_layout(void *dst, struct pl_var_layout dst_layout,
+                   const void *src, struct pl_var_layout src_layout)
+{
+    uint8_t *d = (uint8_t *) dst + dst_layout.offset;
+    const uint8_t *s = (const uint8_t *) src + src_layout.offset;
+    if (src_layout.stride == dst_layout.stride) {
+        memcpy(d, s, src_layout.size);      // same spacing: one block
+        return;
+    }
+    // column by column, as many bytes as the narrower spacing holds
+    const size_t column = PL_MIN(src_layout.stride, dst_layout.stride);
+    for (size_t done = 0; done < src_layout.size; done += src_layout.stride) {
+        memcpy(d, s + done, column);
+        d += dst_layout.stride;
+    }
+}
+
+const char *pl_desc_access_glsl_name(enum pl_desc_access mode)
+{
+    return mode == PL_DESC_ACCESS_READONLY ? "readonly" :
+           mode == PL_DESC_ACCESS_WRITEONLY ? "writeonly" : "";
+}
+
 int pl_desc_namespace(pl_gpu gpu, enum pl_desc_type type)
 {
     (void) gpu;

@@ -51,4 +51,11 @@ gcc $CFLAGS -c "$HERE/ref_shim.c" -o "$OUT/obj/ref_shim.o"
 # cpu_baseline leg, kind "reference"); built with the reference's own flags + OpenMP
 gcc $CFLAGS -fopenmp -c "$HERE/cpu_baseline.c" -o "$OUT/obj/cpu_baseline.o"
 g++ -shared -fopenmp -Wl,--no-undefined -Wl,-Bsymbolic -o "$OUT/libplref.so" $OBJS "$OUT/obj/convert.o" "$OUT/obj/ref_shim.o" "$OUT/obj/cpu_baseline.o" -lm -lpthread
-echo "built $OUT/libplref.so"
+# the reference's src/gpu.c on its own: its shader-variable constructors and std140 / std430 layout
+# functions are pure (tests/test_host.py holds the product's to them); libplref.so cannot take it,
+# its shim stands in for half of that file's entry points
+gcc $CFLAGS -c "$REF/src/gpu.c" -o "$OUT/obj/gpu.o"
+gcc $CFLAGS -c "$HERE/ref_gpu_shim.c" -o "$OUT/obj/ref_gpu_shim.o"
+gcc -shared -Wl,--no-undefined -Wl,-Bsymbolic -o "$OUT/libplref_gpu.so" "$OUT/obj/gpu.o" "$OUT/obj/ref_gpu_shim.o" \
+    "$OUT/obj/common.o" "$OUT/obj/log.o" "$OUT/obj/pl_alloc.o" "$OUT/obj/pl_string.o" "$OUT/obj/format.o" "$OUT/obj/convert.o" -lstdc++ -lm -lpthread
+echo "built $OUT/libplref.so, $OUT/libplref_gpu.so"

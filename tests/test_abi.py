@@ -61,7 +61,8 @@ def test_library_exports_nothing_but_the_api(built):
                          text=True, check=True).stdout
     names = [ln.split()[-1] for ln in out.splitlines() if ln.split()[1:2] and
              ln.split()[-2] in "TDBR"]
-    stray = [n for n in names if not (n.startswith("pl_") or n.startswith("plh_test_")
+    # (memcpy_layout: the one public function of the reference without the prefix, gpu.h:1048)
+    stray = [n for n in names if not (n.startswith("pl_") or n.startswith("plh_test_") or n == "memcpy_layout"
                                       or n.startswith("__hip") or n.startswith("_Z")
                                       or n.startswith("__"))]
     assert not stray, stray[:20]

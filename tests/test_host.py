@@ -133,3 +133,75 @@ def test_icc_entry_points_of_a_build_without_lcms():
     L.pl_icc_close.argtypes = [C.POINTER(C.c_void_p)]
     L.pl_icc_close(C.byref(obj))
     assert not obj.value
+
+
+def test_shader_variable_helpers_match_the_reference():
+    """pl_var_<type>() / pl_var_glsl_types / pl_var_glsl_type_name and the host / std140 / std430
+    layouts (src/gpu.c:745-948) against the reference's own gpu.c (oracle/_ref/libplref_gpu.so):
+    every GLSL type, array lengths 1 and 3, every starting offset 0..19; memcpy_layout moves a
+    mat3 from its host layout into its std140 one column by column."""
+    import ctypes as C
+    import os
+    import numpy as np
+    import libplacebo_amd as pl
+    path = os.path.join(os.path.dirname(__file__), "..", "oracle", "_ref", "libplref_gpu.so")
+    if not os.path.exists(path):
+        pytest.skip("oracle/_ref/libplref_gpu.so not built")
+    ref, our = C.CDLL(path), pl.lib()
+
+    class Var(C.Structure):
+        _fields_ = [("name", C.c_char_p), ("type", C.c_int), ("dim_v", C.c_int), ("dim_m", C.c_int),
+                    ("dim_a", C.c_int)]
+
+    class Named(C.Structure):
+        _fields_ = [("glsl_name", C.c_char_p), ("var", Var)]
+
+    class Layout(C.Structure):
+        _fields_ = [("offset", C.c_size_t), ("stride", C.c_size_t), ("size", C.c_size_t)]
+
+    def tup(v):
+        return (v.type, v.dim_v, v.dim_m, v.dim_a)
+
+    names = []
+    for lib in (ref, our):
+        lib.pl_var_glsl_type_name.restype = C.c_char_p
+        lib.pl_var_glsl_type_name.argtypes = [Var]
+        for f in ("pl_var_host_layout", "pl_std140_layout", "pl_std430_layout"):
+            getattr(lib, f).restype = Layout
+            getattr(lib, f).argtypes = [C.c_size_t, C.POINTER(Var)]
+        tab = (Named * 21).in_dll(lib, "pl_var_glsl_types")
+        assert not tab[20].glsl_name
+        names.append([(tab[i].glsl_name, tup(tab[i].var)) for i in range(20)])
+    assert names[0] == names[1] and len(set(n for n, _ in names[0])) == 20
+    for glsl, (ty, v, m, a) in names[0]:
+        ctor = "pl_var_" + glsl.decode()
+        for lib in (ref, our):
+            getattr(lib, ctor).restype = Var
+            getattr(lib, ctor).argtypes = [C.c_char_p]
+        rv, ov = getattr(ref, ctor)(b"x"), getattr(our, ctor)(b"x")
+        assert tup(rv) == tup(ov) == (ty, v, m, 1) and ov.name == b"x"
+        assert ref.pl_var_glsl_type_name(ov) == our.pl_var_glsl_type_name(ov) == glsl
+        for dim_a in (1, 3):
+            ov.dim_a = dim_a
+            for off in range(20):
+                for f in ("pl_var_host_layout", "pl_std140_layout", "pl_std430_layout"):
+                    r, o = getattr(ref, f)(off, C.byref(ov)), getattr(our, f)(off, C.byref(ov))
+                    assert (r.offset, r.stride, r.size) == (o.offset, o.stride, o.size), (glsl, dim_a, off, f)
+    odd = Var(b"m", 3, 2, 3, 1)      # mat3x2: a name, no constructor
+    assert ref.pl_var_glsl_type_name(odd) == our.pl_var_glsl_type_name(odd) == b"mat3x2"
+    assert our.pl_var_glsl_type_name(Var(b"n", 1, 2, 2, 1)) is None     # no integer matrices
+    # a few layouts spelled out (GLSL 4.60 section 7.6.2.2)
+    mat3 = our.pl_var_mat3(b"m")
+    h, s140 = our.pl_var_host_layout(0, C.byref(mat3)), our.pl_std140_layout(4, C.byref(mat3))
+    assert (h.stride, h.size) == (12, 36) and (s140.offset, s140.stride, s140.size) == (16, 16, 48)
+    vec3 = our.pl_var_vec3(b"v")
+    s = our.pl_std430_layout(4, C.byref(vec3))
+    assert (s.offset, s.stride, s.size) == (16, 12, 12)
+    our.memcpy_layout.argtypes = [C.c_void_p, Layout, C.c_void_p, Layout]
+    src = np.arange(9, dtype=np.float32)
+    dst = np.full(16 + 48 // 4, -1.0, np.float32)
+    our.memcpy_layout(dst.ctypes.data, s140, src.ctypes.data, h)
+    got = dst[4:16].reshape(3, 4)
+    assert np.array_equal(got[:, :3], src.reshape(3, 3)) and np.all(got[:, 3] == -1) and np.all(dst[:4] == -1)
+    our.pl_desc_access_glsl_name.restype = C.c_char_p
+    assert [our.pl_desc_access_glsl_name(i) for i in range(3)] == [b"", b"readonly", b"writeonly"]
