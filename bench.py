@@ -46,6 +46,7 @@ every frame's measurement pass the 816-word peak buffer is all-reduced over RCCL
 frame_max_pq) before the tone mapper consumes it (BASELINE configs[4]).
 """
 import argparse
+import gc
 import ctypes as C
 import json
 import os
@@ -684,6 +685,19 @@ def prime(st, seconds=None):
 
 
 def run_timed(st, steps, warmup, sync=None, barrier=None):
+    # (like timeit: no cyclic garbage collection inside the timed region -- a collection that lands
+    # in a 20-step run is one frame time of host stall, 5 % of the figure)
+    gc_was = gc.isenabled()
+    gc.collect()
+    gc.disable()
+    try:
+        return _run_timed(st, steps, warmup, sync, barrier)
+    finally:
+        if gc_was:
+            gc.enable()
+
+
+def _run_timed(st, steps, warmup, sync=None, barrier=None):
     for _ in range(warmup):
         st.step()
     st.g.finish()
