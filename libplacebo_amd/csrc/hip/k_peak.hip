@@ -466,13 +466,14 @@ void k_peak_fast(const plh_pass p_)
  *   - count / lit count / sum of means / maximum live in registers for the whole walk and the
  *     histogram in one 64-word LDS array per workgroup (black pixels taken out of bin 0 once, at
  *     the end: the sums are integer, their order is free);
- *   - the next tile's texels are in flight while the current one is measured;
+ *   - it needs 30 registers (one row of a lane's two at a time): one of its waves fits on a SIMD
+ *     beside the four waves of the metric's scaler, whose launch the pass then runs inside;
  *   - a workgroup leaves 4 + (bins it touched) global atomics behind, into a layout in which the
- *     scalar words of a slice have a 128-byte line each (85 workgroups per line and frame);
+ *     scalar words of a slice have a 128-byte line each (at most 170 workgroups per line and frame);
  *   - the workgroup that finishes last gathers the 816 words into the result buffer and the
  *     host's mailbox, zeroes the scratch words and publishes the ticket: no second kernel.
  * Same per-pixel code, same tiles, same integer sums as k_peak_fast / k_pass_peak: the 816 words
- * are identical (tests/test_gpu_peak.py).
+ * are identical (tests/test_gpu_kernel_variants.py::test_peak_fast_equals_generic).
  */
 #define PEAK_PAD 32     // words between the scalar accumulators of the scratch layout (one line each)
 #define PEAK_TICKETS 4096    // word offset of the 12 + 1 ticket counters (a line each), behind the 2304 data words
@@ -648,21 +649,19 @@ void k_peak_tiles(const plh_pass p_)
     // access to those words is performed at the point where the XCDs' atomics meet. A workgroup
     // takes its ticket after its own atomics have RETURNED (their results are consumed here).
     uint32_t *scratch = (uint32_t *) p.peak_scratch;
-    if (wave == 0) {
-        uint32_t seen = 0;
-        if (lane < 4) {
-            const uint32_t v = blk[lane];
-            uint32_t *d = peak_pad_word(scratch, (uint32_t) lane * PEAK_SLICES + slice);
-            if (lane == 3)
-                seen += atomicMax(d, v);
-            else if (v)
-                seen += atomicAdd(d, v);
-        }
-        const uint32_t n = blk[4 + lane];
-        if (use_hist && n)
-            seen += atomicAdd(peak_pad_word(scratch, 4 * PEAK_SLICES + slice * PEAK_HIST_BINS + (uint32_t) lane), n);
-        asm volatile("" :: "v"(seen));
+    uint32_t seen = 0;
+    if (lane < 4) {
+        const uint32_t v = blk[lane];
+        uint32_t *d = peak_pad_word(scratch, (uint32_t) lane * PEAK_SLICES + slice);
+        if (lane == 3)
+            seen += atomicMax(d, v);
+        else if (v)
+            seen += atomicAdd(d, v);
     }
+    const uint32_t n = blk[4 + lane];
+    if (use_hist && n)
+        seen += atomicAdd(peak_pad_word(scratch, 4 * PEAK_SLICES + slice * PEAK_HIST_BINS + (uint32_t) lane), n);
+    asm volatile("" :: "v"(seen));
     // tickets in two levels -- per slice, then one for the slices -- so that no word sees more than
     // gridDim.x / 12 of these returning atomics (2040 on one word were 9 us of the kernel)
     uint32_t *tickets = scratch + PEAK_TICKETS;
