@@ -192,3 +192,20 @@ def test_tiny_planar_video_frames(gpu, preset, size):
         assert d.max() <= 64 and ((d > 0).mean() <= 0.02 or d.size <= 256), (size, d.max(), (d > 0).mean())
     else:
         assert d.max() == 0, (size, d.max(), np.argwhere(d > 0)[:3])
+
+
+@pytest.mark.parametrize("size", [((16384, 24), (16384, 24)), ((24, 16384), (24, 16384)),
+                                  ((8192, 18), (16384, 36)), ((18, 8192), (36, 16384))])
+@pytest.mark.parametrize("preset,hdr", [("fast", False), ("default", False), ("default", True)])
+def test_very_wide_and_very_tall_frames(gpu, preset, hdr, size):
+    """16384 texels along one axis, a couple of tiles along the other: index arithmetic, pitches and
+    the measuring pass's tile walk at the far end of a row / column (default = generic kernels)."""
+    (sw, sh), (dw, dh) = size
+    img = frame16(sw, sh, sw + sh)
+    fast = render(gpu, img, dw, dh, preset, hdr, {})
+    slow = render(gpu, img, dw, dh, preset, hdr, GENERIC)
+    d = np.abs(fast.astype(np.int64) - slow.astype(np.int64))
+    if hdr:
+        assert d.max() <= 192 and (d > 64).mean() <= 5e-3 and (d > 0).mean() <= 0.05, (d.max(), (d > 0).mean())
+    else:
+        assert d.max() == 0, (d.max(), np.argwhere(d > 0)[:3])
