@@ -18,6 +18,7 @@
 #include <math.h>
 #include <stdlib.h>
 #include <string.h>
+#include <time.h>
 
 #include <libplacebo/shaders/colorspace.h>
 
@@ -646,6 +647,12 @@ static void peak_filter(float *avg_pq, float *max_pq, struct peak_sample in,
     }
 }
 
+// (profiling hook, tools/r05_22.py: nanoseconds the host has spent waiting for measurements since
+// the last call -- what separates "the host is the bottleneck" from "the host waits for the GPU")
+static long plh_dbg_wait_ns;
+PL_API long plh_test_peak_wait_ns(void);
+long plh_test_peak_wait_ns(void) { const long v = plh_dbg_wait_ns; plh_dbg_wait_ns = 0; return v; }
+
 // Take the outstanding measurement, if there is one and it may be taken now.
 // `must`: the caller is about to reuse the buffer -- wait for the pass rather than give up.
 static void peak_collect(pl_gpu gpu, struct sh_color_map_obj *obj, bool must)
@@ -676,6 +683,8 @@ static void peak_collect(pl_gpu gpu, struct sh_color_map_obj *obj, bool must)
         // that word (a few microseconds after the kernel retires, against ~20 for a stream
         // wait plus a copy). Bounded: a lost kernel must not hang the caller.
         volatile const uint32_t *seen = (volatile const uint32_t *) obj->peak.mirror + PEAK_WORDS;
+        struct timespec w0, w1;
+        clock_gettime(CLOCK_MONOTONIC, &w0);
         for (long spin = 0; spin < 200000000L && !have; spin++) {
             have = __atomic_load_n(seen, __ATOMIC_ACQUIRE) == obj->peak.ticket;
             if (!have && (spin & 1023) == 1023 && plh_event_query(obj->peak.written) != 0)
@@ -683,6 +692,8 @@ static void peak_collect(pl_gpu gpu, struct sh_color_map_obj *obj, bool must)
         }
         if (!have)
             have = __atomic_load_n(seen, __ATOMIC_ACQUIRE) == obj->peak.ticket;
+        clock_gettime(CLOCK_MONOTONIC, &w1);
+        plh_dbg_wait_ns += (w1.tv_sec - w0.tv_sec) * 1000000000L + (w1.tv_nsec - w0.tv_nsec);
     } else {
         // ranks rendering one scene fold their measurements together first (hip.h); the
         // exchange works on the device buffer, which is then copied back
