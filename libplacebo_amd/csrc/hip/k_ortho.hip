@@ -296,6 +296,9 @@ void k_ortho_fast(const plh_pass p_)
     // load: 6 loads instead of 12 for a 6-tap filter
     constexpr bool WIDE = SRC == PLH_FMT_RGBA16 || SRC == PLH_FMT_RGBA16F;
     const bool pair64 = DIR && WIDE && shift == 0 && o0[1] == o0[0] + 1;
+    // ... and in a horizontal pass whose two windows overlap (a 2x upscale), away from the sides,
+    // the N + 1 consecutive texels are N / 2 + 1 such loads instead of N + 1 eight-byte ones
+    const bool wide_h = !DIR && WIDE && NT != 16 && overlap && first[0] >= 0 && first[0] + NT + 2 <= na;
     uint2 extra = make_uint2(0, 0);
     if (pair64) {
 #pragma unroll
@@ -307,6 +310,22 @@ void k_ortho_fast(const plh_pass p_)
             __builtin_memcpy(v, (const void *) (row + (size_t) o0[0] * 8), 16);
             raw[0][n] = make_uint2(v[0], v[1]);
             raw[1][n] = make_uint2(v[2], v[3]);
+        }
+    } else if (wide_h) {
+        // horizontal pass: the N + 1 texels of the two overlapping windows as 16-byte pairs
+#pragma unroll
+        for (int k = 0; k < NT / 2 + 1; k++) {
+            const OF_GLOBAL char *row = (const OF_GLOBAL char *) (uintptr_t) sp + (size_t) o0[0] * spitch;
+            uint32_t v[4];
+            __builtin_memcpy(v, (const void *) (row + (size_t) (first[0] + 2 * k) * 8), 16);
+            if (2 * k < NT)
+                raw[0][2 * k] = make_uint2(v[0], v[1]);
+            else
+                extra = make_uint2(v[0], v[1]);
+            if (2 * k + 1 < NT)
+                raw[0][2 * k + 1] = make_uint2(v[2], v[3]);
+            else if (2 * k + 1 == NT)
+                extra = make_uint2(v[2], v[3]);
         }
     } else if (pair16) {
 #pragma unroll
@@ -328,7 +347,8 @@ void k_ortho_fast(const plh_pass p_)
     if (pair16 || pair64) {
         // (both pixels' taps are in)
     } else if (overlap) {
-        extra = of_load<SRC>(sp, spitch, of_tap(first[0] + N, na, mirror), o0[0]);
+        if (!wide_h)
+            extra = of_load<SRC>(sp, spitch, of_tap(first[0] + N, na, mirror), o0[0]);
     } else {
 #pragma unroll
         for (int n = 0; n < NT; n++) {
