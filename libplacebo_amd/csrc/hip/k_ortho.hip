@@ -265,6 +265,24 @@ void k_ortho_fast(const plh_pass p_)
     const float my = p.out_scale[1] * ((float) idy + 0.5f);
     const bool mirror = s.address_mode == PLH_ADDRESS_MIRROR;
 
+    // The weight table (256 phases x the padded tap count: 4-8 KiB for 4 / 6 / 8 taps) is staged in
+    // LDS once per workgroup -- one row per thread -- and the two rows that bracket a pixel's phase
+    // are read from there: a horizontal pass otherwise issues 8 more vector-memory loads per lane
+    // (2 pixels x 2 rows x 2 float4) than it has texel loads, and the pass is not free of its load
+    // count (with all of them switched off it ran 52 -> 44 us, profiles/r05_25).
+    // (horizontal passes only: a vertical pass's two pixels share their rows -- 4 loads -- and the
+    // staging + barrier cost it 1 us where they save the horizontal pass 1-5, profiles/r05_28)
+    constexpr bool LDS_LUT = NT != 16 && DIR == 0;
+    constexpr int LUT_STRIDE = (NT + 3) / 4 * 4;
+    __shared__ float4 lut_s[LDS_LUT ? 256 * LUT_STRIDE / 4 : 1];
+    if constexpr (LDS_LUT) {
+        const int row = threadIdx.y * ORTHO_BW + threadIdx.x;      // 0 .. 255
+        const float4 *g = (const float4 *) (s.weights + (size_t) row * LUT_STRIDE);
+#pragma unroll
+        for (int j = 0; j < LUT_STRIDE / 4; j++)
+            lut_s[row * (LUT_STRIDE / 4) + j] = g[j];
+    }
+
     uint2 raw[2][NT];
     float w[2][NT];
     int first[2], o0[2];
@@ -373,6 +391,8 @@ void k_ortho_fast(const plh_pass p_)
     // weights: LUT rows bracketing fcoord (linear LUT, lut.c:700-715 semantics). Pixels with
     // the same fcoord (every pair of a vertical pass, bar rounding ties) share them.
     const bool same_w = __float_as_uint(fcoord[1]) == __float_as_uint(fcoord[0]);
+    if constexpr (LDS_LUT)
+        __syncthreads();    // (the staged table; the texel loads above are in flight behind it)
 #pragma unroll
     for (int q = 0; q < 2; q++) {
         if (q == 1 && same_w)
@@ -380,8 +400,14 @@ void k_ortho_fast(const plh_pass p_)
         const float fpos = plh_clamp(fcoord[q], 0.0f, 1.0f) * 255.0f;
         const float fbase = __builtin_floorf(fpos);
         const float fr = fpos - fbase;
-        const float4 *r0 = (const float4 *) (s.weights + (size_t) (int) fbase * s.row_stride);
-        const float4 *r1 = (const float4 *) (s.weights + (size_t) min((int) fbase + 1, 255) * s.row_stride);
+        const float4 *r0, *r1;
+        if constexpr (LDS_LUT) {
+            r0 = lut_s + (int) fbase * (LUT_STRIDE / 4);
+            r1 = lut_s + min((int) fbase + 1, 255) * (LUT_STRIDE / 4);
+        } else {
+            r0 = (const float4 *) (s.weights + (size_t) (int) fbase * s.row_stride);
+            r1 = (const float4 *) (s.weights + (size_t) min((int) fbase + 1, 255) * s.row_stride);
+        }
         float ra[NT], rb[NT];
 #pragma unroll
         for (int j = 0; j < NT / 4 + (NT % 4 != 0); j++) {
@@ -512,11 +538,14 @@ static void launch_ortho_fast(hipStream_t stream, const plh_pass *pass, int epi)
         if (pass->s.dir) PLH_LAUNCH_LAST((k_ortho_fast<SRC, E, 1, NT>), grid, block, 0, stream, *pass); \
         else             PLH_LAUNCH_LAST((k_ortho_fast<SRC, E, 0, NT>), grid, block, 0, stream, *pass); \
     } while (0)
+    // (the variants with the tap count at compile time stage the weight table in LDS and take its
+    // row pitch from the tap count: rows padded to a multiple of four floats, as the host makes them)
+    const bool packed_rows = pass->s.row_stride == (pass->s.row_size + 3) / 4 * 4;
 #define LAUNCH(E) do { \
-        if (pass->s.row_size == 4)      LAUNCH_N(E, 4); \
-        else if (pass->s.row_size == 6) LAUNCH_N(E, 6); \
-        else if (pass->s.row_size == 8) LAUNCH_N(E, 8); \
-        else                            LAUNCH_N(E, 16); \
+        if (pass->s.row_size == 4 && packed_rows)      LAUNCH_N(E, 4); \
+        else if (pass->s.row_size == 6 && packed_rows) LAUNCH_N(E, 6); \
+        else if (pass->s.row_size == 8 && packed_rows) LAUNCH_N(E, 8); \
+        else                                           LAUNCH_N(E, 16); \
     } while (0)
     if (pass->s.use_linear) {
         // linear-trick filters (bicubic / gaussian / hermite ... low-pass), any tap count; colour
@@ -528,9 +557,9 @@ static void launch_ortho_fast(hipStream_t stream, const plh_pass *pass, int epi)
             else             PLH_LAUNCH_LAST((k_ortho_fast<SRC, E, 0, NT, true>), grid, block, 0, stream, *pass); \
         } while (0)
 #define LAUNCH_LIN(E) do { \
-            if (pass->s.row_size == 4)      LAUNCH_LIN_N(E, 4); \
-            else if (pass->s.row_size == 8) LAUNCH_LIN_N(E, 8); \
-            else                            LAUNCH_LIN_N(E, 16); \
+            if (pass->s.row_size == 4 && packed_rows)      LAUNCH_LIN_N(E, 4); \
+            else if (pass->s.row_size == 8 && packed_rows) LAUNCH_LIN_N(E, 8); \
+            else                                           LAUNCH_LIN_N(E, 16); \
         } while (0)
         if constexpr (SRC == PLH_FMT_RGBA16 || SRC == PLH_FMT_RGBA16F) {
             if (epi == 1)      LAUNCH_LIN(1);
