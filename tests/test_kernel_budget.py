@@ -68,7 +68,8 @@ BUDGET = [
     # the map chain as straight-line code: all 8 wave slots (7 with contrast recovery compiled in)
     (r"k_pass_features<(true|false)>", 8),
     (r"k_pass_merge<(true|false)>.*", 8),
-    (r"k_pass_chain<(true|false), 1, false, (true|false)>", 8),
+    (r"k_pass_chain<(true|false), 1, false, false>", 8),
+    (r"k_pass_chain<(true|false), 2, false, true>", 8),     # (into the f16 intermediate: two pixels per lane)
     (r"k_pass_chain<(true|false), 1, true, false>", 8),
     (r"k_peak_fast<(true|false), [012]>", 8),
     (r"k_peak_tiles<(true|false), [01], (true|false)>", 8),
