@@ -304,57 +304,55 @@ void k_ortho_fast(const plh_pass p_)
     // the second pixel's taps are the first one's shifted -> N + 1 loads instead of 2N.
     const int shift = first[1] - first[0];
     const bool overlap = !DIR && o0[1] == o0[0] && (shift == 0 || shift == 1);
-    // Vertical pass over a one-component 16-bit plane (the contrast-recovery feature plane): the
-    // lane's two pixels sit on adjacent columns of the same rows, so ONE 4-byte load per tap row
-    // serves both (the pass is bound by the number of load instructions -- each is 64 addresses
-    // for the texture addresser, whatever it fetches --, not by their bytes).
-    constexpr bool ONE16 = SRC == PLH_FMT_R16 || SRC == PLH_FMT_R16F;
-    const bool pair16 = DIR && ONE16 && shift == 0 && o0[1] == o0[0] + 1;
-    // ... and over an 8-byte texel source (the first pass of every separable upscale) ONE 16-byte
-    // load: 6 loads instead of 12 for a 6-tap filter
-    constexpr bool WIDE = SRC == PLH_FMT_RGBA16 || SRC == PLH_FMT_RGBA16F;
-    const bool pair64 = DIR && WIDE && shift == 0 && o0[1] == o0[0] + 1;
-    // ... and in a horizontal pass whose two windows overlap (a 2x upscale), away from the sides,
-    // the N + 1 consecutive texels are N / 2 + 1 such loads instead of N + 1 eight-byte ones
-    const bool wide_h = !DIR && WIDE && NT != 16 && overlap && first[0] >= 0 && first[0] + NT + 2 <= na;
+    // Bytes of a texel of this source; the raw form of texel i of a run of bytes that was loaded in
+    // 16-byte pieces (what of_load returns for it: the texel's bits in the low end of .x, .y for
+    // the second half of an 8-byte one)
+    constexpr int TB = (SRC == PLH_FMT_RGBA16 || SRC == PLH_FMT_RGBA16F) ? 8 :
+                       (SRC == PLH_FMT_RG16 || SRC == PLH_FMT_RG16F) ? 4 :
+                       (SRC == PLH_FMT_R16 || SRC == PLH_FMT_R16F || SRC == PLH_FMT_RG8) ? 2 : 1;
+    auto texel_of = [](const uint32_t *wds, int i) {
+        if constexpr (TB == 8)
+            return make_uint2(wds[2 * i], wds[2 * i + 1]);
+        else if constexpr (TB == 4)
+            return make_uint2(wds[i], 0);
+        else if constexpr (TB == 2)
+            return make_uint2((wds[i >> 1] >> (16 * (i & 1))) & 0xffffu, 0);
+        else
+            return make_uint2((wds[i >> 2] >> (8 * (i & 3))) & 0xffu, 0);
+    };
+    // Vertical pass: the lane's two pixels sit on adjacent columns of the same rows, so ONE load of
+    // two texels per tap row serves both -- 6 loads instead of 12 for a 6-tap filter (a pass is not
+    // free of the NUMBER of its loads: each is 64 addresses for the texture addresser, whatever it
+    // fetches; profiles/r05_summary.md).
+    const bool pair_v = DIR && shift == 0 && o0[1] == o0[0] + 1;
+    // Horizontal pass whose two windows overlap (a 2x upscale: every chroma plane of 4:2:0 video,
+    // every default-preset upscale), away from the sides: the N + 1 consecutive texels as 16-byte
+    // pieces -- 4 loads instead of 7 for 8-byte texels, ONE for the 14 bytes of an rg8 plane
+    constexpr int HB = (NT + 1) * TB, HL = (HB + 15) / 16;      // bytes wanted, 16-byte loads
+    const bool wide_h = !DIR && NT != 16 && overlap && first[0] >= 0 && first[0] * TB + HL * 16 <= na * TB;
     uint2 extra = make_uint2(0, 0);
-    if (pair64) {
+    if (pair_v) {
 #pragma unroll
         for (int n = 0; n < NT; n++) {
             const int iw = of_tap(first[0] + min(n, N - 1), na, mirror);
             const OF_GLOBAL char *row = (const OF_GLOBAL char *) (uintptr_t) sp + (size_t) iw * spitch;
-            // (8-byte aligned: assembled from the bytes, one global_load_dwordx4)
-            uint32_t v[4];
-            __builtin_memcpy(v, (const void *) (row + (size_t) o0[0] * 8), 16);
-            raw[0][n] = make_uint2(v[0], v[1]);
-            raw[1][n] = make_uint2(v[2], v[3]);
+            // (aligned to the texel only: assembled from the bytes, which is one load instruction)
+            uint32_t wds[4] = { 0, 0, 0, 0 };
+            __builtin_memcpy(wds, (const void *) (row + (size_t) o0[0] * TB), 2 * TB);
+            raw[0][n] = texel_of(wds, 0);
+            raw[1][n] = texel_of(wds, 1);
         }
     } else if (wide_h) {
-        // horizontal pass: the N + 1 texels of the two overlapping windows as 16-byte pairs
+        uint32_t wds[4 * HL];
+        const OF_GLOBAL char *row = (const OF_GLOBAL char *) (uintptr_t) sp + (size_t) o0[0] * spitch +
+                                    (size_t) first[0] * TB;
 #pragma unroll
-        for (int k = 0; k < NT / 2 + 1; k++) {
-            const OF_GLOBAL char *row = (const OF_GLOBAL char *) (uintptr_t) sp + (size_t) o0[0] * spitch;
-            uint32_t v[4];
-            __builtin_memcpy(v, (const void *) (row + (size_t) (first[0] + 2 * k) * 8), 16);
-            if (2 * k < NT)
-                raw[0][2 * k] = make_uint2(v[0], v[1]);
-            else
-                extra = make_uint2(v[0], v[1]);
-            if (2 * k + 1 < NT)
-                raw[0][2 * k + 1] = make_uint2(v[2], v[3]);
-            else if (2 * k + 1 == NT)
-                extra = make_uint2(v[2], v[3]);
-        }
-    } else if (pair16) {
+        for (int k = 0; k < HL; k++)
+            __builtin_memcpy(wds + 4 * k, (const void *) (row + 16 * k), 16);
 #pragma unroll
-        for (int n = 0; n < NT; n++) {
-            const int iw = of_tap(first[0] + min(n, N - 1), na, mirror);
-            const OF_GLOBAL char *row = (const OF_GLOBAL char *) (uintptr_t) sp + (size_t) iw * spitch;
-            uint32_t v;     // (2-byte aligned: fine for global memory)
-            __builtin_memcpy(&v, (const void *) (row + (size_t) o0[0] * 2), 4);
-            raw[0][n] = make_uint2(v & 0xffffu, 0);
-            raw[1][n] = make_uint2(v >> 16, 0);
-        }
+        for (int n = 0; n < NT; n++)
+            raw[0][n] = texel_of(wds, n);
+        extra = texel_of(wds, NT);
     } else {
 #pragma unroll
         for (int n = 0; n < NT; n++) {
@@ -362,7 +360,7 @@ void k_ortho_fast(const plh_pass p_)
             raw[0][n] = DIR ? of_load<SRC>(sp, spitch, o0[0], iw) : of_load<SRC>(sp, spitch, iw, o0[0]);
         }
     }
-    if (pair16 || pair64) {
+    if (pair_v) {
         // (both pixels' taps are in)
     } else if (overlap) {
         if (!wide_h)
