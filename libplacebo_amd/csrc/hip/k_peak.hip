@@ -505,8 +505,28 @@ void k_peak_tiles(const plh_pass p_)
     const uint32_t slice = blockIdx.x % PEAK_SLICES, bs = blockIdx.x / PEAK_SLICES;
     const uint32_t stride = (gridDim.x / PEAK_SLICES) * PEAK_WAVES;
     const uint32_t per_slice = (ntiles + PEAK_SLICES - 1 - slice) / PEAK_SLICES;    // tiles 12 j + slice < ntiles
-    const bool has_map = p.num_ops == 2;    // [identity PLANE_MAP] PEAK_DETECT
-    const plh_op &o_map = p.ops[0], &o_pk = p.ops[p.num_ops - 1];
+    // STORE 0 / 1: [identity PLANE_MAP] PEAK_DETECT; STORE 2: PEAK_DETECT [LINEARIZE (PQ)] FEATURES
+    const bool has_map = STORE != 2 && p.num_ops == 2;
+    const plh_op &o_map = p.ops[0], &o_pk = p.ops[STORE == 2 ? 0 : p.num_ops - 1];
+    // (STORE 2: the fields op_features / lin_values<TRC_PQ> read, copied once and pinned)
+    plh_op feat, flin;
+    bool feat_lin = false;
+    if constexpr (STORE == 2) {
+        const plh_op &of = p.ops[p.num_ops - 1], &ol = p.ops[1];
+        feat_lin = p.num_ops == 3;
+#pragma unroll
+        for (int k = 0; k < 14; k++)
+            feat.f[k] = of.f[k];
+        flin.i1 = ol.i1;
+#pragma unroll
+        for (int k = 0; k < 8; k++)
+            flin.f[k] = ol.f[k];
+        asm volatile("" : "+s"(feat.f[0]), "+s"(feat.f[1]), "+s"(feat.f[2]), "+s"(feat.f[3]), "+s"(feat.f[4]),
+                          "+s"(feat.f[5]), "+s"(feat.f[6]), "+s"(feat.f[7]), "+s"(feat.f[8]), "+s"(feat.f[9]),
+                          "+s"(feat.f[10]), "+s"(feat.f[11]), "+s"(feat.f[12]), "+s"(feat.f[13]));
+        asm volatile("" : "+s"(flin.i1), "+s"(flin.f[0]), "+s"(flin.f[1]), "+s"(flin.f[2]), "+s"(flin.f[3]),
+                          "+s"(flin.f[4]), "+s"(flin.f[5]), "+s"(flin.f[6]), "+s"(flin.f[7]));
+    }
     // (the detect stage's block is read through a global pointer: vector loads of one address)
     auto uni = [](float v) { return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v))); };
     const peak_consts pcv = peak_load_consts(o_pk);
@@ -557,10 +577,11 @@ void k_peak_tiles(const plh_pass p_)
         origin(j, x0, y0);
         const int px = min(x0, w - 2);
         uint32_t lane_sum = 0, nblack = 0;
-#pragma unroll 1
-        for (int k = 0; k < 2; k++) {
+        auto fetch = [&](int k) {
+            return *(g_u32x4 *) (sp + (size_t) min(y0 + 8 * k, h - 1) * (size_t) spitch + (size_t) px * 8);
+        };
+        auto row = [&](int k, plh_u32x4 v) {
             const int y = y0 + 8 * k;
-            plh_u32x4 v = *(g_u32x4 *) (sp + (size_t) min(y, h - 1) * (size_t) spitch + (size_t) px * 8);
             if (x0 + 1 >= w) {      // both texels are the row's last one
                 v.x = v.z; v.y = v.w;
             }
@@ -579,6 +600,29 @@ void k_peak_tiles(const plh_pass p_)
                 if (map_n < 3) t.z = nt2;
                 if (map_n < 2) t.y = nt1;
                 c[i] = t;
+            }
+            if constexpr (STORE == 2) {
+                // the feature plane: I of IPT of every pixel (op_features itself: bit-identical to the
+                // pass of its own, k_pass_features), two f16 per row and lane; an image that is not
+                // linear yet -- HDR10 without a scaler in front -- is linearised for the features
+                float4_t t[2] = { c[0], c[1] };
+                if (feat_lin) {
+                    float v6[6] = { t[0].x, t[0].y, t[0].z, t[1].x, t[1].y, t[1].z };
+                    lin_values<TRC_PQ>(v6, flin);
+                    t[0].x = v6[0]; t[0].y = v6[1]; t[0].z = v6[2];
+                    t[1].x = v6[3]; t[1].y = v6[4]; t[1].z = v6[5];
+                }
+                uint32_t o[2];
+#pragma unroll
+                for (int i = 0; i < 2; i++) {
+                    op_features(t[i], feat);
+                    o[i] = plh_f2h(t[i].x);
+                }
+                const uintptr_t d = dp + (size_t) y * (size_t) dpitch + (size_t) x0 * 2;
+                if (y < h && x0 + 1 < w)
+                    *(__attribute__((address_space(1))) uint32_t *) d = o[0] | (o[1] << 16);
+                else if (y < h && x0 < w)
+                    *(__attribute__((address_space(1))) uint16_t *) d = (uint16_t) o[0];
             }
             // (the intermediate goes out first: its stores are in flight while the measurement computes)
             if constexpr (STORE == 1) {
@@ -617,6 +661,17 @@ void k_peak_tiles(const plh_pass p_)
                 if (pc.cutoff != 0.0f)
                     nblack += (uint32_t) __popcll(__ballot(y_pq == 0u));
             }
+        };
+        if constexpr (STORE == 2) {
+            // (the variant that also writes the feature plane runs alone on the main stream: both
+            // rows at once, their loads in flight together -- it need not fit beside anything)
+            const plh_u32x4 v0 = fetch(0), v1 = fetch(1);
+            row(0, v0);
+            row(1, v1);
+        } else {
+#pragma unroll 1
+            for (int k = 0; k < 2; k++)
+                row(k, fetch(k));
         }
         const uint32_t wg_sum = wave_sum_dpp(lane_sum);
         const uint32_t num = PEAK_BW * PEAK_BH - nblack;
@@ -806,7 +861,9 @@ int plh_launch_peak(hipStream_t stream, const plh_pass *pass)
     const char *v2 = getenv("PL_HIP_PEAK_TILES");
     const int trc = pk_op < pass->num_ops ? pass->ops[pk_op].i0 : -1;
     const bool feat_target = pass->dst.ptr && pass->dst.fmt == PLH_FMT_R16F;
-    if (peak_fast_applies(pass) && !(v2 && v2[0] == '0') && !feat_target && pass->width >= 2 &&
+    // (the feature plane: PEAK_DETECT FEATURES of a linear image, or PEAK_DETECT LINEARIZE FEATURES of PQ)
+    const bool feat_ok = !feat_target || pass->num_ops == 2 || pass->ops[1].i0 == TRC_PQ;
+    if (peak_fast_applies(pass) && !(v2 && v2[0] == '0') && feat_ok && pass->width >= 2 &&
         (trc == TRC_PQ || trc == TRC_LINEAR)) {
         // k_peak_tiles folds its own result (no k_peak_fold behind it)
         const bool f16 = pass->s.src.fmt == PLH_FMT_RGBA16F, store = pass->dst.ptr != NULL, pq = trc == TRC_PQ;
@@ -820,10 +877,12 @@ int plh_launch_peak(hipStream_t stream, const plh_pass *pass)
         groups = groups < 1 ? 1 : groups > gmax ? gmax : groups;
         const dim3 tgrid(PEAK_SLICES * groups);
 #define PEAK_TILES_GO(F, S, Q) PLH_LAUNCH_LAST((k_peak_tiles<F, S, Q>), tgrid, block, 0, stream, *pass)
-        if (f16 && store)   { if (pq) PEAK_TILES_GO(true, 1, true); else PEAK_TILES_GO(true, 1, false); }
-        else if (f16)       { if (pq) PEAK_TILES_GO(true, 0, true); else PEAK_TILES_GO(true, 0, false); }
-        else if (store)     { if (pq) PEAK_TILES_GO(false, 1, true); else PEAK_TILES_GO(false, 1, false); }
-        else                { if (pq) PEAK_TILES_GO(false, 0, true); else PEAK_TILES_GO(false, 0, false); }
+        if (f16 && feat_target) { if (pq) PEAK_TILES_GO(true, 2, true); else PEAK_TILES_GO(true, 2, false); }
+        else if (feat_target)   { if (pq) PEAK_TILES_GO(false, 2, true); else PEAK_TILES_GO(false, 2, false); }
+        else if (f16 && store)  { if (pq) PEAK_TILES_GO(true, 1, true); else PEAK_TILES_GO(true, 1, false); }
+        else if (f16)           { if (pq) PEAK_TILES_GO(true, 0, true); else PEAK_TILES_GO(true, 0, false); }
+        else if (store)         { if (pq) PEAK_TILES_GO(false, 1, true); else PEAK_TILES_GO(false, 1, false); }
+        else                    { if (pq) PEAK_TILES_GO(false, 0, true); else PEAK_TILES_GO(false, 0, false); }
 #undef PEAK_TILES_GO
         const hipError_t terr = hipGetLastError();
         return terr == hipSuccess ? 0 : -(int) terr;

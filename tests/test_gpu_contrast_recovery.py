@@ -129,9 +129,10 @@ def test_high_quality_preset_runs_contrast_recovery(gpu):
 def test_measuring_pass_extracts_the_features_too(gpu, size, monkeypatch):
     """high_quality on HDR10 with peak detection: the pass that reads the scaled intermediate for
     the measurement also writes the contrast-recovery feature plane ([PEAK_DETECT] [FEATURES] into
-    an r16hf target: k_peak_fast<.., 2>) instead of a second pass reading the same image
-    (PL_HIP_FUSED_FEATURES=0 keeps the two passes; the generic measuring kernel with the fused op
-    list: PL_HIP_PEAK_FAST=0). Same measurement, same feature plane, so the same frame bit for bit
+    an r16hf target: k_peak_tiles<.., 2, ..>) instead of a second pass reading the same image
+    (PL_HIP_FUSED_FEATURES=0 keeps the two passes; PL_HIP_PEAK_TILES=0: k_peak_fast<.., 2> and the
+    fold kernel; PL_HIP_PEAK_FAST=0: the generic measuring kernel with the fused op list). Same
+    measurement, same feature plane, so the same frame bit for bit
     and the same scene metadata -- behind an EWA 2:1 downscale (the measurement of an existing
     intermediate: configs[4]) and at 1:1 (where the measurement rides on the decoding pass and
     nothing is merged)."""
@@ -141,8 +142,9 @@ def test_measuring_pass_extracts_the_features_too(gpu, size, monkeypatch):
     (sw, sh), (dw, dh) = size
     outs = []
     for env in ({"PL_HIP_FUSED_FEATURES": "1"}, {"PL_HIP_FUSED_FEATURES": "0"},
+                {"PL_HIP_FUSED_FEATURES": "1", "PL_HIP_PEAK_TILES": "0"},
                 {"PL_HIP_FUSED_FEATURES": "1", "PL_HIP_PEAK_FAST": "0"}):
-        for k in ("PL_HIP_FUSED_FEATURES", "PL_HIP_PEAK_FAST"):
+        for k in ("PL_HIP_FUSED_FEATURES", "PL_HIP_PEAK_FAST", "PL_HIP_PEAK_TILES"):
             monkeypatch.delenv(k, raising=False)
         for k, v in env.items():
             monkeypatch.setenv(k, v)
