@@ -186,7 +186,9 @@ def test_bench_two_ranks_end_to_end(gpu):
     assert out["n_gpus"] == 2 and out["steps"] == 40 and out["scaling"] == "weak"
     assert out["config"]["render_errors"] == 0
     # two ranks' frames over the slower rank's time
-    assert abs(out["value"] - 2 * 40 * 3840 * 2160 / (out["ms_per_step"] * 40 * 1e-3) / 1e6) < 0.01 * out["value"]
+    fps = out["config"]["frames_per_step"]
+    assert fps == out["config"]["pool"] and abs(out["ms_per_frame"] * fps - out["ms_per_step"]) < 1e-3 * out["ms_per_step"] + 2e-4
+    assert abs(out["value"] - 2 * 40 * fps * 3840 * 2160 / (out["ms_per_step"] * 40 * 1e-3) / 1e6) < 0.01 * out["value"]
 
 
 # ---- two PRODUCT instances render one HDR frame -------------------

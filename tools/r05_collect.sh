@@ -17,7 +17,7 @@ driver)
   python3 -c "
 import json,sys
 for l in open('gpurun_out/${tag}_driver_cmd.jsonl'):
-    d=json.loads(l); print(d['value'], d['ms_per_step'], d['roofline'].get('kernel_us'))" ;;
+    d=json.loads(l); print(d['value'], d.get('ms_per_frame', d['ms_per_step']), d['roofline'].get('kernel_us'))" ;;
 trace)
   out=/tmp/prof_default; rm -rf $out
   (cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $out -- python $GRAFT_REPO_ROOT/bench.py --no-traffic --no-cpu-baseline --no-concurrent > $GRAFT_REPO_ROOT/gpurun_out/${tag}_default_bench_under_rocprof.json 2> /tmp/prof_default.err)
