@@ -740,14 +740,15 @@ def config_block(device, workload, steps=60, warmup=8, trace=False):
     """One BASELINE config measured like the headline (single stream): frame rate + roofline."""
     (sw, sh), (dw, dh), _, _ = WORKLOADS[workload]
     per_frame = (sw * sh + dw * dh) * 8
-    st = Stream(device, workload, max(4, -(-800_000_000 // per_frame)))
+    pool = max(4, -(-800_000_000 // per_frame))
+    st = Stream(device, workload, pool)
     prime(st)
-    dt = run_timed(st, steps, warmup)
+    dt = run_timed(st, steps, warmup, fps=pool)     # (a step = the pool of frames, as in main())
     block = roofline_block(workload, measure_passes(st, 24))
     block.update(config=BASELINE_CONFIGS.get(workload),
-                 mpixels_per_s=round(steps * dw * dh / dt / 1e6, 1),
-                 ms_per_step=round(dt / steps * 1e3, 4), steps=steps,
-                 render_errors=st.rr.errors())
+                 mpixels_per_s=round(steps * pool * dw * dh / dt / 1e6, 1),
+                 ms_per_step=round(dt / steps * 1e3, 4), ms_per_frame=round(dt / (steps * pool) * 1e3, 4),
+                 steps=steps, frames_per_step=pool, render_errors=st.rr.errors())
     st.close()
     if workload in ASYNC_WORKLOADS:
         key = "single_stream" if Stream.async_measure else "async_measure"
@@ -814,12 +815,14 @@ def async_measure_block(device, workload, steps, warmup, on):
     of every frame)."""
     (sw, sh), (dw, dh), _, _ = WORKLOADS[workload]
     per_frame = (sw * sh + dw * dh) * 8
-    st = Stream(device, workload, max(4, -(-800_000_000 // per_frame)), async_measure=on)
+    pool = max(4, -(-800_000_000 // per_frame))
+    st = Stream(device, workload, pool, async_measure=on)
     prime(st)
-    dt = run_timed(st, steps, warmup)
-    block = {"pl_hip_params": {"async_measure": bool(on)}, "steps": steps,
-             "mpixels_per_s": round(steps * dw * dh / dt / 1e6, 1),
-             "ms_per_step": round(dt / steps * 1e3, 4), "render_errors": st.rr.errors()}
+    dt = run_timed(st, steps, warmup, fps=pool)
+    block = {"pl_hip_params": {"async_measure": bool(on)}, "steps": steps, "frames_per_step": pool,
+             "mpixels_per_s": round(steps * pool * dw * dh / dt / 1e6, 1),
+             "ms_per_step": round(dt / steps * 1e3, 4),
+             "ms_per_frame": round(dt / (steps * pool) * 1e3, 4), "render_errors": st.rr.errors()}
     st.close()
     return block
 
