@@ -117,6 +117,9 @@ WORKLOADS = {
     "ewa_8k_to_4k_deband_tonemap": (P8K, P4K, px(P8K) * 8 + px(P4K) * 8, "debanding"),
     # the metric's two halves in one frame: 1080p HDR10 -> EWA 2x upscale -> tone map -> 4K SDR
     "ewa_1080p_to_4k_hdr_tonemap": (P1080, P4K, 2 * px(P1080) * 8 + px(P4K) * 8, "polar"),
+    # ... under two lines of subtitles: a translucent box and 96 glyph quads from an r8 atlas (one
+    # PL_OVERLAY_MONOCHROME overlay of the target: k_overlay behind the scaler's launch)
+    "ewa_1080p_to_4k_hdr_tonemap_subtitles": (P1080, P4K, 2 * px(P1080) * 8 + px(P4K) * 8, "polar"),
     # 24 fps -> 60 Hz through pl_queue + pl_render_image_mix (oversampling mixer): a step is one
     # vsync; 0.4 source frames per vsync are scaled into the f16 cache, 40 % of the vsyncs blend
     # two cached frames, the others show one (bytes: the output pass, 1.4 x f16 in + rgba16 out on
@@ -138,6 +141,7 @@ KERNEL_BYTES = {
     "ewa_8k_to_4k_hdr_tonemap": px(P8K) * 8 + px(P4K) * 8,
     "ewa_lanczos_4k_to_1080p_linear_dither10": px(P4K) * 8 + px(P1080) * 8,
     "ewa_1080p_to_4k_hdr_tonemap": px(P1080) * 8 + px(P4K) * 8,    # polar + map launch: 1080p f16 in, 4K out
+    "ewa_1080p_to_4k_hdr_tonemap_subtitles": px(P1080) * 8 + px(P4K) * 8,
 }
 
 # VALU issue ceiling: 256 CUs x 4 SIMDs x 16 lanes x 2.4 GHz = 39.3 T lane-operations / s
@@ -274,7 +278,8 @@ class Stream:
             icsp, tcsp, trepr = bt1886, bt1886, ten_bit
             self.queue = pl.Queue(self.g)
             self.pts, self.fed = 0.0, 0
-        elif workload in ("ewa_1080p_to_4k_hdr_tonemap", "ewa_720p_to_4k_hdr_tonemap"):
+        elif workload in ("ewa_1080p_to_4k_hdr_tonemap", "ewa_720p_to_4k_hdr_tonemap",
+                          "ewa_1080p_to_4k_hdr_tonemap_subtitles"):
             self.params = pl.render_params(
                 "default", upscaler=pl.filter_config("ewa_lanczos"), dither_params=dither,
                 peak_detect_params=pl.peak_detect_params(percentile=99.995))
@@ -305,6 +310,31 @@ class Stream:
                 pl.lib().pl_frame_set_chroma_location(C.byref(f), 1)   # PL_CHROMA_LEFT
                 self.images.append(f)
         self.targets = [pl.frame(t, color=tcsp, repr_=trepr) for t in self.dsts]
+        if workload.endswith("_subtitles"):
+            self.subtitles = self._subtitles(dw, dh)
+            for t in self.targets:
+                pl.set_overlays(t, self.subtitles)
+
+    def _subtitles(self, dw, dh):
+        """two centred lines of 48 glyphs (40 x 64 target pixels each, from a 16 x 16 grid of
+        32 x 32 glyph cells in an r8 atlas) over a translucent box"""
+        yy, xx = np.mgrid[0:512, 0:512]
+        cell = np.hypot((xx % 32) - 15.5, (yy % 32) - 15.5)
+        atlas = (255 * np.clip(1.5 - np.abs(cell - 9.0) / 3.0, 0.0, 1.0)).astype(np.uint8)
+        atlas[480:, 480:] = 255                      # a solid cell: the box
+        self.atlas = self.g.tex_create(512, 512, "r8", atlas[..., None])
+        rng = np.random.default_rng(0)
+        box = [((484, 484, 508, 508), (dw // 2 - 1000, dh - 260, dw // 2 + 1000, dh - 90),
+                (0.0, 0.0, 0.0, 0.5))]
+        glyphs = []
+        for line in range(2):
+            for k in range(48):
+                gx, gy = int(rng.integers(0, 15)) * 32, int(rng.integers(0, 15)) * 32
+                x, y = dw // 2 - 960 + 40 * k, dh - 250 + 76 * line
+                glyphs.append(((gx, gy, gx + 32, gy + 32), (x, y, x + 40, y + 64),
+                               (1.0, 1.0, 1.0, 1.0)))
+        # one pl_overlay, as a subtitle renderer hands them over (libass: one list of bitmaps)
+        return [pl.overlay(self.atlas, box + glyphs, mode=pl.OVERLAY_MONOCHROME)]
 
     def _info(self, _priv, info):
         d = info.contents.pass_.contents
@@ -806,7 +836,8 @@ def concurrent_block(device, workload, nstreams, steps=120, warmup=12):
 
 
 # workloads with a measuring pass the option can move (the others render the same either way)
-ASYNC_WORKLOADS = ("ewa_1080p_to_4k_hdr_tonemap", "hdr10_4k_tonemap", "ewa_720p_to_4k_hdr_tonemap")
+ASYNC_WORKLOADS = ("ewa_1080p_to_4k_hdr_tonemap", "hdr10_4k_tonemap", "ewa_720p_to_4k_hdr_tonemap",
+                   "ewa_1080p_to_4k_hdr_tonemap_subtitles")
 
 
 def async_measure_block(device, workload, steps, warmup, on):

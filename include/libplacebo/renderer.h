@@ -108,7 +108,7 @@ struct pl_render_params {
     const struct pl_error_diffusion_kernel *error_diffusion;
 
     const struct pl_cone_params *cone_params; // colour blindness simulation (NULL = off)
-    const struct pl_blend_params *blend_params;             // unsupported, must be NULL
+    const struct pl_blend_params *blend_params;             // the frame is blended INTO the target
     const struct pl_deinterlace_params *deinterlace_params; // unsupported, must be NULL
     const struct pl_distort_params *distort_params;         // unsupported, must be NULL
     const struct pl_hook * const *hooks;                    // unsupported, must be NULL
@@ -195,8 +195,10 @@ struct pl_overlay_part {
     float color[4];
 };
 
-// On-screen display / subtitle bitmaps. Not drawn by this backend: a frame with overlays is
-// rendered without them and PL_RENDER_ERR_OVERLAY is raised.
+// On-screen display / subtitle bitmaps: a texture and a list of parts of it, each placed on a
+// rectangle of the frame (`coords`: of the image or of the target, whole or cropped) and blended
+// over it in order. NORMAL: the texture's colour (in `repr` / `color`); MONOCHROME: the part's
+// `color`, its alpha times the texture's red channel (glyph atlases).
 struct pl_overlay {
     pl_tex tex;
     enum pl_overlay_mode mode;
@@ -235,7 +237,7 @@ struct pl_frame {
     pl_rotation rotation;     // clockwise, in multiples of 90 degrees (common.h)
     float pixel_aspect_ratio; // informational (0 = square); the renderer never reads it
 
-    const struct pl_overlay *overlays;      // not drawn, see struct pl_overlay
+    const struct pl_overlay *overlays;      // drawn over the frame (images: in mixing, per frame)
     int num_overlays;
 
     struct pl_film_grain_data film_grain;   // not synthesised, see shaders/film_grain.h

@@ -274,10 +274,12 @@ class Shader:
     def failed(self):
         return lib().pl_shader_is_failed(self.sh)
 
-    def finish(self, target, rect=None, timer=None):
+    def finish(self, target, rect=None, timer=None, blend_params=None):
         dp = capi.DispatchParams(shader=C.pointer(self.sh), target=target.ptr, timer=timer)
         if rect is not None:
             dp.rect = capi.Rect2d(*rect)
+        if blend_params is not None:
+            dp.blend_params = C.pointer(blend_params)
         return lib().pl_dispatch_finish(self.gpu.dp, C.byref(dp))
 
     def compute(self, width=0, height=0, timer=None):
@@ -394,6 +396,36 @@ def frame(tex, repr_=None, color=None, crop=None, components=None, mapping=None,
     if crop is not None:
         f.crop = capi.Rect2df(*crop)
     return f
+
+
+OVERLAY_NORMAL, OVERLAY_MONOCHROME = 0, 1
+OVERLAY_COORDS_AUTO, OVERLAY_COORDS_SRC_FRAME, OVERLAY_COORDS_SRC_CROP = 0, 1, 2
+OVERLAY_COORDS_DST_FRAME, OVERLAY_COORDS_DST_CROP = 3, 4
+BLEND_ZERO, BLEND_ONE, BLEND_SRC_ALPHA, BLEND_ONE_MINUS_SRC_ALPHA = 0, 1, 2, 3
+
+
+def overlay(tex, parts, mode=OVERLAY_NORMAL, coords=OVERLAY_COORDS_AUTO, repr_=None, color=None):
+    """pl_overlay around `tex`; parts = [(src rect, dst rect, rgba or None), ...]"""
+    arr = (capi.OverlayPart * max(len(parts), 1))()
+    for i, (src, dst, rgba) in enumerate(parts):
+        arr[i].src = capi.Rect2df(*src)
+        arr[i].dst = capi.Rect2df(*dst)
+        for c in range(4):
+            arr[i].color[c] = rgba[c] if rgba is not None else 0.0
+    o = capi.Overlay(tex=tex.ptr, mode=mode, coords=coords, parts=arr, num_parts=len(parts))
+    o.repr = repr_ if repr_ is not None else color_repr("rgb", "full", alpha="independent")
+    o.color = color if color is not None else color_space("bt709", "srgb")
+    o._keep = arr
+    return o
+
+
+def set_overlays(frame_, overlays):
+    """attach a list of pl_overlay to a pl_frame (kept alive on the frame)"""
+    arr = (capi.Overlay * max(len(overlays), 1))(*overlays)
+    frame_.overlays = C.cast(arr, C.c_void_p)
+    frame_.num_overlays = len(overlays)
+    frame_._keep_overlays = (arr, list(overlays))
+    return frame_
 
 
 FMT_UNORM, FMT_SNORM, FMT_UINT, FMT_SINT, FMT_FLOAT = 1, 2, 3, 4, 5

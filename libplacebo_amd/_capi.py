@@ -273,9 +273,14 @@ class DispatchComputeParams(C.Structure):
                 ("width", C.c_int), ("height", C.c_int), ("timer", C.c_void_p)]
 
 
+class BlendParams(C.Structure):
+    _fields_ = [("src_rgb", C.c_int), ("dst_rgb", C.c_int),
+                ("src_alpha", C.c_int), ("dst_alpha", C.c_int)]
+
+
 class DispatchParams(C.Structure):
     _fields_ = [("shader", C.POINTER(C.c_void_p)), ("target", C.POINTER(Tex)),
-                ("rect", Rect2d), ("blend_params", C.c_void_p), ("timer", C.c_void_p)]
+                ("rect", Rect2d), ("blend_params", C.POINTER(BlendParams)), ("timer", C.c_void_p)]
 
 
 # ---- colorspace.h / tone_mapping.h / gamut_mapping.h --------------------------------
@@ -424,6 +429,16 @@ class FilmGrainData(C.Structure):
     _fields_ = [("type", C.c_int), ("seed", C.c_uint64), ("params", _GrainUnion)]
 
 
+class OverlayPart(C.Structure):
+    _fields_ = [("src", Rect2df), ("dst", Rect2df), ("color", C.c_float * 4)]
+
+
+class Overlay(C.Structure):
+    _fields_ = [("tex", C.POINTER(Tex)), ("mode", C.c_int), ("coords", C.c_int),
+                ("repr", ColorRepr), ("color", ColorSpace),
+                ("parts", C.POINTER(OverlayPart)), ("num_parts", C.c_int)]
+
+
 class Frame(C.Structure):
     _fields_ = [("num_planes", C.c_int), ("planes", Plane * 4),
                 ("field", C.c_int), ("first_field", C.c_int),
@@ -478,7 +493,7 @@ class RenderParams(C.Structure):
                 ("color_map_params", C.POINTER(ColorMapParams)),
                 ("dither_params", C.POINTER(DitherParams)),
                 ("error_diffusion", C.POINTER(ErrorDiffusionKernel)),
-                ("cone_params", C.POINTER(ConeParams)), ("blend_params", C.c_void_p),
+                ("cone_params", C.POINTER(ConeParams)), ("blend_params", C.POINTER(BlendParams)),
                 ("deinterlace_params", C.c_void_p), ("distort_params", C.c_void_p),
                 ("hooks", C.c_void_p), ("num_hooks", C.c_int), ("lut", C.POINTER(CustomLut)),
                 ("lut_type", C.c_int), ("background", C.c_int), ("border", C.c_int),

@@ -349,12 +349,59 @@ struct plh_errdiff_args {
     int32_t block_size, blocks; // one workgroup, `blocks` sequential steps
 };
 
+/* ---- overlays and blended stores (k_overlay.hip) -------------------------------- */
+// What the reference draws as textured quads through the rasteriser with fixed-function blending
+// (draw_overlays, src/renderer.c:811-1020; pl_dispatch_finish with blend_params): a list of
+// axis-aligned parts of the target, each with an affine map from target pixel centres to the
+// overlay texture, blended IN ORDER. A pixel centre p is inside [x0, x1) x [y0, y1) (the
+// rasteriser's top-left rule); its texture coordinate is
+//     u = u0 + ((p.x - ox) * ux + (p.y - oy) * uy),  v likewise
+// (normalised; one of ux / uy is zero: the quads are only ever scaled, flipped and turned by 90
+// degrees).
+struct plh_overlay_part {
+    float x0, y0, x1, y1;
+    float ox, oy;
+    float ux, uy, u0;
+    float vx, vy, v0;
+    float color[4];         // PLH_OVERLAY_MONOCHROME: the part's colour (osd_color)
+};
+
+enum plh_overlay_mode {
+    PLH_OVERLAY_NORMAL = 0,     // color = texture(coord)
+    PLH_OVERLAY_MONOCHROME,     // color = part colour; its alpha (premultiplied: all of it)
+                                // times texture(coord).r after the colour ops [0, num_pre_ops)
+    PLH_OVERLAY_TEXEL,          // color = texel (x - x0, y - y0): a rendered pass being blended
+};
+
+enum plh_blend_factor {         // gpu.h pl_blend_mode
+    PLH_BLEND_ZERO = 0,
+    PLH_BLEND_ONE,
+    PLH_BLEND_SRC_ALPHA,
+    PLH_BLEND_ONE_MINUS_SRC_ALPHA,
+};
+
+#define PLH_OVERLAY_TILE 16     // target pixels per tile side; one workgroup per non-empty tile
+struct plh_overlay_args {
+    const struct plh_overlay_part *parts;   // device
+    const uint32_t *tiles;      // device: {tx | ty << 16, first, count} per non-empty tile
+    const uint32_t *order;      // device: the part indices of every tile, in drawing order
+    int32_t num_tiles;
+    int32_t mode;               // enum plh_overlay_mode
+    int32_t linear;             // overlay texture sampled with LINEAR filtering
+    int32_t premultiplied;      // MONOCHROME: coverage multiplies rgba instead of a
+    int32_t blend;              // 0: the colour replaces the target's
+    int32_t src_rgb, dst_rgb, src_alpha, dst_alpha;     // enum plh_blend_factor
+};
+
 /* ---- launch entry points (implemented in *.hip) --------------------------- */
 typedef void *plh_stream;
 
 // returns 0 on success, a negative hipError otherwise
 int plh_launch_pass(plh_stream stream, const struct plh_pass *pass);
 int plh_launch_errdiff(plh_stream stream, const struct plh_errdiff_args *args);
+// pass: s.src = the overlay texture, ops (split at num_pre_ops), dst = the target
+int plh_launch_overlay(plh_stream stream, const struct plh_pass *pass,
+                       const struct plh_overlay_args *args);
 
 // POLAR phase-class setup helpers (k_polar.hip). `out` = width floats (fcoord.x
 // of every output column on row 0), width ints (base texel), then height floats

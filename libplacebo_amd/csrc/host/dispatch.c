@@ -42,6 +42,24 @@ struct pl_dispatch_t {
     struct pass_timing timings[64];
     int num_timings;
     pl_buf noise;               // white-noise dither plane of the pass being launched
+    // Binned overlays, resident on the device: subtitles and on-screen displays stay the same for
+    // seconds, so an overlay that was drawn before (same parts on a target of the same size) is
+    // neither binned nor uploaded again -- an upload is a copy engine's turn on the stream between
+    // two kernels, which costs the frame more than the overlay's kernel does
+    struct overlay_layout {
+        int num_parts, w, h;
+        struct plh_overlay_part *parts;     // host copy: what the entry was built from
+        pl_buf buf;                         // parts | tiles | order
+        size_t parts_bytes, tiles_bytes;
+        uint32_t num_tiles;
+        uint64_t used;                      // dp->overlay_clock of the last use
+    } overlays[8];
+    uint64_t overlay_clock;
+    pl_tex blend_tmp;           // a pass with blend_params renders here first (rgba32f)
+    uint32_t *bins;             // host scratch of plh_dispatch_overlay
+    size_t bins_cap;
+    uint8_t *blob;
+    size_t blob_cap;
 };
 
 pl_dispatch pl_dispatch_create(pl_log log, pl_gpu gpu)
@@ -62,6 +80,13 @@ void pl_dispatch_destroy(pl_dispatch *ptr)
     for (int i = 0; i < dp->num_pool; i++)
         pl_shader_free(&dp->pool[i]);
     pl_buf_destroy(dp->gpu, &dp->noise);
+    for (size_t i = 0; i < PL_ARRAY_SIZE(dp->overlays); i++) {
+        pl_buf_destroy(dp->gpu, &dp->overlays[i].buf);
+        free(dp->overlays[i].parts);
+    }
+    pl_tex_destroy(dp->gpu, &dp->blend_tmp);
+    free(dp->bins);
+    free(dp->blob);
     for (int i = 0; i < dp->num_timings; i++) {
         pl_timer_destroy(dp->gpu, &dp->timings[i].timer);
         pl_shader_info_deref(&dp->timings[i].info.shader);
@@ -312,6 +337,265 @@ int plh_pass_execute(pl_gpu gpu, pl_log log, const struct plh_pass_exec *x, pl_t
     return err;
 }
 
+/* ---- overlays and blended stores (k_overlay.hip) --------------------------------------------- */
+
+static int blend_factor(enum pl_blend_mode m)
+{
+    switch (m) {
+    case PL_BLEND_ZERO:                return PLH_BLEND_ZERO;
+    case PL_BLEND_ONE:                 return PLH_BLEND_ONE;
+    case PL_BLEND_SRC_ALPHA:           return PLH_BLEND_SRC_ALPHA;
+    case PL_BLEND_ONE_MINUS_SRC_ALPHA: return PLH_BLEND_ONE_MINUS_SRC_ALPHA;
+    case PL_BLEND_MODE_COUNT:          break;
+    }
+    return PLH_BLEND_ZERO;
+}
+
+// the target pixels whose centre lies in [a, b): first and one past the last, within [0, n)
+static void covered_range(float a, float b, int n, int *first, int *end)
+{
+    const float lo = ceilf(a - 0.5f), hi = ceilf(b - 0.5f);
+    *first = lo <= 0.0f ? 0 : lo >= (float) n ? n : (int) lo;
+    *end = hi <= 0.0f ? 0 : hi >= (float) n ? n : (int) hi;
+}
+
+static bool reserve(void **ptr, size_t *cap, size_t need)
+{
+    if (need <= *cap)
+        return true;
+    void *grown = realloc(*ptr, need);
+    if (!grown)
+        return false;
+    *ptr = grown;
+    *cap = need;
+    return true;
+}
+
+// The rasteriser's work, done on the host: every part is clipped to the w x h target and entered
+// into the list of each 16 x 16 tile it touches; tiles keep their parts in drawing order. The
+// result goes to the device as one blob (parts | tiles {xy, first, count} | order). Returns the
+// cache entry that holds it (num_tiles == 0: nothing of the overlay is visible), NULL on failure.
+static struct overlay_layout *overlay_layout(pl_dispatch dp, const struct plh_overlay_part *parts,
+                                             int n, int w, int h)
+{
+    const size_t parts_bytes = (size_t) n * sizeof(struct plh_overlay_part);
+    struct overlay_layout *lay = &dp->overlays[0];
+    for (size_t i = 0; i < PL_ARRAY_SIZE(dp->overlays); i++) {
+        struct overlay_layout *e = &dp->overlays[i];
+        if (e->parts && e->num_parts == n && e->w == w && e->h == h &&
+            !memcmp(e->parts, parts, parts_bytes))
+        {
+            e->used = ++dp->overlay_clock;
+            return e;
+        }
+        if (e->used < lay->used)
+            lay = e;    // the least recently used one is replaced (its buffer is overwritten by
+                        // copies on the stream its kernels ran on: behind them)
+    }
+
+    const int T = PLH_OVERLAY_TILE;
+    const int tiles_w = (w + T - 1) / T, tiles_h = (h + T - 1) / T;
+    const size_t num_bins = (size_t) tiles_w * tiles_h;
+    if (!reserve((void **) &dp->bins, &dp->bins_cap, 2 * num_bins * sizeof(uint32_t)))
+        return NULL;
+    uint32_t *count = dp->bins, *start = dp->bins + num_bins;
+    memset(count, 0, num_bins * sizeof(uint32_t));
+
+    // pass 1: how many parts every tile holds
+    size_t total = 0;
+    for (int i = 0; i < n; i++) {
+        int xs, xe, ys, ye;
+        covered_range(parts[i].x0, parts[i].x1, w, &xs, &xe);
+        covered_range(parts[i].y0, parts[i].y1, h, &ys, &ye);
+        if (xs >= xe || ys >= ye)
+            continue;
+        for (int ty = ys / T; ty <= (ye - 1) / T; ty++) {
+            for (int tx = xs / T; tx <= (xe - 1) / T; tx++) {
+                count[(size_t) ty * tiles_w + tx]++;
+                total++;
+            }
+        }
+    }
+    size_t num_tiles = 0;
+    for (size_t b = 0; b < num_bins; b++)
+        num_tiles += count[b] != 0;
+
+    const size_t tiles_bytes = num_tiles * 3 * sizeof(uint32_t);
+    const size_t blob_bytes = parts_bytes + tiles_bytes + total * sizeof(uint32_t);
+    struct plh_overlay_part *copy = realloc(lay->parts, PL_MAX(parts_bytes, 1));
+    if (!copy || !reserve((void **) &dp->blob, &dp->blob_cap, blob_bytes)) {
+        free(copy);
+        lay->parts = NULL;
+        return NULL;
+    }
+    memcpy(copy, parts, parts_bytes);
+    *lay = (struct overlay_layout) {
+        .num_parts = n, .w = w, .h = h, .parts = copy, .buf = lay->buf,
+        .parts_bytes = parts_bytes, .tiles_bytes = tiles_bytes, .num_tiles = num_tiles,
+        .used = ++dp->overlay_clock,
+    };
+    if (!num_tiles)
+        return lay;
+
+    memcpy(dp->blob, parts, parts_bytes);
+    uint32_t *tiles = (uint32_t *) (dp->blob + parts_bytes);
+    uint32_t *order = (uint32_t *) (dp->blob + parts_bytes + tiles_bytes);
+    uint32_t next = 0, t = 0;
+    for (size_t b = 0; b < num_bins; b++) {
+        if (!count[b])
+            continue;
+        tiles[3 * t + 0] = (uint32_t) (b % tiles_w) | (uint32_t) (b / tiles_w) << 16;
+        tiles[3 * t + 1] = next;
+        tiles[3 * t + 2] = count[b];
+        start[b] = next;
+        next += count[b];
+        t++;
+    }
+    // pass 2: the parts of every tile, in drawing order
+    for (int i = 0; i < n; i++) {
+        int xs, xe, ys, ye;
+        covered_range(parts[i].x0, parts[i].x1, w, &xs, &xe);
+        covered_range(parts[i].y0, parts[i].y1, h, &ys, &ye);
+        if (xs >= xe || ys >= ye)
+            continue;
+        for (int ty = ys / T; ty <= (ye - 1) / T; ty++) {
+            for (int tx = xs / T; tx <= (xe - 1) / T; tx++)
+                order[start[(size_t) ty * tiles_w + tx]++] = i;
+        }
+    }
+
+    if (!lay->buf || lay->buf->params.size < blob_bytes) {
+        pl_buf_destroy(dp->gpu, &lay->buf);
+        lay->buf = pl_buf_create(dp->gpu, pl_buf_params(
+            .size = PL_MAX(blob_bytes * 2, (size_t) 16 * 1024), .storable = true));
+        if (!lay->buf) {
+            free(lay->parts);
+            lay->parts = NULL;
+            return NULL;
+        }
+    }
+    // (in pieces the staging slots take: a larger write waits for the stream)
+    for (size_t off = 0; off < blob_bytes; off += PLH_STAGE_BYTES) {
+        plh_buf_write(dp->gpu, lay->buf, off, dp->blob + off,
+                      PL_MIN(blob_bytes - off, (size_t) PLH_STAGE_BYTES));
+    }
+    return lay;
+}
+
+// Draw `draw->parts`, in order, into `target` (the reference's pl_dispatch_vertex call of
+// draw_overlays, src/renderer.c:1004-1019; and the blending half of pl_dispatch_finish)
+bool plh_dispatch_overlay(pl_dispatch dp, pl_shader *psh, pl_tex target,
+                          const struct plh_overlay_draw *draw)
+{
+    pl_shader sh = *psh;
+    bool ok = false;
+    if (sh->failed) {
+        pl_msg(dp->log, PL_LOG_ERR, "Trying to dispatch a failed shader.");
+        goto done;
+    }
+    if (sh->kind != PLH_SHADER_PASS || sh->pass.s.type != PLH_SAMPLE_NONE ||
+        sh->output != PL_SHADER_SIG_COLOR)
+    {
+        pl_msg(dp->log, PL_LOG_ERR, "An overlay shader consists of colour operations only");
+        goto done;
+    }
+    if (!target->params.storable || !draw->tex) {
+        pl_msg(dp->log, PL_LOG_ERR, "Trying to draw an overlay using an invalid target or texture");
+        goto done;
+    }
+
+    const struct overlay_layout *lay = overlay_layout(dp, draw->parts, draw->num_parts,
+                                                      target->params.w, target->params.h);
+    if (!lay) {
+        pl_msg(dp->log, PL_LOG_ERR, "Failed placing an overlay of %d parts", draw->num_parts);
+        goto done;
+    }
+    if (!lay->num_tiles) {
+        ok = true;      // nothing of it is visible
+        goto done;
+    }
+
+    struct plh_pass *pass = &sh->pass;
+    plh_tex_view(draw->tex, &pass->s.src);
+    plh_tex_view(target, &pass->dst);
+    pass->num_pre_ops = PL_MIN(PL_MAX(draw->coverage_at, 0), pass->num_ops);
+    const uint8_t *dev = pl_hip_buf_ptr(lay->buf);
+    const struct pl_blend_params *bl = draw->blend;
+    const struct plh_overlay_args args = {
+        .parts = (const struct plh_overlay_part *) dev,
+        .tiles = (const uint32_t *) (dev + lay->parts_bytes),
+        .order = (const uint32_t *) (dev + lay->parts_bytes + lay->tiles_bytes),
+        .num_tiles = (int32_t) lay->num_tiles,
+        .mode = draw->mode,
+        .linear = draw->linear,
+        .premultiplied = draw->premultiplied,
+        .blend = bl != NULL,
+        .src_rgb = bl ? blend_factor(bl->src_rgb) : PLH_BLEND_ONE,
+        .dst_rgb = bl ? blend_factor(bl->dst_rgb) : PLH_BLEND_ZERO,
+        .src_alpha = bl ? blend_factor(bl->src_alpha) : PLH_BLEND_ONE,
+        .dst_alpha = bl ? blend_factor(bl->dst_alpha) : PLH_BLEND_ZERO,
+    };
+    struct pass_timing *timing = get_timing(dp, sh);
+    plh_tex_order(dp->gpu, 0, draw->tex, target);
+    if (timing)
+        plh_timer_begin(dp->gpu, timing->timer, 0);
+    const int err = plh_launch_overlay(plh_gpu_stream(dp->gpu), pass, &args);
+    if (timing)
+        plh_timer_end(dp->gpu, timing->timer, 0);
+    if (err) {
+        pl_msg(dp->log, PL_LOG_ERR, "Failed launching overlay pass: %s", plh_strerror(err));
+        goto done;
+    }
+    drain_timing(dp, timing);
+    ok = true;
+
+done:
+    pl_dispatch_abort(dp, psh);
+    return ok;
+}
+
+// pl_dispatch_params.blend_params: the pass renders into an rgba32f image of the rect's size
+// (what the fragment shader would have handed to the blend unit, unrounded), which is then
+// blended into the target texel by texel
+static bool finish_blended(pl_dispatch dp, pl_shader sh, const struct plh_pass_exec *x,
+                           pl_tex target, pl_rect2d rc, pl_timer timer,
+                           const struct pl_blend_params *blend)
+{
+    const int tw = abs(pl_rect_w(rc)), th = abs(pl_rect_h(rc));
+    pl_fmt fmt = pl_find_named_fmt(dp->gpu, "rgba32f");
+    if (!fmt || !pl_tex_recreate(dp->gpu, &dp->blend_tmp, pl_tex_params(
+            .w = tw, .h = th, .format = fmt, .sampleable = true, .storable = true)))
+    {
+        pl_msg(dp->log, PL_LOG_ERR, "Failed creating the intermediate image of a blended pass");
+        return false;
+    }
+    const pl_rect2d local = {
+        .x0 = rc.x0 > rc.x1 ? tw : 0, .x1 = rc.x0 > rc.x1 ? 0 : tw,
+        .y0 = rc.y0 > rc.y1 ? th : 0, .y1 = rc.y0 > rc.y1 ? 0 : th,
+    };
+    struct plh_pass_exec unblended = *x;
+    unblended.on_aux = false;
+    const int err = plh_pass_execute(dp->gpu, dp->log, &unblended, dp->blend_tmp, local, timer,
+                                     &dp->noise);
+    if (err) {
+        pl_msg(dp->log, PL_LOG_ERR, "Failed launching pass '%s': %s",
+               sh_description(sh), plh_strerror(err));
+        return false;
+    }
+    const struct plh_overlay_part whole = {
+        .x0 = PL_MIN(rc.x0, rc.x1), .y0 = PL_MIN(rc.y0, rc.y1),
+        .x1 = PL_MAX(rc.x0, rc.x1), .y1 = PL_MAX(rc.y0, rc.y1),
+    };
+    pl_shader copy = pl_dispatch_begin(dp);
+    if (!copy)
+        return false;
+    copy->output = PL_SHADER_SIG_COLOR;
+    return plh_dispatch_overlay(dp, &copy, target, &(struct plh_overlay_draw) {
+        .tex = dp->blend_tmp, .mode = PLH_OVERLAY_TEXEL, .blend = blend,
+        .parts = &whole, .num_parts = 1,
+    });
+}
+
 // Deprecated front ends of the gpu's pl_cache (src/dispatch.c:1624-1632)
 size_t pl_dispatch_save(pl_dispatch dp, uint8_t *out)
 {
@@ -340,11 +624,6 @@ bool pl_dispatch_finish(pl_dispatch dp, const struct pl_dispatch_params *params)
         pl_msg(dp->log, PL_LOG_ERR, "This shader must be run with pl_dispatch_compute");
         goto done;
     }
-    if (params->blend_params) {
-        pl_msg(dp->log, PL_LOG_ERR, "Blending is not supported by the HIP backend");
-        goto done;
-    }
-
     pl_tex target = params->target;
     if (!target || pl_tex_params_dimension(target->params) != 2) {
         pl_msg(dp->log, PL_LOG_ERR, "Trying to dispatch a shader using an invalid target");
@@ -381,11 +660,16 @@ bool pl_dispatch_finish(pl_dispatch dp, const struct pl_dispatch_params *params)
         .detect_peak = sh->detect_peak, .peak_state = sh->peak_state,
         .src_tex = sh->src_tex, .on_aux = sh->on_aux, .aux_after = sh->aux_after,
     };
-    const int err = plh_pass_execute(dp->gpu, dp->log, &x, target, rc, timer, &dp->noise);
-    if (err) {
-        pl_msg(dp->log, PL_LOG_ERR, "Failed launching pass '%s': %s",
-               sh_description(sh), plh_strerror(err));
-        goto done;
+    if (params->blend_params) {
+        if (!finish_blended(dp, sh, &x, target, rc, timer, params->blend_params))
+            goto done;
+    } else {
+        const int err = plh_pass_execute(dp->gpu, dp->log, &x, target, rc, timer, &dp->noise);
+        if (err) {
+            pl_msg(dp->log, PL_LOG_ERR, "Failed launching pass '%s': %s",
+                   sh_description(sh), plh_strerror(err));
+            goto done;
+        }
     }
     if (!params->timer)
         drain_timing(dp, timing);

@@ -291,6 +291,22 @@ static bool cache_fill(struct frame_job *outer, struct mix_entry *e, const struc
         ok = job.img.w == out_w && job.img.h == out_h &&
              pl_dispatch_finish(rr->dp, pl_dispatch_params( .shader = &job.img.rec, .target = e->tex ));
     }
+    if (ok && image->num_overlays) {
+        // the frame's own overlays go onto its intermediate (:3855-3877): target pixels -> texels
+        // of the intermediate, which holds the target rect only
+        const pl_rect2d dst = job.geo.dst;
+        const float sx = out_w / (float) pl_rect_w(dst), sy = out_h / (float) pl_rect_h(dst);
+        pl_transform2x2 shift = {
+            .mat.m = {{ sx, 0 }, { 0, sy }},
+            .c = { -sx * dst.x0, -sy * dst.y0 },
+        };
+        if (job.geo.rotation % PL_ROTATION_180 == PL_ROTATION_90) {
+            shift.mat = (pl_matrix2x2) {{{ shift.mat.m[0][1], shift.mat.m[0][0] },
+                                         { shift.mat.m[1][1], shift.mat.m[1][0] }}};
+        }
+        plh_draw_overlays(&job, e->tex, job.img.comps, NULL, image->overlays, image->num_overlays,
+                          true, job.img.color, job.img.repr, &shift);
+    }
     if (ok) {
         e->params_digest = digest;
         e->crop = image->crop;

@@ -73,6 +73,27 @@ struct rp_geometry rp_fit_rects(pl_rect2df src, int iw, int ih, pl_rotation imag
     return geo;
 }
 
+// Without an image (:3084-3101): only the target rect is rounded, in the target's own rotation
+struct rp_geometry rp_fit_target(pl_rect2df dst, int tw, int th, pl_rotation target_rot)
+{
+    struct rp_geometry geo = {0};
+    if (rect_unset(&dst)) {
+        dst.x1 = tw;
+        dst.y1 = th;
+    }
+    geo.rotation = pl_rotation_normalize(-target_rot);
+    pl_rect2df_rotate(&dst, -geo.rotation);
+    const bool quarter = geo.rotation % PL_ROTATION_180 == PL_ROTATION_90;
+    const float lim_x = quarter ? th : tw, lim_y = quarter ? tw : th;
+    dst = (pl_rect2df) {
+        .x0 = roundf(PL_CLAMP(dst.x0, 0.0, lim_x)), .y0 = roundf(PL_CLAMP(dst.y0, 0.0, lim_y)),
+        .x1 = roundf(PL_CLAMP(dst.x1, 0.0, lim_x)), .y1 = roundf(PL_CLAMP(dst.y1, 0.0, lim_y)),
+    };
+    geo.dstf = dst;
+    geo.dst = (pl_rect2d) { dst.x0, dst.y0, dst.x1, dst.y1 };
+    return geo;
+}
+
 /* ======================================================================================== */
 /* planes and frames: :287-335 (detect_plane_type), :3048-3066, :3161-3293 (fix_frame)        */
 
@@ -508,7 +529,8 @@ void rp_plan_output(const struct pl_render_params *params, const struct pl_frame
                     struct rp_output_stage *out)
 {
     memset(out, 0, sizeof(*out));
-    const bool target_alpha = target->repr.alpha != PL_ALPHA_NONE;
+    // (a blended output has an alpha whatever the target stores: the blend unit reads it, :2713)
+    const bool target_alpha = target->repr.alpha != PL_ALPHA_NONE || params->blend_params;
 
     // background / border modes, with the pre-v7.346 switches folded in (:2498, :2707)
     out->background = params->background;

@@ -37,6 +37,8 @@ struct rp_geometry {
 // Fit `image_crop` (in texels of an iw x ih reference plane) onto `target_crop` (tw x th).
 struct rp_geometry rp_fit_rects(pl_rect2df image_crop, int iw, int ih, pl_rotation image_rot,
                                 pl_rect2df target_crop, int tw, int th, pl_rotation target_rot);
+// the same without an image: the rounded target rect only
+struct rp_geometry rp_fit_target(pl_rect2df target_crop, int tw, int th, pl_rotation target_rot);
 
 /* ---- frames and planes ---- */
 enum rp_plane_role {

@@ -139,6 +139,7 @@ void pl_renderer_destroy(pl_renderer *ptr)
     pl_shader_obj_destroy(&rr->tone_map_state);
     pl_shader_obj_destroy(&rr->dither_state);
     pl_dispatch_destroy(&rr->dp);
+    free(rr->osd_parts);
     free(rr);
     *ptr = NULL;
 }
@@ -515,8 +516,7 @@ void plh_job_watch_passes(struct frame_job *job)
 
 bool plh_params_supported(pl_renderer rr, const struct pl_render_params *p)
 {
-    const char *what = p->blend_params ? "blend_params" :
-                       p->deinterlace_params ? "deinterlace_params" :
+    const char *what = p->deinterlace_params ? "deinterlace_params" :
                        p->distort_params ? "distort_params" :
                        p->num_hooks ? "hooks" : NULL;
     if (!what)
@@ -533,10 +533,6 @@ static void note_ignored_members(pl_renderer rr, const struct pl_frame *f)
         rr->warned_icc = true;
         RR_LOG(rr, PL_LOG_WARN, "ICC profiles are not interpreted by this build (no lcms2): "
                "rendering from the frame's pl_color_space");
-    }
-    if (f->num_overlays && !rr->warned_overlay) {
-        rr->warned_overlay = true;
-        raise(rr, PL_RENDER_ERR_OVERLAY, PL_LOG_WARN, "Overlays are not drawn by this backend");
     }
     if (f->film_grain.type != PL_FILM_GRAIN_NONE && !rr->warned_grain) {
         rr->warned_grain = true;
@@ -1321,7 +1317,7 @@ static void clear_planes(struct frame_job *job, enum pl_clear_mode mode)
 }
 
 // color = (0, 0, 0, 1) with color[c] = previous[mapping[c]] (reference swizzle_color :791-808)
-static void append_swizzle(pl_shader sh, int comps, const int mapping[4])
+static void append_swizzle(pl_shader sh, int comps, const int mapping[4], bool force_alpha)
 {
     bool identity = comps == 4;
     uint32_t from = 0;
@@ -1337,7 +1333,9 @@ static void append_swizzle(pl_shader sh, int comps, const int mapping[4])
         return;
     op->i0 = from;
     op->i1 = comps;
-    sh_listf(sh, "swizzle(comps=%d, map=0x%08x)\n", comps, (unsigned) from);
+    op->i2 = force_alpha;
+    sh_listf(sh, "swizzle(comps=%d, map=0x%08x%s)\n", comps, (unsigned) from,
+             force_alpha ? ", keep alpha" : "");
 }
 
 // Run `*sh` into an intermediate, diffuse the quantisation error over it (one workgroup, the
@@ -1496,16 +1494,34 @@ bool plh_stage_output(struct frame_job *job)
             rr->last_dither_depth = dithered;
         }
 
-        if (!plh_append_scale(sh, 1.0f / out.scale, true)) {
+        // (a blended output keeps its alpha as it is: the blend unit's, not a stored value, :2911-2917)
+        if (!plh_append_scale(sh, 1.0f / out.scale, !params->blend_params)) {
             pl_dispatch_abort(rr->dp, &sh);
             return false;
         }
-        append_swizzle(sh, plane->components, plane->component_mapping);
+        append_swizzle(sh, plane->components, plane->component_mapping, params->blend_params);
         ok = pl_dispatch_finish(rr->dp, pl_dispatch_params(
             .shader = &sh,
             .target = plane->texture,
             .rect   = op->store,
+            .blend_params = params->blend_params,
         ));
+        if (!ok)
+            break;
+
+        // the frames' overlays over the finished plane (:2948-2958); a mixed frame's own
+        // overlays went onto its cached intermediate (render_mix.c)
+        const pl_transform2x2 shift = plh_plane_shift(plane,
+            target->planes[rp_reference_plane(target)].texture);
+        if (job->info.stage != PL_RENDER_STAGE_BLEND) {
+            plh_draw_overlays(job, plane->texture, plane->components, plane->component_mapping,
+                              job->image.overlays, job->image.num_overlays, true,
+                              target->color, target->repr, &shift);
+        }
+        plh_draw_overlays(job, plane->texture, plane->components, plane->component_mapping,
+                          target->overlays, target->num_overlays,
+                          job->info.stage != PL_RENDER_STAGE_BLEND, target->color, target->repr,
+                          &shift);
     }
     *img = (struct work_image) {0};
     return ok;
@@ -1513,7 +1529,7 @@ bool plh_stage_output(struct frame_job *job)
 
 /* ---- pl_render_image ------------------------------------------------------------------------ */
 
-// clear the target: what remains of a render without an image (there are no overlays here)
+// clear the target and draw its overlays: what remains of a render without an image
 static bool render_nothing(pl_renderer rr, const struct pl_frame *ptarget,
                            const struct pl_render_params *params)
 {
@@ -1536,6 +1552,18 @@ static bool render_nothing(pl_renderer rr, const struct pl_frame *ptarget,
             mode = PL_CLEAR_COLOR;
         if (mode != PL_CLEAR_SKIP)
             clear_planes(&job, mode);
+        // (:3397-3424) the target's overlays over the cleared planes
+        pl_tex ref = job.target.planes[rp_reference_plane(&job.target)].texture;
+        job.geo = rp_fit_target(job.target.crop, ref->params.w, ref->params.h,
+                                job.target.rotation);
+        job.target.crop = job.geo.dstf;
+        for (int i = 0; i < job.target.num_planes; i++) {
+            const struct pl_plane *plane = &job.target.planes[i];
+            const pl_transform2x2 shift = plh_plane_shift(plane, ref);
+            plh_draw_overlays(&job, plane->texture, plane->components, plane->component_mapping,
+                              job.target.overlays, job.target.num_overlays, false,
+                              job.target.color, job.target.repr, &shift);
+        }
     }
     plh_job_end(&job);
     return !bad;

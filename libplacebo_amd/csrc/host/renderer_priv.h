@@ -56,7 +56,9 @@ struct pl_renderer_t {
     pl_shader_obj dither_state;
     pl_shader_obj lut_state[RR_LUT_COUNT];
     int last_dither_depth;
-    bool warned_icc, warned_overlay, warned_grain;
+    bool warned_icc, warned_grain;
+    struct plh_overlay_part *osd_parts;     // the overlay being drawn, placed on the plane
+    int osd_cap;
 
     struct mix_entry cache[RR_MAX_CACHED_FRAMES];
     int num_cached;
@@ -119,5 +121,14 @@ pl_tex plh_work_texture(struct frame_job *job, struct work_image *img);
 // append a plain 1:1 fetch of another texture to `sh` as a colour op
 bool plh_append_plane_fetch(pl_shader sh, const pl_shader fetch, const struct pl_plane *plane);
 struct plh_op *plh_append_scale(pl_shader sh, float k, bool with_alpha);
+
+// render_overlay.c (reference draw_overlays, src/renderer.c:811-1020): `overlays` over `fbo`, which
+// holds `comps` components (`comp_map`: the plane's) of a frame in `color` / `repr`;
+// `output_shift`: target pixels -> texels of `fbo`
+void plh_draw_overlays(struct frame_job *job, pl_tex fbo, int comps, const int comp_map[4],
+                       const struct pl_overlay *overlays, int num, bool have_image,
+                       struct pl_color_space color, struct pl_color_repr repr,
+                       const pl_transform2x2 *output_shift);
+pl_transform2x2 plh_plane_shift(const struct pl_plane *plane, pl_tex ref);
 
 #endif // PLH_RENDERER_PRIV_H_

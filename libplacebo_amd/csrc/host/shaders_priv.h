@@ -9,6 +9,7 @@
 #include <libplacebo/shaders.h>
 #include <libplacebo/shaders/colorspace.h>
 #include <libplacebo/colorspace.h>
+#include <libplacebo/dispatch.h>
 
 #include "gpu_priv.h"
 
@@ -137,6 +138,22 @@ struct plh_pass_exec {
 // returns 0, a negative plh error code, or PLH_EXEC_BAD_* (message already logged)
 int plh_pass_execute(pl_gpu gpu, pl_log log, const struct plh_pass_exec *x, pl_tex target,
                      pl_rect2d rc, pl_timer timer, pl_buf *noise);
+
+// An overlay (or a rendered pass being blended) as the dispatch takes it: `parts` in target pixels,
+// drawn in order. The shader holds colour ops only; for PLH_OVERLAY_MONOCHROME the texture's
+// coverage multiplies the colour in front of op `coverage_at` (the plane's swizzle).
+struct plh_overlay_draw {
+    pl_tex tex;
+    int mode;                               // enum plh_overlay_mode
+    bool linear;
+    bool premultiplied;
+    int coverage_at;
+    const struct pl_blend_params *blend;    // NULL: the colour replaces the target's
+    const struct plh_overlay_part *parts;
+    int num_parts;
+};
+bool plh_dispatch_overlay(pl_dispatch dp, pl_shader *sh, pl_tex target,
+                          const struct plh_overlay_draw *draw);
 
 #define SH_GPU(sh) ((sh)->params.gpu)
 

@@ -1699,6 +1699,92 @@ ORC_API void orc_error_diffusion(const float *img, int w, int h, int depth, int 
 
 // plh_un8 / plh_un16 (csrc/hip/devmath.hiph): q = v*(1/d); q += fma(-q, d, v)*(1/d) must be
 // the correctly rounded v/d for every code value. Returns the number of mismatches.
+/* ======================================================================== */
+/* overlays (src/renderer.c:811-1020) and the blend unit (gpu.h pl_blend_params)  */
+
+// One overlay part as it lands on a plane. The reference emits two triangles whose vertices carry
+// `pos` (the part's dst corners through the overlay transform) and `coord` (its src corners over
+// the texture size) and lets the rasteriser interpolate (:896-931); on a parallelogram that
+// interpolation is the affine function restated here, and a pixel belongs to the part when its
+// centre lies inside (top-left rule: the low edges count, the high ones do not).
+//     coord.x = u0 + ((p.x - ox) * ux + (p.y - oy) * uy),  coord.y likewise with v
+struct orc_overlay_part {
+    float x0, y0, x1, y1;
+    float ox, oy;
+    float ux, uy, u0;
+    float vx, vy, v0;
+    float color[4];
+};
+
+enum { ORC_OVERLAY_NORMAL = 0, ORC_OVERLAY_MONOCHROME };
+
+// The fragments of one part over a w x h plane: mask = covered, color = what the overlay shader
+// starts from (:952-961: the texture, or the part's colour), coverage = texture.r (the factor of
+// :987-991; 1 for NORMAL)
+ORC_API void orc_overlay_fragments(const float *tex, int tw, int th, int linear, int mode,
+                                   const struct orc_overlay_part *q, int w, int h,
+                                   float *color, float *coverage, uint8_t *mask)
+{
+    const struct orc_src s = { .tex = tex, .w = tw, .h = th, .address_mode = ADDR_CLAMP };
+    for (int y = 0; y < h; y++) {
+        for (int x = 0; x < w; x++) {
+            const size_t i = (size_t) y * w + x;
+            const float px = (float) x + 0.5f, py = (float) y + 0.5f;
+            mask[i] = px >= q->x0 && px < q->x1 && py >= q->y0 && py < q->y1;
+            coverage[i] = 1.0f;
+            if (!mask[i])
+                continue;
+            const float u = q->u0 + ((px - q->ox) * q->ux + (py - q->oy) * q->uy);
+            const float v = q->v0 + ((px - q->ox) * q->vx + (py - q->oy) * q->vy);
+            float t[4];
+            if (linear)
+                tex_linear(&s, u, v, t);
+            else
+                tex_nearest(&s, u, v, t);
+            if (mode == ORC_OVERLAY_MONOCHROME) {
+                memcpy(color + 4 * i, q->color, 16);
+                coverage[i] = t[0];
+            } else {
+                memcpy(color + 4 * i, t, 16);
+            }
+        }
+    }
+}
+
+// pl_blend_mode (gpu.h): ZERO, ONE, SRC_ALPHA, ONE_MINUS_SRC_ALPHA
+static float blend_factor(int mode, float src_alpha)
+{
+    return mode == 1 ? 1.0f : mode == 2 ? src_alpha : mode == 3 ? 1.0f - src_alpha : 0.0f;
+}
+
+// The blend unit over the masked pixels: a fixed-point target clamps the fragment to [0, 1]
+// first; result = src * Sf + dst * Df per channel, rgb and alpha with their own factors
+// (factors = src_rgb, dst_rgb, src_alpha, dst_alpha; enable = 0: the fragment replaces the
+// target). The caller rounds `dst` through the target format afterwards.
+ORC_API void orc_blend(float *dst, const float *src, const uint8_t *mask, size_t npix,
+                       const int factors[4], int enable, int fixed_point)
+{
+    for (size_t i = 0; i < npix; i++) {
+        if (mask && !mask[i])
+            continue;
+        float c[4];
+        memcpy(c, src + 4 * i, 16);
+        if (fixed_point) {
+            for (int k = 0; k < 4; k++)
+                c[k] = clampf(c[k], 0.0f, 1.0f);
+        }
+        float *d = dst + 4 * i;
+        if (enable) {
+            const float fs = blend_factor(factors[0], c[3]), fd = blend_factor(factors[1], c[3]);
+            const float as = blend_factor(factors[2], c[3]), ad = blend_factor(factors[3], c[3]);
+            for (int k = 0; k < 3; k++)
+                c[k] = c[k] * fs + d[k] * fd;
+            c[3] = c[3] * as + d[3] * ad;
+        }
+        memcpy(d, c, 16);
+    }
+}
+
 ORC_API int orc_check_unorm_decode(int bits)
 {
     const float d = bits == 8 ? 255.0f : 65535.0f;

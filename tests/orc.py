@@ -387,3 +387,37 @@ def custom_lut(img, lut, size):
     size = tuple(size) + (0,) * (3 - len(size))
     lib().orc_custom_lut(_p(img), C.c_size_t(img.size // 4), _p(lut), (C.c_int * 3)(*size))
     return img
+
+
+class OverlayPart(C.Structure):
+    """struct orc_overlay_part: a part as it lands on a plane (pl_oracle.c)"""
+    _fields_ = [("x0", C.c_float), ("y0", C.c_float), ("x1", C.c_float), ("y1", C.c_float),
+                ("ox", C.c_float), ("oy", C.c_float),
+                ("ux", C.c_float), ("uy", C.c_float), ("u0", C.c_float),
+                ("vx", C.c_float), ("vy", C.c_float), ("v0", C.c_float),
+                ("color", C.c_float * 4)]
+
+
+OVERLAY_NORMAL, OVERLAY_MONOCHROME = 0, 1
+
+
+def overlay_fragments(tex, linear, mode, part, w, h):
+    """fragments of one overlay part over a w x h plane: (color, coverage, mask)"""
+    tex = np.ascontiguousarray(tex, dtype=np.float32)
+    color = np.zeros((h, w, 4), np.float32)
+    cov = np.ones((h, w), np.float32)
+    mask = np.zeros((h, w), np.uint8)
+    lib().orc_overlay_fragments(_p(tex), tex.shape[1], tex.shape[0], int(linear), mode,
+                                C.byref(part), w, h, _p(color), _p(cov), _p(mask))
+    return color, cov, mask
+
+
+def blend(dst, src, mask, factors, enable=True, fixed_point=True):
+    """the blend unit over the masked pixels of `dst` (in place; not yet rounded to a format)"""
+    assert dst.dtype == np.float32 and dst.flags.c_contiguous
+    src = np.ascontiguousarray(src, dtype=np.float32)
+    f = (C.c_int * 4)(*factors)
+    m = np.ascontiguousarray(mask, dtype=np.uint8) if mask is not None else None
+    lib().orc_blend(_p(dst), _p(src), _p(m) if m is not None else None,
+                    dst.shape[0] * dst.shape[1], f, int(enable), int(fixed_point))
+    return dst
