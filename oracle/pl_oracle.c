@@ -18,6 +18,10 @@
  *     "TODO: embed a reference texture") and the reference's Vulkan execution
  *     cannot run here: for those stages parity is "unpinned" beyond the small
  *     gpu_tests.c vectors restated in tests/; see DESIGN.md §Oracle.
+ *   - Overlay rasterisation and blending (orc_overlay_fragments, orc_blend): parity UNPINNED
+ *     -- the reference's tests never draw an overlay on a backend that rasterises; the
+ *     restatement is held to the graphics APIs' rules by hand-worked cases
+ *     (tests/test_oracle_overlay.py).
  *
  * Float semantics. GLSL leaves contraction, mix() and texture filtering
  * precision open; this file fixes them (same choices as csrc/hip/devmath.hiph,
