@@ -109,7 +109,7 @@ struct pl_render_params {
 
     const struct pl_cone_params *cone_params; // colour blindness simulation (NULL = off)
     const struct pl_blend_params *blend_params;             // the frame is blended INTO the target
-    const struct pl_deinterlace_params *deinterlace_params; // unsupported, must be NULL
+    const struct pl_deinterlace_params *deinterlace_params; // frames with a `field` are deinterlaced
     const struct pl_distort_params *distort_params;         // unsupported, must be NULL
     const struct pl_hook * const *hooks;                    // unsupported, must be NULL
     int num_hooks;
@@ -213,8 +213,10 @@ struct pl_frame {
     int num_planes;           // 1..4 (packed, semi-planar, planar)
     struct pl_plane planes[PL_MAX_PLANES];
 
-    // Interlacing description, filled in by pl_queue (utils/frame_queue.h). This backend has no
-    // deinterlacer (`deinterlace_params` is refused), so the renderer shows such frames woven.
+    // Interlacing description, filled in by pl_queue (utils/frame_queue.h): the field to show,
+    // which field comes first in time, and the neighbouring frames the temporal deinterlacers
+    // read (same plane layout and sizes). Deinterlaced with pl_render_params.deinterlace_params,
+    // shown woven without.
     enum pl_field field;
     enum pl_field first_field;
     const struct pl_frame *prev, *next;

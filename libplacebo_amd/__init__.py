@@ -157,6 +157,10 @@ class ShaderObj:
         lib().pl_shader_obj_destroy(C.byref(self.slot))
 
 
+FIELD_NONE, FIELD_TOP, FIELD_BOTTOM = 0, 1, 2
+DEINTERLACE_WEAVE, DEINTERLACE_BOB, DEINTERLACE_YADIF, DEINTERLACE_BWDIF = 0, 1, 2, 3
+
+
 class Shader:
     """A pl_shader obtained from pl_dispatch_begin."""
 
@@ -257,6 +261,18 @@ class Shader:
 
     def extract_features(self, csp):
         lib().pl_shader_extract_features(self.sh, csp)
+
+    def deinterlace(self, cur, prev=None, next_=None, field=FIELD_TOP, first_field=FIELD_TOP,
+                    algo=DEINTERLACE_YADIF, skip_spatial_check=False, component_mask=0):
+        src = capi.DeinterlaceSource(field=field, first_field=first_field,
+                                     component_mask=component_mask)
+        src.cur.top = cur.ptr
+        if prev is not None:
+            src.prev.top = prev.ptr
+        if next_ is not None:
+            src.next.top = next_.ptr
+        params = capi.DeinterlaceParams(algo, skip_spatial_check)
+        lib().pl_shader_deinterlace(self.sh, C.byref(src), C.byref(params))
 
     def color_map(self, src, dst, state_obj=None, params=None, prelinearized=False,
                   feature_map=None):

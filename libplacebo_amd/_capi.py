@@ -429,6 +429,19 @@ class FilmGrainData(C.Structure):
     _fields_ = [("type", C.c_int), ("seed", C.c_uint64), ("params", _GrainUnion)]
 
 
+class DeinterlaceParams(C.Structure):
+    _fields_ = [("algo", C.c_int), ("skip_spatial_check", C.c_bool)]
+
+
+class FieldPair(C.Structure):
+    _fields_ = [("top", C.POINTER(Tex))]
+
+
+class DeinterlaceSource(C.Structure):
+    _fields_ = [("prev", FieldPair), ("cur", FieldPair), ("next", FieldPair),
+                ("field", C.c_int), ("first_field", C.c_int), ("component_mask", C.c_uint8)]
+
+
 class OverlayPart(C.Structure):
     _fields_ = [("src", Rect2df), ("dst", Rect2df), ("color", C.c_float * 4)]
 
@@ -494,7 +507,7 @@ class RenderParams(C.Structure):
                 ("dither_params", C.POINTER(DitherParams)),
                 ("error_diffusion", C.POINTER(ErrorDiffusionKernel)),
                 ("cone_params", C.POINTER(ConeParams)), ("blend_params", C.POINTER(BlendParams)),
-                ("deinterlace_params", C.c_void_p), ("distort_params", C.c_void_p),
+                ("deinterlace_params", C.POINTER(DeinterlaceParams)), ("distort_params", C.c_void_p),
                 ("hooks", C.c_void_p), ("num_hooks", C.c_int), ("lut", C.POINTER(CustomLut)),
                 ("lut_type", C.c_int), ("background", C.c_int), ("border", C.c_int),
                 ("background_color", C.c_float * 3), ("background_transparency", C.c_float),

@@ -1,0 +1,261 @@
+/*
+ * libplacebo-hip -- deinterlacing (pl_shader_deinterlace, reference src/shaders/deinterlacing.c).
+ *
+ * An interlaced frame holds two fields woven row by row. The field being shown passes through;
+ * the rows of the other one are rebuilt from their neighbours in space (the rows above and below)
+ * and in time (the previous and the next frame): doubled (bob), by yadif's edge-directed predictor
+ * clamped to what the temporal neighbours allow, or by bwdif's two cubic filters chosen per pixel
+ * by motion. Every output is a function of a dozen to two dozen texels within +-3 columns and
+ * +-4 rows of three frames: a stencil that moves a frame's bytes in and out once and is bound by
+ * the number of loads a lane issues, not by their bytes (DESIGN 4.10's finding).
+ *
+ * The reference runs one invocation per output pixel and notes itself that half of them idle (the
+ * kept rows). Here a lane owns a ROW PAIR -- one kept row, one rebuilt row of the same column --
+ * so that every lane of a wave does the same work, and the rows of the current frame a pair needs
+ * (two above, two below) are loaded once for both. The colour ops recorded behind the sampler run
+ * through the interpreter, two pixels per lane.
+ */
+#include "colorops.hiph"
+#include "backend.h"
+
+#define DEINT_BW 64
+#define DEINT_BH 4
+
+// GET(TEX, X, Y): nearest texel under the MIRROR address mode the reference binds with (:51)
+DEV float4_t deint_get(const plh_view &v, int x, int y)
+{
+    return plh_fetch(v, plh_wrap(x, v.w, PLH_ADDRESS_MIRROR), plh_wrap(y, v.h, PLH_ADDRESS_MIRROR));
+}
+
+DEV float comp(const float4_t &c, int ch)
+{
+    return ch == 0 ? c.x : ch == 1 ? c.y : ch == 2 ? c.z : c.w;
+}
+
+// yadif's spatial predictor (:131-157): the direction, out of five, along which the rows above
+// and below agree best
+DEV float yadif_spatial(const float (&up)[7], const float (&dn)[7], float bias)
+{
+    float pred = (up[3] + dn[3]) / 2.0f;
+    float best = __builtin_fabsf(up[2] - dn[2]) + __builtin_fabsf(up[3] - dn[3]) +
+                 __builtin_fabsf(up[4] - dn[4]) - bias;
+    // leaning left: one step, then two
+    float score = __builtin_fabsf(up[1] - dn[3]) + __builtin_fabsf(up[2] - dn[4]) +
+                  __builtin_fabsf(up[3] - dn[5]);
+    if (score < best) {
+        pred = (up[2] + dn[4]) / 2.0f;
+        best = score;
+        score = __builtin_fabsf(up[0] - dn[4]) + __builtin_fabsf(up[1] - dn[5]) +
+                __builtin_fabsf(up[2] - dn[6]);
+        if (score < best) {
+            pred = (up[1] + dn[5]) / 2.0f;
+            best = score;
+        }
+    }
+    // leaning right
+    score = __builtin_fabsf(up[3] - dn[1]) + __builtin_fabsf(up[4] - dn[2]) +
+            __builtin_fabsf(up[5] - dn[3]);
+    if (score < best) {
+        pred = (up[4] + dn[2]) / 2.0f;
+        best = score;
+        score = __builtin_fabsf(up[4] - dn[0]) + __builtin_fabsf(up[5] - dn[1]) +
+                __builtin_fabsf(up[6] - dn[2]);
+        if (score < best) {
+            pred = (up[5] + dn[1]) / 2.0f;
+            best = score;
+        }
+    }
+    return pred;
+}
+
+// Rows of one column around the rebuilt row y: the current frame at -3 -1 +1 +3, the nearest
+// temporal neighbours at -1 +1, the second ones at -4 -2 0 +2 +4
+struct deint_column {
+    float cur[4];
+    float prev[2], next[2];
+    float prev2[5], next2[5];
+};
+
+// yadif's temporal predictor (:188-216): the spatial prediction clamped around the average of the
+// second neighbours by as much as the fields around it changed
+DEV float yadif_temporal(const deint_column &t, float pred, bool skip_spatial_check)
+{
+    const float F = t.cur[1], G = t.cur[2];
+    const float p0 = (t.prev2[1] + t.next2[1]) / 2.0f, p2 = (t.prev2[2] + t.next2[2]) / 2.0f,
+                p4 = (t.prev2[3] + t.next2[3]) / 2.0f;
+    const float tdiff0 = __builtin_fabsf(t.prev2[2] - t.next2[2]) / 2.0f;
+    const float tdiff1 = (__builtin_fabsf(t.prev[0] - F) + __builtin_fabsf(t.prev[1] - G)) / 2.0f;
+    const float tdiff2 = (__builtin_fabsf(t.next[0] - F) + __builtin_fabsf(G - t.next[1])) / 2.0f;
+    float diff = fmaxf(tdiff0, fmaxf(tdiff1, tdiff2));
+    if (!skip_spatial_check) {
+        const float maxi = fmaxf(p2 - fminf(G, F), fminf(p0 - F, p4 - G));
+        const float mini = fminf(p2 - fmaxf(G, F), fmaxf(p0 - F, p4 - G));
+        diff = fmaxf(diff, fmaxf(mini, -maxi));
+    }
+    if (pred > p2 + diff)
+        pred = p2 + diff;
+    if (pred < p2 - diff)
+        pred = p2 - diff;
+    return pred;
+}
+
+// bwdif (:270-322)
+DEV float bwdif_intra(const float (&cur)[4])
+{
+    return (5077.0f / 8192.0f) * (cur[1] + cur[2]) - (981.0f / 8192.0f) * (cur[0] + cur[3]);
+}
+
+DEV float bwdif_process(const deint_column &t)
+{
+    const float s = t.prev2[2] + t.next2[2];
+    const float d = s / 2.0f;
+    const float c = t.cur[1], e = t.cur[2];
+
+    const float tdiff0 = __builtin_fabsf(t.prev2[2] - t.next2[2]);
+    const float tdiff1 = __builtin_fabsf(t.prev[0] - c) + __builtin_fabsf(t.prev[1] - e);
+    const float tdiff2 = __builtin_fabsf(t.next[0] - c) + __builtin_fabsf(t.next[1] - e);
+    float diff = fmaxf(tdiff0, fmaxf(tdiff1, tdiff2)) / 2.0f;
+    const bool still = diff == 0.0f;
+
+    const float bs = t.prev2[1] + t.next2[1], fs = t.prev2[3] + t.next2[3];
+    const float b = (bs / 2.0f) - c, f = (fs / 2.0f) - c;
+    const float dc = d - c, de = d - e;
+    const float mmax = fmaxf(de, fmaxf(dc, fminf(b, f)));
+    const float mmin = fminf(de, fminf(dc, fmaxf(b, f)));
+    diff = fmaxf(diff, fmaxf(mmin, -mmax));
+
+    const float edges = t.cur[0] + t.cur[3];
+    const float single = (5077.0f / 8192.0f) * (c + e) - (981.0f / 8192.0f) * edges;
+    float all = ((5570.0f / 8192.0f) * s - (3801.0f / 8192.0f) * (bs + fs) +
+                 (1016.0f / 8192.0f) * (t.prev2[0] + t.next2[0] + t.prev2[4] + t.next2[4])) / 4.0f;
+    all += (4309.0f / 8192.0f) * (c + e) - (213.0f / 8192.0f) * edges;
+
+    float interpol = __builtin_fabsf(c - e) > tdiff0 ? all : single;
+    interpol = fminf(fmaxf(interpol, d - diff), d + diff);
+    return still ? d : interpol;
+}
+
+template <bool LITE>
+__global__ __launch_bounds__(DEINT_BW * DEINT_BH)
+void k_deinterlace(const plh_pass p_)
+{
+    const plh_pass &p = plh_kernarg_pass();
+    const plh_view &cur = p.s.src;
+    const plh_deint_args &a = p.deint;
+    const int x = blockIdx.x * DEINT_BW + (int) (threadIdx.x % DEINT_BW);
+    const int pair = blockIdx.y * DEINT_BH + (int) (threadIdx.x / DEINT_BW);
+    // the pair's kept row and the row to rebuild (the whole frame is kept without a field)
+    const int yk = 2 * pair + a.keep, yr = 2 * pair + 1 - a.keep;
+    const bool rebuild = a.algo != PLH_DEINT_WEAVE && a.keep >= 0;
+
+    float4_t c[2];
+    c[0] = deint_get(cur, x, a.keep >= 0 ? yk : 2 * pair);
+    c[1] = deint_get(cur, x, a.keep >= 0 ? yr : 2 * pair + 1);
+    if (rebuild) {
+        const plh_view &prev2 = a.first ? a.prev : cur, &next2 = a.first ? cur : a.next;
+        if (a.algo == PLH_DEINT_BOB) {
+            // the kept row above (top field shown) or below
+            c[1] = deint_get(cur, x, yr + (a.keep ? 1 : -1));
+        } else if (a.algo == PLH_DEINT_BWDIF && a.intra_only) {
+            const float4_t r[4] = { deint_get(cur, x, yr - 3), deint_get(cur, x, yr - 1),
+                                    deint_get(cur, x, yr + 1), deint_get(cur, x, yr + 3) };
+            float out[4];
+#pragma unroll
+            for (int ch = 0; ch < 4; ch++) {
+                const float col[4] = { comp(r[0], ch), comp(r[1], ch), comp(r[2], ch), comp(r[3], ch) };
+                out[ch] = bwdif_intra(col);
+            }
+            c[1] = { out[0], out[1], out[2], out[3] };
+        } else {
+            // the column's temporal neighbourhood, all four components at once
+            float4_t tc[4], tp[2], tn[2], tp2[5], tn2[5];
+#pragma unroll
+            for (int k = 0; k < 4; k++)
+                tc[k] = deint_get(cur, x, yr + 2 * k - 3);
+#pragma unroll
+            for (int k = 0; k < 2; k++) {
+                tp[k] = deint_get(a.prev, x, yr + 2 * k - 1);
+                tn[k] = deint_get(a.next, x, yr + 2 * k - 1);
+            }
+#pragma unroll
+            for (int k = 0; k < 5; k++) {
+                tp2[k] = deint_get(prev2, x, yr + 2 * k - 4);
+                tn2[k] = deint_get(next2, x, yr + 2 * k - 4);
+            }
+            float4_t up[7], dn[7];
+            if (a.algo == PLH_DEINT_YADIF) {
+#pragma unroll
+                for (int k = 0; k < 7; k++) {
+                    up[k] = k == 3 ? tc[1] : deint_get(cur, x + k - 3, yr - 1);
+                    dn[k] = k == 3 ? tc[2] : deint_get(cur, x + k - 3, yr + 1);
+                }
+            }
+            float out[4];
+#pragma unroll
+            for (int ch = 0; ch < 4; ch++) {
+                deint_column t;
+#pragma unroll
+                for (int k = 0; k < 4; k++)
+                    t.cur[k] = comp(tc[k], ch);
+#pragma unroll
+                for (int k = 0; k < 2; k++) {
+                    t.prev[k] = comp(tp[k], ch);
+                    t.next[k] = comp(tn[k], ch);
+                }
+#pragma unroll
+                for (int k = 0; k < 5; k++) {
+                    t.prev2[k] = comp(tp2[k], ch);
+                    t.next2[k] = comp(tn2[k], ch);
+                }
+                if (a.algo == PLH_DEINT_YADIF) {
+                    float u[7], d[7];
+#pragma unroll
+                    for (int k = 0; k < 7; k++) {
+                        u[k] = comp(up[k], ch);
+                        d[k] = comp(dn[k], ch);
+                    }
+                    out[ch] = yadif_temporal(t, yadif_spatial(u, d, a.spatial_bias),
+                                             a.skip_spatial_check != 0);
+                } else {
+                    out[ch] = bwdif_process(t);
+                }
+            }
+            c[1] = { out[0], out[1], out[2], out[3] };
+        }
+    }
+
+    // components outside the mask keep the shader's initial colour (0, 0, 0, 1) (:37, :364)
+    frag_t fcs[2];
+    int sx[2], sy[2];
+    bool ok[2];
+#pragma unroll
+    for (int q = 0; q < 2; q++) {
+        if (!(p.s.comp_mask & 1u)) c[q].x = 0.0f;
+        if (!(p.s.comp_mask & 2u)) c[q].y = 0.0f;
+        if (!(p.s.comp_mask & 4u)) c[q].z = 0.0f;
+        if (!(p.s.comp_mask & 8u)) c[q].w = 1.0f;
+        const int idx = x, idy = a.keep >= 0 ? (q ? yr : yk) : 2 * pair + q;
+        fcs[q] = { (float) (idx + p.frag_x0) + 0.5f, (float) (idy + p.frag_y0) + 0.5f, 0.0f, 0,
+                   p.out_scale[0] * ((float) idx + 0.5f), p.out_scale[1] * ((float) idy + 0.5f) };
+        sx[q] = p.base_x + p.dir_x * (p.transpose ? idy : idx);
+        sy[q] = p.base_y + p.dir_y * (p.transpose ? idx : idy);
+        ok[q] = idx < p.width && idy < p.height && sx[q] >= 0 && sy[q] >= 0 &&
+                sx[q] < p.dst.w && sy[q] < p.dst.h;
+    }
+    apply_ops_n<2, false, LITE>(c, p.ops, 0, p.num_ops, fcs);
+    plh_store_n<2>(p.dst, sx, sy, ok, c, p.nt_store);
+}
+
+extern "C" int plh_launch_deinterlace(plh_stream stream_, const struct plh_pass *pass)
+{
+    hipStream_t stream = (hipStream_t) stream_;
+    const dim3 grid((pass->width + DEINT_BW - 1) / DEINT_BW,
+                    ((pass->height + 1) / 2 + DEINT_BH - 1) / DEINT_BH);
+    const dim3 block(DEINT_BW * DEINT_BH);
+    if (plh_ops_lite(pass, 0, pass->num_ops))
+        PLH_LAUNCH_LAST(k_deinterlace<true>, grid, block, 0, stream, *pass);
+    else
+        PLH_LAUNCH_LAST(k_deinterlace<false>, grid, block, 0, stream, *pass);
+    const hipError_t err = hipGetLastError();
+    return err == hipSuccess ? 0 : -(int) err;
+}

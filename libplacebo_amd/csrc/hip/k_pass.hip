@@ -1403,6 +1403,7 @@ int plh_launch_polar(hipStream_t stream, const plh_pass *pass);
 int plh_launch_ortho(hipStream_t stream, const plh_pass *pass);
 int plh_launch_deband(hipStream_t stream, const plh_pass *pass);
 int plh_launch_peak(hipStream_t stream, const plh_pass *pass);
+extern "C" int plh_launch_deinterlace(plh_stream stream, const struct plh_pass *pass);
 
 extern "C" int plh_launch_pass(plh_stream stream_, const struct plh_pass *pass)
 {
@@ -1443,6 +1444,14 @@ extern "C" int plh_launch_pass(plh_stream stream_, const struct plh_pass *pass)
         return plh_launch_ortho(stream, pass);
     case PLH_SAMPLE_DEBAND:
         return plh_launch_deband(stream, pass);
+    case PLH_SAMPLE_DEINTERLACE:
+        // (its kernel carries the plain interpreter: a measurement, a frame mix or the tricubic
+        // LUT behind it need the deinterlaced plane as a texture first, as the renderer arranges)
+        for (int i = 0; i < pass->num_ops; i++) {
+            if (pass->ops[i].kind == PLH_OP_PEAK_DETECT || pass->ops[i].kind == PLH_OP_MIX_ADD)
+                return -1004;
+        }
+        return cubic ? -1004 : plh_launch_deinterlace(stream_, pass);
     default:
         break;
     }

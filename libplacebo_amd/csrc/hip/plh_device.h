@@ -47,6 +47,7 @@ enum plh_sampler {
     PLH_SAMPLE_POLAR,       // sampling.c:587 (EWA, LDS-tiled)
     PLH_SAMPLE_ORTHO,       // sampling.c:950 (one separable pass)
     PLH_SAMPLE_DEBAND,      // sampling.c:183
+    PLH_SAMPLE_DEINTERLACE, // shaders/deinterlacing.c:26 (k_deinterlace.hip)
 };
 
 enum plh_address_mode {     // gpu.h pl_tex_address_mode
@@ -300,6 +301,27 @@ struct plh_map_chain {
     float in_mat[9], out_mat[9], out_add;
 };
 
+/* ---- deinterlacing (k_deinterlace.hip; reference src/shaders/deinterlacing.c) ---- */
+enum plh_deint_algo {           // shaders/deinterlacing.h pl_deinterlace_algorithm
+    PLH_DEINT_WEAVE = 0,
+    PLH_DEINT_BOB,
+    PLH_DEINT_YADIF,
+    PLH_DEINT_BWDIF,
+};
+
+// The frame being deinterlaced is the sampler's `src`; rows of parity `keep` are the field being
+// shown and pass through, the others are interpolated.
+struct plh_deint_args {
+    struct plh_view prev, next; // the neighbouring frames (`src` again where there is none)
+    int32_t algo;               // enum plh_deint_algo
+    int32_t keep;               // row parity of the field that is output as it is (0 = top)
+    int32_t first;              // that field is the frame's first in time: the "second" temporal
+                                // neighbours are (prev, cur), else (cur, next)
+    int32_t intra_only;         // BWDIF without the frame it would need: spatial filter only
+    int32_t skip_spatial_check; // YADIF
+    float spatial_bias;         // YADIF: 1 / 255 as the reference prints it
+};
+
 struct plh_pass {
     struct plh_sampler_args s;
 
@@ -336,6 +358,8 @@ struct plh_pass {
     // waiting on the stream and copying the buffer back
     void *peak_mailbox;
     uint32_t peak_ticket;
+
+    struct plh_deint_args deint;    // PLH_SAMPLE_DEINTERLACE
 };
 
 /* ---- error diffusion (k_errdiff.hip) ------------------------------------------ */

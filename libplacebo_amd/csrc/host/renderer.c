@@ -27,6 +27,8 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <libplacebo/shaders/deinterlacing.h>
+
 #include "renderer_priv.h"
 
 const struct pl_render_params pl_render_fast_params = { PL_RENDER_DEFAULTS };
@@ -516,8 +518,7 @@ void plh_job_watch_passes(struct frame_job *job)
 
 bool plh_params_supported(pl_renderer rr, const struct pl_render_params *p)
 {
-    const char *what = p->deinterlace_params ? "deinterlace_params" :
-                       p->distort_params ? "distort_params" :
+    const char *what = p->distort_params ? "distort_params" :
                        p->num_hooks ? "hooks" : NULL;
     if (!what)
         return true;
@@ -552,11 +553,41 @@ void plh_job_end(struct frame_job *job)
         plh_tex_read_so_far(rr->gpu, job->measure_fbo, 0);
         job->measure_fbo = NULL;
     }
+    if (job->prev_acquired && job->prev.release)
+        job->prev.release(rr->gpu, &job->prev);
+    if (job->next_acquired && job->next.release)
+        job->next.release(rr->gpu, &job->next);
+    job->prev_acquired = job->next_acquired = false;
     if (job->image_acquired && job->image.release)
         job->image.release(rr->gpu, &job->image);
     if (job->target_acquired && !job->target_borrowed && job->target.release)
         job->target.release(rr->gpu, &job->target);
     job->image_acquired = job->target_acquired = false;
+}
+
+// validate_deinterlace_ref (:2989-3001, :3033-3039)
+static const char *deinterlace_refs_problem(const struct pl_frame *image)
+{
+    if (image->field == PL_FIELD_NONE)
+        return NULL;
+    if (image->first_field == PL_FIELD_NONE)
+        return "an interlaced frame must say which field comes first (first_field)";
+    const struct pl_frame *refs[2] = { image->prev, image->next };
+    for (int r = 0; r < 2; r++) {
+        const struct pl_frame *ref = refs[r];
+        if (!ref)
+            continue;
+        if (ref->num_planes != image->num_planes)
+            return "prev / next must have the planes of the frame they surround";
+        for (int p = 0; p < image->num_planes; p++) {
+            pl_tex a = image->planes[p].texture, b = ref->planes[p].texture;
+            if (!b || !b->params.sampleable || a->params.w != b->params.w ||
+                a->params.h != b->params.h ||
+                a->params.format->num_components != b->params.format->num_components)
+                return "prev / next must have sampleable planes of the same size and components";
+        }
+    }
+    return NULL;
 }
 
 // acquire both frames, validate, fit the rects, complete the descriptions (:3317-3428)
@@ -576,7 +607,34 @@ bool plh_job_begin(struct frame_job *job, bool acquire_image)
         job->image_acquired = true;
     }
 
+    // the frames a temporal deinterlacer reads beside the image (:3329-3350)
+    const struct pl_deinterlace_params *deint = job->params->deinterlace_params;
+    if (acquire_image && job->image.field != PL_FIELD_NONE && deint &&
+        pl_deinterlace_needs_refs(deint->algo))
+    {
+        if (job->image.prev) {
+            job->prev = *job->image.prev;
+            job->image.prev = &job->prev;
+            if (job->prev.acquire && !job->prev.acquire(rr->gpu, &job->prev)) {
+                plh_job_end(job);
+                return false;
+            }
+            job->prev_acquired = true;
+        }
+        if (job->image.next) {
+            job->next = *job->image.next;
+            job->image.next = &job->next;
+            if (job->next.acquire && !job->next.acquire(rr->gpu, &job->next)) {
+                plh_job_end(job);
+                return false;
+            }
+            job->next_acquired = true;
+        }
+    }
+
     const char *bad = rp_frame_problem(&job->image, false);
+    if (!bad)
+        bad = deinterlace_refs_problem(&job->image);
     if (bad) {
         RR_LOG(rr, PL_LOG_ERR, "Image frame: %s", bad);
     } else if ((bad = rp_frame_problem(&job->target, true))) {
@@ -688,6 +746,36 @@ static void deband_plane(struct frame_job *job, struct work_image *pimg, const f
     pimg->fail_tex = source;
 }
 
+// An interlaced frame: the plane becomes its deinterlaced version (recorded, not yet run),
+// stored -- if it has to be -- in the plane's own format (:1591-1612)
+static void deinterlace_plane(struct frame_job *job, struct work_image *pimg, int plane)
+{
+    pl_renderer rr = job->rr;
+    const struct pl_frame *image = &job->image;
+    const struct pl_render_params *params = job->params;
+    if (image->field == PL_FIELD_NONE || !params->deinterlace_params || !job->caps.fbo[4] ||
+        (rr->errors & PL_RENDER_ERR_DEINTERLACING))
+        return;
+
+    pl_tex source = pimg->tex;
+    const struct pl_deinterlace_source src = {
+        .cur.top  = source,
+        .prev.top = image->prev ? image->prev->planes[plane].texture : NULL,
+        .next.top = image->next ? image->next->planes[plane].texture : NULL,
+        .field    = image->field,
+        .first_field = image->first_field,
+        .component_mask = (1 << pimg->comps) - 1,
+    };
+    pimg->tex = NULL;
+    pimg->rec = pl_dispatch_begin(rr->dp);
+    pl_shader_deinterlace(pimg->rec, &src, params->deinterlace_params);
+    if (source->params.format->caps & PL_FMT_CAP_STORABLE)
+        pimg->store_as = source->params.format;
+    pimg->fail_msg = "Failed deinterlacing plane.. disabling!";
+    pimg->fail_bit = PL_RENDER_ERR_DEINTERLACING;
+    pimg->fail_tex = source;
+}
+
 // `fetch` must be a bare nearest / bilinear fetch: its texture is read from inside `sh`
 bool plh_append_plane_fetch(pl_shader sh, const pl_shader fetch, const struct pl_plane *plane)
 {
@@ -777,6 +865,7 @@ bool plh_stage_read(struct frame_job *job)
             .comps = image->planes[i].components,
             .rect = pl->rect,
         };
+        deinterlace_plane(job, &pimg[i], i);
         deband_plane(job, &pimg[i], pl->neutral);
 
         struct pl_sample_src req = rp_plane_request(&lay, i);
@@ -882,7 +971,8 @@ bool plh_stage_read(struct frame_job *job)
 static bool owns_workgroup_shape(const pl_shader sh)
 {
     const int t = sh->pass.s.type;
-    return t == PLH_SAMPLE_POLAR || t == PLH_SAMPLE_ORTHO || t == PLH_SAMPLE_DEBAND;
+    return t == PLH_SAMPLE_POLAR || t == PLH_SAMPLE_ORTHO || t == PLH_SAMPLE_DEBAND ||
+           t == PLH_SAMPLE_DEINTERLACE;
 }
 
 static void measure_peak(struct frame_job *job)

@@ -101,6 +101,8 @@ struct frame_job {
     struct pl_color_space features_color;   // ... as this colour space (the detected HDR metadata that
                                 // arrives afterwards may change how a non-linear image is linearised)
     bool image_acquired, target_acquired;
+    struct pl_frame prev, next;     // deinterlacing: local copies of image.prev / .next while acquired
+    bool prev_acquired, next_acquired;
     bool target_borrowed;       // the target belongs to an enclosing job: neither acquire nor release
     struct pl_render_info info;
 };

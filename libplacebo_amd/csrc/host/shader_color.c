@@ -744,7 +744,7 @@ bool pl_shader_detect_peak(pl_shader sh, struct pl_color_space csp, pl_shader_ob
         return false;
     }
     if (sh->pass.s.type == PLH_SAMPLE_POLAR || sh->pass.s.type == PLH_SAMPLE_ORTHO ||
-        sh->pass.s.type == PLH_SAMPLE_DEBAND) {
+        sh->pass.s.type == PLH_SAMPLE_DEBAND || sh->pass.s.type == PLH_SAMPLE_DEINTERLACE) {
         // those samplers own the workgroup shape; measure in a separate pass
         pl_msg(sh->log, PL_LOG_ERR, "pl_shader_detect_peak cannot be merged into a "
                "polar/ortho/deband pass on the HIP backend (materialise it first)");

@@ -1789,6 +1789,187 @@ ORC_API void orc_blend(float *dst, const float *src, const uint8_t *mask, size_t
     }
 }
 
+/* ======================================================================== */
+/* deinterlacing (src/shaders/deinterlacing.c:26-370)                            */
+
+enum { ORC_DEINT_WEAVE = 0, ORC_DEINT_BOB, ORC_DEINT_YADIF, ORC_DEINT_BWDIF };
+
+// GET(TEX, X, Y) = textureLod(TEX, pos + pt * vec2(X, Y)) with NEAREST filtering and the MIRROR
+// address mode the shader binds its textures with (:51-53): texel (x + X, y + Y), mirrored
+static const float *deint_get(const float *img, int w, int h, int x, int y)
+{
+    return img + ((size_t) wrap(y, h, ADDR_MIRROR) * w + wrap(x, w, ADDR_MIRROR)) * 4;
+}
+
+// spatial_predictor (:131-157). a..g: row above, x - 3 .. x + 3; h..n: row below
+static float yadif_spatial(const float up[7], const float dn[7], float bias)
+{
+    const float a = up[0], b = up[1], c = up[2], d = up[3], e = up[4], f = up[5], g = up[6];
+    const float h = dn[0], i = dn[1], j = dn[2], k = dn[3], l = dn[4], m = dn[5], n = dn[6];
+    float pred = (d + k) / 2.0f;
+    float best = fabsf(c - j) + fabsf(d - k) + fabsf(e - l) - bias;
+    float score = fabsf(b - k) + fabsf(c - l) + fabsf(d - m);
+    if (score < best) {
+        pred = (c + l) / 2.0f;
+        best = score;
+        score = fabsf(a - l) + fabsf(b - m) + fabsf(c - n);
+        if (score < best) {
+            pred = (b + m) / 2.0f;
+            best = score;
+        }
+    }
+    score = fabsf(d - i) + fabsf(e - j) + fabsf(f - k);
+    if (score < best) {
+        pred = (e + j) / 2.0f;
+        best = score;
+        score = fabsf(e - h) + fabsf(f - i) + fabsf(g - j);
+        if (score < best) {
+            pred = (f + i) / 2.0f;
+            best = score;
+        }
+    }
+    return pred;
+}
+
+// temporal_predictor (:188-216)
+static float yadif_temporal(float A, float B, float C, float D, float E, float F, float G, float H,
+                            float I, float J, float K, float L, float pred, int skip_spatial_check)
+{
+    const float p0 = (C + H) / 2.0f, p1 = F, p2 = (D + I) / 2.0f, p3 = G, p4 = (E + J) / 2.0f;
+    const float tdiff0 = fabsf(D - I) / 2.0f;
+    const float tdiff1 = (fabsf(A - F) + fabsf(B - G)) / 2.0f;
+    const float tdiff2 = (fabsf(K - F) + fabsf(G - L)) / 2.0f;
+    float diff = fmaxf(tdiff0, fmaxf(tdiff1, tdiff2));
+    if (!skip_spatial_check) {
+        const float maxi = fmaxf(p2 - fminf(p3, p1), fminf(p0 - p1, p4 - p3));
+        const float mini = fminf(p2 - fmaxf(p3, p1), fmaxf(p0 - p1, p4 - p3));
+        diff = fmaxf(diff, fmaxf(mini, -maxi));
+    }
+    if (pred > p2 + diff)
+        pred = p2 + diff;
+    if (pred < p2 - diff)
+        pred = p2 - diff;
+    return pred;
+}
+
+// process_bwdif / process_intra_bwdif (:270-322). cur = rows -3 -1 +1 +3; prev, next = rows -1 +1;
+// prev2, next2 = rows -4 -2 0 +2 +4
+static float bwdif_intra(const float cur[4])
+{
+    const float sp0 = 5077.0f / 8192.0f, sp1 = 981.0f / 8192.0f;
+    return sp0 * (cur[1] + cur[2]) - sp1 * (cur[0] + cur[3]);
+}
+
+static float bwdif_process(const float cur[4], const float prev[2], const float next[2],
+                           const float prev2[5], const float next2[5])
+{
+    const float lf0 = 4309.0f / 8192.0f, lf1 = 213.0f / 8192.0f;
+    const float hf0 = 5570.0f / 8192.0f, hf1 = 3801.0f / 8192.0f, hf2 = 1016.0f / 8192.0f;
+    const float sp0 = 5077.0f / 8192.0f, sp1 = 981.0f / 8192.0f;
+
+    const float s = prev2[2] + next2[2];
+    const float d = s / 2.0f;
+    const float c = cur[1], e = cur[2];
+
+    const float tdiff0 = fabsf(prev2[2] - next2[2]);
+    const float tdiff1 = fabsf(prev[0] - c) + fabsf(prev[1] - e);
+    const float tdiff2 = fabsf(next[0] - c) + fabsf(next[1] - e);
+    float diff = fmaxf(tdiff0, fmaxf(tdiff1, tdiff2)) / 2.0f;
+    const int still = diff == 0.0f;
+
+    const float bs = prev2[1] + next2[1], fs = prev2[3] + next2[3];
+    const float b = (bs / 2.0f) - c, f = (fs / 2.0f) - c;
+    const float dc = d - c, de = d - e;
+    const float mmax = fmaxf(de, fmaxf(dc, fminf(b, f)));
+    const float mmin = fminf(de, fminf(dc, fmaxf(b, f)));
+    diff = fmaxf(diff, fmaxf(mmin, -mmax));
+
+    const float single = sp0 * (c + e) - sp1 * (cur[0] + cur[3]);
+    float all = (hf0 * s - hf1 * (bs + fs) +
+                 hf2 * (prev2[0] + next2[0] + prev2[4] + next2[4])) / 4.0f;
+    all += lf0 * (c + e) - lf1 * (cur[0] + cur[3]);
+
+    float interpol = fabsf(c - e) > tdiff0 ? all : single;
+    interpol = fminf(fmaxf(interpol, d - diff), d + diff);     // clamp(x, lo, hi)
+    return still ? d : interpol;
+}
+
+// pl_shader_deinterlace over whole w x h frames of decoded texels; prev / next may be NULL.
+// field: 1 = top / even rows are output as they are, 2 = bottom (enum pl_field); 0 = no-op.
+// The components outside comp_mask keep the shader's initial colour (0, 0, 0, 1).
+ORC_API void orc_deinterlace(const float *cur, const float *prev, const float *next, int w, int h,
+                             int field, int first_field, int algo, int skip_spatial_check,
+                             unsigned comp_mask, float *out)
+{
+    if (!first_field)
+        first_field = 1;
+    int intra_only = algo != ORC_DEINT_YADIF;
+    if (algo == ORC_DEINT_BWDIF)
+        intra_only = (!prev && field == first_field) || (!next && field != first_field);
+    const float *pv = !intra_only && prev ? prev : cur;
+    const float *nx = !intra_only && next ? next : cur;
+    const float *pv2 = field == first_field ? pv : cur;
+    const float *nx2 = field == first_field ? cur : nx;
+    // "%f" of 1 / 255 as the shader text carries it (:129, :134)
+    const float bias = 0.003922f;
+
+    for (int y = 0; y < h; y++) {
+        for (int x = 0; x < w; x++) {
+            float res[4];
+            memcpy(res, deint_get(cur, w, h, x, y), 16);
+            const int kept = field == 0 || (y % 2) == (field == 1 ? 0 : 1);
+            for (int ch = 0; ch < 4 && !kept; ch++) {
+#define G(IMG, X, Y) (deint_get(IMG, w, h, x + (X), y + (Y))[ch])
+                switch (algo) {
+                case ORC_DEINT_WEAVE:
+                    break;
+                case ORC_DEINT_BOB:
+                    res[ch] = G(cur, 0, field == 1 ? -1 : 1);
+                    break;
+                case ORC_DEINT_YADIF: {
+                    float up[7], dn[7];
+                    for (int t = 0; t < 7; t++) {
+                        up[t] = G(cur, t - 3, -1);
+                        dn[t] = G(cur, t - 3, +1);
+                    }
+                    const float sp = yadif_spatial(up, dn, bias);
+                    res[ch] = yadif_temporal(G(pv, 0, -1), G(pv, 0, 1),
+                                             G(pv2, 0, -2), G(pv2, 0, 0), G(pv2, 0, 2),
+                                             G(cur, 0, -1), G(cur, 0, 1),
+                                             G(nx2, 0, -2), G(nx2, 0, 0), G(nx2, 0, 2),
+                                             G(nx, 0, -1), G(nx, 0, 1), sp, skip_spatial_check);
+                    break;
+                }
+                case ORC_DEINT_BWDIF: {
+                    const float c4[4] = { G(cur, 0, -3), G(cur, 0, -1), G(cur, 0, 1), G(cur, 0, 3) };
+                    if (intra_only) {
+                        res[ch] = bwdif_intra(c4);
+                        break;
+                    }
+                    const float p2[2] = { G(pv, 0, -1), G(pv, 0, 1) };
+                    const float n2[2] = { G(nx, 0, -1), G(nx, 0, 1) };
+                    float p5[5], n5[5];
+                    for (int t = 0; t < 5; t++) {
+                        p5[t] = G(pv2, 0, 2 * t - 4);
+                        n5[t] = G(nx2, 0, 2 * t - 4);
+                    }
+                    res[ch] = bwdif_process(c4, p2, n2, p5, n5);
+                    break;
+                }
+                }
+#undef G
+            }
+            float *o = out + ((size_t) y * w + x) * 4;
+            o[0] = o[1] = o[2] = 0.0f;
+            o[3] = 1.0f;
+            for (int ch = 0; ch < 4; ch++) {
+                if (comp_mask & (1u << ch))
+                    o[ch] = res[ch];
+            }
+        }
+    }
+}
+
 ORC_API int orc_check_unorm_decode(int bits)
 {
     const float d = bits == 8 ? 255.0f : 65535.0f;

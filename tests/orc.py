@@ -421,3 +421,28 @@ def blend(dst, src, mask, factors, enable=True, fixed_point=True):
     lib().orc_blend(_p(dst), _p(src), _p(m) if m is not None else None,
                     dst.shape[0] * dst.shape[1], f, int(enable), int(fixed_point))
     return dst
+
+
+DEINT_WEAVE, DEINT_BOB, DEINT_YADIF, DEINT_BWDIF = 0, 1, 2, 3
+
+
+def deinterlace(cur, prev, next_, field, first_field, algo, skip_spatial_check=False,
+                comp_mask=0xf):
+    """pl_shader_deinterlace over decoded frames (h, w, 4); prev / next_ may be None;
+    field / first_field: 0 none, 1 top, 2 bottom"""
+    cur = np.ascontiguousarray(cur, dtype=np.float32)
+    h, w = cur.shape[:2]
+    keep = [cur]
+    ptr = []
+    for a in (prev, next_):
+        if a is None:
+            ptr.append(None)
+        else:
+            a = np.ascontiguousarray(a, dtype=np.float32)
+            assert a.shape == cur.shape
+            keep.append(a)
+            ptr.append(_p(a))
+    out = np.empty_like(cur)
+    lib().orc_deinterlace(_p(cur), ptr[0], ptr[1], w, h, field, first_field, algo,
+                          int(skip_spatial_check), comp_mask, _p(out))
+    return out
