@@ -93,6 +93,9 @@ WORKLOADS = {
     # real video ingest: NV12 (8-bit 4:2:0, BT.709 limited) -> EWA 2x -> RGB, 10-bit dither
     "nv12_1080p_to_4k_ewa_dither10": (P1080, P4K, px(P1080) * 3 // 2 + px(P4K) * 8, "polar"),
     "nv12_1080p_to_4k_default_preset": (P1080, P4K, px(P1080) * 3 // 2 + px(P4K) * 8, "ortho"),
+    # interlaced broadcast video: 1080i NV12, every plane deinterlaced (bwdif, the default: the
+    # frames before and after are read as well), then the default preset to 4K
+    "nv12_1080i_to_4k_bwdif_default_preset": (P1080, P4K, 3 * px(P1080) * 3 // 2 + px(P4K) * 8, "ortho"),
     # pl_render_default_params as shipped: lanczos in linear, sigmoidized light + dither
     "default_preset_1080p_to_4k": (P1080, P4K, px(P1080) * 8 + px(P4K) * 8, "ortho"),
     # pl_render_high_quality_params on SDR video: deband, ewa_lanczossharp in sigmoidized linear
@@ -246,6 +249,10 @@ class Stream:
                                            dither_params=dither,
                                            disable_dither_gamma_correction=True)
             icsp, tcsp, trepr = pl.color_space("bt709", "bt1886"), pl.color_space("bt709", "bt1886"), ten_bit
+        elif workload == "nv12_1080i_to_4k_bwdif_default_preset":
+            self.params = pl.render_params(
+                "default", deinterlace_params=capi.DeinterlaceParams(pl.DEINTERLACE_BWDIF, False))
+            icsp, tcsp, trepr = pl.color_space("bt709", "bt1886"), pl.color_space("bt709", "bt1886"), ten_bit
         elif workload == "nv12_1080p_to_4k_default_preset":
             self.params = pl.render_params("default")
             icsp, tcsp, trepr = pl.color_space("bt709", "bt1886"), pl.color_space("bt709", "bt1886"), ten_bit
@@ -309,6 +316,12 @@ class Stream:
                 f.color = icsp
                 pl.lib().pl_frame_set_chroma_location(C.byref(f), 1)   # PL_CHROMA_LEFT
                 self.images.append(f)
+            if "1080i" in workload:
+                # every frame shows its top field; its neighbours in the pool are its neighbours in time
+                for i, f in enumerate(self.images):
+                    f.field, f.first_field = pl.FIELD_TOP, pl.FIELD_TOP
+                    f.prev = C.cast(C.pointer(self.images[i - 1]), C.c_void_p)
+                    f.next = C.cast(C.pointer(self.images[(i + 1) % pool]), C.c_void_p)
         self.targets = [pl.frame(t, color=tcsp, repr_=trepr) for t in self.dsts]
         if workload.endswith("_subtitles"):
             self.subtitles = self._subtitles(dw, dh)
@@ -425,6 +438,8 @@ def kernel_symbol(workload, name):
         return "k_ortho_fast"
     if "debanding" in name:
         return "k_deband"
+    if "deinterlacing" in name:
+        return "k_deinterlace"
     if workload == "bilinear_1080p_to_4k":
         return "k_bilinear_fast"
     # k_pass_native (source read texel for texel) or k_pass_generic: read off the trace

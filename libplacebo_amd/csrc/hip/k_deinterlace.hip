@@ -15,6 +15,8 @@
  * (two above, two below) are loaded once for both. The colour ops recorded behind the sampler run
  * through the interpreter, two pixels per lane.
  */
+#include <stdlib.h>
+
 #include "colorops.hiph"
 #include "backend.h"
 
@@ -246,12 +248,172 @@ void k_deinterlace(const plh_pass p_)
     plh_store_n<2>(p.dst, sx, sy, ok, c, p.nt_store);
 }
 
+/* ---- the renderer's case: a whole video plane, nothing behind the sampler ----------------------
+ * bob, weave and bwdif (the default) only look up and down, so a row of a plane is an array of
+ * component slots that can be taken four bytes at a time whatever the texel is -- r8: four pixels,
+ * rg8 / r16: two, rg16: one -- and a lane owns one such dword of a row pair: bwdif's 18 rows are 18
+ * dword loads for up to four pixels instead of 18 single bytes per pixel. The plane comes out in
+ * its own format (what the renderer stores when a scaler follows: rounded like any store) or as
+ * floats of the same layout (when the plane is the image's reference grid and continues
+ * unrounded: renderer.c deinterlace_plane). Same arithmetic, same order: bit-identical to
+ * k_deinterlace (tests/test_gpu_deinterlace.py runs both). yadif looks sideways as well and stays
+ * on the general kernel. */
+template <typename C> DEV float deint_slot(uint32_t w, int k);
+template <> DEV float deint_slot<uint8_t>(uint32_t w, int k) { return plh_un8((w >> (8 * k)) & 0xffu); }
+template <> DEV float deint_slot<uint16_t>(uint32_t w, int k) { return plh_un16((w >> (16 * k)) & 0xffffu); }
+
+template <typename C>
+DEV uint32_t deint_pack(const float (&v)[4 / sizeof(C)])
+{
+    if constexpr (sizeof(C) == 1) {
+        return plh_unorm(v[0], 255.0f) | plh_unorm(v[1], 255.0f) << 8 |
+               plh_unorm(v[2], 255.0f) << 16 | plh_unorm(v[3], 255.0f) << 24;
+    } else {
+        return plh_unorm16x2(v[0], v[1]);
+    }
+}
+
+template <typename C, bool F32DST>
+__global__ __launch_bounds__(DEINT_BW * DEINT_BH)
+void k_deint_rows(const plh_pass p_)
+{
+    constexpr int N = 4 / sizeof(C);    // component slots per dword
+    const plh_pass &p = plh_kernarg_pass();
+    const plh_view &cur = p.s.src;
+    const plh_deint_args &a = p.deint;
+    const int seg = blockIdx.x * DEINT_BW + (int) (threadIdx.x % DEINT_BW);
+    const int pair = blockIdx.y * DEINT_BH + (int) (threadIdx.x / DEINT_BW);
+    const int nc = (cur.fmt - 1) % 3 == 2 ? 4 : (cur.fmt - 1) % 3 + 1;
+    const int slots = cur.w * nc;       // of a row
+    if (seg * N >= slots)
+        return;
+    const int yk = 2 * pair + a.keep, yr = 2 * pair + 1 - a.keep;
+
+    auto row = [&](const plh_view &v, int y) {
+        const int my = plh_wrap(y, v.h, PLH_ADDRESS_MIRROR);
+        return *(const uint32_t *) ((const uint8_t *) v.ptr + (size_t) my * v.pitch + 4 * seg);
+    };
+    auto put = [&](int y, uint32_t raw, const float (&val)[N], bool have_raw) {
+        if (y >= cur.h)
+            return;
+        uint8_t *dst = (uint8_t *) p.dst.ptr + (size_t) y * p.dst.pitch;
+        if constexpr (F32DST) {
+            float *o = (float *) dst + seg * N;
+#pragma unroll
+            for (int k = 0; k < N; k++) {
+                if (seg * N + k < slots)
+                    o[k] = have_raw ? deint_slot<C>(raw, k) : val[k];
+            }
+        } else {
+            // (a row's last dword may reach into the pitch padding: both pitches are whole dwords)
+            ((uint32_t *) dst)[seg] = have_raw ? raw : deint_pack<C>(val);
+        }
+    };
+
+    const float none[N] = {};
+    put(yk, row(cur, yk), none, true);
+    if (yr >= cur.h)
+        return;
+    if (a.algo == PLH_DEINT_WEAVE) {
+        put(yr, row(cur, yr), none, true);
+    } else if (a.algo == PLH_DEINT_BOB) {
+        put(yr, row(cur, yr + (a.keep ? 1 : -1)), none, true);
+    } else if (a.intra_only) {
+        const uint32_t r[4] = { row(cur, yr - 3), row(cur, yr - 1), row(cur, yr + 1), row(cur, yr + 3) };
+        float out[N];
+#pragma unroll
+        for (int k = 0; k < N; k++) {
+            const float col[4] = { deint_slot<C>(r[0], k), deint_slot<C>(r[1], k),
+                                   deint_slot<C>(r[2], k), deint_slot<C>(r[3], k) };
+            out[k] = bwdif_intra(col);
+        }
+        put(yr, 0, out, false);
+    } else {
+        const plh_view &prev2 = a.first ? a.prev : cur, &next2 = a.first ? cur : a.next;
+        uint32_t rc[4], rp[2], rn[2], rp2[5], rn2[5];
+#pragma unroll
+        for (int k = 0; k < 4; k++)
+            rc[k] = row(cur, yr + 2 * k - 3);
+#pragma unroll
+        for (int k = 0; k < 2; k++) {
+            rp[k] = row(a.prev, yr + 2 * k - 1);
+            rn[k] = row(a.next, yr + 2 * k - 1);
+        }
+#pragma unroll
+        for (int k = 0; k < 5; k++) {
+            rp2[k] = row(prev2, yr + 2 * k - 4);
+            rn2[k] = row(next2, yr + 2 * k - 4);
+        }
+        float out[N];
+#pragma unroll
+        for (int s = 0; s < N; s++) {
+            deint_column t;
+#pragma unroll
+            for (int k = 0; k < 4; k++)
+                t.cur[k] = deint_slot<C>(rc[k], s);
+#pragma unroll
+            for (int k = 0; k < 2; k++) {
+                t.prev[k] = deint_slot<C>(rp[k], s);
+                t.next[k] = deint_slot<C>(rn[k], s);
+            }
+#pragma unroll
+            for (int k = 0; k < 5; k++) {
+                t.prev2[k] = deint_slot<C>(rp2[k], s);
+                t.next2[k] = deint_slot<C>(rn2[k], s);
+            }
+            out[s] = bwdif_process(t);
+        }
+        put(yr, 0, out, false);
+    }
+}
+
+// whether the pass is what k_deint_rows does: a whole unorm plane into a texture of its own
+// format, or of floats with the same components, every row a whole number of dwords
+static int deint_rows_variant(const plh_pass *p)
+{
+    const plh_view &s = p->s.src, &d = p->dst;
+    const plh_deint_args &a = p->deint;
+    static int off = -1;
+    if (off < 0)
+        off = getenv("PL_HIP_DEINT_ROWS") && !atoi(getenv("PL_HIP_DEINT_ROWS"));
+    if (off || p->num_ops || a.algo == PLH_DEINT_YADIF || a.keep < 0 || s.fmt > PLH_FMT_RGBA16)
+        return 0;
+    const int nc = (s.fmt - 1) % 3 == 2 ? 4 : (s.fmt - 1) % 3 + 1;
+    const bool same = d.fmt == s.fmt, f32 = d.fmt == PLH_FMT_R32F + (s.fmt - 1) % 3;
+    if ((!same && !f32) || p->s.comp_mask != (1u << nc) - 1u)
+        return 0;
+    if (p->base_x || p->base_y || p->dir_x != 1 || p->dir_y != 1 || p->transpose ||
+        p->width != s.w || p->height != s.h || d.w != s.w || d.h != s.h)
+        return 0;
+    const plh_view *views[3] = { &s, &a.prev, &a.next };
+    for (const plh_view *v : views) {
+        if (v->fmt != s.fmt || v->w != s.w || v->h != s.h || v->pitch % 4 || (uintptr_t) v->ptr % 4)
+            return 0;
+    }
+    if (d.pitch % 4 || (uintptr_t) d.ptr % 4)
+        return 0;
+    return (s.fmt <= PLH_FMT_RGBA8 ? 1 : 2) + (f32 ? 2 : 0);
+}
+
 extern "C" int plh_launch_deinterlace(plh_stream stream_, const struct plh_pass *pass)
 {
     hipStream_t stream = (hipStream_t) stream_;
-    const dim3 grid((pass->width + DEINT_BW - 1) / DEINT_BW,
-                    ((pass->height + 1) / 2 + DEINT_BH - 1) / DEINT_BH);
+    const int pairs = (pass->height + 1) / 2;
     const dim3 block(DEINT_BW * DEINT_BH);
+    if (const int variant = deint_rows_variant(pass)) {
+        const int nc = (pass->s.src.fmt - 1) % 3 == 2 ? 4 : (pass->s.src.fmt - 1) % 3 + 1;
+        const int dwords = (pass->s.src.w * nc * (variant & 1 ? 1 : 2) + 3) / 4;
+        const dim3 grid((dwords + DEINT_BW - 1) / DEINT_BW, (pairs + DEINT_BH - 1) / DEINT_BH);
+        switch (variant) {
+        case 1: PLH_LAUNCH_LAST((k_deint_rows<uint8_t, false>), grid, block, 0, stream, *pass); break;
+        case 2: PLH_LAUNCH_LAST((k_deint_rows<uint16_t, false>), grid, block, 0, stream, *pass); break;
+        case 3: PLH_LAUNCH_LAST((k_deint_rows<uint8_t, true>), grid, block, 0, stream, *pass); break;
+        default: PLH_LAUNCH_LAST((k_deint_rows<uint16_t, true>), grid, block, 0, stream, *pass); break;
+        }
+        const hipError_t err = hipGetLastError();
+        return err == hipSuccess ? 0 : -(int) err;
+    }
+    const dim3 grid((pass->width + DEINT_BW - 1) / DEINT_BW, (pairs + DEINT_BH - 1) / DEINT_BH);
     if (plh_ops_lite(pass, 0, pass->num_ops))
         PLH_LAUNCH_LAST(k_deinterlace<true>, grid, block, 0, stream, *pass);
     else

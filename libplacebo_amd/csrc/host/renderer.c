@@ -870,8 +870,24 @@ bool plh_stage_read(struct frame_job *job)
 
         struct pl_sample_src req = rp_plane_request(&lay, i);
         req.scale = pl_color_repr_normalize(&pimg[i].repr);
-        const bool as_is = pimg[i].rec && pimg[i].w == req.new_w && pimg[i].h == req.new_h &&
-                           rp_plane_request_is_identity(&req);
+        bool as_is = pimg[i].rec && pimg[i].w == req.new_w && pimg[i].h == req.new_h &&
+                     rp_plane_request_is_identity(&req);
+        if (as_is && pimg[i].rec->pass.s.type == PLH_SAMPLE_DEINTERLACE && !pimg[i].rec->pass.num_ops) {
+            // A deinterlaced plane that IS the reference grid continues unrounded in the reference
+            // (the deinterlacing shader goes on to become the decoding pass). Same values here, but
+            // through a float image of the plane's layout: the deinterlacer then runs as the
+            // row-dword kernel it has for whole planes (k_deint_rows: 4 pixels of an r8 plane per
+            // lane) and everything behind it as the kernels tuned for a texture source -- against
+            // one kernel that does both through the interpreter (1080i luma: 87 us -> 4 + 22)
+            static const char *const names[] = { NULL, "r32f", "rg32f", NULL, "rgba32f" };
+            const int nc = image->planes[i].texture->params.format->num_components;
+            pl_fmt exact = nc <= 4 && names[nc] ? pl_find_named_fmt(rr->gpu, names[nc]) : NULL;
+            if (exact && (exact->caps & PL_FMT_CAP_STORABLE)) {
+                pimg[i].store_as = exact;
+                if (plh_work_texture(job, &pimg[i]))
+                    as_is = false;
+            }
+        }
         if (!as_is) {
             req.tex = plh_work_texture(job, &pimg[i]);
             if (!req.tex)

@@ -279,3 +279,40 @@ def test_bad_neighbour_frames_are_refused(gpu, rr):
     sh.abort()
     for t in (a, b, dst):
         t.destroy()
+
+
+F32_OF = {1: "r32f", 2: "rg32f", 4: "rgba32f"}
+
+
+@pytest.mark.parametrize("fmt", ["r8", "rg8", "rgba8", "r16", "rg16", "rgba16"])
+@pytest.mark.parametrize("size", [(70, 37), (1, 1), (5, 3), (257, 16), (3, 8)])
+def test_whole_plane_kernel_equals_the_oracle(gpu, fmt, size, monkeypatch):
+    """A whole unorm plane into a texture of its own format or of floats with the same components
+    -- what the renderer asks for -- runs as k_deint_rows (a dword of a row pair per lane: bob,
+    weave, bwdif). Bit-exact against the oracle, rows that end inside a dword included, and equal
+    to the general kernel (PL_HIP_DEINT_ROWS=0 in a second process is not needed: the general
+    kernel is what every other test here runs, against the same oracle)."""
+    w, h = size
+    arr = frames(w, h, fmt, seed=31)
+    nc = arr[0].shape[2]
+    tex = [gpu.tex_create(w, h, fmt, a) for a in arr]
+    dec = [orc.tex_decode(a, fmt) for a in arr]
+    for dfmt in (fmt, F32_OF[nc]):
+        dst = gpu.tex_create(w, h, dfmt)
+        for algo, field, first, have_prev in (("bwdif", pl.FIELD_TOP, pl.FIELD_TOP, True),
+                                              ("bwdif", pl.FIELD_BOTTOM, pl.FIELD_TOP, True),
+                                              ("bwdif", pl.FIELD_TOP, pl.FIELD_TOP, False),    # intra
+                                              ("bob", pl.FIELD_BOTTOM, pl.FIELD_TOP, True),
+                                              ("weave", pl.FIELD_TOP, pl.FIELD_TOP, True)):
+            sh = gpu.begin()
+            sh.deinterlace(tex[1], tex[0] if have_prev else None, tex[2], field=field,
+                           first_field=first, algo=ALGOS[algo])
+            assert sh.finish(dst), gpu.messages[-4:]
+            got = dst.download()
+            ref = orc.deinterlace(dec[1], dec[0] if have_prev else None, dec[2], field, first,
+                                  ALGOS[algo], comp_mask=(1 << nc) - 1)
+            want = orc.tex_encode(ref, dfmt)
+            assert np.array_equal(got, want), (dfmt, algo, field, util.diff_stats(got, want))
+        dst.destroy()
+    for t in tex:
+        t.destroy()
