@@ -19,9 +19,8 @@
  * into the polar kernel (the ops run on the source texels while they are staged, with the
  * rgba16hf rounding the intermediate image would have applied): same values, one pass less.
  *
- * Outside the scope of this backend: hooks, blending onto the target,
- * deinterlacing, distortion (refused); ICC profiles, overlays, film grain (ignored with an
- * error bit / warning).
+ * Outside the scope of this backend: hooks, distortion (refused); ICC profiles,
+ * film grain (ignored with an error bit / warning).
  */
 #include <math.h>
 #include <stdlib.h>

@@ -22,6 +22,9 @@
  *     -- the reference's tests never draw an overlay on a backend that rasterises; the
  *     restatement is held to the graphics APIs' rules by hand-worked cases
  *     (tests/test_oracle_overlay.py).
+ *   - Deinterlacing (orc_deinterlace): parity UNPINNED likewise -- upstream only dispatches and
+ *     times the shader (src/tests/gpu_tests.c:875, bench.c:314-366); pinned by the algorithms'
+ *     own promises on hand-worked cases (tests/test_oracle_deinterlace.py).
  *
  * Float semantics. GLSL leaves contraction, mix() and texture filtering
  * precision open; this file fixes them (same choices as csrc/hip/devmath.hiph,
