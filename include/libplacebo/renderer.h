@@ -110,7 +110,7 @@ struct pl_render_params {
     const struct pl_cone_params *cone_params; // colour blindness simulation (NULL = off)
     const struct pl_blend_params *blend_params;             // the frame is blended INTO the target
     const struct pl_deinterlace_params *deinterlace_params; // frames with a `field` are deinterlaced
-    const struct pl_distort_params *distort_params;         // unsupported, must be NULL
+    const struct pl_distort_params *distort_params;         // shaders/sampling.h: an affine map of the image
     const struct pl_hook * const *hooks;                    // unsupported, must be NULL
     int num_hooks;
     const struct pl_custom_lut *lut;    // applied between the image's and the target's colour

@@ -80,6 +80,28 @@ PL_API bool pl_shader_sample_polar(pl_shader sh, const struct pl_sample_src *src
 PL_API bool pl_shader_sample_ortho2(pl_shader sh, const struct pl_sample_src *src,
                                     const struct pl_sample_filter_params *params);
 
+// An affine transformation of the image inside a canvas of `out_w` x `out_h` (reference
+// shaders/sampling.h:204-244, src/shaders/sampling.c:1106-1217). The image is centred and scaled so
+// that its longer side spans [-1, 1] (y up) before `transform` applies.
+struct pl_distort_params {
+    pl_transform2x2 transform;
+    bool unscaled;      // place the image at its own size instead of stretching it over the canvas
+    bool constrain;     // scale the result down so that it fits the canvas
+    bool bicubic;       // bicubic instead of bilinear interpolation
+    enum pl_tex_address_mode address_mode;  // what lies outside the image ...
+    enum pl_alpha_mode alpha_mode;          // ... or, if set: transparent, in this alpha mode
+};
+
+#define PL_DISTORT_DEFAULTS \
+    .transform.mat.m = {{ 1, 0 }, {0, 1}},
+
+#define pl_distort_params(...) (&(struct pl_distort_params) {PL_DISTORT_DEFAULTS __VA_ARGS__ })
+PL_API extern const struct pl_distort_params pl_distort_default_params;
+
+// A sampling stage (the first of a shader); what leaves the canvas is cut off.
+PL_API void pl_shader_distort(pl_shader sh, pl_tex tex, int out_w, int out_h,
+                              const struct pl_distort_params *params);
+
 PL_API_END
 
 #endif // LIBPLACEBO_SHADERS_SAMPLING_H_

@@ -274,6 +274,10 @@ class Shader:
         params = capi.DeinterlaceParams(algo, skip_spatial_check)
         lib().pl_shader_deinterlace(self.sh, C.byref(src), C.byref(params))
 
+    def distort(self, tex, out_w, out_h, params):
+        self._keep.append(params)
+        lib().pl_shader_distort(self.sh, tex.ptr, out_w, out_h, C.byref(params))
+
     def color_map(self, src, dst, state_obj=None, params=None, prelinearized=False,
                   feature_map=None):
         params = params or color_map_params()
@@ -418,6 +422,17 @@ OVERLAY_NORMAL, OVERLAY_MONOCHROME = 0, 1
 OVERLAY_COORDS_AUTO, OVERLAY_COORDS_SRC_FRAME, OVERLAY_COORDS_SRC_CROP = 0, 1, 2
 OVERLAY_COORDS_DST_FRAME, OVERLAY_COORDS_DST_CROP = 3, 4
 BLEND_ZERO, BLEND_ONE, BLEND_SRC_ALPHA, BLEND_ONE_MINUS_SRC_ALPHA = 0, 1, 2, 3
+
+
+def distort_params(mat=((1, 0), (0, 1)), c=(0, 0), unscaled=False, constrain=False, bicubic=False,
+                   address_mode=ADDRESS_CLAMP, alpha_mode=0):
+    p = capi.DistortParams(unscaled=unscaled, constrain=constrain, bicubic=bicubic,
+                           address_mode=address_mode, alpha_mode=alpha_mode)
+    for i in range(2):
+        for j in range(2):
+            p.transform.m[i][j] = mat[i][j]
+        p.transform.c[i] = c[i]
+    return p
 
 
 def overlay(tex, parts, mode=OVERLAY_NORMAL, coords=OVERLAY_COORDS_AUTO, repr_=None, color=None):

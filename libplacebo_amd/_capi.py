@@ -429,6 +429,15 @@ class FilmGrainData(C.Structure):
     _fields_ = [("type", C.c_int), ("seed", C.c_uint64), ("params", _GrainUnion)]
 
 
+class Transform2x2(C.Structure):
+    _fields_ = [("m", (C.c_float * 2) * 2), ("c", C.c_float * 2)]
+
+
+class DistortParams(C.Structure):
+    _fields_ = [("transform", Transform2x2), ("unscaled", C.c_bool), ("constrain", C.c_bool),
+                ("bicubic", C.c_bool), ("address_mode", C.c_int), ("alpha_mode", C.c_int)]
+
+
 class DeinterlaceParams(C.Structure):
     _fields_ = [("algo", C.c_int), ("skip_spatial_check", C.c_bool)]
 
@@ -507,7 +516,8 @@ class RenderParams(C.Structure):
                 ("dither_params", C.POINTER(DitherParams)),
                 ("error_diffusion", C.POINTER(ErrorDiffusionKernel)),
                 ("cone_params", C.POINTER(ConeParams)), ("blend_params", C.POINTER(BlendParams)),
-                ("deinterlace_params", C.POINTER(DeinterlaceParams)), ("distort_params", C.c_void_p),
+                ("deinterlace_params", C.POINTER(DeinterlaceParams)),
+                ("distort_params", C.POINTER(DistortParams)),
                 ("hooks", C.c_void_p), ("num_hooks", C.c_int), ("lut", C.POINTER(CustomLut)),
                 ("lut_type", C.c_int), ("background", C.c_int), ("border", C.c_int),
                 ("background_color", C.c_float * 3), ("background_transparency", C.c_float),

@@ -28,6 +28,25 @@
 #define BF_DEFAULT_ITERS 1
 #endif
 
+// pl_shader_distort (sampling.c:1174-1215): the canvas position through the inverse transform,
+// then a bilinear or bicubic fetch; `alpha_mode`: the picture's edge fades over one texel
+DEV float4_t sample_distort(const plh_sampler_args &s, const plh_distort_args &d, float cx, float cy)
+{
+    const float px = (d.m[0] * cx + d.m[1] * cy) + d.c[0];
+    const float py = (d.m[2] * cx + d.m[3] * cy) + d.c[1];
+    float4_t c = d.bicubic ? sample_bicubic(s, px, py) : tex_linear(s.src, s.address_mode, px, py);
+    if (d.alpha_mode) {
+        const float bx = smoothstep01(fminf(px, 1.0f - px) / s.pt[0]);
+        const float by = smoothstep01(fminf(py, 1.0f - py) / s.pt[1]);
+        const float border = bx * by;
+        if (d.alpha_mode == 2) {        // PL_ALPHA_PREMULTIPLIED
+            c.x *= border; c.y *= border; c.z *= border;
+        }
+        c.w *= border;
+    }
+    return c;
+}
+
 DEV float4_t run_sampler(const plh_sampler_args &s, float px, float py)
 {
     float4_t c = {0.0f, 0.0f, 0.0f, 1.0f};
@@ -164,7 +183,8 @@ void k_pass_generic(const plh_pass p_)
         if constexpr (!SIMPLE) {
 #pragma unroll
             for (int q = 0; q < NPX; q++)
-                c[q] = run_sampler(s, px[q], py[q]);
+                c[q] = s.type == PLH_SAMPLE_DISTORT ? sample_distort(s, p.distort, px[q], py[q])
+                                                    : run_sampler(s, px[q], py[q]);
         }
         break;
     }

@@ -48,6 +48,7 @@ enum plh_sampler {
     PLH_SAMPLE_ORTHO,       // sampling.c:950 (one separable pass)
     PLH_SAMPLE_DEBAND,      // sampling.c:183
     PLH_SAMPLE_DEINTERLACE, // shaders/deinterlacing.c:26 (k_deinterlace.hip)
+    PLH_SAMPLE_DISTORT,     // sampling.c:1108 (pl_shader_distort: an affine map of the canvas)
 };
 
 enum plh_address_mode {     // gpu.h pl_tex_address_mode
@@ -322,6 +323,15 @@ struct plh_deint_args {
     float spatial_bias;         // YADIF: 1 / 255 as the reference prints it
 };
 
+// PLH_SAMPLE_DISTORT: the sampler's `pos` corners hold the canvas [-1, 1]^2 (y up); a canvas
+// point p is sampled at m * p + c (texture coordinates), bilinear or by the bicubic of
+// PLH_SAMPLE_BICUBIC; with an alpha mode, what lies outside the texture fades out over one texel
+struct plh_distort_args {
+    float m[4], c[2];           // canvas -> texture, row-major 2 x 2 + offset
+    int32_t bicubic;
+    int32_t alpha_mode;         // 0 = none, else enum pl_alpha_mode (premultiplied: all of rgba fades)
+};
+
 struct plh_pass {
     struct plh_sampler_args s;
 
@@ -360,6 +370,7 @@ struct plh_pass {
     uint32_t peak_ticket;
 
     struct plh_deint_args deint;    // PLH_SAMPLE_DEINTERLACE
+    struct plh_distort_args distort;    // PLH_SAMPLE_DISTORT
 };
 
 /* ---- error diffusion (k_errdiff.hip) ------------------------------------------ */

@@ -19,8 +19,8 @@
  * into the polar kernel (the ops run on the source texels while they are staged, with the
  * rgba16hf rounding the intermediate image would have applied): same values, one pass less.
  *
- * Outside the scope of this backend: hooks, distortion (refused); ICC profiles,
- * film grain (ignored with an error bit / warning).
+ * Outside the scope of this backend: hooks (refused); ICC profiles, film grain
+ * (ignored with an error bit / warning).
  */
 #include <math.h>
 #include <stdlib.h>
@@ -517,8 +517,7 @@ void plh_job_watch_passes(struct frame_job *job)
 
 bool plh_params_supported(pl_renderer rr, const struct pl_render_params *p)
 {
-    const char *what = p->distort_params ? "distort_params" :
-                       p->num_hooks ? "hooks" : NULL;
+    const char *what = p->num_hooks ? "hooks" : NULL;
     if (!what)
         return true;
     RR_LOG(rr, PL_LOG_ERR, "pl_render_params.%s requests a stage this backend does not have "
@@ -1482,16 +1481,75 @@ static bool run_error_diffusion(struct frame_job *job, pl_shader *sh, int depth,
     return ok;
 }
 
+// pl_render_params.distort_params (:2655-2701): the finished image through an affine map, onto a
+// target rect grown (within the target) to hold the result
+static bool distort_image(struct frame_job *job, struct work_image *img, struct rp_geometry *geo)
+{
+    pl_renderer rr = job->rr;
+    const struct pl_frame *target = &job->target;
+    struct pl_distort_params dpars = *job->params->distort_params;
+    if (dpars.alpha_mode) {
+        pl_shader_set_alpha(plh_work_shader(job, img), &img->repr, dpars.alpha_mode);
+        img->repr.alpha = dpars.alpha_mode;
+        img->comps = 4;
+    }
+    pl_tex tex = plh_work_texture(job, img);
+    if (!tex)
+        return false;
+
+    // the bounding box of the transformed image, in units of the target rect
+    const float ar = pl_rect2df_aspect(&target->crop);
+    const float sx = fminf(ar, 1.0f), sy = fminf(1.0f / ar, 1.0f);
+    const pl_rect2df unit = { .x0 = -sx, .x1 = sx, .y0 = -sy, .y1 = sy };
+    const pl_rect2df bb = pl_transform2x2_bounds(&dpars.transform, &unit);
+    pl_rect2df tmp = target->crop;
+    pl_rect2df_stretch(&tmp, pl_rect_w(bb) / (2 * sx), pl_rect_h(bb) / (2 * sy));
+    const float tmp_w = pl_rect_w(tmp), tmp_h = pl_rect_h(tmp);
+    pl_tex ref = target->planes[rp_reference_plane(target)].texture;
+    int canvas_w = ref->params.w, canvas_h = ref->params.h;
+    if (geo->rotation % PL_ROTATION_180 == PL_ROTATION_90) {
+        const int t = canvas_w;
+        canvas_w = canvas_h;
+        canvas_h = t;
+    }
+    tmp.x0 = PL_CLAMP(tmp.x0, 0.0f, canvas_w);
+    tmp.x1 = PL_CLAMP(tmp.x1, 0.0f, canvas_w);
+    tmp.y0 = PL_CLAMP(tmp.y0, 0.0f, canvas_h);
+    tmp.y1 = PL_CLAMP(tmp.y1, 0.0f, canvas_h);
+    if (dpars.constrain) {
+        const float rx = pl_rect_w(tmp) / tmp_w, ry = pl_rect_h(tmp) / tmp_h;
+        pl_rect2df_stretch(&tmp, fminf(ry / rx, 1.0f), fminf(rx / ry, 1.0f));
+    }
+    geo->dstf = (pl_rect2df) { roundf(tmp.x0), roundf(tmp.y0), roundf(tmp.x1), roundf(tmp.y1) };
+    geo->dst = (pl_rect2d) { geo->dstf.x0, geo->dstf.y0, geo->dstf.x1, geo->dstf.y1 };
+    if (!pl_rect_w(geo->dst) || !pl_rect_h(geo->dst)) {
+        RR_LOG(rr, PL_LOG_ERR, "Distortion leaves nothing of the image inside the target");
+        return false;
+    }
+
+    dpars.unscaled = true;
+    img->w = abs(pl_rect_w(geo->dst));
+    img->h = abs(pl_rect_h(geo->dst));
+    img->rect = (pl_rect2df) { 0, 0, img->w, img->h };
+    img->tex = NULL;
+    img->rec = pl_dispatch_begin(rr->dp);
+    pl_shader_distort(img->rec, tex, img->w, img->h, &dpars);
+    return true;
+}
+
 bool plh_stage_output(struct frame_job *job)
 {
     pl_renderer rr = job->rr;
     const struct pl_render_params *params = job->params;
     const struct pl_frame *target = &job->target;
     struct work_image *img = &job->img;
+    struct rp_geometry geo = job->geo;
+    if (params->distort_params && !distort_image(job, img, &geo))
+        return false;
     pl_shader sh = plh_work_shader(job, img);
 
     struct rp_output_stage out;
-    rp_plan_output(params, target, &job->geo, img->comps, img->repr.alpha, &out);
+    rp_plan_output(params, target, &geo, img->comps, img->repr.alpha, &out);
 
     if (out.premultiply)
         pl_shader_set_alpha(sh, &img->repr, PL_ALPHA_PREMULTIPLIED);

@@ -1845,3 +1845,81 @@ void pl_shader_deband(pl_shader sh, const struct pl_sample_src *src,
              "mask=0x%x, seed=%u)\n", s->iterations, params->threshold, params->radius,
              params->grain, info.scale, s->comp_mask, s->prng_seed);
 }
+
+/* ---- pl_shader_distort (reference src/shaders/sampling.c:1106-1217) ---------------------------- */
+
+const struct pl_distort_params pl_distort_default_params = { PL_DISTORT_DEFAULTS };
+
+void pl_shader_distort(pl_shader sh, pl_tex src_tex, int out_w, int out_h,
+                       const struct pl_distort_params *params)
+{
+    if (!params || !src_tex) {
+        SH_FAIL(sh, "pl_shader_distort: parameters and a texture are required");
+        return;
+    }
+    if (sh->pass.s.type != PLH_SAMPLE_NONE || sh->output != PL_SHADER_SIG_NONE) {
+        SH_FAIL(sh, "Illegal sequence of shader operations: a sampling stage must "
+                "be the first stage of a shader");
+        return;
+    }
+    if (!sh_require(sh, PL_SHADER_SIG_NONE, out_w, out_h))
+        return;
+
+    // the image in aspect-normalised coordinates: its longer side spans [-1, 1], y up
+    const int src_w = src_tex->params.w, src_h = src_tex->params.h;
+    float rx = 1.0f, ry = 1.0f;
+    if (src_w > src_h) {
+        ry = (float) src_h / src_w;
+    } else {
+        rx = (float) src_w / src_h;
+    }
+    const pl_transform2x2 tex2norm = {
+        .mat.m = {{ 2 * rx, 0 }, { 0, -2 * ry }},
+        .c = { -rx, ry },
+    };
+    // ... and from there to the canvas [-1, 1]^2
+    const float sx = params->unscaled ? (float) src_w / out_w : 1.0f;
+    const float sy = params->unscaled ? (float) src_h / out_h : 1.0f;
+    const pl_transform2x2 norm2canvas = {
+        .mat.m = {{ sx / rx, 0 }, { 0, sy / ry }},
+    };
+
+    pl_transform2x2 transform = params->transform;
+    pl_transform2x2_mul(&transform, &tex2norm);
+    pl_transform2x2_rmul(&norm2canvas, &transform);
+    if (params->constrain) {
+        const pl_rect2df unit = { .x1 = 1, .y1 = 1 };
+        const pl_rect2df bb = pl_transform2x2_bounds(&transform, &unit);
+        const float k = fmaxf(fmaxf(pl_rect_w(bb), pl_rect_h(bb)), 2.0f);
+        pl_transform2x2_scale(&transform, 2.0f / k);
+    }
+
+    // the kernel walks the canvas (a vertex attribute in the reference, :1156-1161: y runs from +1
+    // at the top row to -1) and needs the way back: canvas -> texture coordinates
+    if (!sh_bind(sh, src_tex, params->address_mode, NULL))
+        return;
+    pl_transform2x2_invert(&transform);
+    sh_describef(sh, "distortion");
+
+    struct plh_pass *pass = &sh->pass;
+    struct plh_sampler_args *s = &pass->s;
+    s->type = PLH_SAMPLE_DISTORT;
+    s->pos[0][0] = -1.0f; s->pos[0][1] =  1.0f;
+    s->pos[1][0] =  1.0f; s->pos[1][1] =  1.0f;
+    s->pos[2][0] = -1.0f; s->pos[2][1] = -1.0f;
+    s->pos[3][0] =  1.0f; s->pos[3][1] = -1.0f;
+    s->scale = 1.0f;
+    s->comp_mask = 0xf;
+    s->linear = true;
+    pass->distort = (struct plh_distort_args) {
+        .m = { transform.mat.m[0][0], transform.mat.m[0][1],
+               transform.mat.m[1][0], transform.mat.m[1][1] },
+        .c = { transform.c[0], transform.c[1] },
+        .bicubic = params->bicubic,
+        .alpha_mode = params->alpha_mode,
+    };
+    sh_listf(sh, "distort(tf=[%g %g; %g %g] + (%g, %g)%s%s)\n", pass->distort.m[0],
+             pass->distort.m[1], pass->distort.m[2], pass->distort.m[3], pass->distort.c[0],
+             pass->distort.c[1], params->bicubic ? ", bicubic" : "",
+             params->alpha_mode ? ", transparent outside" : "");
+}

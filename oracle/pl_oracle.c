@@ -24,7 +24,8 @@
  *     (tests/test_oracle_overlay.py).
  *   - Deinterlacing (orc_deinterlace): parity UNPINNED likewise -- upstream only dispatches and
  *     times the shader (src/tests/gpu_tests.c:875, bench.c:314-366); pinned by the algorithms'
- *     own promises on hand-worked cases (tests/test_oracle_deinterlace.py).
+ *     own promises on hand-worked cases (tests/test_oracle_deinterlace.py). The same holds for
+ *     orc_distort (tests/test_oracle_distort.py).
  *
  * Float semantics. GLSL leaves contraction, mix() and texture filtering
  * precision open; this file fixes them (same choices as csrc/hip/devmath.hiph,
@@ -1706,6 +1707,60 @@ ORC_API void orc_error_diffusion(const float *img, int w, int h, int depth, int 
 
 // plh_un8 / plh_un16 (csrc/hip/devmath.hiph): q = v*(1/d); q += fma(-q, d, v)*(1/d) must be
 // the correctly rounded v/d for every code value. Returns the number of mismatches.
+/* ======================================================================== */
+/* pl_shader_distort (src/shaders/sampling.c:1108-1217)                          */
+
+// The canvas [-1, 1]^2 (y up: the attribute runs from +1 at the top row to -1 at the bottom,
+// :1156-1160) through `tf` (canvas -> texture coordinates, row-major 2 x 2 + offset: what the
+// host inverts and binds, :1166-1176), a bilinear fetch or the bicubic of sampling.c:335-361,
+// and with an alpha mode the fade of everything outside the texture over one texel (:1204-1211).
+ORC_API void orc_distort(const struct orc_src *s, const float tf[6], int bicubic, int alpha_mode,
+                         int out_w, int out_h, float *out)
+{
+    const float canvas[4][2] = { { -1.0f, 1.0f }, { 1.0f, 1.0f }, { -1.0f, -1.0f }, { 1.0f, -1.0f } };
+    const float pt[2] = { (float) (1.0 / s->w), (float) (1.0 / s->h) };
+    const float size[2] = { (float) s->w, (float) s->h };
+    const float osx = 1.0 / out_w, osy = 1.0 / out_h;
+    for (int y = 0; y < out_h; y++) {
+        for (int x = 0; x < out_w; x++) {
+            const float fx = osx * ((float) x + 0.5f), fy = osy * ((float) y + 0.5f);
+            const float cx = attr(canvas, 0, fx, fy), cy = attr(canvas, 1, fx, fy);
+            const float pos[2] = { (tf[0] * cx + tf[1] * cy) + tf[4], (tf[2] * cx + tf[3] * cy) + tf[5] };
+            float c[4];
+            if (bicubic) {
+                float g[4], h[4];
+                const float off[2] = {0, 0};
+                for (int k = 0; k < 2; k++) {
+                    const float fr = fractf(pos[k] * size[k] + 0.5f);
+                    const float fr2 = fr * fr, inv = 1.0f - fr, inv2 = inv * inv;
+                    const float w0 = 1.0f / 6.0f * inv2 * inv;
+                    const float w1 = 2.0f / 3.0f - 0.5f * fr2 * (2.0f - fr);
+                    const float w2 = 2.0f / 3.0f - 0.5f * inv2 * (2.0f - inv);
+                    const float w3 = 1.0f / 6.0f * fr2 * fr;
+                    g[k] = w0 + w1;
+                    g[k + 2] = w2 + w3;
+                    h[k] = w1 / g[k] + inv - 2.0f;
+                    h[k + 2] = w3 / g[k + 2] + inv;
+                }
+                fast4(s, pt, pos[0], pos[1], g, h, off, 1.0f, c);
+            } else {
+                tex_linear(s, pos[0], pos[1], c);
+            }
+            if (alpha_mode) {
+                const float bx = smoothstep01(fminf(pos[0], 1.0f - pos[0]) / pt[0]);
+                const float by = smoothstep01(fminf(pos[1], 1.0f - pos[1]) / pt[1]);
+                const float border = bx * by;
+                if (alpha_mode == 2) {      // PL_ALPHA_PREMULTIPLIED
+                    for (int k = 0; k < 3; k++)
+                        c[k] *= border;
+                }
+                c[3] *= border;
+            }
+            memcpy(out + ((size_t) y * out_w + x) * 4, c, 16);
+        }
+    }
+}
+
 /* ======================================================================== */
 /* overlays (src/renderer.c:811-1020) and the blend unit (gpu.h pl_blend_params)  */
 

@@ -446,3 +446,12 @@ def deinterlace(cur, prev, next_, field, first_field, algo, skip_spatial_check=F
     lib().orc_deinterlace(_p(cur), ptr[0], ptr[1], w, h, field, first_field, algo,
                           int(skip_spatial_check), comp_mask, _p(out))
     return out
+
+
+def distort(img, tf, out_w, out_h, bicubic=False, alpha_mode=0, address_mode=0):
+    """pl_shader_distort: tf = canvas -> texture coordinates (m00, m01, m10, m11, c0, c1)"""
+    src, keep = _src(img, None, address_mode)
+    out = np.empty((out_h, out_w, 4), np.float32)
+    t = (C.c_float * 6)(*tf)
+    lib().orc_distort(C.byref(src), t, int(bicubic), int(alpha_mode), out_w, out_h, _p(out))
+    return out
