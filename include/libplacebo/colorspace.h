@@ -28,7 +28,7 @@ enum pl_color_system {
     PL_COLOR_SYSTEM_BT_2020_C,
     PL_COLOR_SYSTEM_BT_2100_PQ,
     PL_COLOR_SYSTEM_BT_2100_HLG,
-    PL_COLOR_SYSTEM_DOLBYVISION,    // enum value kept for ABI; not supported
+    PL_COLOR_SYSTEM_DOLBYVISION,    // needs pl_color_repr.dovi; input only
     PL_COLOR_SYSTEM_YCGCO,
     PL_COLOR_SYSTEM_YCGCO_RE,
     PL_COLOR_SYSTEM_YCGCO_RO,
@@ -78,7 +78,24 @@ struct pl_bit_encoding {
 PL_API bool pl_bit_encoding_equal(const struct pl_bit_encoding *b1,
                                   const struct pl_bit_encoding *b2);
 
-struct pl_dovi_metadata;    // opaque here (Dolby Vision is out of scope)
+// Dolby Vision: what an RPU says about a frame (reference colorspace.h:132-149). The decoding
+// matrices, and per component a piecewise curve of up to 8 pieces between 9 pivots, each a
+// quadratic or a multivariate polynomial (MMR) of all three components.
+struct pl_dovi_metadata {
+    float nonlinear_offset[3];  // "ycc_to_rgb_offset"
+    pl_matrix3x3 nonlinear;     // "ycc_to_rgb", in front of the PQ curve
+    pl_matrix3x3 linear;        // "rgb_to_lms", behind it
+
+    struct pl_reshape_data {
+        uint8_t num_pivots;
+        float pivots[9];        // normalised to [0, 1]
+        uint8_t method[8];      // 0 = polynomial, 1 = MMR
+        float poly_coeffs[8][3];        // x^0, x^1, x^2 (normalised)
+        uint8_t mmr_order[8];           // 1, 2 or 3
+        float mmr_constant[8];
+        float mmr_coeffs[8][3][7];      // per order
+    } comp[3];
+};
 
 struct pl_color_repr {
     enum pl_color_system sys;

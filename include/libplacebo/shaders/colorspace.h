@@ -23,6 +23,9 @@ PL_API void pl_shader_set_alpha(pl_shader sh, struct pl_color_repr *repr,
                                 enum pl_alpha_mode mode);
 
 // Decode `repr` to normalised RGB (updates `repr`) / encode RGB to `repr`
+// Dolby Vision reshaping on its own (pl_shader_decode_color does it for PL_COLOR_SYSTEM_DOLBYVISION)
+PL_API void pl_shader_dovi_reshape(pl_shader sh, const struct pl_dovi_metadata *data);
+
 PL_API void pl_shader_decode_color(pl_shader sh, struct pl_color_repr *repr,
                                    const struct pl_color_adjustment *params);
 PL_API void pl_shader_encode_color(pl_shader sh, const struct pl_color_repr *repr);

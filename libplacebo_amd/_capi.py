@@ -316,6 +316,17 @@ class BitEncoding(C.Structure):
     _fields_ = [("sample_depth", C.c_int), ("color_depth", C.c_int), ("bit_shift", C.c_int)]
 
 
+class ReshapeData(C.Structure):
+    _fields_ = [("num_pivots", C.c_uint8), ("pivots", C.c_float * 9), ("method", C.c_uint8 * 8),
+                ("poly_coeffs", (C.c_float * 3) * 8), ("mmr_order", C.c_uint8 * 8),
+                ("mmr_constant", C.c_float * 8), ("mmr_coeffs", ((C.c_float * 7) * 3) * 8)]
+
+
+class DoviMetadata(C.Structure):
+    _fields_ = [("nonlinear_offset", C.c_float * 3), ("nonlinear", (C.c_float * 3) * 3),
+                ("linear", (C.c_float * 3) * 3), ("comp", ReshapeData * 3)]
+
+
 class ColorRepr(C.Structure):
     _fields_ = [("sys", C.c_int), ("levels", C.c_int), ("alpha", C.c_int),
                 ("bits", BitEncoding), ("dovi", C.c_void_p)]

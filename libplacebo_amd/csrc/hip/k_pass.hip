@@ -101,7 +101,8 @@ DEV lin_fp lin_footprint(const plh_view &v, int mode, float px, float py)
 // samplers are only instantiated in the !SIMPLE variants, whose register budget they set.
 // CH: rows per cell (cells are 2 wide): 2x2 amortises most, 2x1 needs fewer registers
 // CUBIC: the colour map's lut3d_tricubic lookup (only this kernel carries it)
-template <bool LITE, bool SIMPLE, int CH, bool MIX = false, bool CUBIC = false>
+// DOVI: the Dolby Vision reshaping / LMS ops (only this kernel carries them)
+template <bool LITE, bool SIMPLE, int CH, bool MIX = false, bool CUBIC = false, bool DOVI = false>
 __global__ __launch_bounds__(PASS_BW * PASS_BH)
 void k_pass_generic(const plh_pass p_)
 {
@@ -205,7 +206,7 @@ void k_pass_generic(const plh_pass p_)
                 p.out_scale[1] * (float) idy < 1.0f && sx[q] >= 0 && sy[q] >= 0 &&
                 sx[q] < p.dst.w && sy[q] < p.dst.h;
     }
-    apply_ops_n<NPX, false, LITE, MIX, CUBIC>(c, p.ops, 0, p.num_ops, fcs);
+    apply_ops_n<NPX, false, LITE, MIX, CUBIC, DOVI>(c, p.ops, 0, p.num_ops, fcs);
     plh_store_n<NPX>(p.dst, sx, sy, ok, c, p.nt_store);
     }
 }
@@ -1425,6 +1426,60 @@ int plh_launch_deband(hipStream_t stream, const plh_pass *pass);
 int plh_launch_peak(hipStream_t stream, const plh_pass *pass);
 extern "C" int plh_launch_deinterlace(plh_stream stream, const struct plh_pass *pass);
 
+// the generic kernel (any sampler without a kernel of its own, any op list)
+static int plh_launch_generic(hipStream_t stream, const plh_pass *pass, bool cubic, bool dovi)
+{
+    const dim3 block(PASS_BW, PASS_BH);
+    const bool lite = plh_ops_lite(pass, 0, pass->num_ops);
+    const bool simple = pass->s.type == PLH_SAMPLE_NONE || pass->s.type == PLH_SAMPLE_NEAREST ||
+                        pass->s.type == PLH_SAMPLE_BILINEAR;
+    static int rows_override = -1;  // PL_HIP_PASS_ROWS=1|2 (profiling aid)
+    if (rows_override < 0) {
+        const char *e = getenv("PL_HIP_PASS_ROWS");
+        rows_override = e ? atoi(e) : 0;
+    }
+    // 2x2 cells share the bilinear footprint; everything else prefers the lighter 2x1 cells
+    // (measured: 4K colour map 193 -> 168 us, plane copy 20.4 -> 18.8 us)
+    int ch = pass->s.type == PLH_SAMPLE_BILINEAR && lite ? 2 : 1;
+    if (rows_override == 1 || rows_override == 2)
+        ch = rows_override;
+    bool mixing = false;
+    for (int i = 0; i < pass->num_ops; i++)
+        mixing |= pass->ops[i].kind == PLH_OP_MIX_ADD;
+    if (mixing || cubic || dovi)
+        ch = 1;
+    const int cells_w = (pass->width + pass->cell_padx + 1) / 2;
+    const int cells_h = ch == 2 ? (pass->height + pass->cell_pady + 1) / 2 : pass->height;
+    const int bh = PASS_BH * PASS_ITERS;
+    const dim3 grid((cells_w + PASS_BW - 1) / PASS_BW, (cells_h + bh - 1) / bh);
+#define LAUNCH(L, S, C) PLH_LAUNCH_LAST((k_pass_generic<L, S, C>), grid, block, 0, stream, *pass)
+    if (dovi) {
+        if (cubic || mixing)
+            return -1004;
+        PLH_LAUNCH_LAST((k_pass_generic<false, false, 1, false, false, true>), grid, block, 0, stream, *pass);
+    } else if (cubic) {
+        PLH_LAUNCH_LAST((k_pass_generic<false, true, 1, false, true>), grid, block, 0, stream, *pass);
+    } else if (mixing) {
+        // frame mixing: the one variant that carries the second colour register
+        if (!simple)
+            return -1003;
+        PLH_LAUNCH_LAST((k_pass_generic<false, true, 1, true>), grid, block, 0, stream, *pass);
+    } else if (ch == 2) {
+        if (lite && simple) LAUNCH(true, true, 2);
+        else if (lite)      LAUNCH(true, false, 2);
+        else if (simple)    LAUNCH(false, true, 2);
+        else                LAUNCH(false, false, 2);
+    } else {
+        if (lite && simple) LAUNCH(true, true, 1);
+        else if (lite)      LAUNCH(true, false, 1);
+        else if (simple)    LAUNCH(false, true, 1);
+        else                LAUNCH(false, false, 1);
+    }
+#undef LAUNCH
+    const hipError_t err = hipGetLastError();
+    return err == hipSuccess ? 0 : -(int) err;
+}
+
 extern "C" int plh_launch_pass(plh_stream stream_, const struct plh_pass *pass)
 {
     hipStream_t stream = (hipStream_t) stream_;
@@ -1455,6 +1510,22 @@ extern "C" int plh_launch_pass(plh_stream stream_, const struct plh_pass *pass)
             alone &= pass->ops[i].kind != PLH_OP_PEAK_DETECT && pass->ops[i].kind != PLH_OP_MIX_ADD;
         if (!alone)
             return -1004;
+    }
+
+    // Dolby Vision ops exist in one variant of the generic kernel only: such a pass (the
+    // renderer's decoding pass of a Dolby Vision frame) goes straight there, past every
+    // specialised kernel, and is refused behind a sampler that has its own kernel
+    bool dovi = false;
+    for (int i = 0; i < pass->num_ops; i++)
+        dovi |= pass->ops[i].kind == PLH_OP_DOVI_RESHAPE || pass->ops[i].kind == PLH_OP_DOVI_LMS;
+    if (dovi) {
+        for (int i = 0; i < pass->num_ops; i++) {
+            if (pass->ops[i].kind == PLH_OP_PEAK_DETECT)
+                return -1004;
+        }
+        if (pass->s.type >= PLH_SAMPLE_POLAR && pass->s.type != PLH_SAMPLE_DISTORT)
+            return -1004;
+        return plh_launch_generic(stream, pass, cubic, true);
     }
 
     switch (pass->s.type) {
@@ -1595,51 +1666,7 @@ extern "C" int plh_launch_pass(plh_stream stream_, const struct plh_pass *pass)
         return err == hipSuccess ? 0 : -(int) err;
     }
 
-    const dim3 block(PASS_BW, PASS_BH);
-    const bool lite = plh_ops_lite(pass, 0, pass->num_ops);
-    const bool simple = pass->s.type == PLH_SAMPLE_NONE || pass->s.type == PLH_SAMPLE_NEAREST ||
-                        pass->s.type == PLH_SAMPLE_BILINEAR;
-    static int rows_override = -1;  // PL_HIP_PASS_ROWS=1|2 (profiling aid)
-    if (rows_override < 0) {
-        const char *e = getenv("PL_HIP_PASS_ROWS");
-        rows_override = e ? atoi(e) : 0;
-    }
-    // 2x2 cells share the bilinear footprint; everything else prefers the lighter 2x1 cells
-    // (measured: 4K colour map 193 -> 168 us, plane copy 20.4 -> 18.8 us)
-    int ch = pass->s.type == PLH_SAMPLE_BILINEAR && lite ? 2 : 1;
-    if (rows_override == 1 || rows_override == 2)
-        ch = rows_override;
-    bool mixing = false;
-    for (int i = 0; i < pass->num_ops; i++)
-        mixing |= pass->ops[i].kind == PLH_OP_MIX_ADD;
-    if (mixing || cubic)
-        ch = 1;
-    const int cells_w = (pass->width + pass->cell_padx + 1) / 2;
-    const int cells_h = ch == 2 ? (pass->height + pass->cell_pady + 1) / 2 : pass->height;
-    const int bh = PASS_BH * PASS_ITERS;
-    const dim3 grid((cells_w + PASS_BW - 1) / PASS_BW, (cells_h + bh - 1) / bh);
-#define LAUNCH(L, S, C) PLH_LAUNCH_LAST((k_pass_generic<L, S, C>), grid, block, 0, stream, *pass)
-    if (cubic) {
-        PLH_LAUNCH_LAST((k_pass_generic<false, true, 1, false, true>), grid, block, 0, stream, *pass);
-    } else if (mixing) {
-        // frame mixing: the one variant that carries the second colour register
-        if (!simple)
-            return -1003;
-        PLH_LAUNCH_LAST((k_pass_generic<false, true, 1, true>), grid, block, 0, stream, *pass);
-    } else if (ch == 2) {
-        if (lite && simple) LAUNCH(true, true, 2);
-        else if (lite)      LAUNCH(true, false, 2);
-        else if (simple)    LAUNCH(false, true, 2);
-        else                LAUNCH(false, false, 2);
-    } else {
-        if (lite && simple) LAUNCH(true, true, 1);
-        else if (lite)      LAUNCH(true, false, 1);
-        else if (simple)    LAUNCH(false, true, 1);
-        else                LAUNCH(false, false, 1);
-    }
-#undef LAUNCH
-    const hipError_t err = hipGetLastError();
-    return err == hipSuccess ? 0 : -(int) err;
+    return plh_launch_generic(stream, pass, cubic, false);
 }
 
 // Test hook (tests/test_chain_match.py, CPU): plh_match_map_chain on an op list described by its

@@ -241,6 +241,23 @@ enum plh_op_kind {
     // tile = lessThan(fract(outcoord), 0.5); color.rgb += (1 - color.a) * (tile.x == tile.y ?
     // f[0..2] : f[4..6]); color.a = 1
     PLH_OP_BLEND_TILES,
+    // Dolby Vision (colorspace.c:51-271, :392-420), only in the generic pass kernel's DOVI variant:
+    // ptr = struct plh_dovi_comp[3] (device): per component a piecewise polynomial / MMR curve
+    PLH_OP_DOVI_RESHAPE,
+    // PQ EOTF, f[0..8] = LMS -> RGB (row-major), PQ OETF; f[9..13] = 1/m2 c1 c2 c3 1/m1,
+    // f[14], f[15] = m1, m2
+    PLH_OP_DOVI_LMS,
+};
+
+// pl_reshape_data as the reshaping stage reads it (pl_shader_dovi_reshape packs the same)
+struct plh_dovi_comp {
+    int32_t num_pivots;         // 0: the component passes through
+    int32_t has_poly, has_mmr, mmr_single;
+    int32_t min_order, max_order;
+    float lo, hi;               // the outer pivots: the result is clamped to them
+    float pivots[8];            // the inner pivots, then 1e9 (7 used)
+    float coeffs[8][4];         // per piece: polynomial x^0 x^1 x^2, 0 | MMR constant, first row, -, order
+    float mmr[48][4];           // per MMR piece and order: two rows (xyz-, then the cross terms)
 };
 
 // flags in plh_op.i1 of LINEARIZE / DELINEARIZE / PEAK_DETECT

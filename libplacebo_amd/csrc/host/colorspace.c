@@ -1210,6 +1210,10 @@ pl_transform3x3 pl_color_repr_decode(struct pl_color_repr *repr,
         }};
         break;
     }
+    case PL_COLOR_SYSTEM_DOLBYVISION:
+        if (repr->dovi)
+            m = repr->dovi->nonlinear;
+        break;
     case PL_COLOR_SYSTEM_YCGCO:
         m = (pl_matrix3x3) {{ {1, -1, 1}, {1, 1, 0}, {1, -1, -1} }};
         break;
@@ -1222,7 +1226,7 @@ pl_transform3x3 pl_color_repr_decode(struct pl_color_repr *repr,
         m = pl_get_xyz2rgb_matrix(pl_raw_primaries_get(PL_COLOR_PRIM_DCI_P3));
         break;
     default:
-        break; // RGB / unknown / (unsupported) Dolby Vision: identity
+        break; // RGB / unknown: identity
     }
 
     if (pl_color_system_is_ycbcr_like(repr->sys)) {
@@ -1271,7 +1275,13 @@ pl_transform3x3 pl_color_repr_decode(struct pl_color_repr *repr,
 
     double mul[3]   = { ymul, ymul, ymul };
     double black[3] = { ymin, ymin, ymin };
-    if (pl_color_system_is_ycbcr_like(repr->sys)) {
+    if (repr->sys == PL_COLOR_SYSTEM_DOLBYVISION && repr->dovi) {
+        // the stream's matrix already expands the levels; its offsets still apply (:1857-1864)
+        for (int i = 0; i < 3; i++) {
+            mul[i] = 1.0;
+            black[i] = repr->dovi->nonlinear_offset[i] * scale;
+        }
+    } else if (pl_color_system_is_ycbcr_like(repr->sys)) {
         mul[1]   = mul[2]   = cmul;
         black[1] = black[2] = cmid;
     }

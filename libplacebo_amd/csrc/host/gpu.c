@@ -632,6 +632,14 @@ pl_pass pl_pass_create(pl_gpu gpu, const struct pl_pass_params *params)
         pl_msg(gpu->log, PL_LOG_ERR, "pl_pass_create: invalid pass type");
         return NULL;
     }
+    for (int i = 0; i < sh->pass.num_ops; i++) {
+        if (sh->pass.ops[i].kind == PLH_OP_DOVI_RESHAPE) {
+            // its curves sit in a per-pass scratch slot (gpu_priv.h) that a long-lived pass would outlive
+            pl_msg(gpu->log, PL_LOG_ERR, "pl_pass_create: a shader with Dolby Vision reshaping "
+                   "cannot be kept as a pass (its curves change per frame): dispatch it");
+            return NULL;
+        }
+    }
     if (params->num_variables || params->num_constants || params->push_constants_size ||
         params->blend_params) {
         pl_msg(gpu->log, PL_LOG_ERR, "pl_pass_create: variables, constants, push constants and "

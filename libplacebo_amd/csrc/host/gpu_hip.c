@@ -208,6 +208,7 @@ static void hip_destroy(pl_gpu gpu)
         plh_event_destroy(p->stage[i].done);
         plh_host_free(p->stage[i].host);
     }
+    plh_free(p->scratch);
     if (p->own_stream)
         plh_stream_destroy(p->stream);
     free(p);
@@ -749,6 +750,39 @@ void plh_buf_write(pl_gpu gpu, pl_buf buf, size_t buf_offset, const void *data, 
     }
     plh_copy2d_h2d(g->stream, dst, size, data, size, size, 1);
     sync_main(g);
+}
+
+const void *plh_gpu_upload_scratch(pl_gpu gpu, const void *data, size_t size)
+{
+    struct gpu_priv *g = GPU_PRIV(gpu);
+    if (size > PLH_SCRATCH_BYTES)
+        return NULL;
+    if (!g->scratch) {
+        g->scratch = plh_malloc(g->device, (size_t) PLH_SCRATCH_SLOTS * PLH_SCRATCH_BYTES);
+        if (!g->scratch)
+            return NULL;
+    }
+    uint8_t *slot = (uint8_t *) g->scratch + (size_t) (g->scratch_next++ % PLH_SCRATCH_SLOTS) * PLH_SCRATCH_BYTES;
+    // through the pinned staging ring, like plh_buf_write
+    const int i = g->stage_next;
+    if (!g->stage[i].host) {
+        g->stage[i].host = plh_host_alloc(PLH_STAGE_BYTES);
+        if (g->stage[i].host && plh_event_create(&g->stage[i].done)) {
+            plh_host_free(g->stage[i].host);
+            g->stage[i].host = NULL;
+        }
+    }
+    if (!g->stage[i].host)
+        return NULL;
+    if (g->stage[i].in_flight)
+        plh_event_sync(g->stage[i].done);
+    memcpy(g->stage[i].host, data, size);
+    if (plh_copy2d_h2d(g->stream, slot, size, g->stage[i].host, size, size, 1) ||
+        plh_event_record(g->stage[i].done, g->stream))
+        return NULL;
+    g->stage[i].in_flight = true;
+    g->stage_next = (i + 1) % PLH_STAGE_SLOTS;
+    return slot;
 }
 
 bool plh_buf_read(pl_gpu gpu, pl_buf buf, size_t buf_offset, void *dest, size_t size)

@@ -95,7 +95,18 @@ struct gpu_priv {
         bool in_flight;
     } stage[PLH_STAGE_SLOTS];
     int stage_next;
+    // Small per-pass tables that no object of the caller's outlives (Dolby Vision reshaping
+    // curves: pl_shader_decode_color has no state parameter): a ring of device slots, written on
+    // the main stream. A slot is reused PLH_SCRATCH_SLOTS uploads later -- behind, in stream
+    // order, the pass that read it, provided that pass was dispatched by then.
+    void *scratch;
+    unsigned scratch_next;
 };
+
+#define PLH_SCRATCH_SLOTS 32
+#define PLH_SCRATCH_BYTES 4096
+// device pointer to a copy of `data` (size <= PLH_SCRATCH_BYTES); NULL on failure
+const void *plh_gpu_upload_scratch(pl_gpu gpu, const void *data, size_t size);
 
 struct tex_priv {
     struct pl_tex_t tex;

@@ -970,6 +970,14 @@ bool plh_stage_read(struct frame_job *job)
             pl_shader_linearize(sh, &img->color);
             img->color.transfer = PL_COLOR_TRC_LINEAR;
         }
+        if (img->repr.sys == PL_COLOR_SYSTEM_DOLBYVISION && sh->pass.s.type >= PLH_SAMPLE_POLAR) {
+            // the Dolby Vision ops live in the generic kernel only: a plane that arrives through a
+            // sampler with a kernel of its own (debanded) is stored first, unrounded
+            img->store_as = pl_find_named_fmt(rr->gpu, "rgba32f");
+            if (!plh_work_texture(job, img))
+                return false;
+            sh = plh_work_shader(job, img);
+        }
         pl_shader_decode_color(sh, &img->repr, params->color_adjustment);
     }
     if (lut == PL_LUT_NORMALIZED)
@@ -985,8 +993,16 @@ bool plh_stage_read(struct frame_job *job)
 static bool owns_workgroup_shape(const pl_shader sh)
 {
     const int t = sh->pass.s.type;
-    return t == PLH_SAMPLE_POLAR || t == PLH_SAMPLE_ORTHO || t == PLH_SAMPLE_DEBAND ||
-           t == PLH_SAMPLE_DEINTERLACE;
+    if (t == PLH_SAMPLE_POLAR || t == PLH_SAMPLE_ORTHO || t == PLH_SAMPLE_DEBAND ||
+        t == PLH_SAMPLE_DEINTERLACE)
+        return true;
+    // ... and so do the Dolby Vision ops: one variant of the generic kernel, without the
+    // measurement's workgroup state
+    for (int i = 0; i < sh->pass.num_ops; i++) {
+        if (sh->pass.ops[i].kind == PLH_OP_DOVI_RESHAPE || sh->pass.ops[i].kind == PLH_OP_DOVI_LMS)
+            return true;
+    }
+    return false;
 }
 
 static void measure_peak(struct frame_job *job)

@@ -95,17 +95,110 @@ static void ictcp_constants(struct plh_op *op, bool hlg)
     }
 }
 
+// Dolby Vision reshaping (reference colorspace.c:106-271): the curves of the three components,
+// packed the way the reference packs its uniforms (coefficients per piece, MMR rows per piece and
+// order) into one table the op reads (colormap.hiph: op_dovi_reshape)
+void pl_shader_dovi_reshape(pl_shader sh, const struct pl_dovi_metadata *data)
+{
+    if (!sh_require(sh, PL_SHADER_SIG_COLOR, 0, 0) || !data)
+        return;
+    pl_gpu gpu = SH_GPU(sh);
+    if (!gpu) {
+        SH_FAIL(sh, "pl_shader_dovi_reshape requires a GPU (the curves are a device table)");
+        return;
+    }
+
+    struct plh_dovi_comp table[3];
+    memset(table, 0, sizeof(table));
+    bool any = false;
+    for (int c = 0; c < 3; c++) {
+        const struct pl_reshape_data *comp = &data->comp[c];
+        struct plh_dovi_comp *out = &table[c];
+        if (!comp->num_pivots)
+            continue;
+        if (comp->num_pivots < 2 || comp->num_pivots > 9) {
+            SH_FAIL(sh, "pl_shader_dovi_reshape: component %d has %d pivots (2 .. 9 allowed)",
+                    c, comp->num_pivots);
+            return;
+        }
+        any = true;
+        out->num_pivots = comp->num_pivots;
+        out->mmr_single = true;
+        out->min_order = 3;
+        out->max_order = 1;
+        int mmr_idx = 0;
+        for (int i = 0; i < comp->num_pivots - 1; i++) {
+            if (comp->method[i] == 0) {
+                out->has_poly = true;
+                out->coeffs[i][3] = 0.0f;  // order 0 = polynomial
+                for (int k = 0; k < 3; k++)
+                    out->coeffs[i][k] = comp->poly_coeffs[i][k];
+            } else if (comp->method[i] == 1 && comp->mmr_order[i] >= 1 && comp->mmr_order[i] <= 3) {
+                out->min_order = PL_MIN(out->min_order, comp->mmr_order[i]);
+                out->max_order = PL_MAX(out->max_order, comp->mmr_order[i]);
+                out->mmr_single = !out->has_mmr;
+                out->has_mmr = true;
+                out->coeffs[i][3] = comp->mmr_order[i];
+                out->coeffs[i][0] = comp->mmr_constant[i];
+                out->coeffs[i][1] = mmr_idx;
+                for (int j = 0; j < comp->mmr_order[i]; j++) {
+                    const float *w = comp->mmr_coeffs[i][j];
+                    float *rows = &out->mmr[mmr_idx][0];
+                    rows[0] = w[0]; rows[1] = w[1]; rows[2] = w[2]; rows[3] = 0.0f;
+                    rows[4] = w[3]; rows[5] = w[4]; rows[6] = w[5]; rows[7] = w[6];
+                    mmr_idx += 2;
+                }
+            } else {
+                SH_FAIL(sh, "pl_shader_dovi_reshape: invalid method / order in component %d", c);
+                return;
+            }
+        }
+        // the inner pivots, then a quasi-infinite sentinel (:188-196)
+        for (int i = 0; i < 8; i++)
+            out->pivots[i] = i < comp->num_pivots - 2 ? comp->pivots[i + 1] : 1e9f;
+        out->lo = comp->pivots[0];
+        out->hi = comp->pivots[comp->num_pivots - 1];
+    }
+
+    sh_describef(sh, "reshaping");
+    if (!any) {
+        // (the reference still clamps nothing and leaves the colour alone)
+        return;
+    }
+    const void *dev = plh_gpu_upload_scratch(gpu, table, sizeof(table));
+    struct plh_op *op = dev ? sh_op(sh, PLH_OP_DOVI_RESHAPE) : NULL;
+    if (!op) {
+        SH_FAIL(sh, "pl_shader_dovi_reshape: could not upload the reshaping curves");
+        return;
+    }
+    op->ptr = dev;
+    sh_listf(sh, "dovi_reshape(pivots %d %d %d)\n", table[0].num_pivots, table[1].num_pivots,
+             table[2].num_pivots);
+}
+
 void pl_shader_decode_color(pl_shader sh, struct pl_color_repr *repr,
                             const struct pl_color_adjustment *params)
 {
     if (!sh_require(sh, PL_SHADER_SIG_COLOR, 0, 0))
         return;
-    if (repr->sys == PL_COLOR_SYSTEM_DOLBYVISION) {
-        SH_FAIL(sh, "Dolby Vision reshaping is not supported by the HIP backend");
+    if (repr->sys == PL_COLOR_SYSTEM_DOLBYVISION && !repr->dovi) {
+        SH_FAIL(sh, "PL_COLOR_SYSTEM_DOLBYVISION requires pl_color_repr.dovi");
         return;
     }
 
     sh_describef(sh, "color decoding");
+    const struct pl_dovi_metadata *dovi = repr->dovi;
+    if (repr->sys == PL_COLOR_SYSTEM_DOLBYVISION) {
+        // (:285-292) the integer scale first, then the curves work on normalised values
+        const float scale = pl_color_repr_normalize(repr);
+        struct plh_op *op = sh_op(sh, PLH_OP_SCALE);
+        if (!op)
+            return;
+        op->f[0] = op->f[1] = op->f[2] = scale;
+        op->f[3] = 1.0f;
+        sh_listf(sh, "scale(%g, rgb only)\n", scale);
+        pl_shader_dovi_reshape(sh, dovi);
+    }
     const enum pl_color_system orig_sys = repr->sys;
     const pl_transform3x3 tr = pl_color_repr_decode(repr, params);
     if (memcmp(&tr, &pl_transform3x3_identity, sizeof(tr)))
@@ -120,6 +213,28 @@ void pl_shader_decode_color(pl_shader sh, struct pl_color_repr *repr,
         struct plh_op *op = simple_op(sh, PLH_OP_ICTCP_DEC, "ictcp_decode()");
         if (op)
             ictcp_constants(op, orig_sys == PL_COLOR_SYSTEM_BT_2100_HLG);
+        break;
+    }
+    case PL_COLOR_SYSTEM_DOLBYVISION: {
+        // (:392-420) Dolby Vision decodes to BT.2020-referred HPE LMS: the inverse of that matrix,
+        // times the stream's own, between a PQ EOTF and a PQ OETF
+        pl_matrix3x3 lms2rgb = {{
+            { 3.06441879, -2.16597676,  0.10155818},
+            {-0.65612108,  1.78554118, -0.12943749},
+            { 0.01736321, -0.04725154,  1.03004253},
+        }};
+        pl_matrix3x3_mul(&lms2rgb, &dovi->linear);
+        struct plh_op *op = simple_op(sh, PLH_OP_DOVI_LMS, "dovi_lms()");
+        if (op) {
+            for (int i = 0; i < 3; i++) {
+                for (int j = 0; j < 3; j++)
+                    op->f[3 * i + j] = lms2rgb.m[i][j];
+            }
+            const float m1 = plh_fmtf(PQ_M1), m2 = plh_fmtf(PQ_M2);
+            op->f[9] = 1.0f / m2; op->f[10] = plh_fmtf(PQ_C1); op->f[11] = plh_fmtf(PQ_C2);
+            op->f[12] = plh_fmtf(PQ_C3); op->f[13] = 1.0f / m1;
+            op->f[14] = m1; op->f[15] = m2;
+        }
         break;
     }
     default:

@@ -1632,7 +1632,8 @@ bool plh_shader_sample_polar_fused(pl_shader sh, const pl_shader pre,
         return false;
     for (int i = 0; i < pp->num_ops; i++) {
         if (pp->ops[i].kind == PLH_OP_DITHER || pp->ops[i].kind == PLH_OP_PEAK_DETECT ||
-            pp->ops[i].kind == PLH_OP_PLANE_FETCH)
+            pp->ops[i].kind == PLH_OP_PLANE_FETCH || pp->ops[i].kind == PLH_OP_DOVI_RESHAPE ||
+            pp->ops[i].kind == PLH_OP_DOVI_LMS)
             return false; // position dependent / needs its own kernel
     }
 

@@ -17,7 +17,7 @@ fi
 mkdir -p "$OUT/gen/libplacebo" "$OUT/obj"
 # config.h from the reference template (substitution output only)
 sed -e 's/@majorver@/7/' -e 's/@apiver@/365/' \
-    -e 's/@extra_defs@/#undef PL_HAVE_VULKAN\n#undef PL_HAVE_OPENGL\n#undef PL_HAVE_D3D11\n#undef PL_HAVE_LCMS\n#undef PL_HAVE_SHADERC\n#undef PL_HAVE_GLSLANG\n#undef PL_HAVE_XXHASH\n#undef PL_HAVE_DOVI\n#undef PL_HAVE_LIBDOVI/' \
+    -e 's/@extra_defs@/#undef PL_HAVE_VULKAN\n#undef PL_HAVE_OPENGL\n#undef PL_HAVE_D3D11\n#undef PL_HAVE_LCMS\n#undef PL_HAVE_SHADERC\n#undef PL_HAVE_GLSLANG\n#undef PL_HAVE_XXHASH\n#define PL_HAVE_DOVI 1\n#undef PL_HAVE_LIBDOVI/' \
     "$REF/src/include/libplacebo/config.h.in" > "$OUT/gen/libplacebo/config.h"
 cat > "$OUT/gen/config_internal.h" <<'EOT'
 #pragma once

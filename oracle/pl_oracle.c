@@ -1708,6 +1708,97 @@ ORC_API void orc_error_diffusion(const float *img, int w, int h, int depth, int 
 // plh_un8 / plh_un16 (csrc/hip/devmath.hiph): q = v*(1/d); q += fma(-q, d, v)*(1/d) must be
 // the correctly rounded v/d for every code value. Returns the number of mismatches.
 /* ======================================================================== */
+/* Dolby Vision (src/shaders/colorspace.c:51-271, :285-292, :392-420)             */
+
+// struct pl_reshape_data (include/libplacebo/colorspace.h:139-148), as the caller fills it
+struct orc_dovi_comp {
+    int num_pivots;
+    float pivots[9];
+    int method[8];              // 0 = polynomial, 1 = MMR
+    float poly_coeffs[8][3];
+    int mmr_order[8];
+    float mmr_constant[8];
+    float mmr_coeffs[8][3][7];
+};
+
+static float dot3(const float a[3], const float b[3]) { return a[0] * b[0] + a[1] * b[1] + a[2] * b[2]; }
+static float dot4(const float a[4], const float b[4])
+{
+    return a[0] * b[0] + a[1] * b[1] + a[2] * b[2] + a[3] * b[3];
+}
+
+// pl_shader_dovi_reshape: `sig` is the clamped input colour for all three components (:119);
+// the piece is the one whose pivots bracket s (the shader's tree of mix(., ., s >= pivot[i]) over
+// the inner pivots and 1e9 sentinels selects exactly the number of inner pivots <= s, :186-217)
+ORC_API void orc_dovi_reshape(float *img, size_t npix, const struct orc_dovi_comp comp[3])
+{
+    for (size_t i = 0; i < npix; i++) {
+        float *c = img + 4 * i;
+        const float sig[3] = { clampf(c[0], 0.0f, 1.0f), clampf(c[1], 0.0f, 1.0f),
+                               clampf(c[2], 0.0f, 1.0f) };
+        for (int ch = 0; ch < 3; ch++) {
+            const struct orc_dovi_comp *k = &comp[ch];
+            if (!k->num_pivots)
+                continue;
+            float s = sig[ch];
+            int piece = 0;
+            for (int p = 1; p < k->num_pivots - 1; p++)
+                piece += s >= k->pivots[p];
+            if (k->method[piece] == 0) {
+                const float *co = k->poly_coeffs[piece];
+                s = (co[2] * s + co[1]) * s + co[0];                        // reshape_poly (:101)
+            } else {                                                        // reshape_mmr (:52-97)
+                const int order = k->mmr_order[piece];
+                const float (*w)[7] = k->mmr_coeffs[piece];
+                float sigX[4] = { sig[0] * sig[1], sig[0] * sig[2], sig[1] * sig[2], 0.0f };
+                sigX[3] = sigX[0] * sig[2];
+                s = k->mmr_constant[piece];
+                s += dot3(w[0], sig);
+                s += dot4(w[0] + 3, sigX);
+                if (order >= 2) {
+                    const float sig2[3] = { sig[0] * sig[0], sig[1] * sig[1], sig[2] * sig[2] };
+                    const float sigX2[4] = { sigX[0] * sigX[0], sigX[1] * sigX[1], sigX[2] * sigX[2],
+                                             sigX[3] * sigX[3] };
+                    s += dot3(w[1], sig2);
+                    s += dot4(w[1] + 3, sigX2);
+                    if (order >= 3) {
+                        const float sig3[3] = { sig2[0] * sig[0], sig2[1] * sig[1], sig2[2] * sig[2] };
+                        const float sigX3[4] = { sigX2[0] * sigX[0], sigX2[1] * sigX[1],
+                                                 sigX2[2] * sigX[2], sigX2[3] * sigX[3] };
+                        s += dot3(w[2], sig3);
+                        s += dot4(w[2] + 3, sigX3);
+                    }
+                }
+            }
+            c[ch] = clampf(s, k->pivots[0], k->pivots[k->num_pivots - 1]);
+        }
+    }
+}
+
+// The non-linear tail of Dolby Vision decoding (:392-420): PQ EOTF, LMS -> RGB (row-major 3 x 3,
+// the hard-coded BT.2020 HPE inverse times the stream's matrix: the caller multiplies), PQ OETF,
+// with the constants as the shader text prints them
+ORC_API void orc_dovi_lms(float *img, size_t npix, const float m[9])
+{
+    const float im2 = 1.0f / pf(O_PQ_M2), c1 = pf(O_PQ_C1), c2 = pf(O_PQ_C2), c3 = pf(O_PQ_C3),
+                im1 = 1.0f / pf(O_PQ_M1), m1 = pf(O_PQ_M1), m2 = pf(O_PQ_M2);
+    for (size_t i = 0; i < npix; i++) {
+        float *c = img + 4 * i, v[3];
+        for (int k = 0; k < 3; k++) {
+            float x = powf(fmaxf(c[k], 0.0f), im2);
+            x = fmaxf(x - c1, 0.0f) / (c2 - c3 * x);
+            v[k] = powf(x, im1);
+        }
+        for (int r = 0; r < 3; r++) {
+            float x = m[3 * r] * v[0] + m[3 * r + 1] * v[1] + m[3 * r + 2] * v[2];
+            x = powf(fmaxf(x, 0.0f), m1);
+            x = (c1 + c2 * x) / (1.0f + c3 * x);
+            c[r] = powf(x, m2);
+        }
+    }
+}
+
+/* ======================================================================== */
 /* pl_shader_distort (src/shaders/sampling.c:1108-1217)                          */
 
 // The canvas [-1, 1]^2 (y up: the attribute runs from +1 at the top row to -1 at the bottom,

@@ -455,3 +455,24 @@ def distort(img, tf, out_w, out_h, bicubic=False, alpha_mode=0, address_mode=0):
     t = (C.c_float * 6)(*tf)
     lib().orc_distort(C.byref(src), t, int(bicubic), int(alpha_mode), out_w, out_h, _p(out))
     return out
+
+
+class DoviComp(C.Structure):
+    """struct orc_dovi_comp (pl_reshape_data with ints)"""
+    _fields_ = [("num_pivots", C.c_int), ("pivots", C.c_float * 9), ("method", C.c_int * 8),
+                ("poly_coeffs", (C.c_float * 3) * 8), ("mmr_order", C.c_int * 8),
+                ("mmr_constant", C.c_float * 8), ("mmr_coeffs", ((C.c_float * 7) * 3) * 8)]
+
+
+def dovi_reshape(img, comps):
+    """pl_shader_dovi_reshape in place; comps = (DoviComp * 3)"""
+    assert img.dtype == np.float32 and img.flags.c_contiguous
+    lib().orc_dovi_reshape(_p(img), C.c_size_t(img.size // 4), comps)
+    return img
+
+
+def dovi_lms(img, m9):
+    assert img.dtype == np.float32 and img.flags.c_contiguous
+    m = (C.c_float * 9)(*m9)
+    lib().orc_dovi_lms(_p(img), C.c_size_t(img.size // 4), m)
+    return img

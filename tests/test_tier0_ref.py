@@ -215,6 +215,31 @@ def test_color_repr_decode(libs):
                     assert bytes(rr) == bytes(ro)
 
 
+def test_color_repr_decode_dolby_vision(libs):
+    """PL_COLOR_SYSTEM_DOLBYVISION: the stream's own matrix and offsets (src/colorspace.c:1758,
+    :1857-1864; the reference is built with PL_HAVE_DOVI, oracle/build_ref.sh)"""
+    from libplacebo_amd import _capi as capi
+    ref, our = libs
+    rng = np.random.default_rng(5)
+    for trial in range(20):
+        meta = capi.DoviMetadata()
+        for i in range(3):
+            meta.nonlinear_offset[i] = float(rng.random()) * 0.6 - 0.1
+            for j in range(3):
+                meta.nonlinear[i][j] = float(rng.normal())
+                meta.linear[i][j] = float(rng.normal())
+        for bits in ((0, 0, 0), (16, 10, 0), (16, 12, 4), (10, 10, 0)):
+            for levels in (0, 1, 2):
+                for adj in (None, (0.1, 1.2, 1.3, 0.2, 1.0, 0.3)):
+                    rr = Repr(sys=8, levels=levels, bits=Bits(*bits), dovi=C.addressof(meta))
+                    ro = Repr(sys=8, levels=levels, bits=Bits(*bits), dovi=C.addressof(meta))
+                    a = Adj(*adj) if adj else None
+                    tr = ref.pl_color_repr_decode(C.byref(rr), C.byref(a) if a else None)
+                    to = our.pl_color_repr_decode(C.byref(ro), C.byref(a) if a else None)
+                    assert bits_equal(m3(tr.mat) + list(tr.c), m3(to.mat) + list(to.c))
+                    assert bytes(rr) == bytes(ro)
+
+
 def test_cpu_transfer_functions_and_inference(libs):
     ref, our = libs
     rng = np.random.default_rng(0)
