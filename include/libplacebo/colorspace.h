@@ -5,8 +5,8 @@
  * API-compatible with the reference's src/include/libplacebo/colorspace.h for
  * the parts the render hot path uses: enums (:29-60,176-240), pl_color_repr
  * (:118-150), pl_hdr_metadata / pl_color_space (:383-520), matrices
- * (:600-680), pl_color_repr_decode (:700). Dolby Vision reshaping, ICC and
- * cone (colour-blindness) models are out of scope.
+ * (:600-680), pl_color_repr_decode (:700), pl_dovi_metadata (:132-149). ICC profiles are
+ * carried, not interpreted.
  */
 #ifndef LIBPLACEBO_COLORSPACE_H_
 #define LIBPLACEBO_COLORSPACE_H_

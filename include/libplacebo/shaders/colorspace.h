@@ -4,8 +4,7 @@
  * src/include/libplacebo/shaders/colorspace.h: set_alpha :30, decode/encode
  * :52-60, linearize/delinearize :66-72, sigmoid :74-96, peak detection
  * :98-190, colour mapping :200-390.
- * Not provided (out of scope): Dolby Vision reshaping, cone
- * distortion, LUT/clipping visualisation.
+ * Not provided (out of scope): LUT / clipping visualisation.
  */
 #ifndef LIBPLACEBO_SHADERS_COLORSPACE_H_
 #define LIBPLACEBO_SHADERS_COLORSPACE_H_
