@@ -96,6 +96,7 @@ WORKLOADS = {
     # interlaced broadcast video: 1080i NV12, every plane deinterlaced (bwdif, the default: the
     # frames before and after are read as well), then the default preset to 4K
     "nv12_1080i_to_4k_bwdif_default_preset": (P1080, P4K, 3 * px(P1080) * 3 // 2 + px(P4K) * 8, "ortho"),
+    "nv12_1080i_to_4k_yadif_default_preset": (P1080, P4K, 3 * px(P1080) * 3 // 2 + px(P4K) * 8, "ortho"),
     # pl_render_default_params as shipped: lanczos in linear, sigmoidized light + dither
     "default_preset_1080p_to_4k": (P1080, P4K, px(P1080) * 8 + px(P4K) * 8, "ortho"),
     # pl_render_high_quality_params on SDR video: deband, ewa_lanczossharp in sigmoidized linear
@@ -249,9 +250,10 @@ class Stream:
                                            dither_params=dither,
                                            disable_dither_gamma_correction=True)
             icsp, tcsp, trepr = pl.color_space("bt709", "bt1886"), pl.color_space("bt709", "bt1886"), ten_bit
-        elif workload == "nv12_1080i_to_4k_bwdif_default_preset":
+        elif workload in ("nv12_1080i_to_4k_bwdif_default_preset", "nv12_1080i_to_4k_yadif_default_preset"):
+            algo = pl.DEINTERLACE_YADIF if "yadif" in workload else pl.DEINTERLACE_BWDIF
             self.params = pl.render_params(
-                "default", deinterlace_params=capi.DeinterlaceParams(pl.DEINTERLACE_BWDIF, False))
+                "default", deinterlace_params=capi.DeinterlaceParams(algo, False))
             icsp, tcsp, trepr = pl.color_space("bt709", "bt1886"), pl.color_space("bt709", "bt1886"), ten_bit
         elif workload == "nv12_1080p_to_4k_default_preset":
             self.params = pl.render_params("default")

@@ -367,6 +367,148 @@ void k_deint_rows(const plh_pass p_)
     }
 }
 
+// yadif on a whole plane: the same dword-of-a-row-pair scheme, with the rows above and below as
+// WINDOWS of 2 R + 1 dwords (the spatial predictor looks 3 pixels = 3 NC slots to either side:
+// R = ceil(3 NC / N) dwords; r8: 3 loads per row for four pixels where the general kernel issues
+// 14 single-byte loads per pixel). Lanes whose window would leave the row -- the first and last R
+// dwords, and a row's ragged tail -- take every tap through the mirrored per-slot fetch instead.
+template <typename C>
+DEV float deint_slot_at(const plh_view &v, int nc, int y, int slot)
+{
+    const int px = plh_wrap(slot >= 0 ? slot / nc : -((-slot + nc - 1) / nc), v.w, PLH_ADDRESS_MIRROR);
+    const int c = ((slot % nc) + nc) % nc;
+    const int my = plh_wrap(y, v.h, PLH_ADDRESS_MIRROR);
+    const C raw = ((const C *) ((const uint8_t *) v.ptr + (size_t) my * v.pitch))[px * nc + c];
+    if constexpr (sizeof(C) == 1)
+        return plh_un8(raw);
+    else
+        return plh_un16(raw);
+}
+
+template <typename C, int NC, bool F32DST>
+__global__ __launch_bounds__(DEINT_BW * DEINT_BH)
+void k_deint_rows_yadif(const plh_pass p_)
+{
+    constexpr int N = 4 / sizeof(C);            // component slots per dword
+    constexpr int R = (3 * NC + N - 1) / N;     // window radius in dwords
+    const plh_pass &p = plh_kernarg_pass();
+    const plh_view &cur = p.s.src;
+    const plh_deint_args &a = p.deint;
+    const int seg = blockIdx.x * DEINT_BW + (int) (threadIdx.x % DEINT_BW);
+    const int pair = blockIdx.y * DEINT_BH + (int) (threadIdx.x / DEINT_BW);
+    const int slots = cur.w * NC;
+    if (seg * N >= slots)
+        return;
+    const int yk = 2 * pair + a.keep, yr = 2 * pair + 1 - a.keep;
+    const plh_view &prev2 = a.first ? a.prev : cur, &next2 = a.first ? cur : a.next;
+
+    auto row = [&](const plh_view &v, int y, int dw) {
+        const int my = plh_wrap(y, v.h, PLH_ADDRESS_MIRROR);
+        return *(const uint32_t *) ((const uint8_t *) v.ptr + (size_t) my * v.pitch + 4 * dw);
+    };
+    auto put = [&](int y, uint32_t raw, const float (&val)[N], bool have_raw) {
+        if (y >= cur.h)
+            return;
+        uint8_t *dst = (uint8_t *) p.dst.ptr + (size_t) y * p.dst.pitch;
+        if constexpr (F32DST) {
+            float *o = (float *) dst + seg * N;
+#pragma unroll
+            for (int k = 0; k < N; k++) {
+                if (seg * N + k < slots)
+                    o[k] = have_raw ? deint_slot<C>(raw, k) : val[k];
+            }
+        } else {
+            ((uint32_t *) dst)[seg] = have_raw ? raw : deint_pack<C>(val);
+        }
+    };
+
+    const float none[N] = {};
+    put(yk, row(cur, yk, seg), none, true);
+    if (yr >= cur.h)
+        return;
+
+    float out[N];
+    const int whole = slots / N;        // dwords that lie entirely inside the row
+    if (seg - R >= 0 && seg + R < whole) {
+        uint32_t up[2 * R + 1], dn[2 * R + 1];
+#pragma unroll
+        for (int k = 0; k < 2 * R + 1; k++) {
+            up[k] = row(cur, yr - 1, seg - R + k);
+            dn[k] = row(cur, yr + 1, seg - R + k);
+        }
+        const uint32_t rp[2] = { row(a.prev, yr - 1, seg), row(a.prev, yr + 1, seg) };
+        const uint32_t rn[2] = { row(a.next, yr - 1, seg), row(a.next, yr + 1, seg) };
+        const uint32_t rp2[3] = { row(prev2, yr - 2, seg), row(prev2, yr, seg), row(prev2, yr + 2, seg) };
+        const uint32_t rn2[3] = { row(next2, yr - 2, seg), row(next2, yr, seg), row(next2, yr + 2, seg) };
+#pragma unroll
+        for (int s = 0; s < N; s++) {
+            float u[7], d[7];
+#pragma unroll
+            for (int j = 0; j < 7; j++) {
+                constexpr int base = R * N;             // slot index of this lane's first slot in the window
+                const int idx = base + s + (j - 3) * NC;
+                u[j] = deint_slot<C>(up[idx / N], idx % N);
+                d[j] = deint_slot<C>(dn[idx / N], idx % N);
+            }
+            deint_column t = {};
+            t.cur[1] = u[3];
+            t.cur[2] = d[3];
+            t.prev[0] = deint_slot<C>(rp[0], s);  t.prev[1] = deint_slot<C>(rp[1], s);
+            t.next[0] = deint_slot<C>(rn[0], s);  t.next[1] = deint_slot<C>(rn[1], s);
+#pragma unroll
+            for (int k = 0; k < 3; k++) {
+                t.prev2[k + 1] = deint_slot<C>(rp2[k], s);
+                t.next2[k + 1] = deint_slot<C>(rn2[k], s);
+            }
+            out[s] = yadif_temporal(t, yadif_spatial(u, d, a.spatial_bias), a.skip_spatial_check != 0);
+        }
+    } else {
+        // an edge lane: the sideways taps one by one through the mirror; the temporal taps only
+        // look up and down, so they still come as dwords unless this is the row's ragged tail
+        const bool tail = seg >= whole;
+        uint32_t rp[2] = {}, rn[2] = {}, rp2[3] = {}, rn2[3] = {};
+        if (!tail) {
+#pragma unroll
+            for (int k = 0; k < 2; k++) {
+                rp[k] = row(a.prev, yr + 2 * k - 1, seg);
+                rn[k] = row(a.next, yr + 2 * k - 1, seg);
+            }
+#pragma unroll
+            for (int k = 0; k < 3; k++) {
+                rp2[k] = row(prev2, yr + 2 * k - 2, seg);
+                rn2[k] = row(next2, yr + 2 * k - 2, seg);
+            }
+        }
+#pragma unroll
+        for (int s = 0; s < N; s++) {
+            const int slot = seg * N + s;
+            float u[7], d[7];
+#pragma unroll
+            for (int j = 0; j < 7; j++) {
+                u[j] = deint_slot_at<C>(cur, NC, yr - 1, slot + (j - 3) * NC);
+                d[j] = deint_slot_at<C>(cur, NC, yr + 1, slot + (j - 3) * NC);
+            }
+            deint_column t = {};
+            t.cur[1] = u[3];
+            t.cur[2] = d[3];
+#pragma unroll
+            for (int k = 0; k < 2; k++) {
+                t.prev[k] = tail ? deint_slot_at<C>(a.prev, NC, yr + 2 * k - 1, slot) : deint_slot<C>(rp[k], s);
+                t.next[k] = tail ? deint_slot_at<C>(a.next, NC, yr + 2 * k - 1, slot) : deint_slot<C>(rn[k], s);
+            }
+#pragma unroll
+            for (int k = 0; k < 3; k++) {
+                t.prev2[k + 1] = tail ? deint_slot_at<C>(prev2, NC, yr + 2 * k - 2, slot) : deint_slot<C>(rp2[k], s);
+                t.next2[k + 1] = tail ? deint_slot_at<C>(next2, NC, yr + 2 * k - 2, slot) : deint_slot<C>(rn2[k], s);
+            }
+            out[s] = slot < slots
+                   ? yadif_temporal(t, yadif_spatial(u, d, a.spatial_bias), a.skip_spatial_check != 0)
+                   : 0.0f;
+        }
+    }
+    put(yr, 0, out, false);
+}
+
 // whether the pass is what k_deint_rows does: a whole unorm plane into a texture of its own
 // format, or of floats with the same components, every row a whole number of dwords
 static int deint_rows_variant(const plh_pass *p)
@@ -376,8 +518,10 @@ static int deint_rows_variant(const plh_pass *p)
     static int off = -1;
     if (off < 0)
         off = getenv("PL_HIP_DEINT_ROWS") && !atoi(getenv("PL_HIP_DEINT_ROWS"));
-    if (off || p->num_ops || a.algo == PLH_DEINT_YADIF || a.keep < 0 || s.fmt > PLH_FMT_RGBA16)
+    if (off || p->num_ops || a.keep < 0 || s.fmt > PLH_FMT_RGBA16)
         return 0;
+    if (a.algo == PLH_DEINT_YADIF && s.fmt > PLH_FMT_RG16)
+        return 0;   // (rgba16: a window of 13 dwords per row for half a pixel: the general kernel)
     const int nc = (s.fmt - 1) % 3 == 2 ? 4 : (s.fmt - 1) % 3 + 1;
     const bool same = d.fmt == s.fmt, f32 = d.fmt == PLH_FMT_R32F + (s.fmt - 1) % 3;
     if ((!same && !f32) || p->s.comp_mask != (1u << nc) - 1u)
@@ -404,7 +548,18 @@ extern "C" int plh_launch_deinterlace(plh_stream stream_, const struct plh_pass 
         const int nc = (pass->s.src.fmt - 1) % 3 == 2 ? 4 : (pass->s.src.fmt - 1) % 3 + 1;
         const int dwords = (pass->s.src.w * nc * (variant & 1 ? 1 : 2) + 3) / 4;
         const dim3 grid((dwords + DEINT_BW - 1) / DEINT_BW, (pairs + DEINT_BH - 1) / DEINT_BH);
-        switch (variant) {
+        if (pass->deint.algo == PLH_DEINT_YADIF) {
+#define YADIF(C, NC) do { \
+                if (variant > 2) PLH_LAUNCH_LAST((k_deint_rows_yadif<C, NC, true>), grid, block, 0, stream, *pass); \
+                else PLH_LAUNCH_LAST((k_deint_rows_yadif<C, NC, false>), grid, block, 0, stream, *pass); \
+            } while (0)
+            if (variant & 1) {
+                if (nc == 1) YADIF(uint8_t, 1); else if (nc == 2) YADIF(uint8_t, 2); else YADIF(uint8_t, 4);
+            } else {
+                if (nc == 1) YADIF(uint16_t, 1); else YADIF(uint16_t, 2);
+            }
+#undef YADIF
+        } else switch (variant) {
         case 1: PLH_LAUNCH_LAST((k_deint_rows<uint8_t, false>), grid, block, 0, stream, *pass); break;
         case 2: PLH_LAUNCH_LAST((k_deint_rows<uint16_t, false>), grid, block, 0, stream, *pass); break;
         case 3: PLH_LAUNCH_LAST((k_deint_rows<uint8_t, true>), grid, block, 0, stream, *pass); break;

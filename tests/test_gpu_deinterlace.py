@@ -285,11 +285,11 @@ F32_OF = {1: "r32f", 2: "rg32f", 4: "rgba32f"}
 
 
 @pytest.mark.parametrize("fmt", ["r8", "rg8", "rgba8", "r16", "rg16", "rgba16"])
-@pytest.mark.parametrize("size", [(70, 37), (1, 1), (5, 3), (257, 16), (3, 8)])
+@pytest.mark.parametrize("size", [(70, 37), (1, 1), (5, 3), (257, 16), (3, 8), (131, 10), (16, 6)])
 def test_whole_plane_kernel_equals_the_oracle(gpu, fmt, size, monkeypatch):
     """A whole unorm plane into a texture of its own format or of floats with the same components
     -- what the renderer asks for -- runs as k_deint_rows (a dword of a row pair per lane: bob,
-    weave, bwdif). Bit-exact against the oracle, rows that end inside a dword included, and equal
+    weave, bwdif) or k_deint_rows_yadif. Bit-exact against the oracle, rows that end inside a dword included, and equal
     to the general kernel (PL_HIP_DEINT_ROWS=0 in a second process is not needed: the general
     kernel is what every other test here runs, against the same oracle)."""
     w, h = size
@@ -303,7 +303,12 @@ def test_whole_plane_kernel_equals_the_oracle(gpu, fmt, size, monkeypatch):
                                               ("bwdif", pl.FIELD_BOTTOM, pl.FIELD_TOP, True),
                                               ("bwdif", pl.FIELD_TOP, pl.FIELD_TOP, False),    # intra
                                               ("bob", pl.FIELD_BOTTOM, pl.FIELD_TOP, True),
-                                              ("weave", pl.FIELD_TOP, pl.FIELD_TOP, True)):
+                                              ("weave", pl.FIELD_TOP, pl.FIELD_TOP, True),
+                                              # (k_deint_rows_yadif: windows of dwords to either side;
+                                              # rgba16 stays on the general kernel)
+                                              ("yadif", pl.FIELD_TOP, pl.FIELD_TOP, True),
+                                              ("yadif", pl.FIELD_BOTTOM, pl.FIELD_BOTTOM, True),
+                                              ("yadif", pl.FIELD_BOTTOM, pl.FIELD_TOP, False)):
             sh = gpu.begin()
             sh.deinterlace(tex[1], tex[0] if have_prev else None, tex[2], field=field,
                            first_field=first, algo=ALGOS[algo])
