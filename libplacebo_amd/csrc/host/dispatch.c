@@ -354,6 +354,10 @@ static int blend_factor(enum pl_blend_mode m)
 // the target pixels whose centre lies in [a, b): first and one past the last, within [0, n)
 static void covered_range(float a, float b, int n, int *first, int *end)
 {
+    if (!(b > a)) {     // empty, or not a number: covers nothing (the kernel's test says the same)
+        *first = *end = 0;
+        return;
+    }
     const float lo = ceilf(a - 0.5f), hi = ceilf(b - 0.5f);
     *first = lo <= 0.0f ? 0 : lo >= (float) n ? n : (int) lo;
     *end = hi <= 0.0f ? 0 : hi >= (float) n ? n : (int) hi;
@@ -423,11 +427,11 @@ static struct overlay_layout *overlay_layout(pl_dispatch dp, const struct plh_ov
     const size_t tiles_bytes = num_tiles * 3 * sizeof(uint32_t);
     const size_t blob_bytes = parts_bytes + tiles_bytes + total * sizeof(uint32_t);
     struct plh_overlay_part *copy = realloc(lay->parts, PL_MAX(parts_bytes, 1));
-    if (!copy || !reserve((void **) &dp->blob, &dp->blob_cap, blob_bytes)) {
-        free(copy);
-        lay->parts = NULL;
+    if (copy)
+        lay->parts = copy;  // (on failure the old block stays the entry's, to be reused or freed)
+    lay->num_parts = -1;    // the entry no longer describes what its buffer holds
+    if (!copy || !reserve((void **) &dp->blob, &dp->blob_cap, blob_bytes))
         return NULL;
-    }
     memcpy(copy, parts, parts_bytes);
     *lay = (struct overlay_layout) {
         .num_parts = n, .w = w, .h = h, .parts = copy, .buf = lay->buf,
@@ -469,8 +473,7 @@ static struct overlay_layout *overlay_layout(pl_dispatch dp, const struct plh_ov
         lay->buf = pl_buf_create(dp->gpu, pl_buf_params(
             .size = PL_MAX(blob_bytes * 2, (size_t) 16 * 1024), .storable = true));
         if (!lay->buf) {
-            free(lay->parts);
-            lay->parts = NULL;
+            lay->num_parts = -1;
             return NULL;
         }
     }
