@@ -91,3 +91,64 @@ def test_gpu_api_contract_from_c(gpu, binary):
         pytest.fail(f"tests/c/build/{binary} missing: run build()")
     r = subprocess.run([exe], capture_output=True, text=True, timeout=120)
     assert r.returncode == 0 and r.stdout.strip().endswith("ok"), r.stdout + r.stderr
+
+
+def test_round5_stages_from_c_against_both_header_sets(gpu, tmp_path):
+    """tests/c/frame_stages.c: deinterlacing (bob, bwdif with both neighbours), an overlay, a
+    distortion, a blended frame and a Dolby Vision frame through pl_render_image from plain C --
+    compiled against include/ and against the reference's own headers (pl_overlay,
+    pl_deinterlace_params, pl_distort_params, pl_blend_params, pl_dovi_metadata as libplacebo
+    declares them). Identical bytes from both binaries; the frames follow from the inputs."""
+    W, H = 64, 48
+    outs = {}
+    for which in ("ours", "ref"):
+        exe = os.path.join(BUILD, f"frame_stages_{which}")
+        if not os.path.exists(exe):
+            if which == "ref":
+                pytest.skip("frame_stages_ref not built (reference headers absent at build time)")
+            pytest.fail("tests/c/build/frame_stages_ours missing: run build()")
+        path = tmp_path / f"{which}.raw"
+        r = subprocess.run([exe, str(path)], capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stdout + r.stderr
+        outs[which] = np.fromfile(path, np.uint16).reshape(6, H, W, 4)
+    assert np.array_equal(outs["ours"], outs["ref"])
+    bob, bwdif, overlay, turned, blended, dovi = outs["ours"]
+
+    def pattern(t):
+        y, x = np.mgrid[0:H, 0:W]
+        p = np.empty((H, W, 4), np.uint16)
+        p[..., 0] = 1000 * ((x + 3 * t) % 64)
+        p[..., 1] = 1300 * (y % 48)
+        p[..., 2] = np.where(y % 2, 60000, 5000)
+        p[..., 3] = 65535
+        return p
+    frames = [pattern(t) for t in range(3)]
+    # bob: the top field's rows, each twice
+    assert np.array_equal(bob[0::2], frames[1][0::2]) and np.array_equal(bob[1::2], frames[1][0::2])
+    # bwdif: the oracle's
+    dec = [orc.tex_decode(f, "rgba16") for f in frames]
+    ref = orc.deinterlace(dec[1], dec[0], dec[2], 1, 1, orc.DEINT_BWDIF, comp_mask=0x7)
+    assert np.array_equal(bwdif, orc.tex_encode(ref, "rgba16"))
+    # (the blue channel, which is the same in all three frames, comes back as it was: no motion)
+    assert np.array_equal(bwdif[..., 2], frames[1][..., 2])
+    assert not np.array_equal(bwdif, bob)
+    # the overlay: an opaque box of the part's colour, the frame around it
+    want = frames[1].copy()
+    want[4:12, 8:24] = (65535, 32768, 16384, 65535)
+    assert np.array_equal(overlay, want)
+    # the half turn, through the renderer's rgba16hf intermediate
+    base = orc.op_quant_f16(dec[1].copy())
+    assert np.array_equal(turned, orc.tex_encode(base, "rgba16")[::-1, ::-1])
+    # the translucent frame over it
+    under = orc.tex_decode(turned, "rgba16")
+    layer = dec[1].copy()
+    layer[..., 3] = np.float32(32768) / np.float32(65535)
+    layer = orc.tex_decode(orc.tex_encode(layer, "rgba16"), "rgba16")
+    orc.blend(under, layer, None, (2, 3, 1, 3), True, True)
+    assert np.array_equal(blended, orc.tex_encode(under, "rgba16"))
+    # Dolby Vision with do-nothing metadata: the picture comes back. (The matrix in the C file is the
+    # decoder's fixed one inverted to five digits: components near black, where 1e-5 of a
+    # neighbouring channel is as much as the channel itself, move by up to a few thousand codes --
+    # 5 % of this pattern's columns; the rest by single codes.)
+    d = np.abs(dovi[..., :3].astype(np.int64) - frames[1][..., :3].astype(np.int64))
+    assert d.mean() < 150 and np.percentile(d, 90) < 200, (float(d.mean()), float(np.percentile(d, 90)))
