@@ -292,6 +292,7 @@ def test_distort_against_a_numpy_bilinear_resampling():
     rng = np.random.default_rng(8)
     sh, sw, oh, ow = 12, 20, 30, 44
     img = rng.random((sh, sw, 4)).astype(np.float32)
+    img[..., 3] = 1.0
     tf = [0.41, -0.13, 0.09, -0.37, 0.52, 0.47]        # canvas -> texture coordinates
     got = orc.distort(img, tf, ow, oh, alpha_mode=1)
     ys, xs = np.mgrid[0:oh, 0:ow]
