@@ -402,3 +402,119 @@ def test_colorspace_decision_functions_match_reference_code(libs):
             lib.pl_color_space_infer_map(C.byref(c), C.byref(d))
             res.append(bytes(a) + bytes(e) + bytes(c) + bytes(d))
         assert res[0] == res[1], it
+
+
+class _R2(C.Structure):
+    _fields_ = [(n, C.c_float) for n in ("x0", "y0", "x1", "y1")]
+
+
+class _M2(C.Structure):
+    _fields_ = [("m", (C.c_float * 2) * 2)]
+
+
+class _T2(C.Structure):
+    _fields_ = [("mat", _M2), ("c", C.c_float * 2)]
+
+
+def test_rect_and_2x2_transform_helpers(libs):
+    """common.h's rect / 2 x 2 helpers (src/common.c:245-500): what places overlays, distorted
+    images and rotated target rects. Bit for bit against the reference over random inputs,
+    degenerate ones included (singular matrices, flipped and empty rects)."""
+    ref, our = libs
+    rng = np.random.default_rng(11)
+
+    def rnd_t():
+        t = _T2()
+        vals = rng.normal(size=6) * rng.choice([0.01, 1, 50])
+        if rng.random() < 0.15:
+            vals[:4] = [vals[0], vals[1], 2 * vals[0], 2 * vals[1]]     # singular
+        if rng.random() < 0.2:
+            vals[1] = vals[2] = 0.0                                      # diagonal
+        for i in range(2):
+            for j in range(2):
+                t.mat.m[i][j] = vals[2 * i + j]
+            t.c[i] = vals[4 + i]
+        return t
+
+    def rnd_r():
+        v = rng.normal(size=4) * rng.choice([1, 100, 4000])
+        if rng.random() < 0.1:
+            v[2] = v[0]
+        return _R2(*[float(x) for x in v])
+
+    def raw(s):
+        return bytes(s)
+
+    for L in (ref, our):
+        L.pl_rect2df_aspect.restype = C.c_float
+        L.pl_transform2x2_bounds.restype = _R2
+        L.pl_transform2x2_bounds.argtypes = [C.POINTER(_T2), C.POINTER(_R2)]
+        L.pl_matrix2x2_rotation.restype = _M2
+        L.pl_matrix2x2_rotation.argtypes = [C.c_float]
+        for fn in ("pl_transform2x2_scale", "pl_matrix2x2_scale"):
+            getattr(L, fn).argtypes = [C.c_void_p, C.c_float]
+        L.pl_rect2df_stretch.argtypes = [C.POINTER(_R2), C.c_float, C.c_float]
+        L.pl_rect2df_offset.argtypes = [C.POINTER(_R2), C.c_float, C.c_float]
+        L.pl_rect2df_aspect_set.argtypes = [C.POINTER(_R2), C.c_float, C.c_float]
+        L.pl_rect2df_aspect_fit.argtypes = [C.POINTER(_R2), C.POINTER(_R2), C.c_float]
+        L.pl_rect2df_rotate.argtypes = [C.POINTER(_R2), C.c_int]
+
+    for _ in range(400):
+        a, b, r, r2 = rnd_t(), rnd_t(), rnd_r(), rnd_r()
+        k = float(rng.normal() * 3)
+        # binary operations on transforms / matrices (the first argument is written)
+        for fn in ("pl_transform2x2_mul", "pl_transform2x2_rmul"):
+            x, y = _T2.from_buffer_copy(a), _T2.from_buffer_copy(a)
+            bx, by = _T2.from_buffer_copy(b), _T2.from_buffer_copy(b)
+            getattr(ref, fn)(C.byref(x), C.byref(bx))
+            getattr(our, fn)(C.byref(y), C.byref(by))
+            assert raw(x) == raw(y) and raw(bx) == raw(by), fn
+        for fn in ("pl_matrix2x2_mul", "pl_matrix2x2_rmul"):
+            x, y = _M2.from_buffer_copy(a.mat), _M2.from_buffer_copy(a.mat)
+            bx, by = _M2.from_buffer_copy(b.mat), _M2.from_buffer_copy(b.mat)
+            getattr(ref, fn)(C.byref(x), C.byref(bx))
+            getattr(our, fn)(C.byref(y), C.byref(by))
+            assert raw(x) == raw(y) and raw(bx) == raw(by), fn
+        for fn, T, src in (("pl_transform2x2_invert", _T2, a), ("pl_matrix2x2_invert", _M2, a.mat)):
+            x, y = T.from_buffer_copy(src), T.from_buffer_copy(src)
+            getattr(ref, fn)(C.byref(x))
+            getattr(our, fn)(C.byref(y))
+            assert raw(x) == raw(y), fn
+        for fn, T, src in (("pl_transform2x2_scale", _T2, a), ("pl_matrix2x2_scale", _M2, a.mat)):
+            x, y = T.from_buffer_copy(src), T.from_buffer_copy(src)
+            getattr(ref, fn)(C.byref(x), k)
+            getattr(our, fn)(C.byref(y), k)
+            assert raw(x) == raw(y), fn
+        # applying them
+        v1, v2 = (C.c_float * 2)(r.x0, r.y0), (C.c_float * 2)(r.x0, r.y0)
+        ref.pl_transform2x2_apply(C.byref(a), v1)
+        our.pl_transform2x2_apply(C.byref(a), v2)
+        assert bytes(v1) == bytes(v2)
+        v1, v2 = (C.c_float * 2)(r.x1, r.y1), (C.c_float * 2)(r.x1, r.y1)
+        ref.pl_matrix2x2_apply(C.byref(a.mat), v1)
+        our.pl_matrix2x2_apply(C.byref(a.mat), v2)
+        assert bytes(v1) == bytes(v2)
+        for fn, arg in (("pl_transform2x2_apply_rc", a), ("pl_matrix2x2_apply_rc", a.mat)):
+            x, y = _R2.from_buffer_copy(r), _R2.from_buffer_copy(r)
+            getattr(ref, fn)(C.byref(arg), C.byref(x))
+            getattr(our, fn)(C.byref(arg), C.byref(y))
+            assert raw(x) == raw(y), fn
+        assert raw(ref.pl_transform2x2_bounds(C.byref(a), C.byref(r))) == \
+               raw(our.pl_transform2x2_bounds(C.byref(a), C.byref(r)))
+        assert raw(ref.pl_matrix2x2_rotation(k)) == raw(our.pl_matrix2x2_rotation(k))
+        # rects
+        assert bits_equal([ref.pl_rect2df_aspect(C.byref(r))], [our.pl_rect2df_aspect(C.byref(r))])
+        for fn, args in (("pl_rect2df_normalize", ()), ("pl_rect2df_stretch", (k, float(rng.normal()))),
+                         ("pl_rect2df_offset", (k, float(rng.normal() * 10))),
+                         ("pl_rect2df_aspect_set", (abs(k) + 0.1, float(rng.random()))),
+                         ("pl_rect2df_rotate", (int(rng.integers(-5, 6)),))):
+            x, y = _R2.from_buffer_copy(r), _R2.from_buffer_copy(r)
+            getattr(ref, fn)(C.byref(x), *args)
+            getattr(our, fn)(C.byref(y), *args)
+            assert raw(x) == raw(y), (fn, args, list(np.frombuffer(raw(x), np.float32)),
+                                      list(np.frombuffer(raw(y), np.float32)))
+        x, y = _R2.from_buffer_copy(r), _R2.from_buffer_copy(r)
+        p = float(rng.random())
+        ref.pl_rect2df_aspect_fit(C.byref(x), C.byref(r2), p)
+        our.pl_rect2df_aspect_fit(C.byref(y), C.byref(r2), p)
+        assert raw(x) == raw(y), "pl_rect2df_aspect_fit"
