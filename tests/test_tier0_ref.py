@@ -518,3 +518,200 @@ def test_rect_and_2x2_transform_helpers(libs):
         ref.pl_rect2df_aspect_fit(C.byref(x), C.byref(r2), p)
         our.pl_rect2df_aspect_fit(C.byref(y), C.byref(r2), p)
         assert raw(x) == raw(y), "pl_rect2df_aspect_fit"
+
+
+def test_remaining_pure_colour_helpers(libs):
+    """The Tier-0 functions nothing else in the suite names: white points, adaptation, chroma
+    siting, guesses, and the equality / merge / containment predicates of the colour structs
+    (src/colorspace.c). Bit for bit / value for value against the reference build."""
+    ref, our = libs
+    rng = np.random.default_rng(21)
+    for L in (ref, our):
+        for fn in ("pl_white_from_temp", "pl_daylight_from_temp", "pl_blackbody_from_temp"):
+            getattr(L, fn).restype = XY
+            getattr(L, fn).argtypes = [C.c_float]
+        L.pl_get_adaptation_matrix.restype = M3
+        L.pl_get_adaptation_matrix.argtypes = [XY, XY]
+        L.pl_color_transfer_nominal_peak.restype = C.c_float
+        L.pl_color_system_name.restype = C.c_char_p
+        L.pl_color_primaries_name.restype = C.c_char_p
+        for fn in ("pl_color_space_is_hdr", "pl_primaries_valid",
+                   "pl_raw_primaries_equal", "pl_raw_primaries_similar", "pl_primaries_superset",
+                   "pl_hdr_metadata_equal", "pl_color_space_equal", "pl_color_repr_equal",
+                   "pl_bit_encoding_equal"):
+            getattr(L, fn).restype = C.c_bool
+        L.pl_hdr_metadata_contains.restype = C.c_bool
+        L.pl_hdr_metadata_contains.argtypes = [C.POINTER(Hdr), C.c_int]
+
+    for t in list(np.linspace(1500, 25000, 60)) + [6500.0, 6504.0, 4000.0, 7000.0, 1000.0, 30000.0]:
+        for fn in ("pl_white_from_temp", "pl_daylight_from_temp", "pl_blackbody_from_temp"):
+            a, b = getattr(ref, fn)(float(t)), getattr(our, fn)(float(t))
+            assert bits_equal([a.x, a.y], [b.x, b.y]), (fn, t)
+    for _ in range(100):
+        s = XY(float(0.2 + 0.3 * rng.random()), float(0.2 + 0.3 * rng.random()))
+        d = XY(float(0.2 + 0.3 * rng.random()), float(0.2 + 0.3 * rng.random()))
+        assert bits_equal(m3(ref.pl_get_adaptation_matrix(s, d)), m3(our.pl_get_adaptation_matrix(s, d)))
+    assert bits_equal(m3(ref.pl_get_adaptation_matrix(XY(0.3127, 0.329), XY(0.3127, 0.329))),
+                      m3(our.pl_get_adaptation_matrix(XY(0.3127, 0.329), XY(0.3127, 0.329))))
+    for loc in range(8):
+        a, b = (C.c_float * 2)(7, 7), (C.c_float * 2)(7, 7)
+        ref.pl_chroma_location_offset(loc, C.byref(a, 0), C.byref(a, 4))
+        our.pl_chroma_location_offset(loc, C.byref(b, 0), C.byref(b, 4))
+        assert bytes(a) == bytes(b), loc
+    for w, h in ((640, 480), (720, 576), (1280, 720), (1920, 1080), (1920, 1088), (3840, 2160),
+                 (1024, 576), (1281, 576), (1280, 577), (352, 288), (7680, 4320), (1, 1)):
+        assert ref.pl_color_system_guess_ycbcr(w, h) == our.pl_color_system_guess_ycbcr(w, h), (w, h)
+    for trc in range(18):
+        assert bits_equal([ref.pl_color_transfer_nominal_peak(trc)], [our.pl_color_transfer_nominal_peak(trc)])
+    for i in range(14):
+        assert ref.pl_color_system_name(i) == our.pl_color_system_name(i)
+    for i in range(17):
+        assert ref.pl_color_primaries_name(i) == our.pl_color_primaries_name(i)
+
+    def rnd_prim(kind):
+        p = Prim()
+        if kind == 0:
+            return p                                            # unset
+        base = ref.pl_raw_primaries_get(int(rng.integers(1, 17))).contents
+        C.memmove(C.byref(p), C.byref(base), C.sizeof(p))
+        if kind == 2:                                           # nudged
+            p.red.x += float(rng.normal() * 1e-3)
+            p.white.y += float(rng.normal() * 1e-4)
+        if kind == 3:                                           # partly unset
+            p.green = XY(0, 0)
+        return p
+
+    def rnd_hdr():
+        h = Hdr()
+        h.prim = rnd_prim(int(rng.integers(0, 4)))
+        for f in ("min_luma", "max_luma", "max_cll", "max_fall", "scene_avg", "max_pq_y", "avg_pq_y"):
+            if rng.random() < 0.5:
+                setattr(h, f, float(rng.random() * (1000 if "luma" in f or "c" in f else 1)))
+        if rng.random() < 0.4:
+            for k in range(3):
+                h.scene_max[k] = float(rng.random() * 800)
+        if rng.random() < 0.3:
+            h.ootf.num_anchors = int(rng.integers(0, 15))
+            h.ootf.target_luma = float(rng.random() * 500)
+        return h
+
+    def rnd_csp():
+        c = Csp(primaries=int(rng.integers(0, 17)), transfer=int(rng.integers(0, 18)))
+        c.hdr = rnd_hdr()
+        return c
+
+    def rnd_repr():
+        return Repr(sys=int(rng.integers(0, 14)), levels=int(rng.integers(0, 3)),
+                    alpha=int(rng.integers(0, 4)),
+                    bits=Bits(*[int(v) for v in rng.choice([0, 8, 10, 16], 2)], int(rng.integers(0, 3))))
+
+    for _ in range(300):
+        p1, p2 = rnd_prim(int(rng.integers(0, 4))), rnd_prim(int(rng.integers(0, 4)))
+        if rng.random() < 0.3:
+            C.memmove(C.byref(p2), C.byref(p1), C.sizeof(p1))
+        for fn in ("pl_raw_primaries_equal", "pl_raw_primaries_similar", "pl_primaries_superset"):
+            assert getattr(ref, fn)(C.byref(p1), C.byref(p2)) == getattr(our, fn)(C.byref(p1), C.byref(p2)), fn
+        assert ref.pl_primaries_valid(C.byref(p1)) == our.pl_primaries_valid(C.byref(p1))
+        a, b = Prim.from_buffer_copy(p1), Prim.from_buffer_copy(p1)
+        ref.pl_raw_primaries_merge(C.byref(a), C.byref(p2))
+        our.pl_raw_primaries_merge(C.byref(b), C.byref(p2))
+        assert bytes(a) == bytes(b)
+
+        h1, h2 = rnd_hdr(), rnd_hdr()
+        if rng.random() < 0.3:
+            C.memmove(C.byref(h2), C.byref(h1), C.sizeof(h1))
+        assert ref.pl_hdr_metadata_equal(C.byref(h1), C.byref(h2)) == our.pl_hdr_metadata_equal(C.byref(h1), C.byref(h2))
+        for kind in range(5):
+            assert ref.pl_hdr_metadata_contains(C.byref(h1), kind) == our.pl_hdr_metadata_contains(C.byref(h1), kind), kind
+        a, b = Hdr.from_buffer_copy(h1), Hdr.from_buffer_copy(h1)
+        ref.pl_hdr_metadata_merge(C.byref(a), C.byref(h2))
+        our.pl_hdr_metadata_merge(C.byref(b), C.byref(h2))
+        assert bytes(a) == bytes(b)
+
+        c1, c2 = rnd_csp(), rnd_csp()
+        if rng.random() < 0.3:
+            C.memmove(C.byref(c2), C.byref(c1), C.sizeof(c1))
+        assert ref.pl_color_space_equal(C.byref(c1), C.byref(c2)) == our.pl_color_space_equal(C.byref(c1), C.byref(c2))
+        assert ref.pl_color_space_is_hdr(C.byref(c1)) == our.pl_color_space_is_hdr(C.byref(c1))
+        a, b = Csp.from_buffer_copy(c1), Csp.from_buffer_copy(c1)
+        ref.pl_color_space_merge(C.byref(a), C.byref(c2))
+        our.pl_color_space_merge(C.byref(b), C.byref(c2))
+        assert bytes(a) == bytes(b)
+
+        r1, r2 = rnd_repr(), rnd_repr()
+        if rng.random() < 0.3:
+            C.memmove(C.byref(r2), C.byref(r1), C.sizeof(r1))
+        assert ref.pl_color_repr_equal(C.byref(r1), C.byref(r2)) == our.pl_color_repr_equal(C.byref(r1), C.byref(r2))
+        assert ref.pl_bit_encoding_equal(C.byref(r1.bits), C.byref(r2.bits)) == \
+               our.pl_bit_encoding_equal(C.byref(r1.bits), C.byref(r2.bits))
+        a, b = Repr.from_buffer_copy(r1), Repr.from_buffer_copy(r1)
+        ref.pl_color_repr_merge(C.byref(a), C.byref(r2))
+        our.pl_color_repr_merge(C.byref(b), C.byref(r2))
+        assert bytes(a) == bytes(b)
+
+
+def test_constant_tables_and_3x3_helpers(libs):
+    """the exported constants (colour-space / representation presets, metadata presets, identity and
+    IPT matrices) byte for byte, and the 3 x 3 matrix helpers on random and singular inputs"""
+    ref, our = libs
+    consts = {
+        Hdr: ["pl_hdr_metadata_empty", "pl_hdr_metadata_hdr10"],
+        Csp: ["pl_color_space_unknown", "pl_color_space_bt709", "pl_color_space_bt2020_hlg",
+              "pl_color_space_monitor", "pl_color_space_srgb", "pl_color_space_hdr10"],
+        Repr: ["pl_color_repr_unknown", "pl_color_repr_rgb", "pl_color_repr_sdtv", "pl_color_repr_hdtv",
+               "pl_color_repr_uhdtv", "pl_color_repr_jpeg"],
+        Adj: ["pl_color_adjustment_neutral"],
+        M3: ["pl_ipt_lms2ipt", "pl_ipt_ipt2lms", "pl_matrix3x3_identity"],
+        T3: ["pl_transform3x3_identity"],
+        _M2: ["pl_matrix2x2_identity"],
+        _T2: ["pl_transform2x2_identity"],
+    }
+    for T, names in consts.items():
+        for name in names:
+            assert bytes(T.in_dll(ref, name)) == bytes(T.in_dll(our, name)), name
+
+    rng = np.random.default_rng(31)
+    for L in (ref, our):
+        L.pl_matrix3x3_scale.argtypes = [C.POINTER(M3), C.c_float]
+        L.pl_transform3x3_scale.argtypes = [C.POINTER(T3), C.c_float]
+    for trial in range(300):
+        a, b = M3(), M3()
+        va, vb = rng.normal(size=9) * rng.choice([0.01, 1, 30]), rng.normal(size=9)
+        if trial % 7 == 0:
+            va[6:9] = va[0:3] + va[3:6]         # singular
+        for i in range(3):
+            for j in range(3):
+                a.m[i][j], b.m[i][j] = float(va[3 * i + j]), float(vb[3 * i + j])
+        k = float(rng.normal() * 4)
+        for fn, extra in (("pl_matrix3x3_invert", ()), ("pl_matrix3x3_scale", (k,))):
+            x, y = M3.from_buffer_copy(a), M3.from_buffer_copy(a)
+            getattr(ref, fn)(C.byref(x), *extra)
+            getattr(our, fn)(C.byref(y), *extra)
+            assert bytes(x) == bytes(y), fn
+        for fn in ("pl_matrix3x3_mul", "pl_matrix3x3_rmul"):
+            x, y = M3.from_buffer_copy(a), M3.from_buffer_copy(a)
+            bx, by = M3.from_buffer_copy(b), M3.from_buffer_copy(b)
+            getattr(ref, fn)(C.byref(x), C.byref(bx))
+            getattr(our, fn)(C.byref(y), C.byref(by))
+            assert bytes(x) == bytes(y) and bytes(bx) == bytes(by), fn
+        t = T3(mat=a)
+        for i in range(3):
+            t.c[i] = float(rng.normal())
+        for fn, extra in (("pl_transform3x3_scale", (k,)), ("pl_transform3x3_invert", ())):
+            x, y = T3.from_buffer_copy(t), T3.from_buffer_copy(t)
+            getattr(ref, fn)(C.byref(x), *extra)
+            getattr(our, fn)(C.byref(y), *extra)
+            assert bytes(x) == bytes(y), fn
+        v1 = (C.c_float * 3)(*[float(v) for v in vb[:3]])
+        v2 = (C.c_float * 3)(*[float(v) for v in vb[:3]])
+        ref.pl_transform3x3_apply(C.byref(t), v1)
+        our.pl_transform3x3_apply(C.byref(t), v2)
+        assert bytes(v1) == bytes(v2)
+        r1 = (C.c_float * 6)(*[float(v) for v in vb[:6]])
+        r2 = (C.c_float * 6)(*[float(v) for v in vb[:6]])
+        ref.pl_matrix3x3_apply_rc(C.byref(a), r1)
+        our.pl_matrix3x3_apply_rc(C.byref(a), r2)
+        assert bytes(r1) == bytes(r2)
+        ref.pl_transform3x3_apply_rc(C.byref(t), r1)
+        our.pl_transform3x3_apply_rc(C.byref(t), r2)
+        assert bytes(r1) == bytes(r2)
