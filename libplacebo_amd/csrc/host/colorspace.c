@@ -1318,5 +1318,7 @@ bool pl_icc_profile_equal(const struct pl_icc_profile *a, const struct pl_icc_pr
 
 void pl_icc_profile_compute_signature(struct pl_icc_profile *profile)
 {
-    profile->signature = profile->len ? plh_mem_hash(profile->data, profile->len) : 0;
+    // (an empty profile gets the hash of nothing, not 0: src/colorspace.c:1910-1916 assigns 0 and
+    // then goes on to overwrite it)
+    profile->signature = plh_mem_hash(profile->data, profile->len);
 }

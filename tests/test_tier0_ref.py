@@ -715,3 +715,150 @@ def test_constant_tables_and_3x3_helpers(libs):
         ref.pl_transform3x3_apply_rc(C.byref(t), r1)
         our.pl_transform3x3_apply_rc(C.byref(t), r2)
         assert bytes(r1) == bytes(r2)
+
+
+def test_every_filter_function_weight_and_the_eq_predicates(libs):
+    """pl_filter_functions[]: every weighting function's own `weight` callback (not only the ones
+    a filter config happens to use), over its support and with its tunable parameters moved;
+    pl_find_filter_function, pl_filter_function_eq, pl_filter_config_eq."""
+    ref, our = libs
+
+    class Ctx(C.Structure):
+        _fields_ = [("radius", C.c_float), ("params", C.c_float * 2)]
+    WEIGHT = C.CFUNCTYPE(C.c_double, C.POINTER(Ctx), C.c_double)
+    n = C.c_int.in_dll(ref, "pl_num_filter_functions").value
+    assert n == C.c_int.in_dll(our, "pl_num_filter_functions").value
+    RA = (C.POINTER(capi.FilterFunction) * (n + 1)).in_dll(ref, "pl_filter_functions")
+    OA = (C.POINTER(capi.FilterFunction) * (n + 1)).in_dll(our, "pl_filter_functions")
+    for L in libs:
+        L.pl_find_filter_function.restype = C.POINTER(capi.FilterFunction)
+        L.pl_find_filter_function.argtypes = [C.c_char_p]
+        L.pl_filter_function_eq.restype = C.c_bool
+        L.pl_filter_config_eq.restype = C.c_bool
+    rng = np.random.default_rng(3)
+    checked = 0
+    for i in range(n):
+        rf, of = RA[i].contents, OA[i].contents
+        assert (rf.name, rf.radius, rf.resizable, list(rf.tunable), list(rf.params), rf.opaque) == \
+               (of.name, of.radius, of.resizable, list(of.tunable), list(of.params), of.opaque), rf.name
+        assert our.pl_find_filter_function(rf.name).contents.name == rf.name
+        assert bool(rf.weight) == bool(of.weight)
+        if not rf.weight:
+            continue
+        wr, wo = WEIGHT(rf.weight), WEIGHT(of.weight)
+        variants = [tuple(rf.params)]
+        for _ in range(4):
+            variants.append(tuple(p + float(rng.normal() * 0.2) if t else p
+                                  for p, t in zip(rf.params, rf.tunable)))
+        for params in variants:
+            for radius in (rf.radius, rf.radius * 1.5 if rf.resizable else rf.radius):
+                ctx = Ctx(radius, (C.c_float * 2)(*params))
+                for x in list(np.linspace(0.0, radius, 41)) + [1e-9, radius * 0.999999, radius + 0.5]:
+                    a, b = wr(C.byref(ctx), float(x)), wo(C.byref(ctx), float(x))
+                    assert a == b or (np.isnan(a) and np.isnan(b)), (rf.name, params, radius, x, a, b)
+                    checked += 1
+    assert checked > 5000 and not RA[n] and not OA[n]
+    assert not our.pl_find_filter_function(b"nope") and not our.pl_find_filter_function(None)
+
+    # equality predicates over pairs of table entries and tweaked copies
+    for i in range(0, n, 3):
+        for j in range(0, n, 4):
+            assert ref.pl_filter_function_eq(RA[i], RA[j]) == our.pl_filter_function_eq(OA[i], OA[j])
+        a = capi.FilterFunction.from_buffer_copy(OA[i].contents)
+        a.params[0] += 0.125
+        r = capi.FilterFunction.from_buffer_copy(RA[i].contents)
+        r.params[0] += 0.125
+        assert ref.pl_filter_function_eq(C.byref(r), RA[i]) == our.pl_filter_function_eq(C.byref(a), OA[i])
+    nc = C.c_int.in_dll(ref, "pl_num_filter_configs").value
+    RC = (C.POINTER(capi.FilterConfig) * (nc + 1)).in_dll(ref, "pl_filter_configs")
+    OC = (C.POINTER(capi.FilterConfig) * (nc + 1)).in_dll(our, "pl_filter_configs")
+    for i in range(0, nc, 2):
+        for j in range(0, nc, 3):
+            assert ref.pl_filter_config_eq(RC[i], RC[j]) == our.pl_filter_config_eq(OC[i], OC[j]), (i, j)
+        r = capi.FilterConfig.from_buffer_copy(RC[i].contents)
+        o = capi.FilterConfig.from_buffer_copy(OC[i].contents)
+        r.blur, o.blur = 0.9, 0.9
+        assert ref.pl_filter_config_eq(C.byref(r), RC[i]) == our.pl_filter_config_eq(C.byref(o), OC[i])
+
+
+def test_error_diffusion_kernels_params_predicates_and_icc_signatures(libs):
+    """the error-diffusion kernel table (dither.h), pl_gamut_map_sample, the *_params_equal
+    predicates and the ICC profile signature (a hash the frame queue and the renderer key on)"""
+    ref, our = libs
+
+    class EDK(C.Structure):
+        _fields_ = [("name", C.c_char_p), ("description", C.c_char_p), ("shift", C.c_int),
+                    ("pattern", (C.c_int * 5) * 3), ("divisor", C.c_int)]
+    n = C.c_int.in_dll(ref, "pl_num_error_diffusion_kernels").value
+    assert n == C.c_int.in_dll(our, "pl_num_error_diffusion_kernels").value
+    RA = (C.POINTER(EDK) * (n + 1)).in_dll(ref, "pl_error_diffusion_kernels")
+    OA = (C.POINTER(EDK) * (n + 1)).in_dll(our, "pl_error_diffusion_kernels")
+    for i in range(n):
+        r, o = RA[i].contents, OA[i].contents
+        assert (r.name, r.description, r.shift, r.divisor) == (o.name, o.description, o.shift, o.divisor)
+        assert [list(row) for row in r.pattern] == [list(row) for row in o.pattern], r.name
+        sym = {"sierra-2": "sierra2", "sierra-3": "sierra3", "sierra-lite": "sierra_lite",
+               "floyd-steinberg": "floyd_steinberg", "jarvis-judice-ninke": "jarvis_judice_ninke",
+               "false-fs": "false_fs"}.get(r.name.decode(), r.name.decode())
+        assert bytes(EDK.in_dll(our, "pl_error_diffusion_" + sym))[16:] == bytes(o)[16:], sym   # the named object is the entry
+    assert not RA[n] and not OA[n]
+
+    for L in libs:
+        L.pl_gamut_map_params_equal.restype = C.c_bool
+        L.pl_tone_map_params_equal.restype = C.c_bool
+        L.pl_icc_profile_equal.restype = C.c_bool
+    rng = np.random.default_rng(17)
+
+    def gparams(L, name, tweak):
+        p = GMP(function=L.pl_find_gamut_map_function(name), min_luma=0.001, max_luma=1000.0,
+                constants=GMC(*GMC_DEFAULT), lut_size_I=8, lut_size_C=8, lut_size_h=8, lut_stride=3)
+        p.input_gamut = ref.pl_raw_primaries_get(9).contents
+        p.output_gamut = ref.pl_raw_primaries_get(3).contents
+        if tweak == 1:
+            p.max_luma = 400.0
+        if tweak == 2:
+            p.constants.softclip_knee = 0.5
+        if tweak == 3:
+            p.lut_size_h = 16          # LUT geometry is not part of the identity of a mapping
+        return p
+
+    for name in GAMUT_NAMES:
+        for ta in range(4):
+            for tb in range(4):
+                assert ref.pl_gamut_map_params_equal(C.byref(gparams(ref, name, ta)), C.byref(gparams(ref, name, tb))) == \
+                       our.pl_gamut_map_params_equal(C.byref(gparams(our, name, ta)), C.byref(gparams(our, name, tb))), (name, ta, tb)
+        # per-colour evaluation (what the 3DLUT is built from), IPT in PQ space
+        for _ in range(25):
+            v = [float(rng.random()), float(rng.normal() * 0.15), float(rng.normal() * 0.15)]
+            a, b = (C.c_float * 3)(*v), (C.c_float * 3)(*v)
+            ref.pl_gamut_map_sample(a, C.byref(gparams(ref, name, 0)))
+            our.pl_gamut_map_sample(b, C.byref(gparams(our, name, 0)))
+            assert bits_equal(list(a), list(b)), (name, v, list(a), list(b))
+
+    def tparams(L, name, tweak):
+        p = TMP(function=L.pl_find_tone_map_function(name), constants=TMC(*TMC_DEFAULT),
+                input_scaling=HDR_PQ, output_scaling=HDR_PQ, lut_size=64,
+                input_min=0.0, input_max=0.75, output_min=0.0, output_max=0.58)
+        if tweak == 1:
+            p.input_max = 0.9
+        if tweak == 2:
+            p.constants.knee_default = 0.3
+        if tweak == 3:
+            p.lut_size = 128
+        return p
+    for name in TONE_NAMES:
+        for ta in range(4):
+            for tb in range(4):
+                assert ref.pl_tone_map_params_equal(C.byref(tparams(ref, name, ta)), C.byref(tparams(ref, name, tb))) == \
+                       our.pl_tone_map_params_equal(C.byref(tparams(our, name, ta)), C.byref(tparams(our, name, tb))), (name, ta, tb)
+
+    for size in (0, 1, 7, 128, 4096, 100001):
+        blob = rng.integers(0, 256, size, dtype=np.uint8).tobytes()
+        buf = C.create_string_buffer(blob, max(size, 1))
+        pr = capi.IccProfile(C.cast(buf, C.c_void_p), size, 0)
+        po = capi.IccProfile(C.cast(buf, C.c_void_p), size, 0)
+        ref.pl_icc_profile_compute_signature(C.byref(pr))
+        our.pl_icc_profile_compute_signature(C.byref(po))
+        assert pr.signature == po.signature, size
+        other = capi.IccProfile(C.cast(buf, C.c_void_p), size, pr.signature ^ (size != 0))
+        assert ref.pl_icc_profile_equal(C.byref(pr), C.byref(other)) == our.pl_icc_profile_equal(C.byref(po), C.byref(other))
