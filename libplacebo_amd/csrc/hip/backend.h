@@ -31,6 +31,7 @@ int plh_dev_count(void);
 const char *plh_strerror(int err);
 int plh_dev_open(int device, struct plh_dev_info *info);
 int plh_stream_create(int device, plh_stream *out);
+int plh_stream_create_masked(int device, int ncus, plh_stream *out);
 // the device that owns `s` (not the calling thread's current one) and, optionally, its CU count
 int plh_stream_device(plh_stream s, int *cus);
 // raise a kernel's dynamic-LDS limit on the stream's device, once per (kernel, device); `done` =
@@ -72,6 +73,7 @@ int plh_event_elapsed_ns(plh_event a, plh_event b, uint64_t *ns);
 
 // fills the whole texture with a constant colour (pl_tex_clear_ex)
 int plh_launch_clear(plh_stream s, const struct plh_view *dst, const float color[4]);
+int plh_launch_swap_words(plh_stream s, const void *src, void *dst, size_t words, int wordsize);
 // fills the whole texture with two-colour tiles (pl_frame_clear_tiles): texel (x, y) takes c0 where
 // fract((x + 1/2) * kx) < 1/2 and fract((y + 1/2) * ky) < 1/2 agree, c1 where they differ
 int plh_launch_clear_tiles(plh_stream s, const struct plh_view *dst, const float c0[4],

@@ -116,6 +116,30 @@ int plh_stream_create(int device, plh_stream *out)
     return 0;
 }
 
+// A stream whose kernels may only run on `ncus` of the device's compute units (0 or >= all of
+// them: an ordinary stream). The driver deals the bits of a CU mask out to the XCDs in turn -- bit
+// k is a CU of XCD k % 8 -- so the low `ncus` bits are ncus / 8 CUs on every XCD: the measuring
+// pass keeps every L2 and every memory channel, but its waves interleave with the scaler's on that
+// many CUs only instead of on all 256.
+int plh_stream_create_masked(int device, int ncus, plh_stream *out)
+{
+    CHK(hipSetDevice(device));
+    hipDeviceProp_t prop;
+    CHK(hipGetDeviceProperties(&prop, device));
+    if (ncus <= 0 || ncus >= prop.multiProcessorCount)
+        return plh_stream_create(device, out);
+    uint32_t mask[32] = {0};
+    const int words = (prop.multiProcessorCount + 31) / 32;
+    if (words > 32)
+        return plh_stream_create(device, out);
+    for (int k = 0; k < ncus; k++)
+        mask[k / 32] |= 1u << (k % 32);
+    hipStream_t s;
+    CHK(hipExtStreamCreateWithCUMask(&s, (uint32_t) words, mask));
+    *out = (plh_stream) s;
+    return 0;
+}
+
 void plh_stream_destroy(plh_stream s)
 {
     if (s)
@@ -304,6 +328,30 @@ extern "C" int plh_launch_clear(plh_stream s, const struct plh_view *dst, const 
     const dim3 block(64, 4), grid((dst->w + 63) / 64, (dst->h + 3) / 4);
     float4_t c = { color[0], color[1], color[2], color[3] };
     hipLaunchKernelGGL(k_clear, grid, block, 0, (hipStream_t) s, *dst, c);
+    const hipError_t err = hipGetLastError();
+    return err == hipSuccess ? 0 : -(int) err;
+}
+
+// pl_buf_copy_swap (reference src/gpu/utils.c:1065-1138: a GLSL compute pass through the GPU's own
+// dispatch, one invocation per 32-bit word): the bytes of every 16-bit half (wordsize 2) or of the
+// whole word (wordsize 4) reversed; src == dst (same offset) is an in-place swap.
+__global__ void k_swap_words(const uint32_t *src, uint32_t *dst, size_t words, int wordsize)
+{
+    const size_t i = (size_t) blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= words)
+        return;
+    const uint32_t v = src[i];
+    dst[i] = wordsize == 2 ? ((v & 0x00ff00ffu) << 8) | ((v & 0xff00ff00u) >> 8)
+                           : __builtin_bswap32(v);
+}
+
+extern "C" int plh_launch_swap_words(plh_stream s, const void *src, void *dst, size_t words, int wordsize)
+{
+    if (!words)
+        return 0;
+    const size_t groups = (words + 255) / 256;
+    hipLaunchKernelGGL(k_swap_words, dim3((unsigned) groups), dim3(256), 0, (hipStream_t) s,
+                       (const uint32_t *) src, (uint32_t *) dst, words, wordsize);
     const hipError_t err = hipGetLastError();
     return err == hipSuccess ? 0 : -(int) err;
 }

@@ -100,7 +100,14 @@ struct plh_polar_pp {
 // and d B / d fcoord_y, scaled by 2^-PLH_MX_DSHIFT, against dfx[] / dfy[] scaled by 2^+PLH_MX_DSHIFT.
 // One v_mfma_f32_16x16x32_f16 covers two source rows x 16 source columns.
 // The host builds B once per (filter, geometry) in fragment order: frag f, lane l, element e,
-// f = 4 * (py ? 4 + j : j) + {hi, lo, d/dx, d/dy} for row pair j (py = 0: 4 pairs, py = 1: 5).
+// f = 4 * (py * npairs + j) + {hi, lo, d/dx, d/dy} for row pair j of row phase py. A row phase
+// only contracts the tap rows that carry a weight at all: the footprint of the reference's tap
+// list is 8 rows (taps -3 .. 4, sampling.c:510-515), but at the phases of a centred 2x upscale
+// (fcoord 1/4 and 3/4) rows -3 and 4 lie 3.25 and 3.75 texels away, beyond every radius <= 3.25
+// (ewa_lanczos: 3.2383) -- six rows = THREE row pairs per phase, each phase starting at its own
+// tile row (row_first[py], for the output row pair m = 0), where the shared pairing of round 3
+// (py = 0: pairs 0..3, py = 1: pairs 0..4, nine in all) spent a third of its MFMAs on rows of
+// zeros. npairs = 3, or 4 for phases / radii with seven or eight live rows.
 // An exact 2 : 1 DOWNSCALE (enabled == 2, k_polar_mxd.hip) has ONE phase per axis, fcoord = 1/2, and
 // a 14 x 14 footprint that moves two texels per output: out[m][n] = sum_j sum_k S[2 m + j][k] *
 // T_j[k - 2 n], K = 44 source columns = two 32-column blocks per source row j. The weights at
@@ -108,7 +115,7 @@ struct plh_polar_pp {
 // j < 7 are stored: frag f = 4 * (2 * j + kb) + {hi, lo, d/dx, d/dy}.
 #define PLH_MXD_NFRAG 56
 #define PLH_MXD_TAPS 14     // taps per axis, offsets -6 .. 7
-#define PLH_MX_NFRAG 36
+#define PLH_MX_NFRAG 32     // 2 row phases x (at most) 4 row pairs x {hi, lo, d/dx, d/dy}
 #define PLH_MX_DSHIFT 11
 #define PLH_MX_PAD 128      // dfx / dfy are padded to a multiple of this many outputs (the widest tile)
 // An exact INTEGER upscale by R = 3 or 4 (enabled == 3, k_polar_mxr.hip) has R phases per axis;
@@ -129,7 +136,10 @@ struct plh_polar_mx {
     int32_t ratio, sx, sy;  // enabled == 3
     int32_t group, pad_;    // enabled == 3: source texels per base index (1, or 2 for 3 : 2)
     int32_t org_x, org_y;   // source texel held by LDS tile (0, 0) of workgroup tile (0, 0)
-    const void *bfrag;      // device: [PLH_MX_NFRAG][64 lanes][8] f16
+    int32_t npairs;         // enabled == 1: row pairs per row phase (3 or 4)
+    int32_t row_first[2];   // enabled == 1: tile row of the first pair's first row, output row pair 0
+    int32_t pad2_;
+    const void *bfrag;      // device: [<= PLH_MX_NFRAG][64 lanes][8] f16
     const float *dfx, *dfy; // device: phase deviation of every output column / row, x 2^PLH_MX_DSHIFT
 };
 
@@ -200,7 +210,8 @@ enum plh_op_kind {
     PLH_OP_QUANT_F16,       // round through IEEE half (an rgba16hf FBO store+load)
     PLH_OP_QUANT_UNORM,     // round through unorm of i0 bits (unorm FBO)
     PLH_OP_DITHER,          // ptr = size×size float matrix; i0 = size; i1 = method;
-                            // f[0] = 2^depth-1; f[1] = gamma; i2 = depth; f[4..7] = temporal mat2
+                            // f[0] = 2^depth-1; f[1] = gamma; i2 = depth; f[4..7] = temporal mat2;
+                            // ptr2 = the matrix transposed, or NULL (a white-noise plane has none)
     PLH_OP_SWIZZLE,         // i0..i3 packed: output component c takes input comp map[c] (or -1 → 0/1)
     PLH_OP_CLAMP01,         // color = clamp(color, 0, 1)
     PLH_OP_BT2020C_DEC,     // BT.2020 constant luminance (colorspace.c:312-342)
@@ -286,6 +297,7 @@ struct plh_fast_epi {
     int32_t has_dither, has_scale;
     int32_t size, mask;         // dither matrix size (power of two) and size - 1
     const float *matrix;
+    const float *matrix_t;      // the matrix transposed (column-owning kernels: k_polar_mx), or NULL
     float dscale, dinv;         // 2^depth - 1 and its reciprocal
     float scale;                // color *= scale
     int32_t has_alpha;          // color.a = alpha before the dither (identity PLANE_MAP of rgb)

@@ -273,6 +273,7 @@ static bool realize_white_noise(pl_gpu gpu, plh_stream stream, pl_buf *noise, st
         op->i2 = 0;     // not rotated
         op->f[2] = 1.0f / side;
         op->ptr = pl_hip_buf_ptr(*noise);
+        op->ptr2 = NULL;    // (no transposed copy of a noise plane)
     }
     return true;
 }
@@ -711,6 +712,7 @@ bool pl_dispatch_compute(pl_dispatch dp, const struct pl_dispatch_compute_params
     if (sh->kind == PLH_SHADER_ERROR_DIFFUSION) {
         if (timer)
             plh_timer_begin(dp->gpu, timer, 0);
+        plh_gpu_stamp(dp->gpu, 0);   // (numbered although no texture records it: gpu_hip.c, fence_here)
         err = plh_launch_errdiff(plh_gpu_stream(dp->gpu), sh->errdiff);
         if (timer)
             plh_timer_end(dp->gpu, timer, 0);
@@ -738,6 +740,7 @@ bool pl_dispatch_compute(pl_dispatch dp, const struct pl_dispatch_compute_params
             goto done;
         if (timer)
             plh_timer_begin(dp->gpu, timer, 0);
+        plh_gpu_stamp(dp->gpu, 0);   // (as above)
         err = plh_launch_pass(plh_gpu_stream(dp->gpu), pass);
         if (timer)
             plh_timer_end(dp->gpu, timer, 0);

@@ -585,6 +585,33 @@ void pl_buf_copy(pl_gpu gpu, pl_buf dst, size_t dst_offset, pl_buf src, size_t s
     GPU_FNS(gpu)->buf_copy(gpu, dst, dst_offset, src, src_offset, size);
 }
 
+// (reference: src/gpu/utils.c:1065-1076, the same requirements)
+bool pl_buf_copy_swap(pl_gpu gpu, const struct pl_buf_copy_swap_params *params)
+{
+    pl_buf src = params->src, dst = params->dst;
+    if (!src || !dst || !src->params.storable || !dst->params.storable) {
+        pl_msg(gpu->log, PL_LOG_ERR, "pl_buf_copy_swap: both buffers must be storable");
+        return false;
+    }
+    if (params->src_offset % 4 || params->dst_offset % 4 || params->size % 4) {
+        pl_msg(gpu->log, PL_LOG_ERR, "pl_buf_copy_swap: offsets and size must be multiples of 4");
+        return false;
+    }
+    if (params->wordsize != 2 && params->wordsize != 4) {
+        pl_msg(gpu->log, PL_LOG_ERR, "pl_buf_copy_swap: word size %d is neither 2 nor 4", params->wordsize);
+        return false;
+    }
+    if (src == dst && params->src_offset != params->dst_offset) {
+        pl_msg(gpu->log, PL_LOG_ERR, "pl_buf_copy_swap: an in-place swap needs equal offsets");
+        return false;
+    }
+    if (!buf_range_ok(gpu, "pl_buf_copy_swap (src)", src, params->src_offset, params->size) ||
+        !buf_range_ok(gpu, "pl_buf_copy_swap (dst)", dst, params->dst_offset, params->size))
+        return false;
+    return GPU_FNS(gpu)->buf_copy_swap(gpu, dst, params->dst_offset, src, params->src_offset,
+                                       params->size, params->wordsize);
+}
+
 bool pl_buf_export(pl_gpu gpu, pl_buf buf)
 {
     return GPU_FNS(gpu)->buf_export(gpu, buf);

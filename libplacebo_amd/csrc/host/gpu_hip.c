@@ -132,6 +132,9 @@ pl_hip pl_hip_create(pl_log log, const struct pl_hip_params *params)
     const char *async_env = getenv("PL_HIP_ASYNC_MEASURE");
     if (async_env)
         p->async_measure = atoi(async_env) && !params->stream;
+    // PL_HIP_MEASURE_CUS=n: the second stream is created with a CU mask of n units (n / 8 per XCD)
+    const char *cus_env = getenv("PL_HIP_MEASURE_CUS");
+    p->measure_cus = cus_env ? atoi(cus_env) : PLH_MEASURE_CUS_DEFAULT;
     struct pl_gpu_t *gpu = &p->gpu;
     gpu->log = log;
     gpu->glsl = (struct pl_glsl_version) {
@@ -272,7 +275,7 @@ plh_stream plh_gpu_stream_n(pl_gpu gpu, int on)
     if (!on || !p->async_measure)
         return p->stream;
     // (a greatest- or least-priority measuring stream changes nothing: profiles/r05_04_peak_prio.txt)
-    if (!p->aux && plh_stream_create(p->device, &p->aux)) {
+    if (!p->aux && plh_stream_create_masked(p->device, p->measure_cus, &p->aux)) {
         pl_msg(gpu->log, PL_LOG_WARN, "pl_hip: no second stream: async_measure disabled");
         p->async_measure = false;
         return p->stream;
@@ -408,6 +411,16 @@ uint64_t plh_gpu_stamp(pl_gpu gpu, int on)
     return p->async_measure ? ++p->seq[on] : 0;
 }
 
+// Work queued on the main stream that no texture's read / write count records (buffer copies,
+// staging uploads, pl_pass_run's compute path, pl_dispatch_compute) still takes a number: a fence
+// that rode on an earlier launch (plh_gpu_fence_for_launch) must never pass for "the current end
+// of the stream" in fence_here() once anything at all has been queued behind that launch.
+static inline void queued_unnumbered(struct gpu_priv *g)
+{
+    if (g->async_measure)
+        g->seq[0]++;
+}
+
 void plh_gpu_order_after(pl_gpu gpu, int on, uint64_t other_seq)
 {
     if (GPU_PRIV(gpu)->async_measure)
@@ -470,6 +483,7 @@ static pl_tex hip_tex_create(pl_gpu gpu, const struct pl_tex_params *params)
     if (params->initial_data) {
         const int err = plh_copy2d_h2d(g->stream, t->ptr, t->pitch, params->initial_data,
                                        row_bytes, row_bytes, rows);
+        queued_unnumbered(g);
         // initial_data may be freed by the caller right away
         if (err || sync_main(g)) {
             pl_msg(gpu->log, PL_LOG_ERR, "pl_tex_create: initial upload failed");
@@ -703,6 +717,7 @@ static pl_buf hip_buf_create(pl_gpu gpu, const struct pl_buf_params *params)
     if (params->initial_data) {
         plh_copy2d_h2d(g->stream, b->ptr, params->size, params->initial_data, params->size,
                        params->size, 1);
+        queued_unnumbered(g);
         sync_main(g);
     }
     return &b->buf;
@@ -740,6 +755,7 @@ void plh_buf_write(pl_gpu gpu, pl_buf buf, size_t buf_offset, const void *data, 
             if (g->stage[i].in_flight)
                 plh_event_sync(g->stage[i].done);   // eight uploads ago: long finished
             memcpy(g->stage[i].host, data, size);
+            queued_unnumbered(g);
             if (!plh_copy2d_h2d(g->stream, dst, size, g->stage[i].host, size, size, 1) &&
                 !plh_event_record(g->stage[i].done, g->stream)) {
                 g->stage[i].in_flight = true;
@@ -748,6 +764,7 @@ void plh_buf_write(pl_gpu gpu, pl_buf buf, size_t buf_offset, const void *data, 
             }
         }
     }
+    queued_unnumbered(g);
     plh_copy2d_h2d(g->stream, dst, size, data, size, size, 1);
     sync_main(g);
 }
@@ -777,6 +794,7 @@ const void *plh_gpu_upload_scratch(pl_gpu gpu, const void *data, size_t size)
     if (g->stage[i].in_flight)
         plh_event_sync(g->stage[i].done);
     memcpy(g->stage[i].host, data, size);
+    queued_unnumbered(g);
     if (plh_copy2d_h2d(g->stream, slot, size, g->stage[i].host, size, size, 1) ||
         plh_event_record(g->stage[i].done, g->stream))
         return NULL;
@@ -788,6 +806,7 @@ const void *plh_gpu_upload_scratch(pl_gpu gpu, const void *data, size_t size)
 bool plh_buf_read(pl_gpu gpu, pl_buf buf, size_t buf_offset, void *dest, size_t size)
 {
     struct gpu_priv *g = GPU_PRIV(gpu);
+    queued_unnumbered(g);
     int err = plh_copy2d_d2h(g->stream, dest, size, (uint8_t *) BUF_PRIV(buf)->ptr + buf_offset,
                              size, size, 1);
     err = err ? err : sync_main(g);
@@ -797,8 +816,17 @@ bool plh_buf_read(pl_gpu gpu, pl_buf buf, size_t buf_offset, void *dest, size_t 
 static void hip_buf_copy(pl_gpu gpu, pl_buf dst, size_t dst_offset, pl_buf src, size_t src_offset,
                          size_t size)
 {
+    queued_unnumbered(GPU_PRIV(gpu));
     plh_copy2d_d2d(GPU_PRIV(gpu)->stream, (uint8_t *) BUF_PRIV(dst)->ptr + dst_offset, size,
                    (uint8_t *) BUF_PRIV(src)->ptr + src_offset, size, size, 1);
+}
+
+static bool hip_buf_copy_swap(pl_gpu gpu, pl_buf dst, size_t dst_offset, pl_buf src, size_t src_offset,
+                              size_t size, int wordsize)
+{
+    queued_unnumbered(GPU_PRIV(gpu));
+    return !plh_launch_swap_words(GPU_PRIV(gpu)->stream, (const uint8_t *) BUF_PRIV(src)->ptr + src_offset,
+                                  (uint8_t *) BUF_PRIV(dst)->ptr + dst_offset, size / 4, wordsize);
 }
 
 static bool hip_buf_export(pl_gpu gpu, pl_buf buf)
@@ -926,6 +954,7 @@ static void hip_pass_run(pl_gpu gpu, const struct pl_pass_run_params *params, pl
         local.frag_x0 = local.frag_y0 = 0;
         if (params->timer)
             plh_timer_begin(gpu, params->timer, 0);
+        queued_unnumbered(g);
         err = plh_launch_pass(g->stream, &local);
         if (params->timer)
             plh_timer_end(gpu, params->timer, 0);
@@ -1007,6 +1036,7 @@ static const struct plh_gpu_fns hip_fns = {
     .buf_write      = plh_buf_write,
     .buf_read       = plh_buf_read,
     .buf_copy       = hip_buf_copy,
+    .buf_copy_swap  = hip_buf_copy_swap,
     .buf_export     = hip_buf_export,
     .buf_poll       = hip_buf_poll,
     .pass_create    = hip_pass_create,

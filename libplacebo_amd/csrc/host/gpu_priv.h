@@ -41,6 +41,8 @@ struct plh_gpu_fns {
     bool (*buf_read)(pl_gpu gpu, pl_buf buf, size_t offset, void *dest, size_t size);
     void (*buf_copy)(pl_gpu gpu, pl_buf dst, size_t dst_offset, pl_buf src, size_t src_offset,
                      size_t size);
+    bool (*buf_copy_swap)(pl_gpu gpu, pl_buf dst, size_t dst_offset, pl_buf src, size_t src_offset,
+                          size_t size, int wordsize);
     bool (*buf_export)(pl_gpu gpu, pl_buf buf);
     bool (*buf_poll)(pl_gpu gpu, pl_buf buf, uint64_t timeout);
     // `recorded`: the live shader params->glsl_shader names (resolved by the front-end)
@@ -62,6 +64,8 @@ struct plh_gpu_fns {
 #define PLH_STAGE_BYTES (64 * 1024)
 
 #define PLH_FENCES 16
+// compute units of the measuring stream's CU mask (0 = no mask); measured in profiles/r06_*
+#define PLH_MEASURE_CUS_DEFAULT 0
 
 struct gpu_priv {
     struct pl_gpu_t gpu;
@@ -74,6 +78,7 @@ struct gpu_priv {
     // pl_hip_params.async_measure: a second stream for the per-frame measurement pass
     // (index 1 in the functions below; index 0 is `stream`). Created on first use.
     bool async_measure;
+    int measure_cus;    // compute units the second stream may use (0: all; PL_HIP_MEASURE_CUS)
     plh_stream aux;
     bool aux_announced;
     // (gpu_hip.c "two streams") launches counted per stream, how far each is known to have got,
@@ -176,6 +181,19 @@ void plh_gpu_fence_launched(pl_gpu gpu, int on, bool taken);
 void plh_tex_read_so_far(pl_gpu gpu, pl_tex tex, int on);
 // a number for something just queued on `on` that is no texture (a table upload)...
 uint64_t plh_gpu_stamp(pl_gpu gpu, int on);
+
+// The reference's internal byte-swapping copy (src/gpu.h:137-165; src/gpu/utils.c:1065 implements it
+// as a GLSL compute pass through the GPU's own dispatch, which this backend does not have: a kernel
+// of its own here). Its tests call it (src/tests/gpu_tests.c:102-125), so the symbol is exported.
+struct pl_buf_copy_swap_params {
+    pl_buf src;             // must be `storable`
+    size_t src_offset;
+    pl_buf dst;             // must be `storable`; may be `src` (same offset: in place)
+    size_t dst_offset;
+    size_t size;            // bytes, a multiple of 4
+    int wordsize;           // 2: swap the bytes of every 16-bit word, 4: of every 32-bit word
+};
+PL_API bool pl_buf_copy_swap(pl_gpu gpu, const struct pl_buf_copy_swap_params *params);
 // ... which stream `on` (the other one) has to wait for
 void plh_gpu_order_after(pl_gpu gpu, int on, uint64_t other_seq);
 // the host has seen the result of launch `seq` of stream `on`

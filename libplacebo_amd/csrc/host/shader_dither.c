@@ -105,10 +105,24 @@ void pl_shader_dither(pl_shader sh, int new_depth, pl_shader_obj *dither_state,
                 pl_msg(sh->log, PL_LOG_DEBUG, hit ? "Re-using cached dither matrix (%dx%d)"
                        : "Generated dither matrix (%dx%d)", lut_size, lut_size);
             }
+            // The matrix is followed by its transpose: a kernel whose lanes own a COLUMN of output
+            // pixels (k_polar_mx: eight rows per lane) reads its dither values as two 16-byte loads
+            // from there instead of eight gathers (matrix[size * size + x * size + y] = matrix[y * size + x]).
+            const size_t n = (size_t) lut_size * lut_size;
+            float *both = malloc(2 * n * sizeof(float));
+            if (!both) {
+                free(mat);
+                return;
+            }
+            memcpy(both, mat, n * sizeof(float));
+            for (int y = 0; y < lut_size; y++) {
+                for (int x = 0; x < lut_size; x++)
+                    both[n + (size_t) x * lut_size + y] = mat[(size_t) y * lut_size + x];
+            }
             pl_buf_destroy(SH_GPU(sh), &obj->lut);
             obj->lut = pl_buf_create(SH_GPU(sh), pl_buf_params(
-                .size = sizeof(float) * lut_size * lut_size, .storable = true,
-                .initial_data = mat));
+                .size = 2 * n * sizeof(float), .storable = true, .initial_data = both));
+            free(both);
             free(mat);
             obj->size = lut_size;
             obj->method = method;
@@ -146,6 +160,7 @@ void pl_shader_dither(pl_shader sh, int new_depth, pl_shader_obj *dither_state,
     }
     if (obj) {
         op->ptr = pl_hip_buf_ptr(obj->lut);
+        op->ptr2 = (const float *) op->ptr + (size_t) size * size;     // (its transpose: above)
         sh_hold(sh, *dither_state);
     }
     sh_listf(sh, "dither(depth=%d, method=%d, size=%d, gamma=%g, temporal=%d, index=%d)\n",

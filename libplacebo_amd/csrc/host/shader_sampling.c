@@ -694,10 +694,14 @@ static bool polar_mxd_build(pl_gpu gpu, pl_log log, struct sh_sampler_obj *obj,
                             const float *colfc, const int32_t *colbase,
                             const float *rowfc, const int32_t *rowbase);
 
-// B fragments (plh_device.h): frag f = 4 * (py ? 4 + j : j) + kind, lane l, element e hold
-//   T(py, wy)[k][n] with n = l & 15, k = 8 * ((l >> 4) & 1) + e, wy = 2 j + (l >> 5) - cy(py),
+// B fragments (plh_device.h): frag f = 4 * (py * npairs + j) + kind, lane l, element e hold
+//   T(py, wy)[k][n] with n = l & 15, k = 8 * ((l >> 4) & 1) + e, wy = first[py] + 2 j + (l >> 5),
 //   = w'(phase py, phase n & 1, tap (k - dbx[n] - 3, wy - 3)): kind 0 / 1 its hi / lo f16 halves,
 //   kind 2 / 3 its derivative in fcoord_x / fcoord_y times 2^-PLH_MX_DSHIFT.
+// first[py] = the first tap row of row phase py that carries a weight for either column phase;
+// npairs = 3 when both row phases have at most six such rows (every centred 2x upscale with a
+// radius <= 3.25: rows -3 and 4 of the reference's 8 x 8 tap square lie 3.25 / 3.75 texels from
+// the sample), else 4.
 // The derivatives are the slopes of a least-squares line through the normalised weights of the
 // phase classes of that parity -- the weights the per-pixel kernels actually use for them.
 static bool polar_mx_build(pl_gpu gpu, pl_log log, struct sh_sampler_obj *obj,
@@ -789,15 +793,47 @@ static bool polar_mx_build(pl_gpu gpu, pl_log log, struct sh_sampler_obj *obj,
         }
     }
 
+    // live tap rows of each row phase: a row counts when any column phase has a weight, a slope
+    // included (the slopes are fitted through neighbouring classes, whose tap sets are the same:
+    // mx_axis holds every class of a parity within 1e-5 of it)
+    int first[2], npairs = 3;
+    for (int py = 0; py < 2; py++) {
+        int lo = 8, hi = -1;
+        for (int wy = 0; wy < 8; wy++) {
+            bool live = false;
+            for (int wx = 0; wx < 8 && !live; wx++) {
+                const int t = tap_at[wy][wx];
+                if (t < 0)
+                    continue;
+                for (int px = 0; px < 2 && !live; px++) {
+                    live = WN(cx[px], cy[py], t) != 0.0 ||
+                           slope[0][(size_t) (py * 2 + px) * ntaps + t] != 0.0 ||
+                           slope[1][(size_t) (py * 2 + px) * ntaps + t] != 0.0;
+                }
+            }
+            if (live) {
+                lo = PL_MIN(lo, wy);
+                hi = wy;
+            }
+        }
+        if (hi < lo)
+            lo = hi = 3;
+        first[py] = lo;
+        if (hi - lo + 1 > 6)
+            npairs = 4;
+    }
+    for (int py = 0; py < 2; py++)
+        first[py] = PL_MIN(first[py], 8 - 2 * npairs);  // (the pairs stay inside the 8 tap rows)
+
     uint16_t *frag = (uint16_t *) blob;
     const double dscale = ldexp(1.0, -PLH_MX_DSHIFT);
     double worst = 0.0;
     for (int py = 0; py < 2; py++) {
-        for (int j = 0; j < (py ? 5 : 4); j++) {
+        for (int j = 0; j < npairs; j++) {
             for (int l = 0; l < 64; l++) {
                 const int n = l & 15, px = n & 1;
                 const int dbx = (n >> 1) + (px ? c1x : 0);
-                const int wy = 2 * j + (l >> 5) - (py ? c1y : 0);
+                const int wy = first[py] + 2 * j + (l >> 5);
                 for (int e = 0; e < 8; e++) {
                     const int k = 8 * ((l >> 4) & 1) + e, wx = k - dbx;
                     double v = 0.0, vx = 0.0, vy = 0.0;
@@ -811,7 +847,7 @@ static bool polar_mx_build(pl_gpu gpu, pl_log log, struct sh_sampler_obj *obj,
                     const uint16_t lo = f32_to_f16((float) (v - (double) f16_to_f32(hi)));
                     const double err = fabs(v - (double) f16_to_f32(hi) - (double) f16_to_f32(lo));
                     worst = PL_MAX(worst, err);
-                    const size_t f = 4 * (size_t) (py ? 4 + j : j);
+                    const size_t f = 4 * (size_t) (py * npairs + j);
                     frag[((f + 0) * 64 + l) * 8 + e] = hi;
                     frag[((f + 1) * 64 + l) * 8 + e] = lo;
                     frag[((f + 2) * 64 + l) * 8 + e] = f32_to_f16((float) (vx * dscale));
@@ -850,13 +886,18 @@ static bool polar_mx_build(pl_gpu gpu, pl_log log, struct sh_sampler_obj *obj,
     obj->mx_host = (struct plh_polar_mx) {
         .enabled = 1,
         .org_x = colbase[0] - 3, .org_y = rowbase[0] - 3,
+        .npairs = npairs,
+        // tile row of tap row first[py] for the output row pair 0: rows 2 m + py sample from base
+        // rowbase[0] + m + (py ? c1y : 0)
+        .row_first = { first[0], first[1] + c1y },
         .bfrag = base,
         .dfx = (const float *) (base + o_dfx), .dfy = (const float *) (base + o_dfy),
     };
     obj->mx_announced = false;
     pl_msg(log, PL_LOG_DEBUG, "matrix-pipe tables for the polar pass: 2 x 2 phases (fcoord %.6f %.6f / %.6f %.6f, "
-           "per-pixel phases within %.2e: first-order terms), weight split error <= %.2e",
-           colfc[0], colfc[1], rowfc[0], rowfc[1], dev, worst);
+           "per-pixel phases within %.2e: first-order terms), %d row pairs per phase from tile rows %d / %d, "
+           "weight split error <= %.2e",
+           colfc[0], colfc[1], rowfc[0], rowfc[1], dev, npairs, first[0], first[1] + c1y, worst);
     return true;
 }
 

@@ -205,3 +205,16 @@ def test_shader_variable_helpers_match_the_reference():
     assert np.array_equal(got[:, :3], src.reshape(3, 3)) and np.all(got[:, 3] == -1) and np.all(dst[:4] == -1)
     our.pl_desc_access_glsl_name.restype = C.c_char_p
     assert [our.pl_desc_access_glsl_name(i) for i in range(3)] == [b"", b"readonly", b"writeonly"]
+
+
+def test_unorm16_to_f16_by_product():
+    """k_polar_mx's tile decode (mx_un16_for_f16): a 16-bit unorm code enters the rgba16hf tile as
+    f16(fp32(v) * fp32(1 / 65535)) -- conversion and one product -- where the reference's value is
+    f16(fp32(v / 65535)) (texture decode, then PASS A's rgba16hf store: renderer.c:2064). Behind the
+    f16 rounding the two are the same half for every one of the 65536 codes."""
+    v = np.arange(65536, dtype=np.uint32).astype(np.float32)
+    quotient = (v / np.float32(65535)).astype(np.float16)
+    product = (v * np.float32(1.0 / 65535.0)).astype(np.float16)
+    assert np.array_equal(quotient.view(np.uint16), product.view(np.uint16))
+    # (and the quotient is the fp32 quotient: float64 division rounded once gives the same floats)
+    assert np.array_equal((np.arange(65536) / 65535.0).astype(np.float32), v / np.float32(65535))
