@@ -133,10 +133,11 @@ void k_deband(const plh_pass p_)
  * (S / 262140, one rounding) where the general kernel decodes each tap (v / 65535) and adds the
  * floats (four roundings) -- 21 instead of 57 instructions per pixel, an average that is closer to
  * the exact one, and an rgba16hf result that differs from the general kernel's by one f16 ulp on
- * a fraction of a percent of the samples (tests/test_gpu_ortho_deband.py renders with both; a
- * sample whose |res - avg| is within that ulp of the threshold may keep its value here and take
- * the average there -- the general kernel keeps the reference's four-float sum because it is the
- * one held to the oracle bit for bit on fp32 targets). What
+ * a fraction of a percent of the samples (tests/test_gpu_ortho_deband.py renders with both). The
+ * DECISION between a sample's value and the average is the reference's in every kernel (round 6:
+ * deband_compare below; before that a sample within an ulp of the threshold could keep its value
+ * here and take the average there) -- the general kernel keeps the reference's four-float sum for
+ * the value as well, because it is the one held to the oracle bit for bit on fp32 targets. What
  * else goes is what the general kernel pays for being general: the op interpreter, format and
  * address-mode switches, 64-bit address arithmetic (the taps: one 24-bit multiply-add against a
  * uniform base), the alpha channel of the four taps and of a plane that has none, the IEEE
@@ -146,6 +147,50 @@ void k_deband(const plh_pass p_)
  */
 #define DBF_BW 64
 #define DBF_BH 4
+
+// The fast kernels' threshold decision is the REFERENCE's. They average the four taps of a channel
+// as an integer sum (one rounding; the reference and the general kernel decode each tap and add
+// four floats: three more roundings), so |res - avg| can land an ulp or two on the other side of
+// the threshold -- and a sample that keeps its value in one kernel and takes the average in the
+// other differs by the threshold itself, hundreds of 16-bit codes.
+// In exact arithmetic res and avg are multiples of 1 / 262140, the computed differences of either
+// formulation lie within 2e-7 of that lattice (spacing 3.8e-6), so the two can only disagree when
+// the threshold itself lies within 2e-7 of a lattice point and the sample sits on it. Those samples
+// are recognised (|diff - bound| <= 1e-6: none at all unless the threshold is so aligned) and take
+// the decision from the reference's own four-float average; where no lane of a wave has one -- the
+// presets' threshold on full-range planes: always -- the branch is not taken.
+#define DEBAND_NEAR 1e-6f
+DEV float deband_avg_ref(const plh_u32x2 *r, int c)
+{
+    float a = 0.0f;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const uint32_t code = c == 0 ? (r[k].x & 0xffffu) : c == 1 ? (r[k].x >> 16) : (r[k].y & 0xffffu);
+        a += plh_un16(code);
+    }
+    return a * 0.25f;
+}
+
+// one iteration's comparison for one pixel: res = |res - avg| > bound ? res : avg (avg: the integer
+// sum's; the decision: see above)
+DEV void deband_compare(float (&res)[3], const plh_u32x2 *r, const float (&avg)[3], float bound)
+{
+    bool keep[3], near = false;
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+        const float diff = __builtin_fabsf(res[c] - avg[c]);
+        keep[c] = diff > bound;
+        near |= __builtin_fabsf(diff - bound) <= DEBAND_NEAR;
+    }
+    if (__builtin_amdgcn_ballot_w64(near) != 0) {
+#pragma unroll
+        for (int c = 0; c < 3; c++)
+            keep[c] = __builtin_fabsf(res[c] - deband_avg_ref(r, c)) > bound;
+    }
+#pragma unroll
+    for (int c = 0; c < 3; c++)
+        res[c] = keep[c] ? res[c] : avg[c];
+}
 
 __global__ __launch_bounds__(DBF_BW * DBF_BH)
 void k_deband_fast(const plh_pass p_)
@@ -243,11 +288,7 @@ void k_deband_fast(const plh_pass p_)
             const uint32_t s2 = (r[0].y & 0xffffu) + (r[1].y & 0xffffu) + (r[2].y & 0xffffu) + (r[3].y & 0xffffu);
             const float avg[3] = { (float) s0 * (1.0f / 262140.0f), (float) s1 * (1.0f / 262140.0f),
                                    (float) s2 * (1.0f / 262140.0f) };
-#pragma unroll
-            for (int c = 0; c < 3; c++) {
-                const float diff = __builtin_fabsf(res[q][c] - avg[c]);
-                res[q][c] = diff > bound ? res[q][c] : avg[c];
-            }
+            deband_compare(res[q], r, avg, bound);
         }
     }
     if (s.db_grain > 0.0f) {
@@ -456,11 +497,7 @@ void k_deband_lds(const plh_pass p_)
                 const uint32_t s2 = (r[0].y & 0xffffu) + (r[1].y & 0xffffu) + (r[2].y & 0xffffu) + (r[3].y & 0xffffu);
                 const float avg[3] = { (float) s0 * (1.0f / 262140.0f), (float) s1 * (1.0f / 262140.0f),
                                        (float) s2 * (1.0f / 262140.0f) };
-#pragma unroll
-                for (int c = 0; c < 3; c++) {
-                    const float diff = __builtin_fabsf(res[q][c] - avg[c]);
-                    res[q][c] = diff > bound ? res[q][c] : avg[c];
-                }
+                deband_compare(res[q], r, avg, bound);
             }
         }
         if (s.db_grain > 0.0f) {

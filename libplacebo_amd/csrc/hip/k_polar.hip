@@ -275,6 +275,9 @@ int plh_launch_polar_pp_f32_c12(hipStream_t stream, const plh_pass *pass, dim3 g
                                 size_t shmem, int n);
 // k_polar_mx.hip
 int plh_launch_polar_mx(hipStream_t stream, const plh_pass *pass);
+// k_polar_mxp.hip: the same on persistent workgroups, for the commonest shapes
+bool plh_polar_mxp_applies(const plh_pass *pass);
+int plh_launch_polar_mxp(hipStream_t stream, const plh_pass *pass);
 bool plh_polar_mxd_applies(plh_pass *pass);
 int plh_launch_polar_mxd(hipStream_t stream, const plh_pass *pass);
 bool plh_polar_mxr_applies(plh_pass *pass);
@@ -340,6 +343,8 @@ int plh_launch_polar(hipStream_t stream, const plh_pass *pass_in)
             plh_match_map_chain(&local, true);
         if (!local.chain.enabled)
             plh_match_fast_epilogue(&local);
+        if (plh_polar_mxp_applies(pass))
+            return plh_launch_polar_mxp(stream, pass);
         return plh_launch_polar_mx(stream, pass);
     }
     // the phase-class kernels have a CHAIN variant for RGB / RGBA tiles (k_polar_pp.hiph)

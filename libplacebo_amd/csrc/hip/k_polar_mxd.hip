@@ -67,7 +67,15 @@ void k_polar_mxd(const plh_pass p_)
     unsigned char *bl = smem;
     unsigned char *tile = smem + MXD_B_BYTES;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int dbg = s.pp_debug;     // profiling aid: 1 = no contraction, 4 = no stores, 8 = no tile loads
+    // profiling aid (PL_HIP_PP_DEBUG: 1 = no contraction, 4 = no stores, 8 = no tile loads): only in a
+    // library built with -DPLH_MX_DEBUG (k_polar_mx.hiph says what the switches cost)
+#ifdef PLH_MX_DEBUG
+    const int dbg = s.pp_debug;
+#else
+    constexpr int dbg = 0;
+#endif
+    int j0 = mx.row_first[0];       // first source row with a weight (uniform)
+    asm volatile("" : "+s"(j0));
 
     // Persistent workgroups, one per CU: the B fragments are loaded once, and the loads of the next
     // tile are in flight (in registers) while this one is contracted. Workgroups go to the 8 XCDs
@@ -301,14 +309,16 @@ void k_polar_mxd(const plh_pass p_)
         } else {
             init_acc(0.0f);
             fragset f0, f1;
-            read_frags(f0, 0, 0);
+            // (from the first source row that carries a weight -- mx.row_first[0]: row 1 for every
+            // radius <= 3.25, six row steps = 216 MFMAs per wave instead of seven = 252)
+            read_frags(f0, j0, 0);
             // (first step peeled: its accumulators are the constant 0)
-            read_frags(f1, 0, 1);
+            read_frags(f1, j0, 1);
             contract(f0);
-            read_frags(f0, 1, 0);
+            read_frags(f0, min(j0 + 1, PLH_MXD_TAPS / 2 - 1), 0);
             contract(f1);
 #pragma unroll 1
-            for (int j = 1; j < PLH_MXD_TAPS / 2; j++) {
+            for (int j = j0 + 1; j < PLH_MXD_TAPS / 2; j++) {
                 read_frags(f1, j, 1);
                 contract(f0);
                 read_frags(f0, min(j + 1, PLH_MXD_TAPS / 2 - 1), 0);    // (the last one is not used)

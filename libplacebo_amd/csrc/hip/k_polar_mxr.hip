@@ -72,7 +72,11 @@ void k_polar_mxr(const plh_pass p_)
     unsigned char *tile = smem + MXR_B_BYTES;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int ln = lane & 15, lg = lane >> 4;
-    const int dbg = s.pp_debug;
+#ifdef PLH_MX_DEBUG
+    const int dbg = s.pp_debug;     // (profiling aid: only in a -DPLH_MX_DEBUG build, k_polar_mx.hiph)
+#else
+    constexpr int dbg = 0;
+#endif
 
     // uniforms of the per-phase code, read once and pinned in SGPRs (k_polar_mx.hiph says why)
     int u_w = p.width, u_h = p.height, u_dst_w = p.dst.w, u_dst_h = p.dst.h;

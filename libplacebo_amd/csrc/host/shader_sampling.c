@@ -1576,6 +1576,10 @@ static bool polar_mxd_build(pl_gpu gpu, pl_log log, struct sh_sampler_obj *obj,
     uint16_t *frag = (uint16_t *) blob;
     const double dscale = ldexp(1.0, -PLH_MX_DSHIFT);
     double worst = 0.0, asym = 0.0;
+    // the first source row (and, mirrored, the last) that carries a weight at all: at fcoord = 1/2
+    // rows -6 and 7 of the reference's 14 x 14 tap square lie 6.5 texels from the sample, beyond
+    // twice any radius <= 3.25 (ewa_lanczos: 6.4766) -- the kernel starts its contraction there
+    int first_row = NT / 2 - 1;
     for (int j = 0; j < NT / 2; j++) {
         for (int kb = 0; kb < 2; kb++) {
             for (int l = 0; l < 64; l++) {
@@ -1600,6 +1604,8 @@ static bool polar_mxd_build(pl_gpu gpu, pl_log log, struct sh_sampler_obj *obj,
                     const uint16_t hi = f32_to_f16((float) v);
                     const uint16_t lo = f32_to_f16((float) (v - (double) f16_to_f32(hi)));
                     worst = PL_MAX(worst, fabs(v - (double) f16_to_f32(hi) - (double) f16_to_f32(lo)));
+                    if (v != 0.0 || vx != 0.0 || vy != 0.0)
+                        first_row = PL_MIN(first_row, j);
                     const size_t f = 4 * (size_t) (2 * j + kb);
                     frag[((f + 0) * 64 + l) * 8 + e] = hi;
                     frag[((f + 1) * 64 + l) * 8 + e] = lo;
@@ -1635,6 +1641,7 @@ static bool polar_mxd_build(pl_gpu gpu, pl_log log, struct sh_sampler_obj *obj,
     obj->mx_host = (struct plh_polar_mx) {
         .enabled = 2,
         .org_x = colbase[0] - 6, .org_y = rowbase[0] - 6,
+        .row_first = { first_row, 0 },
         .bfrag = base,
         .dfx = (const float *) (base + o_dfx), .dfy = (const float *) (base + o_dfy),
     };

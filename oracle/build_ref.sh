@@ -59,3 +59,6 @@ gcc $CFLAGS -c "$HERE/ref_gpu_shim.c" -o "$OUT/obj/ref_gpu_shim.o"
 gcc -shared -Wl,--no-undefined -Wl,-Bsymbolic -o "$OUT/libplref_gpu.so" "$OUT/obj/gpu.o" "$OUT/obj/ref_gpu_shim.o" \
     "$OUT/obj/common.o" "$OUT/obj/log.o" "$OUT/obj/pl_alloc.o" "$OUT/obj/pl_string.o" "$OUT/obj/format.o" "$OUT/obj/convert.o" -lstdc++ -lm -lpthread
 echo "built $OUT/libplref.so, $OUT/libplref_gpu.so"
+# the reference's own GPU tests and benchmark against the HIP backend (needs the library: built first
+# by __graft_entry__.build())
+"$HERE/ref_tests/build.sh"

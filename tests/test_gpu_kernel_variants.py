@@ -580,15 +580,28 @@ def test_features_pass_equals_generic(gpu, size):
 def test_sdr_chain_equals_interpreter(gpu, scaler, size):
     """pl_render_default_params on an SDR frame: the last scaler pass carries UNSIGMOIDIZE +
     DELINEARIZE + dither + scale -- the chain without a colour map (k_ortho_fast EPI 4, the CHAIN
-    epilogue of k_polar_mx) against the op interpreter (PL_HIP_MAP_CHAIN=0): bit-identical."""
+    epilogues of k_polar_pp and k_polar_mx) against the op interpreter (PL_HIP_MAP_CHAIN=0):
+    bit-identical -- for the separable kernels and k_polar_pp by construction (the same device
+    functions in the same order on the same sums). The two variants of k_polar_mx apply the row-phase
+    term of the contraction at different places (the CHAIN variant to the finished sums of a row
+    phase, the full-interpreter variant inside the contraction: k_polar_mx.hiph, YPHASE), an fp32
+    ulp apart wherever that term is not zero: identical on the bulk, one dither step on a sample in
+    10^4 at most (round 5's 81-MFMA pairing happened to flip none on these two frames; round 6's
+    54-MFMA pairing flips one of 67 000)."""
     sw, sh = size
     img = util.chirp_rgba16(sw, sh)
     params = pl.render_params("default", upscaler=pl.filter_config(scaler))
-    outs = []
-    for chain in ("1", "0"):
-        with _env("PL_HIP_MAP_CHAIN", chain), _env("PL_HIP_POLAR_MFMA", "1"):
-            outs.append(render(gpu, img, 2 * sw, 2 * sh, params, True, {}))
-    assert np.array_equal(outs[0], outs[1]) and outs[0][..., :3].std() > 1000
+    for mfma in ("1", "0"):
+        outs = []
+        for chain in ("1", "0"):
+            with _env("PL_HIP_MAP_CHAIN", chain), _env("PL_HIP_POLAR_MFMA", mfma):
+                outs.append(render(gpu, img, 2 * sw, 2 * sh, params, True, {}))
+        assert outs[0][..., :3].std() > 1000
+        if scaler == "ewa_lanczos" and mfma == "1":
+            d = np.abs(outs[0].astype(np.int64) - outs[1].astype(np.int64))
+            assert d.max() <= 64 and (d > 0).mean() <= 1e-4, (int(d.max()), float((d > 0).mean()))
+        else:
+            assert np.array_equal(outs[0], outs[1]), util.diff_stats(outs[0], outs[1])
 
 
 @pytest.mark.parametrize("case", ["hdr_2x", "hdr_1.5x", "sdr_default_1.5x", "hdr_rgba_2x"])

