@@ -584,10 +584,13 @@ void k_pass_native(const plh_pass p_)
         char *d = (char *) p.dst.ptr + (size_t) y * p.dst.pitch + (size_t) x0 * 8;
         if (two) {
             const plh_u32x4 pk = { o[0], o[1], o[2], o[3] };
-            if (p.nt_store)
-                __builtin_nontemporal_store(pk, (plh_u32x4 *) d);
-            else
+            // (an rgba16 target is a final frame: streamed; an rgba16hf one is the intermediate the next
+            // pass reads: cached. At compile time: `if (nt) non-temporal else plain` is folded into one
+            // plain store, devmath.hiph)
+            if constexpr (F16DST)
                 *(plh_u32x4 *) d = pk;
+            else
+                __builtin_nontemporal_store(pk, (plh_u32x4 *) d);
         } else {
             *(uint2 *) d = make_uint2(o[0], o[1]);
         }
@@ -678,12 +681,19 @@ void k_pass_chain(const plh_pass p_)
     char *d = (char *) p.dst.ptr + (size_t) y * p.dst.pitch + (size_t) x0 * 8;
     if (NP == 2 && all) {
         const plh_u32x4 pk = { o[0], o[1], o[2], o[3] };
-        if (p.nt_store)
-            __builtin_nontemporal_store(pk, (plh_u32x4 *) d);
-        else
+        // (an rgba16 target is a final frame: streamed; an rgba16hf one is the intermediate the next
+        // pass reads: cached. At compile time: `if (nt) non-temporal else plain` is folded into one
+        // plain store, devmath.hiph)
+        if constexpr (F16DST)
             *(plh_u32x4 *) d = pk;
+        else
+            __builtin_nontemporal_store(pk, (plh_u32x4 *) d);
     } else {
-        *(uint2 *) d = make_uint2(o[0], o[1]);
+        const plh_u32x2 one = { o[0], o[1] };
+        if constexpr (F16DST)
+            *(plh_u32x2 *) d = one;
+        else
+            __builtin_nontemporal_store(one, (plh_u32x2 *) d);
     }
 }
 
@@ -804,12 +814,19 @@ void k_pass_merge(const plh_pass p_, const plh_merge m)
     char *d = (char *) p.dst.ptr + (size_t) y * p.dst.pitch + (size_t) x0 * 8;
     if (all) {
         const plh_u32x4 pk = { o[0], o[1], o[2], o[3] };
-        if (p.nt_store)
-            __builtin_nontemporal_store(pk, (plh_u32x4 *) d);
-        else
+        // (an rgba16 target is a final frame: streamed; an rgba16hf one is the intermediate the next
+        // pass reads: cached. At compile time: `if (nt) non-temporal else plain` is folded into one
+        // plain store, devmath.hiph)
+        if constexpr (F16DST)
             *(plh_u32x4 *) d = pk;
+        else
+            __builtin_nontemporal_store(pk, (plh_u32x4 *) d);
     } else {
-        *(uint2 *) d = make_uint2(o[0], o[1]);
+        const plh_u32x2 one = { o[0], o[1] };
+        if constexpr (F16DST)
+            *(plh_u32x2 *) d = one;
+        else
+            __builtin_nontemporal_store(one, (plh_u32x2 *) d);
     }
 }
 
@@ -940,12 +957,19 @@ void k_pass_mix(const plh_pass p_, const plh_mixplan m)
     char *d = (char *) p.dst.ptr + (size_t) y * p.dst.pitch + (size_t) x0 * 8;
     if (all) {
         const plh_u32x4 pk = { o[0], o[1], o[2], o[3] };
-        if (p.nt_store)
-            __builtin_nontemporal_store(pk, (plh_u32x4 *) d);
-        else
+        // (an rgba16 target is a final frame: streamed; an rgba16hf one is the intermediate the next
+        // pass reads: cached. At compile time: `if (nt) non-temporal else plain` is folded into one
+        // plain store, devmath.hiph)
+        if constexpr (F16DST)
             *(plh_u32x4 *) d = pk;
+        else
+            __builtin_nontemporal_store(pk, (plh_u32x4 *) d);
     } else {
-        *(uint2 *) d = make_uint2(o[0], o[1]);
+        const plh_u32x2 one = { o[0], o[1] };
+        if constexpr (F16DST)
+            *(plh_u32x2 *) d = one;
+        else
+            __builtin_nontemporal_store(one, (plh_u32x2 *) d);
     }
 }
 
@@ -1293,18 +1317,20 @@ void k_bilinear_tab(const plh_pass p_, const float *colw_, const float *roww_, i
             const quad8 pk = { a.x, a.y, b.x, b.y };
             if (nt)
                 __builtin_nontemporal_store(pk, (BF_GLOBAL quad8 *) (row + (size_t) ox0 * 8));
-            else
+            else {
                 *(BF_GLOBAL quad8 *) (row + (size_t) ox0 * 8) = pk;
+                PLH_KEEP_APART();
+            }
             continue;
         }
         const plh_u32x2 lo = { a.x, a.y }, hi = { b.x, b.y };
         if (okx0) {
             if (nt) __builtin_nontemporal_store(lo, (gpair *) (row + (size_t) ox0 * 8));
-            else *(gpair *) (row + (size_t) ox0 * 8) = lo;
+            else { *(gpair *) (row + (size_t) ox0 * 8) = lo; PLH_KEEP_APART(); }
         }
         if (okx1) {
             if (nt) __builtin_nontemporal_store(hi, (gpair *) (row + (size_t) ox1 * 8));
-            else *(gpair *) (row + (size_t) ox1 * 8) = hi;
+            else { *(gpair *) (row + (size_t) ox1 * 8) = hi; PLH_KEEP_APART(); }
         }
     }
 }

@@ -368,8 +368,15 @@ void k_polar_mxd(const plh_pass p_)
                 px.x = plh_unorm16x2(o[0], o[1]);
                 px.y = plh_unorm16x2(o[2], a);
             }
-            if (ok && !(dbg & 4))
-                *(plh_u32x2 *) ((char *) p.dst.ptr + (size_t) rpos * p.dst.pitch + (size_t) cpos * 8) = px;
+            if (ok && !(dbg & 4)) {
+                plh_u32x2 *d = (plh_u32x2 *) ((char *) p.dst.ptr + (size_t) rpos * p.dst.pitch + (size_t) cpos * 8);
+                // (an rgba16 target is a final frame: streamed; an rgba16hf one is the intermediate
+                // the next pass reads: cached)
+                if constexpr (F16DST)
+                    *d = px;
+                else
+                    __builtin_nontemporal_store(px, d);
+            }
         }
         __syncthreads();    // (everyone is done with this tile before the next one overwrites it)
     }

@@ -3,7 +3,7 @@
  * matrix pipe: k_polar_mx.hiph explains the numerics, the fragment layout and the live-row pairing)
  * on PERSISTENT workgroups, for the shapes that carry the benchmark configurations: RGB tiles of 8
  * wave-tile columns, an rgba16 / rgba16hf source whose fused pre-ops need no transcendental, and
- * the fused epilogue (dither + scale) or the map chain of an HDR pass behind the contraction.
+ * the fused epilogue (dither + scale) behind the contraction.
  *
  * Why. With the contraction on its live rows (54 MFMAs per wave tile) and 49 VALU instructions per
  * pixel, BASELINE configs[2] spent its time neither in the vector pipe nor in the matrix pipe but
@@ -17,25 +17,46 @@
  *   - the texels of the NEXT tile are requested (into registers: twelve) as soon as this tile's
  *     texels are in LDS, and arrive while this tile is contracted and stored;
  *   - the stores of a tile are never waited for: the wave goes on to the next tile.
- * The row-phase term is folded phase by phase (k_polar_mx.hiph: YPHASE) in every variant, which
- * frees the registers the prefetch needs and costs the epilogue nothing.
+ * The row-phase term is folded phase by phase (k_polar_mx.hiph: YPHASE), which frees the registers
+ * the prefetch needs and costs the epilogue nothing.
+ * What makes the overlap real is the memory counter: gfx950 has ONE counter for vector loads and
+ * stores, retired in order, so a wait for any load is a wait for everything issued before it. A
+ * tile's compute phase therefore issues no load at all -- the dither matrix (transposed: a lane
+ * owns a column of eight rows) lives in LDS for the workgroup's lifetime, the tile's 64 row-phase
+ * deviations arrive with its texels and are parked in LDS too -- and nothing is spilled (a scratch
+ * reload is a vector load like any other): between the request for the next tile's texels and the
+ * top of the next turn the wave only issues stores, which it never waits for.
+ * (The map-chain epilogue gathers from its lookup tables all the time: its variant measured
+ * 111.5 -> 115.6 us on persistent workgroups and stays on k_polar_mx.)
  *
- * Same arithmetic as k_polar_mx<3, true, POST, 8> with YPHASE: its CHAIN variants bit for bit, its
- * FAST variant up to where the row-phase term is added (before instead of inside the epilogue:
- * an fp32 ulp, the statement "one code of k_polar_pp" is unchanged). PL_HIP_MX_PERSIST=0 keeps
- * k_polar_mx (tests compare the two).
+ * Same arithmetic as k_polar_mx<3, true, MX_POST_FAST, 8>, bit for bit (the row-phase term is the
+ * same fma, a few instructions earlier). PL_HIP_MX_PERSIST=0 keeps k_polar_mx (tests compare the two).
  */
 #include "k_polar_mx.hiph"
 
-template <int POST>
+// A workgroup barrier that orders LDS traffic only. __syncthreads() is a release / acquire fence on
+// ALL memory around s_barrier: it waits for every global store of the wave to be acknowledged
+// (s_waitcnt vmcnt(0)) -- twice per tile, exactly the wait this kernel exists to avoid. The tile's
+// hand-over between waves goes through LDS alone: the wave's own LDS operations complete
+// (lgkmcnt(0)), then the barrier. (The "memory" clobber keeps the compiler from moving accesses
+// across it; the waits for data it tracks itself -- the prefetched texels -- it still inserts.)
+DEV void mxp_sync_lds()
+{
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
+#define MXP_DFY_BYTES   (MX_TILE_H * 4)
+#define MXP_STORE_DEFAULT 1         // (profiles/r06_08_store_kinds.txt: plain 25.6 us, non-temporal 22.3, system scope 51.8)
+#define MXP_DMAT_MAX    64          // largest dither matrix kept in LDS (64 x 64 floats = 16 KiB)
+
+// STORE: how the target is written -- 0: plain stores (write-back cached in the XCD's L2), 1:
+// non-temporal, 2: system-scope stores (sc0 sc1: written through the L2)
+template <int STORE>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4)))
 void k_polar_mxp(const plh_pass p_)
 {
     constexpr int NCH = 3, WTC = 8;
     using G = mx_geom<WTC>;
-    constexpr bool FAST = POST == MX_POST_FAST;
-    constexpr bool CHAIN = POST == MX_POST_CHAIN || POST == MX_POST_CHAIN_CR, CR = POST == MX_POST_CHAIN_CR;
-    static_assert(FAST || CHAIN, "the fused epilogue or the map chain");
     constexpr int NT = G::threads, PITCH = G::pitch, PLANE = G::plane, NV = G::nv;
     const plh_pass &p = plh_kernarg_pass();
     const plh_sampler_args &s = p.s;
@@ -43,6 +64,8 @@ void k_polar_mxp(const plh_pass p_)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char *bl = smem;
     unsigned char *tile = smem + MX_B_BYTES;
+    unsigned char *ldfy = tile + NCH * PLANE;           // the tile's 64 row-phase deviations
+    unsigned char *ldm = ldfy + MXP_DFY_BYTES;          // the dither matrix, transposed
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
 
     // uniforms, read once and pinned in SGPRs (k_polar_mx.hiph says why)
@@ -50,15 +73,12 @@ void k_polar_mxp(const plh_pass p_)
     int u_dpitch = p.dst.pitch, u_nt = p.nt_store, u_fx0 = p.frag_x0, u_fy0 = p.frag_y0;
     int u_has_dither = p.epi.has_dither, u_has_scale = p.epi.has_scale, u_emask = p.epi.mask, u_esize = p.epi.size;
     float u_osy = p.out_scale[1], u_ds = p.epi.dscale, u_di = p.epi.dinv, u_sc = p.epi.scale;
-    uintptr_t u_dptr = (uintptr_t) p.dst.ptr, u_matrix = (uintptr_t) p.epi.matrix, u_dfy = (uintptr_t) mx.dfy;
-    uintptr_t u_matrix_t = (uintptr_t) p.epi.matrix_t, u_dfx = (uintptr_t) mx.dfx;
+    uintptr_t u_dptr = (uintptr_t) p.dst.ptr, u_dfy = (uintptr_t) mx.dfy, u_dfx = (uintptr_t) mx.dfx;
     asm volatile("" : "+s"(u_height), "+s"(u_dst_h), "+s"(u_base_y), "+s"(u_dir_y), "+s"(u_dpitch),
                       "+s"(u_nt), "+s"(u_fx0), "+s"(u_fy0), "+s"(u_has_dither), "+s"(u_has_scale),
                       "+s"(u_emask), "+s"(u_esize));
-    asm volatile("" : "+s"(u_osy), "+s"(u_ds), "+s"(u_di), "+s"(u_sc), "+s"(u_dptr), "+s"(u_matrix), "+s"(u_dfy),
-                      "+s"(u_matrix_t), "+s"(u_dfx));
+    asm volatile("" : "+s"(u_osy), "+s"(u_ds), "+s"(u_di), "+s"(u_sc), "+s"(u_dptr), "+s"(u_dfy), "+s"(u_dfx));
     typedef __attribute__((address_space(1))) const float mx_gfloat;
-    typedef __attribute__((address_space(1))) const mx_f32x4 mx_gf4;
 
     // Workgroups go to the 8 XCDs round-robin in launch order and every XCD has its own L2: XCD x
     // works on the x-th contiguous eighth of the tiles (row-major), its workgroups side by side on
@@ -75,7 +95,9 @@ void k_polar_mxp(const plh_pass p_)
         first = (int) (lin >> 3);
     }
 
-    // ---- B fragments: global (L2 resident) -> LDS, once per workgroup ---------------------------
+    // ---- once per workgroup: B fragments and the (transposed) dither matrix, global (L2 resident)
+    // -> LDS without passing through registers (global_load_lds_dwordx4: wave-uniform LDS base +
+    // lane * 16) -------------------------------------------------------------------------------------
     const int nfrag = 8 * mx.npairs;
 #pragma unroll
     for (int f = wave; f < PLH_MX_NFRAG; f += NT / 64) {
@@ -84,6 +106,16 @@ void k_polar_mxp(const plh_pass p_)
         const unsigned char *g = (const unsigned char *) mx.bfrag + ((size_t) f * 64 + lane) * 16;
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *) g,
                                          (__attribute__((address_space(3))) void *) (bl + f * 1024), 16, 0, 0);
+    }
+    if (u_has_dither) {
+        const int kib = (u_esize * u_esize * 4) >> 10;      // (8 x 8 floats = 256 bytes: one partial piece)
+        const unsigned char *mt = (const unsigned char *) p.epi.matrix_t;
+        for (int f = wave; f < max(kib, 1); f += NT / 64) {
+            // (a matrix smaller than a piece: the lanes beyond it re-read its last 16 bytes)
+            const int off = min(f * 1024 + lane * 16, u_esize * u_esize * 4 - 16);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *) (mt + off),
+                                             (__attribute__((address_space(3))) void *) (ldm + f * 1024), 16, 0, 0);
+        }
     }
 
     int sw = s.src.w, sh = s.src.h, u_sfmt = s.src.fmt, u_spitch = s.src.pitch, u_npre = p.num_pre_ops;
@@ -110,9 +142,10 @@ void k_polar_mxp(const plh_pass p_)
     const int ln = lane & 15, lg = lane >> 4;
 
     // what a tile needs from memory, requested together: its texel pairs (one 16-byte load each,
-    // clamped addressing: sampling.c:45-181) and the lane's column-phase deviation
+    // clamped addressing: sampling.c:45-181), the lane's column-phase deviation and -- one per lane
+    // of a wave -- the phase deviations of the tile's 64 rows (the tables are padded to whole tiles)
     uint4 v[NV];
-    float nx_dfx;
+    float nx_dfx, nx_dfy;
     auto tile_load = [&](int t) {
         const int tby = (int) ((uint32_t) t / (uint32_t) tiles_x), tbx = t - tby * tiles_x;
         const int ox = u_org_x + 8 * WTC * tbx, oy = u_org_y + 16 * MX_WT_ROWS * tby;
@@ -124,8 +157,8 @@ void k_polar_mxp(const plh_pass p_)
                                     (u_sptr + (size_t) sy * (size_t) u_spitch + (size_t) px * 8);
             v[u] = make_uint4(q.x, q.y, q.z, q.w);
         }
-        // (the tables are padded to whole tiles)
         nx_dfx = ((mx_gfloat *) u_dfx)[G::tile_w * tbx + 16 * wave + ln];
+        nx_dfy = ((mx_gfloat *) u_dfy)[MX_TILE_H * tby + lane];
     };
     auto pair_store = [&](int ty_, int tp_, uint32_t o0, uint32_t o1, uint32_t o2) {
         unsigned char *d = tile + ty_ * PITCH + tp_ * 4;
@@ -139,27 +172,19 @@ void k_polar_mxp(const plh_pass p_)
     asm volatile("" : "+s"(u_row0), "+s"(u_row1), "+s"(u_npairs));
     const bool u_np4 = u_npairs > 3;
     const unsigned char *bfl1 = bfl + u_npairs * 4096;      // row phase 1's fragments
-    const bool u_tcol = FAST && u_has_dither && u_matrix_t && (u_fy0 & 7) == 0 && u_esize >= 8;
 
-#pragma unroll
-    for (int u = 0; u < NV; u++)
-        v[u] = make_uint4(0, 0, 0, 0);
-    nx_dfx = 0.0f;
-    if (first < band_size)
-        tile_load(band_first + first);
-
-#pragma unroll 1
-    for (int it = first; it < band_size; it += stride) {
-        const int t = band_first + it;
-        const int by = (int) ((uint32_t) t / (uint32_t) tiles_x), bx = t - by * tiles_x;
-        const int ox = u_org_x + 8 * WTC * bx, oy = u_org_y + 16 * MX_WT_ROWS * by;
+    // (the copies into LDS above are vector loads: complete, and visible to every wave, before the
+    // first tile is touched)
+    __syncthreads();
+    // ---- registers -> LDS: decode, the reference's "PASS A" per source texel (recorded pre-ops,
+    // f16 rounding = what the rgba16hf FBO store + load would do), planar stores; with them the
+    // tile's row-phase deviations. Returns the lane's column-phase deviation for that tile. --------
+    auto tile_to_lds = [&](int t) {
+        const int tby = (int) ((uint32_t) t / (uint32_t) tiles_x), tbx = t - tby * tiles_x;
+        const int ox = u_org_x + 8 * WTC * tbx, oy = u_org_y + 16 * MX_WT_ROWS * tby;
         const bool edge = ox < 0 || ox + G::src_w > sw;
-
-        // every wave is done with the previous tile's LDS image (first turn: nothing to wait for)
-        __syncthreads();
-
-        // ---- registers -> LDS: decode, the reference's "PASS A" per source texel (recorded pre-ops,
-        // f16 rounding = what the rgba16hf FBO store + load would do), planar stores ---------------
+        if (wave == 0)
+            ((float *) ldfy)[lane] = nx_dfy;
         if (edge) {
             // a pair at clamped positions: beyond the left edge both texels are the pair's first,
             // beyond the right edge both its second
@@ -238,98 +263,68 @@ void k_polar_mxp(const plh_pass p_)
                                mx_pack(c[2 * u].z, c[2 * u + 1].z));
             }
         }
+        return nx_dfx;
+    };
+
+    // (the copies into LDS above are vector loads: complete, and visible to every wave, before the
+    // first tile is touched)
+    __syncthreads();
+    // The loop is rotated: a turn computes tile t from LDS and, at its END, moves tile t + stride
+    // from the registers into LDS. The request for those texels, the sixteen stores of tile t and
+    // the first use of the texels then lie in ONE straight line of code, and the wait in front of
+    // that use counts past the stores (s_waitcnt vmcnt(16)); with the request in one turn and the
+    // use at the top of the next, the compiler has to assume the worst of the loop's entry and its
+    // back edge -- vmcnt(0), every store acknowledged -- at every tile.
+#pragma unroll
+    for (int u = 0; u < NV; u++)
+        v[u] = make_uint4(0, 0, 0, 0);
+    nx_dfx = nx_dfy = 0.0f;
+    float cur_dfx = 0.0f;
+    if (first < band_size) {
+        tile_load(band_first + first);
+        cur_dfx = tile_to_lds(band_first + first);
+    }
+
+#pragma unroll 1
+    for (int it = first; it < band_size; it += stride) {
+        const int t = band_first + it;
+        const int by = (int) ((uint32_t) t / (uint32_t) tiles_x), bx = t - by * tiles_x;
+        const bool more = it + stride < band_size;
 
         // the lane's column and its phase deviation (x 2^11)
         const int X = G::tile_w * bx + 16 * wave + ln;
-        const _Float16 dxh = (_Float16) nx_dfx;
+        const _Float16 dxh = (_Float16) cur_dfx;
         const mx_f16x8 dx8 = { dxh, dxh, dxh, dxh, dxh, dxh, dxh, dxh };
-        __syncthreads();
-        // the next tile's texels: asked for now, used after this tile's contraction and stores
-        if (it + stride < band_size)
+        // tile t is in LDS
+        mxp_sync_lds();
+        // the next tile's texels: asked for now, used behind this tile's contraction and stores.
+        // From here to that use this wave issues NO other load.
+        if (more)
             tile_load(t + stride);
 
+        // (uniform) the whole tile lies inside the pass and the target: nearly every tile
+        const int tx1 = G::tile_w * bx + G::tile_w - 1, ty0 = MX_TILE_H * by, ty1 = ty0 + MX_TILE_H - 1;
+        const int cp0 = p.base_x + p.dir_x * (G::tile_w * bx), cp1 = p.base_x + p.dir_x * tx1;
+        const int rp0 = u_base_y + u_dir_y * ty0, rp1 = u_base_y + u_dir_y * ty1;
+        const bool inside = tx1 < p.width && p.out_scale[0] * (float) tx1 < 1.0f && min(cp0, cp1) >= 0 &&
+                            max(cp0, cp1) < p.dst.w && ty1 < u_height && u_osy * (float) ty1 < 1.0f &&
+                            min(rp0, rp1) >= 0 && max(rp0, rp1) < u_dst_h;
+        const uintptr_t sink = (uintptr_t) mx.sink + (uint32_t) lane * 8u;
         const int cpos = p.base_x + p.dir_x * X;
         const bool cok = X < p.width && p.out_scale[0] * (float) X < 1.0f && cpos >= 0 && cpos < p.dst.w;
+        // the lane's column of the transposed dither matrix (bytes)
         const uint32_t tcol = (uint32_t) ((X + u_fx0) & u_emask) * (uint32_t) u_esize * 4u;
 
-#pragma unroll 1
-        for (int i = 0; i < MX_WT_ROWS; i++) {
+        // (both wave tiles written out: the store count of a turn must be a constant of the code)
+        static_assert(MX_WT_ROWS == 2, "two wave tiles per wave");
+        auto wave_tile = [&](auto wt) {
+            constexpr int i = decltype(wt)::value;
             // output pixels of this lane: column X, rows Y0 + 2 * r + py (r < 4, py < 2)
             const int Y0 = MX_TILE_H * by + 32 * i + 8 * lg;
-            float bias[8];
-            if constexpr (FAST) {
-                if (!u_has_dither) {
-#pragma unroll
-                    for (int q = 0; q < 8; q++)
-                        bias[q] = 0.0f;
-                } else if (u_tcol) {
-                    // eight consecutive entries of one COLUMN of the matrix: two 16-byte loads from
-                    // its transposed copy (k_polar_mx.hiph)
-                    const uint32_t iy0 = (uint32_t) (Y0 + u_fy0) & (uint32_t) u_emask;
-                    const mx_gf4 *pb = (mx_gf4 *) (u_matrix_t + tcol + iy0 * 4u);
-                    const mx_f32x4 b0 = pb[0], b1 = pb[1];
-#pragma unroll
-                    for (int q = 0; q < 4; q++) {
-                        bias[q] = b0[q];
-                        bias[4 + q] = b1[q];
-                    }
-                } else {
-                    const int ix = (X + u_fx0) & u_emask;
-#pragma unroll
-                    for (int q = 0; q < 8; q++) {
-                        const int iy = (Y0 + q + u_fy0) & u_emask;
-                        bias[q] = ((mx_gfloat *) u_matrix)[iy * u_esize + ix];
-                    }
-                }
-            }
-            // the row-phase deviations of the lane's rows (Y0 is a multiple of 8, the table starts on
-            // a 16-byte boundary): two 16-byte loads per row phase, folded in when the phase is done
-            const mx_gf4 *pd = (mx_gf4 *) ((mx_gfloat *) u_dfy + Y0);
-
-            mx_f32x4 acc[2][NCH];
             const unsigned char *ab = tile + (16 * i + ln + (lg >> 1)) * PITCH + (8 * wave + 8 * (lg & 1)) * 2;
-            __builtin_amdgcn_s_setprio(3);
-#pragma unroll
-            for (int py = 0; py < 2; py++) {
-                const unsigned char *ap = ab + (py ? u_row1 : u_row0) * PITCH;
-                const unsigned char *bp = py ? bfl1 : bfl;
-                mx_f32x4 ay[NCH];
-#pragma unroll
-                for (int ch = 0; ch < NCH; ch++) {
-                    acc[py][ch] = (mx_f32x4) (0.0f);
-                    ay[ch] = (mx_f32x4) (0.0f);
-                }
-                const mx_f32x4 d0 = pd[0], d1 = pd[1];
-                const float dfy[4] = { py ? d0[1] : d0[0], py ? d0[3] : d0[2], py ? d1[1] : d1[0], py ? d1[3] : d1[2] };
-                auto pair = [&](int j) {
-                    const unsigned char *bf = bp + 4 * j * 1024;
-                    const mx_f16x8 bhi = *(const mx_f16x8 *) bf;
-                    const mx_f16x8 blo = __builtin_elementwise_fma(*(const mx_f16x8 *) (bf + 2048), dx8, *(const mx_f16x8 *) (bf + 1024));
-                    const mx_f16x8 bdy = *(const mx_f16x8 *) (bf + 3072);
-#pragma unroll
-                    for (int ch = 0; ch < NCH; ch++) {
-                        const mx_f16x8 a = *(const mx_f16x8 *) (ap + ch * PLANE + 2 * j * PITCH);
-                        acc[py][ch] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, bhi, acc[py][ch], 0, 0, 0);
-                        acc[py][ch] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, blo, acc[py][ch], 0, 0, 0);
-                        ay[ch] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, bdy, ay[ch], 0, 0, 0);
-                    }
-                };
-                pair(0);
-                pair(1);
-                pair(2);
-                if (u_np4)
-                    pair(3);
-                // the lane's rows of phase py are Y0 + 2 r + py, r < 4
-#pragma unroll
-                for (int r = 0; r < 4; r++) {
-#pragma unroll
-                    for (int ch = 0; ch < NCH; ch++)
-                        acc[py][ch][r] = __builtin_fmaf(dfy[r], ay[ch][r], acc[py][ch][r]);
-                }
-            }
-            __builtin_amdgcn_s_setprio(0);
-
-            // ---- epilogue: post-ops, guarded store (dispatch.c:1126-1142) -----------------------
+            // the row-phase deviations of the lane's eight rows
+            const mx_f32x4 *pd = (const mx_f32x4 *) (ldfy + (32 * i + 8 * lg) * 4);
+            // op_dither (plain path) and the SCALE op with their parameters in SGPRs
             typedef __attribute__((address_space(1))) plh_u32x2 mx_gpx;
             const float ds = u_ds, di = u_di;
             const float sc = u_has_scale ? u_sc : 1.0f;
@@ -338,147 +333,118 @@ void k_polar_mxp(const plh_pass p_)
             if (u_has_dither)
                 aw = ds * di;
             aw *= sc;
-            if constexpr (FAST) {
-                const int rpos0 = u_base_y + u_dir_y * Y0, rpos7 = u_base_y + u_dir_y * (Y0 + 7);
-                const bool whole = (int) cok & (int) (Y0 + 7 < u_height) & (int) (u_osy * (float) (Y0 + 7) < 1.0f) &
-                                   (int) (min(rpos0, rpos7) >= 0) & (int) (max(rpos0, rpos7) < u_dst_h);
-                const bool all_whole = __builtin_amdgcn_ballot_w64(!whole) == 0;
-                auto store = [&](uintptr_t d, const plh_u32x2 px) {
-                    if (u_nt)
-                        __builtin_nontemporal_store(px, (mx_gpx *) d);
-                    else
-                        *(mx_gpx *) d = px;
+            const int rpos0 = u_base_y + u_dir_y * Y0;
+            const uintptr_t d0 = u_dptr + (size_t) rpos0 * (size_t) u_dpitch + (size_t) cpos * 8;
+            const ptrdiff_t step = (ptrdiff_t) u_dir_y * (ptrdiff_t) u_dpitch;
+            // eight consecutive entries of the lane's COLUMN of the dither matrix (no wrap: the
+            // fragment offset is a multiple of 8, plh_polar_mxp_applies)
+            const uint32_t iy0 = (uint32_t) (Y0 + u_fy0) & (uint32_t) u_emask;
+            const mx_f32x4 *pb = (const mx_f32x4 *) (ldm + tcol + iy0 * 4u);
+            // Row phase by row phase: contraction of the phase's live tap rows, the row-phase term,
+            // then the epilogue and the stores of ITS four rows (Y0 + 2 r + py) -- twelve accumulator
+            // registers live at a time instead of twenty-four, and the first phase's epilogue runs
+            // in the shadow of other waves' contractions.
+#pragma unroll
+            for (int py = 0; py < 2; py++) {
+                const unsigned char *ap = ab + (py ? u_row1 : u_row0) * PITCH;
+                const unsigned char *bp = py ? bfl1 : bfl;
+                mx_f32x4 acc[NCH], ay[NCH];
+#pragma unroll
+                for (int ch = 0; ch < NCH; ch++) {
+                    acc[ch] = (mx_f32x4) (0.0f);
+                    ay[ch] = (mx_f32x4) (0.0f);
+                }
+                auto pair = [&](int j) {
+                    const unsigned char *bf = bp + 4 * j * 1024;
+                    const mx_f16x8 bhi = *(const mx_f16x8 *) bf;
+                    const mx_f16x8 blo = __builtin_elementwise_fma(*(const mx_f16x8 *) (bf + 2048), dx8, *(const mx_f16x8 *) (bf + 1024));
+                    const mx_f16x8 bdy = *(const mx_f16x8 *) (bf + 3072);
+#pragma unroll
+                    for (int ch = 0; ch < NCH; ch++) {
+                        const mx_f16x8 a = *(const mx_f16x8 *) (ap + ch * PLANE + 2 * j * PITCH);
+                        acc[ch] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, bhi, acc[ch], 0, 0, 0);
+                        acc[ch] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, blo, acc[ch], 0, 0, 0);
+                        ay[ch] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, bdy, ay[ch], 0, 0, 0);
+                    }
                 };
-                auto rows = [&](auto dith) {
-                    constexpr bool DITHER = decltype(dith)::value;
-                    auto pixel = [&](int q) {
-                        const int r = q >> 1, py = q & 1;
+                __builtin_amdgcn_s_setprio(3);
+                pair(0);
+                pair(1);
+                pair(2);
+                if (u_np4)
+                    pair(3);
+                __builtin_amdgcn_s_setprio(0);
+                const mx_f32x4 dv0 = pd[0], dv1 = pd[1];
+                const float dfy[4] = { py ? dv0[1] : dv0[0], py ? dv0[3] : dv0[2], py ? dv1[1] : dv1[0], py ? dv1[3] : dv1[2] };
+                float bias[4] = { 0.0f, 0.0f, 0.0f, 0.0f };
+                if (u_has_dither) {
+                    const mx_f32x4 b0 = pb[0], b1 = pb[1];
+                    bias[0] = py ? b0[1] : b0[0]; bias[1] = py ? b0[3] : b0[2];
+                    bias[2] = py ? b1[1] : b1[0]; bias[3] = py ? b1[3] : b1[2];
+                }
+                // Four stores per phase and lane WHATEVER the tile -- no guard, no exec mask (the
+                // compiler branches around a masked store when no lane is left, and a path without
+                // the store makes the store count of a turn unknowable): a lane outside the target
+                // (clipped edge tiles only) stores to a sink nobody reads. Between the request for
+                // the next tile's texels and their use lie exactly sixteen stores per wave, which is
+                // what lets the wait in front of that use count past them.
+                auto rows = [&](auto dith, auto inside) {
+                    constexpr bool DITHER = decltype(dith)::value, INSIDE = decltype(inside)::value;
+#pragma unroll
+                    for (int r = 0; r < 4; r++) {
+                        const int q = 2 * r + py;
                         float o[NCH];
 #pragma unroll
                         for (int k = 0; k < NCH; k++) {
-                            o[k] = acc[py][k][r];
+                            o[k] = __builtin_fmaf(dfy[r], ay[k][r], acc[k][r]);
                             if (DITHER)
-                                o[k] = __builtin_floorf(__builtin_fmaf(ds, o[k], bias[q])) * di;
+                                o[k] = __builtin_floorf(__builtin_fmaf(ds, o[k], bias[r])) * di;
                             o[k] *= sc;
                         }
                         plh_u32x2 px;
                         px.x = plh_unorm16x2(o[0], o[1]);
                         px.y = plh_unorm16x2(o[2], aw);
-                        return px;
-                    };
-                    if (all_whole) {
-                        uintptr_t d = u_dptr + (size_t) rpos0 * (size_t) u_dpitch + (size_t) cpos * 8;
-                        const ptrdiff_t step = (ptrdiff_t) u_dir_y * (ptrdiff_t) u_dpitch;
-#pragma unroll
-                        for (int q = 0; q < 8; q++, d += step)
-                            store(d, pixel(q));
-                    } else {
-#pragma unroll
-                        for (int q = 0; q < 8; q++) {
-                            const int Y = Y0 + q;
-                            const int rpos = u_base_y + u_dir_y * Y;
-                            const bool ok = cok && Y < u_height && u_osy * (float) Y < 1.0f &&
-                                            rpos >= 0 && rpos < u_dst_h;
-                            const plh_u32x2 px = pixel(q);
-                            if (ok)
-                                store(u_dptr + (size_t) rpos * (size_t) u_dpitch + (size_t) cpos * 8, px);
+                        uintptr_t d = d0 + q * step;
+                        if (!INSIDE) {
+                            const int Y = Y0 + q, rpos = rpos0 + u_dir_y * q;
+                            const bool ok = (int) cok & (int) (Y < u_height) & (int) (u_osy * (float) Y < 1.0f) &
+                                            (int) (rpos >= 0) & (int) (rpos < u_dst_h);
+                            d = ok ? d : sink;
+                        }
+                        // (ONE kind of store per instantiation: `if (nt) non-temporal else plain`
+                        // is merged by the compiler into the plain one)
+                        if constexpr (STORE == 1) {
+                            __builtin_nontemporal_store(px, (mx_gpx *) d);
+                        } else if constexpr (STORE == 2) {
+                            const uint64_t both = (uint64_t) px.x | ((uint64_t) px.y << 32);
+                            __scoped_atomic_store_n((__attribute__((address_space(1))) uint64_t *) d, both,
+                                                    __ATOMIC_RELAXED, __MEMORY_SCOPE_SYSTEM);
+                        } else {
+                            *(mx_gpx *) d = px;
                         }
                     }
                 };
-                if (u_has_dither)
-                    rows(std::true_type{});
-                else
-                    rows(std::false_type{});
-            } else {
-                // the map chain as straight-line code, two pixels at a time, then the fused tail: ONE
-                // instance of the chain in a rolled loop over the lane's four row pairs (k_polar_mx.hiph)
-                constexpr int NP = 2;
-                int ylo, yhi;
-                if (u_dir_y > 0) {
-                    ylo = max(0, -u_base_y);
-                    yhi = min(u_height, u_dst_h - u_base_y);
+                if (inside) {
+                    if (u_has_dither)
+                        rows(std::true_type{}, std::true_type{});
+                    else
+                        rows(std::false_type{}, std::true_type{});
                 } else {
-                    ylo = max(0, u_base_y - u_dst_h + 1);
-                    yhi = min(u_height, u_base_y + 1);
-                }
-                const uint32_t ny = (uint32_t) max(yhi - ylo, 0);
-                const int eshift = __builtin_ctz((unsigned) max(u_esize, 1)) + 2;       // (bytes per matrix row)
-                const uint32_t ix4 = (uint32_t) ((X + u_fx0) & u_emask) << 2;
-                const ptrdiff_t step = (ptrdiff_t) u_dir_y * (ptrdiff_t) u_dpitch;
-                uintptr_t drow = u_dptr + (size_t) (u_base_y + u_dir_y * Y0) * (size_t) u_dpitch + (size_t) cpos * 8;
-
-                float cur[NCH][2], nx1[NCH][2], nx2[NCH][2], nx3[NCH][2];
-#pragma unroll
-                for (int k = 0; k < NCH; k++) {
-#pragma unroll
-                    for (int r = 0; r < 2; r++) {
-                        cur[k][r] = acc[0][k][r];
-                        nx1[k][r] = acc[1][k][r];
-                        nx2[k][r] = acc[0][k][2 + r];
-                        nx3[k][r] = acc[1][k][2 + r];
-                    }
-                }
-#pragma unroll 1
-                for (int part = 0; part < 4; part++) {
-                    const int yoff = 4 * (part >> 1) + (part & 1);      // the pair's rows: Y0 + yoff + {0, 2}
-                    float4_t outs[NP];
-                    float bq[NP];
-#pragma unroll
-                    for (int r = 0; r < NP; r++) {
-                        const uint32_t iy = (uint32_t) (Y0 + yoff + 2 * r + u_fy0) & (uint32_t) u_emask;
-                        bq[r] = u_has_dither ? *(mx_gfloat *) (u_matrix + ((iy << eshift) | ix4)) : 0.0f;
-                        outs[r] = { cur[0][r], cur[1][r], cur[2][r], 1.0f };
-                    }
-                    float pos[NP][2];
-                    if (CR) {
-#pragma unroll
-                        for (int r = 0; r < NP; r++) {
-                            pos[r][0] = p.out_scale[0] * ((float) X + 0.5f);
-                            pos[r][1] = u_osy * ((float) (Y0 + yoff + 2 * r) + 0.5f);
-                        }
-                    }
-                    run_map_chain<NP, CR>(outs, p, pos);
-#pragma unroll
-                    for (int r = 0; r < NP; r++) {
-                        const bool ok = cok && (uint32_t) (Y0 + yoff + 2 * r - ylo) < ny;
-                        float4_t c = outs[r];
-                        if (u_has_dither) {
-                            const float b = bq[r];
-                            c.x = __builtin_floorf(ds * c.x + b) * di;
-                            c.y = __builtin_floorf(ds * c.y + b) * di;
-                            c.z = __builtin_floorf(ds * c.z + b) * di;
-                        }
-                        if (u_has_scale) {
-                            c.x *= sc; c.y *= sc; c.z *= sc;
-                        }
-                        plh_u32x2 px;
-                        px.x = plh_unorm16x2(c.x, c.y);
-                        px.y = plh_unorm16x2(c.z, aw);
-                        if (ok) {
-                            const uintptr_t d = drow + (r ? 2 * step : 0);
-                            if (u_nt)
-                                __builtin_nontemporal_store(px, (mx_gpx *) d);
-                            else
-                                *(mx_gpx *) d = px;
-                        }
-                    }
-                    // the next pair of rows; its start is 1, 3, 1 rows further down
-                    drow += (part & 1) ? 3 * step : step;
-#pragma unroll
-                    for (int k = 0; k < NCH; k++) {
-#pragma unroll
-                        for (int r = 0; r < 2; r++) {
-                            cur[k][r] = nx1[k][r];
-                            nx1[k][r] = nx2[k][r];
-                            nx2[k][r] = nx3[k][r];
-                        }
-                    }
+                    if (u_has_dither)
+                        rows(std::true_type{}, std::false_type{});
+                    else
+                        rows(std::false_type{}, std::false_type{});
                 }
             }
-        }
+        };
+        wave_tile(std::integral_constant<int, 0>{});
+        wave_tile(std::integral_constant<int, 1>{});
+        // every wave is done with this tile's LDS image: the next one moves in
+        mxp_sync_lds();
+        if (more)
+            cur_dfx = tile_to_lds(t + stride);
     }
 }
-
 #undef ty
 #undef tp
 
@@ -491,36 +457,43 @@ bool plh_polar_mxp_applies(const plh_pass *pass)
     const int fmt = pass->s.src.fmt;
     if ((pass->s.comp_mask & 0xf) != 0x7 || (fmt != PLH_FMT_RGBA16 && fmt != PLH_FMT_RGBA16F))
         return false;
-    if (!plh_ops_lite(pass, 0, pass->num_pre_ops))
+    if (!plh_ops_lite(pass, 0, pass->num_pre_ops) || pass->chain.enabled)
         return false;
-    const bool post_lite = plh_ops_lite(pass, pass->num_pre_ops, pass->num_ops);
-    return pass->chain.enabled || (post_lite && pass->epi.enabled);
+    if (!plh_ops_lite(pass, pass->num_pre_ops, pass->num_ops) || !pass->epi.enabled)
+        return false;
+    // the dither matrix lives in LDS, transposed, and a lane reads eight consecutive rows of it
+    const plh_fast_epi &e = pass->epi;
+    if (e.has_dither && (!e.matrix_t || e.size < 8 || e.size > MXP_DMAT_MAX || (pass->frag_y0 & 7)))
+        return false;
+    return true;
 }
 
-template <int POST>
-static void launch_mxp_variant(hipStream_t stream, const plh_pass *pass)
+template <int STORE>
+static void launch_mxp(hipStream_t stream, const plh_pass *pass, int groups, size_t shmem)
 {
-    using G = mx_geom<8>;
-    const int tiles_x = (pass->width + G::tile_w - 1) / G::tile_w;
-    const int tiles_y = (pass->height + MX_TILE_H - 1) / MX_TILE_H;
-    const size_t shmem = MX_B_BYTES + (size_t) 3 * G::plane;
     static uint64_t lds_done;
-    (void) plh_kernel_needs_lds((const void *) k_polar_mxp<POST>, (plh_stream) stream, shmem, &lds_done);
-    // two workgroups per CU (LDS: 51.7 KiB each; 8 waves at <= 128 registers: 4 waves per SIMD)
-    int cus = 256;
-    (void) plh_stream_device((plh_stream) stream, &cus);
-    const int groups = min(tiles_x * tiles_y, 2 * cus);
-    PLH_LAUNCH_LAST((k_polar_mxp<POST>), dim3(groups), dim3(G::threads), shmem, stream, *pass);
+    (void) plh_kernel_needs_lds((const void *) k_polar_mxp<STORE>, (plh_stream) stream, shmem, &lds_done);
+    PLH_LAUNCH_LAST(k_polar_mxp<STORE>, dim3(groups), dim3(mx_geom<8>::threads), shmem, stream, *pass);
 }
 
 int plh_launch_polar_mxp(hipStream_t stream, const plh_pass *pass)
 {
-    if (pass->chain.enabled && pass->chain.contrast_recovery)
-        launch_mxp_variant<MX_POST_CHAIN_CR>(stream, pass);
-    else if (pass->chain.enabled)
-        launch_mxp_variant<MX_POST_CHAIN>(stream, pass);
+    using G = mx_geom<8>;
+    const int tiles_x = (pass->width + G::tile_w - 1) / G::tile_w;
+    const int tiles_y = (pass->height + MX_TILE_H - 1) / MX_TILE_H;
+    const size_t shmem = MX_B_BYTES + (size_t) 3 * G::plane + MXP_DFY_BYTES + MXP_DMAT_MAX * MXP_DMAT_MAX * 4;
+    // two workgroups per CU (LDS: 68 KiB each; 8 waves at <= 128 registers: 4 waves per SIMD)
+    int cus = 256;
+    (void) plh_stream_device((plh_stream) stream, &cus);
+    const int groups = min(tiles_x * tiles_y, 2 * cus);
+    const char *env = getenv("PL_HIP_MXP_STORE");
+    const int kind = env ? atoi(env) : (pass->nt_store ? MXP_STORE_DEFAULT : 0);
+    if (kind == 1)
+        launch_mxp<1>(stream, pass, groups, shmem);
+    else if (kind == 2)
+        launch_mxp<2>(stream, pass, groups, shmem);
     else
-        launch_mxp_variant<MX_POST_FAST>(stream, pass);
+        launch_mxp<0>(stream, pass, groups, shmem);
     const hipError_t err = hipGetLastError();
     return err == hipSuccess ? 0 : -(int) err;
 }

@@ -298,10 +298,7 @@ void k_polar_mxr(const plh_pass p_)
                         o2.y = (plh_unorm16x2(c.z, 0.0f) & 0xffffu) | awbits;
                         if (ok && !(dbg & 4)) {
                             const uintptr_t d = drow + (2 * rp + r) * step;
-                            if (u_nt)
-                                __builtin_nontemporal_store(o2, (gpx *) d);
-                            else
-                                *(gpx *) d = o2;
+                            __builtin_nontemporal_store(o2, (gpx *) d);     // (always: a final rgba16 frame; k_polar_mx.hiph)
                         }
                     }
                 }
@@ -327,10 +324,7 @@ void k_polar_mxr(const plh_pass p_)
                     o2.y = (plh_unorm16x2(o[r][2], 0.0f) & 0xffffu) | awbits;
                     if (ok && !(dbg & 4)) {
                         const uintptr_t d = drow + r * step;
-                        if (u_nt)
-                            __builtin_nontemporal_store(o2, (gpx *) d);
-                        else
-                            *(gpx *) d = o2;
+                        __builtin_nontemporal_store(o2, (gpx *) d);     // (always: a final rgba16 frame; k_polar_mx.hiph)
                     }
                 }
             }

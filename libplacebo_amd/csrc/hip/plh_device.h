@@ -139,6 +139,8 @@ struct plh_polar_mx {
     int32_t npairs;         // enabled == 1: row pairs per row phase (3 or 4)
     int32_t row_first[2];   // enabled == 1: tile row of the first pair's first row, output row pair 0
     int32_t pad2_;
+    void *sink;             // enabled == 1: 512 bytes nobody reads (k_polar_mxp.hip: where the lanes
+                            // outside the target put their store)
     const void *bfrag;      // device: [<= PLH_MX_NFRAG][64 lanes][8] f16
     const float *dfx, *dfy; // device: phase deviation of every output column / row, x 2^PLH_MX_DSHIFT
 };

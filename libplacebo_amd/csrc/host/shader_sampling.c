@@ -758,7 +758,8 @@ static bool polar_mx_build(pl_gpu gpu, pl_log log, struct sh_sampler_obj *obj,
     const size_t nfy = ((size_t) H + PLH_MX_PAD - 1) / PLH_MX_PAD * PLH_MX_PAD;
     const size_t frag_bytes = (size_t) PLH_MX_NFRAG * 64 * 8 * sizeof(uint16_t);
     const size_t o_dfx = frag_bytes, o_dfy = o_dfx + nfx * 4;
-    const size_t bytes = o_dfy + nfy * 4;
+    const size_t o_sink = o_dfy + nfy * 4;      // (512 bytes nobody reads: plh_polar_mx.sink)
+    const size_t bytes = o_sink + 512;
     uint8_t *blob = calloc(1, bytes);
     if (!slope[0] || !slope[1] || !blob) {
         free(slope[0]); free(slope[1]); free(blob);
@@ -890,6 +891,7 @@ static bool polar_mx_build(pl_gpu gpu, pl_log log, struct sh_sampler_obj *obj,
         // tile row of tap row first[py] for the output row pair 0: rows 2 m + py sample from base
         // rowbase[0] + m + (py ? c1y : 0)
         .row_first = { first[0], first[1] + c1y },
+        .sink = (void *) (base + o_sink),
         .bfrag = base,
         .dfx = (const float *) (base + o_dfx), .dfy = (const float *) (base + o_dfy),
     };

@@ -320,46 +320,48 @@ def test_mxd_unorm_source_and_rgba16_target(size):
 
 # ---- k_polar_mxp: the same contraction on persistent workgroups (round 6) ------------------------
 @pytest.mark.parametrize("size", [(96, 64), (130, 77), (1000, 562), (1920, 1080)])
-@pytest.mark.parametrize("case", ["dither10", "rgba16", "hdr_chain", "f16_source", "flipped"])
+@pytest.mark.parametrize("case", ["dither10", "rgba16", "f16_source", "flipped", "offset", "bayer16"])
 def test_mxp_persistent_kernel_against_k_polar_mx(size, case):
-    """k_polar_mxp (the library's default for RGB tiles behind the fused epilogue or the map chain:
-    2 x CUs resident workgroups walking the tiles of their XCD's band, the next tile's texels
-    prefetched during a tile's contraction, the B fragments in LDS once per workgroup) against
-    k_polar_mx, one workgroup per tile (PL_HIP_MX_PERSIST=0). The chain variants share the whole
-    arithmetic (row-phase term folded per phase in both): bit for bit. Behind the fused epilogue
-    k_polar_mx adds that term inside the epilogue, k_polar_mxp before it -- an fp32 ulp: one code /
-    one dither step on a sample in 10^4 at most. Sizes: fewer tiles than workgroups (every group
-    has at most one tile), clipped edge tiles, several tiles per workgroup (1080p -> 4K: 1020 tiles
-    on 512 groups) with bands that do not divide."""
+    """k_polar_mxp (the library's default for RGB tiles behind the fused epilogue: 2 x CUs resident
+    workgroups walking the tiles of their XCD's band, the next tile's texels prefetched during a
+    tile's contraction, B fragments and dither matrix in LDS once per workgroup, clipped lanes
+    storing to a sink) against k_polar_mx, one workgroup per tile (PL_HIP_MX_PERSIST=0): the same
+    arithmetic, bit for bit. Sizes: fewer tiles than workgroups, clipped edge tiles, several tiles
+    per workgroup (1080p -> 4K: 1020 tiles on 512 groups) with bands that do not divide; targets:
+    10-bit dithered (blue noise 64 x 64, Bayer 16 x 16), plain rgba16, flipped, offset by a
+    multiple of 8 rows (the dither column stays contiguous) and by an odd amount (k_polar_mx
+    keeps the pass: logged kernel choice is still the matrix pipe)."""
     sw, sh = size
     rng = np.random.default_rng(sw)
     kw, params, ten, fmt = {}, ewa(), False, "rgba16"
-    if case == "hdr_chain":
-        from test_gpu_fullsize import hdr_frame16
-        img = hdr_frame16(sw, sh)
-        params = pl.render_params("default", upscaler=pl.filter_config("ewa_lanczos"),
-                                  peak_detect_params=pl.peak_detect_params(percentile=99.995), **dither10())
-        kw = dict(image_kw=dict(color=pl.color_space("bt2020", "pq", max_luma=1000.0)),
-                  target_kw=dict(color=pl.color_space("bt709", "bt1886")))
+    dw, dh = 2 * sw, 2 * sh
+    img = rng.integers(0, 65536, (sh, sw, 4), dtype=np.uint16)
+    if case == "dither10":
+        params, ten = ewa(**dither10()), True
+    elif case == "bayer16":
+        params = ewa(dither_params=capi.DitherParams(method=pl.DITHER_ORDERED_LUT, lut_size=4, transfer=0),
+                     disable_dither_gamma_correction=True)
         ten = True
-    else:
-        img = rng.integers(0, 65536, (sh, sw, 4), dtype=np.uint16)
-        if case == "dither10":
-            params, ten = ewa(**dither10()), True
-        elif case == "f16_source":
-            img = (img.astype(np.float32) / 65535.0).astype(np.float16)
-            fmt = "rgba16hf"
-        elif case == "flipped":
-            kw = dict(target_kw=dict(crop=(2.0 * sw, 2.0 * sh, 0.0, 0.0)))
-    outs = []
-    for persist in ("1", "0"):
-        with env(PL_HIP_MX_PERSIST=persist):
-            outs.append(render(img, 2 * sw, 2 * sh, params, True, src_fmt=fmt, ten_bit=ten, expect_mx=True, **kw))
-    a, b = outs
-    assert a[..., :3].std() > 1000
-    if case == "hdr_chain":
+    elif case == "f16_source":
+        img = (img.astype(np.float32) / 65535.0).astype(np.float16)
+        fmt = "rgba16hf"
+    elif case == "flipped":
+        kw = dict(target_kw=dict(crop=(2.0 * sw, 2.0 * sh, 0.0, 0.0)))
+    elif case == "offset":
+        # target 24 columns / 16 + 5 rows larger: one crop on the 8-row grid, one off it
+        params, ten = ewa(**dither10()), True
+        dw, dh = 2 * sw + 24, 2 * sh + 21
+    crops = [None]
+    if case == "offset":
+        crops = [(8.0, 16.0, 8.0 + 2 * sw, 16.0 + 2 * sh), (3.0, 5.0, 3.0 + 2 * sw, 5.0 + 2 * sh)]
+    for crop in crops:
+        k2 = dict(kw)
+        if crop:
+            k2 = dict(target_kw=dict(crop=crop))
+        outs = []
+        for persist in ("1", "0"):
+            with env(PL_HIP_MX_PERSIST=persist):
+                outs.append(render(img, dw, dh, params, True, src_fmt=fmt, ten_bit=ten, expect_mx=True, **k2))
+        a, b = outs
+        assert a[..., :3].std() > 1000
         assert np.array_equal(a, b), util.diff_stats(a, b)
-    else:
-        d = np.abs(a.astype(np.int64) - b.astype(np.int64))
-        print("mxp vs mx (%s, %dx%d): %d samples differ, max %d" % (case, sw, sh, int((d > 0).sum()), int(d.max())))
-        assert d.max() <= (64 if ten else 1) and (d > 0).mean() <= 2e-4, (int(d.max()), float((d > 0).mean()))

@@ -34,12 +34,9 @@ def usage(built):
 # to 128 registers (4 waves per SIMD: worth 183 -> 172 us) and parks up to five dwords once per wave
 # tile, before the contraction, outside every loop body. Likewise the CHAIN variant of the
 # phase-class polar kernel on RGB f16 tiles (129 registers held to 128: 4 waves per SIMD).
-# The persistent matrix-pipe kernel (k_polar_mxp) holds the next tile's twelve prefetched registers
-# across a tile's contraction: at 128 registers it parks the LDS store offsets and load address
-# parts of a lane -- up to seven dwords, written once per workgroup, read once per TILE (outside the
-# wave-tile loop: six scratch loads against ~1500 instructions).
-TOLERATED_SPILL = {"k_polar_mx<3, true, 2, 8>": 20, "k_polar_pp<__half, 7u, 2, true, true, true>": 12,
-                   "k_polar_mxp<0>": 28, "k_polar_mxp<3>": 16, "k_polar_mxp<4>": 20}
+# (The persistent matrix-pipe kernel, k_polar_mxp, must NOT spill: a scratch reload is a vector load, and
+# waiting for it means waiting for every store issued before it -- the overlap the kernel exists for.)
+TOLERATED_SPILL = {"k_polar_mx<3, true, 2, 8>": 20, "k_polar_pp<__half, 7u, 2, true, true, true>": 12}
 
 
 def test_no_kernel_spills(usage):
@@ -58,7 +55,7 @@ BUDGET = [
     # the matrix-pipe polar kernel (exact 2x upscales): 8-wave tiles at 4 waves per SIMD for the
     # fast epilogue and for the colour map (RGB); 4-wave tiles at 3 otherwise
     (r"k_polar_mx<3, true, (0|2|3|4), 8>", 4),
-    (r"k_polar_mxp<(0|3|4)>", 4),
+    (r"k_polar_mxp<[012]>", 4),
     (r"k_polar_mx<3, (true|false), [012], 4>", 3),
     (r"k_polar_mx<4, true, [01], 4>", 3),
     (r"k_polar_mx<4, (true|false), 2, 4>", 2),
