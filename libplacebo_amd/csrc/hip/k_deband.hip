@@ -147,6 +147,13 @@ void k_deband(const plh_pass p_)
  */
 #define DBF_BW 64
 #define DBF_BH 4
+// the debanded plane's store (an rgba16hf intermediate that the next pass reads)
+#ifdef PLH_DEBAND_NT
+#define DEBAND_STORE16(dp, a, b, c, d) do { const plh_u32x4 v_ = { a, b, c, d }; \
+        __builtin_nontemporal_store(v_, (plh_u32x4 *) (dp)); } while (0)
+#else
+#define DEBAND_STORE16(dp, a, b, c, d) (*(uint4 *) (dp) = make_uint4(a, b, c, d))
+#endif
 
 // The fast kernels' threshold decision is the REFERENCE's. They average the four taps of a channel
 // as an integer sum (one rounding; the reference and the general kernel decode each tap and add
@@ -332,7 +339,7 @@ void k_deband_fast(const plh_pass p_)
 
     char *dp = (char *) p.dst.ptr + (size_t) idy * p.dst.pitch + (size_t) idx0 * 8;
     if (two)
-        *(uint4 *) dp = make_uint4(packed[0][0], packed[0][1], packed[1][0], packed[1][1]);
+        DEBAND_STORE16(dp, packed[0][0], packed[0][1], packed[1][0], packed[1][1]);
     else
         *(uint2 *) dp = make_uint2(packed[0][0], packed[0][1]);
 }
@@ -543,7 +550,7 @@ void k_deband_lds(const plh_pass p_)
             const bool inside = idx0 < p.width && idy[r] < p.height;
             char *dp = (char *) p.dst.ptr + (size_t) idy[r] * p.dst.pitch + (size_t) idx0 * 8;
             if (inside && two)
-                *(uint4 *) dp = make_uint4(packed[0][0], packed[0][1], packed[1][0], packed[1][1]);
+                DEBAND_STORE16(dp, packed[0][0], packed[0][1], packed[1][0], packed[1][1]);
             else if (inside)
                 *(uint2 *) dp = make_uint2(packed[0][0], packed[0][1]);
         }
