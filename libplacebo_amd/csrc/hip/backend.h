@@ -37,6 +37,9 @@ int plh_stream_device(plh_stream s, int *cus);
 // raise a kernel's dynamic-LDS limit on the stream's device, once per (kernel, device); `done` =
 // the caller's static per-kernel device mask
 int plh_kernel_needs_lds(const void *kernel, plh_stream s, size_t bytes, uint64_t *done);
+// the PQ transfer pair as piecewise cubics (pqseg.hiph) on the device that owns `s`: built and
+// uploaded on first use; consts = { m1, c3, m2, 1 / m2, 1 / m1 }. NULL = not available
+const void *plh_pqseg_tables(plh_stream s, const float consts[5]);
 void plh_stream_destroy(plh_stream s);
 int plh_stream_sync(plh_stream s);
 int plh_stream_idle(plh_stream s);   // 1 idle, 0 busy, < 0 error

@@ -380,3 +380,139 @@ extern "C" int plh_launch_clear_tiles(plh_stream s, const struct plh_view *dst, 
     const hipError_t err = hipGetLastError();
     return err == hipSuccess ? 0 : -(int) err;
 }
+
+/* ---- the PQ transfer pair as piecewise cubics (pqseg.hiph) ------------------------------------- */
+#include <math.h>
+#include <mutex>
+#include "pqseg.hiph"
+
+// The closed forms, in double, from the constants the ops carry (fp32, as the reference's shader
+// text prints them: src/shaders/colorspace.c:643-668, 745-775 and :1792-1799, :1985-1995) -- the
+// same functions pqmath.hiph evaluates in fp32: c1 = 1 - a, c2 = c3 + a.
+static double pqseg_oetf(double x, double m1, double c3, double m2)
+{
+    const double a = (double) PQ_A;
+    const double y = x > 0.0 ? pow(x, m1) : 0.0;
+    const double w = a * (1.0 - y) / (1.0 + c3 * y);
+    return exp(m2 * log1p(-w));
+}
+
+static double pqseg_eotf(double v, double c3, double inv_m2, double inv_m1)
+{
+    const double a = (double) PQ_A;
+    if (!(v > 0.0))
+        return 0.0;
+    const double u = -expm1(log(v) * inv_m2);
+    double inner = (a - u) / (a + c3 * u);
+    if (!(inner > 0.0))
+        return 0.0;
+    return pow(inner, inv_m1);
+}
+
+// the cubic through f at four nodes of [0, 1): coefficients of 1, u, u^2, u^3 (Newton's divided
+// differences, expanded)
+static void pqseg_fit(const double node[4], const double f[4], float out[4])
+{
+    double d[4] = { f[0], f[1], f[2], f[3] };
+    for (int j = 1; j < 4; j++) {
+        for (int i = 3; i >= j; i--)
+            d[i] = (d[i] - d[i - 1]) / (node[i] - node[i - j]);
+    }
+    // p(u) = d0 + (u - n0) (d1 + (u - n1) (d2 + (u - n2) d3))
+    double c[4] = { d[3], 0.0, 0.0, 0.0 };      // (highest power first while multiplying out)
+    int deg = 0;
+    for (int j = 2; j >= 0; j--) {
+        // c := c * (u - node[j]) + d[j]
+        double n[4] = { 0.0, 0.0, 0.0, 0.0 };
+        for (int i = 0; i <= deg; i++) {
+            n[i] += c[i];
+            n[i + 1] -= c[i] * node[j];
+        }
+        deg++;
+        n[deg] += d[j];
+        for (int i = 0; i <= deg; i++)
+            c[i] = n[i];
+    }
+    out[0] = (float) c[3];
+    out[1] = (float) c[2];
+    out[2] = (float) c[1];
+    out[3] = (float) c[0];
+}
+
+// consts = { m1, c3, m2, 1 / m2, 1 / m1 } (struct pq_consts before its log2(e)); out: PQSEG_N pieces
+// of four floats -- OETF pieces first, then the EOTF's fine and coarse ones (pqseg.hiph)
+static void plh_pqseg_build(const float consts[5], float *out)
+{
+    const double m1 = consts[0], c3 = consts[1], m2 = consts[2], inv_m2 = consts[3], inv_m1 = consts[4];
+    double cheb[4];
+    for (int k = 0; k < 4; k++)
+        cheb[k] = 0.5 - 0.5 * cos((2 * k + 1) * M_PI / 8.0);
+    for (int s = 0; s < PQSEG_O_N; s++) {
+        double f[4];
+        for (int k = 0; k < 4; k++)
+            f[k] = pqseg_oetf(exp2((double) (PQSEG_O_T0 + s) + cheb[k]), m1, c3, m2);
+        pqseg_fit(cheb, f, out + 4 * s);
+    }
+    float *eo = out + 4 * PQSEG_O_N;
+    for (int s = 0; s < PQSEG_E_N; s++) {
+        const bool lo = s < PQSEG_E_LO_N;
+        const double h = lo ? (double) PQSEG_E_SPLIT / (128.0 * PQSEG_E_LO_N) : 1.0 / 128.0;
+        const double v0 = lo ? s * h : (s - PQSEG_E_LO_N + PQSEG_E_SPLIT) * h;
+        // (the first piece starts AT zero, where the curve is exactly zero: black stays black)
+        const double first[4] = { 0.0, 0.3, 0.65, 0.95 };
+        const double *node = s == 0 ? first : cheb;
+        double f[4];
+        for (int k = 0; k < 4; k++)
+            f[k] = pqseg_eotf(v0 + h * node[k], c3, inv_m2, inv_m1);
+        pqseg_fit(node, f, eo + 4 * s);
+    }
+}
+
+// Test hook (tests/test_pqseg.py, CPU): the tables as the host builds them
+extern "C" __attribute__((visibility("default")))
+void plh_test_pqseg_build(const float consts[5], float *out)
+{
+    plh_pqseg_build(consts, out);
+}
+
+// The tables on the device that owns `s`, built and uploaded on first use (one per device and set
+// of constants -- in practice one: the constants are SMPTE ST 2084's), kept for the life of the
+// process. NULL = not available (allocation failed): the kernels then keep the closed forms.
+struct pqseg_slot { int dev; float consts[5]; void *ptr; };
+static std::mutex g_pqseg_mutex;
+static pqseg_slot g_pqseg[16];
+static int g_pqseg_n;
+
+extern "C" const void *plh_pqseg_tables(plh_stream s, const float consts[5])
+{
+    const int dev = plh_stream_device(s, NULL);
+    std::lock_guard<std::mutex> lock(g_pqseg_mutex);
+    for (int i = 0; i < g_pqseg_n; i++) {
+        if (g_pqseg[i].dev == dev && !memcmp(g_pqseg[i].consts, consts, sizeof(g_pqseg[i].consts)))
+            return g_pqseg[i].ptr;
+    }
+    if (g_pqseg_n == 16)
+        return NULL;
+    static float host[PQSEG_N * 4];
+    plh_pqseg_build(consts, host);
+    int cur = dev;
+    (void) hipGetDevice(&cur);
+    if (cur != dev && hipSetDevice(dev) != hipSuccess)
+        return NULL;
+    void *p = NULL;
+    bool ok = hipMalloc(&p, PQSEG_BYTES) == hipSuccess;
+    // (a blocking copy on the null stream: once per process and device)
+    ok = ok && hipMemcpy(p, host, PQSEG_BYTES, hipMemcpyHostToDevice) == hipSuccess;
+    if (cur != dev)
+        (void) hipSetDevice(cur);
+    if (!ok) {
+        if (p)
+            (void) hipFree(p);
+        p = NULL;
+    }
+    pqseg_slot &e = g_pqseg[g_pqseg_n++];
+    e.dev = dev;
+    memcpy(e.consts, consts, sizeof(e.consts));
+    e.ptr = p;
+    return p;
+}

@@ -1335,6 +1335,189 @@ void k_bilinear_tab(const plh_pass p_, const float *colw_, const float *roww_, i
     }
 }
 
+/*
+ * k_bilinear_strip (round 6): the 2x bilinear upscale as a stream -- ONE 16-byte load per 2 x 2
+ * output cell. k_bilinear_fast and k_bilinear_tab fetch the four texels of every cell (four
+ * 8-byte gathers per lane) and recompute, or look up, the geometry per cell; but with the geometry
+ * proven separable (k_bilinear_tab_build: zero deviating pixels, base texel = b0 + cell index on
+ * both axes) a column of cells is a sliding window down the source: cell row cy blends source rows
+ * (b0y + cy, b0y + cy + 1), the next one (b0y + cy + 1, b0y + cy + 2). A wave owns 64 cell columns
+ * and BS_ROWS consecutive cell rows: it requests the BS_ROWS + 1 source rows it needs at once (the
+ * lane's two texels x0, x0 + 1 as one 16-byte load each: all of a wave's memory parallelism up
+ * front), decodes and blends each row horizontally ONCE (it is the bottom row of one cell and the
+ * top row of the next), and per cell does the vertical blends, the epilogue and two 16-byte
+ * non-temporal stores. The lane's column weights live in registers for the whole strip, the row
+ * weights are scalar loads. Arithmetic: k_bilinear_tab's statement for statement, i.e.
+ * k_bilinear_fast's bit for bit (tests/test_gpu_kernel_variants.py). Per cell ~90 vector
+ * instructions where k_bilinear_fast has ~330 -- and the memory shape of the bare 2x expand that
+ * profiles/r02_hbm_rate.txt measured at 12.7 us.
+ * MEASURED (profiles/r06_11_strip_ab.txt, r06_12_strip_rows.txt): 20.2 us in the trace at two cell
+ * rows per wave, 24.0 / 23.8 at four / eight, k_bilinear_fast 19.0 on the same box. A third of the
+ * instructions and a quarter of the load instructions bought nothing: the pass is bound by how
+ * many bytes its waves keep in flight, and a wave that waits for ALL its rows before its first
+ * store keeps fewer than four waves that each wait for one cell. Opt-in (PL_HIP_BILIN_STRIP=1),
+ * kept as the record of the experiment VERDICT r05 item 6 asked for.
+ */
+#define BS_ROWS_DEFAULT 2      // (20.2 us; 4: 24.0, 8: 23.8 -- profiles/r06_12_strip_rows.txt)
+template <bool F16SRC, bool RGB, int BS_ROWS>
+__global__ __launch_bounds__(64)
+void k_bilinear_strip(const plh_pass p_, const float *colw_, const float *roww_, int b0x, int b0y)
+{
+    const plh_pass &p = plh_kernarg_pass();
+    const plh_sampler_args &s = p.s;
+    constexpr int NCH = RGB ? 3 : 4;
+    int W = p.width, H = p.height, padx = p.cell_padx, pady = p.cell_pady;
+    int spitch = s.src.pitch, srcw = s.src.w, srch = s.src.h;
+    int dmask = p.epi.mask, dsize = p.epi.size, has_dither = p.epi.has_dither, has_scale = p.epi.has_scale;
+    int fx0 = p.frag_x0, fy0 = p.frag_y0, bx = p.base_x, by = p.base_y, dirx = p.dir_x, diry = p.dir_y;
+    int dw = p.dst.w, dh = p.dst.h, dpitch = p.dst.pitch;
+    float ds = p.epi.dscale, di = p.epi.dinv, sc = p.epi.scale, alpha = p.epi.alpha, sscale = s.scale;
+    uintptr_t sp = (uintptr_t) s.src.ptr, dmat = (uintptr_t) p.epi.matrix, dptr = (uintptr_t) p.dst.ptr;
+    uintptr_t colw = (uintptr_t) colw_, roww = (uintptr_t) roww_;
+    asm volatile("" : "+s"(W), "+s"(H), "+s"(padx), "+s"(pady), "+s"(spitch), "+s"(srcw), "+s"(srch),
+                      "+s"(dmask), "+s"(dsize), "+s"(has_dither), "+s"(has_scale), "+s"(fx0), "+s"(fy0));
+    asm volatile("" : "+s"(bx), "+s"(by), "+s"(dirx), "+s"(diry), "+s"(dw), "+s"(dh), "+s"(dpitch),
+                      "+s"(ds), "+s"(di), "+s"(sc), "+s"(alpha), "+s"(sscale));
+    asm volatile("" : "+s"(sp), "+s"(dmat), "+s"(dptr), "+s"(colw), "+s"(roww), "+s"(b0x), "+s"(b0y));
+    typedef BF_GLOBAL const float gfloat;
+    typedef __attribute__((address_space(4))) const float cfloat;
+
+    const int cx = blockIdx.x * 64 + threadIdx.x;
+    const int cy0 = blockIdx.y * BS_ROWS;
+    const int idx0 = 2 * cx - padx;
+    if (idx0 >= W)
+        return;
+    // the lane's two texels of a row: x0 = clamp(b), x1 = clamp(b + 1) as ONE 16-byte load at
+    // clamp(b, 0, w - 2); beyond the left edge both are the pair's first, beyond the right edge its
+    // second (the launcher requires a source at least two texels wide)
+    const int b = b0x + cx;
+    const int pcol = min(max(b, 0), srcw - 2);
+    const bool ldup = b < 0, hdup = b > srcw - 2;
+    typedef BF_GLOBAL const plh_u32x4 __attribute__((aligned(8))) gquad;
+    plh_u32x4 raw[BS_ROWS + 1];
+#pragma unroll
+    for (int k = 0; k <= BS_ROWS; k++) {
+        const int y = min(max(b0y + cy0 + k, 0), srch - 1);
+        raw[k] = *(gquad *) (sp + (size_t) y * (size_t) spitch + (size_t) pcol * 8);
+    }
+    // weights of the cell's columns (one 8-byte load; the table is padded by one entry at either
+    // end, which repeat the first / last weight)
+    const plh_u32x2 axw = *(BF_GLOBAL const plh_u32x2 *) (colw + (size_t) (idx0 + 1) * 4);
+    const float ax[2] = { __uint_as_float(axw.x), __uint_as_float(axw.y) };
+    const int ox0 = bx + dirx * idx0, ox1 = bx + dirx * (idx0 + 1);
+    const bool okx0 = idx0 >= 0 && ox0 >= 0 && ox0 < dw, okx1 = idx0 + 1 < W && ox1 >= 0 && ox1 < dw;
+    const bool alpha_one = RGB && alpha == 1.0f;
+    float aw = 1.0f;
+    if (has_dither)
+        aw = ds * di;
+    if (has_scale)
+        aw *= sc;
+    const uint32_t awbits = plh_unorm16x2(0.0f, aw) & 0xffff0000u;
+
+    // a source row, decoded and blended horizontally for the cell's two columns
+    auto hblend = [&](plh_u32x4 v, float (&h)[2][NCH]) {
+        if (ldup) { v.z = v.x; v.w = v.y; }
+        if (hdup) { v.x = v.z; v.y = v.w; }
+        const uint32_t w0[4] = { v.x & 0xffff, v.x >> 16, v.y & 0xffff, v.y >> 16 };
+        const uint32_t w1[4] = { v.z & 0xffff, v.z >> 16, v.w & 0xffff, v.w >> 16 };
+#pragma unroll
+        for (int ch = 0; ch < NCH; ch++) {
+            const float t0 = F16SRC ? plh_h2f(w0[ch]) : plh_un16(w0[ch]);
+            const float t1 = F16SRC ? plh_h2f(w1[ch]) : plh_un16(w1[ch]);
+            h[0][ch] = plh_mix(t0, t1, ax[0]);
+            h[1][ch] = plh_mix(t0, t1, ax[1]);
+        }
+    };
+    // Every row has ARRIVED before the first store is issued: gfx950 retires vector loads and stores
+    // through one in-order counter, and the stores below sit behind guards -- waiting for row k + 2
+    // behind the stores of cell k would be a wait for those stores (23.8 us against k_bilinear_fast's
+    // 19.0 when the rows were left to be waited for one by one: profiles/r06_11_strip_ab.txt).
+#pragma unroll
+    for (int k = 0; k <= BS_ROWS; k++)
+        asm volatile("" : "+v"(raw[k].x), "+v"(raw[k].y), "+v"(raw[k].z), "+v"(raw[k].w));
+    float top[2][NCH], bot[2][NCH];
+    hblend(raw[0], top);
+#pragma unroll
+    for (int k = 0; k < BS_ROWS; k++) {
+        const int cy = cy0 + k, idy0 = 2 * cy - pady;
+        if (idy0 >= H)
+            break;      // (uniform)
+        hblend(raw[k + 1], bot);
+        const float ay[2] = { ((cfloat *) roww)[idy0 + 1], ((cfloat *) roww)[idy0 + 2] };
+        float bias[4] = { 0.0f, 0.0f, 0.0f, 0.0f };
+        if (has_dither) {
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                const int ix = (idx0 + (q & 1) + fx0) & dmask;
+                const int iy = (idy0 + (q >> 1) + fy0) & dmask;
+                bias[q] = ((gfloat *) dmat)[iy * dsize + ix];
+            }
+        }
+        float4_t o[4];
+#pragma unroll
+        for (int ch = 0; ch < NCH; ch++) {
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                const float v = sscale * plh_mix(top[q & 1][ch], bot[q & 1][ch], ay[q >> 1]);
+                if (ch == 0) o[q].x = v;
+                if (ch == 1) o[q].y = v;
+                if (ch == 2) o[q].z = v;
+                if (ch == 3) o[q].w = v;
+            }
+        }
+        // epilogue: op_dither (plain path) + the SCALE op, as k_bilinear_tab
+        uint2 px[4];
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            if (RGB)
+                o[q].w = alpha;
+            if (has_dither) {
+                const float bq = bias[q];
+                o[q].x = __builtin_floorf(ds * o[q].x + bq) * di;
+                o[q].y = __builtin_floorf(ds * o[q].y + bq) * di;
+                o[q].z = __builtin_floorf(ds * o[q].z + bq) * di;
+                if (!alpha_one)
+                    o[q].w = __builtin_floorf(ds * o[q].w + bq) * di;
+            }
+            if (has_scale) {
+                o[q].x *= sc; o[q].y *= sc; o[q].z *= sc;
+                if (!alpha_one)
+                    o[q].w *= sc;
+            }
+            px[q].x = plh_unorm16x2(o[q].x, o[q].y);
+            px[q].y = alpha_one ? ((plh_unorm16x2(o[q].z, 0.0f) & 0xffffu) | awbits) : plh_unorm16x2(o[q].z, o[q].w);
+        }
+        // the cell's two rows: both pixels in one 16-byte non-temporal store where both exist (the
+        // fused epilogue's target is a final rgba16 frame)
+        typedef BF_GLOBAL plh_u32x2 gpair;
+#pragma unroll
+        for (int j = 0; j < 2; j++) {
+            const int idy = idy0 + j, oy = by + diry * idy;
+            if (idy < 0 || idy >= H || oy < 0 || oy >= dh)
+                continue;
+            const uintptr_t row = dptr + (size_t) oy * (size_t) dpitch;
+            const uint2 a = px[2 * j], c = px[2 * j + 1];
+            if (okx0 && okx1 && ox1 == ox0 + 1) {
+                typedef plh_u32x4 __attribute__((aligned(8))) quad8;
+                const quad8 pk = { a.x, a.y, c.x, c.y };
+                __builtin_nontemporal_store(pk, (BF_GLOBAL quad8 *) (row + (size_t) ox0 * 8));
+                continue;
+            }
+            const plh_u32x2 lo = { a.x, a.y }, hi = { c.x, c.y };
+            if (okx0)
+                __builtin_nontemporal_store(lo, (gpair *) (row + (size_t) ox0 * 8));
+            if (okx1)
+                __builtin_nontemporal_store(hi, (gpair *) (row + (size_t) ox1 * 8));
+        }
+#pragma unroll
+        for (int i = 0; i < 2; i++) {
+#pragma unroll
+            for (int ch = 0; ch < NCH; ch++)
+                top[i][ch] = bot[i][ch];
+        }
+    }
+}
+
 // The tables of a geometry, built and proven on first use (one launch + one read-back) and kept
 // for the life of the process: a handful of geometries per application.
 #include <mutex>
@@ -1363,8 +1546,12 @@ static const bl_slot *bilinear_tables(hipStream_t stream, const plh_pass *pass)
     // item 6 asked for this experiment and for the item to be closed if it lost. It is kept
     // selectable (PL_HIP_BILIN_TABLES=1) because its frames are proven identical and it is the
     // record of the measurement.
-    const char *env = getenv("PL_HIP_BILIN_TABLES");
-    if (!env || env[0] != '1')
+    // (round 6: the tables are also what k_bilinear_strip runs on, PL_HIP_BILIN_STRIP=1 -- it lost as
+    // well: 20.2 us in the trace with two cell rows per wave, 24.0 / 23.8 with four / eight, against
+    // k_bilinear_fast's 19.0 on the same box, profiles/r06_11_strip_ab.txt, r06_12_strip_rows.txt)
+    const char *env = getenv("PL_HIP_BILIN_TABLES"), *strip = getenv("PL_HIP_BILIN_STRIP");
+    const bool want_tab = env && env[0] == '1', want_strip = strip && strip[0] == '1';
+    if (!want_tab && !(want_strip && pass->s.src.w >= 2 && pass->dst.fmt == PLH_FMT_RGBA16))
         return nullptr;
     bl_key key = {};
     key.dev = plh_stream_device((plh_stream) stream, nullptr);
@@ -1437,6 +1624,27 @@ static void launch_bilinear_tab(hipStream_t stream, const plh_pass *pass, const 
 {
     const int cells_w = (pass->width + pass->cell_padx + 1) / 2;
     const int cells_h = (pass->height + pass->cell_pady + 1) / 2;
+    const char *env = getenv("PL_HIP_BILIN_TABLES");
+    if (!(env && env[0] == '1')) {
+        // the strip kernel: a wave per 64 cell columns x ROWS cell rows
+        const char *renv = getenv("PL_HIP_BILIN_STRIP_ROWS");
+        const int rows = renv ? atoi(renv) : BS_ROWS_DEFAULT;
+#define BS_LAUNCH(R) do { \
+            const dim3 sgrid((cells_w + 63) / 64, (cells_h + R - 1) / R); \
+            if (pass->epi.has_alpha) \
+                PLH_LAUNCH_LAST((k_bilinear_strip<F16SRC, true, R>), sgrid, dim3(64), 0, stream, *pass, tab->colw, tab->roww, tab->b0x, tab->b0y); \
+            else \
+                PLH_LAUNCH_LAST((k_bilinear_strip<F16SRC, false, R>), sgrid, dim3(64), 0, stream, *pass, tab->colw, tab->roww, tab->b0x, tab->b0y); \
+        } while (0)
+        if (rows == 8)
+            BS_LAUNCH(8);
+        else if (rows == 2)
+            BS_LAUNCH(2);
+        else
+            BS_LAUNCH(4);
+#undef BS_LAUNCH
+        return;
+    }
     const dim3 block(BF_BW, BF_BH), grid((cells_w + BF_BW - 1) / BF_BW, (cells_h + BF_BH - 1) / BF_BH);
     if (pass->epi.has_alpha)
         PLH_LAUNCH_LAST((k_bilinear_tab<F16SRC, true>), grid, block, 0, stream, *pass, tab->colw, tab->roww, tab->b0x, tab->b0y);
@@ -1677,6 +1885,13 @@ extern "C" int plh_launch_pass(plh_stream stream_, const struct plh_pass *pass)
             const int cells_w = (local.width + CHAIN_NP - 1) / CHAIN_NP;
             const dim3 grid((cells_w + PASS_BW - 1) / PASS_BW, (local.height + PASS_BH - 1) / PASS_BH);
             const bool f16 = local.s.src.fmt == PLH_FMT_RGBA16F;
+            // (The PQ pair as piecewise cubics in LDS, pqseg.hiph, was tried here as k_pass_chain_seg and
+            // dropped: 14 % fewer vector instructions and the same time -- 94.5 us against 93.5 with the
+            // tables staged per 64 x 4 pixels, 100 / 102 with two / eight rows per workgroup, whose
+            // gathers then wait for the previous row's store, 119 with two pixels per lane
+            // (profiles/r06_16_seg_ab.txt, r06_17_seg_ab.txt). At eight waves per SIMD this pass is
+            // bound by the latency chain load -> tone gather -> gamut gathers -> store, not by
+            // instruction issue; k_polar_mx at four waves per SIMD is, and gains 14 %.)
             if (local.chain.contrast_recovery) {
                 if (f16) PLH_LAUNCH_LAST((k_pass_chain<true, CHAIN_NP, true>), grid, block, 0, stream, local);
                 else     PLH_LAUNCH_LAST((k_pass_chain<false, CHAIN_NP, true>), grid, block, 0, stream, local);

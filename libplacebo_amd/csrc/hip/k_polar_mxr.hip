@@ -72,6 +72,19 @@ void k_polar_mxr(const plh_pass p_)
     unsigned char *tile = smem + MXR_B_BYTES;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int ln = lane & 15, lg = lane >> 4;
+    // (CHAIN) the PQ pair's piecewise cubics behind the tile (pqseg.hiph), read from the first row
+    // phase's epilogue on -- behind that phase's barriers
+    unsigned char *segl = tile + 3 * MXR_PLANE;
+    uintptr_t u_segp = 0;
+    uint32_t u_segr = 0;
+    if constexpr (CHAIN) {
+        u_segp = (uintptr_t) p.chain.pq_seg_ptr;
+        u_segr = (uint32_t) p.chain.pq_seg_rshift;
+        asm volatile("" : "+s"(u_segp), "+s"(u_segr));
+        if (u_segp)
+            pq_seg_stage(segl, (const void *) u_segp, u_segr, (uint32_t) tid, (uint32_t) MXR_NT);
+    }
+    const pq_seg seg = pq_seg_view(segl, u_segr, (uint32_t) lane, u_segp != 0);
 #ifdef PLH_MX_DEBUG
     const int dbg = s.pp_debug;     // (profiling aid: only in a -DPLH_MX_DEBUG build, k_polar_mx.hiph)
 #else
@@ -278,7 +291,7 @@ void k_polar_mxr(const plh_pass p_)
                         outs[r] = { rp ? o[2 + r][0] : o[r][0], rp ? o[2 + r][1] : o[r][1],
                                     rp ? o[2 + r][2] : o[r][2], 1.0f };
                     }
-                    run_map_chain<2, false>(outs, p);
+                    run_map_chain<2, false, true, true>(outs, p, nullptr, &seg);
 #pragma unroll
                     for (int r = 0; r < 2; r++) {
                         const int Y = Y0 + R * (2 * rp + r);
@@ -364,9 +377,20 @@ int plh_launch_polar_mxr(hipStream_t stream, const plh_pass *pass)
     const int nbx = (pass->width - 1 + pass->s.mx.sx) / R + 1, nby = (pass->height - 1 + pass->s.mx.sy) / R + 1;
     const int tbx = MXR_TSX / G;
     const int tiles = ((nbx + tbx - 1) / tbx) * ((nby + MXR_TBY - 1) / MXR_TBY);
-    const size_t shmem = MXR_B_BYTES + (size_t) 3 * (G * MXR_TBY + 8) * MXR_PITCH;
+    size_t shmem = MXR_B_BYTES + (size_t) 3 * (G * MXR_TBY + 8) * MXR_PITCH;
     const bool chain = pass->chain.enabled;
-#define MXR_LAUNCH(RR, GG, CH) PLH_LAUNCH_LAST((k_polar_mxr<RR, GG, CH>), dim3(tiles), dim3(MXR_NT), shmem, stream, *pass)
+    const plh_pass *arg = pass;
+    plh_pass local;
+    if (chain && pass->chain.pq_seg) {
+        // the PQ pair as piecewise cubics in LDS (pqseg.hiph)
+        local = *pass;
+        local.chain.pq_seg_rshift = 0;
+        local.chain.pq_seg_ptr = plh_pqseg_tables((plh_stream) stream, pass->chain.pq_seg_consts);
+        if (local.chain.pq_seg_ptr)
+            shmem += PQSEG_BYTES;
+        arg = &local;
+    }
+#define MXR_LAUNCH(RR, GG, CH) PLH_LAUNCH_LAST((k_polar_mxr<RR, GG, CH>), dim3(tiles), dim3(MXR_NT), shmem, stream, *arg)
     if (G == 2 && R == 3 && chain)  MXR_LAUNCH(3, 2, true);
     else if (G == 2 && R == 3)      MXR_LAUNCH(3, 2, false);
     else if (G == 2)

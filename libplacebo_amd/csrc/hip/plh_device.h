@@ -331,6 +331,14 @@ struct plh_map_chain {
     //             that step of op_delinearize).
     int32_t pq_front, out_rescaled;
     float in_mat[9], out_mat[9], out_add;
+    // The PQ pair of the colour map (and of a pq_front linearisation) as piecewise cubics in LDS
+    // (pqseg.hiph). The matcher sets pq_seg = 1 when the chain has the stages and their constants
+    // agree, and leaves the constants { m1, c3, m2, 1 / m2, 1 / m1 }; a launcher whose kernel has the
+    // variant asks for the device's tables (plh_pqseg_tables) and sets pq_seg_ptr / pq_seg_rshift
+    // (log2 of the copies per piece in LDS) -- NULL keeps the closed forms.
+    int32_t pq_seg, pq_seg_rshift;
+    float pq_seg_consts[5];
+    const void *pq_seg_ptr;
 };
 
 /* ---- deinterlacing (k_deinterlace.hip; reference src/shaders/deinterlacing.c) ---- */

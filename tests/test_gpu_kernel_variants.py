@@ -64,26 +64,51 @@ def test_bilinear_fast_equals_generic(gpu, scale, ten_bit):
                                   ((1920, 1080), (3840, 2160))])
 @pytest.mark.parametrize("ten_bit", [False, True])
 def test_bilinear_tables_equal_per_pixel_geometry(gpu, size, ten_bit):
-    """k_bilinear_tab (geometry from per-column / per-row tables, proven for the geometry by
-    k_bilinear_tab_build) against k_bilinear_fast (PL_HIP_BILIN_TABLES=0: per-pixel attribute
-    interpolation, floor, fract) and the generic kernel: the same frames bit for bit -- 2x at even
-    and odd sizes, 3x2 (where a cell's two columns do not share a texel: the tables decline and
-    both runs are the per-pixel kernel), the BASELINE frame; rgba16hf source too."""
+    """k_bilinear_strip (round 6, opt-in -- it lost, profiles/r06_12_strip_rows.txt: one 16-byte load per
+    2 x 2 cell, a wave sliding down 64 cell columns) and k_bilinear_tab (geometry from per-column /
+    per-row tables; PL_HIP_BILIN_TABLES=1) against k_bilinear_fast (PL_HIP_BILIN_STRIP=0: per-pixel
+    attribute interpolation, floor, fract) and the generic kernel: the same frames bit for bit -- 2x
+    at even and odd sizes, 3x2 (where a cell's two columns do not share a texel: the tables decline
+    and every run is the per-pixel kernel), the BASELINE frame; rgba16hf source too."""
     (sw, sh), (dw, dh) = size
     img = util.chirp_rgba16(sw, sh)
     kw = dict(dither_params=dither(), disable_dither_gamma_correction=True) if ten_bit else {}
     params = pl.render_params("fast", **kw)
+    per_px_env = {"PL_HIP_BILIN_STRIP": "0", "PL_HIP_BILIN_TABLES": "0"}
+    strip = render(gpu, img, dw, dh, params, ten_bit, {"PL_HIP_BILIN_STRIP": "1", "PL_HIP_BILIN_TABLES": "0"})
     tab = render(gpu, img, dw, dh, params, ten_bit, {"PL_HIP_BILIN_TABLES": "1"})    # (opt-in: it lost, profiles/r04_12)
-    per_px = render(gpu, img, dw, dh, params, ten_bit, {"PL_HIP_BILIN_TABLES": "0"})
+    per_px = render(gpu, img, dw, dh, params, ten_bit, per_px_env)
     assert np.array_equal(tab, per_px), util.diff_stats(tab, per_px)
+    assert np.array_equal(strip, per_px), util.diff_stats(strip, per_px)
     if sw < 1000:
         generic = render(gpu, img, dw, dh, params, ten_bit, {"PL_HIP_BILIN_ITERS": "0"})
         assert np.array_equal(tab, generic)
         f16 = (img.astype(np.float32) / 65535.0).astype(np.float16)
         a = render(gpu, f16, dw, dh, params, ten_bit, {"PL_HIP_BILIN_TABLES": "1"}, src_fmt="rgba16hf")
-        b = render(gpu, f16, dw, dh, params, ten_bit, {"PL_HIP_BILIN_TABLES": "0"}, src_fmt="rgba16hf")
-        assert np.array_equal(a, b)
+        b = render(gpu, f16, dw, dh, params, ten_bit, per_px_env, src_fmt="rgba16hf")
+        c = render(gpu, f16, dw, dh, params, ten_bit, {"PL_HIP_BILIN_STRIP": "1"}, src_fmt="rgba16hf")
+        assert np.array_equal(a, b) and np.array_equal(c, b)
     assert tab[..., :3].std() > 1000
+
+
+@pytest.mark.parametrize("size", [(7, 5), (64, 9), (65, 8), (129, 17), (300, 170), (2, 2)])
+def test_bilinear_strip_odd_sizes_flips_and_alpha(gpu, size):
+    """k_bilinear_strip at sizes whose last wave / last strip are partial (a strip is 8 cell rows, a
+    wave 64 cell columns; the first cell of either axis is the padded one), a flipped source rect
+    (the tables decline: both runs are the per-pixel kernel) and a 10-bit dithered target, against
+    k_bilinear_fast: bit for bit."""
+    sw, sh = size
+    rng = np.random.default_rng(sw * 31 + sh)
+    img = rng.integers(0, 65536, (sh, sw, 4), dtype=np.uint16)
+    params = pl.render_params("fast")
+    for crop in (None, (float(sw), float(sh), 0.0, 0.0)):      # (the second: a flipped source rect)
+        a = render(gpu, img, 2 * sw, 2 * sh, params, False, {"PL_HIP_BILIN_STRIP": "1"}, crop=crop)
+        b = render(gpu, img, 2 * sw, 2 * sh, params, False, {"PL_HIP_BILIN_STRIP": "0"}, crop=crop)
+        assert np.array_equal(a, b), util.diff_stats(a, b)
+    params10 = pl.render_params("fast", dither_params=dither(), disable_dither_gamma_correction=True)
+    a = render(gpu, img, 2 * sw, 2 * sh, params10, True, {"PL_HIP_BILIN_STRIP": "1"})
+    b = render(gpu, img, 2 * sw, 2 * sh, params10, True, {"PL_HIP_BILIN_STRIP": "0"})
+    assert np.array_equal(a, b), util.diff_stats(a, b)
 
 
 def test_bilinear_fast_crop_and_flip(gpu):
@@ -516,7 +541,9 @@ def test_map_chain_equals_interpreter(gpu, case, size):
         dw, dh, params = 2 * w, 2 * h, pl.render_params("default", upscaler=pl.filter_config("ewa_lanczos"), peak_detect_params=None)
     outs = []
     for chain in ("1", "0"):
-        with _env("PL_HIP_MAP_CHAIN", chain), _env("PL_HIP_POLAR_MFMA", "1"):
+        # (the closed forms of the PQ pair on both sides -- the chain's piecewise cubics are held to them
+        # by test_pq_segments_against_closed_forms)
+        with _env("PL_HIP_MAP_CHAIN", chain), _env("PL_HIP_POLAR_MFMA", "1"), _env("PL_HIP_PQ_SEGMENTS", "0"):
             src = gpu.tex_create(w, h, "rgba16", hdr)
             dst = gpu.tex_create(dw, dh, "rgba16")
             rr = pl.Renderer(gpu)
@@ -538,6 +565,71 @@ def test_map_chain_equals_interpreter(gpu, case, size):
         assert d.max() <= 65 and (d > 0).mean() < 0.01, (d.max(), (d > 0).mean())
     else:
         assert_same_up_to_a_dither_step(outs[0], outs[1])
+
+
+@pytest.mark.parametrize("case", ["ewa_2x_map", "ewa_2x_map_no_peak"])
+@pytest.mark.parametrize("size", [(97, 61), (256, 130), (480, 270)])
+def test_pq_segments_against_closed_forms(gpu, case, size):
+    """The PQ pair of the map chain as piecewise cubics in LDS (csrc/hip/pqseg.hiph: the default of the
+    chain kernels that have the variant) against the closed forms of pqmath.hiph (PL_HIP_PQ_SEGMENTS=0)
+    on the metric's launch, 16-bit target without a dither so that every difference shows: both are
+    approximations of the same curves (tests/test_pqseg.py: the pieces are the closer one). On the bulk
+    the frames agree (97 % of the samples identical, 99.8 % within a code); the colour map amplifies
+    what is left on saturated colours -- a few codes on a few samples, the same kind and size of
+    difference either has against the fp32 oracle, and the statement against float64 is
+    tests/util.py::assert_colormap_parity's (test_gpu_metric.py runs it on the default, the pieces).
+    The number of copies per piece in LDS (a bank-conflict matter) changes
+    nothing at all; a frame with values beyond the tables' range (PQ codes above 1.25 out of an
+    rgba16hf source) takes the closed forms wave by wave -- no clamp, no NaN, the same frame to the
+    same tolerance. (That frame is also what found the closed form's own clamp of the EOTF's quotient
+    to [0, 1], which the reference does not have: pqmath.hiph.)"""
+    from test_gpu_fullsize import hdr_frame16
+    w, h = size
+    hdr = hdr_frame16(w, h)
+    peak = pl.peak_detect_params(percentile=99.995) if case == "ewa_2x_map" else None
+    params = pl.render_params("default", upscaler=pl.filter_config("ewa_lanczos"), peak_detect_params=peak,
+                              dither_params=None)
+
+    def run(env, img=hdr, fmt="rgba16"):
+        old = {k: os.environ.get(k) for k in env}
+        os.environ.update(env)
+        try:
+            src = gpu.tex_create(w, h, fmt, img)
+            dst = gpu.tex_create(2 * w, 2 * h, "rgba16")
+            rr = pl.Renderer(gpu)
+            util.srand(1)
+            assert rr.render(pl.frame(src, components=3, color=pl.color_space("bt2020", "pq", max_luma=1000.0)),
+                             pl.frame(dst, color=pl.color_space("bt709", "bt1886")), params)
+            assert rr.errors() == 0
+            out = dst.download()
+            rr.destroy(); src.destroy(); dst.destroy()
+            return out
+        finally:
+            for k, v in old.items():
+                if v is None:
+                    os.environ.pop(k, None)
+                else:
+                    os.environ[k] = v
+
+    closed = run({"PL_HIP_PQ_SEGMENTS": "0", "PL_HIP_POLAR_MFMA": "1"})
+    seg = run({"PL_HIP_PQ_SEGMENTS": "1", "PL_HIP_POLAR_MFMA": "1"})
+    assert closed[..., :3].std() > 1000
+    d = np.abs(seg.astype(np.int64) - closed.astype(np.int64))
+    print("pq segments vs closed forms: max", d.max(), "differing", (d > 0).mean(), "> 1 code", (d > 1).mean())
+    assert d.max() <= 10 and (d > 1).mean() < 0.005 and (d > 0).mean() < 0.06, (d.max(), (d > 0).mean(), (d > 1).mean())
+    for copies in ("2", "4", "16"):
+        again = run({"PL_HIP_PQ_SEGMENTS": "1", "PL_HIP_POLAR_MFMA": "1", "PL_HIP_PQ_SEG_COPIES": copies})
+        assert np.array_equal(again, seg), copies
+    # beyond the tables: an rgba16hf frame whose left half carries PQ "codes" up to 1.6
+    f16 = (hdr.astype(np.float32) / 65535.0)
+    f16[:, : w // 2, :3] *= 1.6 / max(float(f16[..., :3].max()), 1e-3)
+    f16 = f16.astype(np.float16)
+    a = run({"PL_HIP_PQ_SEGMENTS": "0", "PL_HIP_POLAR_MFMA": "1"}, f16, "rgba16hf")
+    b = run({"PL_HIP_PQ_SEGMENTS": "1", "PL_HIP_POLAR_MFMA": "1"}, f16, "rgba16hf")
+    d = np.abs(a.astype(np.int64) - b.astype(np.int64))
+    # (up to 160 000 cd/m^2 through the colour map: what either form rounds differently is amplified a
+    # little further than on the frame above)
+    assert d.max() <= 24 and (d > 1).mean() < 0.005, (d.max(), (d > 1).mean())
 
 
 def assert_same_up_to_a_dither_step(chain, interp):
