@@ -225,11 +225,6 @@ void k_deband_fast(const plh_pass p_)
     const bool has_lin = i_lin < p.num_ops && p.ops[i_lin].kind == PLH_OP_LINEARIZE;
     const bool has_sig = p.num_ops > 0 && p.ops[p.num_ops - 1].kind == PLH_OP_SIGMOIDIZE;
     const plh_op &o_map = p.ops[0], &o_lin = p.ops[i_lin], &o_sig = p.ops[p.num_ops > 0 ? p.num_ops - 1 : 0];
-    // a PQ linearisation from the piecewise cubics of pqseg.hiph, read from device memory (the launcher
-    // leaves their address in chain.pq_seg_ptr when the op is PQ; this kernel's LDS is spoken for)
-    uintptr_t u_segp = (uintptr_t) p.chain.pq_seg_ptr;
-    asm volatile("" : "+s"(u_segp));
-    const pq_seg seg = pq_seg_view((const unsigned char *) u_segp, 0, 0, u_segp != 0);
     const bool has_alpha = !has_map || o_map.i1 >= 4;   // else alpha is the PLANE_MAP's neutral value
     const float my = p.out_scale[1] * ((float) idy + 0.5f);
 
@@ -329,7 +324,7 @@ void k_deband_fast(const plh_pass p_)
         }
     }
     if (has_lin)
-        op_linearize_values_seg(lin, o_lin, seg);
+        op_linearize_values(lin, o_lin);
     if (has_sig) {
 #pragma unroll
         for (int k = 0; k < 6; k++)
@@ -445,11 +440,6 @@ void k_deband_lds(const plh_pass p_)
     const bool has_lin = i_lin < p.num_ops && p.ops[i_lin].kind == PLH_OP_LINEARIZE;
     const bool has_sig = p.num_ops > 0 && p.ops[p.num_ops - 1].kind == PLH_OP_SIGMOIDIZE;
     const plh_op &o_map = p.ops[0], &o_lin = p.ops[i_lin], &o_sig = p.ops[p.num_ops > 0 ? p.num_ops - 1 : 0];
-    // a PQ linearisation from the piecewise cubics of pqseg.hiph, read from device memory (the launcher
-    // leaves their address in chain.pq_seg_ptr when the op is PQ; this kernel's LDS is spoken for)
-    uintptr_t u_segp = (uintptr_t) p.chain.pq_seg_ptr;
-    asm volatile("" : "+s"(u_segp));
-    const pq_seg seg = pq_seg_view((const unsigned char *) u_segp, 0, 0, u_segp != 0);
     const bool has_alpha = !has_map || o_map.i1 >= 4;   // else alpha is the PLANE_MAP's neutral value
 
     // 32 lanes cover a row of the tile (two pixels each), a wave two rows, the workgroup 16 rows; a
@@ -542,7 +532,7 @@ void k_deband_lds(const plh_pass p_)
             }
         }
         if (has_lin)
-            op_linearize_values_seg(lin, o_lin, seg);
+            op_linearize_values(lin, o_lin);
         if (has_sig) {
 #pragma unroll
             for (int k = 0; k < 3 * NP; k++)
@@ -603,30 +593,9 @@ static bool deband_fast_applies(const plh_pass *pass)
            !pass->num_pre_ops && deband_fast_ops(pass);
 }
 
-int plh_launch_deband(hipStream_t stream, const plh_pass *pass_)
+int plh_launch_deband(hipStream_t stream, const plh_pass *pass)
 {
-    const plh_pass *pass = pass_;
-    plh_pass local;
     if (deband_fast_applies(pass)) {
-        // a PQ linearisation behind the taps: the curve from the piecewise cubics (pqseg.hiph;
-        // PL_HIP_PQ_SEGMENTS=0: the closed form)
-        {
-            int i = 0;
-            if (i < pass->num_ops && pass->ops[i].kind == PLH_OP_PLANE_MAP)
-                i++;
-            const char *env = getenv("PL_HIP_PQ_SEGMENTS");
-            local = *pass;
-            local.chain.pq_seg_ptr = nullptr;   // (nobody else fills `chain` for a debanding pass)
-            local.chain.pq_seg_rshift = 0;
-            if (i < pass->num_ops && pass->ops[i].kind == PLH_OP_LINEARIZE && pass->ops[i].i0 == TRC_PQ &&
-                !(env && env[0] == '0')) {
-                const float *f = pass->ops[i].f;
-                // { m1, c3, m2, 1 / m2, 1 / m1 }: the op carries the reciprocals
-                const float k5[5] = { 1.0f / f[6], f[5], 1.0f / f[2], f[2], f[6] };
-                local.chain.pq_seg_ptr = plh_pqseg_tables((plh_stream) stream, k5);
-            }
-            pass = &local;
-        }
         const char *lds = getenv("PL_HIP_DEBAND_LDS");
         const plh_sampler_args &s = pass->s;
         if (!(lds && lds[0] == '0') && s.db_lds && s.iterations >= 1 && s.db_radius * (float) s.iterations <= 16.0f) {

@@ -683,3 +683,325 @@ int plh_launch_ortho(hipStream_t stream, const plh_pass *pass)
     const hipError_t err = hipGetLastError();
     return err == hipSuccess ? 0 : -(int) err;
 }
+
+
+/*
+ * k_lowpass2 (round 6): both passes of a separable DOWNSCALE of a one-component r16hf plane in one
+ * launch -- the low-pass behind the contrast-recovery feature map (4K -> 1097 x 617 with the widened
+ * bicubic, 14 taps per axis: k_ortho_fast<R16F, 0, 1, 16> 24.6 us + <.., 0, 16> 16.7 us for a 16 MB
+ * plane, each lane issuing its 14 - 16 tap loads per pixel; VERDICT r04 / r05 "the two low-pass
+ * passes as one LDS-resident kernel").
+ * A workgroup renders 32 x 16 output pixels. It finds the source columns its horizontal pass needs
+ * and the source rows its vertical pass needs (from the passes' own per-pixel geometry, reduced in
+ * LDS), stages that part of the plane ONCE (mirrored at the plane's edges as the taps would be),
+ * runs the vertical pass for its 16 rows over those columns into an LDS image -- rounded to f16, as
+ * the r16hf intermediate of the two-pass form rounds it -- and the horizontal pass from there.
+ * Arithmetic: k_ortho_fast's statement for statement for either pass (geometry per pixel through
+ * plh_attr, the two weight rows bracketing fcoord blended per pixel, taps accumulated in order by
+ * fma, scale, f16), so the plane is bit-identical to the two-pass one
+ * (tests/test_gpu_contrast_recovery.py::test_fused_lowpass_equals_the_two_passes).
+ */
+#define LP2_TW 32
+#define LP2_TH 16
+#define LP2_NT 256
+#define LP2_KR 20       // rows of the tile per wave (4 waves): rows_cap <= 80
+
+struct lp2_geo { int first; float fcoord; };
+
+// minimum and maximum over the wave, then ONE pair of LDS atomics per wave (every lane on its own:
+// 256 threads x 18 atomics on four addresses, which LDS takes one lane at a time -- the first
+// version of the kernel spent 90 of its 132 us there)
+DEV void lp2_range(int lo, int hi, int *slot_lo, int *slot_hi, int lane)
+{
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        lo = min(lo, __shfl_xor(lo, off));
+        hi = max(hi, __shfl_xor(hi, off));
+    }
+    if (lane == 0) {
+        atomicMin(slot_lo, lo);
+        atomicMax(slot_hi, hi);
+    }
+}
+
+// geometry of pixel (idx, idy) of a pass filtering along DIR (k_ortho_fast, lines "ta = ...")
+template <int DIR>
+DEV lp2_geo lp2_geometry(const float (&pos)[4][2], const float (&os)[2], int idx, int idy, int na, int N)
+{
+    const float mx = os[0] * ((float) idx + 0.5f), my = os[1] * ((float) idy + 0.5f);
+    const float pa = plh_attr(pos, DIR ? 1 : 0, mx, my);
+    const float ta = pa * (float) na - 0.5f;
+    const float fla = __builtin_floorf(ta);
+    lp2_geo g;
+    g.fcoord = ta - fla;
+    g.first = (int) fla - (N / 2 - 1);
+    return g;
+}
+
+// the pixel's weights: the two table rows bracketing fcoord, blended (k_ortho_fast, NT = 16).
+// UNIFORM: fcoord is the same in every lane of the wave (the caller has checked): the rows are then
+// read by the scalar unit
+template <bool UNIFORM>
+DEV void lp2_weights(const float *table, int stride, int N, float fcoord, float (&w)[16])
+{
+    const float fpos = plh_clamp(fcoord, 0.0f, 1.0f) * 255.0f;
+    const float fbase = __builtin_floorf(fpos);
+    const float fr = fpos - fbase;
+    int i0 = (int) fbase, i1 = min((int) fbase + 1, 255);
+    if (UNIFORM) {
+        i0 = __builtin_amdgcn_readfirstlane(i0);
+        i1 = __builtin_amdgcn_readfirstlane(i1);
+    }
+    typedef float lp2_f32x4 __attribute__((ext_vector_type(4)));
+    typedef __attribute__((address_space(1))) const lp2_f32x4 gf4;
+    typedef __attribute__((address_space(4))) const lp2_f32x4 cf4;
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        lp2_f32x4 a = { 0.0f, 0.0f, 0.0f, 0.0f }, b = a;
+        if (4 * j < N) {
+            if (UNIFORM) {
+                a = ((cf4 *) (uintptr_t) (table + (size_t) i0 * stride))[j];
+                b = ((cf4 *) (uintptr_t) (table + (size_t) i1 * stride))[j];
+            } else {
+                a = ((gf4 *) (uintptr_t) (table + (size_t) i0 * stride))[j];
+                b = ((gf4 *) (uintptr_t) (table + (size_t) i1 * stride))[j];
+            }
+        }
+        w[4 * j] = plh_mix(a.x, b.x, fr);
+        w[4 * j + 1] = plh_mix(a.y, b.y, fr);
+        w[4 * j + 2] = plh_mix(a.z, b.z, fr);
+        w[4 * j + 3] = plh_mix(a.w, b.w, fr);
+    }
+}
+
+// LIN: "linear trick" weight rows (all-positive filters, fill_ortho_lut: sampling.c:919-936; the
+// bicubic B-spline of the feature map's low-pass is one): taps in pairs {w0 + w1, w1 / (w0 + w1)},
+// the pair blended first -- k_ortho_fast<.., LIN>'s statements
+template <bool LIN>
+__global__ __launch_bounds__(LP2_NT)
+void k_lowpass2(const plh_lowpass2 a)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char lp2_smem[];
+    __shared__ int rng[4];      // first / last source column, first / last source row of the tile
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int X0 = blockIdx.x * LP2_TW, Y0 = blockIdx.y * LP2_TH;
+    const int wB = a.dst.w, hB = a.dst.h, srcw = a.src.w, srch = a.src.h;
+    const int NV = a.n_v, NH = a.n_h, cap_c = a.cols_cap, cap_r = a.rows_cap;   // (cap_c: a multiple of 4)
+    const bool mirror = a.mirror;
+    uint16_t *tile = (uint16_t *) lp2_smem;                                  // cap_r x cap_c f16 codes
+    float *mid = (float *) (lp2_smem + (((size_t) cap_r * cap_c * 2 + 15) & ~(size_t) 15));    // 16 x cap_c
+    if (tid == 0) {
+        rng[0] = rng[2] = 0x7fffffff;
+        rng[1] = rng[3] = -0x7fffffff;
+    }
+    __syncthreads();
+
+    // ---- the horizontal pass's geometry of this thread's two outputs (rows 8 apart), and with it
+    // the source columns the tile needs
+    const int Xq = min(X0 + (tid & 31), wB - 1);
+    lp2_geo gh[2];
+#pragma unroll
+    for (int q = 0; q < 2; q++)
+        gh[q] = lp2_geometry<0>(a.pos_h, a.os_h, Xq, min(Y0 + (tid >> 5) + 8 * q, hB - 1), a.mid_w, NH);
+    lp2_range(min(gh[0].first, gh[1].first), max(gh[0].first, gh[1].first) + NH - 1, &rng[0], &rng[1], lane);
+    __syncthreads();
+    const int cmin = rng[0], ncols = min(rng[1] - cmin + 1, cap_c);
+
+    // ---- the vertical pass's geometry of this thread's items -- intermediate rows wave, wave + 4,
+    // ... of the tile, the two logical columns 2 lane, 2 lane + 1 -- and the source rows the tile needs
+    lp2_geo gv[4][2];
+    int vlo = 0x7fffffff, vhi = -0x7fffffff;
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+        const int Y = min(Y0 + wave + 4 * r, hB - 1);
+#pragma unroll
+        for (int c = 0; c < 2; c++) {
+            const int j = min(2 * lane + c, ncols - 1);
+            const int x = of_tap(cmin + j, a.mid_w, mirror);
+            gv[r][c] = lp2_geometry<1>(a.pos_v, a.os_v, x, Y, srch, NV);
+            vlo = min(vlo, gv[r][c].first);
+            vhi = max(vhi, gv[r][c].first);
+        }
+    }
+    lp2_range(vlo, vhi + NV - 1, &rng[2], &rng[3], lane);
+    __syncthreads();
+    const int rmin = rng[2], nrows = min(rng[3] - rmin + 1, cap_r);
+
+    // ---- the tile: source rows rmin .., columns cmin .., mirrored (or clamped) like the taps
+    // A tile whose columns lie inside the plane (all but the tiles on its left and right edge) is
+    // moved as 32-bit column pairs with EVERY row's load in flight before the first is waited for: a
+    // loop over the rows with the load inside is a memory round trip per row, 18 in a row per wave
+    // (the first version: 43 us for what the two passes do in 43).
+    if (cmin >= 0 && cmin + cap_c <= srcw) {
+        typedef __attribute__((address_space(1))) const uint32_t gu32;
+        uint32_t v[LP2_KR];
+        const uintptr_t col = (uintptr_t) a.src.ptr + (size_t) (cmin + 2 * min(lane, cap_c / 2 - 1)) * 2;
+#pragma unroll
+        for (int k = 0; k < LP2_KR; k++) {
+            const int y = of_tap(rmin + min(wave + 4 * k, nrows - 1), srch, mirror);
+            // (2-byte aligned: assembled from the bytes, which the backend turns into one dword load)
+            __builtin_memcpy(&v[k], (const void *) (gu32 *) (col + (size_t) y * (size_t) a.src.pitch), 4);
+        }
+        uint32_t *t32 = (uint32_t *) tile;
+#pragma unroll
+        for (int k = 0; k < LP2_KR; k++) {
+            if (wave + 4 * k < nrows && 2 * lane < cap_c)
+                t32[(wave + 4 * k) * (cap_c / 2) + lane] = v[k];
+        }
+    } else {
+        typedef __attribute__((address_space(1))) const uint16_t gu16;
+        for (int r = wave; r < nrows; r += LP2_NT / 64) {
+            const int y = of_tap(rmin + r, srch, mirror);
+            gu16 *row = (gu16 *) ((uintptr_t) a.src.ptr + (size_t) y * (size_t) a.src.pitch);
+            for (int j = lane; j < cap_c; j += 64)
+                tile[r * cap_c + j] = row[of_tap(cmin + min(j, ncols - 1), srcw, mirror)];
+        }
+    }
+    __syncthreads();
+
+    // ---- vertical pass into the LDS image (f16-rounded, as the r16hf intermediate would be): the
+    // lane's two columns share a tap row's 32-bit read, and -- bar a rounding tie in the geometry,
+    // which is checked -- their weights
+    const uint32_t *tile32 = (const uint32_t *) tile;
+    const int pitch32 = cap_c / 2;
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+        if (Y0 + wave + 4 * r >= hB || 2 * lane >= cap_c)
+            continue;
+        const lp2_geo g0 = gv[r][0], g1 = gv[r][1];
+        float w[16];
+        const bool uni = __builtin_amdgcn_ballot_w64(__float_as_uint(g0.fcoord) !=
+                                                     (uint32_t) __builtin_amdgcn_readfirstlane((int) __float_as_uint(g0.fcoord))) == 0;
+        if (uni)
+            lp2_weights<true>(a.wgt_v, a.stride_v, NV, g0.fcoord, w);
+        else
+            lp2_weights<false>(a.wgt_v, a.stride_v, NV, g0.fcoord, w);
+        // (the taps lie inside the tile by construction: one clamp for memory safety)
+        const int t0 = min(max(g0.first - rmin, 0), max(nrows - NV, 0));
+        float ca0 = 0.0f, ca1 = 0.0f;
+#pragma unroll
+        for (int n = 0; n < 16; n += LIN ? 2 : 1) {
+            if (n >= NV)
+                continue;
+            const uint32_t v = tile32[(t0 + n) * pitch32 + lane];
+            float c0 = plh_h2f(v & 0xffffu), c1 = plh_h2f(v >> 16);
+            if (LIN) {
+                // (n + 1 <= N - 1: the tap counts are even)
+                const uint32_t v1 = tile32[(t0 + n + 1) * pitch32 + lane];
+                c0 = plh_mix(c0, plh_h2f(v1 & 0xffffu), w[n + 1 < 16 ? n + 1 : n]);
+                c1 = plh_mix(c1, plh_h2f(v1 >> 16), w[n + 1 < 16 ? n + 1 : n]);
+            }
+            ca0 = __builtin_fmaf(w[n], c0, ca0);
+            ca1 = __builtin_fmaf(w[n], c1, ca1);
+        }
+        // a second column whose geometry rounded differently: on its own
+        const bool same = __float_as_uint(g1.fcoord) == __float_as_uint(g0.fcoord) && g1.first == g0.first;
+        if (__builtin_amdgcn_ballot_w64(!same) != 0) {
+            float w1[16];
+            lp2_weights<false>(a.wgt_v, a.stride_v, NV, g1.fcoord, w1);
+            const int u0 = min(max(g1.first - rmin, 0), max(nrows - NV, 0));
+            float cb = 0.0f;
+#pragma unroll
+            for (int n = 0; n < 16; n += LIN ? 2 : 1) {
+                if (n >= NV)
+                    continue;
+                float c1 = plh_h2f(tile[(u0 + n) * cap_c + 2 * lane + 1]);
+                if (LIN)
+                    c1 = plh_mix(c1, plh_h2f(tile[(u0 + n + 1) * cap_c + 2 * lane + 1]), w1[n + 1 < 16 ? n + 1 : n]);
+                cb = __builtin_fmaf(w1[n], c1, cb);
+            }
+            ca1 = same ? ca1 : cb;
+        }
+        float2 out = make_float2(plh_h2f(plh_f2h(a.scale_v * ca0)), plh_h2f(plh_f2h(a.scale_v * ca1)));
+        *(float2 *) (mid + (wave + 4 * r) * cap_c + 2 * lane) = out;
+    }
+    __syncthreads();
+
+    // ---- horizontal pass from the LDS image: the lane's two outputs (rows 8 apart) share their
+    // column, and -- bar a rounding tie -- their weights
+    {
+        const int X = X0 + (tid & 31), Ya = Y0 + (tid >> 5), Yb = Ya + 8;
+        float w[16];
+        lp2_weights<false>(a.wgt_h, a.stride_h, NH, gh[0].fcoord, w);
+        const int t0 = min(max(gh[0].first - cmin, 0), max(ncols - NH, 0));
+        const float *ra = mid + (Ya - Y0) * cap_c + t0, *rb = ra + 8 * cap_c;
+        float ca0 = 0.0f, ca1 = 0.0f;
+#pragma unroll
+        for (int n = 0; n < 16; n += LIN ? 2 : 1) {
+            if (n >= NH)
+                continue;
+            float c0 = ra[n], c1 = rb[n];
+            if (LIN) {
+                c0 = plh_mix(c0, ra[n + 1], w[n + 1 < 16 ? n + 1 : n]);
+                c1 = plh_mix(c1, rb[n + 1], w[n + 1 < 16 ? n + 1 : n]);
+            }
+            ca0 = __builtin_fmaf(w[n], c0, ca0);
+            ca1 = __builtin_fmaf(w[n], c1, ca1);
+        }
+        const bool same = __float_as_uint(gh[1].fcoord) == __float_as_uint(gh[0].fcoord) && gh[1].first == gh[0].first;
+        if (__builtin_amdgcn_ballot_w64(!same) != 0) {
+            float w1[16];
+            lp2_weights<false>(a.wgt_h, a.stride_h, NH, gh[1].fcoord, w1);
+            const float *rc = mid + (Yb - Y0) * cap_c + min(max(gh[1].first - cmin, 0), max(ncols - NH, 0));
+            float cb = 0.0f;
+#pragma unroll
+            for (int n = 0; n < 16; n += LIN ? 2 : 1) {
+                if (n >= NH)
+                    continue;
+                float c1 = rc[n];
+                if (LIN)
+                    c1 = plh_mix(c1, rc[n + 1], w1[n + 1 < 16 ? n + 1 : n]);
+                cb = __builtin_fmaf(w1[n], c1, cb);
+            }
+            ca1 = same ? ca1 : cb;
+        }
+        typedef __attribute__((address_space(1))) uint16_t gu16o;
+        if (X < wB && Ya < hB)
+            *(gu16o *) ((uintptr_t) a.dst.ptr + (size_t) Ya * (size_t) a.dst.pitch + (size_t) X * 2) =
+                (uint16_t) plh_f2h(a.scale_h * ca0);
+        if (X < wB && Yb < hB)
+            *(gu16o *) ((uintptr_t) a.dst.ptr + (size_t) Yb * (size_t) a.dst.pitch + (size_t) X * 2) =
+                (uint16_t) plh_f2h(a.scale_h * ca1);
+    }
+}
+
+static size_t lowpass2_lds(const plh_lowpass2 &a)
+{
+    const size_t tile = ((size_t) a.rows_cap * a.cols_cap * 2 + 15) & ~(size_t) 15;
+    return tile + (size_t) LP2_TH * a.cols_cap * 4;
+}
+
+// PL_HIP_LOWPASS_FUSED=0: the two passes
+extern "C" int plh_lowpass2_applies(const struct plh_lowpass2 *args)
+{
+    const char *env = getenv("PL_HIP_LOWPASS_FUSED");
+    if (env && env[0] == '0')
+        return 0;
+    const plh_lowpass2 &a = *args;
+    if (a.src.fmt != PLH_FMT_R16F || a.dst.fmt != PLH_FMT_R16F || a.n_v > 16 || a.n_h > 16 || a.n_v < 2 ||
+        a.n_h < 2 || (a.n_v & 1) || (a.n_h & 1) || a.mid_w != a.src.w || a.mid_h != a.dst.h ||
+        a.dst.w < 1 || a.dst.h < 1)
+        return 0;
+    // one reflection only (of_tap), as k_ortho_fast's launcher requires
+    if (a.mirror && (a.src.w < 16 || a.src.h < 16))
+        return 0;
+    // (a lane owns two columns of the tile: 128 at most -- ratios up to 3.5 with the widened bicubic)
+    return a.rows_cap >= a.n_v && a.rows_cap <= 4 * LP2_KR && a.cols_cap >= a.n_h && a.cols_cap <= 128 && !(a.cols_cap & 3) &&
+           lowpass2_lds(a) <= 60 * 1024;
+}
+
+extern "C" int plh_launch_lowpass2(plh_stream stream_, const struct plh_lowpass2 *args)
+{
+    hipStream_t stream = (hipStream_t) stream_;
+    if (!plh_lowpass2_applies(args))
+        return 1;
+    const plh_lowpass2 &a = *args;
+    const size_t shmem = lowpass2_lds(a);
+    const dim3 grid((a.dst.w + LP2_TW - 1) / LP2_TW, (a.dst.h + LP2_TH - 1) / LP2_TH);
+    if (a.linear_trick)
+        PLH_LAUNCH_LAST(k_lowpass2<true>, grid, dim3(LP2_NT), shmem, stream, a);
+    else
+        PLH_LAUNCH_LAST(k_lowpass2<false>, grid, dim3(LP2_NT), shmem, stream, a);
+    const hipError_t err = hipGetLastError();
+    return err == hipSuccess ? 0 : -(int) err;
+}

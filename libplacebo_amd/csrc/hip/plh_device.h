@@ -472,6 +472,26 @@ typedef void *plh_stream;
 
 // returns 0 on success, a negative hipError otherwise
 int plh_launch_pass(plh_stream stream, const struct plh_pass *pass);
+
+/* ---- the two passes of a separable downscale of a one-component half-float plane as ONE launch
+ * (k_lowpass2, k_ortho.hip): the contrast-recovery feature map's low-pass, reference
+ * src/renderer.c:2089-2154 -> pl_shader_sample_ortho2 twice (vertical, then horizontal, through an
+ * r16hf intermediate the fused kernel keeps in LDS) ---- */
+struct plh_lowpass2 {
+    struct plh_view src, dst;           // r16hf in, r16hf out
+    float pos_v[4][2], pos_h[4][2];     // the two passes' `pos` corners (struct plh_sampler_args)
+    float os_v[2], os_h[2];             // their out_scale: 1 / (width, height) of their rects
+    int32_t mid_w, mid_h;               // the intermediate image: src.w x dst.h, never stored
+    const float *wgt_v, *wgt_h;         // their weight tables (256 phases x stride)
+    int32_t n_v, stride_v, n_h, stride_h;
+    float scale_v, scale_h;
+    int32_t mirror;                     // PLH_ADDRESS_MIRROR (else clamp)
+    int32_t linear_trick;               // both tables hold {w0 + w1, w1 / (w0 + w1)} pairs (use_linear)
+    int32_t rows_cap, cols_cap;         // the LDS tile's capacity in source rows / columns
+};
+// 0, a negative error, or 1 = not a shape the fused kernel takes (nothing launched)
+int plh_launch_lowpass2(plh_stream stream, const struct plh_lowpass2 *args);
+int plh_lowpass2_applies(const struct plh_lowpass2 *args);
 int plh_launch_errdiff(plh_stream stream, const struct plh_errdiff_args *args);
 // pass: s.src = the overlay texture, ops (split at num_pre_ops), dst = the target
 int plh_launch_overlay(plh_stream stream, const struct plh_pass *pass,

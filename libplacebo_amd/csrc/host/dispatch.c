@@ -601,6 +601,83 @@ static bool finish_blended(pl_dispatch dp, pl_shader sh, const struct plh_pass_e
 }
 
 // Deprecated front ends of the gpu's pl_cache (src/dispatch.c:1624-1632)
+/* ---- the two passes of a separable downscale as one launch (k_lowpass2, k_ortho.hip) ---------- */
+
+// `vert`: the vertical pass of the contrast-recovery low-pass, recorded (pl_shader_sample_ortho2) on
+// the full-size r16hf plane but not dispatched; `horiz`: the horizontal one, recorded on a texture of
+// the intermediate's size that is never written. Returns 1 = launched as one kernel into `target`
+// (both shaders consumed), 0 = not a shape the fused kernel takes (nothing consumed: dispatch them
+// one after the other), -1 = failed (both consumed).
+int plh_dispatch_lowpass2(pl_dispatch dp, pl_shader *pvert, pl_shader *phoriz, pl_tex target)
+{
+    pl_shader v = *pvert, h = *phoriz;
+    int mw, mh, ow, oh;
+    if (v->failed || h->failed || v->kind != PLH_SHADER_PASS || h->kind != PLH_SHADER_PASS ||
+        v->transpose || h->transpose || v->detect_peak || h->detect_peak || v->on_aux || h->on_aux ||
+        !pl_shader_output_size(v, &mw, &mh) || !pl_shader_output_size(h, &ow, &oh))
+        return 0;
+    const struct plh_pass *pv = &v->pass, *ph = &h->pass;
+    const struct plh_sampler_args *sv = &pv->s, *sh_ = &ph->s;
+    if (sv->type != PLH_SAMPLE_ORTHO || sh_->type != PLH_SAMPLE_ORTHO || sv->dir != 1 || sh_->dir != 0 ||
+        pv->num_ops || ph->num_ops || sv->use_linear != sh_->use_linear || sv->use_ar || sh_->use_ar ||
+        sv->linear || sh_->linear || (sv->comp_mask & 1u) != 1u || (sh_->comp_mask & 1u) != 1u ||
+        sv->address_mode != sh_->address_mode ||
+        (sv->address_mode != PLH_ADDRESS_MIRROR && sv->address_mode != PLH_ADDRESS_CLAMP))
+        return 0;
+    if (!target || !target->params.storable || target->params.w != ow || target->params.h != oh ||
+        oh != mh || sh_->src.w != mw || sh_->src.h != mh || sv->src.w != mw)
+        return 0;
+
+    struct plh_lowpass2 a = {0};
+    a.src = sv->src;
+    plh_tex_view(target, &a.dst);
+    memcpy(a.pos_v, sv->pos, sizeof(a.pos_v));
+    memcpy(a.pos_h, sh_->pos, sizeof(a.pos_h));
+    // (plh_pass_execute's out_scale of either pass)
+    a.os_v[0] = 1.0 / mw; a.os_v[1] = 1.0 / mh;
+    a.os_h[0] = 1.0 / ow; a.os_h[1] = 1.0 / oh;
+    a.mid_w = mw; a.mid_h = mh;
+    a.wgt_v = sv->weights; a.wgt_h = sh_->weights;
+    a.n_v = sv->row_size; a.stride_v = sv->row_stride;
+    a.n_h = sh_->row_size; a.stride_h = sh_->row_stride;
+    a.scale_v = sv->scale; a.scale_h = sh_->scale;
+    a.mirror = sv->address_mode == PLH_ADDRESS_MIRROR;
+    a.linear_trick = sv->use_linear;
+    // the tile of a 32 x 16 workgroup: the taps of its first and last output are (n - 1) x ratio
+    // texels apart, + the tap count, + one texel of slack for the per-pixel rounding of the geometry
+    const double rx = fabs((sh_->pos[1][0] - sh_->pos[0][0]) * mw) / ow;
+    const double ry = fabs((sv->pos[2][1] - sv->pos[0][1]) * sv->src.h) / mh;
+    a.cols_cap = ((int) ceil(31 * rx) + a.n_h + 3 + 3) & ~3;
+    a.rows_cap = (int) ceil(15 * ry) + a.n_v + 3;
+
+    if (!plh_lowpass2_applies(&a))
+        return 0;
+
+    pl_gpu gpu = dp->gpu;
+    struct pass_timing *timing = get_timing(dp, h);
+    pl_timer timer = timing ? timing->timer : NULL;
+    const uint64_t seq = plh_tex_order(gpu, 0, v->src_tex, target);
+    (void) seq;
+    if (timer)
+        plh_timer_begin(gpu, timer, 0);
+    plh_event stop = plh_gpu_fence_for_launch(gpu, 0, v->src_tex);
+    plh_launch_offer_stop(stop);
+    const int err = plh_launch_lowpass2(plh_gpu_stream_n(gpu, 0), &a);
+    const bool taken = plh_launch_stop_taken() && !err;
+    if (timer)
+        plh_timer_end(gpu, timer, 0);
+    if (stop)
+        plh_gpu_fence_launched(gpu, 0, taken);
+    drain_timing(dp, timing);
+    pl_dispatch_abort(dp, pvert);
+    pl_dispatch_abort(dp, phoriz);
+    if (err) {
+        pl_msg(dp->log, PL_LOG_ERR, "Failed launching the fused low-pass: %s", plh_strerror(err));
+        return -1;
+    }
+    return 1;
+}
+
 size_t pl_dispatch_save(pl_dispatch dp, uint8_t *out)
 {
     return pl_cache_save(plh_gpu_cache(dp->gpu), out, out ? SIZE_MAX : 0);

@@ -388,6 +388,56 @@ static bool run_two_pass(struct frame_job *job, pl_shader sh, const struct pl_sa
     return horiz.tex && pl_shader_sample_ortho2(sh, &horiz, fp);
 }
 
+// The low-pass of the contrast-recovery feature map (a separable downscale of a one-component
+// plane: two passes through an intermediate in the reference, src/renderer.c:2089-2154) as ONE launch
+// that keeps the intermediate in LDS (k_lowpass2). true = `small` is written; false = nothing was
+// done (not a separable filter, not a shape the kernel takes): the caller runs the two passes.
+static bool try_fused_lowpass(struct frame_job *job, const struct pl_sample_src *req, pl_tex small)
+{
+    pl_renderer rr = job->rr;
+    const struct pl_render_params *params = job->params;
+    struct rp_scaler sc = rp_pick_scaler(&job->caps, params, RP_USE_LOWPASS, req,
+                                         req->tex ? req->tex->params.format : NULL);
+    if (sc.kind != RP_SCALER_FILTER || sc.filter->polar || !(sc.axis[0] && sc.axis[1]) ||
+        sc.dir == RP_DIR_NONE)
+        return false;
+    const struct pl_sample_filter_params fp = {
+        .filter      = *sc.filter,
+        .antiring    = params->antiringing_strength,
+        .no_widening = false,
+        .lut         = sc.dir == RP_DIR_UP ? &rr->scale_contrast.up : &rr->scale_contrast.down,
+    };
+    // (run_two_pass's two requests)
+    struct pl_sample_src vert = *req, horiz = *req;
+    vert.new_w = req->tex->params.w;
+    vert.rect.x0 = 0;
+    vert.rect.x1 = vert.new_w;
+    horiz.rect.y0 = 0;
+    horiz.rect.y1 = vert.new_h;
+    // the intermediate exists as a texture (the horizontal pass is recorded against it) and is
+    // never written
+    horiz.tex = borrow_fbo(job, vert.new_w, vert.new_h, NULL, 1);
+    horiz.scale = 1.0;
+    if (!horiz.tex)
+        return false;
+    pl_shader first = pl_dispatch_begin(rr->dp), second = pl_dispatch_begin(rr->dp);
+    int done = 0;
+    if (pl_shader_sample_ortho2(first, &vert, &fp) && pl_shader_sample_ortho2(second, &horiz, &fp))
+        done = plh_dispatch_lowpass2(rr->dp, &first, &second, small);
+    if (done <= 0) {
+        // declined: the ordinary two dispatches, from the shaders as recorded
+        bool ok = done == 0 && first && second && !first->failed && !second->failed;
+        if (ok)
+            ok = pl_dispatch_finish(rr->dp, pl_dispatch_params( .shader = &first, .target = horiz.tex ));
+        if (ok)
+            ok = pl_dispatch_finish(rr->dp, pl_dispatch_params( .shader = &second, .target = small ));
+        pl_dispatch_abort(rr->dp, &first);
+        pl_dispatch_abort(rr->dp, &second);
+        return ok;
+    }
+    return true;
+}
+
 // Record the sampling of `req` into `sh` with whatever rp_pick_scaler chooses for it
 static void run_scaler(struct frame_job *job, pl_shader sh, struct scaler_slot *slot,
                        enum rp_usage usage, const struct pl_sample_src *req)
@@ -1210,9 +1260,11 @@ static pl_tex make_feature_map(struct frame_job *job)
             .tex = full, .rect = img->rect, .address_mode = PL_TEX_ADDRESS_MIRROR,
             .components = 1, .new_w = mw, .new_h = mh,
         };
-        pl_shader sh = pl_dispatch_begin(rr->dp);
-        run_scaler(job, sh, &rr->scale_contrast, RP_USE_LOWPASS, &req);
-        ok = pl_dispatch_finish(rr->dp, pl_dispatch_params( .shader = &sh, .target = small ));
+        if (!try_fused_lowpass(job, &req, small)) {
+            pl_shader sh = pl_dispatch_begin(rr->dp);
+            run_scaler(job, sh, &rr->scale_contrast, RP_USE_LOWPASS, &req);
+            ok = pl_dispatch_finish(rr->dp, pl_dispatch_params( .shader = &sh, .target = small ));
+        }
     }
     if (!ok) {
         raise(rr, PL_RENDER_ERR_CONTRAST_RECOVERY, PL_LOG_ERR,

@@ -154,6 +154,9 @@ struct plh_overlay_draw {
 };
 bool plh_dispatch_overlay(pl_dispatch dp, pl_shader *sh, pl_tex target,
                           const struct plh_overlay_draw *draw);
+// the two recorded passes of a separable one-component downscale as one launch (dispatch.c):
+// 1 = done, 0 = declined (nothing consumed), -1 = failed
+int plh_dispatch_lowpass2(pl_dispatch dp, pl_shader *vert, pl_shader *horiz, pl_tex target);
 
 #define SH_GPU(sh) ((sh)->params.gpu)
 

@@ -163,3 +163,44 @@ def test_measuring_pass_extracts_the_features_too(gpu, size, monkeypatch):
         assert meta == outs[0][1]
         assert np.array_equal(out, outs[0][0]), util.diff_stats(out, outs[0][0])
     assert outs[0][0][..., :3].std() > 1000
+
+
+@pytest.mark.parametrize("size", [((96, 64), (96, 64)), ((257, 131), (257, 131)), ((640, 360), (1280, 720)),
+                                  ((1031, 577), (517, 301)), ((3840, 2160), (3840, 2160))])
+def test_fused_lowpass_equals_the_two_passes(gpu, size):
+    """The low-pass behind the contrast-recovery feature map (reference src/renderer.c:2089-2154: a
+    separable bicubic downscale of the full-size r16hf luminance plane by contrast_smoothness, two
+    pl_shader_sample_ortho2 passes through an r16hf intermediate) as ONE launch that keeps the
+    intermediate in LDS (k_lowpass2, csrc/hip/k_ortho.hip) against the two passes
+    (PL_HIP_LOWPASS_FUSED=0): the same geometry per pixel, the same blended weight rows, the same fma
+    order, the same f16 rounding of the intermediate -- the feature map is the same plane bit for
+    bit, and with it the tone-mapped frame. Sizes: tiles that are partial on both axes, planes smaller
+    than a tile's footprint (mirrored on both sides at once), up- and downscaled targets, the bench's
+    4K frame."""
+    import os
+    import util
+    from test_gpu_fullsize import hdr_frame16
+    (sw, sh), (dw, dh) = size
+    hdr = hdr_frame16(sw, sh)
+    outs = []
+    for fused in ("1", "0"):
+        old = os.environ.get("PL_HIP_LOWPASS_FUSED")
+        os.environ["PL_HIP_LOWPASS_FUSED"] = fused
+        try:
+            src = gpu.tex_create(sw, sh, "rgba16", hdr)
+            dst = gpu.tex_create(dw, dh, "rgba16")
+            rr = pl.Renderer(gpu)
+            util.srand(1)
+            params = pl.render_params("high_quality", peak_detect_params=pl.peak_detect_params(percentile=99.995))
+            assert rr.render(pl.frame(src, components=3, color=pl.color_space("bt2020", "pq", max_luma=1000.0)),
+                             pl.frame(dst, color=pl.color_space("bt709", "bt1886")), params)
+            assert rr.errors() == 0
+            outs.append(dst.download())
+            rr.destroy(); src.destroy(); dst.destroy()
+        finally:
+            if old is None:
+                os.environ.pop("PL_HIP_LOWPASS_FUSED", None)
+            else:
+                os.environ["PL_HIP_LOWPASS_FUSED"] = old
+    assert outs[0][..., :3].std() > 1000
+    assert np.array_equal(outs[0], outs[1]), util.diff_stats(outs[0], outs[1])
