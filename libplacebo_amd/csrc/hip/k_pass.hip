@@ -1359,8 +1359,9 @@ void k_bilinear_tab(const plh_pass p_, const float *colw_, const float *roww_, i
  * kept as the record of the experiment VERDICT r05 item 6 asked for.
  */
 #define BS_ROWS_DEFAULT 2      // (20.2 us; 4: 24.0, 8: 23.8 -- profiles/r06_12_strip_rows.txt)
+// (blockDim.y waves per workgroup, each with its own strip: 1 or 4 -- PL_HIP_BILIN_STRIP_WPG)
 template <bool F16SRC, bool RGB, int BS_ROWS>
-__global__ __launch_bounds__(64)
+__global__ __launch_bounds__(256)
 void k_bilinear_strip(const plh_pass p_, const float *colw_, const float *roww_, int b0x, int b0y)
 {
     const plh_pass &p = plh_kernarg_pass();
@@ -1383,7 +1384,7 @@ void k_bilinear_strip(const plh_pass p_, const float *colw_, const float *roww_,
     typedef __attribute__((address_space(4))) const float cfloat;
 
     const int cx = blockIdx.x * 64 + threadIdx.x;
-    const int cy0 = blockIdx.y * BS_ROWS;
+    const int cy0 = (blockIdx.y * blockDim.y + threadIdx.y) * BS_ROWS;
     const int idx0 = 2 * cx - padx;
     if (idx0 >= W)
         return;
@@ -1629,12 +1630,14 @@ static void launch_bilinear_tab(hipStream_t stream, const plh_pass *pass, const 
         // the strip kernel: a wave per 64 cell columns x ROWS cell rows
         const char *renv = getenv("PL_HIP_BILIN_STRIP_ROWS");
         const int rows = renv ? atoi(renv) : BS_ROWS_DEFAULT;
+        const char *wenv = getenv("PL_HIP_BILIN_STRIP_WPG");
+        const int wpg = wenv && atoi(wenv) == 4 ? 4 : 1;
 #define BS_LAUNCH(R) do { \
-            const dim3 sgrid((cells_w + 63) / 64, (cells_h + R - 1) / R); \
+            const dim3 sgrid((cells_w + 63) / 64, ((cells_h + R - 1) / R + wpg - 1) / wpg); \
             if (pass->epi.has_alpha) \
-                PLH_LAUNCH_LAST((k_bilinear_strip<F16SRC, true, R>), sgrid, dim3(64), 0, stream, *pass, tab->colw, tab->roww, tab->b0x, tab->b0y); \
+                PLH_LAUNCH_LAST((k_bilinear_strip<F16SRC, true, R>), sgrid, dim3(64, wpg), 0, stream, *pass, tab->colw, tab->roww, tab->b0x, tab->b0y); \
             else \
-                PLH_LAUNCH_LAST((k_bilinear_strip<F16SRC, false, R>), sgrid, dim3(64), 0, stream, *pass, tab->colw, tab->roww, tab->b0x, tab->b0y); \
+                PLH_LAUNCH_LAST((k_bilinear_strip<F16SRC, false, R>), sgrid, dim3(64, wpg), 0, stream, *pass, tab->colw, tab->roww, tab->b0x, tab->b0y); \
         } while (0)
         if (rows == 8)
             BS_LAUNCH(8);
