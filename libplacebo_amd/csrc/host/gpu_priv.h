@@ -106,12 +106,15 @@ struct gpu_priv {
     // order, the pass that read it, provided that pass was dispatched by then.
     void *scratch;
     unsigned scratch_next;
+    bool scratch_live[32];      // (PLH_SCRATCH_SLOTS) a recorded shader still points at the slot
 };
 
 #define PLH_SCRATCH_SLOTS 32
 #define PLH_SCRATCH_BYTES 4096
 // device pointer to a copy of `data` (size <= PLH_SCRATCH_BYTES); NULL on failure
 const void *plh_gpu_upload_scratch(pl_gpu gpu, const void *data, size_t size);
+// the shader that asked for `slot` has been dispatched, reset or freed: the slot may be reused
+void plh_gpu_release_scratch(pl_gpu gpu, const void *slot);
 
 struct tex_priv {
     struct pl_tex_t tex;

@@ -165,10 +165,16 @@ void pl_shader_dovi_reshape(pl_shader sh, const struct pl_dovi_metadata *data)
         // (the reference still clamps nothing and leaves the colour alone)
         return;
     }
-    const void *dev = plh_gpu_upload_scratch(gpu, table, sizeof(table));
+    // (one table per shader: a second reshaping in the same shader has no meaning)
+    const void *dev = sh->scratch ? NULL : plh_gpu_upload_scratch(gpu, table, sizeof(table));
     struct plh_op *op = dev ? sh_op(sh, PLH_OP_DOVI_RESHAPE) : NULL;
+    if (dev) {
+        sh->scratch = dev;      // (given back by sh_release)
+        sh->scratch_gpu = gpu;
+    }
     if (!op) {
-        SH_FAIL(sh, "pl_shader_dovi_reshape: could not upload the reshaping curves");
+        SH_FAIL(sh, "pl_shader_dovi_reshape: could not upload the reshaping curves (too many shaders "
+                "with reshaping curves recorded and not yet dispatched?)");
         return;
     }
     op->ptr = dev;
@@ -859,10 +865,13 @@ bool pl_shader_detect_peak(pl_shader sh, struct pl_color_space csp, pl_shader_ob
         return false;
     }
     if (sh->pass.s.type == PLH_SAMPLE_POLAR || sh->pass.s.type == PLH_SAMPLE_ORTHO ||
-        sh->pass.s.type == PLH_SAMPLE_DEBAND || sh->pass.s.type == PLH_SAMPLE_DEINTERLACE) {
-        // those samplers own the workgroup shape; measure in a separate pass
+        sh->pass.s.type == PLH_SAMPLE_DEBAND || sh->pass.s.type == PLH_SAMPLE_DEINTERLACE ||
+        sh->pass.s.type == PLH_SAMPLE_DISTORT) {
+        // those samplers own the workgroup shape (or, the distortion, a kernel the measuring
+        // kernels do not carry: they would measure and store (0, 0, 0, 1) without a word);
+        // measure in a separate pass
         pl_msg(sh->log, PL_LOG_ERR, "pl_shader_detect_peak cannot be merged into a "
-               "polar/ortho/deband pass on the HIP backend (materialise it first)");
+               "polar/ortho/deband/deinterlace/distort pass on the HIP backend (materialise it first)");
         return false;
     }
 

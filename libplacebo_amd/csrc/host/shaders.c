@@ -136,6 +136,9 @@ static void sh_release(pl_shader sh)
     sh->num_held = 0;
     free(sh->errdiff);
     sh->errdiff = NULL;
+    if (sh->scratch)
+        plh_gpu_release_scratch(sh->scratch_gpu, sh->scratch);
+    sh->scratch = NULL;
 }
 
 pl_shader pl_shader_alloc(pl_log log, const struct pl_shader_params *params)

@@ -78,6 +78,10 @@ struct pl_shader_t {
     // run on the measurement stream (set by the renderer on a pass plh_shader_aux_eligible accepts)
     bool on_aux;
     uint64_t aux_after;
+    // a slot of the gpu's scratch ring this shader's ops point at (the Dolby Vision reshaping curves,
+    // shader_color.c), given back when the shader is dispatched, reset or freed
+    const void *scratch;
+    pl_gpu scratch_gpu;
 };
 
 // true if the only device memory the recorded pass reads is `src_tex` and the measurement's own

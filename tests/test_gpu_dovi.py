@@ -211,3 +211,38 @@ def test_renderer_decodes_a_dolby_vision_frame(gpu):
     rr.destroy()
     for t in (src, dst, sdr):
         t.destroy()
+
+
+def test_reshaping_curves_never_shared_between_recorded_shaders(gpu):
+    """The reshaping curves of a shader live in a ring of 32 device slots (pl_shader_decode_color has
+    no state object to keep them in). A slot belongs to its shader until that shader is dispatched,
+    reset or freed: recording a 33rd such shader while 32 are pending FAILS (round 5 handed it slot 0
+    again, whose first owner then read the newcomer's curves -- ADVICE r05), and after the pending ones
+    have run or been dropped the ring is whole again."""
+    meta, ocomp = metadata()
+    src = source()
+    h, w = src.shape[:2]
+    t = gpu.tex_create(w, h, "rgba32f", src)
+    pending = []
+    for _ in range(32):
+        sh = gpu.begin()
+        assert sh.sample("nearest", t)
+        pl.lib().pl_shader_dovi_reshape(sh.sh, C.byref(meta))
+        assert not sh.failed()
+        pending.append(sh)
+    extra = gpu.begin()
+    assert extra.sample("nearest", t)
+    pl.lib().pl_shader_dovi_reshape(extra.sh, C.byref(meta))
+    assert extra.failed()
+    pl.lib().pl_dispatch_abort(gpu.dp, C.byref(extra.sh))
+    # the first 32 still render what their own curves say; dispatching / dropping them frees the slots
+    d = gpu.tex_create(w, h, "rgba32f")
+    assert pending[0].finish(d)
+    ref = orc.dovi_reshape(src.copy(), ocomp)
+    assert np.array_equal(d.download(), ref)
+    for sh in pending[1:]:
+        pl.lib().pl_dispatch_abort(gpu.dp, C.byref(sh.sh))
+    for _ in range(3):
+        got = run_ops(gpu, src, lambda sh: pl.lib().pl_shader_dovi_reshape(sh.sh, C.byref(meta)))
+        assert np.array_equal(got, ref)
+    t.destroy(); d.destroy()
