@@ -567,12 +567,13 @@ def test_map_chain_equals_interpreter(gpu, case, size):
         assert_same_up_to_a_dither_step(outs[0], outs[1])
 
 
-@pytest.mark.parametrize("case", ["ewa_2x_map", "ewa_2x_map_no_peak"])
+@pytest.mark.parametrize("case", ["ewa_2x_map", "ewa_2x_map_no_peak", "ewa_3x_map"])
 @pytest.mark.parametrize("size", [(97, 61), (256, 130), (480, 270)])
 def test_pq_segments_against_closed_forms(gpu, case, size):
     """The PQ pair of the map chain as piecewise cubics in LDS (csrc/hip/pqseg.hiph: the default of the
     chain kernels that have the variant) against the closed forms of pqmath.hiph (PL_HIP_PQ_SEGMENTS=0)
-    on the metric's launch, 16-bit target without a dither so that every difference shows: both are
+    on the metric's launch (k_polar_mx's chain epilogue; "ewa_3x_map": k_polar_mxr's, the 3x upscale of
+    720p -> 4K), 16-bit target without a dither so that every difference shows: both are
     approximations of the same curves (tests/test_pqseg.py: the pieces are the closer one). On the bulk
     the frames agree (97 % of the samples identical, 99.8 % within a code); the colour map amplifies
     what is left on saturated colours -- a few codes on a few samples, the same kind and size of
@@ -586,7 +587,8 @@ def test_pq_segments_against_closed_forms(gpu, case, size):
     from test_gpu_fullsize import hdr_frame16
     w, h = size
     hdr = hdr_frame16(w, h)
-    peak = pl.peak_detect_params(percentile=99.995) if case == "ewa_2x_map" else None
+    peak = pl.peak_detect_params(percentile=99.995) if case != "ewa_2x_map_no_peak" else None
+    up = 3 if case == "ewa_3x_map" else 2
     params = pl.render_params("default", upscaler=pl.filter_config("ewa_lanczos"), peak_detect_params=peak,
                               dither_params=None)
 
@@ -595,7 +597,7 @@ def test_pq_segments_against_closed_forms(gpu, case, size):
         os.environ.update(env)
         try:
             src = gpu.tex_create(w, h, fmt, img)
-            dst = gpu.tex_create(2 * w, 2 * h, "rgba16")
+            dst = gpu.tex_create(up * w, up * h, "rgba16")
             rr = pl.Renderer(gpu)
             util.srand(1)
             assert rr.render(pl.frame(src, components=3, color=pl.color_space("bt2020", "pq", max_luma=1000.0)),
