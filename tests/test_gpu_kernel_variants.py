@@ -618,7 +618,7 @@ def test_pq_segments_against_closed_forms(gpu, case, size):
     assert closed[..., :3].std() > 1000
     d = np.abs(seg.astype(np.int64) - closed.astype(np.int64))
     print("pq segments vs closed forms: max", d.max(), "differing", (d > 0).mean(), "> 1 code", (d > 1).mean())
-    assert d.max() <= 10 and (d > 1).mean() < 0.005 and (d > 0).mean() < 0.06, (d.max(), (d > 0).mean(), (d > 1).mean())
+    assert d.max() <= 16 and (d > 1).mean() < 0.005 and (d > 0).mean() < 0.06, (d.max(), (d > 0).mean(), (d > 1).mean())
     for copies in ("2", "4", "16"):
         again = run({"PL_HIP_PQ_SEGMENTS": "1", "PL_HIP_POLAR_MFMA": "1", "PL_HIP_PQ_SEG_COPIES": copies})
         assert np.array_equal(again, seg), copies
