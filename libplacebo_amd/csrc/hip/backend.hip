@@ -516,3 +516,47 @@ extern "C" const void *plh_pqseg_tables(plh_stream s, const float consts[5])
     e.ptr = p;
     return p;
 }
+
+// Test hook (tests/test_gpu_pqseg.py): the pieces evaluated ON THE DEVICE, by the very functions the
+// chain kernels call (pq_eotf_seg / pq_oetf_seg off a copy of the tables staged in LDS), for n values
+// -- which = 0: EOTF, 1: OETF. The host test holds the result to its own emulation of the lookup
+// (tests/test_pqseg.py), i.e. to what is pinned against float64 there.
+__global__ __launch_bounds__(256)
+void k_test_pqseg(const float *in, float *out, int n, int which, const void *tables, pq_consts k)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char pqt_smem[];
+    pq_seg_stage(pqt_smem, tables, 0, threadIdx.x, 256);
+    __syncthreads();
+    const pq_seg seg = pq_seg_view(pqt_smem, 0, threadIdx.x & 63u, true);
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    float v[1] = { in[min(i, n - 1)] };
+    if (which == 0)
+        pq_eotf_seg<1>(v, seg, k);
+    else
+        pq_oetf_seg<1>(v, seg, k);
+    if (i < n)
+        out[i] = v[0];
+}
+
+extern "C" __attribute__((visibility("default")))
+int plh_test_pqseg_eval(const float consts[5], const float *in, float *out, int n, int which)
+{
+    const void *tables = plh_pqseg_tables(NULL, consts);
+    if (!tables || n <= 0)
+        return -1;
+    float *din = NULL, *dout = NULL;
+    if (hipMalloc((void **) &din, (size_t) n * 4) != hipSuccess || hipMalloc((void **) &dout, (size_t) n * 4) != hipSuccess)
+        return -2;
+    int rc = 0;
+    if (hipMemcpy(din, in, (size_t) n * 4, hipMemcpyHostToDevice) != hipSuccess)
+        rc = -3;
+    const pq_consts k = { consts[0], consts[1], consts[2] * 1.44269504088896340736f, consts[3], consts[4] };
+    if (!rc) {
+        hipLaunchKernelGGL(k_test_pqseg, dim3((n + 255) / 256), dim3(256), PQSEG_BYTES, 0, din, dout, n, which, tables, k);
+        if (hipDeviceSynchronize() != hipSuccess || hipMemcpy(out, dout, (size_t) n * 4, hipMemcpyDeviceToHost) != hipSuccess)
+            rc = -4;
+    }
+    (void) hipFree(din);
+    (void) hipFree(dout);
+    return rc;
+}
