@@ -615,6 +615,24 @@ void k_pass_chain(const plh_pass p_)
     const int x0 = NP * (blockIdx.x * PASS_BW + threadIdx.x);
     const int y = blockIdx.y * PASS_BH + threadIdx.y;
     const int w = p.width, h = p.height;
+    // (final frames) the tone curve's table in LDS: the launcher asks for the room when the chain has
+    // a tone op with a table of at most PQSEG_TONE_MAX entries -- one gather per pixel less on the
+    // texture path, which is what bounds this pass (TD busy 84 % under the gamut LUT's four
+    // gathers). Same entries, same blend: same bits.
+    extern __shared__ __attribute__((aligned(16))) unsigned char chain_smem[];
+    pq_seg seg = pq_seg_view(chain_smem, 0, 0, false);     // (no PQ pieces here: the closed forms)
+    if constexpr (!F16DST) {
+        int tone_n = p.chain.tone_lds;
+        asm volatile("" : "+s"(tone_n));
+        if (tone_n) {
+            typedef __attribute__((address_space(1))) const float gfl;
+            gfl *g = (gfl *) (uintptr_t) p.ops[p.chain.tone].ptr;
+            for (int i = threadIdx.y * PASS_BW + threadIdx.x; i < tone_n; i += PASS_BW * PASS_BH)
+                ((float *) chain_smem)[i] = g[i];
+            __syncthreads();
+            seg.tone = (const float *) chain_smem;
+        }
+    }
     if (x0 >= w || y >= h)
         return;
     const bool all = x0 + NP - 1 < w;
@@ -658,7 +676,10 @@ void k_pass_chain(const plh_pass p_)
             pos[i][1] = p.out_scale[1] * ((float) y + 0.5f);
         }
     }
-    run_map_chain<NP, CR>(c, p, pos);
+    if constexpr (F16DST)
+        run_map_chain<NP, CR>(c, p, pos);
+    else
+        run_map_chain<NP, CR, true, true>(c, p, pos, &seg);     // (seg.on == false: only the tone table)
     uint32_t o[2 * NP];
 #pragma unroll
     for (int i = 0; i < NP; i++) {
@@ -1895,12 +1916,26 @@ extern "C" int plh_launch_pass(plh_stream stream_, const struct plh_pass *pass)
             // (profiles/r06_16_seg_ab.txt, r06_17_seg_ab.txt). At eight waves per SIMD this pass is
             // bound by the latency chain load -> tone gather -> gamut gathers -> store, not by
             // instruction issue; k_polar_mx at four waves per SIMD is, and gains 14 %.)
+            // the tone curve's table in LDS (PL_HIP_CHAIN_TONE_LDS=0: read where the op points)
+            size_t shmem = 0;
+            local.chain.tone_lds = 0;
+            {
+                const char *tenv = getenv("PL_HIP_CHAIN_TONE_LDS");
+                const int it = local.chain.tone;
+                if (!(tenv && tenv[0] == '0') && it >= 0 && local.ops[it].i0 >= 2 && local.ops[it].ptr) {
+                    const int n = (int) local.ops[it].f[8] + 1;
+                    if (n >= 2 && n <= PQSEG_TONE_MAX) {
+                        local.chain.tone_lds = n;
+                        shmem = (size_t) n * 4;
+                    }
+                }
+            }
             if (local.chain.contrast_recovery) {
-                if (f16) PLH_LAUNCH_LAST((k_pass_chain<true, CHAIN_NP, true>), grid, block, 0, stream, local);
-                else     PLH_LAUNCH_LAST((k_pass_chain<false, CHAIN_NP, true>), grid, block, 0, stream, local);
+                if (f16) PLH_LAUNCH_LAST((k_pass_chain<true, CHAIN_NP, true>), grid, block, shmem, stream, local);
+                else     PLH_LAUNCH_LAST((k_pass_chain<false, CHAIN_NP, true>), grid, block, shmem, stream, local);
             } else {
-                if (f16) PLH_LAUNCH_LAST((k_pass_chain<true, CHAIN_NP, false>), grid, block, 0, stream, local);
-                else     PLH_LAUNCH_LAST((k_pass_chain<false, CHAIN_NP, false>), grid, block, 0, stream, local);
+                if (f16) PLH_LAUNCH_LAST((k_pass_chain<true, CHAIN_NP, false>), grid, block, shmem, stream, local);
+                else     PLH_LAUNCH_LAST((k_pass_chain<false, CHAIN_NP, false>), grid, block, shmem, stream, local);
             }
         } else if (plh_ops_lite(pass, 0, pass->num_ops))
             launch_pass_native<true>(stream, pass);

@@ -337,6 +337,7 @@ struct plh_map_chain {
     // variant asks for the device's tables (plh_pqseg_tables) and sets pq_seg_ptr / pq_seg_rshift
     // (log2 of the copies per piece in LDS) -- NULL keeps the closed forms.
     int32_t pq_seg, pq_seg_rshift;
+    int32_t tone_lds;           // k_pass_chain: entries of the tone table to stage in LDS (0: none)
     float pq_seg_consts[5];
     const void *pq_seg_ptr;
 };
