@@ -113,3 +113,15 @@ def test_round_trip_of_every_code():
     pos = lin > 0
     back = oetf_seg(to, lin[pos].astype(np.float32).astype(np.float64))
     assert np.abs(back - v[pos]).max() * 65535 <= 0.02
+
+
+def test_tables_against_the_committed_ones():
+    """The 354 pieces as committed (tests/golden/pqseg_tables.npy, written by this file's tables() on the
+    build container): another libm may round a coefficient's last bit differently -- nothing more."""
+    import os
+    to, te = tables()
+    got = np.concatenate([to, te])
+    want = np.load(os.path.join(os.path.dirname(__file__), "golden", "pqseg_tables.npy"))
+    assert got.shape == want.shape == (O_N + E_LO + E_HI, 4)
+    scale = np.maximum(np.abs(want).max(axis=1, keepdims=True), 1e-30)
+    assert (np.abs(got - want) / scale).max() <= 4e-7
